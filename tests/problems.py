@@ -1,0 +1,168 @@
+"""Problem definitions shared by the parity tests (inputs only -- numbers quoted from the reference drivers).
+
+celia1990 : src/driver/standalone/vsfm/vsfm_celia1990_problem.F90 (nz=100, dt=3600 s x 24, VG, TGDPB01,
+            Dirichlet top 93991 Pa / bottom 3535.5 Pa, IC 3535.5 Pa)
+vchannel  : src/driver/standalone/vsfm/vsfm_vchannel_problem.F90 (20x10x30, 7-pt, no BC, dt=8640 s x 3)
+"""
+from __future__ import annotations
+
+import os
+import sys
+from dataclasses import dataclass, field
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from mpp_amd import constants as C  # noqa: E402
+from mpp_amd import mesh as M  # noqa: E402
+
+
+@dataclass
+class Problem:
+    name: str
+    mesh: M.Mesh
+    perm: np.ndarray            # (n,3)
+    por: np.ndarray
+    satfunc_type: np.ndarray
+    alpha: np.ndarray
+    lam: np.ndarray
+    sat_res: np.ndarray
+    density_type: int
+    press_ic: np.ndarray
+    bcs: list = field(default_factory=list)   # [(cond_type, ConnectionSet, values)]
+    sss: list = field(default_factory=list)
+    dt: float = 3600.0
+    nstep: int = 1
+
+
+def clm_soil_conversion(perm, alpha, lam, sucsat_grav):
+    """The CLM-unit round trip every reference driver does before VSFMMPPSetSoils, then
+    VSFMMPPSetSoilsCLM's inverse (MultiPhysicsProbVSFM.F90:374-381): two different gravity constants and
+    two different viscosities are involved, so the numbers are reproduced step by step."""
+    vish2o = 0.001002
+    hksat = perm / vish2o * (C.DENH2O * C.GRAV_CLM) / 0.001          # celia1990_problem.F90:325
+    bsw = 1.0 / lam
+    sucsat = 1.0 / (alpha * sucsat_grav)                             # :327 uses GRAVITY_CONSTANT; vchannel uses grav
+    perm_eff = hksat * vish2o / (C.DENH2O * C.GRAV_CLM) * 0.001      # MultiPhysicsProbVSFM.F90:374
+    alpha_eff = 1.0 / (sucsat * C.GRAV_CLM)                          # :378
+    lam_eff = 1.0 / bsw                                              # :381
+    return perm_eff, alpha_eff, lam_eff
+
+
+def celia1990(ncols=1, nz=100, perm_mult=None) -> Problem:
+    """`ncols` copies of the celia1990 column on a CLM-style (z-fastest) mesh: the 'celia-extruded' grid of
+    SURVEY.md section 8(d).  perm_mult: optional per-column permeability multiplier."""
+    z_column = 1.0
+    m = M.mesh_create_soil_columns("Soil mesh", ncols, nz, z_column / nz, area=1.0)
+    n = m.ncells_local
+    perm, alpha, lam = clm_soil_conversion(8.3913e-12, 3.4257e-4, 0.5, C.GRAVITY_CONSTANT)
+    perm_arr = np.full((n, 3), perm)
+    if perm_mult is not None:
+        perm_arr = perm_arr * np.repeat(np.asarray(perm_mult, dtype=np.float64), nz)[:, None]
+    top = M.create_region_connection_set(m, C.SOIL_TOP_CELLS)
+    bot = M.create_region_connection_set(m, C.SOIL_BOTTOM_CELLS)
+    return Problem(
+        name="vsfm_celia1990", mesh=m, perm=perm_arr, por=np.full(n, 0.368),
+        satfunc_type=np.full(n, C.SAT_FUNC_VAN_GENUCHTEN, dtype=np.int32), alpha=np.full(n, alpha),
+        lam=np.full(n, lam), sat_res=np.full(n, 0.2772), density_type=C.DENSITY_TGDPB01,
+        press_ic=np.full(n, 3.5355e3),
+        bcs=[(C.COND_DIRICHLET, top, np.full(ncols, 9.3991e4)), (C.COND_DIRICHLET, bot, np.full(ncols, 3.5355e3))],
+        dt=3600.0, nstep=24)
+
+
+def vchannel(nx=20, ny=10, nz=30) -> Problem:
+    dx, dy, dz, slope_x, slope_y = 10.0, 10.0, 0.5, 0.1, 0.2
+    n = nx * ny * nz
+    zv_x = np.zeros(nx + 1)
+    for ii in range(1, nx // 2 + 2):
+        zv_x[ii - 1] = slope_x * dx * (nx // 2) - (ii - 1) * slope_x * dx
+    for ii in range(nx // 2 + 2, nx + 2):
+        zv_x[ii - 1] = (ii - nx // 2 - 1) * slope_x * dx
+    zv_y = (np.arange(1, ny + 2) - 1) * slope_y * dy
+    zv = zv_x[:, None] + zv_y[None, :]                      # (nx+1, ny+1)
+    xv = ((np.arange(1, nx + 2) - 1) * dx)[:, None] + np.zeros((1, ny + 1))
+    yv = np.zeros((nx + 1, 1)) + ((np.arange(1, ny + 2) - 1) * dy)[None, :]
+
+    def c4(a):
+        return (a[:-1, :-1] + a[1:, :-1] + a[:-1, 1:] + a[1:, 1:]) / 4.0
+
+    xc2, yc2, zc2 = c4(xv), c4(yv), c4(zv)                  # (nx, ny)
+    kk = np.arange(1, nz + 1)
+    # ids are x-fastest: count over kk, jj, ii  -> arrays shaped [kk, jj, ii]
+    xc = np.broadcast_to(xc2.T[None, :, :], (nz, ny, nx)).ravel()
+    yc = np.broadcast_to(yc2.T[None, :, :], (nz, ny, nx)).ravel()
+    zc = (zc2.T[None, :, :] - (dz / 2.0 + (nz - kk)[:, None, None] * dz)).ravel()
+    m = M.Mesh(name="Soil mesh", ncells_local=n, nlev=nz, orientation=C.MESH_AGAINST_GRAVITY)
+    m.x, m.y, m.z = xc.copy(), yc.copy(), zc.copy()
+    m.dx, m.dy, m.dz = np.full(n, dx), np.full(n, dy), np.full(n, dz)
+    m.area_xy = np.full(n, dx * dy)
+    m.is_active = np.ones(n, dtype=np.int32)
+    m.compute_volume()
+    ids = (np.arange(n, dtype=np.int64) + 1).reshape(nz, ny, nx)
+    ups, dns, dus, dds, areas = [], [], [], [], []
+    # vertical: do kk, ii, jj
+    up = ids[:-1].transpose(0, 2, 1).ravel(); dn = ids[1:].transpose(0, 2, 1).ravel()
+    ups.append(up); dns.append(dn)
+    dus.append(np.full(up.size, 0.5 * dz)); dds.append(np.full(up.size, 0.5 * dz)); areas.append(np.full(up.size, dx * dy))
+
+    def dist_of(u, d):
+        ddx = m.x[u - 1] - m.x[d - 1]; ddy = m.y[u - 1] - m.y[d - 1]; ddz = m.z[u - 1] - m.z[d - 1]
+        return (ddx ** 2.0 + ddy ** 2.0 + ddz ** 2.0) ** 0.5
+
+    # horizontal x: do ii, kk, jj
+    up = ids[:, :, :-1].transpose(2, 0, 1).ravel(); dn = ids[:, :, 1:].transpose(2, 0, 1).ravel()
+    dist = dist_of(up, dn)
+    ups.append(up); dns.append(dn); dus.append(0.5 * dist); dds.append(0.5 * dist); areas.append(np.full(up.size, dz * dy))
+    # horizontal y: do jj, kk, ii
+    up = ids[:, :-1, :].transpose(1, 0, 2).ravel(); dn = ids[:, 1:, :].transpose(1, 0, 2).ravel()
+    dist = dist_of(up, dn)
+    ups.append(up); dns.append(dn); dus.append(0.5 * dist); dds.append(0.5 * dist); areas.append(np.full(up.size, dz * dx))
+    up, dn = np.concatenate(ups), np.concatenate(dns)
+    cs = M.ConnectionSet(up, dn, np.concatenate(dus), np.concatenate(dds), np.concatenate(areas), None, None)
+    cs.unit_vec = M.unit_vec_from_centroids(m, up, dn)
+    m.intrn_conn_sets.append(cs)
+    m.ncols, m.ordering = nx * ny, "x-fastest"
+    perm, alpha, lam = clm_soil_conversion(8.3913e-12, 3.4257e-4, 0.5, C.GRAV_CLM)
+    jj = np.repeat(np.arange(1, nz + 1), nx * ny)
+    press_ic = (18.75 - 0.5 * (jj - 1) - 2.0) * 997.18 * 9.8 + 101325.0
+    return Problem(
+        name="vsfm_vchannel", mesh=m, perm=np.full((n, 3), perm), por=np.full(n, 0.368),
+        satfunc_type=np.full(n, C.SAT_FUNC_VAN_GENUCHTEN, dtype=np.int32), alpha=np.full(n, alpha),
+        lam=np.full(n, lam), sat_res=np.full(n, 0.2772), density_type=C.DENSITY_TGDPB01, press_ic=press_ic,
+        dt=8640.0, nstep=3)
+
+
+def to_oracle(prob: Problem, with_blocks=True):
+    from oracle import vsfm_oracle as VO
+    o = VO.OracleProblem(prob.mesh.ncells_local)
+    o.set_mesh(prob.mesh.vol, prob.mesh.is_active)
+    o.set_connections(prob.mesh.internal_connections())
+    for cond_type, cs, _vals in prob.bcs:
+        o.add_condition(C.COND_BC, cond_type, cs)
+    for cond_type, cs, _vals in prob.sss:
+        o.add_condition(C.COND_SS, cond_type, cs)
+    o.set_soil_permeability(prob.perm[:, 0], prob.perm[:, 1], prob.perm[:, 2])
+    o.set_soil_porosity(prob.por)
+    o.set_saturation_function(prob.satfunc_type, prob.alpha, prob.lam, prob.sat_res)
+    o.set_density_type(prob.density_type)
+    for i, (_t, _cs, vals) in enumerate(prob.bcs):
+        o.set_condition_values(C.COND_BC, i + 1, vals)
+    for i, (_t, _cs, vals) in enumerate(prob.sss):
+        o.set_condition_values(C.COND_SS, i + 1, vals)
+    o.restart(prob.press_ic)
+    if with_blocks:
+        ptr, cells = M.column_blocks(prob.mesh)
+        o.set_blocks(ptr, cells)
+    return o
+
+
+def regression_stats(data, num_cells=5):
+    """min / max / mean / every k-th cell, as regression_mod%WriteData (src/driver/standalone/util/regression.F90:76-124)."""
+    data = np.asarray(data)
+    inc = data.size // min(num_cells, data.size)
+    cells = list(range(1, data.size + 1, inc))
+    return dict(min=float(data.min()), max=float(data.max()), mean=float(data.sum() / data.size),
+                cells={c: float(data[c - 1]) for c in cells})

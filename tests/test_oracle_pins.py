@@ -1,0 +1,80 @@
+"""Pins the CPU oracle against every fixture the reference holds for the VSFM hot path.
+
+* EOS known-answer tests            (reference: src/tests/test_eos_*_density.F90:19-25)
+* celia1990 end-to-end baseline     (reference: regression_tests/vsfm/vsfm_celia1990.regression.baseline)
+* vchannel end-to-end baseline      (reference: regression_tests/vsfm/vsfm_vchannel.regression.baseline)
+
+The baselines are printed with 13 significant digits (e21.13); the oracle must agree to that print
+precision (<= 1 unit in the last printed digit, i.e. 1e-12 relative).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import problems as P
+from conftest import parse_regression_file
+from mpp_amd import constants as C
+from oracle import vsfm_oracle as VO
+
+PRINT_RTOL = 1.0e-12
+
+
+def test_eos_known_answers(golden_dir):
+    kat = json.load(open(os.path.join(golden_dir, "eos_known_answers.json")))
+    for name, c in kat["cases"].items():
+        den, dp, dT = VO.density(kat["p"], kat["t_K"], c["type"])
+        assert abs(den - c["den"]) <= kat["abs_tol"]["den"], name
+        assert abs(dp - c["dden_dp"]) <= kat["abs_tol"]["dden_dp"], name
+        assert abs(dT - c["dden_dT"]) <= kat["abs_tol"]["dden_dT"], name
+
+
+def _run(prob):
+    o = P.to_oracle(prob)
+    for s in range(prob.nstep):
+        conv, reason = o.step_dt(prob.dt, s + 1)
+        assert conv and reason > 0
+    pr = o.get(C.AUXVAR_INTERNAL, C.VAR_PRESSURE)
+    sat = o.get(C.AUXVAR_INTERNAL, C.VAR_LIQ_SAT)
+    return o, pr, sat
+
+
+def _check_section(stats, gold):
+    for key in ("min", "max", "mean"):
+        assert stats[key] == pytest.approx(gold[key], rel=PRINT_RTOL), key
+    for cell, v in stats["cells"].items():
+        assert v == pytest.approx(gold["cell %d" % cell], rel=PRINT_RTOL), cell
+
+
+def test_celia1990_baseline(golden_dir):
+    gold = parse_regression_file(os.path.join(golden_dir, "vsfm_celia1990.regression.baseline"))
+    o, pr, sat = _run(P.celia1990())
+    _check_section(P.regression_stats(pr), gold["liquid_pressure"])
+    _check_section(P.regression_stats(sat), gold["liquid_saturation"])
+    # tridiagonal system: ILU(0) is an exact LU, one GMRES iteration per Newton step
+    c = o.counters()
+    assert c["linear"] == c["newton"] and c["time_cuts"] == 0
+
+
+def test_vchannel_baseline(golden_dir):
+    gold = parse_regression_file(os.path.join(golden_dir, "vsfm_vchannel.regression.baseline"))
+    o, pr, sat = _run(P.vchannel())
+    _check_section(P.regression_stats(pr), gold["liquid_pressure"])
+    _check_section(P.regression_stats(sat), gold["liquid_saturation"])
+
+
+def test_celia_extruded_columns_identical():
+    """Every column of the celia-extruded grid must reproduce the single-column answer."""
+    o1, pr1, _ = _run(P.celia1990())
+    prob = P.celia1990(ncols=3)
+    prob.nstep = 4
+    o = P.to_oracle(prob)
+    p1 = P.to_oracle(P.celia1990())
+    for s in range(prob.nstep):
+        o.step_dt(prob.dt, s + 1)
+        p1.step_dt(prob.dt, s + 1)
+    pr = o.get(C.AUXVAR_INTERNAL, C.VAR_PRESSURE).reshape(3, -1)
+    ref = p1.get(C.AUXVAR_INTERNAL, C.VAR_PRESSURE)
+    for c in range(3):
+        np.testing.assert_allclose(pr[c], ref, rtol=1e-9)
