@@ -1,0 +1,170 @@
+/*
+ * mppgpu.h -- C ABI of the MI355X-native VSFM Newton-Krylov solve path.
+ *
+ * Drop-in boundary for MPP's variably-saturated-flow model: a Fortran (iso_c_binding), C, or
+ * ctypes host keeps the reference's SystemOfEquations / GoverningEquation call sequence and
+ * binds these entry points instead of the PETSc-backed implementations.  Each entry point cites
+ * the reference interface it replaces (paths relative to the reference tree).
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error (PETSc `ierr` convention,
+ *     src/mpp/soe/SystemOfEquationsBaseType.F90:334-365); the message is available from
+ *     mppgpu_last_error().  Nothing aborts the process.
+ *   - cell / connection / condition ids are 1-based exactly as the Fortran callers hold them
+ *     (natural ordering of the caller's mesh, any numbering).
+ *   - all array arguments are caller-owned host memory, copied during the call; the library
+ *     retains no host pointer.  Device memory is owned by the handle.
+ *   - one handle = one GPU + one HIP stream; calls on a handle must be serialised by the caller.
+ *   - the library computes on the GPU only: there is no CPU fallback.  mppgpu_create fails when
+ *     no HIP device is usable.
+ */
+#ifndef MPPGPU_H
+#define MPPGPU_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mppgpu_handle_s *mppgpu_handle;
+
+/* ---- integer ids shared with the reference (MultiPhysicsProbConstants.F90:82-94,102-109,141,172-177) ---- */
+#define MPPGPU_COND_BC 501
+#define MPPGPU_COND_SS 502
+#define MPPGPU_COND_MASS_RATE 503
+#define MPPGPU_COND_MASS_FLUX 504
+#define MPPGPU_COND_DIRICHLET 505
+#define MPPGPU_COND_SEEPAGE_BC 509
+#define MPPGPU_VAR_PRESSURE 604
+#define MPPGPU_VAR_BC_SS_CONDITION 607
+#define MPPGPU_VAR_LIQ_SAT 608
+#define MPPGPU_VAR_MASS 610
+#define MPPGPU_VAR_SOIL_MATRIX_POT 611
+#define MPPGPU_VAR_MASS_FLUX 644
+#define MPPGPU_AUXVAR_INTERNAL 701
+#define MPPGPU_AUXVAR_BC 702
+#define MPPGPU_AUXVAR_SS 703
+#define MPPGPU_AUXVAR_CONN_INTERNAL 704
+/* SaturationFunction.F90:19-23 */
+#define MPPGPU_SAT_FUNC_VAN_GENUCHTEN 1301
+#define MPPGPU_SAT_FUNC_BROOKS_COREY 1302
+#define MPPGPU_SAT_FUNC_SMOOTHED_BROOKS_COREY_BZ2 1304
+#define MPPGPU_SAT_FUNC_SMOOTHED_BROOKS_COREY_BZ3 1305
+/* EOSWaterMod.F90:19-21 */
+#define MPPGPU_DENSITY_CONSTANT 1
+#define MPPGPU_DENSITY_TGDPB01 2
+#define MPPGPU_DENSITY_IFC67 3
+
+/* ------------------------------------------------------------------------------------------------
+ * life cycle -- replaces vsfm_mpp%Init / SetName / SetID(MPP_VSFM_SNES_CLM) / SetMPIRank
+ * (src/driver/standalone/vsfm/vsfm_celia1990_problem.F90:140-168)
+ * ---------------------------------------------------------------------------------------------- */
+int mppgpu_create(int device_id, mppgpu_handle *out);
+int mppgpu_destroy(mppgpu_handle h);
+const char *mppgpu_last_error(mppgpu_handle h); /* h may be NULL: error of the last failed create */
+int mppgpu_synchronize(mppgpu_handle h);
+
+/* ------------------------------------------------------------------------------------------------
+ * problem set-up
+ * ---------------------------------------------------------------------------------------------- */
+/* mpp%MeshSetDimensions / MeshSetGridCellFilter / MeshComputeVolume
+ * (src/mpp/mpp/MultiPhysicsProbBaseType.F90:214-349; src/mpp/dtypes/MeshType.F90:1244-1264).
+ * is_active may be NULL (= all cells active). */
+int mppgpu_set_mesh(mppgpu_handle h, int ncells, int nlev, const double *vol, const int *is_active);
+
+/* mpp%CreateAndAddConnectionSet(imesh, CONN_SET_INTERNAL, nconn, id_up, id_dn, dist_up, dist_dn, area, itype, unit_vec)
+ * (src/mpp/mpp/MultiPhysicsProbBaseType.F90:352-377).  unit_vec is nconn x 3 row-major (up -> dn). */
+int mppgpu_set_connections(mppgpu_handle h, int nconn, const int *id_up, const int *id_dn, const double *dist_up,
+                           const double *dist_dn, const double *area, const double *unit_vec);
+
+/* soe%AddConditionInGovEqn(igoveqn, COND_BC|COND_SS, name, unit, cond_type, conn_set)
+ * (src/mpp/soe/SystemOfEquationsBaseType.F90:1260-1290).  For COND_SS only id_dn is read.
+ * *cond_id receives the 1-based id within its kind (the reference's soe_auxvar_id). */
+int mppgpu_add_condition(mppgpu_handle h, int kind, int cond_type, int nconn, const int *id_dn, const double *dist_up,
+                         const double *dist_dn, const double *area, const double *unit_vec, int swap_order,
+                         int *cond_id);
+
+/* VSFMMPPSetSoilPermeability / SetSoilPorosity / SetSaturationFunction / SetDensityType
+ * (src/mpp/mpp/MultiPhysicsProbVSFM.F90:1115-1182, 1295-1361, 1364-1434, 1247-1292).
+ * Boundary-condition auxvars take their soil parameters from their id_dn cell (:422-471). */
+int mppgpu_set_soil_permeability(mppgpu_handle h, const double *perm_x, const double *perm_y, const double *perm_z);
+int mppgpu_set_soil_porosity(mppgpu_handle h, const double *por);
+int mppgpu_set_saturation_function(mppgpu_handle h, const int *satfunc_type, const double *alpha, const double *lambda,
+                                   const double *sat_res);
+int mppgpu_set_density_type(mppgpu_handle h, int density_type);
+
+/* solver selection: the PETSc options database the reference reads through SNESSetFromOptions
+ * (src/mpp/mpp/MultiPhysicsProbBaseType.F90:1205).  Keys: "ksp_type" (bcgs|gmres|preonly),
+ * "pc_type" (bjacobi|jacobi|none), "ksp_rtol", "ksp_max_it", "snes_rtol", "snes_atol", "snes_stol",
+ * "snes_max_it", "profile" (0|1: HIP-event timing of every kernel class). */
+int mppgpu_set_option(mppgpu_handle h, const char *key, const char *value);
+
+/* mpp%AllocateAuxVars + mpp%SetupProblem (src/mpp/mpp/MultiPhysicsProbVSFM.F90:710-1015): builds the CSR
+ * pattern and the device layout.  Must follow mesh/connections/conditions and precede everything below. */
+int mppgpu_setup(mppgpu_handle h);
+
+/* mpp%Restart(data_1d) (src/mpp/mpp/MultiPhysicsProbVSFM.F90:603-707) */
+int mppgpu_restart(mppgpu_handle h, int n, const double *pressure);
+
+/* ------------------------------------------------------------------------------------------------
+ * time stepping -- the SystemOfEquations API
+ * ---------------------------------------------------------------------------------------------- */
+/* soe%SetDataFromCLM(soe_auxvar_type, var_type, soe_auxvar_id, data_1d)
+ * (src/mpp/soe/SystemOfEquationsVSFMType.F90:663-724); AUXVAR_BC / AUXVAR_SS with VAR_BC_SS_CONDITION. */
+int mppgpu_set_data(mppgpu_handle h, int auxvar_type, int var_type, int cond_id, int n, const double *data);
+
+/* soe%StepDT(dt, nstep, converged, converged_reason, ierr) (src/mpp/soe/SystemOfEquationsBaseType.F90:334-552):
+ * Newton (newtonls + cubic backtracking), linear solve, dt halving (<= 20 cuts).  converged_reason uses
+ * PETSc's SNESConvergedReason numbering (>0 converged, <0 diverged). */
+int mppgpu_step_dt(mppgpu_handle h, double dt, int nstep, int *converged, int *converged_reason);
+
+/* soe%GetDataForCLM(soe_auxvar_type, var_type, soe_auxvar_id, data_1d) (SystemOfEquationsVSFMType.F90:781-845):
+ * AUXVAR_INTERNAL: VAR_PRESSURE, VAR_LIQ_SAT, VAR_MASS, VAR_SOIL_MATRIX_POT;
+ * AUXVAR_BC / AUXVAR_SS / AUXVAR_CONN_INTERNAL: VAR_MASS_FLUX. */
+int mppgpu_get_data(mppgpu_handle h, int auxvar_type, int var_type, int cond_id, int n, double *data);
+
+/* solver_type counters (src/mpp/dtypes/SolverType.F90:40-41,140-169) */
+int mppgpu_get_counters(mppgpu_handle h, long long *newton_its, long long *linear_its, long long *time_cuts,
+                        long long *function_evals);
+
+/* ------------------------------------------------------------------------------------------------
+ * operator level -- the GoverningEquation API, for PETSc-hosted runs and parity tests
+ * ---------------------------------------------------------------------------------------------- */
+/* soe%SetDtime + soe%PreSolve (SystemOfEquationsVSFMType.F90:506-563; GoveqnRichardsODEPressureType.F90:2747-2768) */
+int mppgpu_set_dtime(mppgpu_handle h, double dt);
+int mppgpu_pre_solve(mppgpu_handle h);
+/* goveqn%ComputeResidual(X, F, ierr) behind SOEResidual (GoveqnRichardsODEPressureType.F90:388-421) */
+int mppgpu_residual(mppgpu_handle h, const double *x, double *f);
+/* goveqn%ComputeJacobian(X, A, B, ierr) behind SOEJacobian (:425-453).  CSR, 0-based, sorted columns, caller ordering. */
+int mppgpu_jacobian_nnz(mppgpu_handle h, int *nnz);
+int mppgpu_jacobian(mppgpu_handle h, const double *x, int *rowptr, int *col, double *val);
+/* PETSc MatMult / PCApply / KSPSolve on the Jacobian most recently assembled by mppgpu_jacobian or mppgpu_step_dt */
+int mppgpu_spmv(mppgpu_handle h, const double *x, double *y);
+int mppgpu_pc_apply(mppgpu_handle h, const double *r, double *z);
+int mppgpu_ksp_solve(mppgpu_handle h, const double *b, double *x, int *its, int *reason);
+
+/* ------------------------------------------------------------------------------------------------
+ * measurement
+ * ---------------------------------------------------------------------------------------------- */
+/* HIP-event statistics per kernel class since the last reset ("profile" option must be 1).
+ * names: "spmv", "pc_apply", "pc_setup", "residual", "jacobian", "vec", "reduce".
+ * bytes = algorithmic bytes per launch as defined in DESIGN.md. */
+int mppgpu_kernel_stats(mppgpu_handle h, const char *name, long long *launches, double *total_ms,
+                        double *algorithmic_bytes_per_launch);
+int mppgpu_reset_stats(mppgpu_handle h);
+/* device-resident micro-benchmark of one kernel class on the current state: `reps` launches, average ms */
+int mppgpu_bench_kernel(mppgpu_handle h, const char *name, int variant, int reps, double *avg_ms,
+                        double *algorithmic_bytes);
+
+/* ------------------------------------------------------------------------------------------------
+ * multi-GPU: one handle per rank, columns sharded across ranks, RCCL all-reduce for the global
+ * Newton/Krylov norms and dot products (no counterpart in the reference, whose solver objects are
+ * all PETSC_COMM_SELF: src/mpp/mpp/MultiPhysicsProbBaseType.F90:1132,1154,1193).
+ * The 128-byte unique id is produced on rank 0 and broadcast by the host (MPI_Bcast / torch.distributed).
+ * ---------------------------------------------------------------------------------------------- */
+int mppgpu_comm_get_unique_id(void *id128);
+int mppgpu_comm_init(mppgpu_handle h, int nranks, int rank, const void *id128);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPPGPU_H */

@@ -1,0 +1,130 @@
+// kernels.hpp -- launch interface of the HIP kernels (gfx950).  Every launcher enqueues on `stream` and returns
+// immediately; none allocates or synchronises (so a caller may capture them in a hipGraph).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "physics.hpp"
+
+namespace mpp {
+
+// device-resident scalar block shared by the Krylov/Newton kernels (doubles)
+enum ScalarSlot : int {
+  S_RHO = 0, S_RHOOLD, S_ALPHA, S_OMEGA, S_OMEGAOLD, S_BETA, S_D1, S_D2, S_DP, S_FLAG,
+  S_SUM0 = 16,  // reduction results land in S_SUM0 .. S_SUM0+63
+  S_COUNT = 96
+};
+
+constexpr int kMaxPartialBlocks = 2048;  // grid cap for reductions (guide: ~256 CUs x 8 blocks)
+constexpr int kMaxMultiDot = 32;
+
+// physical parameters every assembly kernel receives by value
+struct CellArrays {
+  const double *P;                                   // pressure the kernel evaluates at
+  const double *por, *sat_res, *alpha, *m, *vol;     // soil (internal ordering)
+  const double *sbc_pu, *sbc_ps, *sbc_b2, *sbc_b3;   // smoothed Brooks-Corey only (else nullptr)
+  const signed char *active;                         // nullptr = every cell active
+  int sat_func;
+  double frac_liq;
+  EosParams eos;
+};
+
+struct ConnArrays {   // internal connections, precomputed geometry
+  const double *Dq, *upw, *dgrav, *area;
+};
+
+// ---- column-structured (vertical-only) fused assembly: one thread marches one soil column segment ----
+struct ColsArgs {
+  CellArrays cell;
+  ConnArrays conn;       // vertical connection (k,c)->(k+1,c) stored at k*ncols+c
+  const double *accum_prev, *src;   // src: dense mass-rate source [kmol/s], nullptr if none
+  double *F;             // residual out (MODE 0,2)
+  double *val;           // CSR values out (MODE 1,2), level-major analytic layout
+  const int *rowptr;     // CSR row pointers (level-major rows)
+  int ncols, nz, nseg;
+  double dtInv;
+};
+// mode 0 residual, 1 Jacobian, 2 both
+void launch_assemble_cols(int mode, const ColsArgs &a, hipStream_t stream);
+// accumulation term only (PreSolve): out[i] = por*den*sat*vol/dt
+void launch_accum(const CellArrays &cell, int n, double dtInv, double *out, hipStream_t stream);
+
+// ---- general (any connection list) assembly: auxvar pass + row-gather pass ----
+struct AuxOut { double *kr, *dkr, *den, *dden; };
+struct GenArgs {
+  CellArrays cell;
+  ConnArrays conn;
+  const int *cup, *cdn;                 // connection end cells
+  const int *rc_ptr, *rc_conn, *rc_slot; // per-row incident connections ((conn<<1)|side), off-diagonal slot
+  const int *diag_slot, *rowptr;
+  const double *accum_prev, *src;
+  AuxOut aux;
+  double *F, *val;
+  int n;
+  double dtInv;
+};
+void launch_assemble_general(int mode, const GenArgs &a, hipStream_t stream);
+
+// ---- boundary conditions: one thread per cell that carries at least one BC connection ----
+struct BcArgs {
+  CellArrays cell;
+  int ncond_cells;
+  const int *cc_cell, *cc_ptr;          // cells with BCs; their BC entries cc_ptr[j]..cc_ptr[j+1]
+  const double *Dq, *dgrav, *area, *value;
+  const int *type;                      // cond_type | (swap_order << 16)
+  const int *diag_slot;
+  double *F, *val;
+  double *flux_out;                     // optional per-BC-connection flux [kg/s] (mode 4)
+};
+void launch_bc(int mode, const BcArgs &a, hipStream_t stream);
+
+// internal-connection mass flux [kg/s] at the pressure in cell.P (VAR_MASS_FLUX, AUXVAR_CONN_INTERNAL)
+void launch_conn_flux(const CellArrays &cell, const ConnArrays &conn, const int *cup, const int *cdn, int nc,
+                      double *flux_out, hipStream_t stream);
+// per-cell outputs: var = 608 sat, 610 mass, 611 soil matrix potential
+void launch_cell_var(const CellArrays &cell, int n, int var_type, double *out, hipStream_t stream);
+
+// ---- sparse linear algebra ----
+void launch_spmv(int variant, int n, const int *rowptr, const int *col, const double *val, const double *x, double *y,
+                 hipStream_t stream);
+// per-column tridiagonal (block-Jacobi): factor from CSR slots, then apply
+struct TriArgs {
+  int ncols, nz;
+  const int *tri_lo, *tri_di, *tri_up;  // CSR slots of the (k-1), k, (k+1) entries of row (k,c); -1 when absent
+  const double *val;
+  double *l, *invb, *c;                 // factors, level-major
+};
+void launch_tri_factor(const TriArgs &a, hipStream_t stream);
+void launch_tri_solve(const TriArgs &a, const double *r, double *z, hipStream_t stream);
+void launch_jacobi_setup(int n, const int *diag_slot, const double *val, double *invd, hipStream_t stream);
+
+// ---- vectors (device scalars in `sc`) ----
+void launch_copy(int n, const double *x, double *y, hipStream_t stream);
+void launch_set(int n, double v, double *y, hipStream_t stream);
+void launch_gather(int n, const int *idx, const double *in, double *out, hipStream_t stream);   // out[i] = in[idx[i]]
+void launch_scatter(int n, const int *idx, const double *in, double *out, hipStream_t stream);  // out[idx[i]] = in[i]
+void launch_pointwise_mult(int n, const double *a, const double *x, double *y, hipStream_t stream);
+// w = y + a*x with a = sign * sc[slot] (or the literal `aval` when slot < 0)
+void launch_waxpy(int n, double *w, const double *sc, int slot, double sign, double aval, const double *x,
+                  const double *y, hipStream_t stream);
+// BiCGStab fused updates (PETSc bcgs.c order of operations)
+void launch_bcgs_p(int n, double *P, const double *R, const double *V, const double *sc, hipStream_t stream);
+// also leaves the partial sums of r.r in `partials`; returns the number of partial blocks
+int launch_bcgs_xr(int n, double *X, double *R, const double *P, const double *S, const double *T, const double *sc,
+                   double *partials, hipStream_t stream);
+// multi-dot: sums[j] = x . ys[j], j < nvec; two-stage deterministic reduction (partials -> sc[S_SUM0+j])
+struct DotArgs { int n, nvec; const double *x[kMaxMultiDot]; const double *y[kMaxMultiDot]; };
+// stage 1 only (returns number of partial blocks); stage 2 is launch_finalize_partials
+int launch_dots(const DotArgs &a, double *partials, hipStream_t stream);
+void launch_finalize_partials(int nblocks, int nvec, const double *partials, double *sc, hipStream_t stream);
+// y -= sum_j h[j] * v_j  (h on device at sc[S_SUM0+j]); GMRES classical Gram-Schmidt update
+struct MaxpyArgs { int n, nvec; const double *v[kMaxMultiDot]; };
+void launch_maxpy_neg(const MaxpyArgs &a, const double *sc, double *y, hipStream_t stream);
+void launch_scale(int n, double *x, const double *sc, int slot_inv_of, hipStream_t stream);  // x *= 1/sc[slot]
+// x += sum_j yv[j]*v_j with yv passed by value
+struct MaxpyValArgs { int n, nvec; const double *v[kMaxMultiDot]; double c[kMaxMultiDot]; };
+void launch_maxpy_val(const MaxpyValArgs &a, double *x, hipStream_t stream);
+// single-thread scalar updates of the BiCGStab recurrence; step = 0 init, 1 rho/beta, 2 alpha, 3 omega
+void launch_bcgs_scalars(int step, double *sc, hipStream_t stream);
+
+}  // namespace mpp

@@ -1,0 +1,278 @@
+// physics.hpp -- constitutive laws and the two-point Darcy flux of the VSFM, as inlined device functions.
+//
+// Behavioural contract (what each function must reproduce) -- reference file:line
+//   saturation / relative permeability  src/mpp/util/SaturationFunction.F90:747-857 (VG), 900-990 (BC), 1027-1140 (SBC)
+//   water density                       src/mpp/util/EOSWaterMod.F90:80-99, 102-178, 181-344
+//   viscosity                           src/mpp/util/EOSWaterMod.F90:568-586
+//   porosity                            src/mpp/util/PorosityFunctionMod.F90:99-140 (constant model)
+//   flux + dflux                        src/mpp/ge/RichardsMod.F90:118-340
+// Branch conditions (`pc < 0`, `p > p0`, `dphi >= 0`, seepage switch) are kept exactly; arithmetic is fp64.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+namespace mpp {
+
+constexpr double kPressureRef = 101325.0;     // MultiPhysicsProbConstants.F90:199
+constexpr double kGravity = 9.80665;          // :201
+constexpr double kFMWH2O = 18.01534;          // :202
+constexpr double kDenH2O = 1.0e3;             // mpp_varcon.F90:17
+constexpr double kViscosity = 8.904156e-4;    // EOSWaterMod.F90:582
+
+enum SatFunc : int { kSatVG = 0, kSatBC = 1, kSatSBC = 2 };
+enum DenType : int { kDenConstant = 1, kDenTGDPB01 = 2, kDenIFC67 = 3 };
+enum CondType : int { kCondMassFlux = 504, kCondDirichlet = 505, kCondSeepage = 509 };
+
+// Problem-wide constants of the equation of state (temperature is uniform, 298.15 K unless set).
+struct EosParams {
+  int density_type;
+  double dent;    // TGDPB01: a5*(1 - (t+a1)^2 (t+a2)/a3/(t+a4))
+  double kcoef;   // TGDPB01: k0 + k1 t + k2 t^2
+  double t_C;     // temperature in degC (IFC67)
+};
+
+// per-cell soil parameters as the kernels hold them in registers
+struct Soil {
+  double sat_res, alpha, m;        // m = vg_m (VG) or bc_lambda (BC/SBC)
+  double pu, ps, b2, b3;           // SBC only
+  double por;
+};
+
+struct Aux {
+  double P, kr, dkr, den, dden, sat, dsat;
+};
+
+__host__ __device__ inline EosParams make_eos(int density_type, double t_K) {
+  EosParams e;
+  e.density_type = density_type;
+  const double a1 = -3.983035, a2 = 301.797, a3 = 522528.9, a4 = 69.34881, a5 = 999.974950;
+  const double k0 = 50.74e-11, k1 = -0.326e-11, k2 = 0.00416e-11;
+  double t_c = t_K - 273.15;
+  double sq = (t_c + a1) * (t_c + a1);
+  e.dent = a5 * (1.0 - sq * (t_c + a2) / a3 / (t_c + a4));
+  e.kcoef = k0 + k1 * t_c + k2 * (t_c * t_c);
+  e.t_C = t_c;
+  return e;
+}
+
+// IFC-67 liquid water density [kmol/m3] and d/dp (EOSWaterMod.F90:181-344)
+__host__ __device__ inline void density_ifc67(double t, double p, double &dwmol, double &dwp) {
+  const double aa11 = 7.982692717e00, aa12 = -2.616571843e-2, aa13 = 1.522411790e-3, aa14 = 2.284279054e-2,
+               aa15 = 2.421647003e02, aa16 = 1.269716088e-10, aa17 = 2.074838328e-7, aa18 = 2.174020350e-8,
+               aa19 = 1.105710498e-9, aa20 = 1.293441934e01, aa21 = 1.308119072e-5, aa22 = 6.047626338e-14;
+  const double a1 = 8.438375405e-1, a2 = 5.362162162e-4, a3 = 1.720000000e00, a4 = 7.342278489e-2;
+  const double a5 = 4.975858870e-2, a6 = 6.537154300e-1, a7 = 1.150000000e-6, a8 = 1.510800000e-5;
+  const double a9 = 1.418800000e-1, a10 = 7.002753165e00, a11 = 2.995284926e-4, a12 = 2.040000000e-1;
+  const double tc1 = 647.3, pc1 = 22.064e6, vc1 = 0.00317;
+  double utc1 = 1.0 / tc1, upc1 = 1.0 / pc1, vc1mol = vc1 * kFMWH2O;
+  double theta = (t + 273.15) * utc1;
+  double theta2x = theta * theta;
+  double theta18 = pow(theta, 18.0);
+  double theta20 = theta18 * theta2x;
+  double beta = p * upc1;
+  double beta2x = beta * beta;
+  double yy = 1.0 - a1 * theta2x - a2 * pow(theta, -6.0);
+  double xx = a3 * yy * yy - 2.0 * (a4 * theta - a5 * beta);
+  xx = sqrt(xx);  // xx <= 0 only near the critical point; NaN propagates to the norm and the step fails
+  double zz = yy + xx;
+  double u0 = -5.0 / 17.0;
+  double u1 = aa11 * a5 * pow(zz, u0);
+  double u2 = 1.0 / (a8 + pow(theta, 11.0));
+  double u3 = aa17 + (2.0 * aa18 + 3.0 * aa19 * beta) * beta;
+  double u4 = 1.0 / (a7 + theta18 * theta);
+  double u5 = pow(a10 + beta, -4.0);
+  double u6 = a11 - 3.0 * u5;
+  double u7 = aa20 * theta18 * (a9 + theta2x);
+  double u8 = aa15 * pow(a6 - theta, 9.0);
+  double vr = u1 + aa12 + theta * (aa13 + aa14 * theta) + u8 * (a6 - theta) + aa16 * u4 - u2 * u3 - u6 * u7 +
+              (3.0 * aa21 * (a12 - theta) + 4.0 * aa22 * beta / theta20) * beta2x;
+  dwmol = 1.0 / (vr * vc1mol);
+  double zpp = a5 / xx;
+  double u9 = u0 * u1 / zz;
+  double vrpp = u9 * zpp - u2 * (2.0 * aa18 + 6.0 * aa19 * beta) - 12.0 * u7 * u5 / (a10 + beta) +
+                (6.0 * aa21 * (a12 - theta) + 12.0 * aa22 * beta / theta20) * beta;
+  double cnv = -1.0 / (vc1mol * vr * vr);
+  dwp = cnv * vrpp * upc1;
+}
+
+__host__ __device__ inline void density(const EosParams &e, double p, double &den, double &dden) {
+  if (e.density_type == kDenTGDPB01) {
+    const double p0 = 101325.0;
+    double kappa, dkappa_dp;
+    if (p > p0) {  // strict: EOSWaterMod.F90:151
+      kappa = 1.0 + e.kcoef * (p - p0);
+      dkappa_dp = e.kcoef;
+    } else {
+      kappa = 1.0;
+      dkappa_dp = 0.0;
+    }
+    den = e.dent * kappa / kFMWH2O;
+    dden = (e.dent * dkappa_dp) / kFMWH2O;
+  } else if (e.density_type == kDenConstant) {
+    den = kDenH2O / kFMWH2O;
+    dden = 0.0;
+  } else {
+    density_ifc67(e.t_C, p, den, dden);
+  }
+}
+
+// SatFunc_PressToSat + SatFunc_PressToRelPerm (Mualem) for one pressure; shares the common powers.
+template <bool DERIV>
+__host__ __device__ inline void sat_relperm(int sat_func, const Soil &s, double press, double frac_liq, double &sat,
+                                            double &dsat, double &kr, double &dkr) {
+  const double pc = press - kPressureRef;
+  const double sat_res = s.sat_res, alpha = s.alpha;
+  if (sat_func == kSatVG) {
+    if (pc < 0.0) {
+      const double mm = s.m;
+      const double nn = 1.0 / (1.0 - mm);  // SatFunc_Set_VG, SaturationFunction.F90:157
+      const double pc_alpha_n = pow(-alpha * pc, nn);
+      const double one_plus = 1.0 + pc_alpha_n;
+      const double Se = pow(one_plus, -mm);
+      sat = sat_res + (1.0 - sat_res) * Se;
+      const double AA = pc_alpha_n / one_plus;
+      const double AAm = pow(AA, mm);
+      const double BB = 1.0 - AAm;
+      kr = sqrt(Se) * BB * BB;
+      if (DERIV) {
+        const double dSe_dpc = -mm * nn * Se * AA / pc;
+        dsat = (1.0 - sat_res) * dSe_dpc;
+        const double dkr_dSe = 0.5 * kr / Se + 2.0 * pow(Se, 1.0 / mm - 0.5) * pow(AA, mm - 1.0) * BB;
+        dkr = dkr_dSe * dSe_dpc;
+      }
+    } else {
+      sat = 1.0; kr = 1.0;
+      if (DERIV) { dsat = 0.0; dkr = 0.0; }
+    }
+  } else if (sat_func == kSatBC) {
+    const double lambda = s.m;
+    const double pc_alpha = -alpha * pc;
+    if (pc_alpha > 1.0) {
+      const double Se = pow(pc_alpha, -lambda);
+      sat = sat_res + (1.0 - sat_res) * Se;
+      const double ex = 2.5 + 2.0 / lambda;
+      kr = pow(Se, ex);
+      if (DERIV) {
+        const double dSe_dpc = -lambda * Se / pc;
+        dsat = (1.0 - sat_res) * dSe_dpc;
+        dkr = (ex * kr / Se) * dSe_dpc;
+      }
+    } else {
+      sat = 1.0; kr = 1.0;
+      if (DERIV) { dsat = 0.0; dkr = 0.0; }
+    }
+    kr = frac_liq * kr;  // SaturationFunction.F90:987-988 (Brooks-Corey only)
+    if (DERIV) dkr = frac_liq * dkr;
+  } else {  // smoothed Brooks-Corey
+    const double lambda = s.m;
+    const double ex = 2.5 + 2.0 / lambda;
+    if (pc <= s.pu) {
+      const double Se = pow(-alpha * pc, -lambda);
+      sat = sat_res + (1.0 - sat_res) * Se;
+      kr = pow(Se, ex);
+      if (DERIV) {
+        const double dSe_dpc = -lambda * Se / pc;
+        dsat = (1.0 - sat_res) * dSe_dpc;
+        dkr = (ex * kr / Se) * dSe_dpc;
+      }
+    } else if (pc < s.ps) {
+      const double deltaPc = pc - s.ps;
+      const double Se = 1.0 + deltaPc * deltaPc * (s.b2 + deltaPc * s.b3);
+      sat = sat_res + (1.0 - sat_res) * Se;
+      kr = pow(Se, ex);
+      if (DERIV) {
+        const double dSe_dpc = deltaPc * (2 * s.b2 + 3 * deltaPc * s.b3);
+        dsat = (1.0 - sat_res) * dSe_dpc;
+        dkr = (ex * kr / Se) * dSe_dpc;
+      }
+    } else {
+      sat = 1.0; kr = 1.0;
+      if (DERIV) { dsat = 0.0; dkr = 0.0; }
+    }
+  }
+}
+
+// RichODEPressureAuxVarCompute (RichardsODEPressureAuxType.F90:237-294)
+template <bool DERIV>
+__host__ __device__ inline Aux auxvar_compute(int sat_func, const EosParams &e, const Soil &s, double press,
+                                              double frac_liq) {
+  Aux a;
+  a.P = press;
+  a.dsat = 0.0; a.dkr = 0.0;
+  sat_relperm<DERIV>(sat_func, s, press, frac_liq, a.sat, a.dsat, a.kr, a.dkr);
+  density(e, press, a.den, a.dden);
+  return a;
+}
+
+// geometry of one connection as the kernels hold it (computed once on the host from
+// area, dist_up, dist_dn, unit_vec and the two cells' permeabilities, RichardsMod.F90:236-272)
+struct ConnGeom {
+  double Dq, upweight, dist_gravity, area;
+};
+
+// RichardsFlux_Internal (RichardsMod.F90:262-336).  `bc_type` = 0 for internal connections.
+// Returns flux; with DERIV also dflux_dP_up / dflux_dP_dn, which are the negatives of d(flux)/dP (:326-334).
+template <bool DERIV>
+__host__ __device__ inline double richards_flux(const Aux &up, const Aux &dn, const ConnGeom &g, int bc_type,
+                                                double &dflux_up, double &dflux_dn) {
+  const double upweight = g.upweight;
+  const double den_ave = upweight * up.den + (1.0 - upweight) * dn.den;
+  const double gravityterm = (upweight * up.den + (1.0 - upweight) * dn.den) * kFMWH2O * g.dist_gravity;
+  double dphi = up.P - dn.P + gravityterm;
+  bool seepage_update = false;
+  if (bc_type == kCondSeepage) {
+    if (dphi > 0.0 && up.P <= kPressureRef) seepage_update = true;
+  }
+  if (seepage_update) dphi = 0.0;
+  const bool upwind_up = (dphi >= 0.0);
+  const double ukvr = upwind_up ? up.kr / kViscosity : dn.kr / kViscosity;
+  const bool massflux = (bc_type == kCondMassFlux);
+  const double v_darcy = massflux ? 0.0 : -g.Dq * ukvr * dphi;
+  const double q = v_darcy * g.area;
+  const double flux = q * den_ave;
+  if (DERIV) {
+    const double dden_ave_up = upweight * up.dden;
+    const double dden_ave_dn = (1.0 - upweight) * dn.dden;
+    const double dgrav_up = upweight * g.dist_gravity * kFMWH2O;
+    const double dgrav_dn = (1.0 - upweight) * g.dist_gravity * kFMWH2O;
+    const double dphi_up = 1.0 + dgrav_up * up.dden;
+    double dphi_dn = -1.0 + dgrav_dn * dn.dden;
+    if (seepage_update) dphi_dn = 0.0;
+    // dvis_dP == 0 (EOSWaterMod.F90:583): the kr/(vis*vis)*dvis_dP term is an exact zero
+    const double dukvr_up = upwind_up ? (up.dkr / kViscosity - up.kr / (kViscosity * kViscosity) * 0.0) : 0.0;
+    const double dukvr_dn = upwind_up ? 0.0 : (dn.dkr / kViscosity - dn.kr / (kViscosity * kViscosity) * 0.0);
+    const double dq_up = g.Dq * (dukvr_up * dphi + ukvr * dphi_up) * g.area;
+    const double dq_dn = g.Dq * (dukvr_dn * dphi + ukvr * dphi_dn) * g.area;
+    if (massflux) {
+      dflux_up = 0.0; dflux_dn = 0.0;
+    } else {
+      dflux_up = dq_up * den_ave - q * dden_ave_up;
+      dflux_dn = dq_dn * den_ave - q * dden_ave_dn;
+    }
+  }
+  return flux;
+}
+
+// host-side geometry precompute (same expression order as RichardsMod.F90:236-272)
+inline ConnGeom make_conn_geom(bool internal_conn, double area, double dist_up, double dist_dn, const double *u,
+                               const double *perm_up, const double *perm_dn) {
+  ConnGeom g;
+  double pu = std::fabs(u[0]) * perm_up[0] + std::fabs(u[1]) * perm_up[1] + std::fabs(u[2]) * perm_up[2];
+  double pd = std::fabs(u[0]) * perm_dn[0] + std::fabs(u[1]) * perm_dn[1] + std::fabs(u[2]) * perm_dn[2];
+  if (internal_conn) {
+    g.upweight = dist_up / (dist_up + dist_dn);
+    g.Dq = (pu * pd) / (dist_up * pd + dist_dn * pu);
+  } else {  // COND_DIRICHLET, COND_MASS_FLUX, COND_SEEPAGE_BC (:249-252)
+    g.upweight = 0.0;
+    g.Dq = pd / (dist_up + dist_dn);
+  }
+  double grav_vec[3] = {0.0, 0.0, -kGravity};
+  double udotg = u[0] * grav_vec[0] + u[1] * grav_vec[1] + u[2] * grav_vec[2];
+  g.dist_gravity = (dist_up + dist_dn) * udotg;
+  g.area = area;
+  return g;
+}
+
+}  // namespace mpp

@@ -1,0 +1,122 @@
+// runtime.cpp -- HIP-event profiler and run-time RCCL binding.
+#include "runtime.hpp"
+
+#include <dlfcn.h>
+
+#include <cstring>
+
+namespace mpp {
+
+const char *kclass_name(int k) {
+  static const char *names[KC_COUNT] = {"spmv", "pc_apply", "pc_setup", "residual", "jacobian", "vec", "reduce"};
+  return (k >= 0 && k < KC_COUNT) ? names[k] : "?";
+}
+
+// ---------------- profiler: HIP events recorded on the solver's own stream around every launch group ----------------
+void Profiler::begin(int cls) {
+  if (!enabled) return;
+  if (used == pool.size()) {
+    if (pool.size() >= 8192) flush();
+    else {
+      Pair pr;
+      HIP_CHECK(hipEventCreate(&pr.a));
+      HIP_CHECK(hipEventCreate(&pr.b));
+      pr.cls = cls;
+      pool.push_back(pr);
+    }
+  }
+  pool[used].cls = cls;
+  HIP_CHECK(hipEventRecord(pool[used].a, stream));
+}
+void Profiler::end() {
+  if (!enabled) return;
+  HIP_CHECK(hipEventRecord(pool[used].b, stream));
+  ++used;
+}
+void Profiler::flush() {
+  if (!used) return;
+  HIP_CHECK(hipStreamSynchronize(stream));
+  for (size_t i = 0; i < used; ++i) {
+    float ms = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&ms, pool[i].a, pool[i].b));
+    launches[pool[i].cls] += 1;
+    total_ms[pool[i].cls] += ms;
+  }
+  used = 0;
+}
+void Profiler::reset() {
+  flush();
+  for (int k = 0; k < KC_COUNT; ++k) { launches[k] = 0; total_ms[k] = 0.0; }
+}
+Profiler::~Profiler() {
+  for (auto &pr : pool) { (void)hipEventDestroy(pr.a); (void)hipEventDestroy(pr.b); }
+}
+
+// ---------------- RCCL through dlopen: ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy ----------------
+namespace {
+struct NcclUniqueId { char internal[128]; };
+using fn_get_id = int (*)(NcclUniqueId *);
+using fn_init_rank = int (*)(void **, int, NcclUniqueId, int);
+using fn_allreduce = int (*)(const void *, void *, size_t, int, int, void *, hipStream_t);
+using fn_destroy = int (*)(void *);
+using fn_errstr = const char *(*)(int);
+constexpr int kNcclFloat64 = 8;  // ncclDataType_t ncclDouble (rccl.h)
+constexpr int kNcclSum = 0;      // ncclRedOp_t ncclSum
+constexpr int kNcclMax = 2;      // ncclRedOp_t ncclMax
+
+void *open_rccl() {
+  const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char *n : names) {
+    void *l = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (l) return l;
+  }
+  throw Error(std::string("cannot load RCCL (librccl.so.1): ") + dlerror());
+}
+template <typename F>
+F sym(void *lib, const char *name) {
+  void *p = dlsym(lib, name);
+  if (!p) throw Error(std::string("RCCL symbol missing: ") + name);
+  return reinterpret_cast<F>(p);
+}
+void nccl_check(void *lib, int rc, const char *what) {
+  if (rc == 0) return;
+  const char *msg = "?";
+  if (void *p = dlsym(lib, "ncclGetErrorString")) msg = reinterpret_cast<fn_errstr>(p)(rc);
+  throw Error(std::string(what) + " failed: " + msg);
+}
+}  // namespace
+
+void Comm::get_unique_id(void *id128) {
+  void *l = open_rccl();
+  NcclUniqueId id;
+  nccl_check(l, sym<fn_get_id>(l, "ncclGetUniqueId")(&id), "ncclGetUniqueId");
+  std::memcpy(id128, id.internal, 128);
+}
+void Comm::init(int nr, int r, const void *id128) {
+  if (comm) throw Error("communicator already initialised");
+  lib = open_rccl();
+  NcclUniqueId id;
+  std::memcpy(id.internal, id128, 128);
+  nccl_check(lib, sym<fn_init_rank>(lib, "ncclCommInitRank")(&comm, nr, id, r), "ncclCommInitRank");
+  nranks = nr;
+  rank = r;
+}
+void Comm::allreduce_sum(double *dev, int count, hipStream_t s) {
+  if (!comm) return;
+  static fn_allreduce f = nullptr;
+  if (!f) f = sym<fn_allreduce>(lib, "ncclAllReduce");
+  nccl_check(lib, f(dev, dev, (size_t)count, kNcclFloat64, kNcclSum, comm, s), "ncclAllReduce");
+}
+void Comm::allreduce_max(double *dev, int count, hipStream_t s) {
+  if (!comm) return;
+  static fn_allreduce f = nullptr;
+  if (!f) f = sym<fn_allreduce>(lib, "ncclAllReduce");
+  nccl_check(lib, f(dev, dev, (size_t)count, kNcclFloat64, kNcclMax, comm, s), "ncclAllReduce");
+}
+Comm::~Comm() {
+  if (comm && lib) {
+    if (void *p = dlsym(lib, "ncclCommDestroy")) (void)reinterpret_cast<fn_destroy>(p)(comm);
+  }
+}
+
+}  // namespace mpp

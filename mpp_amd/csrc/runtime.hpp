@@ -1,0 +1,117 @@
+// runtime.hpp -- host-side runtime of the VSFM solve path: device buffers, HIP-event profiling, RCCL binding,
+// problem layout (permutation, CSR pattern, slot tables) and the Newton / Krylov drivers.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+
+namespace mpp {
+
+struct Error : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+
+#define HIP_CHECK(expr)                                                                                   \
+  do {                                                                                                    \
+    hipError_t _e = (expr);                                                                               \
+    if (_e != hipSuccess)                                                                                 \
+      throw ::mpp::Error(std::string(#expr) + " failed: " + hipGetErrorString(_e) + " (" + __FILE__ + ":" + \
+                         std::to_string(__LINE__) + ")");                                                 \
+  } while (0)
+
+template <typename T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  void alloc(size_t count) {
+    if (count == n && p) return;
+    release();
+    if (count) HIP_CHECK(hipMalloc(&p, count * sizeof(T)));
+    n = count;
+  }
+  void upload(const T *src, size_t count, hipStream_t s) {
+    alloc(count);
+    if (count) HIP_CHECK(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, s));
+  }
+  void upload(const std::vector<T> &v, hipStream_t s) { upload(v.data(), v.size(), s); }
+  void zero(hipStream_t s) {
+    if (n) HIP_CHECK(hipMemsetAsync(p, 0, n * sizeof(T), s));
+  }
+};
+
+// ---- kernel classes for the HIP-event profiler ----
+enum KClass : int { KC_SPMV = 0, KC_PC_APPLY, KC_PC_SETUP, KC_RESIDUAL, KC_JACOBIAN, KC_VEC, KC_REDUCE, KC_COUNT };
+const char *kclass_name(int k);
+
+struct Profiler {
+  bool enabled = false;
+  hipStream_t stream = nullptr;
+  struct Pair { hipEvent_t a, b; int cls; };
+  std::vector<Pair> pool;
+  size_t used = 0;
+  long long launches[KC_COUNT] = {0};
+  double total_ms[KC_COUNT] = {0};
+  void begin(int cls);
+  void end();
+  void flush();   // synchronises the stream and folds recorded pairs into the totals
+  void reset();
+  ~Profiler();
+};
+struct ProfScope {
+  Profiler &p;
+  ProfScope(Profiler &pr, int cls) : p(pr) { p.begin(cls); }
+  ~ProfScope() { p.end(); }
+};
+
+// ---- RCCL, bound at run time (dlopen) so that single-GPU use never needs the library ----
+struct Comm {
+  void *lib = nullptr;
+  void *comm = nullptr;
+  int nranks = 1, rank = 0;
+  bool active() const { return comm != nullptr; }
+  static void get_unique_id(void *id128);
+  void init(int nranks, int rank, const void *id128);
+  void allreduce_sum(double *dev, int count, hipStream_t s);
+  void allreduce_max(double *dev, int count, hipStream_t s);
+  ~Comm();
+};
+
+struct Condition {
+  int kind = 0, cond_type = 0, swap_order = 0, n = 0;
+  std::vector<int> cell;               // external 0-based
+  std::vector<double> dist_up, dist_dn, area, uvec, value;
+  int offset = 0;                      // first entry in the concatenated BC (or SS) numbering
+};
+
+struct Options {
+  int ksp_type = 1;        // 0 preonly, 1 gmres, 2 bcgs       (PETSc default: gmres)
+  int pc_type = 2;         // 0 none, 2 bjacobi (per soil column), 3 jacobi
+  double ksp_rtol = 1e-5, ksp_atol = 1e-50, ksp_dtol = 1e4;
+  int ksp_max_it = 10000, gmres_restart = 30;
+  double snes_rtol = 1e-8, snes_atol = 1e-50, snes_stol = 1e-10, snes_divtol = 1e4;  // stol: MultiPhysicsProbBaseType.F90:1112
+  int snes_max_it = 50, snes_max_funcs = 10000;
+  int spmv_variant = 0;
+  int assembly = -1;       // -1 auto, 0 general kernels, 1 fused column kernels
+  int nseg = 0;            // column segments per thread block row (0 = auto)
+};
+
+struct Solver;  // all state behind a handle
+
+}  // namespace mpp

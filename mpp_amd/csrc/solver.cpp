@@ -1,0 +1,1345 @@
+// solver.cpp -- problem layout, Newton / Krylov drivers and the C ABI (include/mppgpu.h).
+//
+// What it stands in for (reference file:line):
+//   mpp%SetupProblem / MPPSetupProblemSNES     src/mpp/mpp/MultiPhysicsProbBaseType.F90:1089-1213  (DM/Mat/Vec creation)
+//   soe%StepDT -> SOEBaseStepDT_SNES           src/mpp/soe/SystemOfEquationsBaseType.F90:368-552
+//   VSFMSOEPreSolve / PostSolve / Residual / Jacobian   src/mpp/soe/SystemOfEquationsVSFMType.F90:94-403, 506-660
+//   PETSc v3.16.2 SNESSolve_NEWTONLS, SNESLineSearchApply_BT, KSPSolve_BCGS, KSPSolve_GMRES, PCApply (bjacobi)
+//     (third-party; call sites SystemOfEquationsBaseType.F90:478, MultiPhysicsProbBaseType.F90:1193-1205)
+// All arithmetic on vectors and matrices happens in HIP kernels (kernels.hip); the host only sequences launches
+// and reads back a handful of scalars per iteration.  There is no CPU compute path.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+
+#include "../../include/mppgpu.h"
+#include "runtime.hpp"
+
+namespace mpp {
+
+namespace {
+int map_sat_func(int reference_id) {
+  switch (reference_id) {
+    case MPPGPU_SAT_FUNC_VAN_GENUCHTEN: return kSatVG;
+    case MPPGPU_SAT_FUNC_BROOKS_COREY: return kSatBC;
+    case MPPGPU_SAT_FUNC_SMOOTHED_BROOKS_COREY_BZ2:
+    case MPPGPU_SAT_FUNC_SMOOTHED_BROOKS_COREY_BZ3: return kSatSBC;
+    default: return -1;
+  }
+}
+
+// findGu_SBC_zeroCoeff (src/mpp/util/SaturationFunction.F90:425-518): set-up time only, host
+double find_gu_sbc_zero_coeff(double lambda, int AA, double gs) {
+  const double relTol = 1e-12;
+  double gu = std::pow((double)AA / ((double)AA + lambda), -1.0 / lambda);
+  if (gs > 0.0) {
+    double guLeft = 1.0, guRight = gu;
+    for (int guard = 0; guard < 200; ++guard) {
+      if (gu <= guLeft || gu >= guRight) gu = guLeft + 0.5 * (guRight - guLeft);
+      double guInv = 1.0 / gu, guToMinusLam = std::pow(gu, -lambda), gsOnGu = gs * guInv;
+      double resid = AA - guToMinusLam * (AA + lambda - lambda * gsOnGu);
+      if (resid < 0.0) guLeft = gu; else guRight = gu;
+      double dr = (1.0 + lambda) * (1.0 - gsOnGu) + (AA - 1);
+      dr = lambda * guToMinusLam * guInv * dr;
+      double delta = resid / dr;
+      gu = gu - delta;
+      if (std::fabs(delta) < relTol * std::fabs(gu)) break;
+    }
+  }
+  return gu;
+}
+}  // namespace
+
+struct Solver {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  bool setup_done = false;
+  Profiler prof;
+  Comm comm;
+  Options opt;
+
+  // ---------------- staging, caller's ordering, 0-based ----------------
+  int n = 0, nlev = 0;
+  std::vector<double> vol;
+  std::vector<int> active;
+  bool any_inactive = false;
+  int nc = 0;
+  std::vector<int> cup_e, cdn_e;
+  std::vector<double> cdu, cdd, carea, cuv;
+  std::vector<Condition> bcs, sss;
+  std::vector<double> permx, permy, permz, por, alpha, lam, sat_res;
+  std::vector<int> satf;
+  int sat_func = -1;
+  int density_type = MPPGPU_DENSITY_CONSTANT;  // RichODEPressureAuxVarInit default (AuxType :120)
+  double temperature = 273.15 + 25.0, frac_liq = 1.0;
+  bool soil_dirty = true;
+
+  // ---------------- layout ----------------
+  bool columns = false, vertical_only = false, identity_perm = true;
+  int ncols = 0, nz = 0;
+  std::vector<int> ext2int, int2ext, cext2int;
+  int nc_int = 0;
+  std::vector<int> h_rowptr, h_col, h_diag;
+  int nnz = 0;
+  int nb = 0, ns = 0;
+  std::vector<int> bc_pos_of_g, h_bc_cell_int;
+  int ncond_cells = 0;
+
+  // ---------------- device ----------------
+  DevBuf<double> d_vol, d_por, d_sat_res, d_alpha, d_m, d_pu, d_ps, d_b2, d_b3;
+  DevBuf<signed char> d_active;
+  DevBuf<double> d_Dq, d_upw, d_dgrav, d_area;
+  DevBuf<int> d_cup, d_cdn;
+  DevBuf<int> d_rowptr, d_col, d_diag, d_rc_ptr, d_rc_conn, d_rc_slot, d_tri_lo, d_tri_up;
+  DevBuf<double> d_val;
+  DevBuf<int> d_cc_cell, d_cc_ptr, d_bc_type;
+  DevBuf<double> d_bc_Dq, d_bc_dgrav, d_bc_area, d_bc_value, d_bc_flux;
+  DevBuf<double> d_src;
+  bool has_src = false;
+  DevBuf<int> d_ext2int, d_int2ext;
+  DevBuf<double> soln, soln_prev, accum_prev, F, Y, W, G, R, RP, V, T, S, Pv, Wk, tmp_ext, tmp_int;
+  DevBuf<double> aux_kr, aux_dkr, aux_den, aux_dden;
+  DevBuf<double> tri_l, tri_invb, tri_c, jac_invd;
+  DevBuf<double> partials, sc;
+  double *h_sc = nullptr;  // pinned mirror of sc
+  std::vector<DevBuf<double>> vv;
+
+  double dtime = 0.0, time = 0.0;
+  long long cum_newton = 0, cum_linear = 0, cum_cuts = 0, cum_funcs = 0;
+  int nfuncs = 0;
+  bool pc_ready = false;
+  std::vector<double> h_bc_value, h_ss_value;
+
+  ~Solver() {
+    if (h_sc) (void)hipHostFree(h_sc);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+
+  // =====================================================================================
+  // staging setters
+  // =====================================================================================
+  void need_setup(bool want) const {
+    if (want && !setup_done) throw Error("mppgpu_setup has not been called");
+    if (!want && setup_done) throw Error("the mesh cannot change after mppgpu_setup");
+  }
+
+  void set_mesh(int ncells, int nlev_, const double *v, const int *act) {
+    need_setup(false);
+    if (ncells <= 0) throw Error("ncells must be positive");
+    n = ncells; nlev = nlev_;
+    vol.assign(v, v + n);
+    active.assign(n, 1);
+    any_inactive = false;
+    if (act) for (int i = 0; i < n; ++i) { active[i] = act[i] != 0; any_inactive |= !active[i]; }
+  }
+
+  void set_connections(int nconn, const int *up, const int *dn, const double *du, const double *dd, const double *ar,
+                       const double *uv) {
+    need_setup(false);
+    if (n == 0) throw Error("mppgpu_set_mesh must precede mppgpu_set_connections");
+    nc = nconn;
+    cup_e.resize(nc); cdn_e.resize(nc);
+    for (int c = 0; c < nc; ++c) {
+      if (up[c] < 1 || up[c] > n || dn[c] < 1 || dn[c] > n)
+        throw Error("connection " + std::to_string(c + 1) + ": cell id out of range");
+      if (up[c] == dn[c]) throw Error("connection " + std::to_string(c + 1) + ": id_up == id_dn");
+      cup_e[c] = up[c] - 1; cdn_e[c] = dn[c] - 1;
+    }
+    cdu.assign(du, du + nc); cdd.assign(dd, dd + nc); carea.assign(ar, ar + nc); cuv.assign(uv, uv + 3 * (size_t)nc);
+  }
+
+  int add_condition(int kind, int cond_type, int nconn, const int *id_dn, const double *du, const double *dd,
+                    const double *ar, const double *uv, int swap_order) {
+    need_setup(false);
+    if (n == 0) throw Error("mppgpu_set_mesh must precede mppgpu_add_condition");
+    std::vector<Condition> *list;
+    if (kind == MPPGPU_COND_BC) {
+      if (cond_type != MPPGPU_COND_DIRICHLET && cond_type != MPPGPU_COND_SEEPAGE_BC && cond_type != MPPGPU_COND_MASS_FLUX)
+        throw Error("unsupported boundary cond_type " + std::to_string(cond_type));
+      list = &bcs;
+    } else if (kind == MPPGPU_COND_SS) {
+      if (cond_type != MPPGPU_COND_MASS_RATE) throw Error("unsupported source-sink cond_type " + std::to_string(cond_type));
+      list = &sss;
+    } else throw Error("unknown condition kind " + std::to_string(kind));
+    Condition c;
+    c.kind = kind; c.cond_type = cond_type; c.swap_order = swap_order ? 1 : 0; c.n = nconn;
+    c.cell.resize(nconn);
+    for (int i = 0; i < nconn; ++i) {
+      if (id_dn[i] < 1 || id_dn[i] > n) throw Error("condition: cell id out of range");
+      c.cell[i] = id_dn[i] - 1;
+    }
+    if (kind == MPPGPU_COND_BC) {
+      c.dist_up.assign(du, du + nconn); c.dist_dn.assign(dd, dd + nconn); c.area.assign(ar, ar + nconn);
+      c.uvec.assign(uv, uv + 3 * (size_t)nconn);
+    }
+    c.value.assign(nconn, 0.0);
+    list->push_back(std::move(c));
+    return (int)list->size();
+  }
+
+  void set_perm(const double *px, const double *py, const double *pz) {
+    if (!n) throw Error("mesh not set");
+    permx.assign(px, px + n); permy.assign(py, py + n); permz.assign(pz, pz + n);
+    soil_dirty = true;
+  }
+  void set_por(const double *p) {
+    if (!n) throw Error("mesh not set");
+    por.assign(p, p + n);
+    soil_dirty = true;
+  }
+  void set_satfunc(const int *type, const double *a, const double *l, const double *sr) {
+    if (!n) throw Error("mesh not set");
+    for (int i = 0; i < n; ++i) {
+      if (type[i] != type[0]) throw Error("mixed saturation-function types in one mesh are not supported");
+      const double alpha_i = a[i], lam_i = l[i], sr_i = sr[i];
+      bool bad = sr_i < 0.0 || sr_i > 0.5 || alpha_i <= 0.0 || alpha_i > 2.0 || lam_i <= 0.0;
+      if (type[0] == MPPGPU_SAT_FUNC_VAN_GENUCHTEN) bad |= lam_i >= 1.0; else bad |= lam_i >= 2.0;
+      if (bad) throw Error("bad saturation parameters at cell " + std::to_string(i + 1));  // SatFunc_Set_* argument checks
+    }
+    if (map_sat_func(type[0]) < 0) throw Error("unsupported saturation function " + std::to_string(type[0]));
+    satf.assign(type, type + n); alpha.assign(a, a + n); lam.assign(l, l + n); sat_res.assign(sr, sr + n);
+    sat_func = map_sat_func(type[0]);
+    soil_dirty = true;
+  }
+
+  // =====================================================================================
+  // layout
+  // =====================================================================================
+  void detect_columns() {
+    // vertical chains of the internal connection set (any cell numbering)
+    std::vector<int> nxt(n, -1), below(n, -1);
+    std::vector<char> is_vert(nc, 0);
+    bool ok = true;
+    for (int c = 0; c < nc && ok; ++c) {
+      const double ux = cuv[3 * (size_t)c], uy = cuv[3 * (size_t)c + 1], uz = cuv[3 * (size_t)c + 2];
+      if (std::fabs(uz) > 0.5 * std::sqrt(ux * ux + uy * uy + uz * uz)) {
+        is_vert[c] = 1;
+        if (nxt[cup_e[c]] != -1 || below[cdn_e[c]] != -1) ok = false;
+        nxt[cup_e[c]] = cdn_e[c];
+        below[cdn_e[c]] = cup_e[c];
+      }
+    }
+    ext2int.assign(n, -1);
+    int2ext.assign(n, -1);
+    columns = false;
+    if (ok) {
+      std::vector<int> starts;
+      for (int i = 0; i < n; ++i) if (below[i] == -1) starts.push_back(i);
+      const int nchains = (int)starts.size();
+      if (nchains > 0 && n % nchains == 0) {
+        const int len = n / nchains;
+        bool equal = true;
+        std::vector<int> lev(n, -1), colof(n, -1);
+        for (int ch = 0; ch < nchains && equal; ++ch) {
+          int cur = starts[ch], k = 0;
+          while (cur != -1 && k <= len) { lev[cur] = k; colof[cur] = ch; cur = nxt[cur]; ++k; }
+          if (k != len) equal = false;
+        }
+        if (equal) {
+          columns = true; ncols = nchains; nz = len;
+          for (int i = 0; i < n; ++i) {
+            if (lev[i] < 0) { columns = false; break; }
+            ext2int[i] = lev[i] * ncols + colof[i];
+          }
+        }
+      }
+    }
+    if (!columns) {  // every cell its own block: identity layout
+      ncols = n; nz = 1;
+      for (int i = 0; i < n; ++i) ext2int[i] = i;
+    }
+    identity_perm = true;
+    for (int i = 0; i < n; ++i) { int2ext[ext2int[i]] = i; identity_perm &= (ext2int[i] == i); }
+    // internal connection numbering: chain links at the index of their lower cell, the rest appended
+    cext2int.assign(nc, -1);
+    int nlat = 0;
+    if (columns) {
+      const int nvert = (nz - 1) * ncols;
+      for (int c = 0; c < nc; ++c) {
+        if (is_vert[c]) cext2int[c] = ext2int[cup_e[c]]; else cext2int[c] = nvert + nlat++;
+      }
+      nc_int = nvert + nlat;
+      vertical_only = (nlat == 0);
+    } else {
+      for (int c = 0; c < nc; ++c) cext2int[c] = c;
+      nc_int = nc;
+      vertical_only = false;
+    }
+  }
+
+  int find_slot(int row, int col) const {
+    const int *b = h_col.data() + h_rowptr[row], *e = h_col.data() + h_rowptr[row + 1];
+    const int *p = std::lower_bound(b, e, col);
+    return (p != e && *p == col) ? (int)(p - h_col.data()) : -1;
+  }
+
+  void build_pattern() {
+    // CSR pattern = diagonal + both directions of every internal connection: exactly the entries the reference
+    // creates with MatSetValuesLocal (GoveqnRichardsODEPressureType.F90:1689, 2051-2069), rows in internal order
+    std::vector<int> cnt((size_t)n + 1, 0);
+    for (int i = 0; i < n; ++i) cnt[i + 1] = 1;
+    for (int c = 0; c < nc; ++c) { cnt[ext2int[cup_e[c]] + 1]++; cnt[ext2int[cdn_e[c]] + 1]++; }
+    for (int i = 0; i < n; ++i) cnt[i + 1] += cnt[i];
+    std::vector<int> col(cnt[n]), fill(cnt.begin(), cnt.end() - 1);
+    for (int i = 0; i < n; ++i) col[fill[i]++] = i;
+    for (int c = 0; c < nc; ++c) {
+      const int u = ext2int[cup_e[c]], d = ext2int[cdn_e[c]];
+      col[fill[u]++] = d; col[fill[d]++] = u;
+    }
+    h_rowptr.assign((size_t)n + 1, 0);
+    h_col.clear(); h_col.reserve(col.size());
+    for (int i = 0; i < n; ++i) {
+      h_rowptr[i] = (int)h_col.size();
+      std::sort(col.begin() + cnt[i], col.begin() + cnt[i + 1]);
+      for (int k = cnt[i]; k < cnt[i + 1]; ++k)
+        if (k == cnt[i] || col[k] != col[k - 1]) h_col.push_back(col[k]);
+    }
+    nnz = (int)h_col.size();
+    h_rowptr[n] = nnz;
+    h_diag.resize(n);
+    for (int i = 0; i < n; ++i) h_diag[i] = find_slot(i, i);
+  }
+
+  void setup() {
+    need_setup(false);
+    if (n == 0) throw Error("mppgpu_set_mesh has not been called");
+    HIP_CHECK(hipSetDevice(device));
+    detect_columns();
+    build_pattern();
+    d_ext2int.upload(ext2int, stream);
+    d_int2ext.upload(int2ext, stream);
+    d_rowptr.upload(h_rowptr, stream);
+    d_col.upload(h_col, stream);
+    d_diag.upload(h_diag, stream);
+    d_val.alloc(nnz); d_val.zero(stream);
+
+    // mesh arrays in internal order
+    std::vector<double> v(n);
+    for (int i = 0; i < n; ++i) v[i] = vol[int2ext[i]];
+    d_vol.upload(v, stream);
+    if (any_inactive) {
+      std::vector<signed char> a(n);
+      for (int i = 0; i < n; ++i) a[i] = (signed char)active[int2ext[i]];
+      d_active.upload(a.data(), a.size(), stream);
+    }
+    // connection end cells (internal numbering both ways)
+    {
+      std::vector<int> up(nc_int, 0), dn(nc_int, 0);
+      for (int c = 0; c < nc; ++c) { up[cext2int[c]] = ext2int[cup_e[c]]; dn[cext2int[c]] = ext2int[cdn_e[c]]; }
+      d_cup.upload(up, stream); d_cdn.upload(dn, stream);
+    }
+    // per-row incident connection lists, in the caller's connection order (general kernels only)
+    if (!vertical_only || opt.assembly == 0) {
+      std::vector<int> ptr((size_t)n + 1, 0);
+      for (int c = 0; c < nc; ++c) { ptr[ext2int[cup_e[c]] + 1]++; ptr[ext2int[cdn_e[c]] + 1]++; }
+      for (int i = 0; i < n; ++i) ptr[i + 1] += ptr[i];
+      std::vector<int> fill(ptr.begin(), ptr.end() - 1), rconn(ptr[n]), rslot(ptr[n]);
+      for (int c = 0; c < nc; ++c) {
+        const int u = ext2int[cup_e[c]], d = ext2int[cdn_e[c]], ic = cext2int[c];
+        rconn[fill[u]] = (ic << 1) | 0; rslot[fill[u]++] = find_slot(u, d);
+        rconn[fill[d]] = (ic << 1) | 1; rslot[fill[d]++] = find_slot(d, u);
+      }
+      d_rc_ptr.upload(ptr, stream); d_rc_conn.upload(rconn, stream); d_rc_slot.upload(rslot, stream);
+      aux_kr.alloc(n); aux_dkr.alloc(n); aux_den.alloc(n); aux_dden.alloc(n);
+    }
+    // tridiagonal slots of the per-column blocks
+    {
+      std::vector<int> lo(n, -1), up(n, -1);
+      if (columns) {
+        for (int i = 0; i < n; ++i) {
+          const int k = i / ncols;
+          if (k > 0) lo[i] = find_slot(i, i - ncols);
+          if (k < nz - 1) up[i] = find_slot(i, i + ncols);
+        }
+      }
+      d_tri_lo.upload(lo, stream); d_tri_up.upload(up, stream);
+      tri_l.alloc(n); tri_invb.alloc(n); tri_c.alloc(n); jac_invd.alloc(n);
+    }
+    // boundary conditions: entries grouped by cell, (condition, connection) order kept inside a cell
+    nb = 0;
+    for (auto &c : bcs) { c.offset = nb; nb += c.n; }
+    ns = 0;
+    for (auto &c : sss) { c.offset = ns; ns += c.n; }
+    h_bc_value.assign(nb, 0.0);
+    h_ss_value.assign(ns, 0.0);
+    bc_pos_of_g.assign(nb, -1);
+    h_bc_cell_int.assign(nb, 0);
+    {
+      std::vector<std::pair<int, int>> key(nb);  // (internal cell, g)
+      std::vector<int> gtype(nb);
+      for (auto &c : bcs)
+        for (int i = 0; i < c.n; ++i) {
+          key[c.offset + i] = {ext2int[c.cell[i]], c.offset + i};
+          gtype[c.offset + i] = c.cond_type | (c.swap_order << 16);
+        }
+      std::sort(key.begin(), key.end());
+      std::vector<int> cc_cell, cc_ptr, type(nb);
+      for (int e = 0; e < nb; ++e) {
+        if (e == 0 || key[e].first != key[e - 1].first) { cc_cell.push_back(key[e].first); cc_ptr.push_back(e); }
+        bc_pos_of_g[key[e].second] = e;
+        h_bc_cell_int[e] = key[e].first;
+        type[e] = gtype[key[e].second];
+      }
+      cc_ptr.push_back(nb);
+      ncond_cells = (int)cc_cell.size();
+      d_cc_cell.upload(cc_cell, stream); d_cc_ptr.upload(cc_ptr, stream); d_bc_type.upload(type, stream);
+      d_bc_value.alloc(nb); d_bc_value.zero(stream);
+      d_bc_flux.alloc(nb); d_bc_flux.zero(stream);
+      d_bc_Dq.alloc(nb); d_bc_dgrav.alloc(nb); d_bc_area.alloc(nb);
+    }
+    if (ns > 0) { d_src.alloc(n); d_src.zero(stream); has_src = true; }
+    // vectors
+    for (DevBuf<double> *b : {&soln, &soln_prev, &accum_prev, &F, &Y, &W, &G, &R, &RP, &V, &T, &S, &Pv, &Wk, &tmp_ext, &tmp_int}) {
+      b->alloc(n); b->zero(stream);
+    }
+    partials.alloc((size_t)kMaxPartialBlocks * kMaxMultiDot);
+    sc.alloc(S_COUNT); sc.zero(stream);
+    HIP_CHECK(hipHostMalloc(&h_sc, S_COUNT * sizeof(double), hipHostMallocDefault));
+    d_Dq.alloc(nc_int); d_upw.alloc(nc_int); d_dgrav.alloc(nc_int); d_area.alloc(nc_int);
+    HIP_CHECK(hipStreamSynchronize(stream));
+    setup_done = true;
+    soil_dirty = true;
+  }
+
+  // soil parameters + connection geometry -> device (lazy: the reference sets soils after SetupProblem)
+  void ensure_ready() {
+    need_setup(true);
+    if (!soil_dirty) return;
+    if ((int)permx.size() != n || (int)por.size() != n || (int)alpha.size() != n)
+      throw Error("soil properties are incomplete: set permeability, porosity and saturation function");
+    std::vector<double> a(n), b(n), c(n), d(n);
+    for (int i = 0; i < n; ++i) { const int e = int2ext[i]; a[i] = por[e]; b[i] = sat_res[e]; c[i] = alpha[e]; d[i] = lam[e]; }
+    d_por.upload(a, stream); d_sat_res.upload(b, stream); d_alpha.upload(c, stream); d_m.upload(d, stream);
+    if (sat_func == kSatSBC) {
+      // SatFunc_Set_SBC_bz2 / _bz3 (SaturationFunction.F90:260-372), ps = -0.9/alpha (:1409,1412)
+      std::vector<double> pu(n), ps(n), b2(n), b3(n);
+      for (int i = 0; i < n; ++i) {
+        const int e = int2ext[i];
+        const bool bz2 = satf[e] == MPPGPU_SAT_FUNC_SMOOTHED_BROOKS_COREY_BZ2;
+        const double al = alpha[e], la = lam[e];
+        const double p_s = -0.9 / al;
+        const double p_u = find_gu_sbc_zero_coeff(la, bz2 ? 3 : 2, -al * p_s) / (-al);
+        const double bcAtPu = std::pow(-al * p_u, -la), ldp = la * (1.0 - p_s / p_u), inv = 1.0 / (p_u - p_s);
+        ps[i] = p_s; pu[i] = p_u;
+        if (bz2) { b2[i] = 0.0; b3[i] = (2.0 - bcAtPu * (2.0 + ldp)) * inv * inv * inv; }
+        else { b2[i] = -(3.0 - bcAtPu * (3.0 + ldp)) * inv * inv; b3[i] = 0.0; }
+      }
+      d_pu.upload(pu, stream); d_ps.upload(ps, stream); d_b2.upload(b2, stream); d_b3.upload(b3, stream);
+    }
+    // internal connection geometry (RichardsMod.F90:236-272)
+    {
+      std::vector<double> Dq(nc_int, 0.0), upw(nc_int, 0.0), dg(nc_int, 0.0), ar(nc_int, 0.0);
+      for (int cidx = 0; cidx < nc; ++cidx) {
+        const int u = cup_e[cidx], dn = cdn_e[cidx];
+        const double pu[3] = {permx[u], permy[u], permz[u]}, pd[3] = {permx[dn], permy[dn], permz[dn]};
+        ConnGeom g = make_conn_geom(true, carea[cidx], cdu[cidx], cdd[cidx], &cuv[3 * (size_t)cidx], pu, pd);
+        const int ic = cext2int[cidx];
+        Dq[ic] = g.Dq; upw[ic] = g.upweight; dg[ic] = g.dist_gravity; ar[ic] = g.area;
+      }
+      d_Dq.upload(Dq, stream); d_upw.upload(upw, stream); d_dgrav.upload(dg, stream); d_area.upload(ar, stream);
+    }
+    // boundary geometry: the BC auxvar carries the soil of its id_dn cell (MultiPhysicsProbVSFM.F90:422-446)
+    if (nb > 0) {
+      std::vector<double> Dq(nb), dg(nb), ar(nb);
+      for (auto &cd : bcs)
+        for (int i = 0; i < cd.n; ++i) {
+          const int cell = cd.cell[i];
+          const double pp[3] = {permx[cell], permy[cell], permz[cell]};
+          ConnGeom g = make_conn_geom(false, cd.area[i], cd.dist_up[i], cd.dist_dn[i], &cd.uvec[3 * (size_t)i], pp, pp);
+          const int e = bc_pos_of_g[cd.offset + i];
+          Dq[e] = g.Dq; dg[e] = g.dist_gravity; ar[e] = g.area;
+        }
+      d_bc_Dq.upload(Dq, stream); d_bc_dgrav.upload(dg, stream); d_bc_area.upload(ar, stream);
+    }
+    HIP_CHECK(hipStreamSynchronize(stream));
+    soil_dirty = false;
+  }
+
+  // =====================================================================================
+  // kernel argument packs
+  // =====================================================================================
+  CellArrays cells(const double *P) const {
+    CellArrays ca;
+    ca.P = P; ca.por = d_por.p; ca.sat_res = d_sat_res.p; ca.alpha = d_alpha.p; ca.m = d_m.p; ca.vol = d_vol.p;
+    ca.sbc_pu = d_pu.p; ca.sbc_ps = d_ps.p; ca.sbc_b2 = d_b2.p; ca.sbc_b3 = d_b3.p;
+    ca.active = any_inactive ? d_active.p : nullptr;
+    ca.sat_func = sat_func; ca.frac_liq = frac_liq;
+    ca.eos = make_eos(density_type, temperature);
+    return ca;
+  }
+  ConnArrays conns() const { return ConnArrays{d_Dq.p, d_upw.p, d_dgrav.p, d_area.p}; }
+  bool use_cols() const { return vertical_only && opt.assembly != 0; }
+  int pick_nseg() const {
+    if (opt.nseg > 0) return std::min(opt.nseg, nz);
+    // enough threads for >= 8 waves on each of the 256 CUs; one halo level per segment end is the price
+    const long long want = 256LL * 8 * 64;
+    int s = (int)std::min<long long>((want + ncols - 1) / std::max(ncols, 1), std::max(nz / 8, 1));
+    return std::max(s, 1);
+  }
+  ColsArgs cols_args(const double *P, double *Fout) const {
+    ColsArgs a;
+    a.cell = cells(P); a.conn = conns();
+    a.accum_prev = accum_prev.p; a.src = has_src ? d_src.p : nullptr;
+    a.F = Fout; a.val = d_val.p; a.rowptr = d_rowptr.p;
+    a.ncols = ncols; a.nz = nz; a.nseg = pick_nseg(); a.dtInv = 1.0 / dtime;
+    return a;
+  }
+  GenArgs gen_args(const double *P, double *Fout) const {
+    GenArgs a;
+    a.cell = cells(P); a.conn = conns();
+    a.cup = d_cup.p; a.cdn = d_cdn.p;
+    a.rc_ptr = d_rc_ptr.p; a.rc_conn = d_rc_conn.p; a.rc_slot = d_rc_slot.p;
+    a.diag_slot = d_diag.p; a.rowptr = d_rowptr.p;
+    a.accum_prev = accum_prev.p; a.src = has_src ? d_src.p : nullptr;
+    a.aux = AuxOut{aux_kr.p, aux_dkr.p, aux_den.p, aux_dden.p};
+    a.F = Fout; a.val = d_val.p; a.n = n; a.dtInv = 1.0 / dtime;
+    return a;
+  }
+  BcArgs bc_args(const double *P, double *Fout) const {
+    BcArgs a;
+    a.cell = cells(P);
+    a.ncond_cells = ncond_cells; a.cc_cell = d_cc_cell.p; a.cc_ptr = d_cc_ptr.p;
+    a.Dq = d_bc_Dq.p; a.dgrav = d_bc_dgrav.p; a.area = d_bc_area.p; a.value = d_bc_value.p; a.type = d_bc_type.p;
+    a.diag_slot = d_diag.p; a.F = Fout; a.val = d_val.p; a.flux_out = d_bc_flux.p;
+    return a;
+  }
+
+  // =====================================================================================
+  // operators (device pointers, internal ordering)
+  // =====================================================================================
+  void op_residual(const double *P, double *Fout) {
+    if (dtime <= 0.0) throw Error("time step not set");
+    ProfScope ps(prof, KC_RESIDUAL);
+    if (use_cols()) launch_assemble_cols(0, cols_args(P, Fout), stream);
+    else {
+      if (!d_rc_ptr.p) throw Error("option assembly=general must be set before mppgpu_setup");
+      launch_assemble_general(0, gen_args(P, Fout), stream);
+    }
+    launch_bc(0, bc_args(P, Fout), stream);
+    ++nfuncs; ++cum_funcs;
+  }
+  void op_jacobian(const double *P) {
+    if (dtime <= 0.0) throw Error("time step not set");
+    ProfScope ps(prof, KC_JACOBIAN);
+    if (use_cols()) launch_assemble_cols(1, cols_args(P, F.p), stream);
+    else launch_assemble_general(1, gen_args(P, F.p), stream);
+    launch_bc(1, bc_args(P, F.p), stream);
+    pc_ready = false;
+  }
+  void op_pre_solve() {  // VSFMSOEPreSolve: accum_prev from soln_prev
+    ProfScope ps(prof, KC_RESIDUAL);
+    launch_accum(cells(soln_prev.p), n, 1.0 / dtime, accum_prev.p, stream);
+  }
+  void op_spmv(const double *x, double *y) {
+    ProfScope ps(prof, KC_SPMV);
+    launch_spmv(opt.spmv_variant, n, d_rowptr.p, d_col.p, d_val.p, x, y, stream);
+  }
+  TriArgs tri_args() const {
+    return TriArgs{ncols, nz, d_tri_lo.p, d_diag.p, d_tri_up.p, d_val.p, tri_l.p, tri_invb.p, tri_c.p};
+  }
+  void op_pc_setup() {
+    if (pc_ready) return;
+    ProfScope ps(prof, KC_PC_SETUP);
+    if (opt.pc_type == 2) launch_tri_factor(tri_args(), stream);
+    else if (opt.pc_type == 3) launch_jacobi_setup(n, d_diag.p, d_val.p, jac_invd.p, stream);
+    pc_ready = true;
+  }
+  void op_pc_apply(const double *r, double *z) {
+    ProfScope ps(prof, KC_PC_APPLY);
+    if (opt.pc_type == 2) launch_tri_solve(tri_args(), r, z, stream);
+    else if (opt.pc_type == 3) launch_pointwise_mult(n, jac_invd.p, r, z, stream);
+    else launch_copy(n, r, z, stream);
+  }
+  void op_BA(const double *v, double *t) {  // t = M^{-1} A v  (left preconditioning)
+    op_spmv(v, Wk.p);
+    op_pc_apply(Wk.p, t);
+  }
+
+  // ---- reductions: deterministic two-stage sums, RCCL all-reduce across ranks, results on device and host ----
+  void dots_dev(std::initializer_list<std::pair<const double *, const double *>> pairs) {
+    ProfScope ps(prof, KC_REDUCE);
+    DotArgs a;
+    a.n = n; a.nvec = 0;
+    for (auto &p : pairs) { a.x[a.nvec] = p.first; a.y[a.nvec] = p.second; ++a.nvec; }
+    const int nbk = launch_dots(a, partials.p, stream);
+    launch_finalize_partials(nbk, a.nvec, partials.p, sc.p, stream);
+    if (comm.active()) comm.allreduce_sum(sc.p + S_SUM0, a.nvec, stream);
+  }
+  void fetch_scalars() {
+    HIP_CHECK(hipMemcpyAsync(h_sc, sc.p, S_COUNT * sizeof(double), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+  }
+  void dots_host(std::initializer_list<std::pair<const double *, const double *>> pairs, double *out) {
+    dots_dev(pairs);
+    fetch_scalars();
+    int j = 0;
+    for (auto it = pairs.begin(); it != pairs.end(); ++it, ++j) out[j] = h_sc[S_SUM0 + j];
+  }
+  double norm_host(const double *x) {
+    double s;
+    dots_host({{x, x}}, &s);
+    return std::sqrt(s);
+  }
+  void vec_copy(const double *x, double *y) { ProfScope ps(prof, KC_VEC); launch_copy(n, x, y, stream); }
+  void vec_set(double v, double *y) { ProfScope ps(prof, KC_VEC); launch_set(n, v, y, stream); }
+  void vec_waxpy(double *w, double a, const double *x, const double *y) {
+    ProfScope ps(prof, KC_VEC);
+    launch_waxpy(n, w, sc.p, -1, 1.0, a, x, y, stream);
+  }
+
+  // =====================================================================================
+  // Krylov solvers (PETSc v3.16.2 KSPSolve_BCGS / KSPSolve_GMRES restated), zero initial guess, left PC,
+  // preconditioned residual norm, KSPConvergedDefault.  reasons: 2 RTOL, 3 ATOL, 4 ITS; -3 ITS, -4 DTOL, -5 BREAKDOWN, -9 NAN
+  // =====================================================================================
+  struct KspConv { double rtol, atol, dtol, ttol = 0, rnorm0 = 0; };
+  static int ksp_converged(KspConv &c, int it, double rnorm) {
+    if (it == 0) { c.rnorm0 = rnorm; c.ttol = std::max(c.rtol * rnorm, c.atol); }
+    if (!(rnorm == rnorm) || std::isinf(rnorm)) return -9;
+    if (rnorm <= c.ttol) return rnorm < c.atol ? 3 : 2;
+    if (rnorm >= c.dtol * c.rnorm0) return -4;
+    return 0;
+  }
+
+  int ksp_bcgs(const double *b, double *x, int *its) {
+    KspConv cv{opt.ksp_rtol, opt.ksp_atol, opt.ksp_dtol};
+    vec_set(0.0, x);
+    op_pc_apply(b, R.p);
+    double dp = norm_host(R.p);
+    *its = 0;
+    int reason = ksp_converged(cv, 0, dp);
+    if (reason) return reason;
+    vec_copy(R.p, RP.p);
+    launch_bcgs_scalars(0, sc.p, stream);
+    vec_set(0.0, Pv.p);
+    vec_set(0.0, V.p);
+    int i = 0;
+    do {
+      dots_dev({{R.p, RP.p}});
+      launch_bcgs_scalars(1, sc.p, stream);
+      { ProfScope ps(prof, KC_VEC); launch_bcgs_p(n, Pv.p, R.p, V.p, sc.p, stream); }
+      op_BA(Pv.p, V.p);
+      dots_dev({{V.p, RP.p}});
+      launch_bcgs_scalars(2, sc.p, stream);
+      { ProfScope ps(prof, KC_VEC); launch_waxpy(n, S.p, sc.p, S_ALPHA, -1.0, 0.0, V.p, R.p, stream); }
+      op_BA(S.p, T.p);
+      dots_dev({{S.p, T.p}, {T.p, T.p}});
+      launch_bcgs_scalars(3, sc.p, stream);
+      {
+        ProfScope ps(prof, KC_REDUCE);
+        const int nbk = launch_bcgs_xr(n, x, R.p, Pv.p, S.p, T.p, sc.p, partials.p, stream);
+        launch_finalize_partials(nbk, 1, partials.p, sc.p, stream);
+        if (comm.active()) comm.allreduce_sum(sc.p + S_SUM0, 1, stream);
+      }
+      launch_bcgs_scalars(4, sc.p, stream);
+      fetch_scalars();
+      const double rho = h_sc[S_RHO], d1 = h_sc[S_D1];
+      if (d1 == 0.0) return -5;
+      if (h_sc[S_FLAG] != 0.0) {  // t == 0: x += alpha p was applied (omega forced to 0)
+        const double ss = std::sqrt(h_sc[S_SUM0]);  // r == s here
+        ++*its;
+        return ss != 0.0 ? -5 : 2;
+      }
+      dp = h_sc[S_DP];
+      ++*its;
+      reason = ksp_converged(cv, i + 1, dp);
+      if (reason) return reason;
+      if (rho == 0.0) return -5;
+      ++i;
+    } while (i < opt.ksp_max_it);
+    return -3;
+  }
+
+  int ksp_gmres(const double *b, double *x, int *its) {
+    const int m = opt.gmres_restart;
+    if ((int)vv.size() < m + 1) {
+      vv.resize(m + 1);
+      for (auto &v : vv) v.alloc(n);
+    }
+    KspConv cv{opt.ksp_rtol, opt.ksp_atol, opt.ksp_dtol};
+    std::vector<double> H((size_t)(m + 1) * m, 0.0), cs(m), sn(m), rs(m + 1), y(m), hh(m + 1);
+    vec_set(0.0, x);
+    *its = 0;
+    int reason = 0;
+    bool first = true;
+    while (!reason) {
+      if (first) op_pc_apply(b, vv[0].p);
+      else {
+        op_spmv(x, Wk.p);
+        vec_waxpy(Wk.p, -1.0, Wk.p, b);
+        op_pc_apply(Wk.p, vv[0].p);
+      }
+      double res = norm_host(vv[0].p);
+      reason = ksp_converged(cv, first ? 0 : *its, res);
+      first = false;
+      if (reason) break;
+      if (res == 0.0) { reason = 3; break; }
+      scale_host(vv[0].p, res);
+      rs[0] = res;
+      int it = 0;
+      while (it < m && *its < opt.ksp_max_it) {
+        double *vnew = vv[it + 1].p;
+        op_BA(vv[it].p, vnew);
+        {  // classical Gram-Schmidt: all dots, then one fused update
+          ProfScope ps(prof, KC_REDUCE);
+          DotArgs a;
+          a.n = n; a.nvec = it + 1;
+          for (int j = 0; j <= it; ++j) { a.x[j] = vnew; a.y[j] = vv[j].p; }
+          const int nbk = launch_dots(a, partials.p, stream);
+          launch_finalize_partials(nbk, a.nvec, partials.p, sc.p, stream);
+          if (comm.active()) comm.allreduce_sum(sc.p + S_SUM0, a.nvec, stream);
+        }
+        {
+          ProfScope ps(prof, KC_VEC);
+          MaxpyArgs ma;
+          ma.n = n; ma.nvec = it + 1;
+          for (int j = 0; j <= it; ++j) ma.v[j] = vv[j].p;
+          launch_maxpy_neg(ma, sc.p, vnew, stream);
+        }
+        fetch_scalars();
+        for (int j = 0; j <= it; ++j) hh[j] = h_sc[S_SUM0 + j];
+        const double tt = norm_host(vnew);
+        bool hapend = false;
+        if (tt == 0.0) hapend = true; else scale_host(vnew, tt);
+        double *hcol = H.data() + (size_t)it * (m + 1);
+        for (int j = 0; j <= it; ++j) hcol[j] = hh[j];
+        hcol[it + 1] = tt;
+        for (int j = 0; j < it; ++j) {
+          const double t1 = hcol[j], t2 = hcol[j + 1];
+          hcol[j] = cs[j] * t1 + sn[j] * t2;
+          hcol[j + 1] = -sn[j] * t1 + cs[j] * t2;
+        }
+        const double hyp = std::sqrt(hcol[it] * hcol[it] + hcol[it + 1] * hcol[it + 1]);
+        if (hyp == 0.0) { reason = -5; break; }
+        cs[it] = hcol[it] / hyp; sn[it] = hcol[it + 1] / hyp;
+        rs[it + 1] = -sn[it] * rs[it];
+        rs[it] = cs[it] * rs[it];
+        hcol[it] = cs[it] * hcol[it] + sn[it] * hcol[it + 1];
+        hcol[it + 1] = 0.0;
+        res = std::fabs(rs[it + 1]);
+        ++it; ++*its;
+        reason = ksp_converged(cv, *its, res);
+        if (reason || hapend) break;
+      }
+      for (int i = it - 1; i >= 0; --i) {
+        double s = rs[i];
+        for (int j = i + 1; j < it; ++j) s -= H[(size_t)j * (m + 1) + i] * y[j];
+        y[i] = s / H[(size_t)i * (m + 1) + i];
+      }
+      if (it > 0) {
+        ProfScope ps(prof, KC_VEC);
+        MaxpyValArgs ma;
+        ma.n = n; ma.nvec = it;
+        for (int j = 0; j < it; ++j) { ma.v[j] = vv[j].p; ma.c[j] = y[j]; }
+        launch_maxpy_val(ma, x, stream);
+      }
+      if (!reason && *its >= opt.ksp_max_it) reason = -3;
+    }
+    return reason;
+  }
+  void scale_host(double *x, double divisor) {  // x <- x / divisor
+    ProfScope ps(prof, KC_VEC);
+    HIP_CHECK(hipMemcpyAsync(sc.p + S_D2, &divisor, sizeof(double), hipMemcpyHostToDevice, stream));
+    launch_scale(n, x, sc.p, S_D2, stream);
+  }
+
+  int ksp_solve(const double *b, double *x, int *its) {
+    op_pc_setup();
+    switch (opt.ksp_type) {
+      case 0: op_pc_apply(b, x); *its = 1; return 4;
+      case 2: return ksp_bcgs(b, x, its);
+      default: return ksp_gmres(b, x, its);
+    }
+  }
+
+  // =====================================================================================
+  // SNES newtonls + bt line search (PETSc v3.16.2), then the reference's StepDT loop
+  // =====================================================================================
+  int snes_converged(int it, double xnorm, double snorm, double fnorm, double &ttol, double &rnorm0) const {
+    if (!it) { ttol = fnorm * opt.snes_rtol; rnorm0 = fnorm; }
+    if (fnorm != fnorm) return -4;
+    if (fnorm < opt.snes_atol) return 2;
+    if (nfuncs >= opt.snes_max_funcs) return -2;
+    if (it) {
+      if (fnorm <= ttol) return 3;
+      if (snorm < opt.snes_stol * xnorm) return 4;
+      if (opt.snes_divtol > 0 && fnorm > opt.snes_divtol * rnorm0) return -9;
+    }
+    return 0;
+  }
+
+  // X (= soln), F updated in place on success; returns 0 ok / 1 failed.  Same branch structure as the oracle.
+  int linesearch_bt(double *&X, double *&Fv, double *Yv, double *&Wv, double *&Gv, double &fnorm, double &xnorm,
+                    double &ynorm) {
+    const double alpha = 1e-4, maxstep = 1e8, minlambda = 1e-12;
+    const int max_its = 40;
+    double lambda = 1.0, lambdatemp, lambdaprev, gprev, g, gnorm = 0.0, wnorm2 = 0.0;
+    op_spmv(Yv, Wv);  // initslope = F . (J Y)
+    double r3[3];
+    dots_host({{Yv, Yv}, {X, X}, {Fv, Wv}}, r3);
+    ynorm = std::sqrt(r3[0]); xnorm = std::sqrt(r3[1]);
+    double initslope = r3[2];
+    if (ynorm == 0.0) return 1;
+    if (ynorm > maxstep) {
+      vec_waxpy(Yv, maxstep / ynorm - 1.0, Yv, Yv);  // Y *= maxstep/ynorm
+      initslope *= maxstep / ynorm;
+      ynorm = maxstep;
+    }
+    const double f = fnorm * fnorm;
+    if (initslope > 0.0) initslope = -initslope;
+    if (initslope == 0.0) initslope = -1.0;
+    auto eval = [&](double lam) {
+      vec_waxpy(Wv, -lam, Yv, X);
+      op_residual(Wv, Gv);
+      double r2[2];
+      dots_host({{Gv, Gv}, {Wv, Wv}}, r2);
+      gnorm = std::sqrt(r2[0]); wnorm2 = r2[1];
+      return gnorm * gnorm;
+    };
+    for (;;) {
+      if (nfuncs >= opt.snes_max_funcs) return 1;
+      g = eval(lambda);
+      if (std::isfinite(g)) break;
+      if (lambda <= minlambda) return 1;
+      lambda = .5 * lambda;
+    }
+    if (!(.5 * g <= .5 * f + lambda * alpha * initslope)) {
+      if (opt.snes_stol * xnorm > ynorm) return 0;  // tiny step, inadequate reduction: leave X, F untouched
+      lambdatemp = -initslope / (g - f - 2.0 * lambda * initslope);
+      lambdaprev = lambda; gprev = g;
+      if (lambdatemp > .5 * lambda) lambdatemp = .5 * lambda;
+      if (lambdatemp <= .1 * lambda) lambda = .1 * lambda; else lambda = lambdatemp;
+      if (nfuncs >= opt.snes_max_funcs) return 1;
+      g = eval(lambda);
+      if (!std::isfinite(g)) return 1;
+      if (!(.5 * g < .5 * f + lambda * alpha * initslope)) {
+        int count;
+        for (count = 0; count < max_its; ++count) {
+          if (lambda <= minlambda) return 1;
+          const double t1 = .5 * (g - f) - lambda * initslope, t2 = .5 * (gprev - f) - lambdaprev * initslope;
+          const double a = (t1 / (lambda * lambda) - t2 / (lambdaprev * lambdaprev)) / (lambda - lambdaprev);
+          const double b = (-lambdaprev * t1 / (lambda * lambda) + lambda * t2 / (lambdaprev * lambdaprev)) / (lambda - lambdaprev);
+          double d = b * b - 3 * a * initslope;
+          if (d < 0.0) d = 0.0;
+          if (a == 0.0) lambdatemp = -initslope / (2.0 * b); else lambdatemp = (-b + std::sqrt(d)) / (3.0 * a);
+          lambdaprev = lambda; gprev = g;
+          if (lambdatemp > .5 * lambda) lambdatemp = .5 * lambda;
+          if (lambdatemp <= .1 * lambda) lambda = .1 * lambda; else lambda = lambdatemp;
+          if (nfuncs >= opt.snes_max_funcs) return 1;
+          g = eval(lambda);
+          if (!std::isfinite(g)) return 1;
+          if (.5 * g < .5 * f + lambda * alpha * initslope) break;
+        }
+        if (count == max_its) return 1;
+      }
+    }
+    std::swap(X, Wv);   // X <- W, F <- G by pointer exchange (no copies)
+    std::swap(Fv, Gv);
+    xnorm = std::sqrt(wnorm2);
+    fnorm = gnorm;
+    return 0;
+  }
+
+  int snes_solve(int *newton_its, int *linear_its) {
+    // working pointers; `X` must end up in soln
+    double *X = soln.p, *Fv = F.p, *Wv = W.p, *Gv = G.p, *Yv = Y.p;
+    double ttol = 0, rnorm0 = 0, xnorm = 0, ynorm = 0;
+    nfuncs = 0;
+    *newton_its = 0; *linear_its = 0;
+    op_residual(X, Fv);
+    double fnorm = norm_host(Fv);
+    int reason = snes_converged(0, 0.0, 0.0, fnorm, ttol, rnorm0);
+    for (int i = 0; !reason && i < opt.snes_max_it; ++i) {
+      op_jacobian(X);
+      int its = 0;
+      const int kreason = ksp_solve(Fv, Yv, &its);
+      *linear_its += its;
+      if (kreason < 0) { reason = -3; break; }
+      const int lsfail = linesearch_bt(X, Fv, Yv, Wv, Gv, fnorm, xnorm, ynorm);
+      if (lsfail) {
+        reason = (opt.snes_stol * xnorm > ynorm) ? 4 : -6;
+        break;
+      }
+      *newton_its = i + 1;
+      reason = snes_converged(i + 1, xnorm, ynorm, fnorm, ttol, rnorm0);
+    }
+    if (!reason) reason = -5;
+    if (X != soln.p) {  // an odd number of pointer swaps: move the iterate back into soln
+      vec_copy(X, soln.p);
+    }
+    return reason;
+  }
+
+  void step_dt(double dt, int *converged, int *converged_reason) {
+    ensure_ready();
+    const int max_num_time_cuts = 20;
+    int num_time_cuts = 0;
+    const double target_time = dt;
+    double dt_iter = dt;
+    time = 0.0;
+    *converged = 0;
+    for (;;) {
+      dtime = dt_iter;
+      op_pre_solve();
+      int nit = 0, lit = 0;
+      int reason = snes_solve(&nit, &lit);
+      if (comm.active()) {  // every rank must take the same branch: worst reason wins
+        double r = -(double)reason;
+        HIP_CHECK(hipMemcpyAsync(sc.p + S_D2, &r, sizeof(double), hipMemcpyHostToDevice, stream));
+        comm.allreduce_max(sc.p + S_D2, 1, stream);
+        HIP_CHECK(hipMemcpyAsync(&r, sc.p + S_D2, sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        if (reason > 0 && r > 0) reason = -(int)r;
+      }
+      *converged_reason = reason;
+      if (reason < 0) {
+        ++num_time_cuts; ++cum_cuts;
+        dt_iter = 0.5 * dt_iter;
+        vec_copy(soln_prev.p, soln.p);
+      } else {
+        *converged = 1;
+        time += dt_iter;
+        cum_newton += nit; cum_linear += lit;
+        vec_copy(soln.p, soln_prev.p);  // VSFMSOEPostSolve (SystemOfEquationsVSFMType.F90:600)
+      }
+      if (num_time_cuts > max_num_time_cuts) { *converged = 0; break; }
+      if (time >= target_time) break;
+    }
+    HIP_CHECK(hipStreamSynchronize(stream));
+  }
+
+  // =====================================================================================
+  // host <-> device in the caller's ordering
+  // =====================================================================================
+  void put_cells(const double *host_ext, double *dev_int) {
+    if (identity_perm) {
+      HIP_CHECK(hipMemcpyAsync(dev_int, host_ext, (size_t)n * sizeof(double), hipMemcpyHostToDevice, stream));
+    } else {
+      HIP_CHECK(hipMemcpyAsync(tmp_ext.p, host_ext, (size_t)n * sizeof(double), hipMemcpyHostToDevice, stream));
+      launch_gather(n, d_int2ext.p, tmp_ext.p, dev_int, stream);
+    }
+    HIP_CHECK(hipStreamSynchronize(stream));  // the caller's buffer is free again on return
+  }
+  void get_cells(const double *dev_int, double *host_ext, int count) {
+    const double *src = dev_int;
+    if (!identity_perm) { launch_gather(n, d_ext2int.p, dev_int, tmp_ext.p, stream); src = tmp_ext.p; }
+    HIP_CHECK(hipMemcpyAsync(host_ext, src, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+  }
+
+  void set_data(int auxvar_type, int var_type, int cond_id, int cnt, const double *data) {
+    need_setup(true);
+    if (var_type != MPPGPU_VAR_BC_SS_CONDITION) throw Error("set_data: unknown var_type " + std::to_string(var_type));
+    if (auxvar_type == MPPGPU_AUXVAR_BC) {
+      if (cond_id < 1 || cond_id > (int)bcs.size()) throw Error("set_data: bad boundary condition id");
+      Condition &c = bcs[cond_id - 1];
+      if (cnt > c.n) throw Error("set_data: size(data_1d) > nauxvar");
+      for (int i = 0; i < cnt; ++i) { c.value[i] = data[i]; h_bc_value[bc_pos_of_g[c.offset + i]] = data[i]; }
+      d_bc_value.upload(h_bc_value, stream);
+      HIP_CHECK(hipStreamSynchronize(stream));
+    } else if (auxvar_type == MPPGPU_AUXVAR_SS) {
+      if (cond_id < 1 || cond_id > (int)sss.size()) throw Error("set_data: bad source-sink id");
+      Condition &c = sss[cond_id - 1];
+      if (cnt > c.n) throw Error("set_data: size(data_1d) > nauxvar");
+      for (int i = 0; i < cnt; ++i) c.value[i] = data[i];
+      // dense per-cell source [kmol/s]: sum over all mass-rate conditions of value/FMWH2O (GE:1896)
+      std::vector<double> src(n, 0.0);
+      for (auto &s : sss)
+        for (int i = 0; i < s.n; ++i)
+          if (active[s.cell[i]]) src[ext2int[s.cell[i]]] += s.value[i] / kFMWH2O;
+      d_src.upload(src, stream);
+      HIP_CHECK(hipStreamSynchronize(stream));
+    } else throw Error("set_data: unknown auxvar_type " + std::to_string(auxvar_type));
+  }
+
+  void get_data(int auxvar_type, int var_type, int cond_id, int cnt, double *out) {
+    ensure_ready();
+    if (auxvar_type == MPPGPU_AUXVAR_INTERNAL) {
+      if (cnt > n) throw Error("get_data: size(data_1d) > nauxvar");
+      if (var_type == MPPGPU_VAR_PRESSURE) { get_cells(soln.p, out, cnt); return; }
+      if (var_type != MPPGPU_VAR_LIQ_SAT && var_type != MPPGPU_VAR_MASS && var_type != MPPGPU_VAR_SOIL_MATRIX_POT)
+        throw Error("get_data: unknown var_type " + std::to_string(var_type));
+      launch_cell_var(cells(soln.p), n, var_type, tmp_int.p, stream);
+      get_cells(tmp_int.p, out, cnt);
+    } else if (auxvar_type == MPPGPU_AUXVAR_BC) {
+      if (cond_id < 1 || cond_id > (int)bcs.size()) throw Error("get_data: bad boundary condition id");
+      if (var_type != MPPGPU_VAR_MASS_FLUX) throw Error("get_data: unknown var_type");
+      Condition &c = bcs[cond_id - 1];
+      if (cnt > c.n) throw Error("get_data: size(data_1d) > nauxvar");
+      launch_bc(4, bc_args(soln.p, F.p), stream);
+      std::vector<double> fl(nb);
+      HIP_CHECK(hipMemcpyAsync(fl.data(), d_bc_flux.p, nb * sizeof(double), hipMemcpyDeviceToHost, stream));
+      HIP_CHECK(hipStreamSynchronize(stream));
+      for (int i = 0; i < cnt; ++i) out[i] = fl[bc_pos_of_g[c.offset + i]];
+    } else if (auxvar_type == MPPGPU_AUXVAR_SS) {
+      if (cond_id < 1 || cond_id > (int)sss.size()) throw Error("get_data: bad source-sink id");
+      if (var_type != MPPGPU_VAR_MASS_FLUX) throw Error("get_data: unknown var_type");
+      Condition &c = sss[cond_id - 1];
+      if (cnt > c.n) throw Error("get_data: size(data_1d) > nauxvar");
+      for (int i = 0; i < cnt; ++i) out[i] = c.value[i];  // ss_flux = cur_cond%value (GE:1898)
+    } else if (auxvar_type == MPPGPU_AUXVAR_CONN_INTERNAL) {
+      if (var_type != MPPGPU_VAR_MASS_FLUX) throw Error("get_data: unknown var_type");
+      if (cnt > nc) throw Error("get_data: size(data_1d) > nauxvar");
+      DevBuf<double> fl;
+      fl.alloc(nc_int);
+      launch_conn_flux(cells(soln.p), conns(), d_cup.p, d_cdn.p, nc_int, fl.p, stream);
+      std::vector<double> h(nc_int);
+      HIP_CHECK(hipMemcpyAsync(h.data(), fl.p, (size_t)nc_int * sizeof(double), hipMemcpyDeviceToHost, stream));
+      HIP_CHECK(hipStreamSynchronize(stream));
+      for (int i = 0; i < cnt; ++i) out[i] = h[cext2int[i]];
+    } else throw Error("get_data: unknown auxvar_type " + std::to_string(auxvar_type));
+  }
+
+  void set_option(const std::string &key, const std::string &val) {
+    auto num = [&]() { return std::atof(val.c_str()); };
+    if (key == "ksp_type") {
+      if (val == "preonly") opt.ksp_type = 0; else if (val == "gmres") opt.ksp_type = 1; else if (val == "bcgs") opt.ksp_type = 2;
+      else throw Error("unknown ksp_type '" + val + "'");
+    } else if (key == "pc_type") {
+      if (val == "none") opt.pc_type = 0; else if (val == "bjacobi") opt.pc_type = 2; else if (val == "jacobi") opt.pc_type = 3;
+      else throw Error("unknown pc_type '" + val + "' (GPU preconditioners: bjacobi, jacobi, none)");
+      pc_ready = false;
+    } else if (key == "ksp_rtol") opt.ksp_rtol = num();
+    else if (key == "ksp_atol") opt.ksp_atol = num();
+    else if (key == "ksp_max_it") opt.ksp_max_it = (int)num();
+    else if (key == "ksp_gmres_restart") { opt.gmres_restart = std::min((int)num(), kMaxMultiDot - 1); vv.clear(); }
+    else if (key == "snes_rtol") opt.snes_rtol = num();
+    else if (key == "snes_atol") opt.snes_atol = num();
+    else if (key == "snes_stol") opt.snes_stol = num();
+    else if (key == "snes_max_it") opt.snes_max_it = (int)num();
+    else if (key == "spmv_variant") opt.spmv_variant = (int)num();
+    else if (key == "assembly") {
+      if (val == "auto") opt.assembly = -1; else if (val == "general") opt.assembly = 0; else if (val == "columns") opt.assembly = 1;
+      else throw Error("unknown assembly '" + val + "'");
+    } else if (key == "nseg") opt.nseg = (int)num();
+    else if (key == "temperature") temperature = num();
+    else if (key == "profile") { prof.flush(); prof.enabled = num() != 0; }
+    else throw Error("unknown option '" + key + "'");
+  }
+
+  double algorithmic_bytes(int cls) const {
+    const double N = n, NNZ = nnz;
+    switch (cls) {
+      case KC_SPMV: return 12.0 * NNZ + 20.0 * N + 4.0;
+      case KC_PC_APPLY: return 40.0 * N;                   // 3 diagonals + rhs in, x out
+      case KC_PC_SETUP: return 8.0 * NNZ + 24.0 * N;
+      case KC_RESIDUAL: return 96.0 * N;                   // P, 5 soil arrays, accum_prev, 4 geometry arrays in; F out
+      case KC_JACOBIAN: return 84.0 * N + 8.0 * NNZ;       // same reads + rowptr, CSR values out
+      default: return 0.0;
+    }
+  }
+};
+
+}  // namespace mpp
+
+// ===========================================================================================
+// C ABI
+// ===========================================================================================
+using mpp::Solver;
+
+struct mppgpu_handle_s {
+  Solver s;
+};
+
+static thread_local std::string g_create_error;
+
+#define API_BEGIN(h)                    \
+  if (!(h)) return 1;                   \
+  Solver &S = (h)->s;                   \
+  try {                                 \
+    (void)hipSetDevice(S.device);
+#define API_END()                       \
+  }                                     \
+  catch (const std::exception &e) {     \
+    S.err = e.what();                   \
+    return 2;                           \
+  }                                     \
+  return 0;
+
+extern "C" {
+
+int mppgpu_create(int device_id, mppgpu_handle *out) {
+  if (!out) return 1;
+  *out = nullptr;
+  try {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+      throw mpp::Error(std::string("no usable HIP device (this library has no CPU path): ") + hipGetErrorString(e));
+    if (device_id < 0 || device_id >= count) throw mpp::Error("device_id out of range");
+    HIP_CHECK(hipSetDevice(device_id));
+    auto *h = new mppgpu_handle_s();
+    h->s.device = device_id;
+    HIP_CHECK(hipStreamCreateWithFlags(&h->s.stream, hipStreamNonBlocking));
+    h->s.prof.stream = h->s.stream;
+    *out = h;
+  } catch (const std::exception &e) {
+    g_create_error = e.what();
+    return 2;
+  }
+  return 0;
+}
+
+int mppgpu_destroy(mppgpu_handle h) {
+  if (!h) return 1;
+  (void)hipSetDevice(h->s.device);
+  if (h->s.stream) (void)hipStreamSynchronize(h->s.stream);
+  delete h;
+  return 0;
+}
+
+const char *mppgpu_last_error(mppgpu_handle h) { return h ? h->s.err.c_str() : g_create_error.c_str(); }
+
+int mppgpu_synchronize(mppgpu_handle h) {
+  API_BEGIN(h)
+  HIP_CHECK(hipStreamSynchronize(S.stream));
+  API_END()
+}
+
+int mppgpu_set_mesh(mppgpu_handle h, int ncells, int nlev, const double *vol, const int *is_active) {
+  API_BEGIN(h)
+  S.set_mesh(ncells, nlev, vol, is_active);
+  API_END()
+}
+int mppgpu_set_connections(mppgpu_handle h, int nconn, const int *id_up, const int *id_dn, const double *dist_up,
+                           const double *dist_dn, const double *area, const double *unit_vec) {
+  API_BEGIN(h)
+  S.set_connections(nconn, id_up, id_dn, dist_up, dist_dn, area, unit_vec);
+  API_END()
+}
+int mppgpu_add_condition(mppgpu_handle h, int kind, int cond_type, int nconn, const int *id_dn, const double *dist_up,
+                         const double *dist_dn, const double *area, const double *unit_vec, int swap_order,
+                         int *cond_id) {
+  API_BEGIN(h)
+  const int id = S.add_condition(kind, cond_type, nconn, id_dn, dist_up, dist_dn, area, unit_vec, swap_order);
+  if (cond_id) *cond_id = id;
+  API_END()
+}
+int mppgpu_set_soil_permeability(mppgpu_handle h, const double *px, const double *py, const double *pz) {
+  API_BEGIN(h)
+  S.set_perm(px, py, pz);
+  API_END()
+}
+int mppgpu_set_soil_porosity(mppgpu_handle h, const double *por) {
+  API_BEGIN(h)
+  S.set_por(por);
+  API_END()
+}
+int mppgpu_set_saturation_function(mppgpu_handle h, const int *satfunc_type, const double *alpha, const double *lambda,
+                                   const double *sat_res) {
+  API_BEGIN(h)
+  S.set_satfunc(satfunc_type, alpha, lambda, sat_res);
+  API_END()
+}
+int mppgpu_set_density_type(mppgpu_handle h, int density_type) {
+  API_BEGIN(h)
+  if (density_type < 1 || density_type > 3) throw mpp::Error("unknown density type");
+  S.density_type = density_type;
+  API_END()
+}
+int mppgpu_set_option(mppgpu_handle h, const char *key, const char *value) {
+  API_BEGIN(h)
+  S.set_option(key ? key : "", value ? value : "");
+  API_END()
+}
+int mppgpu_setup(mppgpu_handle h) {
+  API_BEGIN(h)
+  S.setup();
+  API_END()
+}
+int mppgpu_restart(mppgpu_handle h, int n, const double *pressure) {
+  API_BEGIN(h)
+  S.need_setup(true);
+  if (n != S.n) throw mpp::Error("restart: size(data_1d) /= ncells_local");
+  S.put_cells(pressure, S.soln.p);
+  S.vec_copy(S.soln.p, S.soln_prev.p);
+  HIP_CHECK(hipStreamSynchronize(S.stream));
+  API_END()
+}
+int mppgpu_set_data(mppgpu_handle h, int auxvar_type, int var_type, int cond_id, int n, const double *data) {
+  API_BEGIN(h)
+  S.set_data(auxvar_type, var_type, cond_id, n, data);
+  API_END()
+}
+int mppgpu_step_dt(mppgpu_handle h, double dt, int nstep, int *converged, int *converged_reason) {
+  (void)nstep;
+  API_BEGIN(h)
+  int c = 0, r = 0;
+  S.step_dt(dt, &c, &r);
+  if (converged) *converged = c;
+  if (converged_reason) *converged_reason = r;
+  API_END()
+}
+int mppgpu_get_data(mppgpu_handle h, int auxvar_type, int var_type, int cond_id, int n, double *data) {
+  API_BEGIN(h)
+  S.get_data(auxvar_type, var_type, cond_id, n, data);
+  API_END()
+}
+int mppgpu_get_counters(mppgpu_handle h, long long *newton_its, long long *linear_its, long long *time_cuts,
+                        long long *function_evals) {
+  API_BEGIN(h)
+  if (newton_its) *newton_its = S.cum_newton;
+  if (linear_its) *linear_its = S.cum_linear;
+  if (time_cuts) *time_cuts = S.cum_cuts;
+  if (function_evals) *function_evals = S.cum_funcs;
+  API_END()
+}
+
+int mppgpu_set_dtime(mppgpu_handle h, double dt) {
+  API_BEGIN(h)
+  if (!(dt > 0.0)) throw mpp::Error("dt must be positive");
+  S.dtime = dt;
+  API_END()
+}
+int mppgpu_pre_solve(mppgpu_handle h) {
+  API_BEGIN(h)
+  S.ensure_ready();
+  if (S.dtime <= 0.0) throw mpp::Error("time step not set");
+  S.op_pre_solve();
+  HIP_CHECK(hipStreamSynchronize(S.stream));
+  API_END()
+}
+int mppgpu_residual(mppgpu_handle h, const double *x, double *f) {
+  API_BEGIN(h)
+  S.ensure_ready();
+  S.put_cells(x, S.W.p);
+  S.op_residual(S.W.p, S.G.p);
+  S.get_cells(S.G.p, f, S.n);
+  API_END()
+}
+int mppgpu_jacobian_nnz(mppgpu_handle h, int *nnz) {
+  API_BEGIN(h)
+  S.need_setup(true);
+  if (nnz) *nnz = S.nnz;
+  API_END()
+}
+int mppgpu_jacobian(mppgpu_handle h, const double *x, int *rowptr, int *col, double *val) {
+  API_BEGIN(h)
+  S.ensure_ready();
+  S.put_cells(x, S.W.p);
+  S.op_jacobian(S.W.p);
+  std::vector<double> v(S.nnz);
+  HIP_CHECK(hipMemcpyAsync(v.data(), S.d_val.p, (size_t)S.nnz * sizeof(double), hipMemcpyDeviceToHost, S.stream));
+  HIP_CHECK(hipStreamSynchronize(S.stream));
+  // back to the caller's ordering, columns sorted
+  int pos = 0;
+  std::vector<std::pair<int, double>> row;
+  for (int e = 0; e < S.n; ++e) {
+    rowptr[e] = pos;
+    const int i = S.ext2int[e];
+    row.clear();
+    for (int k = S.h_rowptr[i]; k < S.h_rowptr[i + 1]; ++k) row.emplace_back(S.int2ext[S.h_col[k]], v[k]);
+    std::sort(row.begin(), row.end());
+    for (auto &p : row) { col[pos] = p.first; val[pos] = p.second; ++pos; }
+  }
+  rowptr[S.n] = pos;
+  API_END()
+}
+int mppgpu_spmv(mppgpu_handle h, const double *x, double *y) {
+  API_BEGIN(h)
+  S.ensure_ready();
+  S.put_cells(x, S.W.p);
+  S.op_spmv(S.W.p, S.G.p);
+  S.get_cells(S.G.p, y, S.n);
+  API_END()
+}
+int mppgpu_pc_apply(mppgpu_handle h, const double *r, double *z) {
+  API_BEGIN(h)
+  S.ensure_ready();
+  S.put_cells(r, S.W.p);
+  S.op_pc_setup();
+  S.op_pc_apply(S.W.p, S.G.p);
+  S.get_cells(S.G.p, z, S.n);
+  API_END()
+}
+int mppgpu_ksp_solve(mppgpu_handle h, const double *b, double *x, int *its, int *reason) {
+  API_BEGIN(h)
+  S.ensure_ready();
+  S.put_cells(b, S.G.p);
+  int it = 0;
+  const int r = S.ksp_solve(S.G.p, S.Y.p, &it);
+  S.get_cells(S.Y.p, x, S.n);
+  if (its) *its = it;
+  if (reason) *reason = r;
+  API_END()
+}
+
+int mppgpu_kernel_stats(mppgpu_handle h, const char *name, long long *launches, double *total_ms,
+                        double *algorithmic_bytes_per_launch) {
+  API_BEGIN(h)
+  S.prof.flush();
+  int cls = -1;
+  for (int k = 0; k < mpp::KC_COUNT; ++k)
+    if (name && std::strcmp(name, mpp::kclass_name(k)) == 0) cls = k;
+  if (cls < 0) throw mpp::Error(std::string("unknown kernel class '") + (name ? name : "") + "'");
+  if (launches) *launches = S.prof.launches[cls];
+  if (total_ms) *total_ms = S.prof.total_ms[cls];
+  if (algorithmic_bytes_per_launch) *algorithmic_bytes_per_launch = S.algorithmic_bytes(cls);
+  API_END()
+}
+int mppgpu_reset_stats(mppgpu_handle h) {
+  API_BEGIN(h)
+  S.prof.reset();
+  API_END()
+}
+
+int mppgpu_bench_kernel(mppgpu_handle h, const char *name, int variant, int reps, double *avg_ms,
+                        double *algorithmic_bytes) {
+  API_BEGIN(h)
+  S.ensure_ready();
+  if (reps < 1) reps = 1;
+  const std::string k = name ? name : "";
+  if (S.dtime <= 0.0) S.dtime = 3600.0;
+  hipEvent_t a, b;
+  HIP_CHECK(hipEventCreate(&a));
+  HIP_CHECK(hipEventCreate(&b));
+  int cls;
+  auto once = [&]() {
+    if (k == "spmv") { cls = mpp::KC_SPMV; mpp::launch_spmv(variant, S.n, S.d_rowptr.p, S.d_col.p, S.d_val.p, S.soln.p, S.G.p, S.stream); }
+    else if (k == "pc_apply") { cls = mpp::KC_PC_APPLY; S.op_pc_setup(); S.op_pc_apply(S.F.p, S.G.p); }
+    else if (k == "pc_setup") { cls = mpp::KC_PC_SETUP; S.pc_ready = false; S.op_pc_setup(); }
+    else if (k == "residual") { cls = mpp::KC_RESIDUAL; S.op_residual(S.soln.p, S.G.p); }
+    else if (k == "jacobian") { cls = mpp::KC_JACOBIAN; S.op_jacobian(S.soln.p); }
+    else if (k == "copy") { cls = mpp::KC_VEC; mpp::launch_copy(S.n, S.soln.p, S.G.p, S.stream); }
+    else if (k == "dot") { cls = mpp::KC_REDUCE; S.dots_dev({{S.soln.p, S.G.p}}); }
+    else throw mpp::Error("unknown kernel '" + k + "'");
+  };
+  const bool prof_was = S.prof.enabled;
+  S.prof.enabled = false;
+  const int saved_funcs = S.nfuncs;
+  const long long saved_cum = S.cum_funcs;
+  once();  // warm-up
+  HIP_CHECK(hipEventRecord(a, S.stream));
+  for (int r = 0; r < reps; ++r) once();
+  HIP_CHECK(hipEventRecord(b, S.stream));
+  HIP_CHECK(hipEventSynchronize(b));
+  float ms = 0.f;
+  HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  S.prof.enabled = prof_was;
+  S.nfuncs = saved_funcs; S.cum_funcs = saved_cum;
+  if (avg_ms) *avg_ms = ms / reps;
+  if (algorithmic_bytes) *algorithmic_bytes = (k == "copy") ? 16.0 * S.n : (k == "dot") ? 16.0 * S.n : S.algorithmic_bytes(cls);
+  API_END()
+}
+
+int mppgpu_comm_get_unique_id(void *id128) {
+  try {
+    mpp::Comm::get_unique_id(id128);
+  } catch (const std::exception &e) {
+    g_create_error = e.what();
+    return 2;
+  }
+  return 0;
+}
+int mppgpu_comm_init(mppgpu_handle h, int nranks, int rank, const void *id128) {
+  API_BEGIN(h)
+  S.comm.init(nranks, rank, id128);
+  API_END()
+}
+
+}  // extern "C"

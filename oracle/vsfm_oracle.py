@@ -42,6 +42,10 @@ def lib():
     global _lib
     if _lib is None:
         build()
+        # one thread by default: deterministic sums, and no spinning OpenMP team on boxes whose visible CPU
+        # count is far above their CPU share; callers that want a threaded baseline call set_num_threads().
+        os.environ.setdefault("OMP_NUM_THREADS", "1")
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
         L = ct.CDLL(_SO)
         L.vo_create.restype = ct.c_void_p
         L.vo_create.argtypes = [ct.c_int]
@@ -63,8 +67,13 @@ def lib():
         L.vo_richards_flux.argtypes = [_dp, _dp, _dp, _dp, ct.c_double, ct.c_double, ct.c_double, _dp, ct.c_int,
                                        ct.c_int, ct.c_int, _dp, _dp, _dp]
         L.vo_set_num_threads.argtypes = [ct.c_int]
+        L.vo_set_num_threads(1)
         _lib = L
     return _lib
+
+
+def set_num_threads(n: int):
+    lib().vo_set_num_threads(int(n))
 
 
 class OracleError(RuntimeError):

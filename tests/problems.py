@@ -166,3 +166,36 @@ def regression_stats(data, num_cells=5):
     cells = list(range(1, data.size + 1, inc))
     return dict(min=float(data.min()), max=float(data.max()), mean=float(data.sum() / data.size),
                 cells={c: float(data[c - 1]) for c in cells})
+
+
+def to_gpu(prob: Problem, options=None, device_id=0):
+    """Build the problem on the GPU through the reference-shaped host API (mpp_amd.vsfm), following the
+    call order of the reference drivers (vsfm_celia1990_problem.F90:106-137)."""
+    from mpp_amd import vsfm as V
+    mpp = V.MultiPhysicsProbVSFM(device_id)
+    mpp.Init()
+    mpp.SetName("Variably-Saturated-Flow-Model")
+    mpp.SetID(C.MPP_VSFM_SNES_CLM)
+    mpp.SetMPIRank(0)
+    mpp.SetNumMeshes(1)
+    mpp.AddMesh(1, prob.mesh)
+    mpp.AddGovEqn(C.GE_RE, "Richards Equation ODE", C.MESH_CLM_SOIL_COL)
+    mpp.SetMeshesOfGoveqns()
+    for cond_type, cs, _vals in prob.bcs:
+        mpp.soe.AddConditionInGovEqn(1, C.COND_BC, "bc", "Pa", cond_type, conn_set=cs)
+    for cond_type, cs, _vals in prob.sss:
+        mpp.soe.AddConditionInGovEqn(1, C.COND_SS, "ss", "kg/s", cond_type, conn_set=cs)
+    for k, v in (options or {}).items():
+        mpp.soe.SetOption(k, v)
+    mpp.AllocateAuxVars()
+    mpp.SetupProblem()
+    V.VSFMMPPSetSoilPermeability(mpp, 1, prob.perm[:, 0], prob.perm[:, 1], prob.perm[:, 2])
+    V.VSFMMPPSetSoilPorosity(mpp, 1, prob.por)
+    V.VSFMMPPSetSaturationFunction(mpp, 1, prob.satfunc_type, prob.alpha, prob.lam, prob.sat_res)
+    V.VSFMMPPSetDensityType(mpp, 1, prob.density_type)
+    for i, (_t, _cs, vals) in enumerate(prob.bcs):
+        mpp.soe.SetDataFromCLM(C.AUXVAR_BC, C.VAR_BC_SS_CONDITION, i + 1, vals)
+    for i, (_t, _cs, vals) in enumerate(prob.sss):
+        mpp.soe.SetDataFromCLM(C.AUXVAR_SS, C.VAR_BC_SS_CONDITION, i + 1, vals)
+    mpp.Restart(prob.press_ic)
+    return mpp

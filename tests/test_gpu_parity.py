@@ -1,0 +1,236 @@
+"""GPU parity tests proper: every call goes through the C ABI (libmppgpu.so) and is compared with the CPU
+oracle on the same seeded inputs, and with the reference's golden baselines.
+
+Tolerances (fp64): the HIP path evaluates the same expressions as the oracle, with the device `pow` (<= a few
+ulp from libm) and FMA contraction, so
+  * auxvar-level quantities, Jacobian entries, SpMV, preconditioner: <= 1e-12 relative to the row/vector scale;
+  * residual: <= 1e-11 of the size of the terms that cancel in it (accumulation + fluxes);
+  * end-to-end (24 Newton-solved steps): <= 1e-9 relative on pressure against the reference baseline.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import problems as P
+from conftest import parse_regression_file
+from mpp_amd import constants as C
+
+pytestmark = pytest.mark.gpu
+
+RTOL_OP = 1e-12
+RTOL_E2E = 1e-9
+
+
+def _hetero(ncols=37, nz=23, seed=0, **kw):
+    rng = np.random.default_rng(seed)
+    prob = P.celia1990(ncols=ncols, nz=nz, perm_mult=np.exp(0.5 * rng.standard_normal(ncols)))
+    n = prob.mesh.ncells_local
+    prob.por = prob.por * rng.uniform(0.8, 1.2, n)
+    prob.alpha = prob.alpha * rng.uniform(0.8, 1.2, n)
+    prob.sat_res = prob.sat_res * rng.uniform(0.8, 1.2, n)
+    prob.lam = np.clip(prob.lam * rng.uniform(0.8, 1.2, n), 0.05, 0.95)
+    for k, v in kw.items():
+        setattr(prob, k, v)
+    x = prob.press_ic + rng.uniform(0, 1.2e5, n)   # both sides of the saturation switch and of p0
+    return prob, x
+
+
+def _dense(rp, cj, val, n):
+    A = np.zeros((n, n))
+    for i in range(n):
+        A[i, cj[rp[i]:rp[i + 1]]] = val[rp[i]:rp[i + 1]]
+    return A
+
+
+def _operator_parity(prob, x, options):
+    o = P.to_oracle(prob)
+    g = P.to_gpu(prob, options)
+    o.set_dtime(prob.dt); o.pre_solve()
+    g.soe.SetDtime(prob.dt); g.soe.PreSolve()
+    n = x.size
+    f_o, f_g = o.residual(x), g.soe.ComputeResidual(x)
+    rp, cj, val = o.jacobian(x)
+    rp_g, cj_g, val_g = g.soe.ComputeJacobian(x)
+    assert np.array_equal(rp, rp_g) and np.array_equal(cj, cj_g)
+    rowscale = np.zeros(n)
+    np.maximum.at(rowscale, np.repeat(np.arange(n), np.diff(rp)), np.abs(val))
+    assert np.abs(val_g - val).max() <= RTOL_OP * np.abs(val).max()
+    assert (np.abs(val_g - val) <= 1e-10 * np.repeat(rowscale, np.diff(rp))).all()
+    # residual: compare against the size of the cancelling terms ~ |J| |x - x0| + |F|
+    fscale = np.abs(f_o) + rowscale * 1.0
+    assert (np.abs(f_g - f_o) <= 1e-11 * fscale + 1e-25).all(), np.abs(f_g - f_o).max()
+    v = np.random.default_rng(7).standard_normal(n)
+    from oracle import vsfm_oracle as VO
+    y_o, y_g = VO.spmv(rp, cj, val, v), g.soe.MatMult(v)
+    assert np.abs(y_g - y_o).max() <= RTOL_OP * np.abs(y_o).max()
+    return o, g, (rp, cj, val), v
+
+
+@pytest.mark.parametrize("assembly", ["columns", "general"])
+def test_operators_celia_extruded(assembly):
+    prob, x = _hetero()
+    o, g, (rp, cj, val), v = _operator_parity(prob, x, {"assembly": assembly, "pc_type": "bjacobi", "ksp_type": "bcgs"})
+    z_o = o.pc_apply(C.PC_BJACOBI, rp, cj, val, v)
+    z_g = g.soe.PCApply(v)
+    assert np.abs(z_g - z_o).max() <= 1e-10 * np.abs(z_o).max()
+    xs, its, reason = g.soe.KSPSolve(v)
+    exact = np.linalg.solve(_dense(rp, cj, val, v.size), v)
+    assert reason > 0 and its <= 2
+    assert np.abs(xs - exact).max() <= 1e-8 * np.abs(exact).max()
+    g.soe.SetOption("ksp_type", "gmres")
+    xs, its, reason = g.soe.KSPSolve(v)
+    assert reason > 0 and its <= 2
+    assert np.abs(xs - exact).max() <= 1e-8 * np.abs(exact).max()
+
+
+@pytest.mark.parametrize("nseg", [1, 3, 23])
+def test_column_segments_agree(nseg):
+    prob, x = _hetero(ncols=70, nz=23, seed=3)
+    _operator_parity(prob, x, {"assembly": "columns", "nseg": nseg})
+
+
+@pytest.mark.parametrize("sf,den", [(C.SAT_FUNC_BROOKS_COREY, C.DENSITY_CONSTANT),
+                                    (C.SAT_FUNC_SMOOTHED_BROOKS_COREY_BZ2, C.DENSITY_IFC67),
+                                    (C.SAT_FUNC_SMOOTHED_BROOKS_COREY_BZ3, C.DENSITY_TGDPB01)])
+def test_operators_other_constitutive_laws(sf, den):
+    prob, x = _hetero(ncols=9, nz=15, seed=5)
+    prob.satfunc_type = np.full(x.size, sf, dtype=np.int32)
+    prob.density_type = den
+    _operator_parity(prob, x, {})
+
+
+def test_operators_inactive_cells_seepage_and_sources():
+    prob, x = _hetero(ncols=6, nz=12, seed=11)
+    n = x.size
+    act = np.ones(n, dtype=np.int32)
+    act[[5, 17, 40]] = 0
+    prob.mesh.is_active = act
+    # top boundary as a seepage face, plus a mass-rate sink on every cell (ELM-style SOIL_CELLS source)
+    t, cs, vals = prob.bcs[0]
+    prob.bcs[0] = (C.COND_SEEPAGE_BC, cs, np.full(vals.size, 101325.0))
+    from mpp_amd import mesh as M
+    ids = np.arange(1, n + 1)
+    z = np.zeros(n)
+    ss = M.ConnectionSet(np.full(n, -1), ids, z, z, np.ones(n), np.zeros((n, 3)))
+    prob.sss = [(C.COND_MASS_RATE, ss, np.random.default_rng(1).uniform(-1e-6, 1e-6, n))]
+    _operator_parity(prob, x, {})
+    _operator_parity(prob, x, {"assembly": "general"})
+
+
+def test_operators_vchannel_7pt():
+    prob = P.vchannel(nx=6, ny=5, nz=7)
+    rng = np.random.default_rng(2)
+    x = prob.press_ic - rng.uniform(0, 2.5e5, prob.press_ic.size)
+    o, g, (rp, cj, val), v = _operator_parity(prob, x, {"ksp_type": "bcgs", "pc_type": "bjacobi", "ksp_rtol": 1e-12})
+    xs, its, reason = g.soe.KSPSolve(v)
+    exact = np.linalg.solve(_dense(rp, cj, val, v.size), v)
+    assert reason > 0
+    assert np.abs(xs - exact).max() <= 1e-7 * np.abs(exact).max()
+    g.soe.SetOption("ksp_type", "gmres")
+    xs, its, reason = g.soe.KSPSolve(v)
+    assert reason > 0
+    assert np.abs(xs - exact).max() <= 1e-7 * np.abs(exact).max()
+
+
+def _stats_close(stats, gold, rtol):
+    for key in ("min", "max", "mean"):
+        assert stats[key] == pytest.approx(gold[key], rel=rtol), key
+    for cell, v in stats["cells"].items():
+        assert v == pytest.approx(gold["cell %d" % cell], rel=rtol), cell
+
+
+@pytest.mark.parametrize("opts", [{"ksp_type": "bcgs", "pc_type": "bjacobi"}, {"ksp_type": "gmres", "pc_type": "bjacobi"},
+                                  {"ksp_type": "preonly", "pc_type": "bjacobi", "assembly": "general"}])
+def test_celia1990_baseline_end_to_end(golden_dir, opts):
+    """regression_tests/vsfm/vsfm_celia1990: 24 x 3600 s, compared with the reference's own golden output."""
+    gold = parse_regression_file(os.path.join(golden_dir, "vsfm_celia1990.regression.baseline"))
+    prob = P.celia1990()
+    g = P.to_gpu(prob, opts)
+    for s in range(prob.nstep):
+        g.soe.SetDataFromCLM(C.AUXVAR_BC, C.VAR_BC_SS_CONDITION, 1, prob.bcs[0][2])
+        g.soe.SetDataFromCLM(C.AUXVAR_BC, C.VAR_BC_SS_CONDITION, 2, prob.bcs[1][2])
+        conv, reason = g.soe.StepDT(prob.dt, s + 1)
+        assert conv and reason > 0
+    pr = g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1)
+    sat = g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_LIQ_SAT, -1)
+    _stats_close(P.regression_stats(pr), gold["liquid_pressure"], RTOL_E2E)
+    _stats_close(P.regression_stats(sat), gold["liquid_saturation"], RTOL_E2E)
+    # same Newton trajectory as the oracle (which reproduces the reference run digit for digit)
+    o = P.to_oracle(prob)
+    for s in range(prob.nstep):
+        o.step_dt(prob.dt, s + 1)
+    assert g.soe.counters()["newton"] == o.counters()["newton"]
+    np.testing.assert_allclose(pr, o.get(C.AUXVAR_INTERNAL, C.VAR_PRESSURE), rtol=RTOL_E2E)
+    for var in (C.VAR_MASS, C.VAR_SOIL_MATRIX_POT):
+        np.testing.assert_allclose(g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, var, -1), o.get(C.AUXVAR_INTERNAL, var),
+                                   rtol=1e-8)
+    for bc in (1, 2):
+        np.testing.assert_allclose(g.soe.GetDataForCLM(C.AUXVAR_BC, C.VAR_MASS_FLUX, bc),
+                                   o.get(C.AUXVAR_BC, C.VAR_MASS_FLUX, bc, 1), rtol=1e-6, atol=1e-18)
+    np.testing.assert_allclose(g.soe.GetDataForCLM(C.AUXVAR_CONN_INTERNAL, C.VAR_MASS_FLUX, -1),
+                               o.get(C.AUXVAR_CONN_INTERNAL, C.VAR_MASS_FLUX, -1, 99), rtol=1e-6, atol=1e-15)
+
+
+def test_vchannel_baseline_end_to_end(golden_dir):
+    """regression_tests/vsfm/vsfm_vchannel (7-pt, 3 x 8640 s).  The reference solved it with GMRES(30)+ILU(0);
+    here BiCGStab + per-column block-Jacobi to a tight linear tolerance, so agreement is to the nonlinear
+    tolerance only: 1e-6 relative on pressure (0.5 Pa), 1e-6 absolute on saturation."""
+    gold = parse_regression_file(os.path.join(golden_dir, "vsfm_vchannel.regression.baseline"))
+    prob = P.vchannel()
+    g = P.to_gpu(prob, {"ksp_type": "bcgs", "pc_type": "bjacobi", "ksp_rtol": 1e-9})
+    for s in range(prob.nstep):
+        conv, reason = g.soe.StepDT(prob.dt, s + 1)
+        assert conv and reason > 0
+    pr = g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1)
+    sat = g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_LIQ_SAT, -1)
+    _stats_close(P.regression_stats(pr), gold["liquid_pressure"], 1e-6)
+    st = P.regression_stats(sat)
+    for key in ("min", "max", "mean"):
+        assert abs(st[key] - gold["liquid_saturation"][key]) < 1e-6
+
+
+def test_celia_extruded_every_column_reproduces_the_baseline(golden_dir):
+    """on the celia-extruded grid every column must give the single-column golden answer
+    (ragged column count: not a multiple of the wave or block size)."""
+    gold = parse_regression_file(os.path.join(golden_dir, "vsfm_celia1990.regression.baseline"))
+    ncols = 333
+    prob = P.celia1990(ncols=ncols)
+    g = P.to_gpu(prob, {"ksp_type": "bcgs", "pc_type": "bjacobi"})
+    for s in range(prob.nstep):
+        conv, reason = g.soe.StepDT(prob.dt, s + 1)
+        assert conv and reason > 0
+    pr = g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1).reshape(ncols, -1)
+    for c in (0, 1, 63, 64, 255, 256, ncols - 1):
+        _stats_close(P.regression_stats(pr[c]), gold["liquid_pressure"], RTOL_E2E)
+    assert np.abs(pr - pr[0]).max() <= 1e-9 * np.abs(pr[0]).max()
+
+
+def test_time_step_cut_path():
+    """dt far too large for Newton: the driver must halve dt (SystemOfEquationsBaseType.F90:500-505) exactly as the oracle."""
+    prob = P.celia1990(ncols=2, nz=40)
+    opts = {"ksp_type": "preonly", "pc_type": "bjacobi", "snes_max_it": 6}
+    g = P.to_gpu(prob, opts)
+    o = P.to_oracle(prob)
+    o.set_solver(C.KSP_PREONLY, C.PC_BJACOBI, snes_max_it=6)
+    conv_g, reason_g = g.soe.StepDT(86400.0, 1)
+    conv_o, reason_o = o.step_dt(86400.0, 1)
+    assert (conv_g, reason_g) == (conv_o, reason_o)
+    cg, co = g.soe.counters(), o.counters()
+    assert cg["time_cuts"] == co["time_cuts"] > 0 and cg["newton"] == co["newton"]
+    np.testing.assert_allclose(g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1),
+                               o.get(C.AUXVAR_INTERNAL, C.VAR_PRESSURE), rtol=1e-8)
+
+
+def test_error_paths():
+    from mpp_amd import vsfm as V
+    prob = P.celia1990(ncols=1, nz=5)
+    g = P.to_gpu(prob)
+    with pytest.raises(V.MPPError):
+        g.soe.SetDataFromCLM(C.AUXVAR_BC, C.VAR_BC_SS_CONDITION, 3, np.zeros(1))   # no such condition
+    with pytest.raises(V.MPPError):
+        g.soe.SetDataFromCLM(C.AUXVAR_BC, C.VAR_BC_SS_CONDITION, 1, np.zeros(2))   # size(data_1d) > nauxvar
+    with pytest.raises(V.MPPError):
+        g.Restart(np.zeros(4))
+    with pytest.raises(V.MPPError):
+        g.soe.SetOption("pc_type", "ilu")
