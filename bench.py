@@ -97,7 +97,7 @@ def main():
     ap.add_argument("--nz", type=int, default=100)
     ap.add_argument("--ksp", default="bcgs")
     ap.add_argument("--pc", default="bjacobi")
-    ap.add_argument("--spmv-variant", type=int, default=0)
+    ap.add_argument("--spmv-variant", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cores", type=int, default=0)
     ap.add_argument("--homogeneous", action="store_true")

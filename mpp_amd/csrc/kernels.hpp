@@ -10,12 +10,13 @@ namespace mpp {
 
 // device-resident scalar block shared by the Krylov/Newton kernels (doubles)
 enum ScalarSlot : int {
-  S_RHO = 0, S_RHOOLD, S_ALPHA, S_OMEGA, S_OMEGAOLD, S_BETA, S_D1, S_D2, S_DP, S_FLAG,
+  S_RHO = 0, S_RHOOLD, S_ALPHA, S_OMEGA, S_OMEGAOLD, S_BETA, S_D1, S_D2, S_DP, S_FLAG, S_ST,
   S_SUM0 = 16,  // reduction results land in S_SUM0 .. S_SUM0+63
   S_COUNT = 96
 };
 
-constexpr int kMaxPartialBlocks = 2048;  // grid cap for reductions (guide: ~256 CUs x 8 blocks)
+constexpr int kRedPairs = 1024;          // 16-byte pairs per reduction block (small problems)
+constexpr int kMaxPartialBlocks = 4096;  // reduction grid cap = partial sums per vector
 constexpr int kMaxMultiDot = 32;
 
 // physical parameters every assembly kernel receives by value
@@ -25,6 +26,7 @@ struct CellArrays {
   const double *sbc_pu, *sbc_ps, *sbc_b2, *sbc_b3;   // smoothed Brooks-Corey only (else nullptr)
   const signed char *active;                         // nullptr = every cell active
   int sat_func;
+  int all_vg_half;                                   // every cell is van Genuchten with m == 1/2 (host-verified)
   double frac_liq;
   EosParams eos;
 };
@@ -36,7 +38,7 @@ struct ConnArrays {   // internal connections, precomputed geometry
 // ---- column-structured (vertical-only) fused assembly: one thread marches one soil column segment ----
 struct ColsArgs {
   CellArrays cell;
-  ConnArrays conn;       // vertical connection (k,c)->(k+1,c) stored at k*ncols+c
+  ConnArrays conn;       // vertical connection (k,c)->(k+1,c) stored at the index of cell (k,c)
   const double *accum_prev, *src;   // src: dense mass-rate source [kmol/s], nullptr if none
   double *F;             // residual out (MODE 0,2)
   double *val;           // CSR values out (MODE 1,2), level-major analytic layout
@@ -85,8 +87,10 @@ void launch_conn_flux(const CellArrays &cell, const ConnArrays &conn, const int 
 void launch_cell_var(const CellArrays &cell, int n, int var_type, double *out, hipStream_t stream);
 
 // ---- sparse linear algebra ----
-void launch_spmv(int variant, int n, const int *rowptr, const int *col, const double *val, const double *x, double *y,
-                 hipStream_t stream);
+// variants: 0 lane-per-row, 1 block CSR-stream, 2 wave CSR-stream, 3 lane-per-row unrolled, 4/5/6 batched wave
+// CSR-stream with 4/2/8 tiles per wave (needs max_row_nnz <= 8, else falls back to variant 0)
+void launch_spmv(int variant, int n, int max_row_nnz, const int *rowptr, const int *col, const double *val,
+                 const double *x, double *y, hipStream_t stream);
 // per-column tridiagonal (block-Jacobi): factor from CSR slots, then apply
 struct TriArgs {
   int ncols, nz;
@@ -108,10 +112,12 @@ void launch_pointwise_mult(int n, const double *a, const double *x, double *y, h
 void launch_waxpy(int n, double *w, const double *sc, int slot, double sign, double aval, const double *x,
                   const double *y, hipStream_t stream);
 // BiCGStab fused updates (PETSc bcgs.c order of operations)
-void launch_bcgs_p(int n, double *P, const double *R, const double *V, const double *sc, hipStream_t stream);
-// also leaves the partial sums of r.r in `partials`; returns the number of partial blocks
-int launch_bcgs_xr(int n, double *X, double *R, const double *P, const double *S, const double *T, const double *sc,
-                   double *partials, hipStream_t stream);
+void launch_bcgs_p(int n, double *P, const double *Pold, const double *R, const double *V, const double *sc,
+                   hipStream_t stream);
+// x <- alpha p + omega s + x (x not read when `first`: zero initial guess), r <- s - omega t; also leaves the
+// partial sums of r.r in `partials`; returns the number of partial blocks
+int launch_bcgs_xr(int n, bool first, double *X, double *R, const double *P, const double *S, const double *T,
+                   const double *sc, double *partials, hipStream_t stream);
 // multi-dot: sums[j] = x . ys[j], j < nvec; two-stage deterministic reduction (partials -> sc[S_SUM0+j])
 struct DotArgs { int n, nvec; const double *x[kMaxMultiDot]; const double *y[kMaxMultiDot]; };
 // stage 1 only (returns number of partial blocks); stage 2 is launch_finalize_partials

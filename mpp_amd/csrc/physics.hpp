@@ -21,7 +21,8 @@ constexpr double kFMWH2O = 18.01534;          // :202
 constexpr double kDenH2O = 1.0e3;             // mpp_varcon.F90:17
 constexpr double kViscosity = 8.904156e-4;    // EOSWaterMod.F90:582
 
-enum SatFunc : int { kSatVG = 0, kSatBC = 1, kSatSBC = 2 };
+enum SatFunc : int { kSatVG = 0, kSatBC = 1, kSatSBC = 2,
+                     kSatVGHalf = 3 /* compile-time specialisation only: van Genuchten with m == 1/2 in every cell */ };
 enum DenType : int { kDenConstant = 1, kDenTGDPB01 = 2, kDenIFC67 = 3 };
 enum CondType : int { kCondMassFlux = 504, kCondDirichlet = 505, kCondSeepage = 509 };
 
@@ -97,7 +98,14 @@ __host__ __device__ inline void density_ifc67(double t, double p, double &dwmol,
   dwp = cnv * vrpp * upc1;
 }
 
+// DEN_T: -1 decide at run time; 0 the density type is not IFC-67 (constant / TGDPB01); 1 it is IFC-67.
+// Compile-time pruning keeps the 60-register IFC-67 polynomial out of kernels that never need it.
+template <int DEN_T = -1>
 __host__ __device__ inline void density(const EosParams &e, double p, double &den, double &dden) {
+  if (DEN_T == 1) {
+    density_ifc67(e.t_C, p, den, dden);
+    return;
+  }
   if (e.density_type == kDenTGDPB01) {
     const double p0 = 101325.0;
     double kappa, dkappa_dp;
@@ -113,33 +121,43 @@ __host__ __device__ inline void density(const EosParams &e, double p, double &de
   } else if (e.density_type == kDenConstant) {
     den = kDenH2O / kFMWH2O;
     dden = 0.0;
-  } else {
+  } else if (DEN_T == -1) {
     density_ifc67(e.t_C, p, den, dden);
+  } else {
+    den = dden = 0.0;  // unreachable: DEN_T == 0 promises constant or TGDPB01
   }
 }
 
 // SatFunc_PressToSat + SatFunc_PressToRelPerm (Mualem) for one pressure; shares the common powers.
-template <bool DERIV>
-__host__ __device__ inline void sat_relperm(int sat_func, const Soil &s, double press, double frac_liq, double &sat,
+// SAT_T >= 0 fixes the saturation function at compile time (the run-time `sat_func_rt` is then ignored)
+template <bool DERIV, int SAT_T = -1>
+__host__ __device__ inline void sat_relperm(int sat_func_rt, const Soil &s, double press, double frac_liq, double &sat,
                                             double &dsat, double &kr, double &dkr) {
+  const int sat_func = SAT_T == kSatVGHalf ? (int)kSatVG : (SAT_T >= 0 ? SAT_T : sat_func_rt);
   const double pc = press - kPressureRef;
   const double sat_res = s.sat_res, alpha = s.alpha;
   if (sat_func == kSatVG) {
     if (pc < 0.0) {
       const double mm = s.m;
       const double nn = 1.0 / (1.0 - mm);  // SatFunc_Set_VG, SaturationFunction.F90:157
-      const double pc_alpha_n = pow(-alpha * pc, nn);
+      const double t = -alpha * pc;
+      // m == 1/2 (n == 2, the reference's celia/vchannel soil): every real power below is a square, a square
+      // root or their reciprocal -- exact or correctly rounded, so results stay within an ulp of pow()
+      const bool half = (SAT_T == kSatVGHalf) ? true : (mm == 0.5);
+      const double pc_alpha_n = half ? t * t : pow(t, nn);
       const double one_plus = 1.0 + pc_alpha_n;
-      const double Se = pow(one_plus, -mm);
+      const double Se = half ? 1.0 / sqrt(one_plus) : pow(one_plus, -mm);
       sat = sat_res + (1.0 - sat_res) * Se;
       const double AA = pc_alpha_n / one_plus;
-      const double AAm = pow(AA, mm);
+      const double AAm = half ? sqrt(AA) : pow(AA, mm);
       const double BB = 1.0 - AAm;
       kr = sqrt(Se) * BB * BB;
       if (DERIV) {
         const double dSe_dpc = -mm * nn * Se * AA / pc;
         dsat = (1.0 - sat_res) * dSe_dpc;
-        const double dkr_dSe = 0.5 * kr / Se + 2.0 * pow(Se, 1.0 / mm - 0.5) * pow(AA, mm - 1.0) * BB;
+        const double p1 = half ? Se * sqrt(Se) : pow(Se, 1.0 / mm - 0.5);
+        const double p2 = half ? 1.0 / AAm : pow(AA, mm - 1.0);
+        const double dkr_dSe = 0.5 * kr / Se + 2.0 * p1 * p2 * BB;
         dkr = dkr_dSe * dSe_dpc;
       }
     } else {
@@ -195,14 +213,14 @@ __host__ __device__ inline void sat_relperm(int sat_func, const Soil &s, double 
 }
 
 // RichODEPressureAuxVarCompute (RichardsODEPressureAuxType.F90:237-294)
-template <bool DERIV>
+template <bool DERIV, int SAT_T = -1, int DEN_T = -1>
 __host__ __device__ inline Aux auxvar_compute(int sat_func, const EosParams &e, const Soil &s, double press,
                                               double frac_liq) {
   Aux a;
   a.P = press;
   a.dsat = 0.0; a.dkr = 0.0;
-  sat_relperm<DERIV>(sat_func, s, press, frac_liq, a.sat, a.dsat, a.kr, a.dkr);
-  density(e, press, a.den, a.dden);
+  sat_relperm<DERIV, SAT_T>(sat_func, s, press, frac_liq, a.sat, a.dsat, a.kr, a.dkr);
+  density<DEN_T>(e, press, a.den, a.dden);
   return a;
 }
 
@@ -241,8 +259,8 @@ __host__ __device__ inline double richards_flux(const Aux &up, const Aux &dn, co
     double dphi_dn = -1.0 + dgrav_dn * dn.dden;
     if (seepage_update) dphi_dn = 0.0;
     // dvis_dP == 0 (EOSWaterMod.F90:583): the kr/(vis*vis)*dvis_dP term is an exact zero
-    const double dukvr_up = upwind_up ? (up.dkr / kViscosity - up.kr / (kViscosity * kViscosity) * 0.0) : 0.0;
-    const double dukvr_dn = upwind_up ? 0.0 : (dn.dkr / kViscosity - dn.kr / (kViscosity * kViscosity) * 0.0);
+    const double dukvr_up = upwind_up ? up.dkr / kViscosity : 0.0;
+    const double dukvr_dn = upwind_up ? 0.0 : dn.dkr / kViscosity;
     const double dq_up = g.Dq * (dukvr_up * dphi + ukvr * dphi_up) * g.area;
     const double dq_dn = g.Dq * (dukvr_dn * dphi + ukvr * dphi_dn) * g.area;
     if (massflux) {

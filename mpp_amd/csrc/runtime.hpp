@@ -107,9 +107,10 @@ struct Options {
   int ksp_max_it = 10000, gmres_restart = 30;
   double snes_rtol = 1e-8, snes_atol = 1e-50, snes_stol = 1e-10, snes_divtol = 1e4;  // stol: MultiPhysicsProbBaseType.F90:1112
   int snes_max_it = 50, snes_max_funcs = 10000;
-  int spmv_variant = 0;
+  int spmv_variant = -1;   // -1 auto: pipelined wave CSR-stream for large matrices, block CSR-stream for small ones
   int assembly = -1;       // -1 auto, 0 general kernels, 1 fused column kernels
   int nseg = 0;            // column segments per thread block row (0 = auto)
+  bool fused_assembly = true;  // F and J of the first line-search trial point in one kernel
 };
 
 struct Solver;  // all state behind a handle

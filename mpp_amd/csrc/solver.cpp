@@ -74,6 +74,7 @@ struct Solver {
   std::vector<double> permx, permy, permz, por, alpha, lam, sat_res;
   std::vector<int> satf;
   int sat_func = -1;
+  bool all_vg_half = false;
   int density_type = MPPGPU_DENSITY_CONSTANT;  // RichODEPressureAuxVarInit default (AuxType :120)
   double temperature = 273.15 + 25.0, frac_liq = 1.0;
   bool soil_dirty = true;
@@ -84,7 +85,7 @@ struct Solver {
   std::vector<int> ext2int, int2ext, cext2int;
   int nc_int = 0;
   std::vector<int> h_rowptr, h_col, h_diag;
-  int nnz = 0;
+  int nnz = 0, max_row_nnz = 0;
   int nb = 0, ns = 0;
   std::vector<int> bc_pos_of_g, h_bc_cell_int;
   int ncond_cells = 0;
@@ -203,12 +204,20 @@ struct Solver {
     if (map_sat_func(type[0]) < 0) throw Error("unsupported saturation function " + std::to_string(type[0]));
     satf.assign(type, type + n); alpha.assign(a, a + n); lam.assign(l, l + n); sat_res.assign(sr, sr + n);
     sat_func = map_sat_func(type[0]);
+    all_vg_half = (sat_func == kSatVG);
+    for (int i = 0; i < n && all_vg_half; ++i) all_vg_half = (l[i] == 0.5);
     soil_dirty = true;
   }
 
   // =====================================================================================
   // layout
   // =====================================================================================
+  // tiled level-major layout: columns in tiles of 64 (one wavefront); see the header of kernels.hip
+  int cell_index(int lev, int col) const {
+    const int t = col >> 6, tw = std::min(64, ncols - (t << 6));
+    return t * 64 * nz + lev * tw + (col & 63);
+  }
+
   void detect_columns() {
     // vertical chains of the internal connection set (any cell numbering)
     std::vector<int> nxt(n, -1), below(n, -1);
@@ -243,7 +252,7 @@ struct Solver {
           columns = true; ncols = nchains; nz = len;
           for (int i = 0; i < n; ++i) {
             if (lev[i] < 0) { columns = false; break; }
-            ext2int[i] = lev[i] * ncols + colof[i];
+            ext2int[i] = cell_index(lev[i], colof[i]);
           }
         }
       }
@@ -258,11 +267,10 @@ struct Solver {
     cext2int.assign(nc, -1);
     int nlat = 0;
     if (columns) {
-      const int nvert = (nz - 1) * ncols;
       for (int c = 0; c < nc; ++c) {
-        if (is_vert[c]) cext2int[c] = ext2int[cup_e[c]]; else cext2int[c] = nvert + nlat++;
+        if (is_vert[c]) cext2int[c] = ext2int[cup_e[c]]; else cext2int[c] = n + nlat++;
       }
-      nc_int = nvert + nlat;
+      nc_int = n + nlat;
       vertical_only = (nlat == 0);
     } else {
       for (int c = 0; c < nc; ++c) cext2int[c] = c;
@@ -301,7 +309,8 @@ struct Solver {
     nnz = (int)h_col.size();
     h_rowptr[n] = nnz;
     h_diag.resize(n);
-    for (int i = 0; i < n; ++i) h_diag[i] = find_slot(i, i);
+    max_row_nnz = 0;
+    for (int i = 0; i < n; ++i) { h_diag[i] = find_slot(i, i); max_row_nnz = std::max(max_row_nnz, h_rowptr[i + 1] - h_rowptr[i]); }
   }
 
   void setup() {
@@ -350,11 +359,12 @@ struct Solver {
     {
       std::vector<int> lo(n, -1), up(n, -1);
       if (columns) {
-        for (int i = 0; i < n; ++i) {
-          const int k = i / ncols;
-          if (k > 0) lo[i] = find_slot(i, i - ncols);
-          if (k < nz - 1) up[i] = find_slot(i, i + ncols);
-        }
+        for (int col = 0; col < ncols; ++col)
+          for (int k = 0; k < nz; ++k) {
+            const int i = cell_index(k, col);
+            if (k > 0) lo[i] = find_slot(i, cell_index(k - 1, col));
+            if (k < nz - 1) up[i] = find_slot(i, cell_index(k + 1, col));
+          }
       }
       d_tri_lo.upload(lo, stream); d_tri_up.upload(up, stream);
       tri_l.alloc(n); tri_invb.alloc(n); tri_c.alloc(n); jac_invd.alloc(n);
@@ -467,7 +477,7 @@ struct Solver {
     ca.P = P; ca.por = d_por.p; ca.sat_res = d_sat_res.p; ca.alpha = d_alpha.p; ca.m = d_m.p; ca.vol = d_vol.p;
     ca.sbc_pu = d_pu.p; ca.sbc_ps = d_ps.p; ca.sbc_b2 = d_b2.p; ca.sbc_b3 = d_b3.p;
     ca.active = any_inactive ? d_active.p : nullptr;
-    ca.sat_func = sat_func; ca.frac_liq = frac_liq;
+    ca.sat_func = sat_func; ca.all_vg_half = all_vg_half ? 1 : 0; ca.frac_liq = frac_liq;
     ca.eos = make_eos(density_type, temperature);
     return ca;
   }
@@ -522,6 +532,19 @@ struct Solver {
     launch_bc(0, bc_args(P, Fout), stream);
     ++nfuncs; ++cum_funcs;
   }
+  // residual and Jacobian of the same state in one pass: the auxvars (the expensive part) are evaluated once
+  void op_residual_jacobian(const double *P, double *Fout) {
+    if (dtime <= 0.0) throw Error("time step not set");
+    ProfScope ps(prof, KC_JACOBIAN);
+    if (use_cols()) launch_assemble_cols(2, cols_args(P, Fout), stream);
+    else {
+      if (!d_rc_ptr.p) throw Error("option assembly=general must be set before mppgpu_setup");
+      launch_assemble_general(2, gen_args(P, Fout), stream);
+    }
+    launch_bc(2, bc_args(P, Fout), stream);
+    ++nfuncs; ++cum_funcs;
+    pc_ready = false;
+  }
   void op_jacobian(const double *P) {
     if (dtime <= 0.0) throw Error("time step not set");
     ProfScope ps(prof, KC_JACOBIAN);
@@ -536,7 +559,13 @@ struct Solver {
   }
   void op_spmv(const double *x, double *y) {
     ProfScope ps(prof, KC_SPMV);
-    launch_spmv(opt.spmv_variant, n, d_rowptr.p, d_col.p, d_val.p, x, y, stream);
+    launch_spmv(spmv_variant(), n, max_row_nnz, d_rowptr.p, d_col.p, d_val.p, x, y, stream);
+  }
+  int spmv_variant() const {
+    if (opt.spmv_variant >= 0) return opt.spmv_variant;
+    // measured on MI355X (profiles/): the software-pipelined wave kernel wins once there are enough row tiles to
+    // fill the chip several times over; the block CSR-stream kernel wins on small, cache-resident matrices
+    return (max_row_nnz <= 8 && n >= (1 << 23)) ? 17 : 1;
   }
   TriArgs tri_args() const {
     return TriArgs{ncols, nz, d_tri_lo.p, d_diag.p, d_tri_up.p, d_val.p, tri_l.p, tri_invb.p, tri_c.p};
@@ -605,35 +634,40 @@ struct Solver {
   }
 
   int ksp_bcgs(const double *b, double *x, int *its) {
+    // First iteration specialised (same arithmetic, fewer passes over memory): with a zero initial guess
+    // r0 = rp = M^{-1} b, p0 = r0 (beta*p and omega*beta*v vanish) and rho0 = (r0,r0) is the squared norm
+    // already reduced for the convergence test, so r0 is written once into RP and aliased as R and P.
     KspConv cv{opt.ksp_rtol, opt.ksp_atol, opt.ksp_dtol};
-    vec_set(0.0, x);
-    op_pc_apply(b, R.p);
-    double dp = norm_host(R.p);
+    op_pc_apply(b, RP.p);
+    double dp = norm_host(RP.p);  // leaves (rp,rp) in sc[S_SUM0]
     *its = 0;
     int reason = ksp_converged(cv, 0, dp);
-    if (reason) return reason;
-    vec_copy(R.p, RP.p);
+    if (reason) { vec_set(0.0, x); return reason; }
     launch_bcgs_scalars(0, sc.p, stream);
-    vec_set(0.0, Pv.p);
-    vec_set(0.0, V.p);
+    const double *Rcur = RP.p, *Pcur = RP.p;
     int i = 0;
     do {
-      dots_dev({{R.p, RP.p}});
+      if (i > 0) dots_dev({{Rcur, RP.p}});
       launch_bcgs_scalars(1, sc.p, stream);
-      { ProfScope ps(prof, KC_VEC); launch_bcgs_p(n, Pv.p, R.p, V.p, sc.p, stream); }
-      op_BA(Pv.p, V.p);
+      if (i > 0) {
+        ProfScope ps(prof, KC_VEC);
+        launch_bcgs_p(n, Pv.p, Pcur, Rcur, V.p, sc.p, stream);
+        Pcur = Pv.p;
+      }
+      op_BA(Pcur, V.p);
       dots_dev({{V.p, RP.p}});
       launch_bcgs_scalars(2, sc.p, stream);
-      { ProfScope ps(prof, KC_VEC); launch_waxpy(n, S.p, sc.p, S_ALPHA, -1.0, 0.0, V.p, R.p, stream); }
+      { ProfScope ps(prof, KC_VEC); launch_waxpy(n, S.p, sc.p, S_ALPHA, -1.0, 0.0, V.p, Rcur, stream); }
       op_BA(S.p, T.p);
       dots_dev({{S.p, T.p}, {T.p, T.p}});
       launch_bcgs_scalars(3, sc.p, stream);
       {
         ProfScope ps(prof, KC_REDUCE);
-        const int nbk = launch_bcgs_xr(n, x, R.p, Pv.p, S.p, T.p, sc.p, partials.p, stream);
+        const int nbk = launch_bcgs_xr(n, i == 0, x, R.p, Pcur, S.p, T.p, sc.p, partials.p, stream);
         launch_finalize_partials(nbk, 1, partials.p, sc.p, stream);
         if (comm.active()) comm.allreduce_sum(sc.p + S_SUM0, 1, stream);
       }
+      Rcur = R.p;
       launch_bcgs_scalars(4, sc.p, stream);
       fetch_scalars();
       const double rho = h_sc[S_RHO], d1 = h_sc[S_D1];
@@ -773,7 +807,7 @@ struct Solver {
 
   // X (= soln), F updated in place on success; returns 0 ok / 1 failed.  Same branch structure as the oracle.
   int linesearch_bt(double *&X, double *&Fv, double *Yv, double *&Wv, double *&Gv, double &fnorm, double &xnorm,
-                    double &ynorm) {
+                    double &ynorm, bool &jac_valid) {
     const double alpha = 1e-4, maxstep = 1e8, minlambda = 1e-12;
     const int max_its = 40;
     double lambda = 1.0, lambdatemp, lambdaprev, gprev, g, gnorm = 0.0, wnorm2 = 0.0;
@@ -791,9 +825,15 @@ struct Solver {
     const double f = fnorm * fnorm;
     if (initslope > 0.0) initslope = -initslope;
     if (initslope == 0.0) initslope = -1.0;
+    // the first trial point is usually accepted: evaluate F and J there together; later (backtracking) trials
+    // evaluate F only.  J(X) is dead once initslope is known, so the trial may overwrite the matrix values.
+    bool first_trial = true, last_fused = false;
+    jac_valid = false;
     auto eval = [&](double lam) {
       vec_waxpy(Wv, -lam, Yv, X);
-      op_residual(Wv, Gv);
+      last_fused = first_trial && opt.fused_assembly;
+      first_trial = false;
+      if (last_fused) op_residual_jacobian(Wv, Gv); else op_residual(Wv, Gv);
       double r2[2];
       dots_host({{Gv, Gv}, {Wv, Wv}}, r2);
       gnorm = std::sqrt(r2[0]); wnorm2 = r2[1];
@@ -838,6 +878,7 @@ struct Solver {
     }
     std::swap(X, Wv);   // X <- W, F <- G by pointer exchange (no copies)
     std::swap(Fv, Gv);
+    jac_valid = last_fused;
     xnorm = std::sqrt(wnorm2);
     fnorm = gnorm;
     return 0;
@@ -849,16 +890,17 @@ struct Solver {
     double ttol = 0, rnorm0 = 0, xnorm = 0, ynorm = 0;
     nfuncs = 0;
     *newton_its = 0; *linear_its = 0;
-    op_residual(X, Fv);
+    bool jac_valid = false;
+    if (opt.fused_assembly) { op_residual_jacobian(X, Fv); jac_valid = true; } else op_residual(X, Fv);
     double fnorm = norm_host(Fv);
     int reason = snes_converged(0, 0.0, 0.0, fnorm, ttol, rnorm0);
     for (int i = 0; !reason && i < opt.snes_max_it; ++i) {
-      op_jacobian(X);
+      if (!jac_valid) op_jacobian(X);
       int its = 0;
       const int kreason = ksp_solve(Fv, Yv, &its);
       *linear_its += its;
       if (kreason < 0) { reason = -3; break; }
-      const int lsfail = linesearch_bt(X, Fv, Yv, Wv, Gv, fnorm, xnorm, ynorm);
+      const int lsfail = linesearch_bt(X, Fv, Yv, Wv, Gv, fnorm, xnorm, ynorm, jac_valid);
       if (lsfail) {
         reason = (opt.snes_stol * xnorm > ynorm) ? 4 : -6;
         break;
@@ -1298,11 +1340,15 @@ int mppgpu_bench_kernel(mppgpu_handle h, const char *name, int variant, int reps
   HIP_CHECK(hipEventCreate(&b));
   int cls;
   auto once = [&]() {
-    if (k == "spmv") { cls = mpp::KC_SPMV; mpp::launch_spmv(variant, S.n, S.d_rowptr.p, S.d_col.p, S.d_val.p, S.soln.p, S.G.p, S.stream); }
+    if (k == "spmv") { cls = mpp::KC_SPMV; mpp::launch_spmv(variant, S.n, S.max_row_nnz, S.d_rowptr.p, S.d_col.p, S.d_val.p, S.soln.p, S.G.p, S.stream); }
     else if (k == "pc_apply") { cls = mpp::KC_PC_APPLY; S.op_pc_setup(); S.op_pc_apply(S.F.p, S.G.p); }
     else if (k == "pc_setup") { cls = mpp::KC_PC_SETUP; S.pc_ready = false; S.op_pc_setup(); }
     else if (k == "residual") { cls = mpp::KC_RESIDUAL; S.op_residual(S.soln.p, S.G.p); }
     else if (k == "jacobian") { cls = mpp::KC_JACOBIAN; S.op_jacobian(S.soln.p); }
+    else if (k == "assemble_both") { cls = mpp::KC_JACOBIAN; S.op_residual_jacobian(S.soln.p, S.G.p); }
+    else if (k == "bcgs_xr") { cls = mpp::KC_VEC; mpp::launch_bcgs_xr(S.n, false, S.Y.p, S.R.p, S.Pv.p, S.S.p, S.T.p, S.sc.p, S.partials.p, S.stream); }
+    else if (k == "waxpy") { cls = mpp::KC_VEC; mpp::launch_waxpy(S.n, S.W.p, S.sc.p, -1, 1.0, 0.5, S.soln.p, S.G.p, S.stream); }
+    else if (k == "dots3") { cls = mpp::KC_REDUCE; S.dots_dev({{S.Y.p, S.Y.p}, {S.soln.p, S.soln.p}, {S.F.p, S.W.p}}); }
     else if (k == "copy") { cls = mpp::KC_VEC; mpp::launch_copy(S.n, S.soln.p, S.G.p, S.stream); }
     else if (k == "dot") { cls = mpp::KC_REDUCE; S.dots_dev({{S.soln.p, S.G.p}}); }
     else throw mpp::Error("unknown kernel '" + k + "'");
@@ -1323,7 +1369,11 @@ int mppgpu_bench_kernel(mppgpu_handle h, const char *name, int variant, int reps
   S.prof.enabled = prof_was;
   S.nfuncs = saved_funcs; S.cum_funcs = saved_cum;
   if (avg_ms) *avg_ms = ms / reps;
-  if (algorithmic_bytes) *algorithmic_bytes = (k == "copy") ? 16.0 * S.n : (k == "dot") ? 16.0 * S.n : S.algorithmic_bytes(cls);
+  if (algorithmic_bytes) {
+    const double N = S.n;
+    *algorithmic_bytes = (k == "copy" || k == "dot") ? 16.0 * N : (k == "waxpy") ? 24.0 * N : (k == "bcgs_xr") ? 48.0 * N
+                         : (k == "dots3") ? 32.0 * N : (k == "assemble_both") ? 92.0 * N + 8.0 * S.nnz : S.algorithmic_bytes(cls);
+  }
   API_END()
 }
 

@@ -133,6 +133,28 @@ def test_operators_vchannel_7pt():
     assert np.abs(xs - exact).max() <= 1e-7 * np.abs(exact).max()
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 13, 14, 17, 18])
+def test_spmv_variants(variant):
+    """every SpMV kernel variant sums each row in entry order (only FMA contraction differs between them):
+    3-point and 7-point patterns, ragged sizes (rows not a multiple of 64, last column tile narrower than 64)"""
+    from oracle import vsfm_oracle as VO
+    for prob, x in ((_hetero(ncols=150, nz=17, seed=4)), (P.vchannel(nx=9, ny=7, nz=11), None)):
+        if x is None:
+            x = prob.press_ic - np.random.default_rng(3).uniform(0, 2e5, prob.press_ic.size)
+        g0 = P.to_gpu(prob, {"spmv_variant": 0})
+        g = P.to_gpu(prob, {"spmv_variant": variant})
+        for h in (g0, g):
+            h.soe.SetDtime(prob.dt); h.soe.PreSolve()
+        rp, cj, val = g0.soe.ComputeJacobian(x)
+        g.soe.ComputeJacobian(x)
+        v = np.random.default_rng(8).standard_normal(x.size)
+        y0, y = g0.soe.MatMult(v), g.soe.MatMult(v)
+        y_o = VO.spmv(rp, cj, val, v)
+        rowscale = VO.spmv(rp, cj, np.abs(val), np.abs(v))
+        assert (np.abs(y - y_o) <= 4e-16 * rowscale).all()
+        assert (np.abs(y - y0) <= 4e-16 * rowscale).all()
+
+
 def _stats_close(stats, gold, rtol):
     for key in ("min", "max", "mean"):
         assert stats[key] == pytest.approx(gold[key], rel=rtol), key
