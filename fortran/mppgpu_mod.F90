@@ -1,0 +1,302 @@
+!> mppgpu_mod -- thin iso_c_binding shim over the C ABI of include/mppgpu.h.
+!!
+!! It keeps the reference's call shapes so that an MPP driver changes only its `use` lines:
+!!   soe%SetDataFromCLM / StepDT / GetDataForCLM   (src/mpp/soe/SystemOfEquationsVSFMType.F90:663-845,
+!!                                                  src/mpp/soe/SystemOfEquationsBaseType.F90:334-365)
+!!   goveqn%ComputeResidual / ComputeJacobian      (src/mpp/ge/GoveqnRichardsODEPressureType.F90:388-453)
+!!   VSFMMPPSetSoil* / Restart                     (src/mpp/mpp/MultiPhysicsProbVSFM.F90:603-707, 1115-1434)
+!! Arrays are default-kind integer / real(8), 1-based ids, exactly as the reference holds them.
+module mppgpu_mod
+  use, intrinsic :: iso_c_binding
+  implicit none
+  private
+
+  integer(c_int), parameter, public :: COND_BC = 501, COND_SS = 502, COND_MASS_RATE = 503, COND_MASS_FLUX = 504
+  integer(c_int), parameter, public :: COND_DIRICHLET = 505, COND_SEEPAGE_BC = 509
+  integer(c_int), parameter, public :: VAR_PRESSURE = 604, VAR_BC_SS_CONDITION = 607, VAR_LIQ_SAT = 608
+  integer(c_int), parameter, public :: VAR_MASS = 610, VAR_SOIL_MATRIX_POT = 611, VAR_MASS_FLUX = 644
+  integer(c_int), parameter, public :: AUXVAR_INTERNAL = 701, AUXVAR_BC = 702, AUXVAR_SS = 703, AUXVAR_CONN_INTERNAL = 704
+  integer(c_int), parameter, public :: SAT_FUNC_VAN_GENUCHTEN = 1301, SAT_FUNC_BROOKS_COREY = 1302
+  integer(c_int), parameter, public :: DENSITY_CONSTANT = 1, DENSITY_TGDPB01 = 2, DENSITY_IFC67 = 3
+
+  interface
+     integer(c_int) function mppgpu_create(device_id, h) bind(C, name='mppgpu_create')
+       import :: c_int, c_ptr
+       integer(c_int), value :: device_id
+       type(c_ptr) :: h
+     end function
+     integer(c_int) function mppgpu_destroy(h) bind(C, name='mppgpu_destroy')
+       import :: c_int, c_ptr
+       type(c_ptr), value :: h
+     end function
+     type(c_ptr) function mppgpu_last_error(h) bind(C, name='mppgpu_last_error')
+       import :: c_ptr
+       type(c_ptr), value :: h
+     end function
+     integer(c_int) function mppgpu_set_mesh(h, ncells, nlev, vol, is_active) bind(C, name='mppgpu_set_mesh')
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: h
+       integer(c_int), value :: ncells, nlev
+       real(c_double) :: vol(*)
+       integer(c_int) :: is_active(*)
+     end function
+     integer(c_int) function mppgpu_set_connections(h, nconn, id_up, id_dn, dist_up, dist_dn, area, unit_vec) &
+          bind(C, name='mppgpu_set_connections')
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: h
+       integer(c_int), value :: nconn
+       integer(c_int) :: id_up(*), id_dn(*)
+       real(c_double) :: dist_up(*), dist_dn(*), area(*), unit_vec(*)
+     end function
+     integer(c_int) function mppgpu_add_condition(h, kind, cond_type, nconn, id_dn, dist_up, dist_dn, area, unit_vec, &
+          swap_order, cond_id) bind(C, name='mppgpu_add_condition')
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: h
+       integer(c_int), value :: kind, cond_type, nconn, swap_order
+       integer(c_int) :: id_dn(*)
+       real(c_double) :: dist_up(*), dist_dn(*), area(*), unit_vec(*)
+       integer(c_int) :: cond_id
+     end function
+     integer(c_int) function mppgpu_set_soil_permeability(h, px, py, pz) bind(C, name='mppgpu_set_soil_permeability')
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: h
+       real(c_double) :: px(*), py(*), pz(*)
+     end function
+     integer(c_int) function mppgpu_set_soil_porosity(h, por) bind(C, name='mppgpu_set_soil_porosity')
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: h
+       real(c_double) :: por(*)
+     end function
+     integer(c_int) function mppgpu_set_saturation_function(h, satfunc_type, alpha, lambda, sat_res) &
+          bind(C, name='mppgpu_set_saturation_function')
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: h
+       integer(c_int) :: satfunc_type(*)
+       real(c_double) :: alpha(*), lambda(*), sat_res(*)
+     end function
+     integer(c_int) function mppgpu_set_density_type(h, density_type) bind(C, name='mppgpu_set_density_type')
+       import :: c_int, c_ptr
+       type(c_ptr), value :: h
+       integer(c_int), value :: density_type
+     end function
+     integer(c_int) function mppgpu_set_option(h, key, val) bind(C, name='mppgpu_set_option')
+       import :: c_int, c_ptr, c_char
+       type(c_ptr), value :: h
+       character(kind=c_char) :: key(*), val(*)
+     end function
+     integer(c_int) function mppgpu_setup(h) bind(C, name='mppgpu_setup')
+       import :: c_int, c_ptr
+       type(c_ptr), value :: h
+     end function
+     integer(c_int) function mppgpu_restart(h, n, pressure) bind(C, name='mppgpu_restart')
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: h
+       integer(c_int), value :: n
+       real(c_double) :: pressure(*)
+     end function
+     integer(c_int) function mppgpu_set_data(h, auxvar_type, var_type, cond_id, n, data) bind(C, name='mppgpu_set_data')
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: h
+       integer(c_int), value :: auxvar_type, var_type, cond_id, n
+       real(c_double) :: data(*)
+     end function
+     integer(c_int) function mppgpu_step_dt(h, dt, nstep, converged, converged_reason) bind(C, name='mppgpu_step_dt')
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: h
+       real(c_double), value :: dt
+       integer(c_int), value :: nstep
+       integer(c_int) :: converged, converged_reason
+     end function
+     integer(c_int) function mppgpu_get_data(h, auxvar_type, var_type, cond_id, n, data) bind(C, name='mppgpu_get_data')
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: h
+       integer(c_int), value :: auxvar_type, var_type, cond_id, n
+       real(c_double) :: data(*)
+     end function
+     integer(c_int) function mppgpu_get_counters(h, newton, linear, cuts, funcs) bind(C, name='mppgpu_get_counters')
+       import :: c_int, c_ptr, c_long_long
+       type(c_ptr), value :: h
+       integer(c_long_long) :: newton, linear, cuts, funcs
+     end function
+     integer(c_int) function mppgpu_set_dtime(h, dt) bind(C, name='mppgpu_set_dtime')
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: h
+       real(c_double), value :: dt
+     end function
+     integer(c_int) function mppgpu_pre_solve(h) bind(C, name='mppgpu_pre_solve')
+       import :: c_int, c_ptr
+       type(c_ptr), value :: h
+     end function
+     integer(c_int) function mppgpu_residual(h, x, f) bind(C, name='mppgpu_residual')
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: h
+       real(c_double) :: x(*), f(*)
+     end function
+     integer(c_int) function mppgpu_jacobian_nnz(h, nnz) bind(C, name='mppgpu_jacobian_nnz')
+       import :: c_int, c_ptr
+       type(c_ptr), value :: h
+       integer(c_int) :: nnz
+     end function
+     integer(c_int) function mppgpu_jacobian(h, x, rowptr, col, val) bind(C, name='mppgpu_jacobian')
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: h
+       real(c_double) :: x(*), val(*)
+       integer(c_int) :: rowptr(*), col(*)
+     end function
+  end interface
+
+  !> sysofeqns_vsfm_type stand-in: same method names as the reference's SoE
+  type, public :: sysofeqns_vsfm_gpu_type
+     type(c_ptr) :: h = c_null_ptr
+     integer     :: ncells = 0
+   contains
+     procedure :: Create, Destroy, SetMesh, SetConnections, AddConditionInGovEqn, SetOption, SetupProblem
+     procedure :: SetSoilPermeability, SetSoilPorosity, SetSaturationFunction, SetDensityType, Restart
+     procedure :: SetDataFromCLM, StepDT, GetDataForCLM, SetDtime, PreSolve, ComputeResidual, LastError
+  end type
+
+contains
+
+  function cstr(s) result(c)
+    character(len=*), intent(in) :: s
+    character(kind=c_char) :: c(len_trim(s) + 1)
+    integer :: i
+    do i = 1, len_trim(s)
+       c(i) = s(i:i)
+    end do
+    c(len_trim(s) + 1) = c_null_char
+  end function
+
+  subroutine Create(this, device_id, ierr)
+    class(sysofeqns_vsfm_gpu_type) :: this
+    integer, intent(in) :: device_id
+    integer, intent(out) :: ierr
+    ierr = mppgpu_create(int(device_id, c_int), this%h)
+  end subroutine
+  subroutine Destroy(this)
+    class(sysofeqns_vsfm_gpu_type) :: this
+    integer :: ierr
+    if (c_associated(this%h)) ierr = mppgpu_destroy(this%h)
+    this%h = c_null_ptr
+  end subroutine
+  function LastError(this) result(msg)
+    class(sysofeqns_vsfm_gpu_type) :: this
+    character(len=512) :: msg
+    character(kind=c_char), pointer :: p(:)
+    integer :: i
+    msg = ''
+    call c_f_pointer(mppgpu_last_error(this%h), p, [512])
+    do i = 1, 512
+       if (p(i) == c_null_char) exit
+       msg(i:i) = p(i)
+    end do
+  end function
+  subroutine SetMesh(this, ncells, nlev, vol, is_active, ierr)
+    class(sysofeqns_vsfm_gpu_type) :: this
+    integer, intent(in) :: ncells, nlev
+    real(8), intent(in) :: vol(:)
+    integer, intent(in) :: is_active(:)
+    integer, intent(out) :: ierr
+    this%ncells = ncells
+    ierr = mppgpu_set_mesh(this%h, ncells, nlev, vol, is_active)
+  end subroutine
+  subroutine SetConnections(this, nconn, id_up, id_dn, dist_up, dist_dn, area, unit_vec, ierr)
+    class(sysofeqns_vsfm_gpu_type) :: this
+    integer, intent(in) :: nconn, id_up(:), id_dn(:)
+    real(8), intent(in) :: dist_up(:), dist_dn(:), area(:), unit_vec(:)   ! unit_vec: 3*nconn, (x,y,z) per connection
+    integer, intent(out) :: ierr
+    ierr = mppgpu_set_connections(this%h, nconn, id_up, id_dn, dist_up, dist_dn, area, unit_vec)
+  end subroutine
+  subroutine AddConditionInGovEqn(this, ss_or_bc_type, cond_type, nconn, id_dn, dist_up, dist_dn, area, unit_vec, cond_id, ierr)
+    class(sysofeqns_vsfm_gpu_type) :: this
+    integer, intent(in) :: ss_or_bc_type, cond_type, nconn, id_dn(:)
+    real(8), intent(in) :: dist_up(:), dist_dn(:), area(:), unit_vec(:)
+    integer, intent(out) :: cond_id, ierr
+    ierr = mppgpu_add_condition(this%h, ss_or_bc_type, cond_type, nconn, id_dn, dist_up, dist_dn, area, unit_vec, 0, cond_id)
+  end subroutine
+  subroutine SetOption(this, key, val, ierr)
+    class(sysofeqns_vsfm_gpu_type) :: this
+    character(len=*), intent(in) :: key, val
+    integer, intent(out) :: ierr
+    ierr = mppgpu_set_option(this%h, cstr(key), cstr(val))
+  end subroutine
+  subroutine SetupProblem(this, ierr)
+    class(sysofeqns_vsfm_gpu_type) :: this
+    integer, intent(out) :: ierr
+    ierr = mppgpu_setup(this%h)
+  end subroutine
+  subroutine SetSoilPermeability(this, perm_x, perm_y, perm_z, ierr)
+    class(sysofeqns_vsfm_gpu_type) :: this
+    real(8), intent(in) :: perm_x(:), perm_y(:), perm_z(:)
+    integer, intent(out) :: ierr
+    ierr = mppgpu_set_soil_permeability(this%h, perm_x, perm_y, perm_z)
+  end subroutine
+  subroutine SetSoilPorosity(this, por, ierr)
+    class(sysofeqns_vsfm_gpu_type) :: this
+    real(8), intent(in) :: por(:)
+    integer, intent(out) :: ierr
+    ierr = mppgpu_set_soil_porosity(this%h, por)
+  end subroutine
+  subroutine SetSaturationFunction(this, satfunc_type, alpha, lambda, sat_res, ierr)
+    class(sysofeqns_vsfm_gpu_type) :: this
+    integer, intent(in) :: satfunc_type(:)
+    real(8), intent(in) :: alpha(:), lambda(:), sat_res(:)
+    integer, intent(out) :: ierr
+    ierr = mppgpu_set_saturation_function(this%h, satfunc_type, alpha, lambda, sat_res)
+  end subroutine
+  subroutine SetDensityType(this, density_type, ierr)
+    class(sysofeqns_vsfm_gpu_type) :: this
+    integer, intent(in) :: density_type
+    integer, intent(out) :: ierr
+    ierr = mppgpu_set_density_type(this%h, density_type)
+  end subroutine
+  subroutine Restart(this, data_1d, ierr)
+    class(sysofeqns_vsfm_gpu_type) :: this
+    real(8), intent(in) :: data_1d(:)
+    integer, intent(out) :: ierr
+    ierr = mppgpu_restart(this%h, size(data_1d), data_1d)
+  end subroutine
+  subroutine SetDataFromCLM(this, soe_auxvar_type, var_type, soe_auxvar_id, data_1d, ierr)
+    class(sysofeqns_vsfm_gpu_type) :: this
+    integer, intent(in) :: soe_auxvar_type, var_type, soe_auxvar_id
+    real(8), intent(in) :: data_1d(:)
+    integer, intent(out) :: ierr
+    ierr = mppgpu_set_data(this%h, soe_auxvar_type, var_type, soe_auxvar_id, size(data_1d), data_1d)
+  end subroutine
+  subroutine StepDT(this, dt, nstep, converged, converged_reason, ierr)
+    class(sysofeqns_vsfm_gpu_type) :: this
+    real(8), intent(in) :: dt
+    integer, intent(in) :: nstep
+    logical, intent(out) :: converged
+    integer, intent(out) :: converged_reason, ierr
+    integer(c_int) :: c
+    ierr = mppgpu_step_dt(this%h, dt, nstep, c, converged_reason)
+    converged = (c /= 0)
+  end subroutine
+  subroutine GetDataForCLM(this, soe_auxvar_type, var_type, soe_auxvar_id, data_1d, ierr)
+    class(sysofeqns_vsfm_gpu_type) :: this
+    integer, intent(in) :: soe_auxvar_type, var_type, soe_auxvar_id
+    real(8), intent(inout) :: data_1d(:)
+    integer, intent(out) :: ierr
+    ierr = mppgpu_get_data(this%h, soe_auxvar_type, var_type, soe_auxvar_id, size(data_1d), data_1d)
+  end subroutine
+  subroutine SetDtime(this, dt, ierr)
+    class(sysofeqns_vsfm_gpu_type) :: this
+    real(8), intent(in) :: dt
+    integer, intent(out) :: ierr
+    ierr = mppgpu_set_dtime(this%h, dt)
+  end subroutine
+  subroutine PreSolve(this, ierr)
+    class(sysofeqns_vsfm_gpu_type) :: this
+    integer, intent(out) :: ierr
+    ierr = mppgpu_pre_solve(this%h)
+  end subroutine
+  subroutine ComputeResidual(this, X, F, ierr)
+    class(sysofeqns_vsfm_gpu_type) :: this
+    real(8), intent(in) :: X(:)
+    real(8), intent(inout) :: F(:)
+    integer, intent(out) :: ierr
+    ierr = mppgpu_residual(this%h, X, F)
+  end subroutine
+
+end module mppgpu_mod
