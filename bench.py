@@ -11,7 +11,8 @@ block-Jacobi, ksp_rtol 1e-5, Newton rtol 1e-8 / stol 1e-10.  One "step" = one so
 
 N > 1: launched by torch.distributed.run, one rank per GPU; the columns are sharded across ranks (strong
 scaling: the global grid is fixed) and the only inter-GPU traffic is the RCCL all-reduce of the Newton/Krylov
-norms and dot products inside libmppgpu.so.  Host coordination (barrier, max-over-ranks) uses gloo.
+norms and dot products inside libmppgpu.so.  Host coordination (unique-id broadcast, barrier, max-over-ranks) is a
+small TCP group built from the RANK / WORLD_SIZE / MASTER_* variables the launcher exports.
 
 Prints ONE JSON line (rank 0).
 """
@@ -117,14 +118,13 @@ def main():
     from mpp_amd import vsfm as V
     import problems as P
 
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist_
-        dist = dist_
-        dist.init_process_group("gloo")
-
+    # Launched by torch.distributed.run: host-side rendezvous over plain TCP (mpp_amd.parallel.HostGroup) from the
+    # RANK / WORLD_SIZE / MASTER_* variables it exports.  torch itself is not imported: a rank process then loads
+    # exactly one ROCm runtime and one RCCL (those of the ROCm installation), the configuration the GPU tests run.
     from mpp_amd import parallel as PAR
+    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ
+    group = PAR.HostGroup() if launched else PAR.HostGroup(rank=0, world=1)
+
     ncols_global = args.nx * args.ny
     col0, ncols_local = PAR.shard_columns(ncols_global, world, rank)
     t_setup = time.perf_counter()
@@ -132,14 +132,24 @@ def main():
     opts = {"ksp_type": args.ksp, "pc_type": args.pc, "spmv_variant": args.spmv_variant}
     mpp = P.to_gpu(prob, opts, device_id=local_rank)
     soe = mpp.soe
-    if world > 1:
-        soe.comm_init(world, rank, PAR.broadcast_unique_id(dist, rank, V.comm_get_unique_id))
+    if launched:
+        # RCCL prints a version banner on stdout at communicator creation: keep stdout for the ONE JSON line
+        import ctypes
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            uid = group.broadcast_bytes(V.comm_get_unique_id() if rank == 0 else b"")
+            soe.comm_init(world, rank, uid)
+            ctypes.CDLL(None).fflush(None)
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
     t_setup = time.perf_counter() - t_setup
 
     def barrier():
         soe.synchronize()
-        if dist is not None:
-            dist.barrier()
+        group.barrier()
 
     def step(i):
         for b, (_t, _cs, vals) in enumerate(prob.bcs):
@@ -159,7 +169,7 @@ def main():
         step(args.warmup + i)
     barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = PAR.max_over_ranks(dist, elapsed)
+    elapsed = group.allreduce([elapsed], op="max")[0]
     c1 = soe.counters()
     newton = c1["newton"] - c0["newton"]
     linear = c1["linear"] - c0["linear"]
@@ -216,9 +226,8 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "Newton iters/s", "cores": cores, "kind": "port",
                                        "sample": "failed: %r" % (e,)}
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    group.barrier()
+    group.close()
 
 
 if __name__ == "__main__":

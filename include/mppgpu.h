@@ -94,7 +94,8 @@ int mppgpu_set_density_type(mppgpu_handle h, int density_type);
 
 /* solver selection: the PETSc options database the reference reads through SNESSetFromOptions
  * (src/mpp/mpp/MultiPhysicsProbBaseType.F90:1205).  Keys: "ksp_type" (bcgs|gmres|preonly),
- * "pc_type" (bjacobi|jacobi|none), "ksp_rtol", "ksp_max_it", "snes_rtol", "snes_atol", "snes_stol",
+ * "pc_type" (bjacobi|ilu|jacobi|none; ilu = PETSc's default ILU(0), available on vertical-only grids where it
+ * coincides with the exact per-column LU), "ksp_rtol", "ksp_max_it", "snes_rtol", "snes_atol", "snes_stol",
  * "snes_max_it", "profile" (0|1: HIP-event timing of every kernel class). */
 int mppgpu_set_option(mppgpu_handle h, const char *key, const char *value);
 

@@ -103,6 +103,7 @@ struct Condition {
 struct Options {
   int ksp_type = 1;        // 0 preonly, 1 gmres, 2 bcgs       (PETSc default: gmres)
   int pc_type = 2;         // 0 none, 2 bjacobi (per soil column), 3 jacobi
+  bool pc_is_ilu = false;  // "ilu" requested: served by the column solver on vertical-only grids
   double ksp_rtol = 1e-5, ksp_atol = 1e-50, ksp_dtol = 1e4;
   int ksp_max_it = 10000, gmres_restart = 30;
   double snes_rtol = 1e-8, snes_atol = 1e-50, snes_stol = 1e-10, snes_divtol = 1e4;  // stol: MultiPhysicsProbBaseType.F90:1112

@@ -413,6 +413,7 @@ struct Solver {
     HIP_CHECK(hipStreamSynchronize(stream));
     setup_done = true;
     soil_dirty = true;
+    check_ilu();
   }
 
   // soil parameters + connection geometry -> device (lazy: the reference sets soils after SetupProblem)
@@ -1035,6 +1036,15 @@ struct Solver {
     } else throw Error("get_data: unknown auxvar_type " + std::to_string(auxvar_type));
   }
 
+  // PETSc's default PC is ILU(0).  On a grid whose connections are all vertical the matrix is block diagonal with
+  // one tridiagonal block per soil column; ILU(0) in that ordering has no fill to drop, i.e. it IS the exact
+  // per-column LU that the block-Jacobi kernels compute.  General (7-point) ILU(0) needs a level-scheduled
+  // triangular solve that is not built yet.
+  void check_ilu() const {
+    if (opt.pc_is_ilu && !vertical_only)
+      throw Error("pc_type ilu is available on vertical-only grids only (use bjacobi for meshes with lateral connections)");
+  }
+
   void set_option(const std::string &key, const std::string &val) {
     auto num = [&]() { return std::atof(val.c_str()); };
     if (key == "ksp_type") {
@@ -1042,7 +1052,9 @@ struct Solver {
       else throw Error("unknown ksp_type '" + val + "'");
     } else if (key == "pc_type") {
       if (val == "none") opt.pc_type = 0; else if (val == "bjacobi") opt.pc_type = 2; else if (val == "jacobi") opt.pc_type = 3;
-      else throw Error("unknown pc_type '" + val + "' (GPU preconditioners: bjacobi, jacobi, none)");
+      else if (val == "ilu") { opt.pc_type = 2; opt.pc_is_ilu = true; if (setup_done) check_ilu(); }
+      else throw Error("unknown pc_type '" + val + "' (GPU preconditioners: bjacobi, ilu [vertical-only grids], jacobi, none)");
+      if (val != "ilu") opt.pc_is_ilu = false;
       pc_ready = false;
     } else if (key == "ksp_rtol") opt.ksp_rtol = num();
     else if (key == "ksp_atol") opt.ksp_atol = num();

@@ -162,7 +162,7 @@ def _stats_close(stats, gold, rtol):
         assert v == pytest.approx(gold["cell %d" % cell], rel=rtol), cell
 
 
-@pytest.mark.parametrize("opts", [{"ksp_type": "bcgs", "pc_type": "bjacobi"}, {"ksp_type": "gmres", "pc_type": "bjacobi"},
+@pytest.mark.parametrize("opts", [{"ksp_type": "bcgs", "pc_type": "bjacobi"}, {"ksp_type": "gmres", "pc_type": "ilu"},
                                   {"ksp_type": "preonly", "pc_type": "bjacobi", "assembly": "general"}])
 def test_celia1990_baseline_end_to_end(golden_dir, opts):
     """regression_tests/vsfm/vsfm_celia1990: 24 x 3600 s, compared with the reference's own golden output."""
@@ -255,4 +255,7 @@ def test_error_paths():
     with pytest.raises(V.MPPError):
         g.Restart(np.zeros(4))
     with pytest.raises(V.MPPError):
-        g.soe.SetOption("pc_type", "ilu")
+        g.soe.SetOption("pc_type", "sor")
+    g.soe.SetOption("pc_type", "ilu")          # vertical-only grid: ILU(0) == exact column LU
+    with pytest.raises(V.MPPError):
+        P.to_gpu(P.vchannel(nx=3, ny=3, nz=4), {"pc_type": "ilu"})   # lateral connections: not available yet

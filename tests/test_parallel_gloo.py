@@ -82,3 +82,42 @@ def test_two_rank_gloo_host_logic():
             oo.set_solver(C.KSP_GMRES, C.PC_ILU0, snes_rtol=1e-13, snes_stol=1e-15)
             oo.step_dt(one.dt, 1)
             np.testing.assert_allclose(pr[j * 20:(j + 1) * 20], oo.get(C.AUXVAR_INTERNAL, C.VAR_PRESSURE), rtol=1e-8)
+
+
+def _hg_worker(rank, world, port, q):
+    g = PAR.HostGroup(rank=rank, world=world, addr="127.0.0.1", port=port, timeout=60.0)
+    uid = g.broadcast_bytes(bytes(range(128)) if rank == 0 else b"")
+    g.barrier()
+    mx = g.allreduce([1.0 + rank, -rank], op="max")
+    sm = g.allreduce([10.0 * (rank + 1)], op="sum")
+    g.barrier()
+    g.close()
+    q.put((rank, uid, mx, sm))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_tcp_host_group(world):
+    """the rendezvous bench.py uses under torch.distributed.run (no torch in the rank processes)"""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_hg_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r, uid, mx, sm in res:
+        assert uid == bytes(range(128))
+        assert mx == [float(world), 0.0]
+        assert sm == [10.0 * world * (world + 1) / 2]
+
+
+def test_host_group_single_rank_is_trivial():
+    g = PAR.HostGroup(rank=0, world=1)
+    assert g.broadcast_bytes(b"abc") == b"abc"
+    assert g.allreduce([2.0, 3.0], op="max") == [2.0, 3.0]
+    g.barrier()
+    g.close()
