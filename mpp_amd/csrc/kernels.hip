@@ -21,13 +21,20 @@ namespace {
 
 constexpr int kBlock = 256;
 
-template <int SAT_T = -1>
+// once-streamed data is loaded / stored non-temporal: on MI355X a CSR-like stream mix runs at 6.1 TB/s that way
+// versus 5.4 TB/s with default cache policy (tools/membench.hip csr_mix vs csr_mix_nt)
+template <class T>
+__device__ __forceinline__ T ldnt(const T *p) { return __builtin_nontemporal_load(p); }
+template <class T>
+__device__ __forceinline__ void stnt(T v, T *p) { __builtin_nontemporal_store(v, p); }
+
+template <int SAT_T = -1, bool NT = false>
 __device__ __forceinline__ Soil load_soil(const CellArrays &ca, size_t i) {
   Soil s;
-  s.sat_res = ca.sat_res[i];
-  s.alpha = ca.alpha[i];
-  s.m = ca.m[i];
-  s.por = ca.por[i];
+  s.sat_res = NT ? ldnt(ca.sat_res + i) : ca.sat_res[i];
+  s.alpha = NT ? ldnt(ca.alpha + i) : ca.alpha[i];
+  s.m = NT ? ldnt(ca.m + i) : ca.m[i];
+  s.por = NT ? ldnt(ca.por + i) : ca.por[i];
   if ((SAT_T >= 0 ? SAT_T : ca.sat_func) == kSatSBC) {
     s.pu = ca.sbc_pu[i]; s.ps = ca.sbc_ps[i]; s.b2 = ca.sbc_b2[i]; s.b3 = ca.sbc_b3[i];
   } else {
@@ -90,24 +97,24 @@ __global__ __launch_bounds__(kBlock) void k_assemble_cols(ColsArgs a) {
     const bool owned = (k >= k0 && k < k1);
     Aux cur = {};
     double f_cur = 0.0, dacc_cur = 1.0;  // inactive cell: diagonal 1 (GE:1682-1684)
-    const double Pi = ca.P[i];
+    const double Pi = ldnt(ca.P + i);
     cur.P = Pi;
     if (act) {
-      Soil s = load_soil<SAT_T>(ca, i);
+      Soil s = load_soil<SAT_T, true>(ca, i);
       cur = auxvar_compute<JAC, SAT_T, DEN_T>(ca.sat_func, ca.eos, s, Pi, ca.frac_liq);
       if (owned) {
-        const double vol = ca.vol[i];
+        const double vol = ldnt(ca.vol + i);
         if (RES) f_cur = s.por * cur.den * cur.sat * vol * a.dtInv;
         if (JAC) dacc_cur = (s.por * cur.dden * cur.sat + s.por * cur.den * cur.dsat) * vol * a.dtInv;
       }
     }
-    if (RES && owned) f_cur = f_cur - a.accum_prev[i];
+    if (RES && owned) f_cur = f_cur - ldnt(a.accum_prev + i);
     double dconn_cur = 0.0, lo_cur = 0.0;
     if (k > kstart) {
       if (prev_act && act) {
         const size_t ic = i - tw;
         ConnGeom g;
-        g.Dq = a.conn.Dq[ic]; g.upweight = a.conn.upw[ic]; g.dist_gravity = a.conn.dgrav[ic]; g.area = a.conn.area[ic];
+        g.Dq = ldnt(a.conn.Dq + ic); g.upweight = ldnt(a.conn.upw + ic); g.dist_gravity = ldnt(a.conn.dgrav + ic); g.area = ldnt(a.conn.area + ic);
         double Jup = 0.0, Jdn = 0.0;
         const double flux = richards_flux<JAC>(prev, cur, g, 0, Jup, Jdn);
         if (RES) { f_prev -= flux; f_cur += flux; }
@@ -118,11 +125,11 @@ __global__ __launch_bounds__(kBlock) void k_assemble_cols(ColsArgs a) {
         const size_t ip = i - tw;
         if (RES) {
           double f = f_prev;
-          if (a.src) f -= a.src[ip];
-          a.F[ip] = f;
+          if (a.src) f -= ldnt(a.src + ip);
+          stnt(f, a.F + ip);
         }
         if (JAC) {
-          int slot = rowptr[ip];
+          int slot = ldnt(rowptr + ip);
           if (kp > 0) a.val[slot++] = lo_prev;
           a.val[slot++] = dconn_prev + dacc_prev;
           a.val[slot] = up_prev;  // kp < nz-1 always holds here
@@ -612,7 +619,7 @@ __global__ __launch_bounds__(kBlock) void k_tri_solve(TriArgs a, const double *_
 #pragma unroll 4
   for (int k = 0; k < a.nz; ++k) {
     const size_t i = cbase + (size_t)k * tw;
-    const double d = r[i] - a.l[i] * prev;
+    const double d = ldnt(r + i) - ldnt(a.l + i) * prev;
     z[i] = d;
     prev = d;
   }
@@ -620,8 +627,8 @@ __global__ __launch_bounds__(kBlock) void k_tri_solve(TriArgs a, const double *_
 #pragma unroll 4
   for (int k = a.nz - 1; k >= 0; --k) {
     const size_t i = cbase + (size_t)k * tw;
-    const double xk = (z[i] - a.c[i] * next) * a.invb[i];
-    z[i] = xk;
+    const double xk = (z[i] - ldnt(a.c + i) * next) * ldnt(a.invb + i);
+    stnt(xk, z + i);
     next = xk;
   }
 }
