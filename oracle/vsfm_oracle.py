@@ -19,8 +19,8 @@ _ip = ct.POINTER(ct.c_int)
 
 
 def build(force: bool = False) -> str:
-    src = os.path.join(_HERE, "vsfm_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("vsfm_oracle.c", "thermal_oracle.c", "vsfm_oracle.h")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
 

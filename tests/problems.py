@@ -199,3 +199,125 @@ def to_gpu(prob: Problem, options=None, device_id=0):
         mpp.soe.SetDataFromCLM(C.AUXVAR_SS, C.VAR_BC_SS_CONDITION, i + 1, vals)
     mpp.Restart(prob.press_ic)
     return mpp
+
+
+# ------------------------------------------------------------------------------------------------------------
+# thermal MMS problems (src/driver/standalone/thermal/thermal_mms_problem.F90 and
+# thermal_mms_steady_state_problem_{1D,2D,3D}.F90): steady heat conduction on the unit cube, Dirichlet faces,
+# manufactured source; cnfac = 0, csol = 0, one StepDT(1.0)
+# ------------------------------------------------------------------------------------------------------------
+@dataclass
+class ThermalProblem:
+    name: str
+    mesh: M.Mesh
+    tkdry: np.ndarray          # per cell, in the cell numbering the reference ends up using (see below)
+    bc: M.ConnectionSet
+    bc_temperature: np.ndarray
+    heat_source: np.ndarray
+    exact: np.ndarray
+    t_init: float = 290.0
+    cnfac: float = 0.0
+    dt: float = 1.0
+
+
+def _mms_funcs(ptype):
+    pi = 4.0 * np.arctan(1.0)
+    if ptype == 1:
+        T = lambda x, y, z: 10 * np.sin(pi * x) + 270.0
+        lam = lambda x, y, z: np.exp(x)
+        src = lambda x, y, z: -np.exp(x) * (10.0 * pi * np.cos(pi * x)) - np.exp(x) * (-10.0 * pi * pi * np.sin(pi * x))
+    elif ptype == 2:
+        T = lambda x, y, z: 10.0 * np.sin(x * pi) * np.cos(2.0 * y * pi) + 270.0
+        lam = lambda x, y, z: (x + 0.5) * np.exp(x + y - 1.0)
+
+        def src(x, y, z):
+            l = (x + 0.5) * np.exp(x + y - 1.0)
+            dl_dx = ((x + 0.5) + 1.0) * np.exp(x + y - 1.0)
+            dl_dy = (x + 0.5) * np.exp(x + y - 1.0)
+            dT_dx = 10.0 * pi * np.cos(x * pi) * np.cos(2.0 * pi * y)
+            dT_dy = -20.0 * pi * np.sin(x * pi) * np.sin(2.0 * pi * y)
+            d2x = -10.0 * pi * pi * np.sin(x * pi) * np.cos(2.0 * pi * y)
+            d2y = -40.0 * pi * pi * np.sin(x * pi) * np.cos(2.0 * pi * y)
+            return -dl_dx * dT_dx - l * d2x - dl_dy * dT_dy - l * d2y
+    else:
+        T = lambda x, y, z: 10.0 * np.sin(x * pi) * np.cos(2.0 * pi * y) * np.sin(3.0 * pi * z) + 270.0
+        lam = lambda x, y, z: np.exp(x + y + z - 1.0)
+
+        def src(x, y, z):
+            a = np.exp(x + y + z - 1.0)
+            sx, cx = np.sin(x * pi), np.cos(x * pi)
+            sy, cy = np.sin(2.0 * pi * y), np.cos(2.0 * pi * y)
+            sz, cz = np.sin(3.0 * pi * z), np.cos(3.0 * pi * z)
+            dT_dx, dT_dy, dT_dz = 10.0 * pi * cx * cy * sz, -20.0 * pi * sx * sy * sz, 30.0 * pi * sx * cy * cz
+            d2x, d2y, d2z = -10.0 * pi * pi * sx * cy * sz, -40.0 * pi * pi * sx * cy * sz, -90.0 * pi * pi * sx * cy * sz
+            return -a * dT_dx - a * d2x - a * dT_dy - a * d2y - a * dT_dz - a * d2z
+    return T, lam, src
+
+
+def thermal_mms(ptype=3, nx=3, ny=3, nz=3, replicate_reference_soil_indexing=True) -> ThermalProblem:
+    """ptype 1/2/3 = STEADY_STATE_1D/2D/3D.  The reference fills the soil arrays as data_2D(c, kk) with
+    c = ii + (jj-1)*nx and MPPThermalSetSoils reads them as cell (c-1)*nlevgrnd + kk (z-fastest) although the mesh is
+    numbered x-fastest: for nz > 1 cell ids and conductivities are permuted against each other.  The regression
+    baseline was produced that way, so it is reproduced by default."""
+    m = M.mesh_create("Soil mesh", 1.0, 1.0, 1.0, nx, ny, nz, C.CONN_IN_XYZ_DIR)
+    dx, dy, dz = 1.0 / nx, 1.0 / ny, 1.0 / nz
+    n = nx * ny * nz
+    T, lam, src = _mms_funcs(ptype)
+    ids = (np.arange(n) + 1).reshape(nz, ny, nx)           # [kk, jj, ii] -> x-fastest id
+    X, Y, Z = m.x.reshape(nz, ny, nx), m.y.reshape(nz, ny, nx), m.z.reshape(nz, ny, nx)
+    lam_pos = lam(X, Y, Z)                                 # conductivity at the position of cell [kk,jj,ii]
+    if replicate_reference_soil_indexing:
+        tk = np.zeros(n)
+        c = (np.arange(ny)[:, None] * nx + np.arange(nx)[None, :])           # c-1 for (jj,ii)
+        for kk in range(nz):
+            tk[(c * nz + kk).ravel()] = lam_pos[kk].ravel()                  # cell (c-1)*nz + kk (0-based)
+    else:
+        tk = lam_pos.ravel().copy()
+    # boundary connections in the driver's order (thermal_mms_problem.F90:365-452)
+    idd, du, dd, ar, tb = [], [], [], [], []
+
+    def face(cell, x, y, z, dist, area):
+        idd.append(cell); du.append(0.0); dd.append(dist); ar.append(area); tb.append(T(x, y, z))
+
+    if nx > 1:
+        for kk in range(nz):
+            for jj in range(ny):
+                face(ids[kk, jj, 0], X[kk, jj, 0] - dx / 2, Y[kk, jj, 0], Z[kk, jj, 0], dx / 2, dy * dz)
+                face(ids[kk, jj, nx - 1], X[kk, jj, nx - 1] + dx / 2, Y[kk, jj, nx - 1], Z[kk, jj, nx - 1], dx / 2, dy * dz)
+    if ny > 1:
+        for kk in range(nz):
+            for ii in range(nx):
+                face(ids[kk, 0, ii], X[kk, 0, ii], Y[kk, 0, ii] - dy / 2, Z[kk, 0, ii], dy / 2, dx * dz)
+                face(ids[kk, ny - 1, ii], X[kk, ny - 1, ii], Y[kk, ny - 1, ii] + dy / 2, Z[kk, ny - 1, ii], dy / 2, dx * dz)
+    if nz > 1:
+        for jj in range(ny):
+            for ii in range(nx):
+                face(ids[0, jj, ii], X[0, jj, ii], Y[0, jj, ii], Z[0, jj, ii] - dz / 2, dz / 2, dx * dy)
+                face(ids[nz - 1, jj, ii], X[nz - 1, jj, ii], Y[nz - 1, jj, ii], Z[nz - 1, jj, ii] + dz / 2, dz / 2, dx * dy)
+    nb = len(idd)
+    uv = np.zeros((nb, 3)); uv[:, 0] = 1.0
+    bc = M.ConnectionSet(np.zeros(nb, dtype=np.int64), np.asarray(idd, dtype=np.int64), np.asarray(du), np.asarray(dd),
+                         np.asarray(ar), uv)
+    return ThermalProblem(name="thermal_mms_%dd" % ptype, mesh=m, tkdry=tk, bc=bc, bc_temperature=np.asarray(tb),
+                          heat_source=(src(X, Y, Z) * dx * dy * dz).ravel(), exact=T(X, Y, Z).ravel())
+
+
+def to_thermal_oracle(tp: ThermalProblem, ksp_rtol=0.0):
+    from oracle import thermal_oracle as TO
+    n = tp.mesh.ncells_local
+    o = TO.ThermalOracle(n)
+    o.set_mesh(tp.mesh.vol, tp.mesh.dz)
+    o.set_connections(tp.mesh.internal_connections())
+    o.add_condition(TO.COND_BC, TO.COND_DIRICHLET, tp.bc)
+    ids = np.arange(1, n + 1)
+    z = np.zeros(n)
+    o.add_condition(TO.COND_SS, TO.COND_HEAT_RATE, M.ConnectionSet(np.zeros(n, dtype=np.int64), ids, z, z, z, np.zeros((n, 3))))
+    o.set_soils(TO.SOIL, 1, 0.1, 0.0, tp.tkdry, 0.0)
+    o.set_options(cnfac=tp.cnfac, ksp_type=C.KSP_GMRES, pc_type=C.PC_ILU0, ksp_rtol=ksp_rtol)
+    o.set_soln_prev_clm(np.full(n, tp.t_init))
+    o.set_cell_data(TO.VAR_TUNING_FACTOR, 1.0)
+    o.set_cell_data(TO.VAR_LIQ_AREAL_DEN, 0.0)
+    o.set_condition_values(TO.COND_BC, 1, tp.bc_temperature)
+    o.set_condition_values(TO.COND_SS, 1, tp.heat_source)
+    o.pre_step_dt()
+    return o
