@@ -257,8 +257,8 @@ def _mms_funcs(ptype):
 def thermal_mms(ptype=3, nx=3, ny=3, nz=3, replicate_reference_soil_indexing=True) -> ThermalProblem:
     """ptype 1/2/3 = STEADY_STATE_1D/2D/3D.  The reference fills the soil arrays as data_2D(c, kk) with
     c = ii + (jj-1)*nx and MPPThermalSetSoils reads them as cell (c-1)*nlevgrnd + kk (z-fastest) although the mesh is
-    numbered x-fastest: for nz > 1 cell ids and conductivities are permuted against each other.  The regression
-    baseline was produced that way, so it is reproduced by default."""
+    numbered x-fastest: for nz > 1 cell ids and conductivities are permuted against each other (invisible on the
+    3x3x3 baseline, whose conductivity is symmetric in x, y, z; reproduced by default for fidelity)."""
     m = M.mesh_create("Soil mesh", 1.0, 1.0, 1.0, nx, ny, nz, C.CONN_IN_XYZ_DIR)
     dx, dy, dz = 1.0 / nx, 1.0 / ny, 1.0 / nz
     n = nx * ny * nz
