@@ -33,12 +33,22 @@ typedef struct mppgpu_handle_s *mppgpu_handle;
 #define MPPGPU_COND_MASS_RATE 503
 #define MPPGPU_COND_MASS_FLUX 504
 #define MPPGPU_COND_DIRICHLET 505
+#define MPPGPU_COND_HEAT_FLUX 507
 #define MPPGPU_COND_SEEPAGE_BC 509
+#define MPPGPU_COND_HEAT_RATE 511
 #define MPPGPU_VAR_PRESSURE 604
 #define MPPGPU_VAR_BC_SS_CONDITION 607
 #define MPPGPU_VAR_LIQ_SAT 608
 #define MPPGPU_VAR_MASS 610
 #define MPPGPU_VAR_SOIL_MATRIX_POT 611
+#define MPPGPU_VAR_LIQ_AREAL_DEN 615
+#define MPPGPU_VAR_ICE_AREAL_DEN 617
+#define MPPGPU_VAR_FRAC 618
+#define MPPGPU_VAR_SNOW_WATER 619
+#define MPPGPU_VAR_NUM_SNOW_LYR 620
+#define MPPGPU_VAR_DHS_DT 621
+#define MPPGPU_VAR_ACTIVE 624
+#define MPPGPU_VAR_TUNING_FACTOR 630
 #define MPPGPU_VAR_MASS_FLUX 644
 #define MPPGPU_AUXVAR_INTERNAL 701
 #define MPPGPU_AUXVAR_BC 702
@@ -142,6 +152,29 @@ int mppgpu_jacobian(mppgpu_handle h, const double *x, int *rowptr, int *col, dou
 int mppgpu_spmv(mppgpu_handle h, const double *x, double *y);
 int mppgpu_pc_apply(mppgpu_handle h, const double *r, double *z);
 int mppgpu_ksp_solve(mppgpu_handle h, const double *b, double *x, int *its, int *reason);
+
+/* ------------------------------------------------------------------------------------------------
+ * thermal KSP path: soil heat diffusion, linear solve per step -- sysofeqns_thermal_type with one
+ * goveqn_thermal_ksp_temp_soil_type.  Select with mppgpu_set_option(h, "problem_type", "thermal") before conditions
+ * are added; mesh, connections, conditions (COND_DIRICHLET / COND_HEAT_FLUX boundaries, COND_HEAT_RATE sources),
+ * mppgpu_setup and mppgpu_set_data / mppgpu_set_option ("cnfac", "ksp_type", "pc_type" incl. "ilu") are shared.
+ * ---------------------------------------------------------------------------------------------- */
+/* MPPThermalSetSoils (src/mpp/mpp/MultiPhysicsProbThermal.F90:76-208) as per-cell arrays; itype 1 soil/crop,
+ * 2 wetland, 3 land ice; dz = mesh%dz (layer thickness used by ThermKSPTempSoilAuxVarCompute) */
+int mppgpu_thermal_set_soils(mppgpu_handle h, const int *itype, const int *is_soil_shallow, const double *watsat,
+                             const double *csol, const double *tkmg, const double *tkdry, const double *dz);
+/* soe%SetSolnPrevCLM / PreStepDT / StepDT / GetSoln (src/mpp/soe/SystemOfEquationsThermalType.F90:171-230, 391-409;
+ * src/mpp/soe/SystemOfEquationsBaseType.F90:555-647).  mppgpu_set_data carries SetRDataFromCLM:
+ * AUXVAR_INTERNAL x {VAR_LIQ_AREAL_DEN, VAR_ICE_AREAL_DEN, VAR_SNOW_WATER, VAR_NUM_SNOW_LYR, VAR_TUNING_FACTOR},
+ * AUXVAR_BC x {VAR_BC_SS_CONDITION, VAR_FRAC, VAR_DHS_DT, VAR_ACTIVE}, AUXVAR_SS x VAR_BC_SS_CONDITION. */
+int mppgpu_thermal_set_soln_prev_clm(mppgpu_handle h, int n, const double *temperature);
+int mppgpu_thermal_pre_step_dt(mppgpu_handle h);
+int mppgpu_thermal_step_dt(mppgpu_handle h, double dt, int *converged, int *linear_its);
+int mppgpu_thermal_get_soln(mppgpu_handle h, int n, double *temperature);
+/* soe%ComputeRHS / ComputeOperators behind SOEComputeRHS / SOEComputeOperators (SystemOfEquationsThermalType.F90:546-759;
+ * src/mpp/ge/GoveqnThermalKSPTemperatureSoilType.F90:646-1229): for PETSc-hosted runs and parity tests */
+int mppgpu_thermal_compute_rhs(mppgpu_handle h, double dt, double *b);
+int mppgpu_thermal_compute_operators(mppgpu_handle h, double dt, int *rowptr, int *col, double *val);
 
 /* ------------------------------------------------------------------------------------------------
  * measurement

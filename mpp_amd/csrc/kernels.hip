@@ -639,6 +639,189 @@ __global__ __launch_bounds__(kBlock) void k_jacobi_setup(int n, const int *diag_
 }
 
 // ------------------------------------------------------------------------------------------------
+// ILU(0), level scheduled.  Same arithmetic as the sequential IKJ factorisation in elimination order `ord`
+// (PETSc MatLUFactorNumeric_SeqAIJ with levels = 0): rows of one level only read rows of earlier levels.
+// Rows have <= ~7 entries on stencil matrices, so position look-ups are short linear searches.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_ilu_factor_level(IluArgs a, const int *__restrict__ rows, int count) {
+  const int t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= count) return;
+  const int i = rows[t];
+  const int oi = a.ord[i];
+  const int rs = a.rowptr[i], re = a.rowptr[i + 1];
+  // process the L-part pivots in increasing elimination order (selection by `ord`, rows are tiny)
+  int last = -1;
+  for (;;) {
+    int kslot = -1, kord = 0x7fffffff;
+    for (int s = rs; s < re; ++s) {
+      const int o = a.ord[a.col[s]];
+      if (o < oi && o > last && o < kord) { kord = o; kslot = s; }
+    }
+    if (kslot < 0) break;
+    last = kord;
+    const int k = a.col[kslot];
+    const double mult = a.lu[kslot] * a.idiag[k];
+    a.lu[kslot] = mult;
+    for (int q = a.rowptr[k]; q < a.rowptr[k + 1]; ++q) {
+      const int j = a.col[q];
+      if (a.ord[j] <= kord) continue;  // U-part of row k only
+      for (int s = rs; s < re; ++s)
+        if (a.col[s] == j) { a.lu[s] -= mult * a.lu[q]; break; }
+    }
+  }
+  a.idiag[i] = 1.0 / a.lu[a.diag_slot[i]];
+}
+
+__global__ __launch_bounds__(kBlock) void k_ilu_lower_level(IluArgs a, const int *__restrict__ rows, int count,
+                                                            const double *__restrict__ r, double *__restrict__ y) {
+  const int t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= count) return;
+  const int i = rows[t];
+  const int oi = a.ord[i];
+  double s = r[i];
+  for (int q = a.rowptr[i]; q < a.rowptr[i + 1]; ++q) {
+    const int j = a.col[q];
+    if (a.ord[j] < oi) s -= a.lu[q] * y[j];
+  }
+  y[i] = s;
+}
+__global__ __launch_bounds__(kBlock) void k_ilu_upper_level(IluArgs a, const int *__restrict__ rows, int count,
+                                                            double *__restrict__ x) {
+  const int t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= count) return;
+  const int i = rows[t];
+  const int oi = a.ord[i];
+  double s = x[i];
+  for (int q = a.rowptr[i]; q < a.rowptr[i + 1]; ++q) {
+    const int j = a.col[q];
+    if (a.ord[j] > oi) s -= a.lu[q] * x[j];
+  }
+  x[i] = s * a.idiag[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// soil heat diffusion.  ThermKSPTempSoilAuxVarCompute
+// (src/mpp/auxvar/ThermalKSPTemperatureSoilAuxType.F90:66-168): itype 1 soil/crop, 2 wetland, 3 land ice
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void thermal_auxvar(int itype, bool shallow, double T, double liq, double ice, double snow,
+                                               bool nsnow_zero, double por, double tkmg, double tkdry, double csol,
+                                               double dz, double &therm_cond, double &heat_cap) {
+  const double cpliq = 4.188e3, cpice = 2.11727e3, denh2o = 1.0e3, denice = 0.917e3;
+  const double tkice = 2.290, tkwat = 0.57, thk_bedrock = 3.0, tfrz = 273.15;
+  if (itype == 1) {
+    if (shallow) {
+      double satw = (liq / denh2o + ice / denice) / (dz * por);
+      satw = fmin(1.0, satw);
+      if (satw > .1e-6) {
+        const double dke = (T >= tfrz) ? fmax(0.0, log10(satw) + 1.0) : satw;
+        const double fl = (liq / (denh2o * dz)) / (liq / (denh2o * dz) + ice / (denice * dz));
+        const double dksat = tkmg * pow(tkwat, fl * por) * pow(tkice, (1.0 - fl) * por);
+        therm_cond = dke * dksat + (1.0 - dke) * tkdry;
+      } else {
+        therm_cond = tkdry;
+      }
+      heat_cap = csol * (1.0 - por) * dz + ice * cpice + liq * cpliq;
+      if (nsnow_zero) heat_cap = heat_cap + snow * cpice;
+    } else {
+      therm_cond = thk_bedrock;
+      heat_cap = csol * (1.0 - por) * dz + ice * cpice + liq * cpliq;
+    }
+    heat_cap = heat_cap / dz;
+  } else if (itype == 2 && !shallow) {
+    therm_cond = thk_bedrock;
+    heat_cap = csol;
+  } else {
+    therm_cond = (T < tfrz) ? tkice : tkwat;
+    heat_cap = ice * cpice + liq * cpliq;
+    if (nsnow_zero) heat_cap = heat_cap + snow * cpice;
+    heat_cap = heat_cap / dz;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_thermal_aux(ThermalArgs a) {
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= (size_t)a.n) return;
+  double k, c;
+  thermal_auxvar(a.itype[i], a.shallow[i] != 0, a.T[i], a.liq[i], a.ice[i], a.snow_water[i], a.nsnow_zero[i] != 0,
+                 a.por[i], a.tkmg[i], a.tkdry[i], a.csol[i], a.dz[i], k, c);
+  a.therm_cond[i] = k;
+  a.heat_cap[i] = c;
+}
+
+// ThermalKSPTempSoilAccum + Divergence (GE :664-860) and ComputeOperatorsDiag (:1064-1147), one lane per row,
+// incident connections in the caller's connection order
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_thermal_rows(ThermalArgs a) {
+  constexpr bool RHS = (MODE == 0 || MODE == 2), OPR = (MODE == 1 || MODE == 2);
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= (size_t)a.n) return;
+  const bool act = a.active ? a.active[i] != 0 : true;
+  const int dslot = a.diag_slot[i];
+  if (OPR)
+    for (int s = a.rowptr[i]; s < a.rowptr[i + 1]; ++s) a.val[s] = 0.0;
+  double b = 0.0, diag = 1.0;
+  if (act) {
+    const double acc = a.heat_cap[i] * a.vol[i] / (a.dt * a.tuning[i]);
+    diag = acc;
+    b = acc * a.T[i];
+    const double Ti = a.T[i], ki = a.therm_cond[i];
+    for (int e = a.rc_ptr[i]; e < a.rc_ptr[i + 1]; ++e) {
+      const int enc = a.rc_conn[e], ic = enc >> 1, side = enc & 1;
+      const int o = side ? a.cup[ic] : a.cdn[ic];
+      if (a.active && !a.active[o]) continue;
+      const double du = a.cdu[ic], dd = a.cdd[ic], dist = du + dd, area = a.carea[ic];
+      const double ku = side ? a.therm_cond[o] : ki, kd = side ? ki : a.therm_cond[o];
+      const double Tu = side ? a.T[o] : Ti, Td = side ? Ti : a.T[o];
+      const double kav = ku * kd * dist / (ku * dd + kd * du);
+      if (RHS) {
+        const double flux = -kav * (Tu - Td) / dist;
+        if (side == 0) b = b + a.cnfac * flux * area * 1.0; else b = b - a.cnfac * flux * area * 1.0;
+      }
+      if (OPR) {
+        const double value = (1.0 - a.cnfac) * kav / dist * area;
+        diag += value * 1.0;
+        a.val[a.rc_slot[e]] += -value * 1.0;
+      }
+    }
+  }
+  if (RHS) {
+    if (a.src && act) b = b + a.src[i];
+    a.rhs[i] = b;
+  }
+  if (OPR) a.val[dslot] = diag;
+}
+
+// boundary conditions of the thermal operator: COND_DIRICHLET (505), COND_HEAT_FLUX (507) (GE :862-944, 1149-1224)
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_thermal_bc(ThermalBcArgs a) {
+  constexpr bool RHS = (MODE == 0 || MODE == 2), OPR = (MODE == 1 || MODE == 2);
+  const int j = blockIdx.x * kBlock + threadIdx.x;
+  if (j >= a.ncond_cells) return;
+  const ThermalArgs &t = a.t;
+  const size_t cell = a.cc_cell[j];
+  if (t.active && !t.active[cell]) return;
+  double b = RHS ? t.rhs[cell] : 0.0, d = 0.0;
+  for (int e = a.cc_ptr[j]; e < a.cc_ptr[j + 1]; ++e) {
+    const int ctype = a.type[e];
+    if (ctype == 505) {
+      if (!a.bc_active[e]) continue;
+      double kbc, cbc;  // the BC auxvar: soil of its id_dn cell, no water, boundary temperature
+      thermal_auxvar(t.itype[cell], t.shallow[cell] != 0, a.value[e], 0.0, 0.0, 0.0, true, t.por[cell], t.tkmg[cell],
+                     t.tkdry[cell], t.csol[cell], t.dz[cell], kbc, cbc);
+      const double du = a.du[e], dd = a.dd[e], dist = du + dd, kc = t.therm_cond[cell];
+      const double kav = kbc * kc * dist / (kbc * dd + kc * du);
+      if (RHS) b = b + kav / dist * a.value[e] * a.area[e] * 1.0;
+      if (OPR) d += a.frac[e] * (1.0 - t.cnfac) * kav / dist * a.area[e] * 1.0;
+    } else if (ctype == 507) {
+      if (RHS) b = b + 1.0 * a.value[e] * a.frac[e] * a.area[e];
+      if (OPR) d += -a.frac[e] * a.dhsdT[e] * a.area[e] * 1.0;
+    }
+  }
+  if (RHS) t.rhs[cell] = b;
+  if (OPR) t.val[t.diag_slot[cell]] += d;
+}
+
+// ------------------------------------------------------------------------------------------------
 // vector kernels (grid-stride, 8 B per lane coalesced)
 // ------------------------------------------------------------------------------------------------
 inline int vec_grid(int n) {  // one 16-byte pair per lane
@@ -978,6 +1161,31 @@ void launch_tri_solve(const TriArgs &a, const double *r, double *z, hipStream_t 
 }
 void launch_jacobi_setup(int n, const int *diag_slot, const double *val, double *invd, hipStream_t stream) {
   if (n > 0) LAUNCH(k_jacobi_setup, dim3(nblk(n)), n, diag_slot, val, invd);
+}
+
+void launch_ilu_factor_level(const IluArgs &a, const int *rows, int count, hipStream_t stream) {
+  if (count > 0) LAUNCH(k_ilu_factor_level, dim3(nblk(count)), a, rows, count);
+}
+void launch_ilu_lower_level(const IluArgs &a, const int *rows, int count, const double *r, double *y, hipStream_t stream) {
+  if (count > 0) LAUNCH(k_ilu_lower_level, dim3(nblk(count)), a, rows, count, r, y);
+}
+void launch_ilu_upper_level(const IluArgs &a, const int *rows, int count, double *x, hipStream_t stream) {
+  if (count > 0) LAUNCH(k_ilu_upper_level, dim3(nblk(count)), a, rows, count, x);
+}
+void launch_thermal_aux(const ThermalArgs &a, hipStream_t stream) {
+  if (a.n > 0) LAUNCH(k_thermal_aux, dim3(nblk(a.n)), a);
+}
+void launch_thermal_rows(int mode, const ThermalArgs &a, hipStream_t stream) {
+  if (a.n <= 0) return;
+  if (mode == 0) LAUNCH(k_thermal_rows<0>, dim3(nblk(a.n)), a);
+  else if (mode == 1) LAUNCH(k_thermal_rows<1>, dim3(nblk(a.n)), a);
+  else LAUNCH(k_thermal_rows<2>, dim3(nblk(a.n)), a);
+}
+void launch_thermal_bc(int mode, const ThermalBcArgs &a, hipStream_t stream) {
+  if (a.ncond_cells <= 0) return;
+  if (mode == 0) LAUNCH(k_thermal_bc<0>, dim3(nblk(a.ncond_cells)), a);
+  else if (mode == 1) LAUNCH(k_thermal_bc<1>, dim3(nblk(a.ncond_cells)), a);
+  else LAUNCH(k_thermal_bc<2>, dim3(nblk(a.ncond_cells)), a);
 }
 
 void launch_copy(int n, const double *x, double *y, hipStream_t stream) {

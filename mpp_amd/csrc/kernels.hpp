@@ -102,6 +102,45 @@ void launch_tri_factor(const TriArgs &a, hipStream_t stream);
 void launch_tri_solve(const TriArgs &a, const double *r, double *z, hipStream_t stream);
 void launch_jacobi_setup(int n, const int *diag_slot, const double *val, double *invd, hipStream_t stream);
 
+// ---- ILU(0), level-scheduled (PETSc's default PC for SeqAIJ; elimination order = the caller's natural ordering) ----
+struct IluArgs {
+  int n;
+  const int *rowptr, *col, *diag_slot;
+  const int *ord;        // elimination position of every row (a permutation of 0..n-1)
+  double *lu;            // factors in A's pattern: L strictly below (in `ord` order), U on and above
+  double *idiag;         // 1 / u_ii
+};
+// one launch per level: rows[level_ptr[l] .. level_ptr[l+1]) are mutually independent
+void launch_ilu_factor_level(const IluArgs &a, const int *rows, int count, hipStream_t stream);
+void launch_ilu_lower_level(const IluArgs &a, const int *rows, int count, const double *r, double *y, hipStream_t stream);
+void launch_ilu_upper_level(const IluArgs &a, const int *rows, int count, double *x, hipStream_t stream);
+
+// ---- soil heat diffusion (thermal KSP path) ----
+struct ThermalArgs {
+  int n;
+  const double *T;                                        // temperature the coefficients are evaluated at (soln_prev)
+  const double *liq, *ice, *snow_water, *tuning, *dz, *vol;
+  const double *por, *tkmg, *tkdry, *csol;
+  const signed char *itype, *shallow, *nsnow_zero, *active;   // nsnow_zero: 1 when num_snow_layer == 0
+  double *therm_cond, *heat_cap;                          // auxvar outputs
+  // rows
+  const int *cup, *cdn, *rc_ptr, *rc_conn, *rc_slot, *diag_slot, *rowptr;
+  const double *cdu, *cdd, *carea;
+  const double *src;                                      // dense heat-rate source [W] or nullptr
+  double *rhs, *val;
+  double dt, cnfac;
+};
+void launch_thermal_aux(const ThermalArgs &a, hipStream_t stream);
+void launch_thermal_rows(int mode, const ThermalArgs &a, hipStream_t stream);   // mode 0 rhs, 1 operator, 2 both
+struct ThermalBcArgs {
+  ThermalArgs t;
+  int ncond_cells;
+  const int *cc_cell, *cc_ptr, *type;            // cond_type per entry
+  const double *du, *dd, *area, *value, *frac, *dhsdT;
+  const signed char *bc_active;
+};
+void launch_thermal_bc(int mode, const ThermalBcArgs &a, hipStream_t stream);
+
 // ---- vectors (device scalars in `sc`) ----
 void launch_copy(int n, const double *x, double *y, hipStream_t stream);
 void launch_set(int n, double v, double *y, hipStream_t stream);

@@ -109,6 +109,25 @@ struct Solver {
   double *h_sc = nullptr;  // pinned mirror of sc
   std::vector<DevBuf<double>> vv;
 
+  // ---------------- thermal KSP path ----------------
+  bool thermal = false;
+  double cnfac = 0.5;  // mpp_varcon.F90:28
+  std::vector<double> th_dz, th_por, th_tkmg, th_tkdry, th_csol, th_liq, th_ice, th_snow, th_tuning;
+  std::vector<int> th_itype, th_shallow, th_nsnow;
+  bool th_cell_dirty = true;
+  DevBuf<double> d_th_dz, d_th_por, d_th_tkmg, d_th_tkdry, d_th_csol, d_th_liq, d_th_ice, d_th_snow, d_th_tuning;
+  DevBuf<signed char> d_th_itype, d_th_shallow, d_th_nsnow0;
+  DevBuf<double> d_therm_cond, d_heat_cap, d_cdu, d_cdd, d_carea, soln_prev_clm;
+  DevBuf<double> d_bc_du, d_bc_dd, d_bc_rawarea, d_bc_frac, d_bc_dhsdT;
+  DevBuf<signed char> d_bc_act;
+  std::vector<double> h_bc_frac, h_bc_dhsdT;
+  std::vector<signed char> h_bc_act;
+  // ---------------- ILU(0) ----------------
+  DevBuf<int> d_ord, d_lrows, d_urows;
+  std::vector<int> h_lptr, h_uptr;
+  DevBuf<double> d_lu, d_idiag;
+  bool ilu_ready = false;
+
   double dtime = 0.0, time = 0.0;
   long long cum_newton = 0, cum_linear = 0, cum_cuts = 0, cum_funcs = 0;
   int nfuncs = 0;
@@ -159,11 +178,14 @@ struct Solver {
     if (n == 0) throw Error("mppgpu_set_mesh must precede mppgpu_add_condition");
     std::vector<Condition> *list;
     if (kind == MPPGPU_COND_BC) {
-      if (cond_type != MPPGPU_COND_DIRICHLET && cond_type != MPPGPU_COND_SEEPAGE_BC && cond_type != MPPGPU_COND_MASS_FLUX)
-        throw Error("unsupported boundary cond_type " + std::to_string(cond_type));
+      const bool ok = thermal ? (cond_type == MPPGPU_COND_DIRICHLET || cond_type == MPPGPU_COND_HEAT_FLUX)
+                              : (cond_type == MPPGPU_COND_DIRICHLET || cond_type == MPPGPU_COND_SEEPAGE_BC ||
+                                 cond_type == MPPGPU_COND_MASS_FLUX);
+      if (!ok) throw Error("unsupported boundary cond_type " + std::to_string(cond_type));
       list = &bcs;
     } else if (kind == MPPGPU_COND_SS) {
-      if (cond_type != MPPGPU_COND_MASS_RATE) throw Error("unsupported source-sink cond_type " + std::to_string(cond_type));
+      if (cond_type != (thermal ? MPPGPU_COND_HEAT_RATE : MPPGPU_COND_MASS_RATE))
+        throw Error("unsupported source-sink cond_type " + std::to_string(cond_type));
       list = &sss;
     } else throw Error("unknown condition kind " + std::to_string(kind));
     Condition c;
@@ -342,7 +364,7 @@ struct Solver {
       d_cup.upload(up, stream); d_cdn.upload(dn, stream);
     }
     // per-row incident connection lists, in the caller's connection order (general kernels only)
-    if (!vertical_only || opt.assembly == 0) {
+    if (!vertical_only || opt.assembly == 0 || thermal) {
       std::vector<int> ptr((size_t)n + 1, 0);
       for (int c = 0; c < nc; ++c) { ptr[ext2int[cup_e[c]] + 1]++; ptr[ext2int[cdn_e[c]] + 1]++; }
       for (int i = 0; i < n; ++i) ptr[i + 1] += ptr[i];
@@ -410,6 +432,24 @@ struct Solver {
     sc.alloc(S_COUNT); sc.zero(stream);
     HIP_CHECK(hipHostMalloc(&h_sc, S_COUNT * sizeof(double), hipHostMallocDefault));
     d_Dq.alloc(nc_int); d_upw.alloc(nc_int); d_dgrav.alloc(nc_int); d_area.alloc(nc_int);
+    if (thermal) {
+      std::vector<double> du(nc_int, 0.0), dd(nc_int, 0.0), ar(nc_int, 0.0);
+      for (int c = 0; c < nc; ++c) { du[cext2int[c]] = cdu[c]; dd[cext2int[c]] = cdd[c]; ar[cext2int[c]] = carea[c]; }
+      d_cdu.upload(du, stream); d_cdd.upload(dd, stream); d_carea.upload(ar, stream);
+      std::vector<double> bdu(nb, 0.0), bdd(nb, 0.0), bar(nb, 0.0);
+      for (auto &cd : bcs)
+        for (int i = 0; i < cd.n; ++i) {
+          const int e = bc_pos_of_g[cd.offset + i];
+          bdu[e] = cd.dist_up[i]; bdd[e] = cd.dist_dn[i]; bar[e] = cd.area[i];
+        }
+      d_bc_du.upload(bdu, stream); d_bc_dd.upload(bdd, stream); d_bc_rawarea.upload(bar, stream);
+      h_bc_frac.assign(nb, 1.0); h_bc_dhsdT.assign(nb, 0.0); h_bc_act.assign(nb, 1);
+      d_bc_frac.upload(h_bc_frac, stream); d_bc_dhsdT.upload(h_bc_dhsdT, stream);
+      d_bc_act.upload(h_bc_act.data(), h_bc_act.size(), stream);
+      d_therm_cond.alloc(n); d_heat_cap.alloc(n); soln_prev_clm.alloc(n); soln_prev_clm.zero(stream);
+      if (ns > 0 && !has_src) { d_src.alloc(n); d_src.zero(stream); has_src = true; }
+      th_liq.assign(n, 0.0); th_ice.assign(n, 0.0); th_snow.assign(n, 0.0); th_tuning.assign(n, 1.0); th_nsnow.assign(n, 0);
+    }
     HIP_CHECK(hipStreamSynchronize(stream));
     setup_done = true;
     soil_dirty = true;
@@ -576,13 +616,26 @@ struct Solver {
     ProfScope ps(prof, KC_PC_SETUP);
     if (opt.pc_type == 2) launch_tri_factor(tri_args(), stream);
     else if (opt.pc_type == 3) launch_jacobi_setup(n, d_diag.p, d_val.p, jac_invd.p, stream);
+    else if (opt.pc_type == 1) {
+      ilu_analyse();
+      launch_copy(nnz, d_val.p, d_lu.p, stream);
+      const IluArgs a = ilu_args();
+      for (size_t l = 0; l + 1 < h_lptr.size(); ++l)
+        launch_ilu_factor_level(a, d_lrows.p + h_lptr[l], h_lptr[l + 1] - h_lptr[l], stream);
+    }
     pc_ready = true;
   }
   void op_pc_apply(const double *r, double *z) {
     ProfScope ps(prof, KC_PC_APPLY);
     if (opt.pc_type == 2) launch_tri_solve(tri_args(), r, z, stream);
     else if (opt.pc_type == 3) launch_pointwise_mult(n, jac_invd.p, r, z, stream);
-    else launch_copy(n, r, z, stream);
+    else if (opt.pc_type == 1) {
+      const IluArgs a = ilu_args();
+      for (size_t l = 0; l + 1 < h_lptr.size(); ++l)
+        launch_ilu_lower_level(a, d_lrows.p + h_lptr[l], h_lptr[l + 1] - h_lptr[l], r, z, stream);
+      for (size_t l = 0; l + 1 < h_uptr.size(); ++l)
+        launch_ilu_upper_level(a, d_urows.p + h_uptr[l], h_uptr[l + 1] - h_uptr[l], z, stream);
+    } else launch_copy(n, r, z, stream);
   }
   void op_BA(const double *v, double *t) {  // t = M^{-1} A v  (left preconditioning)
     op_spmv(v, Wk.p);
@@ -619,6 +672,73 @@ struct Solver {
   void vec_waxpy(double *w, double a, const double *x, const double *y) {
     ProfScope ps(prof, KC_VEC);
     launch_waxpy(n, w, sc.p, -1, 1.0, a, x, y, stream);
+  }
+
+  // =====================================================================================
+  // thermal KSP path: SOEBaseStepDT_KSP (src/mpp/soe/SystemOfEquationsBaseType.F90:555-647) with
+  // ThermalSOEComputeRHS / ComputeOperators (src/mpp/soe/SystemOfEquationsThermalType.F90:546-759)
+  // =====================================================================================
+  void thermal_upload_cells() {
+    if (!th_cell_dirty) return;
+    if ((int)th_dz.size() != n) throw Error("thermal soils are not set (mppgpu_thermal_set_soils)");
+    auto perm_d = [&](const std::vector<double> &v, DevBuf<double> &d) {
+      std::vector<double> t(n);
+      for (int i = 0; i < n; ++i) t[i] = v[int2ext[i]];
+      d.upload(t, stream);
+    };
+    auto perm_c = [&](const std::vector<int> &v, DevBuf<signed char> &d, bool zero_is_one) {
+      std::vector<signed char> t(n);
+      for (int i = 0; i < n; ++i) t[i] = (signed char)(zero_is_one ? (v[int2ext[i]] == 0) : v[int2ext[i]]);
+      d.upload(t.data(), t.size(), stream);
+    };
+    perm_d(th_dz, d_th_dz); perm_d(th_por, d_th_por); perm_d(th_tkmg, d_th_tkmg); perm_d(th_tkdry, d_th_tkdry);
+    perm_d(th_csol, d_th_csol); perm_d(th_liq, d_th_liq); perm_d(th_ice, d_th_ice); perm_d(th_snow, d_th_snow);
+    perm_d(th_tuning, d_th_tuning);
+    perm_c(th_itype, d_th_itype, false); perm_c(th_shallow, d_th_shallow, false); perm_c(th_nsnow, d_th_nsnow0, true);
+    HIP_CHECK(hipStreamSynchronize(stream));
+    th_cell_dirty = false;
+  }
+  ThermalArgs thermal_args() const {
+    ThermalArgs a;
+    a.n = n; a.T = soln_prev.p;
+    a.liq = d_th_liq.p; a.ice = d_th_ice.p; a.snow_water = d_th_snow.p; a.tuning = d_th_tuning.p; a.dz = d_th_dz.p; a.vol = d_vol.p;
+    a.por = d_th_por.p; a.tkmg = d_th_tkmg.p; a.tkdry = d_th_tkdry.p; a.csol = d_th_csol.p;
+    a.itype = d_th_itype.p; a.shallow = d_th_shallow.p; a.nsnow_zero = d_th_nsnow0.p;
+    a.active = any_inactive ? d_active.p : nullptr;
+    a.therm_cond = d_therm_cond.p; a.heat_cap = d_heat_cap.p;
+    a.cup = d_cup.p; a.cdn = d_cdn.p; a.rc_ptr = d_rc_ptr.p; a.rc_conn = d_rc_conn.p; a.rc_slot = d_rc_slot.p;
+    a.diag_slot = d_diag.p; a.rowptr = d_rowptr.p;
+    a.cdu = d_cdu.p; a.cdd = d_cdd.p; a.carea = d_carea.p;
+    a.src = has_src ? d_src.p : nullptr;
+    a.rhs = F.p; a.val = d_val.p; a.dt = dtime; a.cnfac = cnfac;
+    return a;
+  }
+  void thermal_assemble(int mode) {  // 0 rhs, 1 operator, 2 both
+    if (!thermal) throw Error("problem_type is not thermal");
+    need_setup(true);
+    thermal_upload_cells();
+    if (dtime <= 0.0) throw Error("time step not set");
+    ProfScope ps(prof, mode == 0 ? KC_RESIDUAL : KC_JACOBIAN);
+    ThermalArgs a = thermal_args();
+    launch_thermal_aux(a, stream);
+    launch_thermal_rows(mode, a, stream);
+    ThermalBcArgs b;
+    b.t = a; b.ncond_cells = ncond_cells; b.cc_cell = d_cc_cell.p; b.cc_ptr = d_cc_ptr.p; b.type = d_bc_type.p;
+    b.du = d_bc_du.p; b.dd = d_bc_dd.p; b.area = d_bc_rawarea.p; b.value = d_bc_value.p; b.frac = d_bc_frac.p;
+    b.dhsdT = d_bc_dhsdT.p; b.bc_active = d_bc_act.p;
+    launch_thermal_bc(mode, b, stream);
+    if (mode != 0) pc_ready = false;
+  }
+  void thermal_step_dt(double dt, int *converged, int *its) {
+    dtime = dt;
+    thermal_assemble(2);
+    int it = 0;
+    const int reason = ksp_solve(F.p, soln.p, &it);
+    *converged = reason >= 0;
+    if (its) *its = it;
+    cum_linear += it;
+    vec_copy(soln.p, soln_prev.p);
+    HIP_CHECK(hipStreamSynchronize(stream));
   }
 
   // =====================================================================================
@@ -973,8 +1093,58 @@ struct Solver {
     HIP_CHECK(hipStreamSynchronize(stream));
   }
 
+  // ThermalSOESetRDataFromCLM (src/mpp/soe/SystemOfEquationsThermalType.F90:234-289) + ThermKSPTempSoilAuxVarSetRValues
+  void thermal_set_data(int auxvar_type, int var_type, int cond_id, int cnt, const double *data) {
+    need_setup(true);
+    if (!thermal) throw Error("problem_type is not thermal");
+    if (auxvar_type == MPPGPU_AUXVAR_INTERNAL) {
+      if (cnt > n) throw Error("set_data: size(data_1d) > nauxvar");
+      std::vector<double> *dst = nullptr;
+      switch (var_type) {
+        case MPPGPU_VAR_LIQ_AREAL_DEN: dst = &th_liq; break;
+        case MPPGPU_VAR_ICE_AREAL_DEN: dst = &th_ice; break;
+        case MPPGPU_VAR_SNOW_WATER: dst = &th_snow; break;
+        case MPPGPU_VAR_TUNING_FACTOR: dst = &th_tuning; break;
+        case MPPGPU_VAR_NUM_SNOW_LYR: for (int i = 0; i < cnt; ++i) th_nsnow[i] = (int)data[i]; th_cell_dirty = true; return;
+        default: throw Error("set_data: unknown var_type " + std::to_string(var_type));
+      }
+      for (int i = 0; i < cnt; ++i) (*dst)[i] = data[i];
+      th_cell_dirty = true;
+    } else if (auxvar_type == MPPGPU_AUXVAR_BC) {
+      if (cond_id < 1 || cond_id > (int)bcs.size()) throw Error("set_data: bad boundary condition id");
+      Condition &c = bcs[cond_id - 1];
+      if (cnt > c.n) throw Error("set_data: size(data_1d) > nauxvar");
+      for (int i = 0; i < cnt; ++i) {
+        const int e = bc_pos_of_g[c.offset + i];
+        switch (var_type) {
+          case MPPGPU_VAR_BC_SS_CONDITION: c.value[i] = data[i]; h_bc_value[e] = data[i]; break;
+          case MPPGPU_VAR_FRAC: h_bc_frac[e] = data[i]; break;
+          case MPPGPU_VAR_DHS_DT: h_bc_dhsdT[e] = data[i]; break;
+          case MPPGPU_VAR_ACTIVE: h_bc_act[e] = (signed char)(data[i] != 0.0); break;
+          default: throw Error("set_data: unknown var_type " + std::to_string(var_type));
+        }
+      }
+      d_bc_value.upload(h_bc_value, stream); d_bc_frac.upload(h_bc_frac, stream); d_bc_dhsdT.upload(h_bc_dhsdT, stream);
+      d_bc_act.upload(h_bc_act.data(), h_bc_act.size(), stream);
+      HIP_CHECK(hipStreamSynchronize(stream));
+    } else if (auxvar_type == MPPGPU_AUXVAR_SS) {
+      if (var_type != MPPGPU_VAR_BC_SS_CONDITION) throw Error("set_data: unknown var_type " + std::to_string(var_type));
+      if (cond_id < 1 || cond_id > (int)sss.size()) throw Error("set_data: bad source-sink id");
+      Condition &c = sss[cond_id - 1];
+      if (cnt > c.n) throw Error("set_data: size(data_1d) > nauxvar");
+      for (int i = 0; i < cnt; ++i) c.value[i] = data[i];
+      std::vector<double> src(n, 0.0);   // dense heat-rate source [W]: sum over conditions (GE :950-962)
+      for (auto &sc_ : sss)
+        for (int i = 0; i < sc_.n; ++i)
+          if (active[sc_.cell[i]]) src[ext2int[sc_.cell[i]]] += sc_.value[i];
+      d_src.upload(src, stream);
+      HIP_CHECK(hipStreamSynchronize(stream));
+    } else throw Error("set_data: unknown auxvar_type " + std::to_string(auxvar_type));
+  }
+
   void set_data(int auxvar_type, int var_type, int cond_id, int cnt, const double *data) {
     need_setup(true);
+    if (thermal) { thermal_set_data(auxvar_type, var_type, cond_id, cnt, data); return; }
     if (var_type != MPPGPU_VAR_BC_SS_CONDITION) throw Error("set_data: unknown var_type " + std::to_string(var_type));
     if (auxvar_type == MPPGPU_AUXVAR_BC) {
       if (cond_id < 1 || cond_id > (int)bcs.size()) throw Error("set_data: bad boundary condition id");
@@ -1040,9 +1210,70 @@ struct Solver {
   // one tridiagonal block per soil column; ILU(0) in that ordering has no fill to drop, i.e. it IS the exact
   // per-column LU that the block-Jacobi kernels compute.  General (7-point) ILU(0) needs a level-scheduled
   // triangular solve that is not built yet.
-  void check_ilu() const {
-    if (opt.pc_is_ilu && !vertical_only)
-      throw Error("pc_type ilu is available on vertical-only grids only (use bjacobi for meshes with lateral connections)");
+  void check_ilu() {
+    if (!opt.pc_is_ilu) return;
+    opt.pc_type = vertical_only ? 2 : 1;   // general meshes: level-scheduled ILU(0) in the caller's natural ordering
+    pc_ready = false;
+  }
+
+  // Level sets of the ILU(0) dependency graphs.  Elimination order = the caller's numbering (PETSc factors in natural
+  // ordering), i.e. ord[i] = external id of internal row i; level(i) = 1 + max level over the row's L (resp. U) part.
+  void ilu_analyse() {
+    if (d_ord.p) return;
+    std::vector<int> lvl(n, 0), ulvl(n, 0);
+    int nl = 0, nu = 0;
+    for (int pos = 0; pos < n; ++pos) {
+      const int i = ext2int[pos];
+      int m = 0;
+      for (int q = h_rowptr[i]; q < h_rowptr[i + 1]; ++q) {
+        const int j = h_col[q];
+        if (int2ext[j] < pos) m = std::max(m, lvl[j] + 1);
+      }
+      lvl[i] = m; nl = std::max(nl, m + 1);
+    }
+    for (int pos = n - 1; pos >= 0; --pos) {
+      const int i = ext2int[pos];
+      int m = 0;
+      for (int q = h_rowptr[i]; q < h_rowptr[i + 1]; ++q) {
+        const int j = h_col[q];
+        if (int2ext[j] > pos) m = std::max(m, ulvl[j] + 1);
+      }
+      ulvl[i] = m; nu = std::max(nu, m + 1);
+    }
+    auto bucket = [&](const std::vector<int> &lv, int nlev_, std::vector<int> &ptr, std::vector<int> &rows) {
+      ptr.assign(nlev_ + 1, 0);
+      for (int i = 0; i < n; ++i) ptr[lv[i] + 1]++;
+      for (int l = 0; l < nlev_; ++l) ptr[l + 1] += ptr[l];
+      rows.resize(n);
+      std::vector<int> fill(ptr.begin(), ptr.end() - 1);
+      for (int pos = 0; pos < n; ++pos) { const int i = ext2int[pos]; rows[fill[lv[i]]++] = i; }
+    };
+    std::vector<int> lrows, urows;
+    bucket(lvl, nl, h_lptr, lrows);
+    bucket(ulvl, nu, h_uptr, urows);
+    d_lrows.upload(lrows, stream); d_urows.upload(urows, stream);
+    d_ord.upload(int2ext, stream);
+    d_lu.alloc(nnz); d_idiag.alloc(n);
+    HIP_CHECK(hipStreamSynchronize(stream));
+  }
+  IluArgs ilu_args() const { return IluArgs{n, d_rowptr.p, d_col.p, d_diag.p, d_ord.p, d_lu.p, d_idiag.p}; }
+
+  // current matrix values in the caller's ordering, columns sorted
+  void export_csr(int *rowptr, int *col, double *val) {
+    std::vector<double> v(nnz);
+    HIP_CHECK(hipMemcpyAsync(v.data(), d_val.p, (size_t)nnz * sizeof(double), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    int pos = 0;
+    std::vector<std::pair<int, double>> row;
+    for (int e = 0; e < n; ++e) {
+      rowptr[e] = pos;
+      const int i = ext2int[e];
+      row.clear();
+      for (int k = h_rowptr[i]; k < h_rowptr[i + 1]; ++k) row.emplace_back(int2ext[h_col[k]], v[k]);
+      std::sort(row.begin(), row.end());
+      for (auto &pr : row) { col[pos] = pr.first; val[pos] = pr.second; ++pos; }
+    }
+    rowptr[n] = pos;
   }
 
   void set_option(const std::string &key, const std::string &val) {
@@ -1070,6 +1301,11 @@ struct Solver {
       else throw Error("unknown assembly '" + val + "'");
     } else if (key == "nseg") opt.nseg = (int)num();
     else if (key == "temperature") temperature = num();
+    else if (key == "problem_type") {
+      if (setup_done || !bcs.empty() || !sss.empty()) throw Error("problem_type must be set before conditions are added");
+      if (val == "thermal") thermal = true; else if (val == "vsfm") thermal = false;
+      else throw Error("unknown problem_type '" + val + "' (vsfm | thermal)");
+    } else if (key == "cnfac") cnfac = num();
     else if (key == "profile") { prof.flush(); prof.enabled = num() != 0; }
     else throw Error("unknown option '" + key + "'");
   }
@@ -1275,21 +1511,7 @@ int mppgpu_jacobian(mppgpu_handle h, const double *x, int *rowptr, int *col, dou
   S.ensure_ready();
   S.put_cells(x, S.W.p);
   S.op_jacobian(S.W.p);
-  std::vector<double> v(S.nnz);
-  HIP_CHECK(hipMemcpyAsync(v.data(), S.d_val.p, (size_t)S.nnz * sizeof(double), hipMemcpyDeviceToHost, S.stream));
-  HIP_CHECK(hipStreamSynchronize(S.stream));
-  // back to the caller's ordering, columns sorted
-  int pos = 0;
-  std::vector<std::pair<int, double>> row;
-  for (int e = 0; e < S.n; ++e) {
-    rowptr[e] = pos;
-    const int i = S.ext2int[e];
-    row.clear();
-    for (int k = S.h_rowptr[i]; k < S.h_rowptr[i + 1]; ++k) row.emplace_back(S.int2ext[S.h_col[k]], v[k]);
-    std::sort(row.begin(), row.end());
-    for (auto &p : row) { col[pos] = p.first; val[pos] = p.second; ++pos; }
-  }
-  rowptr[S.n] = pos;
+  S.export_csr(rowptr, col, val);
   API_END()
 }
 int mppgpu_spmv(mppgpu_handle h, const double *x, double *y) {
@@ -1318,6 +1540,68 @@ int mppgpu_ksp_solve(mppgpu_handle h, const double *b, double *x, int *its, int 
   S.get_cells(S.Y.p, x, S.n);
   if (its) *its = it;
   if (reason) *reason = r;
+  API_END()
+}
+
+/* ---- thermal KSP path ---- */
+int mppgpu_thermal_set_soils(mppgpu_handle h, const int *itype, const int *is_soil_shallow, const double *watsat,
+                             const double *csol, const double *tkmg, const double *tkdry, const double *dz) {
+  API_BEGIN(h)
+  if (!S.n) throw mpp::Error("mesh not set");
+  if (!S.thermal) throw mpp::Error("problem_type is not thermal");
+  const int n = S.n;
+  for (int i = 0; i < n; ++i)
+    if (itype[i] < 1 || itype[i] > 3) throw mpp::Error("thermal_set_soils: itype must be 1 (soil/crop), 2 (wetland) or 3 (land ice)");
+  S.th_itype.assign(itype, itype + n); S.th_shallow.assign(is_soil_shallow, is_soil_shallow + n);
+  S.th_por.assign(watsat, watsat + n); S.th_csol.assign(csol, csol + n); S.th_tkmg.assign(tkmg, tkmg + n);
+  S.th_tkdry.assign(tkdry, tkdry + n); S.th_dz.assign(dz, dz + n);
+  S.th_cell_dirty = true;
+  API_END()
+}
+int mppgpu_thermal_set_soln_prev_clm(mppgpu_handle h, int n, const double *temperature) {
+  API_BEGIN(h)
+  S.need_setup(true);
+  if (!S.thermal) throw mpp::Error("problem_type is not thermal");
+  if (n != S.n) throw mpp::Error("size(data_1d) /= ncells_local");
+  S.put_cells(temperature, S.soln_prev_clm.p);
+  API_END()
+}
+int mppgpu_thermal_pre_step_dt(mppgpu_handle h) {
+  API_BEGIN(h)
+  S.need_setup(true);
+  if (!S.thermal) throw mpp::Error("problem_type is not thermal");
+  S.vec_copy(S.soln_prev_clm.p, S.soln_prev.p);
+  S.vec_copy(S.soln_prev_clm.p, S.soln.p);
+  HIP_CHECK(hipStreamSynchronize(S.stream));
+  API_END()
+}
+int mppgpu_thermal_step_dt(mppgpu_handle h, double dt, int *converged, int *linear_its) {
+  API_BEGIN(h)
+  int c = 0, it = 0;
+  S.thermal_step_dt(dt, &c, &it);
+  if (converged) *converged = c;
+  if (linear_its) *linear_its = it;
+  API_END()
+}
+int mppgpu_thermal_get_soln(mppgpu_handle h, int n, double *temperature) {
+  API_BEGIN(h)
+  S.need_setup(true);
+  if (n > S.n) throw mpp::Error("size(data_1d) > ncells_local");
+  S.get_cells(S.soln.p, temperature, n);
+  API_END()
+}
+int mppgpu_thermal_compute_rhs(mppgpu_handle h, double dt, double *b) {
+  API_BEGIN(h)
+  S.dtime = dt;
+  S.thermal_assemble(0);
+  S.get_cells(S.F.p, b, S.n);
+  API_END()
+}
+int mppgpu_thermal_compute_operators(mppgpu_handle h, double dt, int *rowptr, int *col, double *val) {
+  API_BEGIN(h)
+  S.dtime = dt;
+  S.thermal_assemble(1);
+  S.export_csr(rowptr, col, val);
   API_END()
 }
 

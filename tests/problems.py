@@ -321,3 +321,30 @@ def to_thermal_oracle(tp: ThermalProblem, ksp_rtol=0.0):
     o.set_condition_values(TO.COND_SS, 1, tp.heat_source)
     o.pre_step_dt()
     return o
+
+
+def to_thermal_gpu(tp: ThermalProblem, options=None, device_id=0):
+    """the call sequence of thermal_mms_problem.F90:236-262 / :603-705 through the reference-shaped host API"""
+    from mpp_amd import thermal as T
+    n = tp.mesh.ncells_local
+    mpp = T.MultiPhysicsProbThermal(device_id)
+    mpp.Init(); mpp.SetName("Thermal model for MMS"); mpp.SetID(T.MPP_THERMAL_TBASED_KSP_CLM); mpp.SetMPIRank(0)
+    mpp.SetNumMeshes(1)
+    mpp.AddMesh(1, tp.mesh)
+    mpp.AddGovEqn(T.GE_THERM_SOIL_TBASED, "Thermal equation using temprature formulation in soil (KSP formulation)", 302)
+    mpp.SetMeshesOfGoveqns()
+    mpp.soe.AddConditionInGovEqn(1, C.COND_BC, "Temp BC", "T", C.COND_DIRICHLET, conn_set=tp.bc)
+    mpp.soe.AddConditionInGovEqn(1, C.COND_SS, "Source term for MMS", "W/m^2", T.COND_HEAT_RATE, region_type=T.ALL_CELLS)
+    mpp.soe.SetOption("cnfac", tp.cnfac)
+    for k, v in (options or {}).items():
+        mpp.soe.SetOption(k, v)
+    mpp.AllocateAuxVars()
+    mpp.SetupProblem()
+    T.MPPThermalSetSoils(mpp, T.ISTSOIL, 1, 0.1, 0.0, 0.0, tp.tkdry)
+    mpp.soe.SetSolnPrevCLM(np.full(n, tp.t_init))
+    mpp.soe.SetRDataFromCLM(C.AUXVAR_INTERNAL, T.VAR_TUNING_FACTOR, 1, np.ones(n))
+    mpp.soe.SetRDataFromCLM(C.AUXVAR_INTERNAL, T.VAR_LIQ_AREAL_DEN, 1, np.zeros(n))
+    mpp.soe.SetRDataFromCLM(C.AUXVAR_BC, C.VAR_BC_SS_CONDITION, 1, tp.bc_temperature)
+    mpp.soe.SetRDataFromCLM(C.AUXVAR_SS, C.VAR_BC_SS_CONDITION, 1, tp.heat_source)
+    mpp.soe.PreStepDT()
+    return mpp

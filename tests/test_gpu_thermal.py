@@ -1,0 +1,93 @@
+"""GPU parity of the thermal KSP path and of the level-scheduled ILU(0), through the C ABI."""
+import os
+
+import numpy as np
+import pytest
+
+import problems as P
+from conftest import parse_regression_file
+from mpp_amd import constants as C
+
+pytestmark = pytest.mark.gpu
+CASES = [(1, (20, 1, 1), 5, "thermal_mms"), (2, (3, 3, 1), 2, "thermal_mms_2d"), (3, (3, 3, 3), 3, "thermal_mms_3d")]
+
+
+@pytest.mark.parametrize("ptype,dims,ncell,name", CASES)
+def test_thermal_mms_baselines_with_petsc_defaults(golden_dir, ptype, dims, ncell, name):
+    """regression_tests/thermal: GMRES(30) + ILU(0), rtol 1e-5 -- the reference's default solver, on the GPU"""
+    gold = parse_regression_file(os.path.join(golden_dir, name + ".regression.baseline"))["temperature"]
+    tp = P.thermal_mms(ptype, *dims)
+    g = P.to_thermal_gpu(tp, {"ksp_type": "gmres", "pc_type": "ilu"})
+    conv, _ = g.soe.StepDT(tp.dt, 1)
+    assert conv
+    st = P.regression_stats(g.soe.GetSoln(), ncell)
+    for key in ("min", "max", "mean"):
+        assert st[key] == pytest.approx(gold[key], rel=1e-9)
+    for cell, v in st["cells"].items():
+        assert v == pytest.approx(gold["cell %d" % cell], rel=1e-9)
+    o = P.to_thermal_oracle(tp)
+    o.step_dt(tp.dt)
+    assert g.soe.last_linear_iterations == o.linear_iterations()
+
+
+@pytest.mark.parametrize("dims", [(7, 5, 6), (13, 1, 9), (24, 20, 16)])
+def test_thermal_operator_and_rhs_match_the_oracle(dims):
+    tp = P.thermal_mms(3, *dims)
+    tp.cnfac = 0.5                                   # exercise the Crank-Nicolson terms too
+    g = P.to_thermal_gpu(tp)
+    o = P.to_thermal_oracle(tp)
+    b_o = o.compute_rhs(1800.0)
+    rp, cj, val = o.compute_operators()
+    b_g = g.soe.ComputeRHS(1800.0)
+    rp_g, cj_g, val_g = g.soe.ComputeOperators(1800.0)
+    assert np.array_equal(rp, rp_g) and np.array_equal(cj, cj_g)
+    assert np.abs(val_g - val).max() <= 1e-13 * np.abs(val).max()
+    assert np.abs(b_g - b_o).max() <= 1e-12 * np.abs(b_o).max()
+
+
+@pytest.mark.parametrize("ksp,pc", [("gmres", "ilu"), ("bcgs", "ilu"), ("bcgs", "bjacobi"), ("gmres", "jacobi")])
+def test_thermal_solve_matches_tight_oracle_solution(ksp, pc):
+    tp = P.thermal_mms(3, 12, 10, 9, replicate_reference_soil_indexing=False)   # consistent lambda(x,y,z) per cell
+    g = P.to_thermal_gpu(tp, {"ksp_type": ksp, "pc_type": pc, "ksp_rtol": 1e-12})
+    conv, _ = g.soe.StepDT(tp.dt, 1)
+    assert conv
+    o = P.to_thermal_oracle(tp, ksp_rtol=1e-13)
+    o.step_dt(tp.dt)
+    assert np.abs(g.soe.GetSoln() - o.get_soln()).max() <= 1e-8
+    # second-order accurate against the manufactured solution as well
+    assert np.abs(g.soe.GetSoln() - tp.exact).max() < 1.0   # 0.75 K on this grid, 0.19 K at twice the resolution
+
+
+def test_ilu0_apply_matches_the_oracle_on_the_vchannel_jacobian():
+    """level-scheduled ILU(0) in the caller's natural ordering == sequential ILU(0) of the oracle / PETSc"""
+    prob = P.vchannel(nx=9, ny=7, nz=8)
+    g = P.to_gpu(prob, {"ksp_type": "gmres", "pc_type": "ilu"})
+    o = P.to_oracle(prob)
+    for h in (o,):
+        h.set_dtime(prob.dt); h.pre_solve()
+    g.soe.SetDtime(prob.dt); g.soe.PreSolve()
+    x = prob.press_ic - np.random.default_rng(4).uniform(0, 2e5, prob.press_ic.size)
+    rp, cj, val = o.jacobian(x)
+    g.soe.ComputeJacobian(x)
+    r = np.random.default_rng(6).standard_normal(x.size)
+    z_o = o.pc_apply(C.PC_ILU0, rp, cj, val, r)
+    z_g = g.soe.PCApply(r)
+    assert np.abs(z_g - z_o).max() <= 1e-11 * np.abs(z_o).max()
+
+
+def test_vchannel_baseline_with_petsc_default_solver(golden_dir):
+    """regression_tests/vsfm/vsfm_vchannel with the reference's own solver choice (GMRES(30) + ILU(0)) on the GPU:
+    now the Krylov iterates follow PETSc's, so the baseline is met to 1e-9 instead of the nonlinear tolerance."""
+    gold = parse_regression_file(os.path.join(golden_dir, "vsfm_vchannel.regression.baseline"))
+    prob = P.vchannel()
+    g = P.to_gpu(prob, {"ksp_type": "gmres", "pc_type": "ilu"})
+    o = P.to_oracle(prob)
+    for s in range(prob.nstep):
+        conv, reason = g.soe.StepDT(prob.dt, s + 1)
+        assert conv and reason > 0
+        o.step_dt(prob.dt, s + 1)
+    pr = g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1)
+    st = P.regression_stats(pr)
+    for key in ("min", "max", "mean"):
+        assert st[key] == pytest.approx(gold["liquid_pressure"][key], rel=1e-9)
+    assert g.soe.counters()["newton"] == o.counters()["newton"]
