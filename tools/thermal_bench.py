@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Thermal KSP step (SURVEY 8 f-1 / BASELINE config 4) on one GPU: 3-D heat-diffusion MMS problem, n^3 cells,
+GMRES(30) + ILU(0) (PETSc defaults) or another ksp/pc.  Prints timings and per-kernel-class statistics."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+import problems as P  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=128)
+    ap.add_argument("--ksp", default="gmres")
+    ap.add_argument("--pc", default="ilu")
+    ap.add_argument("--rtol", type=float, default=1e-5)
+    ap.add_argument("--out", default="")
+    a = ap.parse_args()
+    t0 = time.perf_counter()
+    tp = P.thermal_mms(3, a.n, a.n, a.n, replicate_reference_soil_indexing=False)
+    t_build = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    g = P.to_thermal_gpu(tp, {"ksp_type": a.ksp, "pc_type": a.pc, "ksp_rtol": a.rtol})
+    t_setup = time.perf_counter() - t0
+    g.soe.StepDT(tp.dt, 1)          # warm-up (ILU analysis, allocations)
+    g.soe.PreStepDT()
+    g.soe.SetOption("profile", 1)
+    g.soe.reset_stats()
+    g.soe.synchronize()
+    t0 = time.perf_counter()
+    conv, _ = g.soe.StepDT(tp.dt, 1)
+    g.soe.synchronize()
+    t_step = time.perf_counter() - t0
+    err = float(np.abs(g.soe.GetSoln() - tp.exact).max())
+    stats = {k: g.soe.kernel_stats(k) for k in ("spmv", "pc_apply", "pc_setup", "residual", "jacobian", "vec", "reduce")}
+    out = {"grid": a.n, "cells": a.n ** 3, "ksp": a.ksp, "pc": a.pc, "converged": conv,
+           "linear_iterations": g.soe.last_linear_iterations, "step_s": t_step, "setup_s": t_setup, "build_s": t_build,
+           "max_error_vs_manufactured_solution": err,
+           "kernels": {k: {"launches": s["launches"], "total_ms": round(s["total_ms"], 3),
+                           "GBps": (round(s["bytes_per_launch"] * s["launches"] / (s["total_ms"] * 1e-3) / 1e9, 1)
+                                    if s["total_ms"] > 0 and s["bytes_per_launch"] > 0 else None)}
+                       for k, s in stats.items() if s["launches"]}}
+    print(json.dumps(out), flush=True)
+    if a.out:
+        json.dump(out, open(a.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
