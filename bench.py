@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cores", type=int, default=0)
     ap.add_argument("--homogeneous", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="extra mppgpu_set_option pairs")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -130,6 +131,7 @@ def main():
     t_setup = time.perf_counter()
     prob = build_problem(ncols_global, args.nz, col0, ncols_local, hetero=not args.homogeneous)
     opts = {"ksp_type": args.ksp, "pc_type": args.pc, "spmv_variant": args.spmv_variant}
+    opts.update(kv.split("=", 1) for kv in args.opt)
     mpp = P.to_gpu(prob, opts, device_id=local_rank)
     soe = mpp.soe
     if launched:

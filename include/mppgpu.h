@@ -104,9 +104,12 @@ int mppgpu_set_density_type(mppgpu_handle h, int density_type);
 
 /* solver selection: the PETSc options database the reference reads through SNESSetFromOptions
  * (src/mpp/mpp/MultiPhysicsProbBaseType.F90:1205).  Keys: "ksp_type" (bcgs|gmres|preonly),
- * "pc_type" (bjacobi|ilu|jacobi|none; ilu = PETSc's default ILU(0), available on vertical-only grids where it
- * coincides with the exact per-column LU), "ksp_rtol", "ksp_max_it", "snes_rtol", "snes_atol", "snes_stol",
- * "snes_max_it", "profile" (0|1: HIP-event timing of every kernel class). */
+ * "pc_type" (bjacobi|ilu|jacobi|none; ilu = PETSc's default ILU(0) in the caller's natural ordering -- on
+ * vertical-only grids it coincides with the exact per-column LU and is served by the same kernels),
+ * "ksp_rtol", "ksp_atol", "ksp_dtol", "ksp_max_it", "snes_rtol", "snes_atol", "snes_stol", "snes_max_it",
+ * "profile" (0|1: HIP-event timing of every kernel class), "problem_type" (vsfm|thermal), "cnfac" (thermal).
+ * Tuning keys (results unchanged): "spmv_variant", "assembly" (auto|general|columns), "nseg", "fused_assembly"
+ * (0|1), "fused_trials" (line-search trial points whose Jacobian is assembled together with the residual). */
 int mppgpu_set_option(mppgpu_handle h, const char *key, const char *value);
 
 /* mpp%AllocateAuxVars + mpp%SetupProblem (src/mpp/mpp/MultiPhysicsProbVSFM.F90:710-1015): builds the CSR

@@ -111,7 +111,8 @@ struct Options {
   int spmv_variant = -1;   // -1 auto: pipelined wave CSR-stream for large matrices, block CSR-stream for small ones
   int assembly = -1;       // -1 auto, 0 general kernels, 1 fused column kernels
   int nseg = 0;            // column segments per thread block row (0 = auto)
-  bool fused_assembly = true;  // F and J of the first line-search trial point in one kernel
+  bool fused_assembly = true;  // F and J of a line-search trial point in one kernel ...
+  int fused_trials = 2;        // ... for the first `fused_trials` trial points of a line search (later ones: F only)
 };
 
 struct Solver;  // all state behind a handle

@@ -928,15 +928,20 @@ struct Solver {
 
   // X (= soln), F updated in place on success; returns 0 ok / 1 failed.  Same branch structure as the oracle.
   int linesearch_bt(double *&X, double *&Fv, double *Yv, double *&Wv, double *&Gv, double &fnorm, double &xnorm,
-                    double &ynorm, bool &jac_valid) {
+                    double &ynorm, bool &jac_valid, bool xnorm_known) {
     const double alpha = 1e-4, maxstep = 1e8, minlambda = 1e-12;
     const int max_its = 40;
     double lambda = 1.0, lambdatemp, lambdaprev, gprev, g, gnorm = 0.0, wnorm2 = 0.0;
     op_spmv(Yv, Wv);  // initslope = F . (J Y)
     double r3[3];
-    dots_host({{Yv, Yv}, {X, X}, {Fv, Wv}}, r3);
-    ynorm = std::sqrt(r3[0]); xnorm = std::sqrt(r3[1]);
-    double initslope = r3[2];
+    if (xnorm_known) {  // ||X|| was reduced together with ||F(X)|| when X was the accepted trial point
+      dots_host({{Yv, Yv}, {Fv, Wv}}, r3);
+    } else {
+      dots_host({{Yv, Yv}, {Fv, Wv}, {X, X}}, r3);
+      xnorm = std::sqrt(r3[2]);
+    }
+    ynorm = std::sqrt(r3[0]);
+    double initslope = r3[1];
     if (ynorm == 0.0) return 1;
     if (ynorm > maxstep) {
       vec_waxpy(Yv, maxstep / ynorm - 1.0, Yv, Yv);  // Y *= maxstep/ynorm
@@ -948,12 +953,13 @@ struct Solver {
     if (initslope == 0.0) initslope = -1.0;
     // the first trial point is usually accepted: evaluate F and J there together; later (backtracking) trials
     // evaluate F only.  J(X) is dead once initslope is known, so the trial may overwrite the matrix values.
-    bool first_trial = true, last_fused = false;
+    int trial = 0;
+    bool last_fused = false;
     jac_valid = false;
     auto eval = [&](double lam) {
       vec_waxpy(Wv, -lam, Yv, X);
-      last_fused = first_trial && opt.fused_assembly;
-      first_trial = false;
+      last_fused = opt.fused_assembly && trial < opt.fused_trials;
+      ++trial;
       if (last_fused) op_residual_jacobian(Wv, Gv); else op_residual(Wv, Gv);
       double r2[2];
       dots_host({{Gv, Gv}, {Wv, Wv}}, r2);
@@ -1021,7 +1027,7 @@ struct Solver {
       const int kreason = ksp_solve(Fv, Yv, &its);
       *linear_its += its;
       if (kreason < 0) { reason = -3; break; }
-      const int lsfail = linesearch_bt(X, Fv, Yv, Wv, Gv, fnorm, xnorm, ynorm, jac_valid);
+      const int lsfail = linesearch_bt(X, Fv, Yv, Wv, Gv, fnorm, xnorm, ynorm, jac_valid, i > 0);
       if (lsfail) {
         reason = (opt.snes_stol * xnorm > ynorm) ? 4 : -6;
         break;
@@ -1277,7 +1283,12 @@ struct Solver {
   }
 
   void set_option(const std::string &key, const std::string &val) {
-    auto num = [&]() { return std::atof(val.c_str()); };
+    auto num = [&]() {
+      char *end = nullptr;
+      const double v = std::strtod(val.c_str(), &end);
+      if (end == val.c_str() || *end != '\0') throw Error("option '" + key + "': '" + val + "' is not a number");
+      return v;
+    };
     if (key == "ksp_type") {
       if (val == "preonly") opt.ksp_type = 0; else if (val == "gmres") opt.ksp_type = 1; else if (val == "bcgs") opt.ksp_type = 2;
       else throw Error("unknown ksp_type '" + val + "'");
@@ -1300,6 +1311,8 @@ struct Solver {
       if (val == "auto") opt.assembly = -1; else if (val == "general") opt.assembly = 0; else if (val == "columns") opt.assembly = 1;
       else throw Error("unknown assembly '" + val + "'");
     } else if (key == "nseg") opt.nseg = (int)num();
+    else if (key == "fused_assembly") opt.fused_assembly = num() != 0;
+    else if (key == "fused_trials") opt.fused_trials = (int)num();
     else if (key == "temperature") temperature = num();
     else if (key == "problem_type") {
       if (setup_done || !bcs.empty() || !sss.empty()) throw Error("problem_type must be set before conditions are added");

@@ -257,5 +257,6 @@ def test_error_paths():
     with pytest.raises(V.MPPError):
         g.soe.SetOption("pc_type", "sor")
     g.soe.SetOption("pc_type", "ilu")          # vertical-only grid: ILU(0) == exact column LU
+    P.to_gpu(P.vchannel(nx=3, ny=3, nz=4), {"pc_type": "ilu"})       # lateral connections: level-scheduled ILU(0)
     with pytest.raises(V.MPPError):
-        P.to_gpu(P.vchannel(nx=3, ny=3, nz=4), {"pc_type": "ilu"})   # lateral connections: not available yet
+        g.soe.SetOption("fused_trials", "many")
