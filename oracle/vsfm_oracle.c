@@ -5,7 +5,7 @@
  * file:line it follows (paths relative to /root/reference).  Order of floating-point
  * operations follows the reference expressions so results agree to rounding.
  */
-#include "vsfm_oracle.h"
+#include "vsfm_oracle_internal.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -15,12 +15,6 @@
 #include <omp.h>
 #endif
 
-/* MultiPhysicsProbConstants.F90:199-202 */
-#define PRESSURE_REF 101325.0
-#define GRAVITY_CONSTANT 9.80665
-#define FMWH2O 18.01534
-/* mpp_varcon.F90:17 */
-#define DENH2O 1.0e3
 
 static char g_err[512] = "";
 const char *vo_last_error(void) { return g_err; }
@@ -151,10 +145,7 @@ void vo_viscosity(double p, double t_K, double *vis, double *dvis_dp, double *dv
 /* ------------------------------------------------------------------ */
 /* Saturation functions: src/mpp/util/SaturationFunction.F90            */
 /* ------------------------------------------------------------------ */
-typedef struct {
-  int sat_func_type;  /* VG / BC / SBC (bz2,bz3 are stored as SBC: SaturationFunction.F90:291,348) */
-  double sat_res, alpha, vg_m, vg_n, bc_lambda, sbc_pu, sbc_ps, sbc_b2, sbc_b3;
-} satparams;
+/* satparams: vsfm_oracle_internal.h */
 
 /* findGu_SBC_zeroCoeff, SaturationFunction.F90:425-518 */
 static double find_gu_sbc_zero_coeff(double lambda, int AA, double gs) {
@@ -352,16 +343,7 @@ static void press_to_relperm(const satparams *s, double press, double frac_liq, 
 /* ------------------------------------------------------------------ */
 /* Auxiliary variable: src/mpp/auxvar/RichardsODEPressureAuxType.F90    */
 /* ------------------------------------------------------------------ */
-typedef struct {
-  /* state + parameters (RichardsODEPressureAuxType.F90:18-60) */
-  double pressure, temperature, frac_liq_sat, condition_value;
-  double perm[3];
-  double por_base;   /* constant porosity model only (PorosityFunctionMod.F90:99-140) */
-  satparams sp;
-  /* derived */
-  double vis, kr, sat, den, por;
-  double dpor_dP, dvis_dP, dkr_dP, dsat_dP, dden_dP, dden_dT;
-} auxvar;
+/* auxvar: vsfm_oracle_internal.h */
 
 static void auxvar_init(auxvar *a) { /* RichODEPressureAuxVarInit :77-122 */
   memset(a, 0, sizeof *a);
@@ -400,9 +382,7 @@ void vo_auxvar_compute(int sat_func_type, double sat_res, double alpha, double l
 /* ------------------------------------------------------------------ */
 /* Two-point flux: src/mpp/ge/RichardsMod.F90                           */
 /* ------------------------------------------------------------------ */
-typedef struct {
-  double area, dist_up, dist_dn, uvec[3];
-} conn_geom;
+/* conn_geom: vsfm_oracle_internal.h */
 
 /* RichardsFlux_Internal, RichardsMod.F90:118-340.  Note dflux_dP_* are the NEGATIVES of d(flux)/dP (:326-334). */
 static void richards_flux_internal(const auxvar *up, const auxvar *dn, const conn_geom *g, int compute_deriv,
@@ -502,48 +482,17 @@ void vo_richards_flux(const double *aux_up, const double *perm_up, const double 
 /* ------------------------------------------------------------------ */
 /* Problem object                                                      */
 /* ------------------------------------------------------------------ */
-typedef struct {
-  int kind, cond_type, n, swap_order;
-  int *id_dn;      /* 0-based */
-  conn_geom *geom;
-  auxvar *aux;     /* BC auxvars (aux_vars_bc) */
-  double *value;   /* SS condition values (cur_cond%value) */
-  double *flux;    /* boundary_flux / ss_flux [kg/s] */
-} condition;
+/* condition: vsfm_oracle_internal.h */
 
-struct vo_problem {
-  int n;
-  double *vol;
-  int *active;
-  auxvar *aux;          /* aux_vars_in */
-  int density_type;
-  int nc;
-  int *up, *dn;         /* 0-based */
-  conn_geom *geom;
-  double *internal_flux;
-  int nbc, nss;
-  condition *bc, *ss;
-  /* CSR pattern (sorted columns) + assembly slot tables */
-  int *rowptr, *col, *diag_slot;
-  int *slot_uu, *slot_ud, *slot_du, *slot_dd; /* per internal connection */
-  double *val;
-  /* vectors */
-  double *soln, *soln_prev, *accum_prev;
-  double dtime, time;
-  /* block-Jacobi blocks */
-  int nblocks, *block_ptr, *block_cells;
-  /* solver options (PETSc defaults) */
-  int ksp_type, pc_type;
-  double ksp_rtol, ksp_atol, ksp_dtol; int ksp_max_it, gmres_restart;
-  double snes_rtol, snes_atol, snes_stol, snes_divtol; int snes_max_it, snes_max_funcs;
-  /* counters (SolverType.F90:40-41,140-169) */
-  long cum_newton, cum_linear, cum_cuts, cum_funcs;
-  int nfuncs;
-};
+/* struct vo_problem: vsfm_oracle_internal.h */
+
+static void jacobian_assemble(vo_problem *p);
 
 vo_problem *vo_create(int ncells) {
   vo_problem *p = (vo_problem *)calloc(1, sizeof *p);
   p->n = ncells;
+  p->residual_fn = vo_residual;
+  p->jacobian_fn = jacobian_assemble;
   p->vol = (double *)calloc(ncells, sizeof(double));
   p->active = (int *)malloc(ncells * sizeof(int));
   p->aux = (auxvar *)malloc(ncells * sizeof(auxvar));
@@ -1268,7 +1217,7 @@ static int linesearch_bt(vo_problem *p, double *X, double *F, double *Y, double 
   for (;;) {
     for (int i = 0; i < n; i++) W[i] = X[i] - lambda * Y[i];
     if (p->nfuncs >= p->snes_max_funcs) { *xnorm_o = xnorm; *ynorm_o = ynorm; return 1; }
-    vo_residual(p, W, G);
+    p->residual_fn(p, W, G);
     gnorm = vnorm(n, G);
     g = gnorm * gnorm;
     if (isfinite(g)) break;
@@ -1285,7 +1234,7 @@ static int linesearch_bt(vo_problem *p, double *X, double *F, double *Y, double 
     if (lambdatemp <= .1 * lambda) lambda = .1 * lambda; else lambda = lambdatemp;
     for (int i = 0; i < n; i++) W[i] = X[i] - lambda * Y[i];
     if (p->nfuncs >= p->snes_max_funcs) { *xnorm_o = xnorm; *ynorm_o = ynorm; return 1; }
-    vo_residual(p, W, G);
+    p->residual_fn(p, W, G);
     gnorm = vnorm(n, G); g = gnorm * gnorm;
     if (!isfinite(g)) { *xnorm_o = xnorm; *ynorm_o = ynorm; return 1; }
     if (.5 * g < .5 * f + lambda * alpha * initslope) {
@@ -1306,7 +1255,7 @@ static int linesearch_bt(vo_problem *p, double *X, double *F, double *Y, double 
         if (lambdatemp <= .1 * lambda) lambda = .1 * lambda; else lambda = lambdatemp;
         for (int i = 0; i < n; i++) W[i] = X[i] - lambda * Y[i];
         if (p->nfuncs >= p->snes_max_funcs) { *xnorm_o = xnorm; *ynorm_o = ynorm; return 1; }
-        vo_residual(p, W, G);
+        p->residual_fn(p, W, G);
         gnorm = vnorm(n, G); g = gnorm * gnorm;
         if (!isfinite(g)) { *xnorm_o = xnorm; *ynorm_o = ynorm; return 1; }
         if (.5 * g < .5 * f + lambda * alpha * initslope) break;
@@ -1330,12 +1279,12 @@ static int snes_solve(vo_problem *p, double *X, int *newton_its, int *linear_its
   double ttol = 0, rnorm0 = 0, xnorm = 0, ynorm = 0;
   p->nfuncs = 0;
   *newton_its = 0; *linear_its = 0;
-  vo_residual(p, X, F);
+  p->residual_fn(p, X, F);
   double fnorm = vnorm(n, F);
   reason = snes_converged_default(p, 0, 0.0, 0.0, fnorm, &ttol, &rnorm0);
   int i;
   for (i = 0; !reason && i < p->snes_max_it; i++) {
-    jacobian_assemble(p); /* auxvars are those of the last residual evaluation, at X */
+    p->jacobian_fn(p); /* auxvars are those of the last residual evaluation, at X */
     int its;
     int kreason = ksp_solve(p, p->ksp_type, p->pc_type, p->ksp_rtol, p->rowptr, p->col, p->val, F, Y, &its);
     *linear_its += its;
@@ -1424,3 +1373,23 @@ void vo_get_counters(vo_problem *p, long *newton, long *linear, long *time_cuts,
   if (time_cuts) *time_cuts = p->cum_cuts;
   if (func_evals) *func_evals = p->cum_funcs;
 }
+
+/* ------------------------------------------------------------------ */
+/* internals exported to th_oracle.c (vsfm_oracle_internal.h)           */
+/* ------------------------------------------------------------------ */
+int vo__satparams_set(satparams *s, int type, double alpha, double lambda, double sat_res) { return satparams_set(s, type, alpha, lambda, sat_res); }
+void vo__press_to_sat(const satparams *s, double press, double *sat, double *dsat_dP) { press_to_sat(s, press, sat, dsat_dP); }
+void vo__press_to_relperm(const satparams *s, double press, double frac_liq, double *kr, double *dkr_dP) { press_to_relperm(s, press, frac_liq, kr, dkr_dP); }
+void vo__auxvar_init(auxvar *a) { auxvar_init(a); }
+void vo__auxvar_compute(auxvar *a, int density_type) { auxvar_compute(a, density_type); }
+void vo__richards_flux_internal(const auxvar *up, const auxvar *dn, const conn_geom *g, int compute_deriv, int internal_conn,
+                                int cond_type, double *flux, double *dflux_dP_up, double *dflux_dP_dn) {
+  richards_flux_internal(up, dn, g, compute_deriv, internal_conn, cond_type, flux, dflux_dP_up, dflux_dP_dn);
+}
+void vo__richards_flux(const auxvar *up, const auxvar *dn, const conn_geom *g, int compute_deriv, int internal_conn,
+                       int swap_order, int cond_type, double *flux, double *dflux_dP_up, double *dflux_dP_dn) {
+  richards_flux(up, dn, g, compute_deriv, internal_conn, swap_order, cond_type, flux, dflux_dP_up, dflux_dP_dn);
+}
+int vo__density_ifc67(double t_C, double p, double *dwmol, double *dwp, double *dwt) { return density_ifc67(t_C, p, dwmol, dwp, dwt); }
+int vo__snes_solve(vo_problem *p, double *X, int *newton_its, int *linear_its) { return snes_solve(p, X, newton_its, linear_its); }
+void vo__set_error(const char *msg) { snprintf(g_err, sizeof g_err, "%s", msg); }

@@ -19,7 +19,8 @@ _ip = ct.POINTER(ct.c_int)
 
 
 def build(force: bool = False) -> str:
-    srcs = [os.path.join(_HERE, f) for f in ("vsfm_oracle.c", "thermal_oracle.c", "vsfm_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("vsfm_oracle.c", "thermal_oracle.c", "th_oracle.c", "vsfm_oracle.h",
+                                             "vsfm_oracle_internal.h", "th_oracle.h")]
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
@@ -111,16 +112,17 @@ def richards_flux(aux_up, perm_up, aux_dn, perm_dn, area, dist_up, dist_dn, unit
 class OracleProblem:
     """Mirrors the calls the reference drivers make (vsfm_celia1990_problem.F90:106-137)."""
 
-    def __init__(self, ncells: int):
+    def __init__(self, ncells: int, handle=None):
         self.L = lib()
         self.n = int(ncells)
-        self.h = ct.c_void_p(self.L.vo_create(self.n))
+        self._owned = handle is None      # a borrowed handle belongs to a THOracle (oracle/th_oracle.py)
+        self.h = ct.c_void_p(self.L.vo_create(self.n)) if handle is None else handle
         self._keep = []
 
     def close(self):
-        if self.h:
+        if self.h and self._owned:
             self.L.vo_destroy(self.h)
-            self.h = None
+        self.h = None
 
     def __del__(self):
         try:

@@ -348,3 +348,102 @@ def to_thermal_gpu(tp: ThermalProblem, options=None, device_id=0):
     mpp.soe.SetRDataFromCLM(C.AUXVAR_SS, C.VAR_BC_SS_CONDITION, 1, tp.heat_source)
     mpp.soe.PreStepDT()
     return mpp
+
+
+# ======================================================================================================
+# coupled thermal-hydrology: Richards mass equation + enthalpy-based heat equation
+# ======================================================================================================
+@dataclass
+class THProblem:
+    name: str
+    mesh: M.Mesh
+    # mass equation (goveqn_richards_ode_pressure_type)
+    perm: np.ndarray
+    por: np.ndarray
+    satfunc_type: np.ndarray
+    alpha: np.ndarray
+    lam: np.ndarray
+    sat_res: np.ndarray
+    density_type: int
+    ie_type: int
+    # heat equation (goveqn_thermal_enthalpy_soil_type)
+    heat_cap: np.ndarray
+    tcond_wet: np.ndarray
+    tcond_dry: np.ndarray
+    talpha: np.ndarray
+    den_soil: np.ndarray
+    energy_perm: object = None          # None: the auxvar default 8.3913e-12 (MPPTHSetSoils never sets it)
+    press_ic: np.ndarray = None
+    temp_ic: np.ndarray = None
+    mass_bcs: list = field(default_factory=list)     # [(cond_type, ConnectionSet, values, bc_temperature or None)]
+    mass_sss: list = field(default_factory=list)     # [(cond_type, ConnectionSet, values)]
+    energy_bcs: list = field(default_factory=list)   # [(cond_type, ConnectionSet, values, bc_pressure)]
+    energy_sss: list = field(default_factory=list)
+    dt: float = 3600.0
+    nstep: int = 1
+
+
+def mass_and_heat(nx=100) -> THProblem:
+    """src/driver/standalone/thermal-e/mass_and_heat_model_problem.F90: nx x 1 x 1 cells along x (no gravity term),
+    VG + IFC67 density + IFC67 enthalpy, P = 91325 Pa, T = 283.15 K initially, heat equation held at 303.15 K / 293.15 K
+    at the two ends (with boundary pressure 91325 Pa), no condition on the mass equation, one step of 3600 s."""
+    m = M.mesh_create("Soil mesh", 1.0, 1.0, 1.0, nx, 1, 1, C.CONN_IN_X_DIR)
+    n = m.ncells_local
+    dx = 1.0 / nx
+    perm_eff, alpha_eff, lam_eff = clm_soil_conversion(8.3913e-12, 3.4257e-4, 0.5, C.GRAVITY_CONSTANT)  # :361-366; MPPTH :505-513
+
+    def end_face(cell, ux):
+        return M.ConnectionSet(np.array([0]), np.array([cell]), np.array([0.0]), np.array([0.5 * dx]), np.array([1.0 * 1.0]),
+                               np.array([[ux, 0.0, 0.0]]))
+    return THProblem(
+        name="mass_and_heat", mesh=m, perm=np.full((n, 3), perm_eff), por=np.full(n, 0.368),
+        satfunc_type=np.full(n, C.SAT_FUNC_VAN_GENUCHTEN, dtype=np.int32), alpha=np.full(n, alpha_eff),
+        lam=np.full(n, lam_eff), sat_res=np.full(n, 0.2772), density_type=C.DENSITY_IFC67, ie_type=2,
+        heat_cap=np.full(n, 837.0), tcond_wet=np.full(n, 1.3), tcond_dry=np.full(n, 0.25), talpha=np.full(n, 0.45),
+        den_soil=np.full(n, 2700.0), press_ic=np.full(n, 91325.0), temp_ic=np.full(n, 283.15),
+        energy_bcs=[(C.COND_DIRICHLET, end_face(1, 1.0), np.array([303.15]), np.array([91325.0])),
+                    (C.COND_DIRICHLET, end_face(nx, -1.0), np.array([293.15]), np.array([91325.0]))],
+        dt=3600.0, nstep=1)
+
+
+def to_th_oracle(tp: THProblem, ksp_rtol=0.0):
+    from oracle import th_oracle as TO
+    o = TO.THOracle(tp.mesh.ncells_local)
+    ms = o.mass
+    ms.set_mesh(tp.mesh.vol, tp.mesh.is_active)
+    ms.set_connections(tp.mesh.intrn_conn_sets[0])
+    for bc in tp.mass_bcs:
+        ms.add_condition(C.COND_BC, bc[0], bc[1])
+    for ss in tp.mass_sss:
+        ms.add_condition(C.COND_SS, ss[0], ss[1])
+    for bc in tp.energy_bcs:
+        o.energy_add_condition(C.COND_BC, bc[0], bc[1])
+    for ss in tp.energy_sss:
+        o.energy_add_condition(C.COND_SS, ss[0], ss[1])
+    ms.set_soil_permeability(tp.perm[:, 0], tp.perm[:, 1], tp.perm[:, 2])
+    ms.set_soil_porosity(tp.por)
+    ms.set_saturation_function(tp.satfunc_type, tp.alpha, tp.lam, tp.sat_res)
+    o.set_eos(tp.density_type, tp.ie_type)
+    o.energy_set_soils(tp.por, tp.satfunc_type, tp.alpha, tp.lam, tp.sat_res, tp.heat_cap, tp.tcond_wet, tp.tcond_dry,
+                       tp.talpha, tp.den_soil, perm=tp.energy_perm)
+    o.setup()
+    o.restart(tp.press_ic, tp.temp_ic)
+    if ksp_rtol:
+        o.glob.set_solver(C.KSP_GMRES, C.PC_ILU0, ksp_rtol=ksp_rtol)
+    th_set_conditions(tp, o)
+    return o
+
+
+def th_set_conditions(tp: THProblem, o):
+    """what the reference drivers do before every StepDT (set_bondary_conditions / set_source_sink_conditions)"""
+    for i, bc in enumerate(tp.mass_bcs):
+        o.mass.set_condition_values(C.COND_BC, i + 1, bc[2])
+        if len(bc) > 3 and bc[3] is not None:
+            o.mass_set_bc_temperature(i + 1, bc[3])
+    for i, ss in enumerate(tp.mass_sss):
+        o.mass.set_condition_values(C.COND_SS, i + 1, ss[2])
+    for i, bc in enumerate(tp.energy_bcs):
+        o.energy_set_condition_values(C.COND_BC, i + 1, bc[2])
+        o.energy_set_bc_pressure(i + 1, bc[3])
+    for i, ss in enumerate(tp.energy_sss):
+        o.energy_set_condition_values(C.COND_SS, i + 1, ss[2])

@@ -78,3 +78,47 @@ def test_celia_extruded_columns_identical():
     ref = p1.get(C.AUXVAR_INTERNAL, C.VAR_PRESSURE)
     for c in range(3):
         np.testing.assert_allclose(pr[c], ref, rtol=1e-9)
+
+
+# ------------------------------------------------------------------------------------------------------
+# coupled thermal-hydrology
+# ------------------------------------------------------------------------------------------------------
+def test_th_mass_and_heat_baseline(golden_dir):
+    """regression_tests/th/mass_and_heat: Richards + enthalpy-based heat equation, IFC67 density and enthalpy,
+    100 cells along x, one 3600 s step through Newton + GMRES(30) + ILU(0) on the 2N x 2N field-blocked system.
+    Every printed value (13 significant digits) of both fields."""
+    gold = parse_regression_file(os.path.join(golden_dir, "mass_and_heat.regression.baseline"))
+    tp = P.mass_and_heat()
+    o = P.to_th_oracle(tp)
+    conv, reason = o.step_dt(tp.dt)
+    assert conv and reason > 0
+    p, t = o.solution()
+    for name, data in (("liquid_pressure", p), ("temperature", t)):
+        st = P.regression_stats(data, 5)
+        g = gold[name]
+        for key in ("min", "max", "mean"):
+            assert st[key] == pytest.approx(g[key], rel=2e-13), (name, key)
+        for cell, v in st["cells"].items():
+            assert v == pytest.approx(g["cell %d" % cell], rel=2e-13), (name, cell)
+    assert o.counters()["newton"] == 3
+
+
+def test_th_jacobian_is_the_derivative_of_the_residual():
+    """all four blocks of the restated TH Jacobian against central differences of the restated residual (the
+    reference's own analytic blocks: d(mass)/dP, d(mass)/dT, d(energy)/dP, d(energy)/dT)"""
+    tp = P.mass_and_heat(nx=12)
+    o = P.to_th_oracle(tp)
+    o.set_dtime(tp.dt); o.pre_solve()
+    n = tp.mesh.ncells_local
+    rng = np.random.default_rng(3)
+    x = np.concatenate([tp.press_ic + rng.uniform(-2e4, 3e4, n), tp.temp_ic + rng.uniform(0, 20, n)])
+    rp, cj, val = o.jacobian(x)
+    J = np.zeros((2 * n, 2 * n))
+    for i in range(2 * n):
+        J[i, cj[rp[i]:rp[i + 1]]] = val[rp[i]:rp[i + 1]]
+    for j in range(2 * n):
+        h = 1.0 if j < n else 1e-3
+        e = np.zeros(2 * n); e[j] = h
+        fd = (o.residual(x + e) - o.residual(x - e)) / (2 * h)
+        scale = np.abs(J[:, j]).max()
+        assert np.abs(fd - J[:, j]).max() <= 2e-5 * scale, j
