@@ -38,6 +38,17 @@
 #define H2O_CRITICAL_TEMPERATURE 647.3   /* EOSWaterMod.F90 */
 #define H2O_CRITICAL_PRESSURE 22.064e6
 
+/* x**m with an INTEGER exponent as gfortran evaluates it (libgcc __powidf2: binary exponentiation) -- not pow() */
+static double powi(double x, int m) {
+  unsigned n = m < 0 ? -(unsigned)m : (unsigned)m;
+  double y = (n % 2) ? x : 1.0;
+  while (n >>= 1) {
+    x = x * x;
+    if (n % 2) y *= x;
+  }
+  return m < 0 ? 1.0 / y : y;
+}
+
 /* EnthalpyIFC67, EOSWaterMod.F90:346-566 (t in centigrade, p in Pa; hw J/kmol) */
 static void enthalpy_ifc67(double t, double p, double *hw, double *hwp, double *hwt) {
   static const double aa[23] = {
@@ -70,7 +81,7 @@ static void enthalpy_ifc67(double t, double p, double *hw, double *hwp, double *
   double term2 = -aa[1];
   double term2t = 0.0;
   for (int i = 3; i <= 10; i++) {
-    double tempreal = (double)(i - 2) * aa[i] * pow(theta, (double)(i - 1));  /* theta**(i-1): integer power */
+    double tempreal = (double)(i - 2) * aa[i] * powi(theta, i - 1);  /* theta**(i-1): integer power */
     term2t = term2t + tempreal * utheta * (double)(i - 1);
     term2 = term2 + tempreal;
   }

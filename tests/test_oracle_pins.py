@@ -122,3 +122,25 @@ def test_th_jacobian_is_the_derivative_of_the_residual():
         fd = (o.residual(x + e) - o.residual(x - e)) / (2 * h)
         scale = np.abs(J[:, j]).max()
         assert np.abs(fd - J[:, j]).max() <= 2e-5 * scale, j
+
+
+def test_th_mms_baseline(golden_dir):
+    """regression_tests/th/th_mms: manufactured steady P and T with Dirichlet ends and sources on both equations.
+    Pressure: every printed digit.  Temperature: <= 1e-9 K -- the reference's manufactured heat source differentiates
+    the IFC67 enthalpy by a 1e-6 central difference, which amplifies last-bit differences of the enthalpy evaluation
+    (sin/pow library bits) ~1e6 times; the reference's own tolerance for this test is 1e-8 K (th.cfg)."""
+    gold = parse_regression_file(os.path.join(golden_dir, "th_mms.regression.baseline"))
+    tp = P.th_mms()
+    o = P.to_th_oracle(tp)
+    conv, reason = o.step_dt(tp.dt)
+    assert conv and reason > 0
+    p, t = o.solution()
+    sp, stt = P.regression_stats(p, 5), P.regression_stats(t, 5)
+    for key in ("min", "max", "mean"):
+        assert sp[key] == pytest.approx(gold["liquid_pressure"][key], rel=2e-13), key
+        assert stt[key] == pytest.approx(gold["temperature"][key], abs=1e-9), key
+    for cell, v in sp["cells"].items():
+        assert v == pytest.approx(gold["liquid_pressure"]["cell %d" % cell], rel=2e-13), cell
+    for cell, v in stt["cells"].items():
+        assert v == pytest.approx(gold["temperature"]["cell %d" % cell], abs=1e-9), cell
+    assert o.counters()["newton"] == 10
