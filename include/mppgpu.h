@@ -37,6 +37,7 @@ typedef struct mppgpu_handle_s *mppgpu_handle;
 #define MPPGPU_COND_SEEPAGE_BC 509
 #define MPPGPU_COND_HEAT_RATE 511
 #define MPPGPU_VAR_PRESSURE 604
+#define MPPGPU_VAR_TEMPERATURE 605
 #define MPPGPU_VAR_BC_SS_CONDITION 607
 #define MPPGPU_VAR_LIQ_SAT 608
 #define MPPGPU_VAR_MASS 610
@@ -54,6 +55,9 @@ typedef struct mppgpu_handle_s *mppgpu_handle;
 #define MPPGPU_AUXVAR_BC 702
 #define MPPGPU_AUXVAR_SS 703
 #define MPPGPU_AUXVAR_CONN_INTERNAL 704
+/* EOSWaterMod.F90:23-24 */
+#define MPPGPU_INT_ENERGY_ENTHALPY_CONSTANT 1
+#define MPPGPU_INT_ENERGY_ENTHALPY_IFC67 2
 /* SaturationFunction.F90:19-23 */
 #define MPPGPU_SAT_FUNC_VAN_GENUCHTEN 1301
 #define MPPGPU_SAT_FUNC_BROOKS_COREY 1302
@@ -155,6 +159,38 @@ int mppgpu_jacobian(mppgpu_handle h, const double *x, int *rowptr, int *col, dou
 int mppgpu_spmv(mppgpu_handle h, const double *x, double *y);
 int mppgpu_pc_apply(mppgpu_handle h, const double *r, double *z);
 int mppgpu_ksp_solve(mppgpu_handle h, const double *b, double *x, int *its, int *reason);
+
+/* ------------------------------------------------------------------------------------------------
+ * coupled thermal-hydrology: sysofeqns_th_type with goveqn_richards_ode_pressure_type (equation 1) and
+ * goveqn_thermal_enthalpy_soil_type (equation 2) on one mesh, coupled through their internal auxvars
+ * (src/mpp/soe/SystemOfEquationsTHType.F90:736-1003; src/mpp/ge/GoveqnThermalEnthalpySoilType.F90:1060-2376;
+ * src/mpp/ge/GoveqnRichardsODEPressureType.F90:2473-2612).  Select with mppgpu_set_option(h, "problem_type", "th")
+ * before conditions are added.  Unknowns, residuals and the Jacobian are field-blocked [P(1..N); T(1..N)] (the
+ * reference's DMComposite order): mppgpu_restart, mppgpu_residual, mppgpu_jacobian, mppgpu_spmv, mppgpu_pc_apply and
+ * mppgpu_ksp_solve take / return 2N values and a 2N x 2N CSR; mppgpu_step_dt solves the coupled system;
+ * mppgpu_get_data(AUXVAR_INTERNAL, VAR_PRESSURE | VAR_TEMPERATURE) returns one field.  Mesh, connections, mass-equation
+ * soils (mppgpu_set_soil_*, shared by both equations as in MPPTHSetSoils, MultiPhysicsProbTH.F90:75-176) and
+ * mppgpu_set_density_type are the VSFM calls; "int_energy_enthalpy_type" (1 constant | 2 IFC67) is an option.
+ * Preconditioners: ilu (PETSc's default), jacobi, none.
+ * ---------------------------------------------------------------------------------------------- */
+/* soe%AddConditionInGovEqn(igoveqn, ...) (SystemOfEquationsBaseType.F90:1260-1290): igoveqn 1 = mass, 2 = heat.
+ * Heat equation: COND_DIRICHLET boundaries and COND_HEAT_RATE sources (the reference aborts on any other boundary type,
+ * GoveqnThermalEnthalpySoilType.F90:1008-1012).  *cond_id is the SoE-level id (mass-equation conditions are numbered
+ * before heat-equation ones, as sysofeqns_th_type does) -- an id returned earlier for a heat-equation condition moves up
+ * by one when a mass-equation condition of the same kind is added after it: add the mass equation's conditions first. */
+int mppgpu_th_add_condition(mppgpu_handle h, int igoveqn, int kind, int cond_type, int nconn, const int *id_dn,
+                            const double *dist_up, const double *dist_dn, const double *area, const double *unit_vec,
+                            int swap_order, int *cond_id);
+/* heat-equation material: ThermEnthalpySetHeatCapacity / ThermalCondWet / ThermalCondDry / ThermalAlpha /
+ * SetSoilDensity / SetSoilPermeability (GoveqnThermalEnthalpySoilType.F90:2454-2700) or the constants MPPTHSetSoils
+ * writes (MultiPhysicsProbTH.F90:331-335).  perm_* may be NULL: the auxvar default 8.3913e-12 m^2 stays
+ * (ThermalEnthalpySoilAuxType.F90:93), which is what MPPTHSetSoils leaves in place. */
+int mppgpu_th_set_soils(mppgpu_handle h, const double *heat_cap, const double *therm_cond_wet, const double *therm_cond_dry,
+                        const double *therm_alpha, const double *den_soil, const double *perm_x, const double *perm_y,
+                        const double *perm_z);
+/* The other field of a boundary auxvar is set with mppgpu_set_data(h, AUXVAR_BC, VAR_TEMPERATURE, id, ...) for a
+ * mass-equation boundary (default 298.15 K) and (AUXVAR_BC, VAR_PRESSURE, id, ...) for a heat-equation boundary --
+ * the reference drivers assign aux_vars_bc(:)%temperature / %pressure directly (th_mms_problem.F90:846-875). */
 
 /* ------------------------------------------------------------------------------------------------
  * thermal KSP path: soil heat diffusion, linear solve per step -- sysofeqns_thermal_type with one

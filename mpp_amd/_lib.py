@@ -53,6 +53,8 @@ SIGNATURES = {
     "mppgpu_thermal_get_soln": (ct.c_int, [_h, ct.c_int, _dp]),
     "mppgpu_thermal_compute_rhs": (ct.c_int, [_h, ct.c_double, _dp]),
     "mppgpu_thermal_compute_operators": (ct.c_int, [_h, ct.c_double, _ip, _ip, _dp]),
+    "mppgpu_th_add_condition": (ct.c_int, [_h, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _ip, _dp, _dp, _dp, _dp, ct.c_int, _ip]),
+    "mppgpu_th_set_soils": (ct.c_int, [_h, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
     "mppgpu_kernel_stats": (ct.c_int, [_h, ct.c_char_p, _llp, _dp, _dp]),
     "mppgpu_reset_stats": (ct.c_int, [_h]),
     "mppgpu_bench_kernel": (ct.c_int, [_h, ct.c_char_p, ct.c_int, ct.c_int, _dp, _dp]),

@@ -141,6 +141,40 @@ struct ThermalBcArgs {
 };
 void launch_thermal_bc(int mode, const ThermalBcArgs &a, hipStream_t stream);
 
+// ---- coupled thermal-hydrology: [P(1..N); T(1..N)] unknowns, 2N x 2N CSR, see th_kernels.hip ----
+struct ThArgs {
+  int n;                                   // cells
+  const double *x;                         // state the kernels evaluate at: [P; T], internal cell order
+  const double *por, *sat_res, *alpha, *m, *vol;           // soil shared by both equations
+  const double *sbc_pu, *sbc_ps, *sbc_b2, *sbc_b3;         // smoothed Brooks-Corey only
+  const signed char *active;                                // nullptr = every cell active
+  const double *tc_wet, *tc_dry, *talpha, *heat_cap, *den_soil;
+  int sat_func, density_type, ie_type;
+  // auxvars stored by pass 1 for passes 2 and 3
+  double *kr, *dkr, *den_m, *ddenP_m, *ddenT_m, *den_e, *ddenP_e, *ddenT_e, *hl, *dhl_dP, *dhl_dT, *tc, *dtc_dP;
+  // internal connections
+  const int *cup, *cdn, *rc_ptr, *rc_conn, *rc_slot;
+  const int *crowptr, *cdiag;              // the mesh (cell) pattern: row pointer and absolute diagonal slots
+  const double *Dq_m, *Dq_e, *upw, *dgrav, *area, *cdu, *cdd;
+  const double *accum_prev;                // [mass; heat]
+  const double *src;                       // [mass-rate kmol/s; heat-rate W] dense, or nullptr
+  double *F;                               // [mass; heat]
+  double *val;                             // values of the 2N x 2N CSR
+  int nnzc;                                // entries of the cell pattern
+  double dtInv;
+};
+struct ThBcArgs {
+  ThArgs t;
+  int ncond_cells;
+  const int *cc_cell, *cc_ptr;
+  const int *type;                         // cond_type | swap_order << 16 | (1 << 20 for the heat equation)
+  const double *Dq, *dgrav, *area, *du, *dd;
+  const double *value;                     // condition value (pressure / temperature)
+  const double *other;                     // the other field at the boundary auxvar (temperature / pressure)
+};
+// mode 0 residual, 2 residual + Jacobian, 3 PreSolve (accumulation terms into F)
+void launch_th_assemble(int mode, const ThBcArgs &b, hipStream_t stream);
+
 // ---- vectors (device scalars in `sc`) ----
 void launch_copy(int n, const double *x, double *y, hipStream_t stream);
 void launch_set(int n, double v, double *y, hipStream_t stream);

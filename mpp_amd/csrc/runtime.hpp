@@ -95,8 +95,10 @@ struct Comm {
 
 struct Condition {
   int kind = 0, cond_type = 0, swap_order = 0, n = 0;
+  int eqn = 0;                         // coupled TH: 0 mass equation, 1 heat equation
   std::vector<int> cell;               // external 0-based
   std::vector<double> dist_up, dist_dn, area, uvec, value;
+  std::vector<double> other;           // coupled TH: temperature (mass eqn) / pressure (heat eqn) of the boundary auxvar
   int offset = 0;                      // first entry in the concatenated BC (or SS) numbering
 };
 

@@ -64,6 +64,7 @@ struct Solver {
 
   // ---------------- staging, caller's ordering, 0-based ----------------
   int n = 0, nlev = 0;
+  int nrow = 0;   // unknowns = rows of the linear system: n, or 2n for the coupled thermal-hydrology system [P; T]
   std::vector<double> vol;
   std::vector<int> active;
   bool any_inactive = false;
@@ -122,6 +123,16 @@ struct Solver {
   DevBuf<signed char> d_bc_act;
   std::vector<double> h_bc_frac, h_bc_dhsdT;
   std::vector<signed char> h_bc_act;
+  // ---------------- coupled thermal-hydrology ----------------
+  bool th = false;
+  int ie_type = 1;                    // INT_ENERGY_ENTHALPY_CONSTANT (ThermEnthalpyAuxVarInit :97)
+  std::vector<double> the_heat_cap, the_tcw, the_tcd, the_talpha, the_dsoil, the_permx, the_permy, the_permz;
+  std::vector<int> hc_rowptr, hc_diag;   // the mesh (cell) pattern; h_rowptr / h_col / h_diag hold the 2N x 2N one
+  int nnzc = 0;
+  DevBuf<int> d_crowptr, d_cdiag;
+  DevBuf<double> d_tcw, d_tcd, d_talpha, d_hcap, d_dsoil, d_Dq_e, d_bc_other, th_scratch;
+  DevBuf<double> tha[13];
+  std::vector<double> h_bc_other;
   // ---------------- ILU(0) ----------------
   DevBuf<int> d_ord, d_lrows, d_urows;
   std::vector<int> h_lptr, h_uptr;
@@ -172,24 +183,31 @@ struct Solver {
     cdu.assign(du, du + nc); cdd.assign(dd, dd + nc); carea.assign(ar, ar + nc); cuv.assign(uv, uv + 3 * (size_t)nc);
   }
 
+  // igoveqn: 1 = the (only, or mass) equation, 2 = the heat equation of the coupled thermal-hydrology system
   int add_condition(int kind, int cond_type, int nconn, const int *id_dn, const double *du, const double *dd,
-                    const double *ar, const double *uv, int swap_order) {
+                    const double *ar, const double *uv, int swap_order, int igoveqn = 1) {
     need_setup(false);
     if (n == 0) throw Error("mppgpu_set_mesh must precede mppgpu_add_condition");
+    if (igoveqn != 1 && !(th && igoveqn == 2)) throw Error("no governing equation " + std::to_string(igoveqn));
+    const bool heat = thermal || igoveqn == 2;
     std::vector<Condition> *list;
     if (kind == MPPGPU_COND_BC) {
-      const bool ok = thermal ? (cond_type == MPPGPU_COND_DIRICHLET || cond_type == MPPGPU_COND_HEAT_FLUX)
-                              : (cond_type == MPPGPU_COND_DIRICHLET || cond_type == MPPGPU_COND_SEEPAGE_BC ||
-                                 cond_type == MPPGPU_COND_MASS_FLUX);
+      bool ok;
+      if (thermal) ok = (cond_type == MPPGPU_COND_DIRICHLET || cond_type == MPPGPU_COND_HEAT_FLUX);
+      else if (heat) ok = (cond_type == MPPGPU_COND_DIRICHLET);   // ThermEnthalpySoilUpdateAuxVarsBC aborts on others (GE :964-1017)
+      else ok = (cond_type == MPPGPU_COND_DIRICHLET || cond_type == MPPGPU_COND_SEEPAGE_BC || cond_type == MPPGPU_COND_MASS_FLUX);
       if (!ok) throw Error("unsupported boundary cond_type " + std::to_string(cond_type));
       list = &bcs;
     } else if (kind == MPPGPU_COND_SS) {
-      if (cond_type != (thermal ? MPPGPU_COND_HEAT_RATE : MPPGPU_COND_MASS_RATE))
+      if (cond_type != (heat ? MPPGPU_COND_HEAT_RATE : MPPGPU_COND_MASS_RATE))
         throw Error("unsupported source-sink cond_type " + std::to_string(cond_type));
       list = &sss;
     } else throw Error("unknown condition kind " + std::to_string(kind));
     Condition c;
     c.kind = kind; c.cond_type = cond_type; c.swap_order = swap_order ? 1 : 0; c.n = nconn;
+    c.eqn = igoveqn - 1;
+    // boundary auxvar defaults: temperature 298.15 K (RichODEPressureAuxVarInit :91), pressure 0 (:90)
+    c.other.assign(nconn, c.eqn == 0 ? 273.15 + 25.0 : 0.0);
     c.cell.resize(nconn);
     for (int i = 0; i < nconn; ++i) {
       if (id_dn[i] < 1 || id_dn[i] > n) throw Error("condition: cell id out of range");
@@ -200,8 +218,12 @@ struct Solver {
       c.uvec.assign(uv, uv + 3 * (size_t)nconn);
     }
     c.value.assign(nconn, 0.0);
-    list->push_back(std::move(c));
-    return (int)list->size();
+    // the SoE numbers conditions equation by equation (mass first): keep the list in that order
+    auto pos = list->end();
+    if (th && c.eqn == 0) pos = std::find_if(list->begin(), list->end(), [](const Condition &q) { return q.eqn == 1; });
+    const int id = (int)(pos - list->begin()) + 1;
+    list->insert(pos, std::move(c));
+    return id;
   }
 
   void set_perm(const double *px, const double *py, const double *pz) {
@@ -339,6 +361,7 @@ struct Solver {
     need_setup(false);
     if (n == 0) throw Error("mppgpu_set_mesh has not been called");
     HIP_CHECK(hipSetDevice(device));
+    nrow = th ? 2 * n : n;
     detect_columns();
     build_pattern();
     d_ext2int.upload(ext2int, stream);
@@ -364,7 +387,7 @@ struct Solver {
       d_cup.upload(up, stream); d_cdn.upload(dn, stream);
     }
     // per-row incident connection lists, in the caller's connection order (general kernels only)
-    if (!vertical_only || opt.assembly == 0 || thermal) {
+    if (!vertical_only || opt.assembly == 0 || thermal || th) {
       std::vector<int> ptr((size_t)n + 1, 0);
       for (int c = 0; c < nc; ++c) { ptr[ext2int[cup_e[c]] + 1]++; ptr[ext2int[cdn_e[c]] + 1]++; }
       for (int i = 0; i < n; ++i) ptr[i + 1] += ptr[i];
@@ -389,7 +412,7 @@ struct Solver {
           }
       }
       d_tri_lo.upload(lo, stream); d_tri_up.upload(up, stream);
-      tri_l.alloc(n); tri_invb.alloc(n); tri_c.alloc(n); jac_invd.alloc(n);
+      tri_l.alloc(n); tri_invb.alloc(n); tri_c.alloc(n); jac_invd.alloc(nrow);
     }
     // boundary conditions: entries grouped by cell, (condition, connection) order kept inside a cell
     nb = 0;
@@ -406,7 +429,7 @@ struct Solver {
       for (auto &c : bcs)
         for (int i = 0; i < c.n; ++i) {
           key[c.offset + i] = {ext2int[c.cell[i]], c.offset + i};
-          gtype[c.offset + i] = c.cond_type | (c.swap_order << 16);
+          gtype[c.offset + i] = c.cond_type | (c.swap_order << 16) | (c.eqn << 20);
         }
       std::sort(key.begin(), key.end());
       std::vector<int> cc_cell, cc_ptr, type(nb);
@@ -423,16 +446,16 @@ struct Solver {
       d_bc_flux.alloc(nb); d_bc_flux.zero(stream);
       d_bc_Dq.alloc(nb); d_bc_dgrav.alloc(nb); d_bc_area.alloc(nb);
     }
-    if (ns > 0) { d_src.alloc(n); d_src.zero(stream); has_src = true; }
+    if (ns > 0) { d_src.alloc(nrow); d_src.zero(stream); has_src = true; }
     // vectors
     for (DevBuf<double> *b : {&soln, &soln_prev, &accum_prev, &F, &Y, &W, &G, &R, &RP, &V, &T, &S, &Pv, &Wk, &tmp_ext, &tmp_int}) {
-      b->alloc(n); b->zero(stream);
+      b->alloc(nrow); b->zero(stream);
     }
     partials.alloc((size_t)kMaxPartialBlocks * kMaxMultiDot);
     sc.alloc(S_COUNT); sc.zero(stream);
     HIP_CHECK(hipHostMalloc(&h_sc, S_COUNT * sizeof(double), hipHostMallocDefault));
     d_Dq.alloc(nc_int); d_upw.alloc(nc_int); d_dgrav.alloc(nc_int); d_area.alloc(nc_int);
-    if (thermal) {
+    if (thermal || th) {
       std::vector<double> du(nc_int, 0.0), dd(nc_int, 0.0), ar(nc_int, 0.0);
       for (int c = 0; c < nc; ++c) { du[cext2int[c]] = cdu[c]; dd[cext2int[c]] = cdd[c]; ar[cext2int[c]] = carea[c]; }
       d_cdu.upload(du, stream); d_cdd.upload(dd, stream); d_carea.upload(ar, stream);
@@ -443,6 +466,9 @@ struct Solver {
           bdu[e] = cd.dist_up[i]; bdd[e] = cd.dist_dn[i]; bar[e] = cd.area[i];
         }
       d_bc_du.upload(bdu, stream); d_bc_dd.upload(bdd, stream); d_bc_rawarea.upload(bar, stream);
+    }
+    if (th) th_setup();
+    if (thermal) {
       h_bc_frac.assign(nb, 1.0); h_bc_dhsdT.assign(nb, 0.0); h_bc_act.assign(nb, 1);
       d_bc_frac.upload(h_bc_frac, stream); d_bc_dhsdT.upload(h_bc_dhsdT, stream);
       d_bc_act.upload(h_bc_act.data(), h_bc_act.size(), stream);
@@ -454,6 +480,33 @@ struct Solver {
     setup_done = true;
     soil_dirty = true;
     check_ilu();
+  }
+
+  // coupled thermal-hydrology: the 2N x 2N pattern (four blocks with the mesh pattern, rows [P(1..N); T(1..N)]),
+  // the per-cell auxvar store and the boundary "other field" array
+  void th_setup() {
+    hc_rowptr = h_rowptr; hc_diag = h_diag; nnzc = nnz;
+    const std::vector<int> ccol = h_col;
+    d_crowptr.upload(hc_rowptr, stream); d_cdiag.upload(hc_diag, stream);
+    h_rowptr.assign((size_t)nrow + 1, 0); h_col.assign(4 * (size_t)nnzc, 0); h_diag.assign(nrow, 0);
+    int k = 0;
+    for (int r = 0; r < nrow; ++r) {
+      const int i = r < n ? r : r - n;
+      h_rowptr[r] = k;
+      for (int q = hc_rowptr[i]; q < hc_rowptr[i + 1]; ++q) { if (r < n && q == hc_diag[i]) h_diag[r] = k; h_col[k++] = ccol[q]; }
+      for (int q = hc_rowptr[i]; q < hc_rowptr[i + 1]; ++q) { if (r >= n && q == hc_diag[i]) h_diag[r] = k; h_col[k++] = n + ccol[q]; }
+    }
+    h_rowptr[nrow] = k;
+    nnz = k; max_row_nnz *= 2;
+    d_rowptr.upload(h_rowptr, stream); d_col.upload(h_col, stream); d_diag.upload(h_diag, stream);
+    d_val.alloc(nnz); d_val.zero(stream);
+    for (auto &b : tha) { b.alloc(n); b.zero(stream); }
+    th_scratch.alloc(nrow);
+    d_Dq_e.alloc(nc_int);
+    h_bc_other.assign(nb, 0.0);
+    for (auto &cd : bcs)
+      for (int i = 0; i < cd.n; ++i) h_bc_other[bc_pos_of_g[cd.offset + i]] = cd.other[i];
+    d_bc_other.upload(h_bc_other, stream);
   }
 
   // soil parameters + connection geometry -> device (lazy: the reference sets soils after SetupProblem)
@@ -504,10 +557,67 @@ struct Solver {
           const int e = bc_pos_of_g[cd.offset + i];
           Dq[e] = g.Dq; dg[e] = g.dist_gravity; ar[e] = g.area;
         }
+      if (th) {  // heat-equation boundaries see the heat equation's own permeability
+        for (auto &cd : bcs) {
+          if (cd.eqn != 1) continue;
+          for (int i = 0; i < cd.n; ++i) {
+            const int cell = cd.cell[i];
+            double pp[3];
+            th_energy_perm(cell, pp);
+            ConnGeom g = make_conn_geom(false, cd.area[i], cd.dist_up[i], cd.dist_dn[i], &cd.uvec[3 * (size_t)i], pp, pp);
+            Dq[bc_pos_of_g[cd.offset + i]] = g.Dq;
+          }
+        }
+      }
       d_bc_Dq.upload(Dq, stream); d_bc_dgrav.upload(dg, stream); d_bc_area.upload(ar, stream);
+    }
+    if (th) {
+      if ((int)the_heat_cap.size() != n) throw Error("heat-equation soil properties are not set (mppgpu_th_set_soils)");
+      std::vector<double> Dq(nc_int, 0.0);
+      for (int cidx = 0; cidx < nc; ++cidx) {
+        double pu[3], pd[3];
+        th_energy_perm(cup_e[cidx], pu); th_energy_perm(cdn_e[cidx], pd);
+        Dq[cext2int[cidx]] = make_conn_geom(true, carea[cidx], cdu[cidx], cdd[cidx], &cuv[3 * (size_t)cidx], pu, pd).Dq;
+      }
+      d_Dq_e.upload(Dq, stream);
+      auto perm_d = [&](const std::vector<double> &v, DevBuf<double> &d) {
+        std::vector<double> t(n);
+        for (int i = 0; i < n; ++i) t[i] = v[int2ext[i]];
+        d.upload(t, stream);
+      };
+      perm_d(the_heat_cap, d_hcap); perm_d(the_tcw, d_tcw); perm_d(the_tcd, d_tcd); perm_d(the_talpha, d_talpha);
+      perm_d(the_dsoil, d_dsoil);
     }
     HIP_CHECK(hipStreamSynchronize(stream));
     soil_dirty = false;
+  }
+  // permeability of the heat equation's auxvars: 8.3913e-12 unless set (ThermEnthalpyAuxVarInit,
+  // ThermalEnthalpySoilAuxType.F90:93; MPPTHSetSoils leaves it, MultiPhysicsProbTH.F90:293)
+  void th_energy_perm(int cell_ext, double *pp) const {
+    if ((int)the_permx.size() == n) { pp[0] = the_permx[cell_ext]; pp[1] = the_permy[cell_ext]; pp[2] = the_permz[cell_ext]; }
+    else pp[0] = pp[1] = pp[2] = 8.3913e-12;
+  }
+  ThBcArgs th_args(const double *x, double *Fout) const {
+    ThBcArgs b;
+    ThArgs &a = b.t;
+    a.n = n; a.x = x;
+    a.por = d_por.p; a.sat_res = d_sat_res.p; a.alpha = d_alpha.p; a.m = d_m.p; a.vol = d_vol.p;
+    a.sbc_pu = d_pu.p; a.sbc_ps = d_ps.p; a.sbc_b2 = d_b2.p; a.sbc_b3 = d_b3.p;
+    a.active = any_inactive ? d_active.p : nullptr;
+    a.tc_wet = d_tcw.p; a.tc_dry = d_tcd.p; a.talpha = d_talpha.p; a.heat_cap = d_hcap.p; a.den_soil = d_dsoil.p;
+    a.sat_func = sat_func; a.density_type = density_type; a.ie_type = ie_type;
+    a.kr = tha[0].p; a.dkr = tha[1].p; a.den_m = tha[2].p; a.ddenP_m = tha[3].p; a.ddenT_m = tha[4].p;
+    a.den_e = tha[5].p; a.ddenP_e = tha[6].p; a.ddenT_e = tha[7].p; a.hl = tha[8].p; a.dhl_dP = tha[9].p;
+    a.dhl_dT = tha[10].p; a.tc = tha[11].p; a.dtc_dP = tha[12].p;
+    a.cup = d_cup.p; a.cdn = d_cdn.p; a.rc_ptr = d_rc_ptr.p; a.rc_conn = d_rc_conn.p; a.rc_slot = d_rc_slot.p;
+    a.crowptr = d_crowptr.p; a.cdiag = d_cdiag.p;
+    a.Dq_m = d_Dq.p; a.Dq_e = d_Dq_e.p; a.upw = d_upw.p; a.dgrav = d_dgrav.p; a.area = d_area.p; a.cdu = d_cdu.p; a.cdd = d_cdd.p;
+    a.accum_prev = accum_prev.p; a.src = has_src ? d_src.p : nullptr;
+    a.F = Fout; a.val = d_val.p; a.nnzc = nnzc; a.dtInv = 1.0 / dtime;
+    b.ncond_cells = ncond_cells; b.cc_cell = d_cc_cell.p; b.cc_ptr = d_cc_ptr.p; b.type = d_bc_type.p;
+    b.Dq = d_bc_Dq.p; b.dgrav = d_bc_dgrav.p; b.area = d_bc_area.p; b.du = d_bc_du.p; b.dd = d_bc_dd.p;
+    b.value = d_bc_value.p; b.other = d_bc_other.p;
+    return b;
   }
 
   // =====================================================================================
@@ -523,7 +633,7 @@ struct Solver {
     return ca;
   }
   ConnArrays conns() const { return ConnArrays{d_Dq.p, d_upw.p, d_dgrav.p, d_area.p}; }
-  bool use_cols() const { return vertical_only && opt.assembly != 0; }
+  bool use_cols() const { return vertical_only && opt.assembly != 0 && !th; }
   int pick_nseg() const {
     if (opt.nseg > 0) return std::min(opt.nseg, nz);
     // enough threads for >= 8 waves on each of the 256 CUs; one halo level per segment end is the price
@@ -565,6 +675,7 @@ struct Solver {
   void op_residual(const double *P, double *Fout) {
     if (dtime <= 0.0) throw Error("time step not set");
     ProfScope ps(prof, KC_RESIDUAL);
+    if (th) { launch_th_assemble(0, th_args(P, Fout), stream); ++nfuncs; ++cum_funcs; return; }
     if (use_cols()) launch_assemble_cols(0, cols_args(P, Fout), stream);
     else {
       if (!d_rc_ptr.p) throw Error("option assembly=general must be set before mppgpu_setup");
@@ -577,6 +688,7 @@ struct Solver {
   void op_residual_jacobian(const double *P, double *Fout) {
     if (dtime <= 0.0) throw Error("time step not set");
     ProfScope ps(prof, KC_JACOBIAN);
+    if (th) { launch_th_assemble(2, th_args(P, Fout), stream); ++nfuncs; ++cum_funcs; pc_ready = false; return; }
     if (use_cols()) launch_assemble_cols(2, cols_args(P, Fout), stream);
     else {
       if (!d_rc_ptr.p) throw Error("option assembly=general must be set before mppgpu_setup");
@@ -589,6 +701,7 @@ struct Solver {
   void op_jacobian(const double *P) {
     if (dtime <= 0.0) throw Error("time step not set");
     ProfScope ps(prof, KC_JACOBIAN);
+    if (th) { launch_th_assemble(2, th_args(P, th_scratch.p), stream); pc_ready = false; return; }
     if (use_cols()) launch_assemble_cols(1, cols_args(P, F.p), stream);
     else launch_assemble_general(1, gen_args(P, F.p), stream);
     launch_bc(1, bc_args(P, F.p), stream);
@@ -596,17 +709,18 @@ struct Solver {
   }
   void op_pre_solve() {  // VSFMSOEPreSolve: accum_prev from soln_prev
     ProfScope ps(prof, KC_RESIDUAL);
+    if (th) { launch_th_assemble(3, th_args(soln_prev.p, accum_prev.p), stream); return; }  // SOETHPreSolve :119-272
     launch_accum(cells(soln_prev.p), n, 1.0 / dtime, accum_prev.p, stream);
   }
   void op_spmv(const double *x, double *y) {
     ProfScope ps(prof, KC_SPMV);
-    launch_spmv(spmv_variant(), n, max_row_nnz, d_rowptr.p, d_col.p, d_val.p, x, y, stream);
+    launch_spmv(spmv_variant(), nrow, max_row_nnz, d_rowptr.p, d_col.p, d_val.p, x, y, stream);
   }
   int spmv_variant() const {
     if (opt.spmv_variant >= 0) return opt.spmv_variant;
     // measured on MI355X (profiles/): the software-pipelined wave kernel wins once there are enough row tiles to
     // fill the chip several times over; the block CSR-stream kernel wins on small, cache-resident matrices
-    return (max_row_nnz <= 8 && n >= (1 << 23)) ? 17 : 1;
+    return (max_row_nnz <= 8 && nrow >= (1 << 23)) ? 17 : 1;
   }
   TriArgs tri_args() const {
     return TriArgs{ncols, nz, d_tri_lo.p, d_diag.p, d_tri_up.p, d_val.p, tri_l.p, tri_invb.p, tri_c.p};
@@ -614,8 +728,9 @@ struct Solver {
   void op_pc_setup() {
     if (pc_ready) return;
     ProfScope ps(prof, KC_PC_SETUP);
+    if (opt.pc_type == 2 && th) throw Error("pc_type bjacobi is not available for the coupled system (use ilu, jacobi or none)");
     if (opt.pc_type == 2) launch_tri_factor(tri_args(), stream);
-    else if (opt.pc_type == 3) launch_jacobi_setup(n, d_diag.p, d_val.p, jac_invd.p, stream);
+    else if (opt.pc_type == 3) launch_jacobi_setup(nrow, d_diag.p, d_val.p, jac_invd.p, stream);
     else if (opt.pc_type == 1) {
       ilu_analyse();
       launch_copy(nnz, d_val.p, d_lu.p, stream);
@@ -628,14 +743,14 @@ struct Solver {
   void op_pc_apply(const double *r, double *z) {
     ProfScope ps(prof, KC_PC_APPLY);
     if (opt.pc_type == 2) launch_tri_solve(tri_args(), r, z, stream);
-    else if (opt.pc_type == 3) launch_pointwise_mult(n, jac_invd.p, r, z, stream);
+    else if (opt.pc_type == 3) launch_pointwise_mult(nrow, jac_invd.p, r, z, stream);
     else if (opt.pc_type == 1) {
       const IluArgs a = ilu_args();
       for (size_t l = 0; l + 1 < h_lptr.size(); ++l)
         launch_ilu_lower_level(a, d_lrows.p + h_lptr[l], h_lptr[l + 1] - h_lptr[l], r, z, stream);
       for (size_t l = 0; l + 1 < h_uptr.size(); ++l)
         launch_ilu_upper_level(a, d_urows.p + h_uptr[l], h_uptr[l + 1] - h_uptr[l], z, stream);
-    } else launch_copy(n, r, z, stream);
+    } else launch_copy(nrow, r, z, stream);
   }
   void op_BA(const double *v, double *t) {  // t = M^{-1} A v  (left preconditioning)
     op_spmv(v, Wk.p);
@@ -646,7 +761,7 @@ struct Solver {
   void dots_dev(std::initializer_list<std::pair<const double *, const double *>> pairs) {
     ProfScope ps(prof, KC_REDUCE);
     DotArgs a;
-    a.n = n; a.nvec = 0;
+    a.n = nrow; a.nvec = 0;
     for (auto &p : pairs) { a.x[a.nvec] = p.first; a.y[a.nvec] = p.second; ++a.nvec; }
     const int nbk = launch_dots(a, partials.p, stream);
     launch_finalize_partials(nbk, a.nvec, partials.p, sc.p, stream);
@@ -667,11 +782,11 @@ struct Solver {
     dots_host({{x, x}}, &s);
     return std::sqrt(s);
   }
-  void vec_copy(const double *x, double *y) { ProfScope ps(prof, KC_VEC); launch_copy(n, x, y, stream); }
-  void vec_set(double v, double *y) { ProfScope ps(prof, KC_VEC); launch_set(n, v, y, stream); }
+  void vec_copy(const double *x, double *y) { ProfScope ps(prof, KC_VEC); launch_copy(nrow, x, y, stream); }
+  void vec_set(double v, double *y) { ProfScope ps(prof, KC_VEC); launch_set(nrow, v, y, stream); }
   void vec_waxpy(double *w, double a, const double *x, const double *y) {
     ProfScope ps(prof, KC_VEC);
-    launch_waxpy(n, w, sc.p, -1, 1.0, a, x, y, stream);
+    launch_waxpy(nrow, w, sc.p, -1, 1.0, a, x, y, stream);
   }
 
   // =====================================================================================
@@ -772,19 +887,19 @@ struct Solver {
       launch_bcgs_scalars(1, sc.p, stream);
       if (i > 0) {
         ProfScope ps(prof, KC_VEC);
-        launch_bcgs_p(n, Pv.p, Pcur, Rcur, V.p, sc.p, stream);
+        launch_bcgs_p(nrow, Pv.p, Pcur, Rcur, V.p, sc.p, stream);
         Pcur = Pv.p;
       }
       op_BA(Pcur, V.p);
       dots_dev({{V.p, RP.p}});
       launch_bcgs_scalars(2, sc.p, stream);
-      { ProfScope ps(prof, KC_VEC); launch_waxpy(n, S.p, sc.p, S_ALPHA, -1.0, 0.0, V.p, Rcur, stream); }
+      { ProfScope ps(prof, KC_VEC); launch_waxpy(nrow, S.p, sc.p, S_ALPHA, -1.0, 0.0, V.p, Rcur, stream); }
       op_BA(S.p, T.p);
       dots_dev({{S.p, T.p}, {T.p, T.p}});
       launch_bcgs_scalars(3, sc.p, stream);
       {
         ProfScope ps(prof, KC_REDUCE);
-        const int nbk = launch_bcgs_xr(n, i == 0, x, R.p, Pcur, S.p, T.p, sc.p, partials.p, stream);
+        const int nbk = launch_bcgs_xr(nrow, i == 0, x, R.p, Pcur, S.p, T.p, sc.p, partials.p, stream);
         launch_finalize_partials(nbk, 1, partials.p, sc.p, stream);
         if (comm.active()) comm.allreduce_sum(sc.p + S_SUM0, 1, stream);
       }
@@ -812,7 +927,7 @@ struct Solver {
     const int m = opt.gmres_restart;
     if ((int)vv.size() < m + 1) {
       vv.resize(m + 1);
-      for (auto &v : vv) v.alloc(n);
+      for (auto &v : vv) v.alloc(nrow);
     }
     KspConv cv{opt.ksp_rtol, opt.ksp_atol, opt.ksp_dtol};
     std::vector<double> H((size_t)(m + 1) * m, 0.0), cs(m), sn(m), rs(m + 1), y(m), hh(m + 1);
@@ -841,7 +956,7 @@ struct Solver {
         {  // classical Gram-Schmidt: all dots, then one fused update
           ProfScope ps(prof, KC_REDUCE);
           DotArgs a;
-          a.n = n; a.nvec = it + 1;
+          a.n = nrow; a.nvec = it + 1;
           for (int j = 0; j <= it; ++j) { a.x[j] = vnew; a.y[j] = vv[j].p; }
           const int nbk = launch_dots(a, partials.p, stream);
           launch_finalize_partials(nbk, a.nvec, partials.p, sc.p, stream);
@@ -850,7 +965,7 @@ struct Solver {
         {
           ProfScope ps(prof, KC_VEC);
           MaxpyArgs ma;
-          ma.n = n; ma.nvec = it + 1;
+          ma.n = nrow; ma.nvec = it + 1;
           for (int j = 0; j <= it; ++j) ma.v[j] = vv[j].p;
           launch_maxpy_neg(ma, sc.p, vnew, stream);
         }
@@ -887,7 +1002,7 @@ struct Solver {
       if (it > 0) {
         ProfScope ps(prof, KC_VEC);
         MaxpyValArgs ma;
-        ma.n = n; ma.nvec = it;
+        ma.n = nrow; ma.nvec = it;
         for (int j = 0; j < it; ++j) { ma.v[j] = vv[j].p; ma.c[j] = y[j]; }
         launch_maxpy_val(ma, x, stream);
       }
@@ -898,7 +1013,7 @@ struct Solver {
   void scale_host(double *x, double divisor) {  // x <- x / divisor
     ProfScope ps(prof, KC_VEC);
     HIP_CHECK(hipMemcpyAsync(sc.p + S_D2, &divisor, sizeof(double), hipMemcpyHostToDevice, stream));
-    launch_scale(n, x, sc.p, S_D2, stream);
+    launch_scale(nrow, x, sc.p, S_D2, stream);
   }
 
   int ksp_solve(const double *b, double *x, int *its) {
@@ -1092,6 +1207,13 @@ struct Solver {
     }
     HIP_CHECK(hipStreamSynchronize(stream));  // the caller's buffer is free again on return
   }
+  // whole unknown vectors: one field of n cells, or [P; T] for the coupled system
+  void put_state(const double *host_ext, double *dev_int) {
+    for (int f = 0; f * n < nrow; ++f) put_cells(host_ext + (size_t)f * n, dev_int + (size_t)f * n);
+  }
+  void get_state(const double *dev_int, double *host_ext) {
+    for (int f = 0; f * n < nrow; ++f) get_cells(dev_int + (size_t)f * n, host_ext + (size_t)f * n, n);
+  }
   void get_cells(const double *dev_int, double *host_ext, int count) {
     const double *src = dev_int;
     if (!identity_perm) { launch_gather(n, d_ext2int.p, dev_int, tmp_ext.p, stream); src = tmp_ext.p; }
@@ -1151,6 +1273,20 @@ struct Solver {
   void set_data(int auxvar_type, int var_type, int cond_id, int cnt, const double *data) {
     need_setup(true);
     if (thermal) { thermal_set_data(auxvar_type, var_type, cond_id, cnt, data); return; }
+    if (th && auxvar_type == MPPGPU_AUXVAR_BC && (var_type == MPPGPU_VAR_PRESSURE || var_type == MPPGPU_VAR_TEMPERATURE)) {
+      // the other field of a boundary auxvar: aux_vars_bc(:)%temperature of the mass equation, %pressure of the heat
+      // equation -- the reference drivers assign them directly (mass_and_heat_model_problem.F90:583-640,
+      // th_mms_problem.F90:846-875)
+      if (cond_id < 1 || cond_id > (int)bcs.size()) throw Error("set_data: bad boundary condition id");
+      Condition &c = bcs[cond_id - 1];
+      if ((c.eqn == 0) != (var_type == MPPGPU_VAR_TEMPERATURE))
+        throw Error("set_data: a mass-equation boundary takes VAR_TEMPERATURE, a heat-equation boundary VAR_PRESSURE");
+      if (cnt > c.n) throw Error("set_data: size(data_1d) > nauxvar");
+      for (int i = 0; i < cnt; ++i) { c.other[i] = data[i]; h_bc_other[bc_pos_of_g[c.offset + i]] = data[i]; }
+      d_bc_other.upload(h_bc_other, stream);
+      HIP_CHECK(hipStreamSynchronize(stream));
+      return;
+    }
     if (var_type != MPPGPU_VAR_BC_SS_CONDITION) throw Error("set_data: unknown var_type " + std::to_string(var_type));
     if (auxvar_type == MPPGPU_AUXVAR_BC) {
       if (cond_id < 1 || cond_id > (int)bcs.size()) throw Error("set_data: bad boundary condition id");
@@ -1165,10 +1301,13 @@ struct Solver {
       if (cnt > c.n) throw Error("set_data: size(data_1d) > nauxvar");
       for (int i = 0; i < cnt; ++i) c.value[i] = data[i];
       // dense per-cell source [kmol/s]: sum over all mass-rate conditions of value/FMWH2O (GE:1896)
-      std::vector<double> src(n, 0.0);
+      std::vector<double> src(nrow, 0.0);
       for (auto &s : sss)
-        for (int i = 0; i < s.n; ++i)
-          if (active[s.cell[i]]) src[ext2int[s.cell[i]]] += s.value[i] / kFMWH2O;
+        for (int i = 0; i < s.n; ++i) {
+          if (!active[s.cell[i]]) continue;
+          if (s.eqn == 0) src[ext2int[s.cell[i]]] += s.value[i] / kFMWH2O;
+          else src[n + ext2int[s.cell[i]]] += s.value[i];   // COND_HEAT_RATE [W] (GoveqnThermalEnthalpySoilType.F90:1481)
+        }
       d_src.upload(src, stream);
       HIP_CHECK(hipStreamSynchronize(stream));
     } else throw Error("set_data: unknown auxvar_type " + std::to_string(auxvar_type));
@@ -1179,10 +1318,14 @@ struct Solver {
     if (auxvar_type == MPPGPU_AUXVAR_INTERNAL) {
       if (cnt > n) throw Error("get_data: size(data_1d) > nauxvar");
       if (var_type == MPPGPU_VAR_PRESSURE) { get_cells(soln.p, out, cnt); return; }
+      if (th && var_type == MPPGPU_VAR_TEMPERATURE) { get_cells(soln.p + n, out, cnt); return; }
+      if (th) throw Error("get_data: the coupled system exports VAR_PRESSURE and VAR_TEMPERATURE");
       if (var_type != MPPGPU_VAR_LIQ_SAT && var_type != MPPGPU_VAR_MASS && var_type != MPPGPU_VAR_SOIL_MATRIX_POT)
         throw Error("get_data: unknown var_type " + std::to_string(var_type));
       launch_cell_var(cells(soln.p), n, var_type, tmp_int.p, stream);
       get_cells(tmp_int.p, out, cnt);
+    } else if (th) {
+      throw Error("get_data: the coupled system exports AUXVAR_INTERNAL only");
     } else if (auxvar_type == MPPGPU_AUXVAR_BC) {
       if (cond_id < 1 || cond_id > (int)bcs.size()) throw Error("get_data: bad boundary condition id");
       if (var_type != MPPGPU_VAR_MASS_FLUX) throw Error("get_data: unknown var_type");
@@ -1218,51 +1361,56 @@ struct Solver {
   // triangular solve that is not built yet.
   void check_ilu() {
     if (!opt.pc_is_ilu) return;
-    opt.pc_type = vertical_only ? 2 : 1;   // general meshes: level-scheduled ILU(0) in the caller's natural ordering
+    opt.pc_type = (vertical_only && !th) ? 2 : 1;   // general meshes: level-scheduled ILU(0) in the caller's natural ordering
     pc_ready = false;
   }
 
   // Level sets of the ILU(0) dependency graphs.  Elimination order = the caller's numbering (PETSc factors in natural
   // ordering), i.e. ord[i] = external id of internal row i; level(i) = 1 + max level over the row's L (resp. U) part.
+  // caller's (natural) position of an internal row and back; coupled TH: field-blocked [P(1..N); T(1..N)] both ways
+  int row_int2ext(int r) const { return r < n ? int2ext[r] : n + int2ext[r - n]; }
+  int row_ext2int(int pos) const { return pos < n ? ext2int[pos] : n + ext2int[pos - n]; }
   void ilu_analyse() {
     if (d_ord.p) return;
-    std::vector<int> lvl(n, 0), ulvl(n, 0);
-    int nl = 0, nu = 0;
-    for (int pos = 0; pos < n; ++pos) {
-      const int i = ext2int[pos];
+    const int N = nrow;
+    std::vector<int> lvl(N, 0), ulvl(N, 0);
+    int nl = 0, nul = 0;
+    for (int pos = 0; pos < N; ++pos) {
+      const int i = row_ext2int(pos);
       int m = 0;
       for (int q = h_rowptr[i]; q < h_rowptr[i + 1]; ++q) {
         const int j = h_col[q];
-        if (int2ext[j] < pos) m = std::max(m, lvl[j] + 1);
+        if (row_int2ext(j) < pos) m = std::max(m, lvl[j] + 1);
       }
       lvl[i] = m; nl = std::max(nl, m + 1);
     }
-    for (int pos = n - 1; pos >= 0; --pos) {
-      const int i = ext2int[pos];
+    for (int pos = N - 1; pos >= 0; --pos) {
+      const int i = row_ext2int(pos);
       int m = 0;
       for (int q = h_rowptr[i]; q < h_rowptr[i + 1]; ++q) {
         const int j = h_col[q];
-        if (int2ext[j] > pos) m = std::max(m, ulvl[j] + 1);
+        if (row_int2ext(j) > pos) m = std::max(m, ulvl[j] + 1);
       }
-      ulvl[i] = m; nu = std::max(nu, m + 1);
+      ulvl[i] = m; nul = std::max(nul, m + 1);
     }
     auto bucket = [&](const std::vector<int> &lv, int nlev_, std::vector<int> &ptr, std::vector<int> &rows) {
       ptr.assign(nlev_ + 1, 0);
-      for (int i = 0; i < n; ++i) ptr[lv[i] + 1]++;
+      for (int i = 0; i < N; ++i) ptr[lv[i] + 1]++;
       for (int l = 0; l < nlev_; ++l) ptr[l + 1] += ptr[l];
-      rows.resize(n);
+      rows.resize(N);
       std::vector<int> fill(ptr.begin(), ptr.end() - 1);
-      for (int pos = 0; pos < n; ++pos) { const int i = ext2int[pos]; rows[fill[lv[i]]++] = i; }
+      for (int pos = 0; pos < N; ++pos) { const int i = row_ext2int(pos); rows[fill[lv[i]]++] = i; }
     };
-    std::vector<int> lrows, urows;
+    std::vector<int> lrows, urows, ord(N);
     bucket(lvl, nl, h_lptr, lrows);
-    bucket(ulvl, nu, h_uptr, urows);
+    bucket(ulvl, nul, h_uptr, urows);
+    for (int r = 0; r < N; ++r) ord[r] = row_int2ext(r);
     d_lrows.upload(lrows, stream); d_urows.upload(urows, stream);
-    d_ord.upload(int2ext, stream);
-    d_lu.alloc(nnz); d_idiag.alloc(n);
+    d_ord.upload(ord, stream);
+    d_lu.alloc(nnz); d_idiag.alloc(N);
     HIP_CHECK(hipStreamSynchronize(stream));
   }
-  IluArgs ilu_args() const { return IluArgs{n, d_rowptr.p, d_col.p, d_diag.p, d_ord.p, d_lu.p, d_idiag.p}; }
+  IluArgs ilu_args() const { return IluArgs{nrow, d_rowptr.p, d_col.p, d_diag.p, d_ord.p, d_lu.p, d_idiag.p}; }
 
   // current matrix values in the caller's ordering, columns sorted
   void export_csr(int *rowptr, int *col, double *val) {
@@ -1271,15 +1419,15 @@ struct Solver {
     HIP_CHECK(hipStreamSynchronize(stream));
     int pos = 0;
     std::vector<std::pair<int, double>> row;
-    for (int e = 0; e < n; ++e) {
+    for (int e = 0; e < nrow; ++e) {
       rowptr[e] = pos;
-      const int i = ext2int[e];
+      const int i = row_ext2int(e);
       row.clear();
-      for (int k = h_rowptr[i]; k < h_rowptr[i + 1]; ++k) row.emplace_back(int2ext[h_col[k]], v[k]);
+      for (int k = h_rowptr[i]; k < h_rowptr[i + 1]; ++k) row.emplace_back(row_int2ext(h_col[k]), v[k]);
       std::sort(row.begin(), row.end());
       for (auto &pr : row) { col[pos] = pr.first; val[pos] = pr.second; ++pos; }
     }
-    rowptr[n] = pos;
+    rowptr[nrow] = pos;
   }
 
   void set_option(const std::string &key, const std::string &val) {
@@ -1316,8 +1464,14 @@ struct Solver {
     else if (key == "temperature") temperature = num();
     else if (key == "problem_type") {
       if (setup_done || !bcs.empty() || !sss.empty()) throw Error("problem_type must be set before conditions are added");
-      if (val == "thermal") thermal = true; else if (val == "vsfm") thermal = false;
-      else throw Error("unknown problem_type '" + val + "' (vsfm | thermal)");
+      if (val == "thermal") { thermal = true; th = false; }
+      else if (val == "vsfm") { thermal = false; th = false; }
+      else if (val == "th") { thermal = false; th = true; if (!opt.pc_is_ilu && opt.pc_type == 2) { opt.pc_is_ilu = true; } }
+      else throw Error("unknown problem_type '" + val + "' (vsfm | thermal | th)");
+    } else if (key == "int_energy_enthalpy_type") {
+      const int t = (int)num();
+      if (t != 1 && t != 2) throw Error("int_energy_enthalpy_type must be 1 (constant) or 2 (IFC67)");
+      ie_type = t;
     } else if (key == "cnfac") cnfac = num();
     else if (key == "profile") { prof.flush(); prof.enabled = num() != 0; }
     else throw Error("unknown option '" + key + "'");
@@ -1421,6 +1575,28 @@ int mppgpu_add_condition(mppgpu_handle h, int kind, int cond_type, int nconn, co
   if (cond_id) *cond_id = id;
   API_END()
 }
+int mppgpu_th_add_condition(mppgpu_handle h, int igoveqn, int kind, int cond_type, int nconn, const int *id_dn,
+                            const double *dist_up, const double *dist_dn, const double *area, const double *unit_vec,
+                            int swap_order, int *cond_id) {
+  API_BEGIN(h)
+  if (!S.th) throw mpp::Error("problem_type is not th");
+  const int id = S.add_condition(kind, cond_type, nconn, id_dn, dist_up, dist_dn, area, unit_vec, swap_order, igoveqn);
+  if (cond_id) *cond_id = id;
+  API_END()
+}
+int mppgpu_th_set_soils(mppgpu_handle h, const double *heat_cap, const double *tcw, const double *tcd, const double *talpha,
+                        const double *den_soil, const double *px, const double *py, const double *pz) {
+  API_BEGIN(h)
+  if (!S.th) throw mpp::Error("problem_type is not th");
+  const int n = S.n;
+  if (!n) throw mpp::Error("mesh not set");
+  S.the_heat_cap.assign(heat_cap, heat_cap + n); S.the_tcw.assign(tcw, tcw + n); S.the_tcd.assign(tcd, tcd + n);
+  S.the_talpha.assign(talpha, talpha + n); S.the_dsoil.assign(den_soil, den_soil + n);
+  if (px && py && pz) { S.the_permx.assign(px, px + n); S.the_permy.assign(py, py + n); S.the_permz.assign(pz, pz + n); }
+  else { S.the_permx.clear(); S.the_permy.clear(); S.the_permz.clear(); }
+  S.soil_dirty = true;
+  API_END()
+}
 int mppgpu_set_soil_permeability(mppgpu_handle h, const double *px, const double *py, const double *pz) {
   API_BEGIN(h)
   S.set_perm(px, py, pz);
@@ -1456,8 +1632,8 @@ int mppgpu_setup(mppgpu_handle h) {
 int mppgpu_restart(mppgpu_handle h, int n, const double *pressure) {
   API_BEGIN(h)
   S.need_setup(true);
-  if (n != S.n) throw mpp::Error("restart: size(data_1d) /= ncells_local");
-  S.put_cells(pressure, S.soln.p);
+  if (n != S.nrow) throw mpp::Error("restart: size(data_1d) /= number of unknowns (ncells_local, or 2 ncells_local [P; T] for the coupled system)");
+  S.put_state(pressure, S.soln.p);
   S.vec_copy(S.soln.p, S.soln_prev.p);
   HIP_CHECK(hipStreamSynchronize(S.stream));
   API_END()
@@ -1508,9 +1684,9 @@ int mppgpu_pre_solve(mppgpu_handle h) {
 int mppgpu_residual(mppgpu_handle h, const double *x, double *f) {
   API_BEGIN(h)
   S.ensure_ready();
-  S.put_cells(x, S.W.p);
+  S.put_state(x, S.W.p);
   S.op_residual(S.W.p, S.G.p);
-  S.get_cells(S.G.p, f, S.n);
+  S.get_state(S.G.p, f);
   API_END()
 }
 int mppgpu_jacobian_nnz(mppgpu_handle h, int *nnz) {
@@ -1522,7 +1698,7 @@ int mppgpu_jacobian_nnz(mppgpu_handle h, int *nnz) {
 int mppgpu_jacobian(mppgpu_handle h, const double *x, int *rowptr, int *col, double *val) {
   API_BEGIN(h)
   S.ensure_ready();
-  S.put_cells(x, S.W.p);
+  S.put_state(x, S.W.p);
   S.op_jacobian(S.W.p);
   S.export_csr(rowptr, col, val);
   API_END()
@@ -1530,27 +1706,27 @@ int mppgpu_jacobian(mppgpu_handle h, const double *x, int *rowptr, int *col, dou
 int mppgpu_spmv(mppgpu_handle h, const double *x, double *y) {
   API_BEGIN(h)
   S.ensure_ready();
-  S.put_cells(x, S.W.p);
+  S.put_state(x, S.W.p);
   S.op_spmv(S.W.p, S.G.p);
-  S.get_cells(S.G.p, y, S.n);
+  S.get_state(S.G.p, y);
   API_END()
 }
 int mppgpu_pc_apply(mppgpu_handle h, const double *r, double *z) {
   API_BEGIN(h)
   S.ensure_ready();
-  S.put_cells(r, S.W.p);
+  S.put_state(r, S.W.p);
   S.op_pc_setup();
   S.op_pc_apply(S.W.p, S.G.p);
-  S.get_cells(S.G.p, z, S.n);
+  S.get_state(S.G.p, z);
   API_END()
 }
 int mppgpu_ksp_solve(mppgpu_handle h, const double *b, double *x, int *its, int *reason) {
   API_BEGIN(h)
   S.ensure_ready();
-  S.put_cells(b, S.G.p);
+  S.put_state(b, S.G.p);
   int it = 0;
   const int r = S.ksp_solve(S.G.p, S.Y.p, &it);
-  S.get_cells(S.Y.p, x, S.n);
+  S.get_state(S.Y.p, x);
   if (its) *its = it;
   if (reason) *reason = r;
   API_END()

@@ -540,3 +540,50 @@ def th_mms(nx=20) -> THProblem:
         mass_bcs=[(C.COND_DIRICHLET, ends, pres_bc, temp_bc)], mass_sss=[(C.COND_MASS_RATE, allcells, mass_src)],
         energy_bcs=[(C.COND_DIRICHLET, ends, temp_bc, pres_bc)], energy_sss=[(C.COND_HEAT_RATE, allcells, heat_src)],
         dt=1.0, nstep=1)
+
+
+def to_th_gpu(tp: THProblem, options=None, device_id=0):
+    """the reference drivers' call sequence (mass_and_heat_model_problem.F90:112-139) through the Python mirror"""
+    from mpp_amd import th as TH
+    mpp = TH.MultiPhysicsProbTH(device_id)
+    mpp.Init(); mpp.SetName(tp.name); mpp.SetID(TH.MPP_TH_SNES_CLM); mpp.SetMPIRank(0)
+    mpp.SetNumMeshes(1); mpp.AddMesh(1, tp.mesh)
+    mpp.AddGovEqn(C.GE_RE, "Mass equation", 0)
+    mpp.AddGovEqn(TH.GE_THERM_SOIL_EBASED, "Heat transport based on enthalpy", 0)
+    mpp.SetMeshesOfGoveqns()
+    ids = {"mass_bc": [], "mass_ss": [], "energy_bc": [], "energy_ss": []}
+    for bc in tp.mass_bcs:
+        ids["mass_bc"].append(mpp.soe.AddConditionInGovEqn(1, C.COND_BC, "bc", "Pa", bc[0], conn_set=bc[1]))
+    for ss in tp.mass_sss:
+        ids["mass_ss"].append(mpp.soe.AddConditionInGovEqn(1, C.COND_SS, "ss", "kg/s", ss[0], conn_set=ss[1]))
+    for bc in tp.energy_bcs:
+        ids["energy_bc"].append(mpp.soe.AddConditionInGovEqn(2, C.COND_BC, "bc", "K", bc[0], conn_set=bc[1]))
+    for ss in tp.energy_sss:
+        ids["energy_ss"].append(mpp.soe.AddConditionInGovEqn(2, C.COND_SS, "ss", "W", ss[0], conn_set=ss[1]))
+    mpp.GovEqnSetInternalCouplingVars(1, 1, [TH.VAR_TEMPERATURE], [2])
+    mpp.GovEqnSetInternalCouplingVars(2, 1, [C.VAR_PRESSURE], [1])
+    mpp.AllocateAuxVars()
+    for k, v in (options or {}).items():
+        mpp.soe.SetOption(k, v)
+    mpp.SetupProblem()
+    TH.MPPTHSetSoilsSI(mpp, tp.perm, tp.por, tp.satfunc_type, tp.alpha, tp.lam, tp.sat_res, tp.density_type, tp.ie_type,
+                       tp.heat_cap, tp.tcond_wet, tp.tcond_dry, tp.talpha, tp.den_soil, energy_perm=tp.energy_perm)
+    mpp.Restart(tp.press_ic, tp.temp_ic)
+    mpp.cond_ids = ids
+    th_gpu_set_conditions(tp, mpp)
+    return mpp
+
+
+def th_gpu_set_conditions(tp: THProblem, mpp):
+    ids = mpp.cond_ids
+    for i, bc in enumerate(tp.mass_bcs):
+        mpp.soe.SetDataFromCLM(C.AUXVAR_BC, C.VAR_BC_SS_CONDITION, ids["mass_bc"][i], bc[2])
+        if len(bc) > 3 and bc[3] is not None:
+            mpp.soe.SetBoundaryAuxVarTemperature(ids["mass_bc"][i], bc[3])
+    for i, ss in enumerate(tp.mass_sss):
+        mpp.soe.SetDataFromCLM(C.AUXVAR_SS, C.VAR_BC_SS_CONDITION, ids["mass_ss"][i], ss[2])
+    for i, bc in enumerate(tp.energy_bcs):
+        mpp.soe.SetDataFromCLM(C.AUXVAR_BC, C.VAR_BC_SS_CONDITION, ids["energy_bc"][i], bc[2])
+        mpp.soe.SetBoundaryAuxVarPressure(ids["energy_bc"][i], bc[3])
+    for i, ss in enumerate(tp.energy_sss):
+        mpp.soe.SetDataFromCLM(C.AUXVAR_SS, C.VAR_BC_SS_CONDITION, ids["energy_ss"][i], ss[2])

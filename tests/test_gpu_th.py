@@ -1,0 +1,115 @@
+"""GPU parity tests of the coupled thermal-hydrology system: every call goes through the C
+ABI (libmppgpu.so) and is compared with the CPU oracle (oracle/th_oracle.c, pinned on the reference's th baselines)
+on the same inputs, and with the reference's golden baselines.
+
+Tolerances (fp64): the HIP path evaluates the same expressions as the oracle with the device pow/sqrt and FMA
+contraction: residual rows <= 1e-11 of the size of their cancelling terms, Jacobian entries <= 1e-10 of the row
+scale of their block; end-to-end <= 1e-9 relative on pressure, <= 1e-8 K on temperature (the reference's tolerance).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import problems as P
+from conftest import parse_regression_file
+from mpp_amd import constants as C
+
+pytestmark = pytest.mark.gpu
+
+
+def _dense(rp, cj, val, n):
+    A = np.zeros((n, n))
+    for i in range(n):
+        A[i, cj[rp[i]:rp[i + 1]]] = val[rp[i]:rp[i + 1]]
+    return A
+
+
+def _state(tp, seed=0, dp=(-2e4, 3e4), dt=(0.0, 20.0)):
+    n = tp.mesh.ncells_local
+    rng = np.random.default_rng(seed)
+    return np.concatenate([tp.press_ic + rng.uniform(*dp, n), tp.temp_ic + rng.uniform(*dt, n)])
+
+
+@pytest.mark.parametrize("case", ["mass_and_heat", "th_mms"])
+def test_th_operators(case):
+    """residual of both equations and all four Jacobian blocks against the oracle at a random state"""
+    tp = P.mass_and_heat(nx=37) if case == "mass_and_heat" else P.th_mms(nx=23)
+    n = tp.mesh.ncells_local
+    o = P.to_th_oracle(tp)
+    g = P.to_th_gpu(tp)
+    x = _state(tp, seed=4)
+    o.set_dtime(tp.dt); o.pre_solve()
+    g.soe.SetDtime(tp.dt); g.soe.PreSolve()
+    f_o, f_g = o.residual(x), g.soe.ComputeResidual(x)
+    rp, cj, val = o.jacobian(x)
+    rp_g, cj_g, val_g = g.soe.ComputeJacobian(x)
+    assert np.array_equal(rp, rp_g) and np.array_equal(cj, cj_g)
+    J, Jg = _dense(rp, cj, val, 2 * n), _dense(rp_g, cj_g, val_g, 2 * n)
+    for (r0, c0) in ((0, 0), (0, n), (n, 0), (n, n)):
+        B, Bg = J[r0:r0 + n, c0:c0 + n], Jg[r0:r0 + n, c0:c0 + n]
+        scale = np.abs(B).max(axis=1, keepdims=True) + 1e-300
+        assert (np.abs(Bg - B) <= 1e-10 * scale).all(), (r0, c0, np.abs((Bg - B) / scale).max())
+    # residual: against the size of the cancelling terms ~ |J| |dx| + |F|
+    dx = np.concatenate([np.full(n, 1.0), np.full(n, 1e-3)])
+    fscale = np.abs(f_o) + np.abs(J) @ dx
+    assert (np.abs(f_g - f_o) <= 1e-11 * fscale + 1e-25).all(), np.abs((f_g - f_o) / fscale).max()
+    # SpMV and ILU(0) of the 2N x 2N system in the caller's [P; T] ordering
+    v = np.random.default_rng(1).standard_normal(2 * n)
+    y_g = g.soe.MatMult(v)
+    assert np.abs(y_g - Jg @ v).max() <= 1e-12 * np.abs(Jg @ v).max()
+    g.soe.SetOption("pc_type", "ilu")
+    z_g = g.soe.PCApply(v)
+    z_o = o.glob.pc_apply(C.PC_ILU0, rp, cj, val, v)
+    assert np.abs(z_g - z_o).max() <= 1e-9 * np.abs(z_o).max()
+
+
+def test_th_mass_and_heat_baseline(golden_dir):
+    """regression_tests/th/mass_and_heat end to end on the GPU: Newton + GMRES(30) + ILU(0), same iteration counts
+    as the oracle, every value of the reference's baseline to 1e-9 (pressure, relative) / 1e-8 K"""
+    gold = parse_regression_file(os.path.join(golden_dir, "mass_and_heat.regression.baseline"))
+    tp = P.mass_and_heat()
+    g = P.to_th_gpu(tp, {"ksp_type": "gmres", "pc_type": "ilu"})
+    conv, reason = g.soe.StepDT(tp.dt, 1)
+    assert conv and reason > 0
+    p = g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE)
+    t = g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, 605)
+    sp, stt = P.regression_stats(p, 5), P.regression_stats(t, 5)
+    for key in ("min", "max", "mean"):
+        assert sp[key] == pytest.approx(gold["liquid_pressure"][key], rel=1e-9), key
+        assert stt[key] == pytest.approx(gold["temperature"][key], abs=1e-8), key
+    for cell, v in sp["cells"].items():
+        assert v == pytest.approx(gold["liquid_pressure"]["cell %d" % cell], rel=1e-9), cell
+    for cell, v in stt["cells"].items():
+        assert v == pytest.approx(gold["temperature"]["cell %d" % cell], abs=1e-8), cell
+    o = P.to_th_oracle(tp); o.step_dt(tp.dt)
+    co, cg = o.counters(), g.soe.counters()
+    assert cg["newton"] == co["newton"] and cg["linear"] == co["linear"]
+
+
+def test_th_mms_baseline(golden_dir):
+    gold = parse_regression_file(os.path.join(golden_dir, "th_mms.regression.baseline"))
+    tp = P.th_mms()
+    g = P.to_th_gpu(tp, {"ksp_type": "gmres", "pc_type": "ilu"})
+    conv, reason = g.soe.StepDT(tp.dt, 1)
+    assert conv and reason > 0
+    p = g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE)
+    t = g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, 605)
+    sp, stt = P.regression_stats(p, 5), P.regression_stats(t, 5)
+    for cell, v in sp["cells"].items():
+        assert v == pytest.approx(gold["liquid_pressure"]["cell %d" % cell], rel=1e-9), cell
+    for cell, v in stt["cells"].items():
+        assert v == pytest.approx(gold["temperature"]["cell %d" % cell], abs=1e-8), cell
+    assert g.soe.counters()["newton"] == 10
+
+
+def test_th_error_paths():
+    from mpp_amd import vsfm as V
+    tp = P.mass_and_heat(nx=5)
+    g = P.to_th_gpu(tp)
+    with pytest.raises(V.MPPError):
+        g.soe.SetOption("pc_type", "bjacobi"); g.soe.SetDtime(1.0); g.soe.PreSolve(); g.soe.PCApply(np.zeros(10))
+    with pytest.raises(V.MPPError):
+        g.soe.SetBoundaryAuxVarTemperature(1, np.zeros(1))       # condition 1 belongs to the heat equation
+    with pytest.raises(V.MPPError):
+        g.Restart(np.zeros(5), np.zeros(4))
