@@ -587,3 +587,22 @@ def th_gpu_set_conditions(tp: THProblem, mpp):
         mpp.soe.SetBoundaryAuxVarPressure(ids["energy_bc"][i], bc[3])
     for i, ss in enumerate(tp.energy_sss):
         mpp.soe.SetDataFromCLM(C.AUXVAR_SS, C.VAR_BC_SS_CONDITION, ids["energy_ss"][i], ss[2])
+
+
+def th_columns(ncols=1, nz=100, perm_mult=None, density_type=None, ie_type=2) -> THProblem:
+    """'TH-extruded' grid (BASELINE.json configs[4] shape): `ncols` celia1990 soil columns (vertical connections,
+    gravity) carrying the coupled mass + heat equations: the celia soil and pressure boundary values, 283.15 K initially,
+    303.15 K at the wet top boundary and 283.15 K at the bottom."""
+    vs = celia1990(ncols=ncols, nz=nz, perm_mult=perm_mult)
+    m = vs.mesh
+    n = m.ncells_local
+    (ttype, tcs, tvals), (btype, bcs_, bvals) = vs.bcs
+    one = lambda cs, v: np.full(cs.num_connections, v)
+    return THProblem(
+        name="th_columns", mesh=m, perm=vs.perm, por=vs.por, satfunc_type=vs.satfunc_type, alpha=vs.alpha, lam=vs.lam,
+        sat_res=vs.sat_res, density_type=C.DENSITY_IFC67 if density_type is None else density_type, ie_type=ie_type,
+        heat_cap=np.full(n, 837.0), tcond_wet=np.full(n, 1.3), tcond_dry=np.full(n, 0.25), talpha=np.full(n, 0.45),
+        den_soil=np.full(n, 2700.0), press_ic=vs.press_ic.copy(), temp_ic=np.full(n, 283.15),
+        mass_bcs=[(ttype, tcs, tvals, one(tcs, 303.15)), (btype, bcs_, bvals, one(bcs_, 283.15))],
+        energy_bcs=[(C.COND_DIRICHLET, tcs, one(tcs, 303.15), tvals.copy()), (C.COND_DIRICHLET, bcs_, one(bcs_, 283.15), bvals.copy())],
+        dt=vs.dt, nstep=1)

@@ -53,6 +53,7 @@ def test_th_operators(case):
     # residual: against the size of the cancelling terms ~ |J| |dx| + |F|
     dx = np.concatenate([np.full(n, 1.0), np.full(n, 1e-3)])
     fscale = np.abs(f_o) + np.abs(J) @ dx
+    fscale[n:] += np.abs(np.diag(J)[n:]) * 300.0   # heat rows: differences of accumulation terms ~ dE/dT * T
     assert (np.abs(f_g - f_o) <= 1e-11 * fscale + 1e-25).all(), np.abs((f_g - f_o) / fscale).max()
     # SpMV and ILU(0) of the 2N x 2N system in the caller's [P; T] ordering
     v = np.random.default_rng(1).standard_normal(2 * n)
@@ -113,3 +114,46 @@ def test_th_error_paths():
         g.soe.SetBoundaryAuxVarTemperature(1, np.zeros(1))       # condition 1 belongs to the heat equation
     with pytest.raises(V.MPPError):
         g.Restart(np.zeros(5), np.zeros(4))
+
+
+@pytest.mark.parametrize("ncols,nz", [(3, 20), (70, 9)])
+def test_th_columns_vs_oracle(ncols, nz):
+    """soil columns with gravity, Dirichlet boundaries on both equations, permuted internal layout (column tiles):
+    operators and two coupled time steps against the oracle"""
+    rng = np.random.default_rng(5)
+    tp = P.th_columns(ncols=ncols, nz=nz, perm_mult=np.exp(0.3 * rng.standard_normal(ncols)))
+    n = tp.mesh.ncells_local
+    o = P.to_th_oracle(tp)
+    g = P.to_th_gpu(tp, {"ksp_type": "gmres", "pc_type": "ilu"})
+    x = _state(tp, seed=2, dp=(0.0, 9e4), dt=(0.0, 15.0))
+    o.set_dtime(tp.dt); o.pre_solve()
+    g.soe.SetDtime(tp.dt); g.soe.PreSolve()
+    rp, cj, val = o.jacobian(x)
+    rp_g, cj_g, val_g = g.soe.ComputeJacobian(x)
+    assert np.array_equal(rp, rp_g) and np.array_equal(cj, cj_g)
+    J = _dense(rp, cj, val, 2 * n)
+    scale = np.zeros(val.size)
+    for i in range(2 * n):
+        for (a, b) in ((0, n), (n, 2 * n)):
+            sel = np.arange(rp[i], rp[i + 1])[(cj[rp[i]:rp[i + 1]] >= a) & (cj[rp[i]:rp[i + 1]] < b)]
+            scale[sel] = np.abs(val[sel]).max()
+    assert (np.abs(val_g - val) <= 1e-10 * scale + 1e-300).all()
+    f_o, f_g = o.residual(x), g.soe.ComputeResidual(x)
+    # the heat rows are differences of two accumulation terms of size ~ dE/dT * T
+    fscale = np.abs(f_o) + np.abs(J) @ np.concatenate([np.full(n, 1.0), np.full(n, 1e-3)])
+    fscale[n:] += np.abs(np.diag(J)[n:]) * 300.0
+    assert (np.abs(f_g - f_o) <= 1e-11 * fscale + 1e-25).all(), np.abs((f_g - f_o) / fscale).max()
+    v = np.random.default_rng(1).standard_normal(2 * n)
+    z_g, z_o = g.soe.PCApply(v), o.glob.pc_apply(C.PC_ILU0, rp, cj, val, v)
+    assert np.abs(z_g - z_o).max() <= 1e-9 * np.abs(z_o).max()
+    for s in range(2):
+        P.th_set_conditions(tp, o); P.th_gpu_set_conditions(tp, g)
+        co, ro = o.step_dt(tp.dt)
+        cg, rg = g.soe.StepDT(tp.dt, s + 1)
+        assert co and cg and ro == rg
+    p_o, t_o = o.solution()
+    p_g = g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE)
+    t_g = g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, 605)
+    assert np.abs(p_g - p_o).max() <= 1e-8 * np.abs(p_o).max()
+    assert np.abs(t_g - t_o).max() <= 1e-8
+    assert g.soe.counters()["newton"] == o.counters()["newton"]

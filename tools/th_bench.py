@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Coupled thermal-hydrology steps (SURVEY 8 f-2 / BASELINE config 5 shape) on one GPU: nx*ny soil columns x nz layers,
+Richards + enthalpy heat equation, 2N unknowns [P; T], Newton + GMRES(30)/BiCGStab + ILU(0).  Prints Newton
+iterations/s and per-kernel-class statistics."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+import problems as P  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--nx", type=int, default=128)
+    ap.add_argument("--ny", type=int, default=128)
+    ap.add_argument("--nz", type=int, default=80)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--ksp", default="gmres")
+    ap.add_argument("--pc", default="ilu")
+    ap.add_argument("--out", default="")
+    a = ap.parse_args()
+    ncols = a.nx * a.ny
+    t0 = time.perf_counter()
+    tp = P.th_columns(ncols=ncols, nz=a.nz, perm_mult=np.exp(0.5 * np.random.default_rng(12345).standard_normal(ncols)))
+    t_build = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    g = P.to_th_gpu(tp, {"ksp_type": a.ksp, "pc_type": a.pc})
+    t_setup = time.perf_counter() - t0
+    conv, reason = g.soe.StepDT(tp.dt, 1)          # warm-up (ILU analysis, allocations)
+    c0 = g.soe.counters()
+    g.soe.SetOption("profile", 1)
+    g.soe.reset_stats()
+    g.soe.synchronize()
+    t0 = time.perf_counter()
+    for s in range(a.steps):
+        P.th_gpu_set_conditions(tp, g)
+        conv, reason = g.soe.StepDT(tp.dt, s + 2)
+        if not conv:
+            break
+    g.soe.synchronize()
+    t_steps = time.perf_counter() - t0
+    c1 = g.soe.counters()
+    stats = {k: g.soe.kernel_stats(k) for k in ("spmv", "pc_apply", "pc_setup", "residual", "jacobian", "vec", "reduce")}
+    newton = c1["newton"] - c0["newton"]
+    out = {"columns": ncols, "nz": a.nz, "cells": ncols * a.nz, "unknowns": 2 * ncols * a.nz, "ksp": a.ksp, "pc": a.pc,
+           "converged": conv, "reason": reason, "steps": a.steps, "newton_iterations": newton,
+           "linear_iterations": c1["linear"] - c0["linear"], "time_cuts": c1["time_cuts"] - c0["time_cuts"],
+           "newton_its_per_s": newton / t_steps, "steps_s": t_steps, "setup_s": t_setup, "build_s": t_build,
+           "kernels": {k: {"launches": s["launches"], "total_ms": round(s["total_ms"], 3),
+                           "avg_ms": round(s["total_ms"] / s["launches"], 4),
+                           "GBps": (round(s["bytes_per_launch"] * s["launches"] / (s["total_ms"] * 1e-3) / 1e9, 1)
+                                    if s["total_ms"] > 0 and s["bytes_per_launch"] > 0 else None)}
+                       for k, s in stats.items() if s["launches"]}}
+    print(json.dumps(out), flush=True)
+    if a.out:
+        json.dump(out, open(a.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
