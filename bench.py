@@ -212,7 +212,9 @@ def main():
                        "cells": n_global, "cells_per_gpu": ncols_local * args.nz, "dt_s": prob.dt,
                        "parallelism": "columns sharded over %d GPU(s), RCCL all-reduce of Krylov/Newton scalars" % world},
             "newton_iterations": newton, "linear_iterations": linear, "setup_s": round(t_setup, 2),
-            "roofline": {"kernel": "csr_spmv_fp64", "bound": "hbm", "achieved": round(achieved, 1),
+            "roofline": {"kernel": "csr_spmv_fp64 (k_spmv_pipe_c: CSR values + compact 16-bit index, see DESIGN.md section 4)"
+                                   if ncols_local * args.nz >= (1 << 23) and args.spmv_variant < 0 else "csr_spmv_fp64",
+                         "bound": "hbm", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "bytes_per_launch": sp["bytes_per_launch"],
                          "avg_launch_ms": round(avg_ms, 5), "launches": sp["launches"]},

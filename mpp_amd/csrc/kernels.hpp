@@ -91,6 +91,10 @@ void launch_cell_var(const CellArrays &cell, int n, int var_type, double *out, h
 // CSR-stream with 4/2/8 tiles per wave (needs max_row_nnz <= 8, else falls back to variant 0)
 void launch_spmv(int variant, int n, int max_row_nnz, const int *rowptr, const int *col, const double *val,
                  const double *x, double *y, hipStream_t stream);
+// the pipelined kernel on the compact index (16-bit in-tile row offsets + 16-bit column offsets from the tile's first
+// row, int32 tile pointers): needs max_row_nnz <= 8; `tpw` tiles per wave
+void launch_spmv_compact(int tpw, int n, int max_row_nnz, const int *tileptr, const unsigned short *roff, const short *dcol,
+                         const double *val, const double *x, double *y, hipStream_t stream);
 // per-column tridiagonal (block-Jacobi): factor from CSR slots, then apply
 struct TriArgs {
   int ncols, nz;

@@ -98,6 +98,11 @@ struct Solver {
   DevBuf<int> d_cup, d_cdn;
   DevBuf<int> d_rowptr, d_col, d_diag, d_rc_ptr, d_rc_conn, d_rc_slot, d_tri_lo, d_tri_up;
   DevBuf<double> d_val;
+  // compact SpMV index (see k_spmv_pipe_c): built when the pattern allows it
+  DevBuf<int> d_tileptr;
+  DevBuf<unsigned short> d_roff;
+  DevBuf<short> d_dcol;
+  bool compact_index = false;
   DevBuf<int> d_cc_cell, d_cc_ptr, d_bc_type;
   DevBuf<double> d_bc_Dq, d_bc_dgrav, d_bc_area, d_bc_value, d_bc_flux;
   DevBuf<double> d_src;
@@ -476,6 +481,7 @@ struct Solver {
       if (ns > 0 && !has_src) { d_src.alloc(n); d_src.zero(stream); has_src = true; }
       th_liq.assign(n, 0.0); th_ice.assign(n, 0.0); th_snow.assign(n, 0.0); th_tuning.assign(n, 1.0); th_nsnow.assign(n, 0);
     }
+    build_compact_index();
     HIP_CHECK(hipStreamSynchronize(stream));
     setup_done = true;
     soil_dirty = true;
@@ -714,10 +720,39 @@ struct Solver {
   }
   void op_spmv(const double *x, double *y) {
     ProfScope ps(prof, KC_SPMV);
-    launch_spmv(spmv_variant(), nrow, max_row_nnz, d_rowptr.p, d_col.p, d_val.p, x, y, stream);
+    const int v = spmv_variant();
+    if (v == 20 || v == 21) {
+      if (!compact_index) throw Error("spmv_variant 20/21 need the compact index (rows of <= 8 entries whose columns lie within 2^15 of their 64-row tile)");
+      launch_spmv_compact(v == 20 ? 4 : 8, nrow, max_row_nnz, d_tileptr.p, d_roff.p, d_dcol.p, d_val.p, x, y, stream);
+    } else launch_spmv(v, nrow, max_row_nnz, d_rowptr.p, d_col.p, d_val.p, x, y, stream);
+  }
+  // 16-bit in-tile row offsets + 16-bit column offsets from the tile's first row (the pattern is fixed after setup)
+  void build_compact_index() {
+    compact_index = false;
+    if (max_row_nnz > 8) return;
+    const int ntiles = (nrow + 63) / 64;
+    std::vector<int> tp((size_t)ntiles + 2, 0);
+    std::vector<unsigned short> ro(nrow);
+    std::vector<short> dc(nnz);
+    for (int t = 0; t < ntiles; ++t) {
+      const int r0 = t * 64, r1 = std::min(nrow, r0 + 64);
+      tp[t] = h_rowptr[r0];
+      for (int r = r0; r < r1; ++r) {
+        ro[r] = (unsigned short)(h_rowptr[r] - h_rowptr[r0]);
+        for (int k = h_rowptr[r]; k < h_rowptr[r + 1]; ++k) {
+          const int d = h_col[k] - r0;
+          if (d < -32768 || d > 32767) return;
+          dc[k] = (short)d;
+        }
+      }
+    }
+    tp[ntiles] = nnz; tp[ntiles + 1] = nnz;
+    d_tileptr.upload(tp, stream); d_roff.upload(ro.data(), ro.size(), stream); d_dcol.upload(dc.data(), dc.size(), stream);
+    compact_index = true;
   }
   int spmv_variant() const {
     if (opt.spmv_variant >= 0) return opt.spmv_variant;
+    if (compact_index && nrow >= (1 << 23)) return 20;
     // measured on MI355X (profiles/): the software-pipelined wave kernel wins once there are enough row tiles to
     // fill the chip several times over; the block CSR-stream kernel wins on small, cache-resident matrices
     return (max_row_nnz <= 8 && nrow >= (1 << 23)) ? 17 : 1;
@@ -1825,7 +1860,13 @@ int mppgpu_bench_kernel(mppgpu_handle h, const char *name, int variant, int reps
   HIP_CHECK(hipEventCreate(&b));
   int cls;
   auto once = [&]() {
-    if (k == "spmv") { cls = mpp::KC_SPMV; mpp::launch_spmv(variant, S.n, S.max_row_nnz, S.d_rowptr.p, S.d_col.p, S.d_val.p, S.soln.p, S.G.p, S.stream); }
+    if (k == "spmv") {
+      cls = mpp::KC_SPMV;
+      if (variant == 20 || variant == 21) {
+        if (!S.compact_index) throw mpp::Error("no compact index for this pattern");
+        mpp::launch_spmv_compact(variant == 20 ? 4 : 8, S.nrow, S.max_row_nnz, S.d_tileptr.p, S.d_roff.p, S.d_dcol.p, S.d_val.p, S.soln.p, S.G.p, S.stream);
+      } else mpp::launch_spmv(variant, S.nrow, S.max_row_nnz, S.d_rowptr.p, S.d_col.p, S.d_val.p, S.soln.p, S.G.p, S.stream);
+    }
     else if (k == "pc_apply") { cls = mpp::KC_PC_APPLY; S.op_pc_setup(); S.op_pc_apply(S.F.p, S.G.p); }
     else if (k == "pc_setup") { cls = mpp::KC_PC_SETUP; S.pc_ready = false; S.op_pc_setup(); }
     else if (k == "residual") { cls = mpp::KC_RESIDUAL; S.op_residual(S.soln.p, S.G.p); }

@@ -30,7 +30,7 @@ def main():
     conv, reason = soe.StepDT(prob.dt, 1)   # populate J, F, factors with a real state
     rows = []
     plan = [("copy", 0), ("dot", 0), ("waxpy", 0), ("dots3", 0), ("bcgs_xr", 0),
-            ("spmv", 0), ("spmv", 1), ("spmv", 2), ("spmv", 3), ("spmv", 4), ("spmv", 5), ("spmv", 8), ("spmv", 9), ("spmv", 17), ("spmv", 18), ("spmv", 10),
+            ("spmv", 0), ("spmv", 1), ("spmv", 2), ("spmv", 3), ("spmv", 4), ("spmv", 5), ("spmv", 8), ("spmv", 9), ("spmv", 17), ("spmv", 18), ("spmv", 10), ("spmv", 20), ("spmv", 21),
             ("pc_setup", 0), ("pc_apply", 0), ("residual", 0), ("jacobian", 0), ("assemble_both", 0)]
     for name, var in plan:
         ms, by = soe.bench_kernel(name, var, args.reps)
