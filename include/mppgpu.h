@@ -36,6 +36,8 @@ typedef struct mppgpu_handle_s *mppgpu_handle;
 #define MPPGPU_COND_HEAT_FLUX 507
 #define MPPGPU_COND_SEEPAGE_BC 509
 #define MPPGPU_COND_HEAT_RATE 511
+#define MPPGPU_COND_DOWNREG_MASS_RATE_CAMPBELL 512
+#define MPPGPU_COND_DOWNREG_MASS_RATE_FETCH2 513
 #define MPPGPU_VAR_PRESSURE 604
 #define MPPGPU_VAR_TEMPERATURE 605
 #define MPPGPU_VAR_BC_SS_CONDITION 607
@@ -50,6 +52,8 @@ typedef struct mppgpu_handle_s *mppgpu_handle;
 #define MPPGPU_VAR_DHS_DT 621
 #define MPPGPU_VAR_ACTIVE 624
 #define MPPGPU_VAR_TUNING_FACTOR 630
+#define MPPGPU_VAR_POT_MASS_SINK_PRESSURE 638
+#define MPPGPU_VAR_POT_MASS_SINK_EXPONENT 639
 #define MPPGPU_VAR_MASS_FLUX 644
 #define MPPGPU_AUXVAR_INTERNAL 701
 #define MPPGPU_AUXVAR_BC 702
@@ -105,6 +109,26 @@ int mppgpu_set_soil_porosity(mppgpu_handle h, const double *por);
 int mppgpu_set_saturation_function(mppgpu_handle h, const int *satfunc_type, const double *alpha, const double *lambda,
                                    const double *sat_res);
 int mppgpu_set_density_type(mppgpu_handle h, int density_type);
+
+/* Operator split of lateral flow (ELM mode).  mppgpu_set_lateral_connections: the mesh's lateral_conn_set_list
+ * (src/mpp/dtypes/MeshType.F90:53, 635) -- connections that are NOT part of the implicit system.
+ * mppgpu_compute_lateral_flux = soe%ComputeLateralFlux(dt) (src/mpp/soe/SystemOfEquationsVSFMType.F90:848-889 ->
+ * RichardsODEComputeLateralFlux, src/mpp/ge/GoveqnRichardsODEPressureType.F90:2615-2743): SetDtime, PreSolve, then the
+ * Darcy flux of every lateral connection at soln_prev is accumulated [kg/s] (+ at id_up, - at id_dn) into the
+ * COND_MASS_RATE source-sink `ss_cond_id` (the reference locates it by its name 'Lateral_flux'), which must list every
+ * cell once in cell order.  mppgpu_get_condition_values reads a condition's current values back
+ * (SetDataInSOEAuxVar(AUXVAR_SS, ...) in the reference). */
+int mppgpu_set_lateral_connections(mppgpu_handle h, int nconn, const int *id_up, const int *id_dn, const double *dist_up,
+                                   const double *dist_dn, const double *area, const double *unit_vec);
+int mppgpu_compute_lateral_flux(mppgpu_handle h, double dt, int ss_cond_id);
+int mppgpu_get_condition_values(mppgpu_handle h, int kind, int cond_id, int n, double *values);
+
+/* VSFMMPPSetSourceSinkAuxVarRealValue (src/mpp/mpp/MultiPhysicsProbVSFM.F90:1437-1520): var_type
+ * VAR_POT_MASS_SINK_PRESSURE | VAR_POT_MASS_SINK_EXPONENT of the down-regulated potential sinks
+ * (COND_DOWNREG_MASS_RATE_CAMPBELL: rate = value / (1 + (dP/Pc)^n); _FETCH2: value * exp(-(dP/Pc)^n), dP = P - P_ref <= 0;
+ * GoveqnRichardsODEPressureType.F90:1900-1927, 2158-2188).  `values` runs over the concatenation of all source-sink
+ * connections of the equation, in the order the conditions were added. */
+int mppgpu_set_source_sink_auxvar(mppgpu_handle h, int var_type, int n, const double *values);
 
 /* solver selection: the PETSc options database the reference reads through SNESSetFromOptions
  * (src/mpp/mpp/MultiPhysicsProbBaseType.F90:1205).  Keys: "ksp_type" (bcgs|gmres|preonly),

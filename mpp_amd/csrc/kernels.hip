@@ -271,6 +271,37 @@ __global__ __launch_bounds__(kBlock) void k_bc(BcArgs a) {
   if (JAC) a.val[a.diag_slot[cell]] += d;
 }
 
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_sinks(SinkArgs a) {
+  constexpr bool RES = (MODE == 0 || MODE == 2), JAC = (MODE == 1 || MODE == 2), OUT = (MODE == 4);
+  const int j = blockIdx.x * kBlock + threadIdx.x;
+  if (j >= a.ncells) return;
+  const size_t cell = a.cell[j];
+  if (a.active && !a.active[cell]) return;
+  const double dP = a.P[cell] - kPressureRef;
+  double f = RES ? a.F[cell] : 0.0, d = 0.0;
+  for (int e = a.ptr[j]; e < a.ptr[j + 1]; ++e) {
+    const double v = a.value[e], Pc = a.pc[e], n = a.expo[e];
+    const bool campbell = (a.type[e] == 512);
+    const double pw = (dP <= 0.0) ? pow(dP / Pc, n) : 0.0;
+    double rate;   // actual rate [kg/s]
+    if (campbell) {
+      const double factor = (dP <= 0.0) ? 1.0 + pw : 1.0;
+      rate = v / factor;
+      if (RES) f = f - v / factor / kFMWH2O;
+      if (JAC && dP <= 0.0) d += (v / kFMWH2O) * (n * pw) / (dP * (factor * factor));
+    } else {
+      const double factor = (dP <= 0.0) ? exp(-pw) : 1.0;
+      rate = v * factor;
+      if (RES) f = f - v * factor / kFMWH2O;
+      if (JAC && dP <= 0.0) d += (v / kFMWH2O) * (n * pw) * factor / dP;
+    }
+    if (OUT) a.flux_out[e] = rate;
+  }
+  if (RES) a.F[cell] = f;
+  if (JAC) a.val[a.diag_slot[cell]] += d;
+}
+
 __global__ __launch_bounds__(kBlock) void k_conn_flux(CellArrays ca, ConnArrays cn, const int *cup, const int *cdn,
                                                       int nc, double *out) {
   const int ic = blockIdx.x * kBlock + threadIdx.x;
@@ -1172,6 +1203,15 @@ void launch_bc(int mode, const BcArgs &a, hipStream_t stream) {
   else if (mode == 1) LAUNCH(k_bc<1>, grid, a);
   else if (mode == 2) LAUNCH(k_bc<2>, grid, a);
   else LAUNCH(k_bc<4>, grid, a);
+}
+
+void launch_sinks(int mode, const SinkArgs &a, hipStream_t stream) {
+  if (a.ncells <= 0) return;
+  dim3 grid(nblk(a.ncells));
+  if (mode == 0) LAUNCH(k_sinks<0>, grid, a);
+  else if (mode == 1) LAUNCH(k_sinks<1>, grid, a);
+  else if (mode == 2) LAUNCH(k_sinks<2>, grid, a);
+  else LAUNCH(k_sinks<4>, grid, a);
 }
 
 void launch_conn_flux(const CellArrays &cell, const ConnArrays &conn, const int *cup, const int *cdn, int nc,

@@ -80,6 +80,21 @@ struct BcArgs {
 };
 void launch_bc(int mode, const BcArgs &a, hipStream_t stream);
 
+// ---- down-regulated potential mass sinks (COND_DOWNREG_MASS_RATE_CAMPBELL / _FETCH2, GoveqnRichardsODEPressureType.F90
+// :1900-1927 residual, :2158-2188 Jacobian): one thread per cell that carries such sinks ----
+struct SinkArgs {
+  const double *P;                       // pressure the sinks are evaluated at
+  const signed char *active;
+  int ncells;
+  const int *cell, *ptr;                 // cells with sinks; their entries ptr[j]..ptr[j+1]
+  const int *type;                       // 512 Campbell | 513 FETCH2
+  const double *value, *pc, *expo;       // potential rate [kg/s], pot_mass_sink_pressure, pot_mass_sink_exponent
+  const int *diag_slot;
+  double *F, *val;
+  double *flux_out;                      // mode 4: actual rate [kg/s] per entry
+};
+void launch_sinks(int mode, const SinkArgs &a, hipStream_t stream);   // mode 0 residual, 1 Jacobian, 2 both, 4 flux output
+
 // internal-connection mass flux [kg/s] at the pressure in cell.P (VAR_MASS_FLUX, AUXVAR_CONN_INTERNAL)
 void launch_conn_flux(const CellArrays &cell, const ConnArrays &conn, const int *cup, const int *cdn, int nc,
                       double *flux_out, hipStream_t stream);

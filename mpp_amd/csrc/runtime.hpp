@@ -98,6 +98,7 @@ struct Condition {
   int eqn = 0;                         // coupled TH: 0 mass equation, 1 heat equation
   std::vector<int> cell;               // external 0-based
   std::vector<double> dist_up, dist_dn, area, uvec, value;
+  std::vector<double> sink_p, sink_n;  // down-regulated sinks: pot_mass_sink_pressure / _exponent
   std::vector<double> other;           // coupled TH: temperature (mass eqn) / pressure (heat eqn) of the boundary auxvar
   int offset = 0;                      // first entry in the concatenated BC (or SS) numbering
 };

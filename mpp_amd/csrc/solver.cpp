@@ -72,6 +72,12 @@ struct Solver {
   std::vector<int> cup_e, cdn_e;
   std::vector<double> cdu, cdd, carea, cuv;
   std::vector<Condition> bcs, sss;
+  // mesh%lateral_conn_set_list (operator split: RichardsODEComputeLateralFlux, GE:2615-2743)
+  int nlat = 0;
+  std::vector<int> lat_up_e, lat_dn_e;
+  std::vector<double> lat_du, lat_dd, lat_area, lat_uv;
+  DevBuf<int> d_lat_up, d_lat_dn;
+  DevBuf<double> d_lat_Dq, d_lat_upw, d_lat_dgrav, d_lat_area, d_lat_flux;
   std::vector<double> permx, permy, permz, por, alpha, lam, sat_res;
   std::vector<int> satf;
   int sat_func = -1;
@@ -107,6 +113,12 @@ struct Solver {
   DevBuf<double> d_bc_Dq, d_bc_dgrav, d_bc_area, d_bc_value, d_bc_flux;
   DevBuf<double> d_src;
   bool has_src = false;
+  // down-regulated sinks, grouped by cell
+  int ndr_cells = 0, ndr = 0;
+  std::vector<int> dr_pos_of_g;          // position of (condition offset + i) in the grouped arrays, -1 if not down-regulated
+  std::vector<double> h_dr_value, h_dr_pc, h_dr_n;
+  DevBuf<int> d_dr_cell, d_dr_ptr, d_dr_type;
+  DevBuf<double> d_dr_value, d_dr_pc, d_dr_n, d_dr_flux;
   DevBuf<int> d_ext2int, d_int2ext;
   DevBuf<double> soln, soln_prev, accum_prev, F, Y, W, G, R, RP, V, T, S, Pv, Wk, tmp_ext, tmp_int;
   DevBuf<double> aux_kr, aux_dkr, aux_den, aux_dden;
@@ -188,6 +200,21 @@ struct Solver {
     cdu.assign(du, du + nc); cdd.assign(dd, dd + nc); carea.assign(ar, ar + nc); cuv.assign(uv, uv + 3 * (size_t)nc);
   }
 
+  void set_lateral_connections(int nconn, const int *up, const int *dn, const double *du, const double *dd, const double *ar,
+                               const double *uv) {
+    if (n == 0) throw Error("mppgpu_set_mesh must precede mppgpu_set_lateral_connections");
+    lat_up_e.resize(nconn); lat_dn_e.resize(nconn);
+    for (int c = 0; c < nconn; ++c) {
+      if (up[c] < 1 || up[c] > n || dn[c] < 1 || dn[c] > n)
+        throw Error("lateral connection " + std::to_string(c + 1) + ": cell id out of range");
+      lat_up_e[c] = up[c] - 1; lat_dn_e[c] = dn[c] - 1;
+    }
+    nlat = nconn;
+    lat_du.assign(du, du + nconn); lat_dd.assign(dd, dd + nconn); lat_area.assign(ar, ar + nconn);
+    lat_uv.assign(uv, uv + 3 * (size_t)nconn);
+    soil_dirty = true;
+  }
+
   // igoveqn: 1 = the (only, or mass) equation, 2 = the heat equation of the coupled thermal-hydrology system
   int add_condition(int kind, int cond_type, int nconn, const int *id_dn, const double *du, const double *dd,
                     const double *ar, const double *uv, int swap_order, int igoveqn = 1) {
@@ -204,7 +231,8 @@ struct Solver {
       if (!ok) throw Error("unsupported boundary cond_type " + std::to_string(cond_type));
       list = &bcs;
     } else if (kind == MPPGPU_COND_SS) {
-      if (cond_type != (heat ? MPPGPU_COND_HEAT_RATE : MPPGPU_COND_MASS_RATE))
+      const bool downreg = (cond_type == MPPGPU_COND_DOWNREG_MASS_RATE_CAMPBELL || cond_type == MPPGPU_COND_DOWNREG_MASS_RATE_FETCH2);
+      if (cond_type != (heat ? MPPGPU_COND_HEAT_RATE : MPPGPU_COND_MASS_RATE) && !(downreg && !heat && !th))
         throw Error("unsupported source-sink cond_type " + std::to_string(cond_type));
       list = &sss;
     } else throw Error("unknown condition kind " + std::to_string(kind));
@@ -223,6 +251,7 @@ struct Solver {
       c.uvec.assign(uv, uv + 3 * (size_t)nconn);
     }
     c.value.assign(nconn, 0.0);
+    c.sink_p.assign(nconn, 0.0); c.sink_n.assign(nconn, 0.0);
     // the SoE numbers conditions equation by equation (mass first): keep the list in that order
     auto pos = list->end();
     if (th && c.eqn == 0) pos = std::find_if(list->begin(), list->end(), [](const Condition &q) { return q.eqn == 1; });
@@ -452,6 +481,30 @@ struct Solver {
       d_bc_Dq.alloc(nb); d_bc_dgrav.alloc(nb); d_bc_area.alloc(nb);
     }
     if (ns > 0) { d_src.alloc(nrow); d_src.zero(stream); has_src = true; }
+    {  // down-regulated sinks grouped by cell, (condition, connection) order kept inside a cell
+      std::vector<std::pair<int, int>> key;
+      std::vector<int> gtype(ns, 0);
+      for (auto &c : sss)
+        if (c.cond_type == MPPGPU_COND_DOWNREG_MASS_RATE_CAMPBELL || c.cond_type == MPPGPU_COND_DOWNREG_MASS_RATE_FETCH2)
+          for (int i = 0; i < c.n; ++i) { key.push_back({ext2int[c.cell[i]], c.offset + i}); gtype[c.offset + i] = c.cond_type; }
+      std::sort(key.begin(), key.end());
+      ndr = (int)key.size();
+      dr_pos_of_g.assign(ns, -1);
+      std::vector<int> cell, ptr, type(ndr);
+      for (int e = 0; e < ndr; ++e) {
+        if (e == 0 || key[e].first != key[e - 1].first) { cell.push_back(key[e].first); ptr.push_back(e); }
+        dr_pos_of_g[key[e].second] = e;
+        type[e] = gtype[key[e].second];
+      }
+      ptr.push_back(ndr);
+      ndr_cells = (int)cell.size();
+      h_dr_value.assign(ndr, 0.0); h_dr_pc.assign(ndr, 0.0); h_dr_n.assign(ndr, 0.0);
+      if (ndr > 0) {
+        d_dr_cell.upload(cell, stream); d_dr_ptr.upload(ptr, stream); d_dr_type.upload(type, stream);
+        d_dr_flux.alloc(ndr);
+        upload_sink_params();
+      }
+    }
     // vectors
     for (DevBuf<double> *b : {&soln, &soln_prev, &accum_prev, &F, &Y, &W, &G, &R, &RP, &V, &T, &S, &Pv, &Wk, &tmp_ext, &tmp_int}) {
       b->alloc(nrow); b->zero(stream);
@@ -486,6 +539,32 @@ struct Solver {
     setup_done = true;
     soil_dirty = true;
     check_ilu();
+  }
+
+  void upload_sink_params() {
+    for (auto &c : sss)
+      for (int i = 0; i < c.n; ++i) {
+        const int e = dr_pos_of_g.empty() ? -1 : dr_pos_of_g[c.offset + i];
+        if (e < 0) continue;
+        h_dr_value[e] = c.value[i]; h_dr_pc[e] = c.sink_p[i]; h_dr_n[e] = c.sink_n[i];
+      }
+    if (ndr > 0) { d_dr_value.upload(h_dr_value, stream); d_dr_pc.upload(h_dr_pc, stream); d_dr_n.upload(h_dr_n, stream); }
+  }
+  // VSFMMPPSetSourceSinkAuxVarRealValue (MultiPhysicsProbVSFM.F90:1437-1520): values over the concatenated SS connections
+  void set_ss_auxvar(int var_type, int cnt, const double *values) {
+    if (var_type != MPPGPU_VAR_POT_MASS_SINK_PRESSURE && var_type != MPPGPU_VAR_POT_MASS_SINK_EXPONENT)
+      throw Error("VSFMMPPSetSourceSinkAuxVarRealValue: Unknown var_type");
+    int sum_conn = 0;
+    for (auto &c : sss)
+      for (int i = 0; i < c.n; ++i, ++sum_conn) {
+        if (sum_conn >= cnt) throw Error("fewer values than source-sink connections");
+        (var_type == MPPGPU_VAR_POT_MASS_SINK_PRESSURE ? c.sink_p : c.sink_n)[i] = values[sum_conn];
+      }
+    if (setup_done) { upload_sink_params(); HIP_CHECK(hipStreamSynchronize(stream)); }
+  }
+  SinkArgs sink_args(const double *P, double *Fout) const {
+    return SinkArgs{P, any_inactive ? d_active.p : nullptr, ndr_cells, d_dr_cell.p, d_dr_ptr.p, d_dr_type.p, d_dr_value.p,
+                    d_dr_pc.p, d_dr_n.p, d_diag.p, Fout, d_val.p, d_dr_flux.p};
   }
 
   // coupled thermal-hydrology: the 2N x 2N pattern (four blocks with the mesh pattern, rows [P(1..N); T(1..N)]),
@@ -576,6 +655,20 @@ struct Solver {
         }
       }
       d_bc_Dq.upload(Dq, stream); d_bc_dgrav.upload(dg, stream); d_bc_area.upload(ar, stream);
+    }
+    if (nlat > 0) {
+      std::vector<double> Dq(nlat), upw(nlat), dg(nlat), ar(nlat);
+      std::vector<int> up(nlat), dn(nlat);
+      for (int c = 0; c < nlat; ++c) {
+        const int u = lat_up_e[c], d = lat_dn_e[c];
+        const double pu[3] = {permx[u], permy[u], permz[u]}, pd[3] = {permx[d], permy[d], permz[d]};
+        ConnGeom g = make_conn_geom(true, lat_area[c], lat_du[c], lat_dd[c], &lat_uv[3 * (size_t)c], pu, pd);
+        Dq[c] = g.Dq; upw[c] = g.upweight; dg[c] = g.dist_gravity; ar[c] = g.area;
+        up[c] = ext2int[u]; dn[c] = ext2int[d];
+      }
+      d_lat_Dq.upload(Dq, stream); d_lat_upw.upload(upw, stream); d_lat_dgrav.upload(dg, stream); d_lat_area.upload(ar, stream);
+      d_lat_up.upload(up, stream); d_lat_dn.upload(dn, stream);
+      d_lat_flux.alloc(nlat);
     }
     if (th) {
       if ((int)the_heat_cap.size() != n) throw Error("heat-equation soil properties are not set (mppgpu_th_set_soils)");
@@ -688,6 +781,7 @@ struct Solver {
       launch_assemble_general(0, gen_args(P, Fout), stream);
     }
     launch_bc(0, bc_args(P, Fout), stream);
+    launch_sinks(0, sink_args(P, Fout), stream);
     ++nfuncs; ++cum_funcs;
   }
   // residual and Jacobian of the same state in one pass: the auxvars (the expensive part) are evaluated once
@@ -701,6 +795,7 @@ struct Solver {
       launch_assemble_general(2, gen_args(P, Fout), stream);
     }
     launch_bc(2, bc_args(P, Fout), stream);
+    launch_sinks(2, sink_args(P, Fout), stream);
     ++nfuncs; ++cum_funcs;
     pc_ready = false;
   }
@@ -711,6 +806,7 @@ struct Solver {
     if (use_cols()) launch_assemble_cols(1, cols_args(P, F.p), stream);
     else launch_assemble_general(1, gen_args(P, F.p), stream);
     launch_bc(1, bc_args(P, F.p), stream);
+    launch_sinks(1, sink_args(P, F.p), stream);
     pc_ready = false;
   }
   void op_pre_solve() {  // VSFMSOEPreSolve: accum_prev from soln_prev
@@ -1335,17 +1431,57 @@ struct Solver {
       Condition &c = sss[cond_id - 1];
       if (cnt > c.n) throw Error("set_data: size(data_1d) > nauxvar");
       for (int i = 0; i < cnt; ++i) c.value[i] = data[i];
-      // dense per-cell source [kmol/s]: sum over all mass-rate conditions of value/FMWH2O (GE:1896)
-      std::vector<double> src(nrow, 0.0);
-      for (auto &s : sss)
-        for (int i = 0; i < s.n; ++i) {
-          if (!active[s.cell[i]]) continue;
-          if (s.eqn == 0) src[ext2int[s.cell[i]]] += s.value[i] / kFMWH2O;
-          else src[n + ext2int[s.cell[i]]] += s.value[i];   // COND_HEAT_RATE [W] (GoveqnThermalEnthalpySoilType.F90:1481)
-        }
-      d_src.upload(src, stream);
-      HIP_CHECK(hipStreamSynchronize(stream));
+      rebuild_src();
     } else throw Error("set_data: unknown auxvar_type " + std::to_string(auxvar_type));
+  }
+
+  // dense per-cell source: sum over all mass-rate conditions of value/FMWH2O [kmol/s] (GE:1896); coupled TH: heat rates [W]
+  void rebuild_src() {
+    std::vector<double> src(nrow, 0.0);
+    for (auto &s : sss)
+      for (int i = 0; i < s.n; ++i) {
+        if (!active[s.cell[i]]) continue;
+        if (s.cond_type == MPPGPU_COND_DOWNREG_MASS_RATE_CAMPBELL || s.cond_type == MPPGPU_COND_DOWNREG_MASS_RATE_FETCH2) continue;
+        if (s.eqn == 0) src[ext2int[s.cell[i]]] += s.value[i] / kFMWH2O;
+        else src[n + ext2int[s.cell[i]]] += s.value[i];   // COND_HEAT_RATE [W] (GoveqnThermalEnthalpySoilType.F90:1481)
+      }
+    d_src.upload(src, stream);
+    upload_sink_params();
+    HIP_CHECK(hipStreamSynchronize(stream));
+  }
+
+  // VSFMComputeLateralFlux (SystemOfEquationsVSFMType.F90:848-889) + RichardsODEComputeLateralFlux (GE:2615-2743):
+  // SetDtime, PreSolve, then the Darcy flux of every lateral connection at soln_prev, accumulated [kg/s] into the
+  // mass-rate condition `cond_id` (the reference's 'Lateral_flux' source-sink: one entry per cell, in cell order)
+  void compute_lateral_flux(double dt, int cond_id) {
+    if (th || thermal) throw Error("lateral-flux operator split is a VSFM operation");
+    if (cond_id < 1 || cond_id > (int)sss.size()) throw Error("RichardsODEComputeLateralFlux: Lateral source-sink not found.");
+    Condition &lc = sss[cond_id - 1];
+    if (lc.cond_type != MPPGPU_COND_MASS_RATE || lc.n != n) throw Error("the lateral-flux condition must be a COND_MASS_RATE over every cell");
+    for (int i = 0; i < n; ++i) if (lc.cell[i] != i) throw Error("the lateral-flux condition must list the cells in order");
+    if (!(dt > 0.0)) throw Error("dt must be positive");
+    dtime = dt;
+    ensure_ready();
+    op_pre_solve();
+    std::fill(lc.value.begin(), lc.value.end(), 0.0);
+    if (nlat > 0) {
+      launch_conn_flux(cells(soln_prev.p), ConnArrays{d_lat_Dq.p, d_lat_upw.p, d_lat_dgrav.p, d_lat_area.p}, d_lat_up.p, d_lat_dn.p,
+                       nlat, d_lat_flux.p, stream);
+      std::vector<double> fl(nlat);
+      HIP_CHECK(hipMemcpyAsync(fl.data(), d_lat_flux.p, (size_t)nlat * sizeof(double), hipMemcpyDeviceToHost, stream));
+      HIP_CHECK(hipStreamSynchronize(stream));
+      for (int c = 0; c < nlat; ++c) {   // flux*FMWH2O [kg/s] (GE:2733-2737)
+        lc.value[lat_up_e[c]] = lc.value[lat_up_e[c]] + fl[c];
+        lc.value[lat_dn_e[c]] = lc.value[lat_dn_e[c]] - fl[c];
+      }
+    }
+    rebuild_src();
+  }
+  void get_condition_values(int kind, int cond_id, int cnt, double *out) const {
+    const std::vector<Condition> &list = kind == MPPGPU_COND_BC ? bcs : sss;
+    if (cond_id < 1 || cond_id > (int)list.size()) throw Error("bad condition id");
+    if (cnt > list[cond_id - 1].n) throw Error("size(data_1d) > nauxvar");
+    for (int i = 0; i < cnt; ++i) out[i] = list[cond_id - 1].value[i];
   }
 
   void get_data(int auxvar_type, int var_type, int cond_id, int cnt, double *out) {
@@ -1376,7 +1512,16 @@ struct Solver {
       if (var_type != MPPGPU_VAR_MASS_FLUX) throw Error("get_data: unknown var_type");
       Condition &c = sss[cond_id - 1];
       if (cnt > c.n) throw Error("get_data: size(data_1d) > nauxvar");
-      for (int i = 0; i < cnt; ++i) out[i] = c.value[i];  // ss_flux = cur_cond%value (GE:1898)
+      std::vector<double> fl(ndr);
+      if (ndr > 0) {   // down-regulated: ss_flux = value / factor (Campbell) or value * factor (FETCH2) (GE:1911, 1927)
+        launch_sinks(4, sink_args(soln.p, F.p), stream);
+        HIP_CHECK(hipMemcpyAsync(fl.data(), d_dr_flux.p, ndr * sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+      }
+      for (int i = 0; i < cnt; ++i) {
+        const int e = dr_pos_of_g[c.offset + i];
+        out[i] = e >= 0 ? fl[e] : c.value[i];  // ss_flux = cur_cond%value (GE:1898)
+      }
     } else if (auxvar_type == MPPGPU_AUXVAR_CONN_INTERNAL) {
       if (var_type != MPPGPU_VAR_MASS_FLUX) throw Error("get_data: unknown var_type");
       if (cnt > nc) throw Error("get_data: size(data_1d) > nauxvar");
@@ -1608,6 +1753,28 @@ int mppgpu_add_condition(mppgpu_handle h, int kind, int cond_type, int nconn, co
   API_BEGIN(h)
   const int id = S.add_condition(kind, cond_type, nconn, id_dn, dist_up, dist_dn, area, unit_vec, swap_order);
   if (cond_id) *cond_id = id;
+  API_END()
+}
+int mppgpu_set_lateral_connections(mppgpu_handle h, int nconn, const int *id_up, const int *id_dn, const double *dist_up,
+                                   const double *dist_dn, const double *area, const double *unit_vec) {
+  API_BEGIN(h)
+  S.set_lateral_connections(nconn, id_up, id_dn, dist_up, dist_dn, area, unit_vec);
+  API_END()
+}
+int mppgpu_compute_lateral_flux(mppgpu_handle h, double dt, int ss_cond_id) {
+  API_BEGIN(h)
+  S.need_setup(true);
+  S.compute_lateral_flux(dt, ss_cond_id);
+  API_END()
+}
+int mppgpu_get_condition_values(mppgpu_handle h, int kind, int cond_id, int n, double *values) {
+  API_BEGIN(h)
+  S.get_condition_values(kind, cond_id, n, values);
+  API_END()
+}
+int mppgpu_set_source_sink_auxvar(mppgpu_handle h, int var_type, int n, const double *values) {
+  API_BEGIN(h)
+  S.set_ss_auxvar(var_type, n, values);
   API_END()
 }
 int mppgpu_th_add_condition(mppgpu_handle h, int igoveqn, int kind, int cond_type, int nconn, const int *id_dn,

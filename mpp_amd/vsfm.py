@@ -135,6 +135,22 @@ class SystemOfEquationsVSFM:
                                          data_1d.ctypes.data_as(ct.POINTER(ct.c_double))))
         return data_1d
 
+    def SetLateralConnections(self, conn_set):
+        """mesh%lateral_conn_set_list: connections handled by the explicit lateral-flux operator split"""
+        up, pup = _i(conn_set.id_up); dn, pdn = _i(conn_set.id_dn)
+        du, pdu = _d(conn_set.dist_up); dd, pdd = _d(conn_set.dist_dn); ar, par = _d(conn_set.area); uv, puv = _d(conn_set.unit_vec)
+        self._chk(self.L.mppgpu_set_lateral_connections(self.h, conn_set.num_connections, pup, pdn, pdu, pdd, par, puv))
+
+    def ComputeLateralFlux(self, dt, lateral_ss_id):
+        """VSFMComputeLateralFlux (SystemOfEquationsVSFMType.F90:848-889); lateral_ss_id: the 'Lateral_flux' condition"""
+        self._chk(self.L.mppgpu_compute_lateral_flux(self.h, float(dt), int(lateral_ss_id)))
+
+    def GetConditionValues(self, kind, cond_id):
+        n = (self._bc_sizes if kind == C.COND_BC else self._ss_sizes)[cond_id - 1]
+        out = np.zeros(n)
+        self._chk(self.L.mppgpu_get_condition_values(self.h, kind, cond_id, n, out.ctypes.data_as(ct.POINTER(ct.c_double))))
+        return out
+
     def counters(self):
         a, b, c, d = ct.c_longlong(), ct.c_longlong(), ct.c_longlong(), ct.c_longlong()
         self._chk(self.L.mppgpu_get_counters(self.h, ct.byref(a), ct.byref(b), ct.byref(c), ct.byref(d)))
@@ -295,6 +311,13 @@ def VSFMMPPSetSaturationFunction(vsfm_mpp, igoveqn, vsfm_satfunc_type, alpha, la
 
 def VSFMMPPSetDensityType(vsfm_mpp, igoveqn, density_type):
     vsfm_mpp.soe._chk(vsfm_mpp.soe.L.mppgpu_set_density_type(vsfm_mpp.soe.h, int(density_type)))
+
+
+def VSFMMPPSetSourceSinkAuxVarRealValue(vsfm_mpp, igoveqn, var_type, var_value):
+    """VSFMMPPSetSourceSinkAuxVarRealValue (MultiPhysicsProbVSFM.F90:1437-1520): VAR_POT_MASS_SINK_PRESSURE / _EXPONENT of
+    the down-regulated sinks, values over the concatenated source-sink connections."""
+    v, pv = _d(var_value)
+    vsfm_mpp.soe._chk(vsfm_mpp.soe.L.mppgpu_set_source_sink_auxvar(vsfm_mpp.soe.h, int(var_type), v.size, pv))
 
 
 _SATFUNC_NAMES = {

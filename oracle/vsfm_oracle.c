@@ -509,8 +509,65 @@ vo_problem *vo_create(int ncells) {
   return p;
 }
 
+int vo_set_lateral_connections(vo_problem *p, int nconn, const int *id_up, const int *id_dn, const double *dist_up,
+                               const double *dist_dn, const double *area, const double *unitvec) {
+  free(p->lat_up); free(p->lat_dn); free(p->lat_geom);
+  p->nlat = nconn;
+  p->lat_up = (int *)malloc((nconn + 1) * sizeof(int)); p->lat_dn = (int *)malloc((nconn + 1) * sizeof(int));
+  p->lat_geom = (conn_geom *)calloc(nconn + 1, sizeof(conn_geom));
+  for (int c = 0; c < nconn; c++) {
+    if (id_up[c] < 1 || id_up[c] > p->n || id_dn[c] < 1 || id_dn[c] > p->n) FAIL("lateral connection: cell id out of range");
+    p->lat_up[c] = id_up[c] - 1; p->lat_dn[c] = id_dn[c] - 1;
+    p->lat_geom[c].area = area[c]; p->lat_geom[c].dist_up = dist_up[c]; p->lat_geom[c].dist_dn = dist_dn[c];
+    for (int k = 0; k < 3; k++) p->lat_geom[c].uvec[k] = unitvec[3 * c + k];
+  }
+  return 0;
+}
+
+/* VSFMComputeLateralFlux + RichardsODEComputeLateralFlux */
+int vo_compute_lateral_flux(vo_problem *p, double dt, int ss_cond_id) {
+  if (ss_cond_id < 1 || ss_cond_id > p->nss) FAIL("RichardsODEComputeLateralFlux: Lateral source-sink not found.");
+  condition *lc = &p->ss[ss_cond_id - 1];
+  if (lc->cond_type != VO_COND_MASS_RATE || lc->n != p->n) FAIL("the lateral-flux condition must be a COND_MASS_RATE over every cell");
+  for (int i = 0; i < lc->n; i++) if (lc->id_dn[i] != i) FAIL("the lateral-flux condition must list the cells in order");
+  vo_set_dtime(p, dt);
+  vo_pre_solve(p);
+  double flux, d1, d2;
+  for (int i = 0; i < lc->n; i++) lc->value[i] = 0.0;
+  for (int c = 0; c < p->nlat; c++) {
+    int u = p->lat_up[c], d = p->lat_dn[c];
+    if (!p->active[u] || !p->active[d]) continue;
+    richards_flux(&p->aux[u], &p->aux[d], &p->lat_geom[c], 0, 1, 0, VO_COND_NULL, &flux, &d1, &d2);
+    lc->value[u] = lc->value[u] + flux * FMWH2O;
+    lc->value[d] = lc->value[d] - flux * FMWH2O;
+  }
+  return 0;
+}
+
+int vo_get_condition_values(vo_problem *p, int kind, int cond_id, int n, double *values) {
+  int cnt = kind == VO_COND_BC ? p->nbc : p->nss;
+  if (cond_id < 1 || cond_id > cnt) FAIL("bad condition id");
+  condition *c = kind == VO_COND_BC ? &p->bc[cond_id - 1] : &p->ss[cond_id - 1];
+  if (n > c->n) FAIL("size(data_1d) > nauxvar");
+  for (int i = 0; i < n; i++) values[i] = c->value[i];
+  return 0;
+}
+
+int vo_set_source_sink_auxvar(vo_problem *p, int var_type, int n, const double *values) {
+  if (var_type != VO_VAR_POT_MASS_SINK_PRESSURE && var_type != VO_VAR_POT_MASS_SINK_EXPONENT)
+    FAIL("VSFMMPPSetSourceSinkAuxVarRealValue: Unknown var_type");
+  int sum_conn = 0;
+  for (int s = 0; s < p->nss; s++)
+    for (int i = 0; i < p->ss[s].n; i++, sum_conn++) {
+      if (sum_conn >= n) FAIL("fewer values than source-sink connections");
+      (var_type == VO_VAR_POT_MASS_SINK_PRESSURE ? p->ss[s].sink_pressure : p->ss[s].sink_exponent)[i] = values[sum_conn];
+    }
+  return 0;
+}
+
 static void free_cond(condition *c) {
   free(c->id_dn); free(c->geom); free(c->aux); free(c->value); free(c->flux);
+  free(c->sink_pressure); free(c->sink_exponent);
 }
 
 void vo_destroy(vo_problem *p) {
@@ -522,6 +579,7 @@ void vo_destroy(vo_problem *p) {
   free(p->rowptr); free(p->col); free(p->diag_slot); free(p->slot_uu); free(p->slot_ud); free(p->slot_du);
   free(p->slot_dd); free(p->val); free(p->soln); free(p->soln_prev); free(p->accum_prev);
   free(p->block_ptr); free(p->block_cells);
+  free(p->lat_up); free(p->lat_dn); free(p->lat_geom);
   free(p);
 }
 
@@ -611,7 +669,9 @@ int vo_add_condition(vo_problem *p, int kind, int cond_type, int nconn, const in
   if (kind == VO_COND_BC && cond_type != VO_COND_DIRICHLET && cond_type != VO_COND_SEEPAGE_BC &&
       cond_type != VO_COND_MASS_FLUX)
     FAIL("unsupported BC cond_type %d", cond_type);
-  if (kind == VO_COND_SS && cond_type != VO_COND_MASS_RATE) FAIL("unsupported SS cond_type %d", cond_type);
+  if (kind == VO_COND_SS && cond_type != VO_COND_MASS_RATE && cond_type != VO_COND_DOWNREG_MASS_RATE_CAMPBELL &&
+      cond_type != VO_COND_DOWNREG_MASS_RATE_FETCH2)
+    FAIL("unsupported SS cond_type %d", cond_type);
   *list = (condition *)realloc(*list, (*cnt + 1) * sizeof(condition));
   condition *c = &(*list)[*cnt];
   memset(c, 0, sizeof *c);
@@ -621,6 +681,8 @@ int vo_add_condition(vo_problem *p, int kind, int cond_type, int nconn, const in
   c->aux = (auxvar *)malloc((nconn + 1) * sizeof(auxvar));
   c->value = (double *)calloc(nconn + 1, sizeof(double));
   c->flux = (double *)calloc(nconn + 1, sizeof(double));
+  c->sink_pressure = (double *)calloc(nconn + 1, sizeof(double));
+  c->sink_exponent = (double *)calloc(nconn + 1, sizeof(double));
   for (int i = 0; i < nconn; i++) {
     if (id_dn[i] < 1 || id_dn[i] > p->n) FAIL("condition: cell id out of range");
     c->id_dn[i] = id_dn[i] - 1;
@@ -770,8 +832,21 @@ static void divergence(vo_problem *p, double *ff) {
     for (int i = 0; i < cd->n; i++) {
       int cell = cd->id_dn[i];
       if (!p->active[cell]) continue; /* active_conn_ids */
-      ff[cell] -= cd->value[i] / FMWH2O; /* COND_MASS_RATE :1896 */
-      cd->flux[i] = cd->value[i];
+      if (cd->cond_type == VO_COND_MASS_RATE) {
+        ff[cell] -= cd->value[i] / FMWH2O; /* :1896 */
+        cd->flux[i] = cd->value[i];
+      } else { /* down-regulated potential sinks :1900-1927 */
+        double dP = p->aux[cell].pressure - PRESSURE_REF, Pc = cd->sink_pressure[i], n = cd->sink_exponent[i], factor;
+        if (cd->cond_type == VO_COND_DOWNREG_MASS_RATE_CAMPBELL) {
+          factor = (dP <= 0.0) ? 1.0 + pow(dP / Pc, n) : 1.0;
+          ff[cell] = ff[cell] - cd->value[i] / factor / FMWH2O;
+          cd->flux[i] = cd->value[i] / factor;
+        } else {
+          factor = (dP <= 0.0) ? exp(-pow(dP / Pc, n)) : 1.0;
+          ff[cell] = ff[cell] - cd->value[i] * factor / FMWH2O;
+          cd->flux[i] = cd->value[i] * factor;
+        }
+      }
     }
   }
 }
@@ -819,6 +894,26 @@ static void jacobian_assemble(vo_problem *p) {
       if (!p->active[cell]) continue;
       richards_flux(&cd->aux[i], &p->aux[cell], &cd->geom[i], 1, 0, cd->swap_order, cd->cond_type, &flux, &Jup, &Jdn);
       p->val[p->diag_slot[cell]] += -Jdn;
+    }
+  }
+  for (int s = 0; s < p->nss; s++) { /* :2141-2195 */
+    condition *cd = &p->ss[s];
+    if (cd->cond_type == VO_COND_MASS_RATE) continue;
+    for (int i = 0; i < cd->n; i++) {
+      int cell = cd->id_dn[i];
+      if (!p->active[cell]) continue;
+      double dP = p->aux[cell].pressure - PRESSURE_REF, Pc = cd->sink_pressure[i], n = cd->sink_exponent[i];
+      if (dP <= 0.0) {
+        double val;
+        if (cd->cond_type == VO_COND_DOWNREG_MASS_RATE_CAMPBELL) {
+          double factor = 1.0 + pow(dP / Pc, n);
+          val = (cd->value[i] / FMWH2O) * (n * pow(dP / Pc, n)) / (dP * pow(factor, 2.0));
+        } else {
+          double factor = exp(-pow(dP / Pc, n));
+          val = (cd->value[i] / FMWH2O) * (n * pow(dP / Pc, n)) * factor / dP;
+        }
+        p->val[p->diag_slot[cell]] += val;
+      }
     }
   }
   double dtInv = 1.0 / p->dtime;

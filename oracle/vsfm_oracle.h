@@ -34,8 +34,9 @@ extern "C" {
 enum {
   VO_COND_NULL = 500, VO_COND_BC = 501, VO_COND_SS = 502, VO_COND_MASS_RATE = 503,
   VO_COND_MASS_FLUX = 504, VO_COND_DIRICHLET = 505, VO_COND_DIRICHLET_FRM_OTR_GOVEQ = 506,
-  VO_COND_SEEPAGE_BC = 509
+  VO_COND_SEEPAGE_BC = 509, VO_COND_DOWNREG_MASS_RATE_CAMPBELL = 512, VO_COND_DOWNREG_MASS_RATE_FETCH2 = 513
 };
+enum { VO_VAR_POT_MASS_SINK_PRESSURE = 638, VO_VAR_POT_MASS_SINK_EXPONENT = 639 };
 enum { VO_VAR_PRESSURE = 604, VO_VAR_LIQ_SAT = 608, VO_VAR_MASS = 610,
        VO_VAR_SOIL_MATRIX_POT = 611, VO_VAR_MASS_FLUX = 644 };
 enum { VO_AUXVAR_INTERNAL = 701, VO_AUXVAR_BC = 702, VO_AUXVAR_SS = 703, VO_AUXVAR_CONN_INTERNAL = 704 };
@@ -82,6 +83,17 @@ int vo_set_saturation_function(vo_problem *p, const int *satfunc_type, const dou
                                const double *lambda, const double *sat_res);
 int vo_set_density_type(vo_problem *p, int density_type);
 int vo_set_condition_values(vo_problem *p, int kind, int cond_id, int n, const double *values);
+/* lateral connection set of the mesh + VSFMComputeLateralFlux (SystemOfEquationsVSFMType.F90:848-889,
+ * GoveqnRichardsODEPressureType.F90:2615-2743): SetDtime, PreSolve, then the Darcy flux of every lateral connection at
+ * soln_prev is accumulated [kg/s] into the mass-rate source-sink condition `ss_cond_id` (the reference finds it by its name
+ * 'Lateral_flux'; it must list every cell once, in cell order) */
+int vo_set_lateral_connections(vo_problem *p, int nconn, const int *id_up, const int *id_dn, const double *dist_up,
+                               const double *dist_dn, const double *area, const double *unitvec);
+int vo_compute_lateral_flux(vo_problem *p, double dt, int ss_cond_id);
+int vo_get_condition_values(vo_problem *p, int kind, int cond_id, int n, double *values);
+/* VSFMMPPSetSourceSinkAuxVarRealValue (MultiPhysicsProbVSFM.F90:1437-1520): values run over the concatenation of all
+ * source-sink connections of the equation */
+int vo_set_source_sink_auxvar(vo_problem *p, int var_type, int n, const double *values);
 int vo_restart(vo_problem *p, const double *pressure);
 /* column blocks for PC bjacobi: block b holds cells block_cells[block_ptr[b]..block_ptr[b+1]) (1-based ids, bottom->top) */
 int vo_set_blocks(vo_problem *p, int nblocks, const int *block_ptr, const int *block_cells);

@@ -53,11 +53,12 @@ def lib():
         L.vo_last_error.restype = ct.c_char_p
         for name in ("vo_destroy", "vo_set_mesh", "vo_set_connections", "vo_add_condition", "vo_set_soil_permeability",
                      "vo_set_soil_porosity", "vo_set_saturation_function", "vo_set_density_type",
-                     "vo_set_condition_values", "vo_restart", "vo_set_blocks", "vo_set_solver", "vo_set_dtime",
+                     "vo_set_condition_values", "vo_set_source_sink_auxvar", "vo_set_lateral_connections", "vo_get_condition_values", "vo_restart", "vo_set_blocks", "vo_set_solver", "vo_set_dtime",
                      "vo_pre_solve", "vo_residual", "vo_jacobian_nnz", "vo_jacobian", "vo_pc_setup_apply",
                      "vo_ksp_solve", "vo_step_dt", "vo_get", "vo_get_counters"):
             getattr(L, name).argtypes = None
         L.vo_set_dtime.argtypes = [ct.c_void_p, ct.c_double]
+        L.vo_compute_lateral_flux.argtypes = [ct.c_void_p, ct.c_double, ct.c_int]
         L.vo_step_dt.argtypes = [ct.c_void_p, ct.c_double, ct.c_int, _ip, _ip]
         L.vo_set_solver.argtypes = [ct.c_void_p, ct.c_int, ct.c_int, ct.c_double, ct.c_double, ct.c_double,
                                     ct.c_double, ct.c_int]
@@ -172,6 +173,23 @@ class OracleProblem:
     def set_condition_values(self, kind, cond_id, values):
         v, pv = _d(values)
         _chk(self.L.vo_set_condition_values(self.h, kind, cond_id, v.size, pv))
+
+    def set_lateral_connections(self, cs):
+        up, pup = _i(cs.id_up); dn, pdn = _i(cs.id_dn)
+        du, pdu = _d(cs.dist_up); dd, pdd = _d(cs.dist_dn); ar, par = _d(cs.area); uv, puv = _d(cs.unit_vec)
+        _chk(self.L.vo_set_lateral_connections(self.h, cs.num_connections, pup, pdn, pdu, pdd, par, puv))
+
+    def compute_lateral_flux(self, dt, ss_cond_id):
+        _chk(self.L.vo_compute_lateral_flux(self.h, ct.c_double(dt), int(ss_cond_id)))
+
+    def get_condition_values(self, kind, cond_id, n):
+        out = np.zeros(n)
+        _chk(self.L.vo_get_condition_values(self.h, kind, cond_id, n, out.ctypes.data_as(_dp)))
+        return out
+
+    def set_source_sink_auxvar(self, var_type, values):
+        v, pv = _d(values)
+        _chk(self.L.vo_set_source_sink_auxvar(self.h, int(var_type), v.size, pv))
 
     def restart(self, pressure):
         v, pv = _d(pressure)

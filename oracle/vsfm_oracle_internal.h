@@ -41,6 +41,7 @@ typedef struct {
   conn_geom *geom;
   auxvar *aux;     /* BC auxvars (aux_vars_bc) */
   double *value;   /* SS condition values (cur_cond%value) */
+  double *sink_pressure, *sink_exponent; /* aux_vars_ss%pot_mass_sink_pressure / _exponent (down-regulated sinks) */
   double *flux;    /* boundary_flux / ss_flux [kg/s] */
 } condition;
 
@@ -54,6 +55,9 @@ struct vo_problem {
   int *up, *dn;         /* 0-based */
   conn_geom *geom;
   double *internal_flux;
+  int nlat;             /* mesh%lateral_conn_set_list (operator split, GE:2615-2743) */
+  int *lat_up, *lat_dn;
+  conn_geom *lat_geom;
   int nbc, nss;
   condition *bc, *ss;
   /* CSR pattern (sorted columns) + assembly slot tables */

@@ -34,6 +34,9 @@ class Problem:
     press_ic: np.ndarray
     bcs: list = field(default_factory=list)   # [(cond_type, ConnectionSet, values)]
     sss: list = field(default_factory=list)
+    lateral: object = None                    # ConnectionSet of the explicit (operator-split) lateral connections
+    sink_pressure: np.ndarray = None          # down-regulated sinks: over the concatenated source-sink connections
+    sink_exponent: np.ndarray = None
     dt: float = 3600.0
     nstep: int = 1
 
@@ -135,6 +138,26 @@ def vchannel(nx=20, ny=10, nz=30) -> Problem:
         dt=8640.0, nstep=3)
 
 
+def vchannel_operator_split(nx=6, ny=5, nz=7) -> Problem:
+    """the v-channel grid in ELM's operator-split form: only the vertical connections are implicit (mesh%intrn_conn_set_list),
+    the horizontal ones form mesh%lateral_conn_set_list and enter through the 'Lateral_flux' mass-rate source
+    (VSFMComputeLateralFlux, SystemOfEquationsVSFMType.F90:848-889)"""
+    prob = vchannel(nx, ny, nz)
+    cs = prob.mesh.intrn_conn_sets[0]
+    nv = nx * ny * (nz - 1)
+    pick = lambda a, sl: None if a is None else a[sl]
+    vert = M.ConnectionSet(cs.id_up[:nv], cs.id_dn[:nv], cs.dist_up[:nv], cs.dist_dn[:nv], cs.area[:nv], cs.unit_vec[:nv], pick(cs.itype, slice(0, nv)))
+    lat = M.ConnectionSet(cs.id_up[nv:], cs.id_dn[nv:], cs.dist_up[nv:], cs.dist_dn[nv:], cs.area[nv:], cs.unit_vec[nv:], pick(cs.itype, slice(nv, None)))
+    prob.mesh.intrn_conn_sets = [vert]
+    prob.lateral = lat
+    n = prob.mesh.ncells_local
+    z = np.zeros(n)
+    allcells = M.ConnectionSet(np.full(n, -1), np.arange(1, n + 1), z, z, np.ones(n), np.zeros((n, 3)))
+    prob.sss = [(C.COND_MASS_RATE, allcells, np.zeros(n))]
+    prob.name = "vsfm_vchannel_operator_split"
+    return prob
+
+
 def to_oracle(prob: Problem, with_blocks=True):
     from oracle import vsfm_oracle as VO
     o = VO.OracleProblem(prob.mesh.ncells_local)
@@ -152,6 +175,11 @@ def to_oracle(prob: Problem, with_blocks=True):
         o.set_condition_values(C.COND_BC, i + 1, vals)
     for i, (_t, _cs, vals) in enumerate(prob.sss):
         o.set_condition_values(C.COND_SS, i + 1, vals)
+    if prob.lateral is not None:
+        o.set_lateral_connections(prob.lateral)
+    if prob.sink_pressure is not None:
+        o.set_source_sink_auxvar(C.VAR_POT_MASS_SINK_PRESSURE, prob.sink_pressure)
+        o.set_source_sink_auxvar(C.VAR_POT_MASS_SINK_EXPONENT, prob.sink_exponent)
     o.restart(prob.press_ic)
     if with_blocks:
         ptr, cells = M.column_blocks(prob.mesh)
@@ -197,6 +225,11 @@ def to_gpu(prob: Problem, options=None, device_id=0):
         mpp.soe.SetDataFromCLM(C.AUXVAR_BC, C.VAR_BC_SS_CONDITION, i + 1, vals)
     for i, (_t, _cs, vals) in enumerate(prob.sss):
         mpp.soe.SetDataFromCLM(C.AUXVAR_SS, C.VAR_BC_SS_CONDITION, i + 1, vals)
+    if prob.lateral is not None:
+        mpp.soe.SetLateralConnections(prob.lateral)
+    if prob.sink_pressure is not None:
+        V.VSFMMPPSetSourceSinkAuxVarRealValue(mpp, 1, C.VAR_POT_MASS_SINK_PRESSURE, prob.sink_pressure)
+        V.VSFMMPPSetSourceSinkAuxVarRealValue(mpp, 1, C.VAR_POT_MASS_SINK_EXPONENT, prob.sink_exponent)
     mpp.Restart(prob.press_ic)
     return mpp
 

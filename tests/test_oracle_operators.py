@@ -109,3 +109,63 @@ def test_saturation_derivatives(sf):
             fd = (ap[q] - am[q]) / (2 * h)
             assert abs(fd - a[dq]) <= 1e-4 * max(abs(a[dq]), 1e-12) + 1e-14, (sf, p, q)
         assert 0.0 < a["sat"] <= 1.0 and 0.0 < a["kr"] <= 1.0
+
+
+def _sink_problem(cond_type, ncols=4, nz=12, seed=3):
+    """celia columns with a down-regulated potential sink (root water uptake) in every cell"""
+    import problems as P
+    from mpp_amd import mesh as M
+    rng = np.random.default_rng(seed)
+    prob = P.celia1990(ncols=ncols, nz=nz, perm_mult=np.exp(0.3 * rng.standard_normal(ncols)))
+    n = prob.mesh.ncells_local
+    z = np.zeros(n)
+    cs = M.ConnectionSet(np.full(n, -1), np.arange(1, n + 1), z, z, np.ones(n), np.zeros((n, 3)))
+    prob.sss = [(cond_type, cs, rng.uniform(1e-7, 1e-6, n))]
+    prob.sink_pressure = np.full(n, -1.5e6) * rng.uniform(0.05, 1.0, n)
+    prob.sink_exponent = rng.uniform(2.0, 10.0, n)
+    x = prob.press_ic + rng.uniform(0, 1.2e5, n)
+    return prob, x
+
+
+@pytest.mark.parametrize("cond_type", [512, 513])
+def test_downregulated_sink_jacobian_is_the_derivative(cond_type):
+    """COND_DOWNREG_MASS_RATE_CAMPBELL / _FETCH2 (GoveqnRichardsODEPressureType.F90:1900-1927, 2158-2188): the restated
+    diagonal derivative against central differences of the restated residual; rate limits checked directly"""
+    import problems as P
+    prob, x = _sink_problem(cond_type)
+    o = P.to_oracle(prob)
+    o.set_dtime(prob.dt); o.pre_solve()
+    n = x.size
+    rp, cj, val = o.jacobian(x)
+    J = np.zeros((n, n))
+    for i in range(n):
+        J[i, cj[rp[i]:rp[i + 1]]] = val[rp[i]:rp[i + 1]]
+    for j in range(n):
+        e = np.zeros(n); e[j] = 0.5
+        fd = (o.residual(x + e) - o.residual(x - e)) / 1.0
+        assert np.abs(fd - J[:, j]).max() <= 1e-4 * np.abs(J[:, j]).max(), j
+    # a saturated cell (P >= P_ref) takes the full potential rate, a very dry one almost none
+    from mpp_amd import constants as C
+    o.residual(np.full(n, 2e5))
+    assert np.allclose(o.get(C.AUXVAR_SS, C.VAR_MASS_FLUX, 1), prob.sss[0][2])
+    o.residual(np.full(n, 101325.0 - 3e7))
+    assert (o.get(C.AUXVAR_SS, C.VAR_MASS_FLUX, 1) < 1e-3 * prob.sss[0][2]).all()
+
+
+def test_lateral_flux_operator_split_equals_the_implicit_lateral_terms():
+    """VSFMComputeLateralFlux: with soln_prev = x, the residual of the operator-split problem (vertical connections
+    implicit, lateral fluxes as the 'Lateral_flux' source) equals the residual of the fully coupled 7-point problem at x;
+    the lateral source conserves mass"""
+    full = P.vchannel(6, 5, 7)
+    split = P.vchannel_operator_split(6, 5, 7)
+    n = full.mesh.ncells_local
+    x = full.press_ic - np.random.default_rng(9).uniform(0, 2.5e5, n)
+    of, os_ = P.to_oracle(full, with_blocks=False), P.to_oracle(split, with_blocks=False)
+    of.restart(x); os_.restart(x)
+    of.set_dtime(full.dt); of.pre_solve()
+    os_.compute_lateral_flux(split.dt, 1)
+    lat = os_.get_condition_values(C.COND_SS, 1, n)
+    assert abs(lat.sum()) <= 1e-12 * np.abs(lat).sum()
+    f_full, f_split = of.residual(x), os_.residual(x)
+    scale = np.abs(lat) / 18.01534 + np.abs(f_full)
+    assert (np.abs(f_split - f_full) <= 1e-12 * scale + 1e-25).all()
