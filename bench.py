@@ -79,8 +79,14 @@ def cpu_baseline(ncols_global, nz, nsteps, warmup, cores, cols_per_core, budget_
     dt = run_all(nsteps, True)
     cell_its_per_s = sum(work) / dt
     n_full = ncols_global * nz
+    # the reference itself is serial (PETSC_COMM_SELF, one rank): the same measure on ONE core, one more step of shard 0
+    work[0] = 0.0
+    t0 = time.perf_counter()
+    run(0, 1, True)
+    one_core = work[0] / (time.perf_counter() - t0) / n_full
     return {
         "value": cell_its_per_s / n_full, "unit": "Newton iters/s", "cores": cores, "kind": "port",
+        "value_one_core": one_core,
         "sample": "%d of %d columns (%d threads x %d columns x %d layers), %d timed steps after %d warm-up, "
                   "GMRES(30)+ILU(0); %.3g cell-Newton-updates/s scaled by 1/%d cells" %
                   (cores * cols_per_core, ncols_global, cores, cols_per_core, nz, nsteps, warmup, cell_its_per_s, n_full),

@@ -801,6 +801,75 @@ __global__ __launch_bounds__(kBlock) void k_ilu_upper_level(IluArgs a, const int
   x[i] = s * a.idiag[i];
 }
 
+// ILU(0) numeric factorisation of the rows at positions [lo, hi) of the level order (PETSc MatLUFactorNumeric_SeqAIJ,
+// levels = 0): the symbolic part -- which entries meet -- was resolved on the host into a per-row program
+__global__ __launch_bounds__(kBlock) void k_ilu_factor_program(const long long *__restrict__ ptr, const int *__restrict__ prog,
+                                                               const int *__restrict__ rows, const int *__restrict__ diag_slot,
+                                                               int lo, int hi, double *__restrict__ lu,
+                                                               double *__restrict__ idiag) {
+  const int p = lo + blockIdx.x * kBlock + threadIdx.x;
+  if (p >= hi) return;
+  long long w = ptr[p];
+  const long long we = ptr[p + 1];
+  while (w < we) {
+    const int mslot = prog[w], k = prog[w + 1], m = prog[w + 2];
+    w += 3;
+    const double mult = lu[mslot] * idiag[k];
+    lu[mslot] = mult;
+    for (int t = 0; t < m; ++t, w += 2) lu[prog[w + 1]] -= mult * lu[prog[w]];
+  }
+  const int i = rows[p];
+  idiag[i] = 1.0 / lu[diag_slot[i]];
+}
+
+// level-ordered ELL triangular solves (see kernels.hpp): one lane per position of the level, K entries each
+__global__ __launch_bounds__(kBlock) void k_ilu_repack(long long total, const int *__restrict__ slot,
+                                                       const double *__restrict__ lu, double *__restrict__ out) {
+  const long long e = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= total) return;
+  const int s = slot[e];
+  out[e] = s >= 0 ? lu[s] : 0.0;
+}
+template <int K>
+__global__ __launch_bounds__(kBlock) void k_ell_lower(int n, int Kdyn, const int *__restrict__ col, const double *__restrict__ val,
+                                                      int lo, int hi, double *__restrict__ y) {
+  const int p = lo + blockIdx.x * kBlock + threadIdx.x;
+  if (p >= hi) return;
+  const int kk = K > 0 ? K : Kdyn;
+  double s = y[p];
+  if (K > 0) {
+    int c[K > 0 ? K : 1];
+    double v[K > 0 ? K : 1];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { c[k] = col[(size_t)k * n + p]; v[k] = val[(size_t)k * n + p]; }
+#pragma unroll
+    for (int k = 0; k < K; ++k) s -= v[k] * y[c[k]];
+  } else {
+    for (int k = 0; k < kk; ++k) s -= val[(size_t)k * n + p] * y[col[(size_t)k * n + p]];
+  }
+  y[p] = s;
+}
+template <int K>
+__global__ __launch_bounds__(kBlock) void k_ell_upper(int n, int Kdyn, const int *__restrict__ col, const double *__restrict__ val,
+                                                      const double *__restrict__ idiag, int lo, int hi, double *__restrict__ x) {
+  const int p = lo + blockIdx.x * kBlock + threadIdx.x;
+  if (p >= hi) return;
+  const int kk = K > 0 ? K : Kdyn;
+  double s = x[p];
+  const double id = idiag[p];
+  if (K > 0) {
+    int c[K > 0 ? K : 1];
+    double v[K > 0 ? K : 1];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { c[k] = col[(size_t)k * n + p]; v[k] = val[(size_t)k * n + p]; }
+#pragma unroll
+    for (int k = 0; k < K; ++k) s -= v[k] * x[c[k]];
+  } else {
+    for (int k = 0; k < kk; ++k) s -= val[(size_t)k * n + p] * x[col[(size_t)k * n + p]];
+  }
+  x[p] = s * id;
+}
+
 // ------------------------------------------------------------------------------------------------
 // soil heat diffusion.  ThermKSPTempSoilAuxVarCompute
 // (src/mpp/auxvar/ThermalKSPTemperatureSoilAuxType.F90:66-168): itype 1 soil/crop, 2 wetland, 3 land ice
@@ -1292,6 +1361,34 @@ void launch_ilu_lower_level(const IluArgs &a, const int *rows, int count, const 
 }
 void launch_ilu_upper_level(const IluArgs &a, const int *rows, int count, double *x, hipStream_t stream) {
   if (count > 0) LAUNCH(k_ilu_upper_level, dim3(nblk(count)), a, rows, count, x);
+}
+void launch_ilu_factor_program(const long long *ptr, const int *prog, const int *rows, const int *diag_slot, int lo, int hi,
+                               double *lu, double *idiag, hipStream_t stream) {
+  if (hi > lo) LAUNCH(k_ilu_factor_program, dim3(nblk(hi - lo)), ptr, prog, rows, diag_slot, lo, hi, lu, idiag);
+}
+void launch_ilu_repack(long long total, const int *slot, const double *lu, double *out, hipStream_t stream) {
+  if (total > 0) LAUNCH(k_ilu_repack, dim3(nblk(total)), total, slot, lu, out);
+}
+void launch_ell_lower_level(int n, int K, const int *col, const double *val, int lo, int hi, double *y, hipStream_t stream) {
+  if (hi <= lo) return;
+  const dim3 grid(nblk(hi - lo));
+  switch (K) {
+    case 1: LAUNCH(k_ell_lower<1>, grid, n, K, col, val, lo, hi, y); break;
+    case 2: LAUNCH(k_ell_lower<2>, grid, n, K, col, val, lo, hi, y); break;
+    case 3: LAUNCH(k_ell_lower<3>, grid, n, K, col, val, lo, hi, y); break;
+    default: LAUNCH(k_ell_lower<0>, grid, n, K, col, val, lo, hi, y);
+  }
+}
+void launch_ell_upper_level(int n, int K, const int *col, const double *val, const double *idiag, int lo, int hi, double *x,
+                            hipStream_t stream) {
+  if (hi <= lo) return;
+  const dim3 grid(nblk(hi - lo));
+  switch (K) {
+    case 1: LAUNCH(k_ell_upper<1>, grid, n, K, col, val, idiag, lo, hi, x); break;
+    case 2: LAUNCH(k_ell_upper<2>, grid, n, K, col, val, idiag, lo, hi, x); break;
+    case 3: LAUNCH(k_ell_upper<3>, grid, n, K, col, val, idiag, lo, hi, x); break;
+    default: LAUNCH(k_ell_upper<0>, grid, n, K, col, val, idiag, lo, hi, x);
+  }
 }
 void launch_thermal_aux(const ThermalArgs &a, hipStream_t stream) {
   if (a.n > 0) LAUNCH(k_thermal_aux, dim3(nblk(a.n)), a);

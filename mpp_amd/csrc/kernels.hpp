@@ -134,6 +134,19 @@ void launch_ilu_factor_level(const IluArgs &a, const int *rows, int count, hipSt
 void launch_ilu_lower_level(const IluArgs &a, const int *rows, int count, const double *r, double *y, hipStream_t stream);
 void launch_ilu_upper_level(const IluArgs &a, const int *rows, int count, double *x, hipStream_t stream);
 
+// Level-ordered triangular solves.  The factors are repacked (after every numeric factorisation) into two ELL blocks
+// whose rows are sorted by dependency level -- `n` positions, entry k of position p at [k*n + p], columns are
+// positions of the same ordering, padding entries have value 0 and point at the row itself -- so a level is one
+// contiguous, fully coalesced range and its dependencies sit in the ranges just before it.  In place on y / x.
+// numeric ILU(0) of one level from a precomputed elimination program (level-ordered): for position p the words
+// prog[ptr[p] .. ptr[p+1]) are, per L entry in elimination order, {slot(i,k), k, m, (slot(k,j), slot(i,j)) x m}
+void launch_ilu_factor_program(const long long *ptr, const int *prog, const int *rows, const int *diag_slot, int lo, int hi,
+                               double *lu, double *idiag, hipStream_t stream);
+void launch_ilu_repack(long long total, const int *slot, const double *lu, double *out, hipStream_t stream);  // out[e] = slot[e] >= 0 ? lu[slot[e]] : 0
+void launch_ell_lower_level(int n, int K, const int *col, const double *val, int lo, int hi, double *y, hipStream_t stream);
+void launch_ell_upper_level(int n, int K, const int *col, const double *val, const double *idiag, int lo, int hi, double *x,
+                            hipStream_t stream);
+
 // ---- soil heat diffusion (thermal KSP path) ----
 struct ThermalArgs {
   int n;
@@ -181,6 +194,7 @@ struct ThArgs {
   double *val;                             // values of the 2N x 2N CSR
   int nnzc;                                // entries of the cell pattern
   double dtInv;
+  int ncols, nz, use_cols;                 // vertical-only grids: fused column march instead of passes 1 + 2
 };
 struct ThBcArgs {
   ThArgs t;
@@ -193,6 +207,17 @@ struct ThBcArgs {
 };
 // mode 0 residual, 2 residual + Jacobian, 3 PreSolve (accumulation terms into F)
 void launch_th_assemble(int mode, const ThBcArgs &b, hipStream_t stream);
+
+// coupled TH block-Jacobi: one block per soil column = exact LU of the column's block-tridiagonal system (2 x 2 blocks
+// {P_k, T_k}, block Thomas), for grids whose internal connections are all vertical
+struct ThTriArgs {
+  int ncols, nz, n, nnzc;
+  const int *crowptr, *tri_lo, *cdiag, *tri_up;   // cell-pattern slots of the (k-1), k, (k+1) entries of cell row (k,c); -1 absent
+  const double *val;                               // the 2N x 2N CSR values
+  double *L, *inv, *C;                             // 2 x 2 blocks as four planes of n doubles each: [q*n + i], q = pp, pt, tp, tt
+};
+void launch_th_tri_factor(const ThTriArgs &a, hipStream_t stream);
+void launch_th_tri_solve(const ThTriArgs &a, const double *r, double *z, hipStream_t stream);   // r, z: [P; T]
 
 // ---- vectors (device scalars in `sc`) ----
 void launch_copy(int n, const double *x, double *y, hipStream_t stream);

@@ -149,12 +149,20 @@ struct Solver {
   DevBuf<int> d_crowptr, d_cdiag;
   DevBuf<double> d_tcw, d_tcd, d_talpha, d_hcap, d_dsoil, d_Dq_e, d_bc_other, th_scratch;
   DevBuf<double> tha[13];
+  DevBuf<double> thtri_L, thtri_inv, thtri_C;   // block-Thomas factors of the per-column blocks (4 planes each)
   std::vector<double> h_bc_other;
   // ---------------- ILU(0) ----------------
   DevBuf<int> d_ord, d_lrows, d_urows;
   std::vector<int> h_lptr, h_uptr;
   DevBuf<double> d_lu, d_idiag;
   bool ilu_ready = false;
+  // level-ordered ELL copies of the factors for the triangular solves (kernels.hpp)
+  int ell_KL = 0, ell_KU = 0;
+  DevBuf<int> d_Lslot, d_Uslot, d_Lcol, d_Ucol, d_l2u, d_posU, d_fprog;
+  DevBuf<long long> d_fptr;
+  DevBuf<double> d_Lval, d_Uval, d_Uidiag, ilu_y, ilu_x;
+  hipGraph_t ilu_graph = nullptr;
+  hipGraphExec_t ilu_graph_exec = nullptr;
 
   double dtime = 0.0, time = 0.0;
   long long cum_newton = 0, cum_linear = 0, cum_cuts = 0, cum_funcs = 0;
@@ -163,6 +171,8 @@ struct Solver {
   std::vector<double> h_bc_value, h_ss_value;
 
   ~Solver() {
+    if (ilu_graph_exec) (void)hipGraphExecDestroy(ilu_graph_exec);
+    if (ilu_graph) (void)hipGraphDestroy(ilu_graph);
     if (h_sc) (void)hipHostFree(h_sc);
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -713,6 +723,9 @@ struct Solver {
     a.Dq_m = d_Dq.p; a.Dq_e = d_Dq_e.p; a.upw = d_upw.p; a.dgrav = d_dgrav.p; a.area = d_area.p; a.cdu = d_cdu.p; a.cdd = d_cdd.p;
     a.accum_prev = accum_prev.p; a.src = has_src ? d_src.p : nullptr;
     a.F = Fout; a.val = d_val.p; a.nnzc = nnzc; a.dtInv = 1.0 / dtime;
+    a.ncols = ncols; a.nz = nz;
+    // the column march needs enough columns to fill the chip (one lane per column); otherwise the 3-pass kernels
+    a.use_cols = (vertical_only && columns && opt.assembly != 0 && (opt.assembly == 1 || ncols >= 16384)) ? 1 : 0;
     b.ncond_cells = ncond_cells; b.cc_cell = d_cc_cell.p; b.cc_ptr = d_cc_ptr.p; b.type = d_bc_type.p;
     b.Dq = d_bc_Dq.p; b.dgrav = d_bc_dgrav.p; b.area = d_bc_area.p; b.du = d_bc_du.p; b.dd = d_bc_dd.p;
     b.value = d_bc_value.p; b.other = d_bc_other.p;
@@ -856,31 +869,57 @@ struct Solver {
   TriArgs tri_args() const {
     return TriArgs{ncols, nz, d_tri_lo.p, d_diag.p, d_tri_up.p, d_val.p, tri_l.p, tri_invb.p, tri_c.p};
   }
+  ThTriArgs th_tri_args() const {
+    return ThTriArgs{ncols, nz, n, nnzc, d_crowptr.p, d_tri_lo.p, d_cdiag.p, d_tri_up.p, d_val.p, thtri_L.p, thtri_inv.p, thtri_C.p};
+  }
   void op_pc_setup() {
     if (pc_ready) return;
     ProfScope ps(prof, KC_PC_SETUP);
-    if (opt.pc_type == 2 && th) throw Error("pc_type bjacobi is not available for the coupled system (use ilu, jacobi or none)");
-    if (opt.pc_type == 2) launch_tri_factor(tri_args(), stream);
+    if (opt.pc_type == 2 && th) {
+      if (!vertical_only || !columns) throw Error("pc_type bjacobi of the coupled system needs a grid whose connections are all vertical (use ilu)");
+      if (!thtri_L.p) { thtri_L.alloc(4 * (size_t)n); thtri_inv.alloc(4 * (size_t)n); thtri_C.alloc(4 * (size_t)n); }
+      launch_th_tri_factor(th_tri_args(), stream);
+    } else if (opt.pc_type == 2) launch_tri_factor(tri_args(), stream);
     else if (opt.pc_type == 3) launch_jacobi_setup(nrow, d_diag.p, d_val.p, jac_invd.p, stream);
     else if (opt.pc_type == 1) {
       ilu_analyse();
       launch_copy(nnz, d_val.p, d_lu.p, stream);
       const IluArgs a = ilu_args();
+      (void)a;
       for (size_t l = 0; l + 1 < h_lptr.size(); ++l)
-        launch_ilu_factor_level(a, d_lrows.p + h_lptr[l], h_lptr[l + 1] - h_lptr[l], stream);
+        launch_ilu_factor_program(d_fptr.p, d_fprog.p, d_lrows.p, d_diag.p, h_lptr[l], h_lptr[l + 1], d_lu.p, d_idiag.p, stream);
+      // repack into the level-ordered ELL blocks the solves stream through
+      launch_ilu_repack((long long)ell_KL * nrow, d_Lslot.p, d_lu.p, d_Lval.p, stream);
+      launch_ilu_repack((long long)ell_KU * nrow, d_Uslot.p, d_lu.p, d_Uval.p, stream);
+      launch_gather(nrow, d_urows.p, d_idiag.p, d_Uidiag.p, stream);
     }
     pc_ready = true;
   }
+  // every level of both triangular solves, on the fixed buffers ilu_y / ilu_x (captured once into a hipGraph)
+  void ilu_solve_levels() {
+    for (size_t l = 1; l + 1 < h_lptr.size(); ++l)   // level 0 of L has no dependencies: y = r already
+      launch_ell_lower_level(nrow, ell_KL, d_Lcol.p, d_Lval.p, h_lptr[l], h_lptr[l + 1], ilu_y.p, stream);
+    launch_gather(nrow, d_l2u.p, ilu_y.p, ilu_x.p, stream);
+    for (size_t l = 0; l + 1 < h_uptr.size(); ++l)
+      launch_ell_upper_level(nrow, ell_KU, d_Ucol.p, d_Uval.p, d_Uidiag.p, h_uptr[l], h_uptr[l + 1], ilu_x.p, stream);
+  }
   void op_pc_apply(const double *r, double *z) {
     ProfScope ps(prof, KC_PC_APPLY);
-    if (opt.pc_type == 2) launch_tri_solve(tri_args(), r, z, stream);
+    if (opt.pc_type == 2 && th) launch_th_tri_solve(th_tri_args(), r, z, stream);
+    else if (opt.pc_type == 2) launch_tri_solve(tri_args(), r, z, stream);
     else if (opt.pc_type == 3) launch_pointwise_mult(nrow, jac_invd.p, r, z, stream);
     else if (opt.pc_type == 1) {
-      const IluArgs a = ilu_args();
-      for (size_t l = 0; l + 1 < h_lptr.size(); ++l)
-        launch_ilu_lower_level(a, d_lrows.p + h_lptr[l], h_lptr[l + 1] - h_lptr[l], r, z, stream);
-      for (size_t l = 0; l + 1 < h_uptr.size(); ++l)
-        launch_ilu_upper_level(a, d_urows.p + h_uptr[l], h_uptr[l + 1] - h_uptr[l], z, stream);
+      launch_gather(nrow, d_lrows.p, r, ilu_y.p, stream);            // r into the L level order
+      if (opt.ilu_graph) {
+        if (!ilu_graph_exec) {
+          HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+          ilu_solve_levels();
+          HIP_CHECK(hipStreamEndCapture(stream, &ilu_graph));
+          HIP_CHECK(hipGraphInstantiate(&ilu_graph_exec, ilu_graph, nullptr, nullptr, 0));
+        }
+        HIP_CHECK(hipGraphLaunch(ilu_graph_exec, stream));
+      } else ilu_solve_levels();
+      launch_gather(nrow, d_posU.p, ilu_x.p, z, stream);             // back to the internal row order
     } else launch_copy(nrow, r, z, stream);
   }
   void op_BA(const double *v, double *t) {  // t = M^{-1} A v  (left preconditioning)
@@ -1588,6 +1627,67 @@ struct Solver {
     d_lrows.upload(lrows, stream); d_urows.upload(urows, stream);
     d_ord.upload(ord, stream);
     d_lu.alloc(nnz); d_idiag.alloc(N);
+    // level-ordered ELL maps: position of every row in the L ordering (lrows) and in the U ordering (urows)
+    std::vector<int> posL(N), posU(N);
+    for (int p = 0; p < N; ++p) { posL[lrows[p]] = p; posU[urows[p]] = p; }
+    ell_KL = ell_KU = 0;
+    for (int i = 0; i < N; ++i) {
+      int kl = 0, ku = 0;
+      for (int q = h_rowptr[i]; q < h_rowptr[i + 1]; ++q) {
+        const int oj = ord[h_col[q]];
+        if (oj < ord[i]) ++kl; else if (oj > ord[i]) ++ku;
+      }
+      ell_KL = std::max(ell_KL, kl); ell_KU = std::max(ell_KU, ku);
+    }
+    std::vector<int> Lslot((size_t)ell_KL * N, -1), Lcol((size_t)ell_KL * N), Uslot((size_t)ell_KU * N, -1), Ucol((size_t)ell_KU * N);
+    std::vector<int> l2u(N);
+    for (int i = 0; i < N; ++i) {
+      const int pl = posL[i], pu = posU[i];
+      for (int k = 0; k < ell_KL; ++k) Lcol[(size_t)k * N + pl] = pl;
+      for (int k = 0; k < ell_KU; ++k) Ucol[(size_t)k * N + pu] = pu;
+      int kl = 0, ku = 0;
+      for (int q = h_rowptr[i]; q < h_rowptr[i + 1]; ++q) {   // entries in column (= elimination) order of the sorted row
+        const int j = h_col[q], oj = ord[j];
+        if (oj < ord[i]) { Lslot[(size_t)kl * N + pl] = q; Lcol[(size_t)kl * N + pl] = posL[j]; ++kl; }
+        else if (oj > ord[i]) { Uslot[(size_t)ku * N + pu] = q; Ucol[(size_t)ku * N + pu] = posU[j]; ++ku; }
+      }
+      l2u[pu] = pl;
+    }
+    d_Lslot.upload(Lslot, stream); d_Lcol.upload(Lcol, stream); d_Uslot.upload(Uslot, stream); d_Ucol.upload(Ucol, stream);
+    d_l2u.upload(l2u, stream); d_posU.upload(posU, stream);
+    {  // elimination program of the numeric factorisation, rows in L level order (see k_ilu_factor_program)
+      std::vector<long long> fptr((size_t)N + 1, 0);
+      std::vector<int> prog;
+      prog.reserve((size_t)N * 16);
+      std::vector<std::pair<int, int>> lpart;   // (ord of k, slot of (i,k))
+      for (int p = 0; p < N; ++p) {
+        const int i = lrows[p];
+        fptr[p] = (long long)prog.size();
+        lpart.clear();
+        for (int q = h_rowptr[i]; q < h_rowptr[i + 1]; ++q)
+          if (ord[h_col[q]] < ord[i]) lpart.emplace_back(ord[h_col[q]], q);
+        std::sort(lpart.begin(), lpart.end());   // pivots in increasing elimination order
+        for (auto &lk : lpart) {
+          const int k = h_col[lk.second];
+          prog.push_back(lk.second); prog.push_back(k);
+          const size_t mpos = prog.size();
+          prog.push_back(0);
+          int m = 0;
+          for (int q = h_rowptr[k]; q < h_rowptr[k + 1]; ++q) {   // U part of row k, in its CSR order
+            const int j = h_col[q];
+            if (ord[j] <= lk.first) continue;
+            const int s_ij = find_slot(i, j);
+            if (s_ij >= 0) { prog.push_back(q); prog.push_back(s_ij); ++m; }
+          }
+          prog[mpos] = m;
+        }
+      }
+      fptr[N] = (long long)prog.size();
+      d_fptr.upload(fptr, stream); d_fprog.upload(prog, stream);
+      HIP_CHECK(hipStreamSynchronize(stream));
+    }
+    d_Lval.alloc((size_t)ell_KL * N); d_Uval.alloc((size_t)ell_KU * N); d_Uidiag.alloc(N);
+    ilu_y.alloc(N); ilu_x.alloc(N);
     HIP_CHECK(hipStreamSynchronize(stream));
   }
   IluArgs ilu_args() const { return IluArgs{nrow, d_rowptr.p, d_col.p, d_diag.p, d_ord.p, d_lu.p, d_idiag.p}; }
@@ -1640,13 +1740,14 @@ struct Solver {
       else throw Error("unknown assembly '" + val + "'");
     } else if (key == "nseg") opt.nseg = (int)num();
     else if (key == "fused_assembly") opt.fused_assembly = num() != 0;
+    else if (key == "ilu_graph") opt.ilu_graph = num() != 0;
     else if (key == "fused_trials") opt.fused_trials = (int)num();
     else if (key == "temperature") temperature = num();
     else if (key == "problem_type") {
       if (setup_done || !bcs.empty() || !sss.empty()) throw Error("problem_type must be set before conditions are added");
       if (val == "thermal") { thermal = true; th = false; }
       else if (val == "vsfm") { thermal = false; th = false; }
-      else if (val == "th") { thermal = false; th = true; if (!opt.pc_is_ilu && opt.pc_type == 2) { opt.pc_is_ilu = true; } }
+      else if (val == "th") { thermal = false; th = true; if (!opt.pc_is_ilu && opt.pc_type == 2) { opt.pc_is_ilu = true; } }   // PETSc's default PC
       else throw Error("unknown problem_type '" + val + "' (vsfm | thermal | th)");
     } else if (key == "int_energy_enthalpy_type") {
       const int t = (int)num();

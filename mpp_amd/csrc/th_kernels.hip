@@ -168,6 +168,103 @@ __global__ __launch_bounds__(kBlock) void k_th_rows(ThArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// vertical-only grids: passes 1 and 2 fused into one column march (one lane per soil column, tiled level-major layout).
+// Every cell's auxvars and every connection's fluxes are evaluated once and live in registers; nothing but x, the soil
+// parameters and the geometry is read, nothing but F and the 12 Jacobian entries per cell is written.  Row k-1 is
+// complete when level k has been visited; its entries sit at crp, crp+1, crp+2 of each block (sorted columns: the cell
+// below, the cell, the cell above), so no slot tables are needed.  Same per-row summation order as the 3-pass kernels.
+// ------------------------------------------------------------------------------------------------
+struct ThRowAcc {      // what a row accumulates before it is written
+  double fm, fe;
+  double dPP, dPT, dTP, dTT;        // diagonal entries: connection part
+  double aPP, aPT, aTP, aTT;        // diagonal entries: accumulation part
+  double lPP, lPT, lTP, lTT;        // coupling to the cell below
+};
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_th_cols(ThArgs a) {
+  constexpr bool JAC = (MODE == 2);
+  const int c = blockIdx.x * kBlock + threadIdx.x;
+  if (c >= a.ncols) return;
+  const int nz = a.nz;
+  const int tile = c >> 6, tw = min(64, a.ncols - (tile << 6));
+  const size_t cbase = (size_t)tile * 64 * nz + (c & 63), n = (size_t)a.n;
+  ThAux prev;
+  bool prev_act = false;
+  ThRowAcc rp = {};
+  for (int k = 0; k <= nz; ++k) {
+    const size_t i = cbase + (size_t)k * tw;
+    ThAux cur;
+    bool act = false;
+    ThRowAcc rc = {};
+    double uPP = 0.0, uPT = 0.0, uTP = 0.0, uTT = 0.0;   // row k-1's coupling to cell k
+    if (k < nz) {
+      act = th_active(a, i);
+      const Soil s = th_load_soil(a, i);
+      const ThSoil ts{a.tc_wet[i], a.tc_dry[i], a.talpha[i]};
+      const double P = a.x[i], T = a.x[n + i];
+      cur = th_auxvar_compute<true>(a.sat_func, a.density_type, a.ie_type, s, ts, P, T, true);
+      const double vol = a.vol[i], dsoil = a.den_soil[i], csoil = a.heat_cap[i];
+      double fm = 0.0, fe = 0.0;
+      rc.aPP = rc.aPT = rc.aTP = rc.aTT = 1.0;
+      if (act) {
+        fm = s.por * cur.den_m * cur.sat * vol * a.dtInv;
+        fe = (s.por * cur.den_e * cur.sat * cur.ul + (1.0 - s.por) * dsoil * csoil * (T - 273.15)) * vol * a.dtInv;
+        if (JAC) {
+          rc.aPP = (s.por * cur.ddenP_m * cur.sat + s.por * cur.den_m * cur.dsat) * vol * a.dtInv;
+          rc.aPT = (s.por * cur.ddenT_m * cur.sat) * vol * a.dtInv;
+          rc.aTP = (s.por * cur.ddenP_e * cur.sat * cur.ul + s.por * cur.den_e * cur.dsat * cur.ul + s.por * cur.den_e * cur.sat * cur.dul_dP) * vol * a.dtInv;
+          rc.aTT = ((s.por * cur.ddenT_e * cur.sat * cur.ul + s.por * cur.den_e * cur.sat * cur.dul_dT) + (1.0 - s.por) * dsoil * csoil) * vol * a.dtInv;
+        }
+      }
+      rc.fm = fm - a.accum_prev[i];
+      rc.fe = fe - a.accum_prev[n + i];
+      if (k > 0 && prev_act && act) {   // the vertical connection (k-1) -> (k), stored at the index of cell k-1
+        const size_t ic = i - tw;
+        ConnGeom gm, ge;
+        gm.Dq = a.Dq_m[ic]; gm.upweight = a.upw[ic]; gm.dist_gravity = a.dgrav[ic]; gm.area = a.area[ic];
+        ge = gm; ge.Dq = a.Dq_e[ic];
+        const double du = a.cdu[ic], dd = a.cdd[ic];
+        double Jup = 0.0, Jdn = 0.0, Eup = 0.0, Edn = 0.0, t1, t2;
+        const double flux_m = richards_flux<JAC>(mass_view(prev), mass_view(cur), gm, 0, Jup, Jdn);
+        const double mflux = richards_flux<JAC>(heat_view(prev), heat_view(cur), ge, 0, Eup, Edn);
+        const double eflux = thermal_enthalpy_flux<false>(prev, cur, mflux, 0.0, 0.0, gm.area, du, dd, true, t1, t2);
+        rp.fm -= flux_m; rc.fm += flux_m;
+        rp.fe -= eflux; rc.fe += eflux;
+        if (JAC) {
+          rp.dPP += Jup; uPP = Jdn; rc.lPP = -Jup; rc.dPP += -Jdn;
+          double Tu, Td, Pu, Pd, mTu, mTd, Hu, Hd;
+          richards_flux_dT(prev.P, prev.kr, prev.den_m, prev.ddenT_m, cur.P, cur.kr, cur.den_m, cur.ddenT_m, gm, 0, Tu, Td);
+          rp.dPT += -Tu; uPT = -Td; rc.lPT = Tu; rc.dPT += Td;
+          thermal_enthalpy_flux_dP(prev, cur, mflux, -Eup, -Edn, gm.area, du, dd, true, Pu, Pd);
+          rp.dTP += -Pu; uTP = -Pd; rc.lTP = Pu; rc.dTP += Pd;
+          richards_flux_dT(prev.P, prev.kr, prev.den_e, prev.ddenT_e, cur.P, cur.kr, cur.den_e, cur.ddenT_e, ge, 0, mTu, mTd);
+          thermal_enthalpy_flux<true>(prev, cur, mflux, mTu, mTd, gm.area, du, dd, true, Hu, Hd);
+          rp.dTT += -Hu; uTT = -Hd; rc.lTT = Hu; rc.dTT += Hd;
+        }
+      }
+    }
+    if (k > 0) {   // row k-1 is complete
+      const size_t ip = i - tw;
+      const int kp = k - 1;
+      double fm = rp.fm, fe = rp.fe;
+      if (a.src) { fm -= a.src[ip]; fe += a.src[n + ip]; }
+      a.F[ip] = fm; a.F[n + ip] = fe;
+      if (JAC) {
+        const int r0 = a.crowptr[ip], len = a.crowptr[ip + 1] - r0;
+        size_t g0 = (size_t)2 * r0, g1 = g0 + len, h0 = (size_t)2 * a.nnzc + g0, h1 = h0 + len;   // first entry of each block
+        if (kp > 0) { a.val[g0++] = rp.lPP; a.val[g1++] = rp.lPT; a.val[h0++] = rp.lTP; a.val[h1++] = rp.lTT; }
+        a.val[g0++] = rp.dPP + rp.aPP;   // divergence first, accumulation last (GE:425-453; heat :1092-1120)
+        a.val[h1++] = rp.dTT + rp.aTT;
+        a.val[g1++] = rp.aPT + rp.dPT;   // accumulation first, then connections (GE:2501-2597; heat :2136-2250)
+        a.val[h0++] = rp.aTP + rp.dTP;
+        if (kp < nz - 1) { a.val[g0] = uPP; a.val[g1] = uPT; a.val[h0] = uTP; a.val[h1] = uTT; }
+      }
+    }
+    prev = cur; prev_act = act; rp = rc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // pass 3: boundary connections of both equations, grouped by cell.  Mass equation: Dirichlet / seepage / mass-flux
 // (GE:1815-1877, 2076-2139); heat equation: COND_DIRICHLET (heat :1391-1452, 1627-1680, 2283-2370).  A boundary
 // auxvar has the soil of its id_dn cell; the mass equation's carries a temperature, the heat equation's a pressure
@@ -184,7 +281,7 @@ __global__ __launch_bounds__(kBlock) void k_th_bc(ThBcArgs b) {
   if (!th_active(a, cell)) return;
   const Soil s = th_load_soil(a, cell);
   const ThSoil ts{a.tc_wet[cell], a.tc_dry[cell], a.talpha[cell]};
-  const ThAux in = th_load_aux(a, cell);
+  const ThAux in = th_auxvar_compute<true>(a.sat_func, a.density_type, a.ie_type, s, ts, a.x[cell], a.x[n + cell], true);
   double fm = a.F[cell], fe = a.F[n + cell];
   double dPP = 0.0, dTP = 0.0, dTT = 0.0;
   for (int e = b.cc_ptr[j]; e < b.cc_ptr[j + 1]; ++e) {
@@ -227,11 +324,89 @@ __global__ __launch_bounds__(kBlock) void k_th_bc(ThBcArgs b) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// block-Jacobi for the coupled system on vertical-only grids: per soil column the unknowns (P_0,T_0,...,P_nz-1,T_nz-1)
+// form a block-tridiagonal system with 2 x 2 blocks; block Thomas is its exact LU (the role PETSc's bjacobi + sub-PC lu
+// plays).  One lane per column, tiled level-major layout as everywhere else.
+// ------------------------------------------------------------------------------------------------
+struct B2 { double pp, pt, tp, tt; };
+__device__ __forceinline__ B2 b2_load_val(const ThTriArgs &a, size_t i, int s) {   // the 2 x 2 block of cell row i at cell slot s
+  const int r0 = a.crowptr[i], len = a.crowptr[i + 1] - r0;
+  const size_t g = (size_t)r0 + s, h = (size_t)2 * a.nnzc + g;
+  return B2{a.val[g], a.val[g + len], a.val[h], a.val[h + len]};
+}
+__device__ __forceinline__ B2 b2_load(const double *p, size_t n, size_t i) { return B2{p[i], p[n + i], p[2 * n + i], p[3 * n + i]}; }
+__device__ __forceinline__ void b2_store(double *p, size_t n, size_t i, const B2 &b) {
+  p[i] = b.pp; p[n + i] = b.pt; p[2 * n + i] = b.tp; p[3 * n + i] = b.tt;
+}
+__device__ __forceinline__ B2 b2_mul(const B2 &x, const B2 &y) {
+  return B2{x.pp * y.pp + x.pt * y.tp, x.pp * y.pt + x.pt * y.tt, x.tp * y.pp + x.tt * y.tp, x.tp * y.pt + x.tt * y.tt};
+}
+__device__ __forceinline__ B2 b2_inv(const B2 &x) {
+  const double id = 1.0 / (x.pp * x.tt - x.pt * x.tp);
+  return B2{x.tt * id, -x.pt * id, -x.tp * id, x.pp * id};
+}
+
+__global__ __launch_bounds__(kBlock) void k_th_tri_factor(ThTriArgs a) {
+  const int c = blockIdx.x * kBlock + threadIdx.x;
+  if (c >= a.ncols) return;
+  const int tile = c >> 6, tw = min(64, a.ncols - (tile << 6));
+  const size_t cbase = (size_t)tile * 64 * a.nz + (c & 63), n = (size_t)a.n;
+  B2 inv_prev{0, 0, 0, 0}, c_prev{0, 0, 0, 0};
+  for (int k = 0; k < a.nz; ++k) {
+    const size_t i = cbase + (size_t)k * tw;
+    const int sl = a.tri_lo[i], su = a.tri_up[i];
+    const B2 zero{0, 0, 0, 0};
+    const B2 lo = sl >= 0 ? b2_load_val(a, i, sl) : zero;
+    const B2 di = b2_load_val(a, i, a.cdiag[i]);
+    const B2 up = su >= 0 ? b2_load_val(a, i, su) : zero;
+    const B2 l = b2_mul(lo, inv_prev);
+    const B2 lc = b2_mul(l, c_prev);
+    const B2 piv{di.pp - lc.pp, di.pt - lc.pt, di.tp - lc.tp, di.tt - lc.tt};
+    const B2 inv = b2_inv(piv);
+    b2_store(a.L, n, i, l); b2_store(a.inv, n, i, inv); b2_store(a.C, n, i, up);
+    inv_prev = inv; c_prev = up;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_th_tri_solve(ThTriArgs a, const double *__restrict__ r, double *__restrict__ z) {
+  const int c = blockIdx.x * kBlock + threadIdx.x;
+  if (c >= a.ncols) return;
+  const int tile = c >> 6, tw = min(64, a.ncols - (tile << 6));
+  const size_t cbase = (size_t)tile * 64 * a.nz + (c & 63), n = (size_t)a.n;
+  double dp = 0.0, dt = 0.0;
+  for (int k = 0; k < a.nz; ++k) {
+    const size_t i = cbase + (size_t)k * tw;
+    const B2 l = b2_load(a.L, n, i);
+    const double np = r[i] - (l.pp * dp + l.pt * dt);
+    const double nt = r[n + i] - (l.tp * dp + l.tt * dt);
+    z[i] = np; z[n + i] = nt;
+    dp = np; dt = nt;
+  }
+  double xp = 0.0, xt = 0.0;
+  for (int k = a.nz - 1; k >= 0; --k) {
+    const size_t i = cbase + (size_t)k * tw;
+    const B2 cc = b2_load(a.C, n, i), inv = b2_load(a.inv, n, i);
+    const double bp = z[i] - (cc.pp * xp + cc.pt * xt);
+    const double bt = z[n + i] - (cc.tp * xp + cc.tt * xt);
+    const double yp = inv.pp * bp + inv.pt * bt, yt = inv.tp * bp + inv.tt * bt;
+    z[i] = yp; z[n + i] = yt;
+    xp = yp; xt = yt;
+  }
+}
+
 inline dim3 nblk(long long n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
 
 }  // namespace
 
 #define TH_LAUNCH(kernel, grid, ...) hipLaunchKernelGGL(kernel, grid, dim3(kBlock), 0, stream, __VA_ARGS__)
+
+void launch_th_tri_factor(const ThTriArgs &a, hipStream_t stream) {
+  if (a.ncols > 0) TH_LAUNCH(k_th_tri_factor, nblk(a.ncols), a);
+}
+void launch_th_tri_solve(const ThTriArgs &a, const double *r, double *z, hipStream_t stream) {
+  if (a.ncols > 0) TH_LAUNCH(k_th_tri_solve, nblk(a.ncols), a, r, z);
+}
 
 // mode 0 residual, 2 residual + Jacobian, 3 PreSolve (accumulation terms of both equations into F)
 void launch_th_assemble(int mode, const ThBcArgs &b, hipStream_t stream) {
@@ -239,7 +414,9 @@ void launch_th_assemble(int mode, const ThBcArgs &b, hipStream_t stream) {
   if (a.n <= 0) return;
   const dim3 grid = nblk(a.n);
   if (mode == 3) { TH_LAUNCH(k_th_aux<3>, grid, a); return; }
-  if (mode == 0) { TH_LAUNCH(k_th_aux<0>, grid, a); TH_LAUNCH(k_th_rows<0>, grid, a); }
+  if (a.use_cols) {
+    if (mode == 0) TH_LAUNCH(k_th_cols<0>, nblk(a.ncols), a); else TH_LAUNCH(k_th_cols<2>, nblk(a.ncols), a);
+  } else if (mode == 0) { TH_LAUNCH(k_th_aux<0>, grid, a); TH_LAUNCH(k_th_rows<0>, grid, a); }
   else { TH_LAUNCH(k_th_aux<2>, grid, a); TH_LAUNCH(k_th_rows<2>, grid, a); }
   if (b.ncond_cells > 0) {
     if (mode == 0) TH_LAUNCH(k_th_bc<0>, nblk(b.ncond_cells), b);

@@ -116,15 +116,16 @@ def test_th_error_paths():
         g.Restart(np.zeros(5), np.zeros(4))
 
 
+@pytest.mark.parametrize("assembly", ["general", "columns"])
 @pytest.mark.parametrize("ncols,nz", [(3, 20), (70, 9)])
-def test_th_columns_vs_oracle(ncols, nz):
+def test_th_columns_vs_oracle(ncols, nz, assembly):
     """soil columns with gravity, Dirichlet boundaries on both equations, permuted internal layout (column tiles):
     operators and two coupled time steps against the oracle"""
     rng = np.random.default_rng(5)
     tp = P.th_columns(ncols=ncols, nz=nz, perm_mult=np.exp(0.3 * rng.standard_normal(ncols)))
     n = tp.mesh.ncells_local
     o = P.to_th_oracle(tp)
-    g = P.to_th_gpu(tp, {"ksp_type": "gmres", "pc_type": "ilu"})
+    g = P.to_th_gpu(tp, {"ksp_type": "gmres", "pc_type": "ilu", "assembly": assembly})
     x = _state(tp, seed=2, dp=(0.0, 9e4), dt=(0.0, 15.0))
     o.set_dtime(tp.dt); o.pre_solve()
     g.soe.SetDtime(tp.dt); g.soe.PreSolve()
@@ -157,3 +158,33 @@ def test_th_columns_vs_oracle(ncols, nz):
     assert np.abs(p_g - p_o).max() <= 1e-8 * np.abs(p_o).max()
     assert np.abs(t_g - t_o).max() <= 1e-8
     assert g.soe.counters()["newton"] == o.counters()["newton"]
+
+
+@pytest.mark.parametrize("ncols,nz", [(3, 20), (130, 7)])
+def test_th_block_jacobi_is_the_exact_column_solve(ncols, nz):
+    """pc_type bjacobi of the coupled system on a vertical-only grid = block Thomas with 2 x 2 {P,T} blocks per soil
+    column: M^-1 is the exact inverse of the Jacobian, the Krylov solver converges at once, the time step agrees with
+    the GMRES + ILU(0) solution"""
+    rng = np.random.default_rng(8)
+    tp = P.th_columns(ncols=ncols, nz=nz, perm_mult=np.exp(0.3 * rng.standard_normal(ncols)))
+    n = tp.mesh.ncells_local
+    g = P.to_th_gpu(tp, {"ksp_type": "bcgs", "pc_type": "bjacobi"})
+    x = _state(tp, seed=2, dp=(0.0, 9e4), dt=(0.0, 15.0))
+    g.soe.SetDtime(tp.dt); g.soe.PreSolve()
+    rp, cj, val = g.soe.ComputeJacobian(x)
+    J = _dense(rp, cj, val, 2 * n)
+    v = np.random.default_rng(1).standard_normal(2 * n)
+    z = g.soe.PCApply(v)
+    exact = np.linalg.solve(J, v)
+    assert np.abs(z - exact).max() <= 1e-9 * np.abs(exact).max()
+    xs, its, reason = g.soe.KSPSolve(v)
+    assert reason > 0 and its <= 2
+    ref = P.to_th_gpu(tp, {"ksp_type": "gmres", "pc_type": "ilu", "ksp_rtol": 1e-10})
+    for s in range(2):
+        P.th_gpu_set_conditions(tp, g); P.th_gpu_set_conditions(tp, ref)
+        c1, _ = g.soe.StepDT(tp.dt, s + 1)
+        c2, _ = ref.soe.StepDT(tp.dt, s + 1)
+        assert c1 and c2
+    for var, tol in ((C.VAR_PRESSURE, 1e-6), (605, 1e-7)):
+        a = g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, var); b = ref.soe.GetDataForCLM(C.AUXVAR_INTERNAL, var)
+        assert np.abs(a - b).max() <= tol * np.abs(b).max()

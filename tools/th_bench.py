@@ -24,13 +24,16 @@ def main():
     ap.add_argument("--ksp", default="gmres")
     ap.add_argument("--pc", default="ilu")
     ap.add_argument("--out", default="")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="extra mppgpu_set_option pairs")
     a = ap.parse_args()
     ncols = a.nx * a.ny
     t0 = time.perf_counter()
     tp = P.th_columns(ncols=ncols, nz=a.nz, perm_mult=np.exp(0.5 * np.random.default_rng(12345).standard_normal(ncols)))
     t_build = time.perf_counter() - t0
     t0 = time.perf_counter()
-    g = P.to_th_gpu(tp, {"ksp_type": a.ksp, "pc_type": a.pc})
+    opts = {"ksp_type": a.ksp, "pc_type": a.pc}
+    opts.update(kv.split("=", 1) for kv in a.opt)
+    g = P.to_th_gpu(tp, opts)
     t_setup = time.perf_counter() - t0
     conv, reason = g.soe.StepDT(tp.dt, 1)          # warm-up (ILU analysis, allocations)
     c0 = g.soe.counters()

@@ -21,12 +21,15 @@ def main():
     ap.add_argument("--pc", default="ilu")
     ap.add_argument("--rtol", type=float, default=1e-5)
     ap.add_argument("--out", default="")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="extra mppgpu_set_option pairs")
     a = ap.parse_args()
     t0 = time.perf_counter()
     tp = P.thermal_mms(3, a.n, a.n, a.n, replicate_reference_soil_indexing=False)
     t_build = time.perf_counter() - t0
     t0 = time.perf_counter()
-    g = P.to_thermal_gpu(tp, {"ksp_type": a.ksp, "pc_type": a.pc, "ksp_rtol": a.rtol})
+    opts = {"ksp_type": a.ksp, "pc_type": a.pc, "ksp_rtol": a.rtol}
+    opts.update(kv.split("=", 1) for kv in a.opt)
+    g = P.to_thermal_gpu(tp, opts)
     t_setup = time.perf_counter() - t0
     g.soe.StepDT(tp.dt, 1)          # warm-up (ILU analysis, allocations)
     g.soe.PreStepDT()
