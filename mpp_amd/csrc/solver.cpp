@@ -167,6 +167,7 @@ struct Solver {
   double dtime = 0.0, time = 0.0;
   long long cum_newton = 0, cum_linear = 0, cum_cuts = 0, cum_funcs = 0;
   int nfuncs = 0;
+  bool ls_backtracked_last = false;
   bool pc_ready = false;
   std::vector<double> h_bc_value, h_ss_value;
 
@@ -1243,7 +1244,9 @@ struct Solver {
     jac_valid = false;
     auto eval = [&](double lam) {
       vec_waxpy(Wv, -lam, Yv, X);
-      last_fused = opt.fused_assembly && trial < opt.fused_trials;
+      // a trial point's Jacobian is assembled together with its residual when the point is likely to be accepted:
+      // the full step unless the previous line search of this solve had to backtrack, and always the second trial
+      last_fused = opt.fused_assembly && trial < opt.fused_trials && !(trial == 0 && opt.fused_predict && ls_backtracked_last);
       ++trial;
       if (last_fused) op_residual_jacobian(Wv, Gv); else op_residual(Wv, Gv);
       double r2[2];
@@ -1288,6 +1291,7 @@ struct Solver {
         if (count == max_its) return 1;
       }
     }
+    ls_backtracked_last = trial > 1;
     std::swap(X, Wv);   // X <- W, F <- G by pointer exchange (no copies)
     std::swap(Fv, Gv);
     jac_valid = last_fused;
@@ -1301,6 +1305,7 @@ struct Solver {
     double *X = soln.p, *Fv = F.p, *Wv = W.p, *Gv = G.p, *Yv = Y.p;
     double ttol = 0, rnorm0 = 0, xnorm = 0, ynorm = 0;
     nfuncs = 0;
+    ls_backtracked_last = false;
     *newton_its = 0; *linear_its = 0;
     bool jac_valid = false;
     if (opt.fused_assembly) { op_residual_jacobian(X, Fv); jac_valid = true; } else op_residual(X, Fv);
@@ -1742,6 +1747,7 @@ struct Solver {
     else if (key == "fused_assembly") opt.fused_assembly = num() != 0;
     else if (key == "ilu_graph") opt.ilu_graph = num() != 0;
     else if (key == "fused_trials") opt.fused_trials = (int)num();
+    else if (key == "fused_predict") opt.fused_predict = num() != 0;
     else if (key == "temperature") temperature = num();
     else if (key == "problem_type") {
       if (setup_done || !bcs.empty() || !sss.empty()) throw Error("problem_type must be set before conditions are added");
