@@ -12,12 +12,26 @@ module mppgpu_mod
   private
 
   integer(c_int), parameter, public :: COND_BC = 501, COND_SS = 502, COND_MASS_RATE = 503, COND_MASS_FLUX = 504
-  integer(c_int), parameter, public :: COND_DIRICHLET = 505, COND_SEEPAGE_BC = 509
+  integer(c_int), parameter, public :: COND_DIRICHLET = 505, COND_HEAT_FLUX = 507, COND_SEEPAGE_BC = 509, COND_HEAT_RATE = 511
+  integer(c_int), parameter, public :: COND_DOWNREG_MASS_RATE_CAMPBELL = 512, COND_DOWNREG_MASS_RATE_FETCH2 = 513
+  integer(c_int), parameter, public :: VAR_TEMPERATURE = 605, VAR_POT_MASS_SINK_PRESSURE = 638, VAR_POT_MASS_SINK_EXPONENT = 639
   integer(c_int), parameter, public :: VAR_PRESSURE = 604, VAR_BC_SS_CONDITION = 607, VAR_LIQ_SAT = 608
   integer(c_int), parameter, public :: VAR_MASS = 610, VAR_SOIL_MATRIX_POT = 611, VAR_MASS_FLUX = 644
   integer(c_int), parameter, public :: AUXVAR_INTERNAL = 701, AUXVAR_BC = 702, AUXVAR_SS = 703, AUXVAR_CONN_INTERNAL = 704
   integer(c_int), parameter, public :: SAT_FUNC_VAN_GENUCHTEN = 1301, SAT_FUNC_BROOKS_COREY = 1302
   integer(c_int), parameter, public :: DENSITY_CONSTANT = 1, DENSITY_TGDPB01 = 2, DENSITY_IFC67 = 3
+
+  ! the raw bindings are public too: one per entry point of include/mppgpu.h
+  public :: mppgpu_create, mppgpu_destroy, mppgpu_last_error, mppgpu_set_mesh, mppgpu_set_connections, &
+        mppgpu_add_condition, mppgpu_set_soil_permeability, mppgpu_set_soil_porosity, mppgpu_set_saturation_function, &
+        mppgpu_set_density_type, mppgpu_set_option, mppgpu_setup, mppgpu_restart, mppgpu_set_data, mppgpu_step_dt, &
+        mppgpu_get_data, mppgpu_get_counters, mppgpu_set_dtime, mppgpu_pre_solve, mppgpu_residual, &
+        mppgpu_jacobian_nnz, mppgpu_jacobian, mppgpu_synchronize, mppgpu_spmv, mppgpu_pc_apply, mppgpu_ksp_solve, &
+        mppgpu_set_lateral_connections, mppgpu_compute_lateral_flux, mppgpu_get_condition_values, &
+        mppgpu_set_source_sink_auxvar, mppgpu_thermal_set_soils, mppgpu_thermal_set_soln_prev_clm, &
+        mppgpu_thermal_pre_step_dt, mppgpu_thermal_step_dt, mppgpu_thermal_get_soln, mppgpu_thermal_compute_rhs, &
+        mppgpu_thermal_compute_operators, mppgpu_th_add_condition, mppgpu_th_set_soils, mppgpu_kernel_stats, &
+        mppgpu_reset_stats, mppgpu_bench_kernel, mppgpu_comm_get_unique_id, mppgpu_comm_init
 
   interface
      integer(c_int) function mppgpu_create(device_id, h) bind(C, name='mppgpu_create')
@@ -142,6 +156,142 @@ module mppgpu_mod
        type(c_ptr), value :: h
        real(c_double) :: x(*), val(*)
        integer(c_int) :: rowptr(*), col(*)
+     end function
+     integer(c_int) function mppgpu_synchronize(h) bind(C, name='mppgpu_synchronize')
+       import :: c_int, c_ptr
+       type(c_ptr), value :: h
+     end function
+     integer(c_int) function mppgpu_spmv(h, x, y) bind(C, name='mppgpu_spmv')
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: h
+       real(c_double) :: x(*), y(*)
+     end function
+     integer(c_int) function mppgpu_pc_apply(h, r, z) bind(C, name='mppgpu_pc_apply')
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: h
+       real(c_double) :: r(*), z(*)
+     end function
+     integer(c_int) function mppgpu_ksp_solve(h, b, x, its, reason) bind(C, name='mppgpu_ksp_solve')
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: h
+       real(c_double) :: b(*), x(*)
+       integer(c_int) :: its, reason
+     end function
+     ! ---- operator split of lateral flow, down-regulated sinks (ELM coupling surface) ----
+     integer(c_int) function mppgpu_set_lateral_connections(h, nconn, id_up, id_dn, dist_up, dist_dn, area, unit_vec) &
+          bind(C, name='mppgpu_set_lateral_connections')
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: h
+       integer(c_int), value :: nconn
+       integer(c_int) :: id_up(*), id_dn(*)
+       real(c_double) :: dist_up(*), dist_dn(*), area(*), unit_vec(*)
+     end function
+     integer(c_int) function mppgpu_compute_lateral_flux(h, dt, ss_cond_id) bind(C, name='mppgpu_compute_lateral_flux')
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: h
+       real(c_double), value :: dt
+       integer(c_int), value :: ss_cond_id
+     end function
+     integer(c_int) function mppgpu_get_condition_values(h, kind, cond_id, n, values) bind(C, name='mppgpu_get_condition_values')
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: h
+       integer(c_int), value :: kind, cond_id, n
+       real(c_double) :: values(*)
+     end function
+     integer(c_int) function mppgpu_set_source_sink_auxvar(h, var_type, n, values) bind(C, name='mppgpu_set_source_sink_auxvar')
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: h
+       integer(c_int), value :: var_type, n
+       real(c_double) :: values(*)
+     end function
+     ! ---- thermal KSP path (sysofeqns_thermal_type) ----
+     integer(c_int) function mppgpu_thermal_set_soils(h, itype, is_soil_shallow, watsat, csol, tkmg, tkdry, dz) &
+          bind(C, name='mppgpu_thermal_set_soils')
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: h
+       integer(c_int) :: itype(*), is_soil_shallow(*)
+       real(c_double) :: watsat(*), csol(*), tkmg(*), tkdry(*), dz(*)
+     end function
+     integer(c_int) function mppgpu_thermal_set_soln_prev_clm(h, n, temperature) bind(C, name='mppgpu_thermal_set_soln_prev_clm')
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: h
+       integer(c_int), value :: n
+       real(c_double) :: temperature(*)
+     end function
+     integer(c_int) function mppgpu_thermal_pre_step_dt(h) bind(C, name='mppgpu_thermal_pre_step_dt')
+       import :: c_int, c_ptr
+       type(c_ptr), value :: h
+     end function
+     integer(c_int) function mppgpu_thermal_step_dt(h, dt, converged, linear_its) bind(C, name='mppgpu_thermal_step_dt')
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: h
+       real(c_double), value :: dt
+       integer(c_int) :: converged, linear_its
+     end function
+     integer(c_int) function mppgpu_thermal_get_soln(h, n, temperature) bind(C, name='mppgpu_thermal_get_soln')
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: h
+       integer(c_int), value :: n
+       real(c_double) :: temperature(*)
+     end function
+     integer(c_int) function mppgpu_thermal_compute_rhs(h, dt, b) bind(C, name='mppgpu_thermal_compute_rhs')
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: h
+       real(c_double), value :: dt
+       real(c_double) :: b(*)
+     end function
+     integer(c_int) function mppgpu_thermal_compute_operators(h, dt, rowptr, col, val) bind(C, name='mppgpu_thermal_compute_operators')
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: h
+       real(c_double), value :: dt
+       integer(c_int) :: rowptr(*), col(*)
+       real(c_double) :: val(*)
+     end function
+     ! ---- coupled thermal-hydrology (sysofeqns_th_type) ----
+     integer(c_int) function mppgpu_th_add_condition(h, igoveqn, kind, cond_type, nconn, id_dn, dist_up, dist_dn, area, &
+          unit_vec, swap_order, cond_id) bind(C, name='mppgpu_th_add_condition')
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: h
+       integer(c_int), value :: igoveqn, kind, cond_type, nconn, swap_order
+       integer(c_int) :: id_dn(*)
+       real(c_double) :: dist_up(*), dist_dn(*), area(*), unit_vec(*)
+       integer(c_int) :: cond_id
+     end function
+     integer(c_int) function mppgpu_th_set_soils(h, heat_cap, therm_cond_wet, therm_cond_dry, therm_alpha, den_soil, &
+          perm_x, perm_y, perm_z) bind(C, name='mppgpu_th_set_soils')
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: h
+       real(c_double) :: heat_cap(*), therm_cond_wet(*), therm_cond_dry(*), therm_alpha(*), den_soil(*)
+       type(c_ptr), value :: perm_x, perm_y, perm_z   ! c_loc(array) or c_null_ptr (keep the auxvar default)
+     end function
+     ! ---- measurement, multi-GPU ----
+     integer(c_int) function mppgpu_kernel_stats(h, kclass, launches, total_ms, bytes_per_launch) bind(C, name='mppgpu_kernel_stats')
+       import :: c_int, c_ptr, c_double, c_char, c_long_long
+       type(c_ptr), value :: h
+       character(kind=c_char) :: kclass(*)
+       integer(c_long_long) :: launches
+       real(c_double) :: total_ms, bytes_per_launch
+     end function
+     integer(c_int) function mppgpu_reset_stats(h) bind(C, name='mppgpu_reset_stats')
+       import :: c_int, c_ptr
+       type(c_ptr), value :: h
+     end function
+     integer(c_int) function mppgpu_bench_kernel(h, kernel, variant, reps, avg_ms, bytes) bind(C, name='mppgpu_bench_kernel')
+       import :: c_int, c_ptr, c_double, c_char
+       type(c_ptr), value :: h
+       character(kind=c_char) :: kernel(*)
+       integer(c_int), value :: variant, reps
+       real(c_double) :: avg_ms, bytes
+     end function
+     integer(c_int) function mppgpu_comm_get_unique_id(id128) bind(C, name='mppgpu_comm_get_unique_id')
+       import :: c_int, c_char
+       character(kind=c_char) :: id128(128)
+     end function
+     integer(c_int) function mppgpu_comm_init(h, nranks, rank, id128) bind(C, name='mppgpu_comm_init')
+       import :: c_int, c_ptr, c_char
+       type(c_ptr), value :: h
+       integer(c_int), value :: nranks, rank
+       character(kind=c_char) :: id128(128)
      end function
   end interface
 

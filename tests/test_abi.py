@@ -61,3 +61,15 @@ def test_product_package_never_imports_the_oracle():
                 assert "vsfm_oracle" not in text and "oracle/" not in text, os.path.join(dirpath, f)
     deps = subprocess.check_output(["ldd", _lib.SO_PATH], text=True)
     assert "oracle" not in deps
+
+
+def test_fortran_module_binds_every_entry_point():
+    """fortran/mppgpu_mod.F90 declares a bind(C) interface for every function include/mppgpu.h declares (the binding an
+    MPP maintainer links against), and nothing else"""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "mppgpu.h")).read()
+    mod = open(os.path.join(root, "fortran", "mppgpu_mod.F90")).read()
+    declared = set(re.findall(r"\b(mppgpu_\w+)\s*\(", hdr))
+    bound = set(re.findall(r"bind\(C, name='(mppgpu_\w+)'\)", mod))
+    assert declared == bound, (sorted(declared - bound), sorted(bound - declared))
