@@ -226,7 +226,7 @@ def main():
                          "avg_launch_ms": round(avg_ms, 5), "launches": sp["launches"]},
             "kernels": kernels,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU baseline is reported at N = 1 only
             cores = args.cpu_cores or min(16, os.cpu_count() or 1)
             try:
                 # ~10-30 s of CPU work: 16 x 8192 columns x 100 layers = 13 M cells (1/8 of the grid), 3+1 steps
