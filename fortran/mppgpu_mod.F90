@@ -31,7 +31,8 @@ module mppgpu_mod
         mppgpu_set_source_sink_auxvar, mppgpu_thermal_set_soils, mppgpu_thermal_set_soln_prev_clm, &
         mppgpu_thermal_pre_step_dt, mppgpu_thermal_step_dt, mppgpu_thermal_get_soln, mppgpu_thermal_compute_rhs, &
         mppgpu_thermal_compute_operators, mppgpu_th_add_condition, mppgpu_th_set_soils, mppgpu_kernel_stats, &
-        mppgpu_reset_stats, mppgpu_bench_kernel, mppgpu_comm_get_unique_id, mppgpu_comm_init
+        mppgpu_reset_stats, mppgpu_bench_kernel, mppgpu_comm_get_unique_id, mppgpu_comm_init, &
+        mppgpu_comm_init_local
 
   interface
      integer(c_int) function mppgpu_create(device_id, h) bind(C, name='mppgpu_create')
@@ -286,6 +287,11 @@ module mppgpu_mod
      integer(c_int) function mppgpu_comm_get_unique_id(id128) bind(C, name='mppgpu_comm_get_unique_id')
        import :: c_int, c_char
        character(kind=c_char) :: id128(128)
+     end function
+     integer(c_int) function mppgpu_comm_init_local(handles, nranks) bind(C, name='mppgpu_comm_init_local')
+       import :: c_int, c_ptr
+       type(c_ptr) :: handles(*)
+       integer(c_int), value :: nranks
      end function
      integer(c_int) function mppgpu_comm_init(h, nranks, rank, id128) bind(C, name='mppgpu_comm_init')
        import :: c_int, c_ptr, c_char

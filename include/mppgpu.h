@@ -260,6 +260,11 @@ int mppgpu_bench_kernel(mppgpu_handle h, const char *name, int variant, int reps
  * ---------------------------------------------------------------------------------------------- */
 int mppgpu_comm_get_unique_id(void *id128);
 int mppgpu_comm_init(mppgpu_handle h, int nranks, int rank, const void *id128);
+/* The same global solve across several handles of ONE process: rank r = handles[r], every handle driven by its own host
+ * thread (the calls block in the reductions until all ranks have arrived).  Reductions go through host memory in rank
+ * order.  For hosts that drive several GPUs from one process, and for exercising the multi-rank path on a single GPU
+ * (RCCL accepts one rank per device). */
+int mppgpu_comm_init_local(mppgpu_handle *handles, int nranks);
 
 #ifdef __cplusplus
 }

@@ -64,6 +64,7 @@ SIGNATURES = {
     "mppgpu_bench_kernel": (ct.c_int, [_h, ct.c_char_p, ct.c_int, ct.c_int, _dp, _dp]),
     "mppgpu_comm_get_unique_id": (ct.c_int, [ct.c_void_p]),
     "mppgpu_comm_init": (ct.c_int, [_h, ct.c_int, ct.c_int, ct.c_void_p]),
+    "mppgpu_comm_init_local": (ct.c_int, [ct.POINTER(_h), ct.c_int]),
 }
 
 

@@ -1,6 +1,8 @@
 // runtime.cpp -- HIP-event profiler and run-time RCCL binding.
 #include "runtime.hpp"
 
+#include <algorithm>
+
 #include <dlfcn.h>
 
 #include <cstring>
@@ -101,19 +103,56 @@ void Comm::init(int nr, int r, const void *id128) {
   nranks = nr;
   rank = r;
 }
+void LocalGroup::allreduce(int rank, double *v, int count, bool is_max) {
+  std::unique_lock<std::mutex> lk(m);
+  for (int i = 0; i < count; ++i) slots[(size_t)rank * 64 + i] = v[i];
+  const long long gen = generation;
+  if (++arrived == nranks) {
+    // the last arriver reduces in rank order and publishes the result in every rank's slots
+    for (int i = 0; i < count; ++i) {
+      double acc = slots[i];
+      for (int r = 1; r < nranks; ++r) acc = is_max ? std::max(acc, slots[(size_t)r * 64 + i]) : acc + slots[(size_t)r * 64 + i];
+      for (int r = 0; r < nranks; ++r) slots[(size_t)r * 64 + i] = acc;
+    }
+    arrived = 0;
+    ++generation;
+    cv.notify_all();
+  } else {
+    cv.wait(lk, [&] { return generation != gen; });
+  }
+  for (int i = 0; i < count; ++i) v[i] = slots[(size_t)rank * 64 + i];
+}
+void Comm::init_local(std::shared_ptr<LocalGroup> g, int r) {
+  if (active()) throw Error("communicator already initialised");
+  local = std::move(g);
+  nranks = local->nranks;
+  rank = r;
+  HIP_CHECK(hipHostMalloc(&h_buf, 64 * sizeof(double), hipHostMallocDefault));
+}
+static void local_allreduce(Comm &c, double *dev, int count, hipStream_t s, bool is_max) {
+  if (count > 64) throw Error("in-process all-reduce: more than 64 values");
+  HIP_CHECK(hipMemcpyAsync(c.h_buf, dev, count * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+  c.local->allreduce(c.rank, c.h_buf, count, is_max);
+  HIP_CHECK(hipMemcpyAsync(dev, c.h_buf, count * sizeof(double), hipMemcpyHostToDevice, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+}
 void Comm::allreduce_sum(double *dev, int count, hipStream_t s) {
+  if (local) { local_allreduce(*this, dev, count, s, false); return; }
   if (!comm) return;
   static fn_allreduce f = nullptr;
   if (!f) f = sym<fn_allreduce>(lib, "ncclAllReduce");
   nccl_check(lib, f(dev, dev, (size_t)count, kNcclFloat64, kNcclSum, comm, s), "ncclAllReduce");
 }
 void Comm::allreduce_max(double *dev, int count, hipStream_t s) {
+  if (local) { local_allreduce(*this, dev, count, s, true); return; }
   if (!comm) return;
   static fn_allreduce f = nullptr;
   if (!f) f = sym<fn_allreduce>(lib, "ncclAllReduce");
   nccl_check(lib, f(dev, dev, (size_t)count, kNcclFloat64, kNcclMax, comm, s), "ncclAllReduce");
 }
 Comm::~Comm() {
+  if (h_buf) (void)hipHostFree(h_buf);
   if (comm && lib) {
     if (void *p = dlsym(lib, "ncclCommDestroy")) (void)reinterpret_cast<fn_destroy>(p)(comm);
   }

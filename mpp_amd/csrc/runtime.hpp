@@ -7,6 +7,9 @@
 #include <cstddef>
 #include <cstdint>
 #include <stdexcept>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -80,12 +83,30 @@ struct ProfScope {
   ~ProfScope() { p.end(); }
 };
 
+// In-process group: several handles of ONE process (one host thread each, any devices) reduce through host memory.
+// Same call sites as the RCCL path; exists so that the multi-rank control flow can be exercised on a single GPU
+// (RCCL accepts one rank per device) and for hosts that drive several GPUs from one process.
+struct LocalGroup {
+  int nranks;
+  std::mutex m;
+  std::condition_variable cv;
+  int arrived = 0;
+  long long generation = 0;
+  std::vector<double> slots;   // nranks x 64
+  explicit LocalGroup(int n) : nranks(n), slots((size_t)n * 64, 0.0) {}
+  // every rank contributes `count` (<= 64) values; returns, in rank order (deterministic), the sum or max in `v`
+  void allreduce(int rank, double *v, int count, bool is_max);
+};
+
 // ---- RCCL, bound at run time (dlopen) so that single-GPU use never needs the library ----
 struct Comm {
   void *lib = nullptr;
   void *comm = nullptr;
+  std::shared_ptr<LocalGroup> local;
+  double *h_buf = nullptr;     // pinned staging of the in-process path
   int nranks = 1, rank = 0;
-  bool active() const { return comm != nullptr; }
+  bool active() const { return comm != nullptr || local != nullptr; }
+  void init_local(std::shared_ptr<LocalGroup> g, int rank);
   static void get_unique_id(void *id128);
   void init(int nranks, int rank, const void *id128);
   void allreduce_sum(double *dev, int count, hipStream_t s);

@@ -2191,5 +2191,20 @@ int mppgpu_comm_init(mppgpu_handle h, int nranks, int rank, const void *id128) {
   S.comm.init(nranks, rank, id128);
   API_END()
 }
+int mppgpu_comm_init_local(mppgpu_handle *handles, int nranks) {
+  if (!handles || nranks < 1) return 1;
+  for (int r = 0; r < nranks; ++r) if (!handles[r]) return 1;
+  try {
+    auto g = std::make_shared<mpp::LocalGroup>(nranks);
+    for (int r = 0; r < nranks; ++r) {
+      (void)hipSetDevice(handles[r]->s.device);
+      handles[r]->s.comm.init_local(g, r);
+    }
+  } catch (const std::exception &e) {
+    handles[0]->s.err = e.what();
+    return 2;
+  }
+  return 0;
+}
 
 }  // extern "C"

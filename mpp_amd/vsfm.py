@@ -223,6 +223,14 @@ class SystemOfEquationsVSFM:
         self._chk(self.L.mppgpu_comm_init(self.h, int(nranks), int(rank), buf))
 
 
+def comm_init_local(soes):
+    """one global Newton-Krylov solve across several SoEs of this process (one host thread each): mppgpu_comm_init_local"""
+    L = _lib.lib()
+    arr = (ct.c_void_p * len(soes))(*[s.h for s in soes])
+    if L.mppgpu_comm_init_local(arr, len(soes)):
+        raise MPPError(L.mppgpu_last_error(soes[0].h).decode())
+
+
 def comm_get_unique_id() -> bytes:
     buf = ct.create_string_buffer(128)
     L = _lib.lib()
