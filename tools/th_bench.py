@@ -15,6 +15,25 @@ import numpy as np  # noqa: E402
 import problems as P  # noqa: E402
 
 
+def cpu_baseline(cols, nz, ncols_full):
+    """the CPU oracle ("port": th_oracle.c, GMRES(30)+ILU(0) as the reference's PETSc defaults, one core -- the reference is
+    serial) on a bounded sample of the same workload, scaled to full-grid Newton iterations/s"""
+    mult = np.exp(0.5 * np.random.default_rng(12345).standard_normal(ncols_full))[:cols]
+    tp = P.th_columns(ncols=cols, nz=nz, perm_mult=mult)
+    o = P.to_th_oracle(tp)
+    o.step_dt(tp.dt)
+    c0 = o.counters()["newton"]
+    t0 = time.perf_counter()
+    for s in range(2):
+        P.th_set_conditions(tp, o)
+        o.step_dt(tp.dt)
+    dt = time.perf_counter() - t0
+    its = o.counters()["newton"] - c0
+    return {"value": its * cols / ncols_full / dt, "unit": "Newton iters/s", "cores": 1, "kind": "port",
+            "sample": "%d of %d columns x %d layers, 2 timed steps after 1 warm-up, GMRES(30)+ILU(0); %d Newton iterations in %.2f s"
+                      % (cols, ncols_full, nz, its, dt)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--nx", type=int, default=128)
@@ -24,6 +43,7 @@ def main():
     ap.add_argument("--ksp", default="gmres")
     ap.add_argument("--pc", default="ilu")
     ap.add_argument("--out", default="")
+    ap.add_argument("--cpu-cols", type=int, default=256, help="columns of the CPU-oracle sample (0 = skip)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="extra mppgpu_set_option pairs")
     a = ap.parse_args()
     ncols = a.nx * a.ny
@@ -60,6 +80,16 @@ def main():
                            "GBps": (round(s["bytes_per_launch"] * s["launches"] / (s["total_ms"] * 1e-3) / 1e9, 1)
                                     if s["total_ms"] > 0 and s["bytes_per_launch"] > 0 else None)}
                        for k, s in stats.items() if s["launches"]}}
+    # roofline of the dominant kernel (fused column assembly): algorithmic bytes per cell = x 16 + soil/heat parameters 80
+    # + accum_prev 16 + connection geometry 56 read, F 16 + 12 Jacobian entries 96 written = 280 B
+    if "jacobian" in out["kernels"]:
+        jk = out["kernels"]["jacobian"]
+        by = 280.0 * ncols * a.nz
+        out["roofline"] = {"kernel": "k_th_cols<2> (residual + 2x2-block Jacobian)", "bound": "hbm", "unit": "GB/s", "peak": 8000.0,
+                           "achieved": round(by / (jk["avg_ms"] * 1e-3) / 1e9, 1), "frac": round(by / (jk["avg_ms"] * 1e-3) / 1e9 / 8000.0, 4),
+                           "bytes_per_launch": by, "note": "pow/div-bound at occupancy 1 (256 VGPRs), not bandwidth-bound"}
+    if a.cpu_cols > 0:
+        out["cpu_baseline"] = cpu_baseline(a.cpu_cols, a.nz, ncols)
     print(json.dumps(out), flush=True)
     if a.out:
         json.dump(out, open(a.out, "w"), indent=1)

@@ -14,6 +14,19 @@ import numpy as np  # noqa: E402
 import problems as P  # noqa: E402
 
 
+def cpu_baseline(n, n_full, rtol):
+    """the CPU oracle ("port": thermal_oracle.c + the restated GMRES(30)+ILU(0), one core) on a smaller grid of the same
+    problem; reported as cell-iterations per second so that it can be set against the GPU's"""
+    tp = P.thermal_mms(3, n, n, n, replicate_reference_soil_indexing=False)
+    o = P.to_thermal_oracle(tp, ksp_rtol=rtol)
+    t0 = time.perf_counter()
+    o.step_dt(tp.dt)
+    dt = time.perf_counter() - t0
+    its = o.linear_iterations()
+    return {"value": its * n ** 3 / dt, "unit": "cell-iterations/s", "cores": 1, "kind": "port",
+            "sample": "%d^3 grid (GPU run: %d^3), %d GMRES iterations in %.2f s" % (n, n_full, its, dt)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=128)
@@ -21,6 +34,7 @@ def main():
     ap.add_argument("--pc", default="ilu")
     ap.add_argument("--rtol", type=float, default=1e-5)
     ap.add_argument("--out", default="")
+    ap.add_argument("--cpu-n", type=int, default=64, help="grid size of the CPU-oracle sample (0 = skip)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="extra mppgpu_set_option pairs")
     a = ap.parse_args()
     t0 = time.perf_counter()
@@ -44,11 +58,24 @@ def main():
     stats = {k: g.soe.kernel_stats(k) for k in ("spmv", "pc_apply", "pc_setup", "residual", "jacobian", "vec", "reduce")}
     out = {"grid": a.n, "cells": a.n ** 3, "ksp": a.ksp, "pc": a.pc, "converged": conv,
            "linear_iterations": g.soe.last_linear_iterations, "step_s": t_step, "setup_s": t_setup, "build_s": t_build,
-           "max_error_vs_manufactured_solution": err,
+           "max_error_vs_manufactured_solution": err, "cell_iterations_per_s": a.n ** 3 * g.soe.last_linear_iterations / t_step,
            "kernels": {k: {"launches": s["launches"], "total_ms": round(s["total_ms"], 3),
                            "GBps": (round(s["bytes_per_launch"] * s["launches"] / (s["total_ms"] * 1e-3) / 1e9, 1)
                                     if s["total_ms"] > 0 and s["bytes_per_launch"] > 0 else None)}
                        for k, s in stats.items() if s["launches"]}}
+    # roofline of the dominant kernel class (ILU(0) apply): algorithmic bytes 12 nnz + 24 N
+    N = a.n ** 3
+    nnz = 7 * N - 6 * a.n * a.n
+    pa = stats["pc_apply"]
+    if pa["launches"]:
+        ms = pa["total_ms"] / pa["launches"]
+        by = 12.0 * nnz + 24.0 * N
+        out["roofline"] = {"kernel": "ILU(0) triangular solves (level-ordered ELL, one launch per level)", "bound": "hbm", "unit": "GB/s",
+                           "peak": 8000.0, "achieved": round(by / (ms * 1e-3) / 1e9, 1), "frac": round(by / (ms * 1e-3) / 1e9 / 8000.0, 4),
+                           "bytes_per_launch": by, "avg_apply_ms": round(ms, 4), "levels": 2 * (3 * a.n - 2),
+                           "note": "latency-bound by the number of dependency levels"}
+    if a.cpu_n > 0:
+        out["cpu_baseline"] = cpu_baseline(a.cpu_n, a.n, a.rtol)
     print(json.dumps(out), flush=True)
     if a.out:
         json.dump(out, open(a.out, "w"), indent=1)
