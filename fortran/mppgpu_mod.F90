@@ -32,7 +32,7 @@ module mppgpu_mod
         mppgpu_thermal_pre_step_dt, mppgpu_thermal_step_dt, mppgpu_thermal_get_soln, mppgpu_thermal_compute_rhs, &
         mppgpu_thermal_compute_operators, mppgpu_th_add_condition, mppgpu_th_set_soils, mppgpu_kernel_stats, &
         mppgpu_reset_stats, mppgpu_bench_kernel, mppgpu_comm_get_unique_id, mppgpu_comm_init, &
-        mppgpu_comm_init_local
+        mppgpu_comm_init_local, mppgpu_set_ghost_cells, mppgpu_set_halo
 
   interface
      integer(c_int) function mppgpu_create(device_id, h) bind(C, name='mppgpu_create')
@@ -179,6 +179,17 @@ module mppgpu_mod
        integer(c_int) :: its, reason
      end function
      ! ---- operator split of lateral flow, down-regulated sinks (ELM coupling surface) ----
+     integer(c_int) function mppgpu_set_ghost_cells(h, nghost) bind(C, name='mppgpu_set_ghost_cells')
+       import :: c_int, c_ptr
+       type(c_ptr), value :: h
+       integer(c_int), value :: nghost
+     end function
+     integer(c_int) function mppgpu_set_halo(h, nneigh, peer_rank, send_ptr, send_cells, recv_count) bind(C, name='mppgpu_set_halo')
+       import :: c_int, c_ptr
+       type(c_ptr), value :: h
+       integer(c_int), value :: nneigh
+       integer(c_int) :: peer_rank(*), send_ptr(*), send_cells(*), recv_count(*)
+     end function
      integer(c_int) function mppgpu_set_lateral_connections(h, nconn, id_up, id_dn, dist_up, dist_dn, area, unit_vec) &
           bind(C, name='mppgpu_set_lateral_connections')
        import :: c_int, c_ptr, c_double

@@ -110,6 +110,20 @@ int mppgpu_set_saturation_function(mppgpu_handle h, const int *satfunc_type, con
                                    const double *sat_res);
 int mppgpu_set_density_type(mppgpu_handle h, int density_type);
 
+/* 3-D meshes split across ranks ("one-plane halo exchange per neighbour per SpMV").  mppgpu_set_ghost_cells:
+ * the LAST nghost cells of the mesh (mesh%ncells_ghost in the reference, src/mpp/dtypes/MeshType.F90:42) are copies of
+ * cells that another rank owns; connections may join an owned and a ghost cell (never two ghosts); conditions sit on
+ * owned cells.  mppgpu_set_halo: for neighbour k the values of the owned cells send_cells[send_ptr[k] .. send_ptr[k+1])
+ * (1-based) go to rank peer_rank[k], and recv_count[k] values arrive from it into the next ghost cells -- ghosts are
+ * grouped by owner in the order of that owner's send list.  The library refreshes ghost values before every residual /
+ * Jacobian / SpMV (RCCL grouped send/recv on the solver's stream, or device copies inside an in-process group) and applies
+ * the preconditioner rank-locally (PETSc's parallel default: block-Jacobi with ILU(0) per rank).  Vectors passed through
+ * the ABI keep their ghost entries (ignored on input, unspecified on output).  Call both before mppgpu_setup, and
+ * mppgpu_comm_init(_local) before the first solve. */
+int mppgpu_set_ghost_cells(mppgpu_handle h, int nghost);
+int mppgpu_set_halo(mppgpu_handle h, int nneigh, const int *peer_rank, const int *send_ptr, const int *send_cells,
+                    const int *recv_count);
+
 /* Operator split of lateral flow (ELM mode).  mppgpu_set_lateral_connections: the mesh's lateral_conn_set_list
  * (src/mpp/dtypes/MeshType.F90:53, 635) -- connections that are NOT part of the implicit system.
  * mppgpu_compute_lateral_flux = soe%ComputeLateralFlux(dt) (src/mpp/soe/SystemOfEquationsVSFMType.F90:848-889 ->

@@ -31,6 +31,8 @@ SIGNATURES = {
     "mppgpu_set_soil_porosity": (ct.c_int, [_h, _dp]),
     "mppgpu_set_saturation_function": (ct.c_int, [_h, _ip, _dp, _dp, _dp]),
     "mppgpu_set_density_type": (ct.c_int, [_h, ct.c_int]),
+    "mppgpu_set_ghost_cells": (ct.c_int, [_h, ct.c_int]),
+    "mppgpu_set_halo": (ct.c_int, [_h, ct.c_int, _ip, _ip, _ip, _ip]),
     "mppgpu_set_lateral_connections": (ct.c_int, [_h, ct.c_int, _ip, _ip, _dp, _dp, _dp, _dp]),
     "mppgpu_compute_lateral_flux": (ct.c_int, [_h, ct.c_double, ct.c_int]),
     "mppgpu_get_condition_values": (ct.c_int, [_h, ct.c_int, ct.c_int, ct.c_int, _dp]),

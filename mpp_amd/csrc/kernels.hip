@@ -43,8 +43,13 @@ __device__ __forceinline__ Soil load_soil(const CellArrays &ca, size_t i) {
   return s;
 }
 
+// cell states: 0 inactive (mesh%is_active false), 1 active, 2 ghost -- a cell owned by another rank: its auxvars are
+// evaluated and its neighbours exchange flux with it, but its own row is an identity row (see Solver::halo_exchange)
 __device__ __forceinline__ bool is_active(const CellArrays &ca, size_t i) {
   return ca.active ? ca.active[i] != 0 : true;
+}
+__device__ __forceinline__ bool owns_row(const CellArrays &ca, size_t i) {
+  return ca.active ? ca.active[i] == 1 : true;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -54,7 +59,7 @@ __global__ __launch_bounds__(kBlock) void k_accum(CellArrays ca, int n, double d
   const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= (size_t)n) return;
   double acc = 0.0;
-  if (is_active(ca, i)) {
+  if (owns_row(ca, i)) {
     Soil s = load_soil(ca, i);
     Aux a = auxvar_compute<false>(ca.sat_func, ca.eos, s, ca.P[i], ca.frac_liq);
     acc = s.por * a.den * a.sat * ca.vol[i] * dtInv;
@@ -168,9 +173,11 @@ __global__ __launch_bounds__(kBlock) void k_auxvars(GenArgs a) {
   if (is_active(ca, i)) {
     Soil s = load_soil(ca, i);
     x = auxvar_compute<JAC>(ca.sat_func, ca.eos, s, ca.P[i], ca.frac_liq);
-    const double vol = ca.vol[i];
-    if (RES) f = s.por * x.den * x.sat * vol * a.dtInv;
-    if (JAC) dacc = (s.por * x.dden * x.sat + s.por * x.den * x.dsat) * vol * a.dtInv;
+    if (owns_row(ca, i)) {
+      const double vol = ca.vol[i];
+      if (RES) f = s.por * x.den * x.sat * vol * a.dtInv;
+      if (JAC) dacc = (s.por * x.dden * x.sat + s.por * x.den * x.dsat) * vol * a.dtInv;
+    }
   }
   a.aux.kr[i] = x.kr;
   a.aux.den[i] = x.den;
@@ -194,7 +201,7 @@ __global__ __launch_bounds__(kBlock) void k_flux_rows(GenArgs a) {
       if (s != dslot) a.val[s] = 0.0;
   }
   double f = RES ? a.F[i] : 0.0;
-  if (is_active(ca, i)) {
+  if (owns_row(ca, i)) {
     Aux me;
     me.P = ca.P[i]; me.kr = a.aux.kr[i]; me.den = a.aux.den[i];
     me.dkr = JAC ? a.aux.dkr[i] : 0.0; me.dden = JAC ? a.aux.dden[i] : 0.0;
@@ -243,7 +250,7 @@ __global__ __launch_bounds__(kBlock) void k_bc(BcArgs a) {
   if (j >= a.ncond_cells) return;
   const CellArrays &ca = a.cell;
   const size_t cell = a.cc_cell[j];
-  if (!is_active(ca, cell)) return;
+  if (!owns_row(ca, cell)) return;
   Soil s = load_soil(ca, cell);
   const Aux in = auxvar_compute<JAC>(ca.sat_func, ca.eos, s, ca.P[cell], ca.frac_liq);
   double f = RES ? a.F[cell] : 0.0;
@@ -926,7 +933,7 @@ __global__ __launch_bounds__(kBlock) void k_thermal_rows(ThermalArgs a) {
   constexpr bool RHS = (MODE == 0 || MODE == 2), OPR = (MODE == 1 || MODE == 2);
   const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= (size_t)a.n) return;
-  const bool act = a.active ? a.active[i] != 0 : true;
+  const bool act = a.active ? a.active[i] == 1 : true;   // a ghost cell (2) keeps an identity row
   const int dslot = a.diag_slot[i];
   if (OPR)
     for (int s = a.rowptr[i]; s < a.rowptr[i + 1]; ++s) a.val[s] = 0.0;
@@ -970,7 +977,7 @@ __global__ __launch_bounds__(kBlock) void k_thermal_bc(ThermalBcArgs a) {
   if (j >= a.ncond_cells) return;
   const ThermalArgs &t = a.t;
   const size_t cell = a.cc_cell[j];
-  if (t.active && !t.active[cell]) return;
+  if (t.active && t.active[cell] != 1) return;
   double b = RHS ? t.rhs[cell] : 0.0, d = 0.0;
   for (int e = a.cc_ptr[j]; e < a.cc_ptr[j + 1]; ++e) {
     const int ctype = a.type[e];

@@ -61,6 +61,8 @@ using fn_get_id = int (*)(NcclUniqueId *);
 using fn_init_rank = int (*)(void **, int, NcclUniqueId, int);
 using fn_allreduce = int (*)(const void *, void *, size_t, int, int, void *, hipStream_t);
 using fn_destroy = int (*)(void *);
+using fn_sendrecv = int (*)(void *, size_t, int, int, void *, hipStream_t);   // ncclSend (const void*) / ncclRecv
+using fn_group = int (*)();
 using fn_errstr = const char *(*)(int);
 constexpr int kNcclFloat64 = 8;  // ncclDataType_t ncclDouble (rccl.h)
 constexpr int kNcclSum = 0;      // ncclRedOp_t ncclSum
@@ -143,6 +145,47 @@ void Comm::allreduce_sum(double *dev, int count, hipStream_t s) {
   static fn_allreduce f = nullptr;
   if (!f) f = sym<fn_allreduce>(lib, "ncclAllReduce");
   nccl_check(lib, f(dev, dev, (size_t)count, kNcclFloat64, kNcclSum, comm, s), "ncclAllReduce");
+}
+void Comm::register_sendbuf(const double *sendbuf, const std::vector<int> &peer, const std::vector<int> &send_ptr) {
+  if (!local) return;   // the RCCL path needs no registration
+  std::lock_guard<std::mutex> lk(local->m);
+  local->sendbuf[rank] = sendbuf;
+  local->send_off[rank].clear();
+  for (size_t k = 0; k < peer.size(); ++k) local->send_off[rank].emplace_back(peer[k], send_ptr[k]);
+}
+void Comm::exchange(const double *sendbuf, const std::vector<int> &peer, const std::vector<int> &send_ptr, double *recv,
+                    const std::vector<int> &recv_ptr, hipStream_t s) {
+  const int nn = (int)peer.size();
+  if (local) {
+    register_sendbuf(sendbuf, peer, send_ptr);
+    HIP_CHECK(hipStreamSynchronize(s));   // my packed values are in place
+    local->barrier(rank);                 // ... and everybody else's
+    for (int k = 0; k < nn; ++k) {
+      const int q = peer[k], cnt = recv_ptr[k + 1] - recv_ptr[k];
+      int off = -1;
+      for (auto &de : local->send_off[q]) if (de.first == rank) off = de.second;
+      if (off < 0 || !local->sendbuf[q]) throw Error("halo exchange: rank " + std::to_string(q) + " has no send list for rank " + std::to_string(rank));
+      if (cnt > 0)
+        HIP_CHECK(hipMemcpyAsync(recv + recv_ptr[k], local->sendbuf[q] + off, (size_t)cnt * sizeof(double), hipMemcpyDeviceToDevice, s));
+    }
+    HIP_CHECK(hipStreamSynchronize(s));
+    local->barrier(rank);                 // nobody repacks before every reader is done
+    return;
+  }
+  if (!comm) throw Error("halo exchange without a communicator");
+  static fn_sendrecv fsend = nullptr, frecv = nullptr;
+  static fn_group gstart = nullptr, gend = nullptr;
+  if (!fsend) {
+    fsend = sym<fn_sendrecv>(lib, "ncclSend"); frecv = sym<fn_sendrecv>(lib, "ncclRecv");
+    gstart = sym<fn_group>(lib, "ncclGroupStart"); gend = sym<fn_group>(lib, "ncclGroupEnd");
+  }
+  nccl_check(lib, gstart(), "ncclGroupStart");
+  for (int k = 0; k < nn; ++k) {
+    const size_t ns = (size_t)(send_ptr[k + 1] - send_ptr[k]), nr = (size_t)(recv_ptr[k + 1] - recv_ptr[k]);
+    if (ns) nccl_check(lib, fsend(const_cast<double *>(sendbuf) + send_ptr[k], ns, kNcclFloat64, peer[k], comm, s), "ncclSend");
+    if (nr) nccl_check(lib, frecv(recv + recv_ptr[k], nr, kNcclFloat64, peer[k], comm, s), "ncclRecv");
+  }
+  nccl_check(lib, gend(), "ncclGroupEnd");
 }
 void Comm::allreduce_max(double *dev, int count, hipStream_t s) {
   if (local) { local_allreduce(*this, dev, count, s, true); return; }

@@ -93,7 +93,11 @@ struct LocalGroup {
   int arrived = 0;
   long long generation = 0;
   std::vector<double> slots;   // nranks x 64
-  explicit LocalGroup(int n) : nranks(n), slots((size_t)n * 64, 0.0) {}
+  // halo exchange: every rank publishes its packed send buffer and where each destination's part starts
+  std::vector<const double *> sendbuf;
+  std::vector<std::vector<std::pair<int, int>>> send_off;   // per rank: (destination, offset)
+  explicit LocalGroup(int n) : nranks(n), slots((size_t)n * 64, 0.0), sendbuf(n, nullptr), send_off(n) {}
+  void barrier(int rank) { double d = 0.0; allreduce(rank, &d, 0, false); }
   // every rank contributes `count` (<= 64) values; returns, in rank order (deterministic), the sum or max in `v`
   void allreduce(int rank, double *v, int count, bool is_max);
 };
@@ -110,6 +114,11 @@ struct Comm {
   static void get_unique_id(void *id128);
   void init(int nranks, int rank, const void *id128);
   void allreduce_sum(double *dev, int count, hipStream_t s);
+  // halo exchange: `sendbuf` holds, for neighbour k, the values for peer[k] at [send_ptr[k], send_ptr[k+1]); the values
+  // received from peer[k] land at recv[recv_ptr[k] .. recv_ptr[k+1]).  RCCL: grouped ncclSend / ncclRecv on the stream.
+  void register_sendbuf(const double *sendbuf, const std::vector<int> &peer, const std::vector<int> &send_ptr);
+  void exchange(const double *sendbuf, const std::vector<int> &peer, const std::vector<int> &send_ptr, double *recv,
+                const std::vector<int> &recv_ptr, hipStream_t s);
   void allreduce_max(double *dev, int count, hipStream_t s);
   ~Comm();
 };

@@ -65,6 +65,19 @@ struct Solver {
   // ---------------- staging, caller's ordering, 0-based ----------------
   int n = 0, nlev = 0;
   int nrow = 0;   // unknowns = rows of the linear system: n, or 2n for the coupled thermal-hydrology system [P; T]
+  // ---------------- ghost cells + halo exchange (3-D meshes split across ranks) ----------------
+  // The LAST nghost cells of the mesh are copies of cells another rank owns.  They are cells like any other for the
+  // assembly kernels (auxvars, fluxes with their neighbours) but their own rows are identity rows; vector operations,
+  // reductions and SpMV rows run over the first nred = nrow - nghost entries only, and the ghost tail of a vector is
+  // (a) refreshed from the owners before it is read as a state or as an SpMV operand, (b) zeroed before a preconditioner
+  // apply -- which makes the local ILU(0) exactly the block-Jacobi/ILU(0) PETSc applies in parallel.
+  int nghost = 0, nred = 0;
+  struct HaloPlan {
+    std::vector<int> peer, send_ptr, send_cells, recv_ptr;   // per neighbour: send list (owned cells, 0-based), ghost range
+    DevBuf<int> d_send_idx;
+    DevBuf<double> sendbuf;
+    bool set = false;
+  } halo;
   std::vector<double> vol;
   std::vector<int> active;
   bool any_inactive = false;
@@ -194,6 +207,33 @@ struct Solver {
     active.assign(n, 1);
     any_inactive = false;
     if (act) for (int i = 0; i < n; ++i) { active[i] = act[i] != 0; any_inactive |= !active[i]; }
+    nghost = 0;
+  }
+
+  void set_ghost_cells(int ng) {
+    need_setup(false);
+    if (ng < 0 || ng >= n) throw Error("mppgpu_set_ghost_cells: need 0 <= nghost < ncells");
+    if (th) throw Error("ghost cells are not available for the coupled thermal-hydrology system");
+    for (int i = 0; i < n; ++i) if (active[i] == 2) active[i] = 1;
+    nghost = ng;
+    for (int i = n - ng; i < n; ++i) active[i] = 2;
+    any_inactive = false;
+    for (int i = 0; i < n; ++i) any_inactive |= (active[i] != 1);
+  }
+  void set_halo(int nneigh, const int *peer, const int *send_ptr, const int *send_cells, const int *recv_count) {
+    need_setup(false);
+    if (nghost <= 0 && nneigh > 0) throw Error("mppgpu_set_halo: no ghost cells");
+    halo.peer.assign(peer, peer + nneigh);
+    halo.send_ptr.assign(send_ptr, send_ptr + nneigh + 1);
+    halo.send_cells.resize(send_ptr[nneigh]);
+    for (int k = 0; k < send_ptr[nneigh]; ++k) {
+      if (send_cells[k] < 1 || send_cells[k] > n - nghost) throw Error("mppgpu_set_halo: only owned cells can be sent");
+      halo.send_cells[k] = send_cells[k] - 1;
+    }
+    halo.recv_ptr.assign(nneigh + 1, 0);
+    for (int k = 0; k < nneigh; ++k) halo.recv_ptr[k + 1] = halo.recv_ptr[k] + recv_count[k];
+    if (halo.recv_ptr[nneigh] != nghost) throw Error("mppgpu_set_halo: the receive counts must add up to nghost");
+    halo.set = true;
   }
 
   void set_connections(int nconn, const int *up, const int *dn, const double *du, const double *dd, const double *ar,
@@ -324,6 +364,7 @@ struct Solver {
     ext2int.assign(n, -1);
     int2ext.assign(n, -1);
     columns = false;
+    if (nghost > 0) ok = false;   // ghost cells stay last: identity layout
     if (ok) {
       std::vector<int> starts;
       for (int i = 0; i < n; ++i) if (below[i] == -1) starts.push_back(i);
@@ -407,6 +448,8 @@ struct Solver {
     if (n == 0) throw Error("mppgpu_set_mesh has not been called");
     HIP_CHECK(hipSetDevice(device));
     nrow = th ? 2 * n : n;
+    nred = nrow - nghost;
+    if (nghost > 0 && !halo.set) throw Error("ghost cells need a halo plan (mppgpu_set_halo)");
     detect_columns();
     build_pattern();
     d_ext2int.upload(ext2int, stream);
@@ -546,6 +589,10 @@ struct Solver {
       th_liq.assign(n, 0.0); th_ice.assign(n, 0.0); th_snow.assign(n, 0.0); th_tuning.assign(n, 1.0); th_nsnow.assign(n, 0);
     }
     build_compact_index();
+    if (nghost > 0) {
+      halo.d_send_idx.upload(halo.send_cells, stream);
+      halo.sendbuf.alloc(std::max<size_t>(halo.send_cells.size(), 1));
+    }
     HIP_CHECK(hipStreamSynchronize(stream));
     setup_done = true;
     soil_dirty = true;
@@ -785,8 +832,19 @@ struct Solver {
   // =====================================================================================
   // operators (device pointers, internal ordering)
   // =====================================================================================
+  // refresh the ghost tail of `x` from the ranks that own those cells (no-op without ghost cells)
+  void halo_exchange(const double *x_const) {
+    if (nghost <= 0) return;
+    if (!comm.active()) throw Error("ghost cells need a communicator (mppgpu_comm_init / mppgpu_comm_init_local)");
+    ProfScope ps(prof, KC_VEC);
+    double *x = const_cast<double *>(x_const);
+    launch_gather((int)halo.send_cells.size(), halo.d_send_idx.p, x, halo.sendbuf.p, stream);
+    comm.exchange(halo.sendbuf.p, halo.peer, halo.send_ptr, x + nred, halo.recv_ptr, stream);
+  }
+
   void op_residual(const double *P, double *Fout) {
     if (dtime <= 0.0) throw Error("time step not set");
+    halo_exchange(P);
     ProfScope ps(prof, KC_RESIDUAL);
     if (th) { launch_th_assemble(0, th_args(P, Fout), stream); ++nfuncs; ++cum_funcs; return; }
     if (use_cols()) launch_assemble_cols(0, cols_args(P, Fout), stream);
@@ -801,6 +859,7 @@ struct Solver {
   // residual and Jacobian of the same state in one pass: the auxvars (the expensive part) are evaluated once
   void op_residual_jacobian(const double *P, double *Fout) {
     if (dtime <= 0.0) throw Error("time step not set");
+    halo_exchange(P);
     ProfScope ps(prof, KC_JACOBIAN);
     if (th) { launch_th_assemble(2, th_args(P, Fout), stream); ++nfuncs; ++cum_funcs; pc_ready = false; return; }
     if (use_cols()) launch_assemble_cols(2, cols_args(P, Fout), stream);
@@ -815,6 +874,7 @@ struct Solver {
   }
   void op_jacobian(const double *P) {
     if (dtime <= 0.0) throw Error("time step not set");
+    halo_exchange(P);
     ProfScope ps(prof, KC_JACOBIAN);
     if (th) { launch_th_assemble(2, th_args(P, th_scratch.p), stream); pc_ready = false; return; }
     if (use_cols()) launch_assemble_cols(1, cols_args(P, F.p), stream);
@@ -824,22 +884,24 @@ struct Solver {
     pc_ready = false;
   }
   void op_pre_solve() {  // VSFMSOEPreSolve: accum_prev from soln_prev
+    halo_exchange(soln_prev.p);
     ProfScope ps(prof, KC_RESIDUAL);
     if (th) { launch_th_assemble(3, th_args(soln_prev.p, accum_prev.p), stream); return; }  // SOETHPreSolve :119-272
     launch_accum(cells(soln_prev.p), n, 1.0 / dtime, accum_prev.p, stream);
   }
   void op_spmv(const double *x, double *y) {
+    halo_exchange(x);
     ProfScope ps(prof, KC_SPMV);
     const int v = spmv_variant();
     if (v == 20 || v == 21) {
       if (!compact_index) throw Error("spmv_variant 20/21 need the compact index (rows of <= 8 entries whose columns lie within 2^15 of their 64-row tile)");
-      launch_spmv_compact(v == 20 ? 4 : 8, nrow, max_row_nnz, d_tileptr.p, d_roff.p, d_dcol.p, d_val.p, x, y, stream);
-    } else launch_spmv(v, nrow, max_row_nnz, d_rowptr.p, d_col.p, d_val.p, x, y, stream);
+      launch_spmv_compact(v == 20 ? 4 : 8, nred, max_row_nnz, d_tileptr.p, d_roff.p, d_dcol.p, d_val.p, x, y, stream);
+    } else launch_spmv(v, nred, max_row_nnz, d_rowptr.p, d_col.p, d_val.p, x, y, stream);
   }
   // 16-bit in-tile row offsets + 16-bit column offsets from the tile's first row (the pattern is fixed after setup)
   void build_compact_index() {
     compact_index = false;
-    if (max_row_nnz > 8) return;
+    if (max_row_nnz > 8 || nghost > 0) return;   // (with ghost rows the last owned tile would need its own extent)
     const int ntiles = (nrow + 63) / 64;
     std::vector<int> tp((size_t)ntiles + 2, 0);
     std::vector<unsigned short> ro(nrow);
@@ -906,9 +968,10 @@ struct Solver {
   }
   void op_pc_apply(const double *r, double *z) {
     ProfScope ps(prof, KC_PC_APPLY);
+    if (nghost > 0) launch_set(nghost, 0.0, const_cast<double *>(r) + nred, stream);   // block-Jacobi across ranks
     if (opt.pc_type == 2 && th) launch_th_tri_solve(th_tri_args(), r, z, stream);
     else if (opt.pc_type == 2) launch_tri_solve(tri_args(), r, z, stream);
-    else if (opt.pc_type == 3) launch_pointwise_mult(nrow, jac_invd.p, r, z, stream);
+    else if (opt.pc_type == 3) launch_pointwise_mult(nred, jac_invd.p, r, z, stream);
     else if (opt.pc_type == 1) {
       launch_gather(nrow, d_lrows.p, r, ilu_y.p, stream);            // r into the L level order
       if (opt.ilu_graph) {
@@ -921,7 +984,7 @@ struct Solver {
         HIP_CHECK(hipGraphLaunch(ilu_graph_exec, stream));
       } else ilu_solve_levels();
       launch_gather(nrow, d_posU.p, ilu_x.p, z, stream);             // back to the internal row order
-    } else launch_copy(nrow, r, z, stream);
+    } else launch_copy(nred, r, z, stream);
   }
   void op_BA(const double *v, double *t) {  // t = M^{-1} A v  (left preconditioning)
     op_spmv(v, Wk.p);
@@ -932,7 +995,7 @@ struct Solver {
   void dots_dev(std::initializer_list<std::pair<const double *, const double *>> pairs) {
     ProfScope ps(prof, KC_REDUCE);
     DotArgs a;
-    a.n = nrow; a.nvec = 0;
+    a.n = nred; a.nvec = 0;
     for (auto &p : pairs) { a.x[a.nvec] = p.first; a.y[a.nvec] = p.second; ++a.nvec; }
     const int nbk = launch_dots(a, partials.p, stream);
     launch_finalize_partials(nbk, a.nvec, partials.p, sc.p, stream);
@@ -953,11 +1016,11 @@ struct Solver {
     dots_host({{x, x}}, &s);
     return std::sqrt(s);
   }
-  void vec_copy(const double *x, double *y) { ProfScope ps(prof, KC_VEC); launch_copy(nrow, x, y, stream); }
-  void vec_set(double v, double *y) { ProfScope ps(prof, KC_VEC); launch_set(nrow, v, y, stream); }
+  void vec_copy(const double *x, double *y) { ProfScope ps(prof, KC_VEC); launch_copy(nred, x, y, stream); }
+  void vec_set(double v, double *y) { ProfScope ps(prof, KC_VEC); launch_set(nred, v, y, stream); }
   void vec_waxpy(double *w, double a, const double *x, const double *y) {
     ProfScope ps(prof, KC_VEC);
-    launch_waxpy(nrow, w, sc.p, -1, 1.0, a, x, y, stream);
+    launch_waxpy(nred, w, sc.p, -1, 1.0, a, x, y, stream);
   }
 
   // =====================================================================================
@@ -1004,6 +1067,7 @@ struct Solver {
     need_setup(true);
     thermal_upload_cells();
     if (dtime <= 0.0) throw Error("time step not set");
+    halo_exchange(soln_prev.p);
     ProfScope ps(prof, mode == 0 ? KC_RESIDUAL : KC_JACOBIAN);
     ThermalArgs a = thermal_args();
     launch_thermal_aux(a, stream);
@@ -1058,19 +1122,19 @@ struct Solver {
       launch_bcgs_scalars(1, sc.p, stream);
       if (i > 0) {
         ProfScope ps(prof, KC_VEC);
-        launch_bcgs_p(nrow, Pv.p, Pcur, Rcur, V.p, sc.p, stream);
+        launch_bcgs_p(nred, Pv.p, Pcur, Rcur, V.p, sc.p, stream);
         Pcur = Pv.p;
       }
       op_BA(Pcur, V.p);
       dots_dev({{V.p, RP.p}});
       launch_bcgs_scalars(2, sc.p, stream);
-      { ProfScope ps(prof, KC_VEC); launch_waxpy(nrow, S.p, sc.p, S_ALPHA, -1.0, 0.0, V.p, Rcur, stream); }
+      { ProfScope ps(prof, KC_VEC); launch_waxpy(nred, S.p, sc.p, S_ALPHA, -1.0, 0.0, V.p, Rcur, stream); }
       op_BA(S.p, T.p);
       dots_dev({{S.p, T.p}, {T.p, T.p}});
       launch_bcgs_scalars(3, sc.p, stream);
       {
         ProfScope ps(prof, KC_REDUCE);
-        const int nbk = launch_bcgs_xr(nrow, i == 0, x, R.p, Pcur, S.p, T.p, sc.p, partials.p, stream);
+        const int nbk = launch_bcgs_xr(nred, i == 0, x, R.p, Pcur, S.p, T.p, sc.p, partials.p, stream);
         launch_finalize_partials(nbk, 1, partials.p, sc.p, stream);
         if (comm.active()) comm.allreduce_sum(sc.p + S_SUM0, 1, stream);
       }
@@ -1127,7 +1191,7 @@ struct Solver {
         {  // classical Gram-Schmidt: all dots, then one fused update
           ProfScope ps(prof, KC_REDUCE);
           DotArgs a;
-          a.n = nrow; a.nvec = it + 1;
+          a.n = nred; a.nvec = it + 1;
           for (int j = 0; j <= it; ++j) { a.x[j] = vnew; a.y[j] = vv[j].p; }
           const int nbk = launch_dots(a, partials.p, stream);
           launch_finalize_partials(nbk, a.nvec, partials.p, sc.p, stream);
@@ -1136,7 +1200,7 @@ struct Solver {
         {
           ProfScope ps(prof, KC_VEC);
           MaxpyArgs ma;
-          ma.n = nrow; ma.nvec = it + 1;
+          ma.n = nred; ma.nvec = it + 1;
           for (int j = 0; j <= it; ++j) ma.v[j] = vv[j].p;
           launch_maxpy_neg(ma, sc.p, vnew, stream);
         }
@@ -1173,7 +1237,7 @@ struct Solver {
       if (it > 0) {
         ProfScope ps(prof, KC_VEC);
         MaxpyValArgs ma;
-        ma.n = nrow; ma.nvec = it;
+        ma.n = nred; ma.nvec = it;
         for (int j = 0; j < it; ++j) { ma.v[j] = vv[j].p; ma.c[j] = y[j]; }
         launch_maxpy_val(ma, x, stream);
       }
@@ -1184,7 +1248,7 @@ struct Solver {
   void scale_host(double *x, double divisor) {  // x <- x / divisor
     ProfScope ps(prof, KC_VEC);
     HIP_CHECK(hipMemcpyAsync(sc.p + S_D2, &divisor, sizeof(double), hipMemcpyHostToDevice, stream));
-    launch_scale(nrow, x, sc.p, S_D2, stream);
+    launch_scale(nred, x, sc.p, S_D2, stream);
   }
 
   int ksp_solve(const double *b, double *x, int *its) {
@@ -1860,6 +1924,17 @@ int mppgpu_add_condition(mppgpu_handle h, int kind, int cond_type, int nconn, co
   API_BEGIN(h)
   const int id = S.add_condition(kind, cond_type, nconn, id_dn, dist_up, dist_dn, area, unit_vec, swap_order);
   if (cond_id) *cond_id = id;
+  API_END()
+}
+int mppgpu_set_ghost_cells(mppgpu_handle h, int nghost) {
+  API_BEGIN(h)
+  S.set_ghost_cells(nghost);
+  API_END()
+}
+int mppgpu_set_halo(mppgpu_handle h, int nneigh, const int *peer_rank, const int *send_ptr, const int *send_cells,
+                    const int *recv_count) {
+  API_BEGIN(h)
+  S.set_halo(nneigh, peer_rank, send_ptr, send_cells, recv_count);
   API_END()
 }
 int mppgpu_set_lateral_connections(mppgpu_handle h, int nconn, const int *id_up, const int *id_dn, const double *dist_up,

@@ -170,3 +170,62 @@ class HostGroup:
         if self.sock is not None:
             self.sock.close()
         self.peers, self.sock = [], None
+
+
+# ------------------------------------------------------------------------------------------------------------
+# 3-D meshes split across ranks: owned cells + ghost cells + halo plan (mppgpu_set_ghost_cells / mppgpu_set_halo)
+# ------------------------------------------------------------------------------------------------------------
+class MeshPart:
+    """one rank's piece of a global mesh: `mesh` (owned cells in global order first, ghost cells last, grouped by owner),
+    `l2g` (0-based global id of every local cell), `nghost`, and the halo plan arrays of mppgpu_set_halo"""
+
+    def __init__(self, mesh, l2g, nghost, peer, send_ptr, send_cells, recv_count):
+        self.mesh, self.l2g, self.nghost = mesh, l2g, nghost
+        self.peer, self.send_ptr, self.send_cells, self.recv_count = peer, send_ptr, send_cells, recv_count
+        self.nowned = mesh.ncells_local - nghost
+
+
+def partition_mesh(mesh, nranks):
+    """Split `mesh` into `nranks` contiguous id ranges (z-slabs for the x-fastest numbering of MeshCreate).  A cell is a
+    ghost on rank r when an internal connection joins it to a cell r owns; connections with at least one owned end are
+    kept (in the global connection order); both neighbours list shared cells in ascending global id, which makes rank
+    q's send list match the order of its cells among rank r's ghosts."""
+    import numpy as np
+    from . import mesh as M
+    n = mesh.ncells_local
+    cs = mesh.internal_connections()
+    up, dn = np.asarray(cs.id_up) - 1, np.asarray(cs.id_dn) - 1
+    bounds = [shard_columns(n, nranks, r) for r in range(nranks)]
+    owner = np.empty(n, dtype=np.int64)
+    for r, (c0, cnt) in enumerate(bounds):
+        owner[c0:c0 + cnt] = r
+    parts = []
+    for r, (c0, cnt) in enumerate(bounds):
+        mine_up, mine_dn = owner[up] == r, owner[dn] == r
+        keep = mine_up | mine_dn
+        ghost_g = np.unique(np.concatenate([dn[mine_up & ~mine_dn], up[mine_dn & ~mine_up]]))
+        ghost_g = ghost_g[np.lexsort((ghost_g, owner[ghost_g]))]          # grouped by owner, ascending id inside a group
+        l2g = np.concatenate([np.arange(c0, c0 + cnt), ghost_g])
+        g2l = np.full(n, -1, dtype=np.int64)
+        g2l[l2g] = np.arange(l2g.size)
+        peers = np.unique(owner[ghost_g])
+        recv_count = [int((owner[ghost_g] == q).sum()) for q in peers]
+        send_ptr, send_cells = [0], []
+        for q in peers:   # my cells that rank q sees as ghosts = my cells joined to one of q's cells
+            mineq = np.unique(np.concatenate([up[mine_up & (owner[dn] == q)], dn[mine_dn & (owner[up] == q)]]))
+            send_cells.extend((g2l[mineq] + 1).tolist())
+            send_ptr.append(len(send_cells))
+        pick = lambda a: None if a is None else np.asarray(a)[l2g].copy()
+        lm = M.Mesh(name=mesh.name, ncells_local=int(l2g.size), nlev=mesh.nlev, orientation=mesh.orientation)
+        lm.x, lm.y, lm.z, lm.dx, lm.dy, lm.dz = (pick(a) for a in (mesh.x, mesh.y, mesh.z, mesh.dx, mesh.dy, mesh.dz))
+        lm.area_xy, lm.vol, lm.is_active = pick(mesh.area_xy), pick(mesh.vol), pick(mesh.is_active)
+        sel = np.nonzero(keep)[0]
+        lcs = M.ConnectionSet(g2l[up[sel]] + 1, g2l[dn[sel]] + 1, np.asarray(cs.dist_up)[sel], np.asarray(cs.dist_dn)[sel],
+                              np.asarray(cs.area)[sel], np.asarray(cs.unit_vec)[sel], None if cs.itype is None else np.asarray(cs.itype)[sel])
+        lm.intrn_conn_sets.append(lcs)
+        lm.ncols, lm.ordering = mesh.ncols, mesh.ordering
+        lm.nghost = int(ghost_g.size)
+        lm.halo = (np.asarray(peers, dtype=np.int32), np.asarray(send_ptr, dtype=np.int32), np.asarray(send_cells, dtype=np.int32),
+                   np.asarray(recv_count, dtype=np.int32))
+        parts.append(MeshPart(lm, l2g, int(ghost_g.size), *lm.halo))
+    return parts

@@ -639,3 +639,49 @@ def th_columns(ncols=1, nz=100, perm_mult=None, density_type=None, ie_type=2) ->
         mass_bcs=[(ttype, tcs, tvals, one(tcs, 303.15)), (btype, bcs_, bvals, one(bcs_, 283.15))],
         energy_bcs=[(C.COND_DIRICHLET, tcs, one(tcs, 303.15), tvals.copy()), (C.COND_DIRICHLET, bcs_, one(bcs_, 283.15), bvals.copy())],
         dt=vs.dt, nstep=1)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# a problem split across ranks: owned cells + ghost cells per rank (mpp_amd.parallel.partition_mesh)
+# ------------------------------------------------------------------------------------------------------------
+def _restrict_conn_set(cs, vals, part, g2l):
+    """the entries of a boundary / source connection set whose cell this rank owns (cells renumbered locally)"""
+    cells = np.asarray(cs.id_dn) - 1
+    loc = g2l[cells]
+    keep = (loc >= 0) & (loc < part.nowned)
+    sub = M.ConnectionSet(np.asarray(cs.id_up)[keep], loc[keep] + 1, np.asarray(cs.dist_up)[keep], np.asarray(cs.dist_dn)[keep],
+                          np.asarray(cs.area)[keep], np.asarray(cs.unit_vec)[keep], None if cs.itype is None else np.asarray(cs.itype)[keep])
+    return sub, np.asarray(vals)[keep]
+
+
+def split_problem(prob: Problem, nranks):
+    """per-rank VSFM problems of a 3-D problem (no column structure is assumed); returns [(part, local problem)]"""
+    from mpp_amd import parallel as PAR
+    out = []
+    n = prob.mesh.ncells_local
+    for part in PAR.partition_mesh(prob.mesh, nranks):
+        g2l = np.full(n, -1, dtype=np.int64)
+        g2l[part.l2g] = np.arange(part.l2g.size)
+        l = part.l2g
+        lp = Problem(name=prob.name, mesh=part.mesh, perm=prob.perm[l], por=prob.por[l], satfunc_type=prob.satfunc_type[l],
+                     alpha=prob.alpha[l], lam=prob.lam[l], sat_res=prob.sat_res[l], density_type=prob.density_type,
+                     press_ic=prob.press_ic[l], dt=prob.dt, nstep=prob.nstep)
+        lp.bcs = [(t,) + _restrict_conn_set(cs, v, part, g2l) for (t, cs, v) in prob.bcs]
+        lp.sss = [(t,) + _restrict_conn_set(cs, v, part, g2l) for (t, cs, v) in prob.sss]
+        out.append((part, lp))
+    return out
+
+
+def split_thermal_problem(tp: ThermalProblem, nranks):
+    from mpp_amd import parallel as PAR
+    out = []
+    n = tp.mesh.ncells_local
+    for part in PAR.partition_mesh(tp.mesh, nranks):
+        g2l = np.full(n, -1, dtype=np.int64)
+        g2l[part.l2g] = np.arange(part.l2g.size)
+        l = part.l2g
+        bc, bct = _restrict_conn_set(tp.bc, tp.bc_temperature, part, g2l)
+        out.append((part, ThermalProblem(name=tp.name, mesh=part.mesh, tkdry=np.asarray(tp.tkdry)[l], bc=bc, bc_temperature=bct,
+                                         heat_source=np.asarray(tp.heat_source)[l], exact=np.asarray(tp.exact)[l], t_init=tp.t_init,
+                                         cnfac=tp.cnfac, dt=tp.dt)))
+    return out

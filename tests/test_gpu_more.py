@@ -150,3 +150,106 @@ def test_sharded_global_solve_on_one_gpu_equals_the_unsharded_solve():
     for c0, nloc, prob, g in shards:
         p = g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE).reshape(nloc, nz)
         assert np.abs(p - p_ref[c0:c0 + nloc]).max() <= 1e-9 * np.abs(p_ref).max()
+
+
+def _run_ranks(fns):
+    import threading
+    errors, out = [], [None] * len(fns)
+
+    def run(r):
+        try:
+            out[r] = fns[r]()
+        except Exception as e:   # noqa: BLE001
+            errors.append((r, e))
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(len(fns))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not errors, errors
+    assert all(not t.is_alive() for t in th)
+    return out
+
+
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_3d_mesh_split_across_ranks_thermal(nranks):
+    """the thermal MMS grid split into z-slabs over `nranks` handles with ghost planes and a halo
+    exchange before every operator assembly and SpMV, GMRES + rank-local ILU(0) (PETSc's parallel default).  The
+    operator rows of the owned cells equal the single-handle rows; the solution equals the single-handle one to the
+    linear tolerance."""
+    from mpp_amd import vsfm as V
+    tp = P.thermal_mms(3, 7, 6, 9, replicate_reference_soil_indexing=False)
+    opts = {"ksp_type": "gmres", "pc_type": "ilu", "ksp_rtol": 1e-12}
+    ref = P.to_thermal_gpu(tp, opts)
+    rp, cj, val = ref.soe.ComputeOperators(tp.dt)
+    b_ref = ref.soe.ComputeRHS(tp.dt)
+    ref.soe.PreStepDT()
+    conv, _ = ref.soe.StepDT(tp.dt)
+    assert conv
+    t_ref = ref.soe.GetSoln()
+    parts = P.split_thermal_problem(tp, nranks)
+    gs = [P.to_thermal_gpu(lp, opts) for _, lp in parts]
+    V.comm_init_local([g.soe for g in gs])
+    ops = _run_ranks([lambda g=g: (g.soe.ComputeOperators(tp.dt), g.soe.ComputeRHS(tp.dt)) for g in gs])
+    n = tp.mesh.ncells_local
+    A = np.zeros((n, n))
+    for i in range(n):
+        A[i, cj[rp[i]:rp[i + 1]]] = val[rp[i]:rp[i + 1]]
+    for (part, lp), ((lrp, lcj, lval), lb) in zip(parts, ops):
+        for li in range(part.nowned):           # owned rows, columns mapped back to global ids
+            row = np.zeros(n)
+            row[part.l2g[lcj[lrp[li]:lrp[li + 1]]]] = lval[lrp[li]:lrp[li + 1]]
+            assert np.abs(row - A[part.l2g[li]]).max() <= 1e-13 * np.abs(A[part.l2g[li]]).max()
+        assert np.abs(lb[:part.nowned] - b_ref[part.l2g[:part.nowned]]).max() <= 1e-12 * np.abs(b_ref).max()
+        for li in range(part.nowned, lp.mesh.ncells_local):   # ghost rows are identity rows
+            assert lval[lrp[li]:lrp[li + 1]].sum() == 1.0 and np.count_nonzero(lval[lrp[li]:lrp[li + 1]]) == 1
+
+    def step(g):
+        g.soe.PreStepDT()
+        return g.soe.StepDT(tp.dt)
+
+    res = _run_ranks([lambda g=g: step(g) for g in gs])
+    assert all(r[0] for r in res)
+    for (part, lp), g in zip(parts, gs):
+        t = g.soe.GetSoln()
+        assert np.abs(t[:part.nowned] - t_ref[part.l2g[:part.nowned]]).max() <= 1e-8
+
+
+def test_3d_mesh_split_across_ranks_vsfm():
+    """the 7-point v-channel problem on 3 ranks (ghost planes, halo exchange before every residual / Jacobian / SpMV,
+    rank-local ILU(0)) against the single-handle solve: residual rows of the owned cells at a random state, then three
+    time steps"""
+    from mpp_amd import vsfm as V
+    prob = P.vchannel(6, 5, 9)
+    n = prob.mesh.ncells_local
+    opts = {"ksp_type": "gmres", "pc_type": "ilu", "ksp_rtol": 1e-10}
+    ref = P.to_gpu(prob, opts)
+    x = prob.press_ic - np.random.default_rng(5).uniform(0, 2.5e5, n)
+    ref.soe.SetDtime(prob.dt); ref.soe.PreSolve()
+    f_ref = ref.soe.ComputeResidual(x)
+    parts = P.split_problem(prob, 3)
+    gs = [P.to_gpu(lp, opts) for _, lp in parts]
+    V.comm_init_local([g.soe for g in gs])
+
+    def resid(part, g):
+        g.soe.SetDtime(prob.dt); g.soe.PreSolve()
+        return g.soe.ComputeResidual(x[part.l2g])
+
+    fs = _run_ranks([lambda part=part, g=g: resid(part, g) for (part, _), g in zip(parts, gs)])
+    for (part, lp), f in zip(parts, fs):
+        own = part.l2g[:part.nowned]
+        assert np.abs(f[:part.nowned] - f_ref[own]).max() <= 1e-11 * np.abs(f_ref).max()
+        assert (f[part.nowned:] == 0.0).all()
+    for s in range(prob.nstep):
+        assert ref.soe.StepDT(prob.dt, s + 1)[0]
+    p_ref = ref.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE)
+
+    def steps(g):
+        return [g.soe.StepDT(prob.dt, s + 1) for s in range(prob.nstep)]
+
+    res = _run_ranks([lambda g=g: steps(g) for g in gs])
+    assert all(c for r in res for (c, _) in r)
+    for (part, lp), g in zip(parts, gs):
+        p = g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE)
+        assert np.abs(p[:part.nowned] - p_ref[part.l2g[:part.nowned]]).max() <= 1e-7 * np.abs(p_ref).max()

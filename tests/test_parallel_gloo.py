@@ -121,3 +121,33 @@ def test_host_group_single_rank_is_trivial():
     assert g.allreduce([2.0, 3.0], op="max") == [2.0, 3.0]
     g.barrier()
     g.close()
+
+
+def test_partition_mesh_halo_plans_are_consistent():
+    """mpp_amd.parallel.partition_mesh: every rank's ghosts from rank q are, in order, the cells of q's send list to it;
+    owned cells partition the mesh; every kept connection has an owned end and no connection joins two ghosts"""
+    import numpy as np
+    import problems as P
+    from mpp_amd import parallel as PAR
+    prob = P.vchannel(5, 4, 7)
+    n = prob.mesh.ncells_local
+    for nranks in (2, 3, 4):
+        parts = PAR.partition_mesh(prob.mesh, nranks)
+        owned = np.concatenate([pt.l2g[:pt.nowned] for pt in parts])
+        assert np.array_equal(np.sort(owned), np.arange(n))
+        nconn_owned_both = 0
+        for r, pr in enumerate(parts):
+            off = pr.nowned
+            for k, q in enumerate(pr.peer):
+                gl = pr.l2g[off:off + pr.recv_count[k]]
+                off += pr.recv_count[k]
+                pq = parts[q]
+                kk = list(pq.peer).index(r)
+                sl = pq.l2g[pq.send_cells[pq.send_ptr[kk]:pq.send_ptr[kk + 1]] - 1]
+                assert np.array_equal(gl, sl)
+            assert off == pr.mesh.ncells_local
+            cs = pr.mesh.internal_connections()
+            up_owned, dn_owned = cs.id_up <= pr.nowned, cs.id_dn <= pr.nowned
+            assert (up_owned | dn_owned).all()
+            nconn_owned_both += int((up_owned & dn_owned).sum()) * 2 + int((up_owned ^ dn_owned).sum())
+        assert nconn_owned_both == 2 * prob.mesh.internal_connections().num_connections
