@@ -32,7 +32,8 @@ module mppgpu_mod
         mppgpu_thermal_pre_step_dt, mppgpu_thermal_step_dt, mppgpu_thermal_get_soln, mppgpu_thermal_compute_rhs, &
         mppgpu_thermal_compute_operators, mppgpu_th_add_condition, mppgpu_th_set_soils, mppgpu_kernel_stats, &
         mppgpu_reset_stats, mppgpu_bench_kernel, mppgpu_comm_get_unique_id, mppgpu_comm_init, &
-        mppgpu_comm_init_local, mppgpu_set_ghost_cells, mppgpu_set_halo
+        mppgpu_comm_init_local, mppgpu_set_ghost_cells, mppgpu_set_halo, &
+        mppgpu_pre_step_dt, mppgpu_post_step_dt
 
   interface
      integer(c_int) function mppgpu_create(device_id, h) bind(C, name='mppgpu_create')
@@ -179,6 +180,14 @@ module mppgpu_mod
        integer(c_int) :: its, reason
      end function
      ! ---- operator split of lateral flow, down-regulated sinks (ELM coupling surface) ----
+     integer(c_int) function mppgpu_pre_step_dt(h) bind(C, name='mppgpu_pre_step_dt')
+       import :: c_int, c_ptr
+       type(c_ptr), value :: h
+     end function
+     integer(c_int) function mppgpu_post_step_dt(h) bind(C, name='mppgpu_post_step_dt')
+       import :: c_int, c_ptr
+       type(c_ptr), value :: h
+     end function
      integer(c_int) function mppgpu_set_ghost_cells(h, nghost) bind(C, name='mppgpu_set_ghost_cells')
        import :: c_int, c_ptr
        type(c_ptr), value :: h

@@ -44,6 +44,9 @@ typedef struct mppgpu_handle_s *mppgpu_handle;
 #define MPPGPU_VAR_LIQ_SAT 608
 #define MPPGPU_VAR_MASS 610
 #define MPPGPU_VAR_SOIL_MATRIX_POT 611
+#define MPPGPU_VAR_FRAC_LIQ_SAT 612
+#define MPPGPU_VAR_LATERAL_MASS_EXCHANGED 613
+#define MPPGPU_VAR_BC_MASS_EXCHANGED 614
 #define MPPGPU_VAR_LIQ_AREAL_DEN 615
 #define MPPGPU_VAR_ICE_AREAL_DEN 617
 #define MPPGPU_VAR_FRAC 618
@@ -109,6 +112,17 @@ int mppgpu_set_soil_porosity(mppgpu_handle h, const double *por);
 int mppgpu_set_saturation_function(mppgpu_handle h, const int *satfunc_type, const double *alpha, const double *lambda,
                                    const double *sat_res);
 int mppgpu_set_density_type(mppgpu_handle h, int density_type);
+
+/* soe%PreStepDT / soe%PostStepDT of ELM's calling sequence (src/mpp/soe/SystemOfEquationsVSFMType.F90:892-940):
+ * PreStepDT copies soln_prev_clm into soln_prev and soln and resets the exchanged-mass accumulators
+ * (GoveqnRichardsODEPressureType.F90:2773-2785); PostStepDT copies soln_prev into soln_prev_clm.  mppgpu_restart also
+ * fills soln_prev_clm.  With option "track_mass_exchange" = 1 every successful sub-step of mppgpu_step_dt adds flux*dt of
+ * the horizontal internal connections and of the boundary connections to the accumulators read back with
+ * mppgpu_get_data(AUXVAR_INTERNAL, VAR_LATERAL_MASS_EXCHANGED) / (AUXVAR_BC, VAR_BC_MASS_EXCHANGED, id) (GE:1150-1166,
+ * 1338-1342).  mppgpu_set_data(AUXVAR_INTERNAL, VAR_FRAC_LIQ_SAT, -1, ...) sets the per-cell frac_liq_sat the reference
+ * copies into the auxvars in PreSolve (GE:536-582). */
+int mppgpu_pre_step_dt(mppgpu_handle h);
+int mppgpu_post_step_dt(mppgpu_handle h);
 
 /* 3-D meshes split across ranks ("one-plane halo exchange per neighbour per SpMV").  mppgpu_set_ghost_cells:
  * the LAST nghost cells of the mesh (mesh%ncells_ghost in the reference, src/mpp/dtypes/MeshType.F90:42) are copies of

@@ -31,6 +31,8 @@ SIGNATURES = {
     "mppgpu_set_soil_porosity": (ct.c_int, [_h, _dp]),
     "mppgpu_set_saturation_function": (ct.c_int, [_h, _ip, _dp, _dp, _dp]),
     "mppgpu_set_density_type": (ct.c_int, [_h, ct.c_int]),
+    "mppgpu_pre_step_dt": (ct.c_int, [_h]),
+    "mppgpu_post_step_dt": (ct.c_int, [_h]),
     "mppgpu_set_ghost_cells": (ct.c_int, [_h, ct.c_int]),
     "mppgpu_set_halo": (ct.c_int, [_h, ct.c_int, _ip, _ip, _ip, _ip]),
     "mppgpu_set_lateral_connections": (ct.c_int, [_h, ct.c_int, _ip, _ip, _dp, _dp, _dp, _dp]),

@@ -48,6 +48,7 @@ __device__ __forceinline__ Soil load_soil(const CellArrays &ca, size_t i) {
 __device__ __forceinline__ bool is_active(const CellArrays &ca, size_t i) {
   return ca.active ? ca.active[i] != 0 : true;
 }
+__device__ __forceinline__ double frac_of(const CellArrays &ca, size_t i) { return ca.frac_cell ? ca.frac_cell[i] : ca.frac_liq; }
 __device__ __forceinline__ bool owns_row(const CellArrays &ca, size_t i) {
   return ca.active ? ca.active[i] == 1 : true;
 }
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(kBlock) void k_accum(CellArrays ca, int n, double d
   double acc = 0.0;
   if (owns_row(ca, i)) {
     Soil s = load_soil(ca, i);
-    Aux a = auxvar_compute<false>(ca.sat_func, ca.eos, s, ca.P[i], ca.frac_liq);
+    Aux a = auxvar_compute<false>(ca.sat_func, ca.eos, s, ca.P[i], frac_of(ca, i));
     acc = s.por * a.den * a.sat * ca.vol[i] * dtInv;
   }
   out[i] = acc;
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(kBlock) void k_assemble_cols(ColsArgs a) {
     cur.P = Pi;
     if (act) {
       Soil s = load_soil<SAT_T, true>(ca, i);
-      cur = auxvar_compute<JAC, SAT_T, DEN_T>(ca.sat_func, ca.eos, s, Pi, ca.frac_liq);
+      cur = auxvar_compute<JAC, SAT_T, DEN_T>(ca.sat_func, ca.eos, s, Pi, frac_of(ca, i));
       if (owned) {
         const double vol = ldnt(ca.vol + i);
         if (RES) f_cur = s.por * cur.den * cur.sat * vol * a.dtInv;
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(kBlock) void k_auxvars(GenArgs a) {
   Aux x = {};
   if (is_active(ca, i)) {
     Soil s = load_soil(ca, i);
-    x = auxvar_compute<JAC>(ca.sat_func, ca.eos, s, ca.P[i], ca.frac_liq);
+    x = auxvar_compute<JAC>(ca.sat_func, ca.eos, s, ca.P[i], frac_of(ca, i));
     if (owns_row(ca, i)) {
       const double vol = ca.vol[i];
       if (RES) f = s.por * x.den * x.sat * vol * a.dtInv;
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(kBlock) void k_bc(BcArgs a) {
   const size_t cell = a.cc_cell[j];
   if (!owns_row(ca, cell)) return;
   Soil s = load_soil(ca, cell);
-  const Aux in = auxvar_compute<JAC>(ca.sat_func, ca.eos, s, ca.P[cell], ca.frac_liq);
+  const Aux in = auxvar_compute<JAC>(ca.sat_func, ca.eos, s, ca.P[cell], frac_of(ca, cell));
   double f = RES ? a.F[cell] : 0.0;
   double d = 0.0;
   for (int e = a.cc_ptr[j]; e < a.cc_ptr[j + 1]; ++e) {
@@ -317,8 +318,8 @@ __global__ __launch_bounds__(kBlock) void k_conn_flux(CellArrays ca, ConnArrays 
   double flux = 0.0;
   if (is_active(ca, u) && is_active(ca, d)) {
     Soil su = load_soil(ca, u), sd = load_soil(ca, d);
-    Aux au = auxvar_compute<false>(ca.sat_func, ca.eos, su, ca.P[u], ca.frac_liq);
-    Aux ad = auxvar_compute<false>(ca.sat_func, ca.eos, sd, ca.P[d], ca.frac_liq);
+    Aux au = auxvar_compute<false>(ca.sat_func, ca.eos, su, ca.P[u], frac_of(ca, u));
+    Aux ad = auxvar_compute<false>(ca.sat_func, ca.eos, sd, ca.P[d], frac_of(ca, d));
     ConnGeom g;
     g.Dq = cn.Dq[ic]; g.upweight = cn.upw[ic]; g.dist_gravity = cn.dgrav[ic]; g.area = cn.area[ic];
     double j1, j2;
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(kBlock) void k_cell_var(CellArrays ca, int n, int v
   if (i >= (size_t)n) return;
   Soil s = load_soil(ca, i);
   const double P = ca.P[i];
-  Aux a = auxvar_compute<false>(ca.sat_func, ca.eos, s, P, ca.frac_liq);
+  Aux a = auxvar_compute<false>(ca.sat_func, ca.eos, s, P, frac_of(ca, i));
   double v;
   if (var_type == 608) v = a.sat;
   else if (var_type == 610) v = s.por * a.den * kFMWH2O * a.sat * ca.vol[i];

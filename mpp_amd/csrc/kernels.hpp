@@ -27,7 +27,8 @@ struct CellArrays {
   const signed char *active;                         // nullptr = every cell active
   int sat_func;
   int all_vg_half;                                   // every cell is van Genuchten with m == 1/2 (host-verified)
-  double frac_liq;
+  double frac_liq;                                   // frac_liq_sat of boundary auxvars (1.0) and of every cell when ...
+  const double *frac_cell;                           // ... no per-cell values were set (VAR_FRAC_LIQ_SAT), else per cell
   EosParams eos;
 };
 

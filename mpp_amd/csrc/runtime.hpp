@@ -145,6 +145,7 @@ struct Options {
   int assembly = -1;       // -1 auto, 0 general kernels, 1 fused column kernels
   int nseg = 0;            // column segments per thread block row (0 = auto)
   bool fused_assembly = true;  // F and J of a line-search trial point in one kernel ...
+  bool track_mass_exchange = false;  // accumulate VAR_LATERAL_MASS_EXCHANGED / VAR_BC_MASS_EXCHANGED after every sub-step
   bool ilu_graph = true;       // replay the level launches of the ILU(0) triangular solves from a hipGraph
   bool fused_predict = true;   // skip the fused Jacobian at the first trial when the previous line search backtracked
   int fused_trials = 2;        // ... for the first `fused_trials` trial points of a line search (later ones: F only)

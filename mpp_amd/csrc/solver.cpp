@@ -124,7 +124,12 @@ struct Solver {
   bool compact_index = false;
   DevBuf<int> d_cc_cell, d_cc_ptr, d_bc_type;
   DevBuf<double> d_bc_Dq, d_bc_dgrav, d_bc_area, d_bc_value, d_bc_flux;
-  DevBuf<double> d_src;
+  DevBuf<double> d_src, d_frac;
+  std::vector<double> h_frac;             // per-cell frac_liq_sat, caller's ordering (empty = 1 everywhere)
+  // exchanged-mass bookkeeping of the ELM coupling (GE:33-34, 1150-1166, 1338-1342); option "track_mass_exchange"
+  std::vector<double> lat_mass_exc, bnd_mass_exc;   // per cell (caller's ordering) / per boundary connection (offset numbering)
+  std::vector<char> conn_horizontal;
+  bool has_clm_state = false;
   bool has_src = false;
   // down-regulated sinks, grouped by cell
   int ndr_cells = 0, ndr = 0;
@@ -560,7 +565,7 @@ struct Solver {
       }
     }
     // vectors
-    for (DevBuf<double> *b : {&soln, &soln_prev, &accum_prev, &F, &Y, &W, &G, &R, &RP, &V, &T, &S, &Pv, &Wk, &tmp_ext, &tmp_int}) {
+    for (DevBuf<double> *b : {&soln, &soln_prev, &soln_prev_clm, &accum_prev, &F, &Y, &W, &G, &R, &RP, &V, &T, &S, &Pv, &Wk, &tmp_ext, &tmp_int}) {
       b->alloc(nrow); b->zero(stream);
     }
     partials.alloc((size_t)kMaxPartialBlocks * kMaxMultiDot);
@@ -584,7 +589,7 @@ struct Solver {
       h_bc_frac.assign(nb, 1.0); h_bc_dhsdT.assign(nb, 0.0); h_bc_act.assign(nb, 1);
       d_bc_frac.upload(h_bc_frac, stream); d_bc_dhsdT.upload(h_bc_dhsdT, stream);
       d_bc_act.upload(h_bc_act.data(), h_bc_act.size(), stream);
-      d_therm_cond.alloc(n); d_heat_cap.alloc(n); soln_prev_clm.alloc(n); soln_prev_clm.zero(stream);
+      d_therm_cond.alloc(n); d_heat_cap.alloc(n);
       if (ns > 0 && !has_src) { d_src.alloc(n); d_src.zero(stream); has_src = true; }
       th_liq.assign(n, 0.0); th_ice.assign(n, 0.0); th_snow.assign(n, 0.0); th_tuning.assign(n, 1.0); th_nsnow.assign(n, 0);
     }
@@ -789,6 +794,7 @@ struct Solver {
     ca.sbc_pu = d_pu.p; ca.sbc_ps = d_ps.p; ca.sbc_b2 = d_b2.p; ca.sbc_b3 = d_b3.p;
     ca.active = any_inactive ? d_active.p : nullptr;
     ca.sat_func = sat_func; ca.all_vg_half = all_vg_half ? 1 : 0; ca.frac_liq = frac_liq;
+    ca.frac_cell = d_frac.p;   // nullptr until VAR_FRAC_LIQ_SAT is set
     ca.eos = make_eos(density_type, temperature);
     return ca;
   }
@@ -1396,6 +1402,56 @@ struct Solver {
     return reason;
   }
 
+  // SetDataInSOEAuxVar in PostSolve (GE:1150-1166, 1338-1342): mass that crossed the horizontal internal connections and
+  // the boundary connections during the sub-step, from the fluxes at the accepted state
+  void accumulate_mass_exchange(double dt_sub) {
+    if (lat_mass_exc.empty()) {
+      lat_mass_exc.assign(n, 0.0); bnd_mass_exc.assign(nb, 0.0);
+      conn_horizontal.assign(nc, 0);
+      for (int c = 0; c < nc; ++c) {
+        const double ux = cuv[3 * (size_t)c], uy = cuv[3 * (size_t)c + 1], uz = cuv[3 * (size_t)c + 2];
+        conn_horizontal[c] = !(std::fabs(uz) > 0.5 * std::sqrt(ux * ux + uy * uy + uz * uz));
+      }
+    }
+    if (nb > 0) {
+      launch_bc(4, bc_args(soln.p, F.p), stream);
+      std::vector<double> fl(nb);
+      HIP_CHECK(hipMemcpyAsync(fl.data(), d_bc_flux.p, nb * sizeof(double), hipMemcpyDeviceToHost, stream));
+      HIP_CHECK(hipStreamSynchronize(stream));
+      for (int g = 0; g < nb; ++g) bnd_mass_exc[g] = bnd_mass_exc[g] + fl[bc_pos_of_g[g]] * dt_sub;
+    }
+    bool any_h = false;
+    for (char h : conn_horizontal) any_h |= (h != 0);
+    if (any_h) {
+      DevBuf<double> fl;
+      fl.alloc(nc_int);
+      launch_conn_flux(cells(soln.p), conns(), d_cup.p, d_cdn.p, nc_int, fl.p, stream);
+      std::vector<double> h(nc_int);
+      HIP_CHECK(hipMemcpyAsync(h.data(), fl.p, (size_t)nc_int * sizeof(double), hipMemcpyDeviceToHost, stream));
+      HIP_CHECK(hipStreamSynchronize(stream));
+      for (int c = 0; c < nc; ++c)
+        if (conn_horizontal[c]) {
+          const double f = h[cext2int[c]] * dt_sub;
+          lat_mass_exc[cup_e[c]] = lat_mass_exc[cup_e[c]] + f;
+          lat_mass_exc[cdn_e[c]] = lat_mass_exc[cdn_e[c]] - f;
+        }
+    }
+  }
+  // soe%PreStepDT / PostStepDT of ELM's calling sequence (SystemOfEquationsVSFMType.F90:892-940; GE:2773-2785)
+  void pre_step_dt() {
+    need_setup(true);
+    vec_copy(soln_prev_clm.p, soln_prev.p);
+    vec_copy(soln_prev_clm.p, soln.p);
+    std::fill(lat_mass_exc.begin(), lat_mass_exc.end(), 0.0);
+    std::fill(bnd_mass_exc.begin(), bnd_mass_exc.end(), 0.0);
+    HIP_CHECK(hipStreamSynchronize(stream));
+  }
+  void post_step_dt() {
+    need_setup(true);
+    vec_copy(soln_prev.p, soln_prev_clm.p);
+    HIP_CHECK(hipStreamSynchronize(stream));
+  }
+
   void step_dt(double dt, int *converged, int *converged_reason) {
     ensure_ready();
     const int max_num_time_cuts = 20;
@@ -1427,6 +1483,7 @@ struct Solver {
         time += dt_iter;
         cum_newton += nit; cum_linear += lit;
         vec_copy(soln.p, soln_prev.p);  // VSFMSOEPostSolve (SystemOfEquationsVSFMType.F90:600)
+        if (opt.track_mass_exchange && !th) accumulate_mass_exchange(dt_iter);
       }
       if (num_time_cuts > max_num_time_cuts) { *converged = 0; break; }
       if (time >= target_time) break;
@@ -1526,6 +1583,15 @@ struct Solver {
       HIP_CHECK(hipStreamSynchronize(stream));
       return;
     }
+    if (auxvar_type == MPPGPU_AUXVAR_INTERNAL && var_type == MPPGPU_VAR_FRAC_LIQ_SAT && !th) {
+      // VSFMSOESetDataFromCLM + RichardsODEPressureGetFromSOEAuxVarsIntrn (GE:536-582): active cells only
+      if (cnt > n) throw Error("set_data: size(data_1d) > nauxvar");
+      if (h_frac.empty()) h_frac.assign(n, 1.0);
+      for (int i = 0; i < cnt; ++i) if (active[i]) h_frac[i] = data[i];
+      if (!d_frac.p) d_frac.alloc(n);
+      put_cells(h_frac.data(), d_frac.p);
+      return;
+    }
     if (var_type != MPPGPU_VAR_BC_SS_CONDITION) throw Error("set_data: unknown var_type " + std::to_string(var_type));
     if (auxvar_type == MPPGPU_AUXVAR_BC) {
       if (cond_id < 1 || cond_id > (int)bcs.size()) throw Error("set_data: bad boundary condition id");
@@ -1598,6 +1664,12 @@ struct Solver {
       if (cnt > n) throw Error("get_data: size(data_1d) > nauxvar");
       if (var_type == MPPGPU_VAR_PRESSURE) { get_cells(soln.p, out, cnt); return; }
       if (th && var_type == MPPGPU_VAR_TEMPERATURE) { get_cells(soln.p + n, out, cnt); return; }
+      if (var_type == MPPGPU_VAR_FRAC_LIQ_SAT) { for (int i = 0; i < cnt; ++i) out[i] = h_frac.empty() ? 1.0 : h_frac[i]; return; }
+      if (var_type == MPPGPU_VAR_LATERAL_MASS_EXCHANGED) {
+        if (!opt.track_mass_exchange) throw Error("get_data: set option track_mass_exchange first");
+        for (int i = 0; i < cnt; ++i) out[i] = lat_mass_exc.empty() ? 0.0 : lat_mass_exc[i];
+        return;
+      }
       if (th) throw Error("get_data: the coupled system exports VAR_PRESSURE and VAR_TEMPERATURE");
       if (var_type != MPPGPU_VAR_LIQ_SAT && var_type != MPPGPU_VAR_MASS && var_type != MPPGPU_VAR_SOIL_MATRIX_POT)
         throw Error("get_data: unknown var_type " + std::to_string(var_type));
@@ -1607,6 +1679,13 @@ struct Solver {
       throw Error("get_data: the coupled system exports AUXVAR_INTERNAL only");
     } else if (auxvar_type == MPPGPU_AUXVAR_BC) {
       if (cond_id < 1 || cond_id > (int)bcs.size()) throw Error("get_data: bad boundary condition id");
+      if (var_type == MPPGPU_VAR_BC_MASS_EXCHANGED) {
+        if (!opt.track_mass_exchange) throw Error("get_data: set option track_mass_exchange first");
+        Condition &cm = bcs[cond_id - 1];
+        if (cnt > cm.n) throw Error("get_data: size(data_1d) > nauxvar");
+        for (int i = 0; i < cnt; ++i) out[i] = bnd_mass_exc.empty() ? 0.0 : bnd_mass_exc[cm.offset + i];
+        return;
+      }
       if (var_type != MPPGPU_VAR_MASS_FLUX) throw Error("get_data: unknown var_type");
       Condition &c = bcs[cond_id - 1];
       if (cnt > c.n) throw Error("get_data: size(data_1d) > nauxvar");
@@ -1812,6 +1891,7 @@ struct Solver {
     else if (key == "ilu_graph") opt.ilu_graph = num() != 0;
     else if (key == "fused_trials") opt.fused_trials = (int)num();
     else if (key == "fused_predict") opt.fused_predict = num() != 0;
+    else if (key == "track_mass_exchange") opt.track_mass_exchange = num() != 0;
     else if (key == "temperature") temperature = num();
     else if (key == "problem_type") {
       if (setup_done || !bcs.empty() || !sss.empty()) throw Error("problem_type must be set before conditions are added");
@@ -1926,6 +2006,16 @@ int mppgpu_add_condition(mppgpu_handle h, int kind, int cond_type, int nconn, co
   if (cond_id) *cond_id = id;
   API_END()
 }
+int mppgpu_pre_step_dt(mppgpu_handle h) {
+  API_BEGIN(h)
+  S.pre_step_dt();
+  API_END()
+}
+int mppgpu_post_step_dt(mppgpu_handle h) {
+  API_BEGIN(h)
+  S.post_step_dt();
+  API_END()
+}
 int mppgpu_set_ghost_cells(mppgpu_handle h, int nghost) {
   API_BEGIN(h)
   S.set_ghost_cells(nghost);
@@ -2019,6 +2109,7 @@ int mppgpu_restart(mppgpu_handle h, int n, const double *pressure) {
   if (n != S.nrow) throw mpp::Error("restart: size(data_1d) /= number of unknowns (ncells_local, or 2 ncells_local [P; T] for the coupled system)");
   S.put_state(pressure, S.soln.p);
   S.vec_copy(S.soln.p, S.soln_prev.p);
+  S.vec_copy(S.soln.p, S.soln_prev_clm.p);   // the drivers VecCopy soln into soln_prev_clm after Restart
   HIP_CHECK(hipStreamSynchronize(S.stream));
   API_END()
 }

@@ -140,6 +140,14 @@ class SystemOfEquationsVSFM:
                                          data_1d.ctypes.data_as(ct.POINTER(ct.c_double))))
         return data_1d
 
+    def PreStepDT(self):
+        """VSFMSPreStepDT (SystemOfEquationsVSFMType.F90:892-923)"""
+        self._chk(self.L.mppgpu_pre_step_dt(self.h))
+
+    def PostStepDT(self):
+        """VSFMSPostStepDT (:926-940)"""
+        self._chk(self.L.mppgpu_post_step_dt(self.h))
+
     def SetLateralConnections(self, conn_set):
         """mesh%lateral_conn_set_list: connections handled by the explicit lateral-flux operator split"""
         up, pup = _i(conn_set.id_up); dn, pdn = _i(conn_set.id_dn)

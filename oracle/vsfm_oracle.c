@@ -501,6 +501,8 @@ vo_problem *vo_create(int ncells) {
   p->soln = (double *)calloc(ncells, sizeof(double));
   p->soln_prev = (double *)calloc(ncells, sizeof(double));
   p->accum_prev = (double *)calloc(ncells, sizeof(double));
+  p->soln_prev_clm = (double *)calloc(ncells, sizeof(double));
+  p->lat_mass_exc = (double *)calloc(ncells, sizeof(double));
   /* PETSc 3.16 defaults; stol from MultiPhysicsProbBaseType.F90:1112 */
   p->ksp_type = VO_KSP_GMRES; p->pc_type = VO_PC_ILU0;
   p->ksp_rtol = 1e-5; p->ksp_atol = 1e-50; p->ksp_dtol = 1e4; p->ksp_max_it = 10000; p->gmres_restart = 30;
@@ -567,7 +569,7 @@ int vo_set_source_sink_auxvar(vo_problem *p, int var_type, int n, const double *
 
 static void free_cond(condition *c) {
   free(c->id_dn); free(c->geom); free(c->aux); free(c->value); free(c->flux);
-  free(c->sink_pressure); free(c->sink_exponent);
+  free(c->sink_pressure); free(c->sink_exponent); free(c->mass_exc);
 }
 
 void vo_destroy(vo_problem *p) {
@@ -580,6 +582,7 @@ void vo_destroy(vo_problem *p) {
   free(p->slot_dd); free(p->val); free(p->soln); free(p->soln_prev); free(p->accum_prev);
   free(p->block_ptr); free(p->block_cells);
   free(p->lat_up); free(p->lat_dn); free(p->lat_geom);
+  free(p->horizontal); free(p->lat_mass_exc); free(p->soln_prev_clm);
   free(p);
 }
 
@@ -645,8 +648,9 @@ static int build_pattern(vo_problem *p) {
 
 int vo_set_connections(vo_problem *p, int nconn, const int *id_up, const int *id_dn, const double *dist_up,
                        const double *dist_dn, const double *area, const double *unitvec) {
-  free(p->up); free(p->dn); free(p->geom); free(p->internal_flux);
+  free(p->up); free(p->dn); free(p->geom); free(p->internal_flux); free(p->horizontal);
   p->nc = nconn;
+  p->horizontal = (int *)calloc(nconn + 1, sizeof(int));
   p->up = (int *)malloc((nconn + 1) * sizeof(int));
   p->dn = (int *)malloc((nconn + 1) * sizeof(int));
   p->geom = (conn_geom *)malloc((nconn + 1) * sizeof(conn_geom));
@@ -656,6 +660,10 @@ int vo_set_connections(vo_problem *p, int nconn, const int *id_up, const int *id
     p->up[c] = id_up[c] - 1; p->dn[c] = id_dn[c] - 1;
     p->geom[c].area = area[c]; p->geom[c].dist_up = dist_up[c]; p->geom[c].dist_dn = dist_dn[c];
     for (int k = 0; k < 3; k++) p->geom[c].uvec[k] = unitvec[3 * c + k];
+    /* conn%GetType(): the mesh builders tag a connection CONN_HORIZONTAL / CONN_VERTICAL by its direction
+     * (mpp_mesh_utils.F90:430-466); here from the unit vector */
+    const double *u = p->geom[c].uvec;
+    p->horizontal[c] = !(fabs(u[2]) > 0.5 * sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]));
   }
   return build_pattern(p);
 }
@@ -681,6 +689,7 @@ int vo_add_condition(vo_problem *p, int kind, int cond_type, int nconn, const in
   c->aux = (auxvar *)malloc((nconn + 1) * sizeof(auxvar));
   c->value = (double *)calloc(nconn + 1, sizeof(double));
   c->flux = (double *)calloc(nconn + 1, sizeof(double));
+  c->mass_exc = (double *)calloc(nconn + 1, sizeof(double));
   c->sink_pressure = (double *)calloc(nconn + 1, sizeof(double));
   c->sink_exponent = (double *)calloc(nconn + 1, sizeof(double));
   for (int i = 0; i < nconn; i++) {
@@ -741,10 +750,24 @@ int vo_set_condition_values(vo_problem *p, int kind, int cond_id, int n, const d
   return 0;
 }
 
+int vo_pre_step_dt(vo_problem *p) {
+  memcpy(p->soln_prev, p->soln_prev_clm, p->n * sizeof(double));
+  memcpy(p->soln, p->soln_prev_clm, p->n * sizeof(double));
+  memset(p->lat_mass_exc, 0, p->n * sizeof(double));
+  for (int b = 0; b < p->nbc; b++) memset(p->bc[b].mass_exc, 0, p->bc[b].n * sizeof(double));
+  return 0;
+}
+int vo_post_step_dt(vo_problem *p) { memcpy(p->soln_prev_clm, p->soln_prev, p->n * sizeof(double)); return 0; }
+int vo_set_frac_liq_sat(vo_problem *p, const double *frac) {
+  for (int i = 0; i < p->n; i++) if (p->active[i]) p->aux[i].frac_liq_sat = frac[i];
+  return 0;
+}
+
 /* VSFMMPPRestart, MultiPhysicsProbVSFM.F90:603-707 */
 int vo_restart(vo_problem *p, const double *pressure) {
   memcpy(p->soln, pressure, p->n * sizeof(double));
   memcpy(p->soln_prev, pressure, p->n * sizeof(double));
+  memcpy(p->soln_prev_clm, pressure, p->n * sizeof(double));   /* the drivers VecCopy soln into soln_prev_clm after Restart */
   return 0;
 }
 
@@ -1421,6 +1444,14 @@ int vo_step_dt(vo_problem *p, double dt, int nstep, int *converged, int *converg
       p->time += dt_iter;
       p->cum_newton += nit; p->cum_linear += lit;
       memcpy(p->soln_prev, p->soln, p->n * sizeof(double)); /* VSFMSOEPostSolve :600 */
+      /* SetDataInSOEAuxVar in PostSolve (GE:1150-1166, 1338-1342): exchanged mass from the fluxes of the last residual */
+      for (int c = 0; c < p->nc; c++)
+        if (p->horizontal[c]) {
+          p->lat_mass_exc[p->up[c]] = p->lat_mass_exc[p->up[c]] + p->internal_flux[c] * p->dtime;
+          p->lat_mass_exc[p->dn[c]] = p->lat_mass_exc[p->dn[c]] - p->internal_flux[c] * p->dtime;
+        }
+      for (int b = 0; b < p->nbc; b++)
+        for (int i = 0; i < p->bc[b].n; i++) p->bc[b].mass_exc[i] = p->bc[b].mass_exc[i] + p->bc[b].flux[i] * p->dtime;
     }
     if (num_time_cuts > max_num_time_cuts) { *converged = 0; return 0; }
     if (p->time >= target_time) break;
@@ -1439,6 +1470,8 @@ int vo_get(vo_problem *p, int auxvar_type, int var_type, int cond_id, int n, dou
         case VO_VAR_LIQ_SAT: out[i] = a->sat; break;
         case VO_VAR_MASS: out[i] = a->por * a->den * FMWH2O * a->sat * p->vol[i]; break;
         case VO_VAR_SOIL_MATRIX_POT: out[i] = (a->pressure - PRESSURE_REF) / (a->den * FMWH2O * GRAVITY_CONSTANT); break;
+        case VO_VAR_LATERAL_MASS_EXCHANGED: out[i] = p->lat_mass_exc[i]; break;
+        case VO_VAR_FRAC_LIQ_SAT: out[i] = a->frac_liq_sat; break;
         default: FAIL("unknown var_type %d", var_type);
       }
     }
@@ -1449,6 +1482,7 @@ int vo_get(vo_problem *p, int auxvar_type, int var_type, int cond_id, int n, dou
     if (cond_id < 1 || cond_id > nb) FAIL("bad condition id");
     condition *c = auxvar_type == VO_AUXVAR_BC ? &p->bc[cond_id - 1] : &p->ss[cond_id - 1];
     if (n > c->n) FAIL("size(data_1d) > nauxvar");
+    if (var_type == VO_VAR_BC_MASS_EXCHANGED && auxvar_type == VO_AUXVAR_BC) { for (int i = 0; i < n; i++) out[i] = c->mass_exc[i]; return 0; }
     if (var_type != VO_VAR_MASS_FLUX) FAIL("unknown var_type %d", var_type);
     for (int i = 0; i < n; i++) out[i] = c->flux[i];
     return 0;

@@ -36,6 +36,7 @@ enum {
   VO_COND_MASS_FLUX = 504, VO_COND_DIRICHLET = 505, VO_COND_DIRICHLET_FRM_OTR_GOVEQ = 506,
   VO_COND_SEEPAGE_BC = 509, VO_COND_DOWNREG_MASS_RATE_CAMPBELL = 512, VO_COND_DOWNREG_MASS_RATE_FETCH2 = 513
 };
+enum { VO_VAR_FRAC_LIQ_SAT = 612, VO_VAR_LATERAL_MASS_EXCHANGED = 613, VO_VAR_BC_MASS_EXCHANGED = 614 };
 enum { VO_VAR_POT_MASS_SINK_PRESSURE = 638, VO_VAR_POT_MASS_SINK_EXPONENT = 639 };
 enum { VO_VAR_PRESSURE = 604, VO_VAR_LIQ_SAT = 608, VO_VAR_MASS = 610,
        VO_VAR_SOIL_MATRIX_POT = 611, VO_VAR_MASS_FLUX = 644 };
@@ -95,6 +96,12 @@ int vo_get_condition_values(vo_problem *p, int kind, int cond_id, int n, double 
  * source-sink connections of the equation */
 int vo_set_source_sink_auxvar(vo_problem *p, int var_type, int n, const double *values);
 int vo_restart(vo_problem *p, const double *pressure);
+/* soe%PreStepDT / PostStepDT of ELM's calling sequence (SystemOfEquationsVSFMType.F90:892-940; GE:2773-2785): soln_prev_clm ->
+ * soln_prev, soln and reset of the exchanged-mass accumulators; soln_prev -> soln_prev_clm */
+int vo_pre_step_dt(vo_problem *p);
+int vo_post_step_dt(vo_problem *p);
+/* per-cell frac_liq_sat (SetDataFromCLM(AUXVAR_INTERNAL, VAR_FRAC_LIQ_SAT), copied into the GE auxvars in PreSolve, GE:536-582) */
+int vo_set_frac_liq_sat(vo_problem *p, const double *frac);
 /* column blocks for PC bjacobi: block b holds cells block_cells[block_ptr[b]..block_ptr[b+1]) (1-based ids, bottom->top) */
 int vo_set_blocks(vo_problem *p, int nblocks, const int *block_ptr, const int *block_cells);
 int vo_set_solver(vo_problem *p, int ksp_type, int pc_type, double ksp_rtol, double snes_rtol,

@@ -53,7 +53,7 @@ def lib():
         L.vo_last_error.restype = ct.c_char_p
         for name in ("vo_destroy", "vo_set_mesh", "vo_set_connections", "vo_add_condition", "vo_set_soil_permeability",
                      "vo_set_soil_porosity", "vo_set_saturation_function", "vo_set_density_type",
-                     "vo_set_condition_values", "vo_set_source_sink_auxvar", "vo_set_lateral_connections", "vo_get_condition_values", "vo_restart", "vo_set_blocks", "vo_set_solver", "vo_set_dtime",
+                     "vo_set_condition_values", "vo_set_source_sink_auxvar", "vo_set_lateral_connections", "vo_get_condition_values", "vo_pre_step_dt", "vo_post_step_dt", "vo_set_frac_liq_sat", "vo_restart", "vo_set_blocks", "vo_set_solver", "vo_set_dtime",
                      "vo_pre_solve", "vo_residual", "vo_jacobian_nnz", "vo_jacobian", "vo_pc_setup_apply",
                      "vo_ksp_solve", "vo_step_dt", "vo_get", "vo_get_counters"):
             getattr(L, name).argtypes = None
@@ -186,6 +186,16 @@ class OracleProblem:
         out = np.zeros(n)
         _chk(self.L.vo_get_condition_values(self.h, kind, cond_id, n, out.ctypes.data_as(_dp)))
         return out
+
+    def pre_step_dt(self):
+        _chk(self.L.vo_pre_step_dt(self.h))
+
+    def post_step_dt(self):
+        _chk(self.L.vo_post_step_dt(self.h))
+
+    def set_frac_liq_sat(self, frac):
+        v, pv = _d(np.broadcast_to(frac, (self.n,)))
+        _chk(self.L.vo_set_frac_liq_sat(self.h, pv))
 
     def set_source_sink_auxvar(self, var_type, values):
         v, pv = _d(values)

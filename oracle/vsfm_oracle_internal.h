@@ -43,6 +43,7 @@ typedef struct {
   double *value;   /* SS condition values (cur_cond%value) */
   double *sink_pressure, *sink_exponent; /* aux_vars_ss%pot_mass_sink_pressure / _exponent (down-regulated sinks) */
   double *flux;    /* boundary_flux / ss_flux [kg/s] */
+  double *mass_exc; /* bnd_mass_exc [kg] (GoveqnRichardsODEPressureType.F90:34, 1338) */
 } condition;
 
 struct vo_problem {
@@ -55,6 +56,9 @@ struct vo_problem {
   int *up, *dn;         /* 0-based */
   conn_geom *geom;
   double *internal_flux;
+  int *horizontal;      /* conn%GetType() == CONN_HORIZONTAL */
+  double *lat_mass_exc; /* [kg] (GE:33, 1159-1163) */
+  double *soln_prev_clm;
   int nlat;             /* mesh%lateral_conn_set_list (operator split, GE:2615-2743) */
   int *lat_up, *lat_dn;
   conn_geom *lat_geom;

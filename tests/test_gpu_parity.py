@@ -315,3 +315,51 @@ def test_lateral_flux_operator_split():
     p_o = o.get(C.AUXVAR_INTERNAL, C.VAR_PRESSURE)
     p_g = g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE)
     assert np.abs(p_g - p_o).max() <= 1e-8 * np.abs(p_o).max()
+
+
+def test_elm_surface_frac_liq_sat_and_exchanged_mass(golden_dir):
+    """ELM coupling variables: per-cell VAR_FRAC_LIQ_SAT (Brooks-Corey relative permeability is scaled by it), the
+    PreStepDT / PostStepDT state hand-over, and the exchanged-mass accumulators VAR_BC_MASS_EXCHANGED /
+    VAR_LATERAL_MASS_EXCHANGED -- against the oracle"""
+    # (1) frac_liq_sat on a Brooks-Corey soil: operators
+    prob, x = _hetero(ncols=9, nz=15, seed=5)
+    n = x.size
+    prob.satfunc_type = np.full(n, C.SAT_FUNC_BROOKS_COREY, dtype=np.int32)
+    frac = np.random.default_rng(2).uniform(0.4, 1.0, n)
+    for assembly in ("columns", "general"):
+        o = P.to_oracle(prob)
+        g = P.to_gpu(prob, {"assembly": assembly})
+        o.set_frac_liq_sat(frac)
+        g.soe.SetDataFromCLM(C.AUXVAR_INTERNAL, C.VAR_FRAC_LIQ_SAT, -1, frac)
+        o.set_dtime(prob.dt); o.pre_solve(); g.soe.SetDtime(prob.dt); g.soe.PreSolve()
+        f_o, f_g = o.residual(x), g.soe.ComputeResidual(x)
+        rp, cj, val = o.jacobian(x)
+        _, _, val_g = g.soe.ComputeJacobian(x)
+        assert np.abs(val_g - val).max() <= RTOL_OP * np.abs(val).max()
+        assert np.abs(f_g - f_o).max() <= 1e-11 * (np.abs(f_o).max() + np.abs(val).max())
+        assert np.array_equal(g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_FRAC_LIQ_SAT), frac)
+        o2 = P.to_oracle(prob); o2.set_dtime(prob.dt); o2.pre_solve()
+        assert np.abs(o2.residual(x) - f_o).max() > 1e-6 * np.abs(f_o).max()     # the scaling is not a no-op
+    # (2) boundary mass exchanged on the celia column over 3 steps with PreStepDT / PostStepDT around every step
+    prob = P.celia1990(ncols=5, nz=40, perm_mult=[1.0, 0.8, 1.3, 0.6, 1.1])
+    o = P.to_oracle(prob)
+    g = P.to_gpu(prob, {"ksp_type": "bcgs", "pc_type": "bjacobi", "track_mass_exchange": 1})
+    for s in range(3):
+        o.pre_step_dt(); g.soe.PreStepDT()
+        assert o.step_dt(prob.dt, s + 1)[0] and g.soe.StepDT(prob.dt, s + 1)[0]
+        o.post_step_dt(); g.soe.PostStepDT()
+        for b in (1, 2):
+            m_o = o.get(C.AUXVAR_BC, C.VAR_BC_MASS_EXCHANGED, b, 5)
+            m_g = g.soe.GetDataForCLM(C.AUXVAR_BC, C.VAR_BC_MASS_EXCHANGED, b)
+            assert np.abs(m_g - m_o).max() <= 1e-8 * np.abs(m_o).max() + 1e-12
+            # one sub-step per step here: the accumulator holds flux * dt of this step only (reset by PreStepDT)
+            assert np.abs(m_g - g.soe.GetDataForCLM(C.AUXVAR_BC, C.VAR_MASS_FLUX, b) * prob.dt).max() <= 1e-10 * np.abs(m_g).max() + 1e-12
+    # (3) lateral mass exchanged on the 7-point grid: conservative, equal to the oracle's
+    prob = P.vchannel(6, 5, 7)
+    o = P.to_oracle(prob, with_blocks=False)
+    g = P.to_gpu(prob, {"ksp_type": "gmres", "pc_type": "ilu", "track_mass_exchange": 1})
+    assert o.step_dt(prob.dt, 1)[0] and g.soe.StepDT(prob.dt, 1)[0]
+    l_o = o.get(C.AUXVAR_INTERNAL, C.VAR_LATERAL_MASS_EXCHANGED)
+    l_g = g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_LATERAL_MASS_EXCHANGED)
+    assert np.abs(l_g).max() > 0 and abs(l_g.sum()) <= 1e-10 * np.abs(l_g).sum()
+    assert np.abs(l_g - l_o).max() <= 1e-7 * np.abs(l_o).max()
