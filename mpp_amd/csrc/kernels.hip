@@ -1112,6 +1112,44 @@ __global__ __launch_bounds__(kBlock) void k_bcgs_xr(int n, double *X, double *R,
   if (threadIdx.x == 0) partials[blockIdx.x] = t;
 }
 
+// block-Jacobi apply with the Krylov dot products of its result fused in (the solve holds z_k in a register when it
+// writes it): ND = 1 leaves the partial sums of z.z, ND = 2 those of z.w and z.z (in that order), layout partials[j*nb + b]
+template <int ND>
+__global__ __launch_bounds__(kBlock) void k_tri_solve_dots(TriArgs a, const double *__restrict__ r, double *__restrict__ z,
+                                                           const double *__restrict__ w, double *__restrict__ partials) {
+  __shared__ double lds[kBlock / 64];
+  const int c = blockIdx.x * kBlock + threadIdx.x;
+  double acc0 = 0.0, acc1 = 0.0;
+  if (c < a.ncols) {
+    const int tile = c >> 6, tw = min(64, a.ncols - (tile << 6));
+    const size_t cbase = (size_t)tile * 64 * a.nz + (c & 63);
+    double prev = 0.0;
+#pragma unroll 4
+    for (int k = 0; k < a.nz; ++k) {
+      const size_t i = cbase + (size_t)k * tw;
+      const double d = ldnt(r + i) - ldnt(a.l + i) * prev;
+      z[i] = d;
+      prev = d;
+    }
+    double next = 0.0;
+#pragma unroll 4
+    for (int k = a.nz - 1; k >= 0; --k) {
+      const size_t i = cbase + (size_t)k * tw;
+      const double xk = (z[i] - ldnt(a.c + i) * next) * ldnt(a.invb + i);
+      z[i] = xk;
+      next = xk;
+      if (ND == 2) { acc0 += xk * w[i]; acc1 += xk * xk; } else acc0 += xk * xk;
+    }
+  }
+  const double t0 = block_sum(acc0, lds);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t0;
+  if (ND == 2) {
+    __syncthreads();
+    const double t1 = block_sum(acc1, lds);
+    if (threadIdx.x == 0) partials[(size_t)gridDim.x + blockIdx.x] = t1;
+  }
+}
+
 // dot-product patterns the solvers use; every distinct vector is streamed once
 //  PAT 0: a.a            PAT 1: a.b            PAT 2: a.b, b.b          PAT 3: a.a, b.b, c.d         PAT 4: a.a, b.b
 template <int PAT>
@@ -1356,6 +1394,12 @@ void launch_tri_factor(const TriArgs &a, hipStream_t stream) {
 }
 void launch_tri_solve(const TriArgs &a, const double *r, double *z, hipStream_t stream) {
   if (a.ncols > 0) LAUNCH(k_tri_solve, dim3(nblk(a.ncols)), a, r, z);
+}
+int launch_tri_solve_dots(const TriArgs &a, const double *r, double *z, const double *w, double *partials, hipStream_t stream) {
+  const dim3 grid(nblk(a.ncols));
+  if (w) LAUNCH(k_tri_solve_dots<2>, grid, a, r, z, w, partials);
+  else LAUNCH(k_tri_solve_dots<1>, grid, a, r, z, w, partials);
+  return (int)grid.x;
 }
 void launch_jacobi_setup(int n, const int *diag_slot, const double *val, double *invd, hipStream_t stream) {
   if (n > 0) LAUNCH(k_jacobi_setup, dim3(nblk(n)), n, diag_slot, val, invd);

@@ -120,6 +120,9 @@ struct TriArgs {
 };
 void launch_tri_factor(const TriArgs &a, hipStream_t stream);
 void launch_tri_solve(const TriArgs &a, const double *r, double *z, hipStream_t stream);
+// the same solve with fused dot products of the result: z.z (w == nullptr) or z.w and z.z; returns the number of partial
+// blocks (<= kMaxPartialBlocks is the caller's responsibility); finish with launch_finalize_partials
+int launch_tri_solve_dots(const TriArgs &a, const double *r, double *z, const double *w, double *partials, hipStream_t stream);
 void launch_jacobi_setup(int n, const int *diag_slot, const double *val, double *invd, hipStream_t stream);
 
 // ---- ILU(0), level-scheduled (PETSc's default PC for SeqAIJ; elimination order = the caller's natural ordering) ----

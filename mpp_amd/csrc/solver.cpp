@@ -996,6 +996,24 @@ struct Solver {
     op_spmv(v, Wk.p);
     op_pc_apply(Wk.p, t);
   }
+  // z = M^{-1} r together with the dot products (z.z) or (z.w, z.z) of the result, left in sc[S_SUM0..]: one pass less
+  // over z (and w) when the preconditioner is the column solver; otherwise the apply followed by the reduction kernels
+  bool fused_pc_dots() const {
+    return opt.pc_type == 2 && !th && nghost == 0 && (ncols + 255) / 256 <= kMaxPartialBlocks;
+  }
+  void op_pc_apply_dots(const double *r, double *z, const double *w) {
+    if (!fused_pc_dots()) {
+      op_pc_apply(r, z);
+      if (w) dots_dev({{w, z}, {z, z}}); else dots_dev({{z, z}});
+      return;
+    }
+    {
+      ProfScope ps(prof, KC_PC_APPLY);
+      const int nbk = launch_tri_solve_dots(tri_args(), r, z, w, partials.p, stream);
+      launch_finalize_partials(nbk, w ? 2 : 1, partials.p, sc.p, stream);
+    }
+    if (comm.active()) comm.allreduce_sum(sc.p + S_SUM0, w ? 2 : 1, stream);
+  }
 
   // ---- reductions: deterministic two-stage sums, RCCL all-reduce across ranks, results on device and host ----
   void dots_dev(std::initializer_list<std::pair<const double *, const double *>> pairs) {
@@ -1115,8 +1133,9 @@ struct Solver {
     // r0 = rp = M^{-1} b, p0 = r0 (beta*p and omega*beta*v vanish) and rho0 = (r0,r0) is the squared norm
     // already reduced for the convergence test, so r0 is written once into RP and aliased as R and P.
     KspConv cv{opt.ksp_rtol, opt.ksp_atol, opt.ksp_dtol};
-    op_pc_apply(b, RP.p);
-    double dp = norm_host(RP.p);  // leaves (rp,rp) in sc[S_SUM0]
+    op_pc_apply_dots(b, RP.p, nullptr);   // leaves (rp,rp) in sc[S_SUM0]
+    fetch_scalars();
+    double dp = std::sqrt(h_sc[S_SUM0]);
     *its = 0;
     int reason = ksp_converged(cv, 0, dp);
     if (reason) { vec_set(0.0, x); return reason; }
@@ -1131,12 +1150,12 @@ struct Solver {
         launch_bcgs_p(nred, Pv.p, Pcur, Rcur, V.p, sc.p, stream);
         Pcur = Pv.p;
       }
-      op_BA(Pcur, V.p);
-      dots_dev({{V.p, RP.p}});
+      op_spmv(Pcur, Wk.p);
+      op_pc_apply_dots(Wk.p, V.p, RP.p);   // (v,rp) in sc[S_SUM0]  [(v,v) in S_SUM0+1 is not used]
       launch_bcgs_scalars(2, sc.p, stream);
       { ProfScope ps(prof, KC_VEC); launch_waxpy(nred, S.p, sc.p, S_ALPHA, -1.0, 0.0, V.p, Rcur, stream); }
-      op_BA(S.p, T.p);
-      dots_dev({{S.p, T.p}, {T.p, T.p}});
+      op_spmv(S.p, Wk.p);
+      op_pc_apply_dots(Wk.p, T.p, S.p);    // (t,s), (t,t) in sc[S_SUM0], sc[S_SUM0+1]
       launch_bcgs_scalars(3, sc.p, stream);
       {
         ProfScope ps(prof, KC_REDUCE);
