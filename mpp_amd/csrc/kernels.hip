@@ -28,6 +28,26 @@ __device__ __forceinline__ T ldnt(const T *p) { return __builtin_nontemporal_loa
 template <class T>
 __device__ __forceinline__ void stnt(T v, T *p) { __builtin_nontemporal_store(v, p); }
 
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+// block-wide sum in a fixed order (lanes -> wave leaders -> thread 0); valid result in thread 0
+__device__ __forceinline__ double block_sum(double v, double *lds) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) lds[w] = v;
+  __syncthreads();
+  double t = 0.0;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < kBlock / 64; ++k) t += lds[k];
+  }
+  return t;
+}
+
 template <int SAT_T = -1, bool NT = false>
 __device__ __forceinline__ Soil load_soil(const CellArrays &ca, size_t i) {
   Soil s;
@@ -75,88 +95,109 @@ __global__ __launch_bounds__(kBlock) void k_accum(CellArrays ca, int n, double d
 // previous level's auxvars in registers, so every auxvar and every flux is evaluated once (plus one halo level
 // per segment end when nseg > 1).  Sum order per row equals the reference's serial connection loop.
 // ------------------------------------------------------------------------------------------------
-template <int MODE, int SAT_T, int DEN_T>  // MODE 0 residual, 1 Jacobian, 2 both; SAT_T / DEN_T: see physics.hpp
+// FUSE (nseg == 1, boundary conditions only on the end cells of a column, their fluxes evaluated beforehand by k_bc
+// into side arrays): every row is complete when the march leaves it, so the kernel also leaves the partial sums of
+// F.F and P.P (the line search's ||F||, ||X||) and, when a.tl is set, the column's LU factors (k_tri_factor's arithmetic).
+template <int MODE, int SAT_T, int DEN_T, bool FUSE>  // MODE 0 residual, 1 Jacobian, 2 both; SAT_T / DEN_T: see physics.hpp
 __global__ __launch_bounds__(kBlock) void k_assemble_cols(ColsArgs a) {
+  __shared__ double red[kBlock / 64];
   const int *__restrict__ rowptr = a.rowptr;
   constexpr bool RES = (MODE == 0 || MODE == 2), JAC = (MODE == 1 || MODE == 2);
   const int c = blockIdx.x * kBlock + threadIdx.x;
-  if (c >= a.ncols) return;
-  const int nz = a.nz;
-  const int tile = c >> 6;
-  const int tw = min(64, a.ncols - (tile << 6));          // width of this column tile
-  const size_t cbase = (size_t)tile * 64 * nz + (c & 63);  // cell (k,c) = cbase + k*tw
-  const int seg = blockIdx.y;
-  const int k0 = (int)((long long)nz * seg / a.nseg);
-  const int k1 = (int)((long long)nz * (seg + 1) / a.nseg);
-  if (k0 >= k1) return;
-  const int kstart = k0 > 0 ? k0 - 1 : 0;
-  const int kend = k1 < nz ? k1 + 1 : nz;
-  const CellArrays &ca = a.cell;
+  const bool valid = c < a.ncols;
+  if (!FUSE && !valid) return;
+  double accF = 0.0, accP = 0.0;
+  if (valid) {
+    const int nz = a.nz;
+    const int tile = c >> 6;
+    const int tw = min(64, a.ncols - (tile << 6));          // width of this column tile
+    const size_t cbase = (size_t)tile * 64 * nz + (c & 63);  // cell (k,c) = cbase + k*tw
+    const int seg = FUSE ? 0 : blockIdx.y;
+    const int nseg = FUSE ? 1 : a.nseg;
+    const int k0 = (int)((long long)nz * seg / nseg);
+    const int k1 = (int)((long long)nz * (seg + 1) / nseg);
+    if (!FUSE && k0 >= k1) return;
+    const int kstart = k0 > 0 ? k0 - 1 : 0;
+    const int kend = k1 < nz ? k1 + 1 : nz;
+    const CellArrays &ca = a.cell;
+    const bool factor = FUSE && JAC && a.tl != nullptr;
+    const int jb = FUSE ? a.col_bc[c] : -1, jt = FUSE ? a.col_bc[a.ncols + c] : -1;  // side entries of rows 0 / nz-1
+    double inv_pp = 0.0, c_pp = 0.0;   // 1/pivot and super-diagonal of the row before the one being completed
 
-  Aux prev = {};
-  bool prev_act = false;
-  double f_prev = 0.0, dconn_prev = 0.0, dacc_prev = 0.0, lo_prev = 0.0, up_prev = 0.0;
+    Aux prev = {};
+    bool prev_act = false;
+    double f_prev = 0.0, dconn_prev = 0.0, dacc_prev = 0.0, lo_prev = 0.0, up_prev = 0.0;
 
-  for (int k = kstart; k < kend; ++k) {
-    const size_t i = cbase + (size_t)k * tw;
-    const bool act = is_active(ca, i);
-    const bool owned = (k >= k0 && k < k1);
-    Aux cur = {};
-    double f_cur = 0.0, dacc_cur = 1.0;  // inactive cell: diagonal 1 (GE:1682-1684)
-    const double Pi = ldnt(ca.P + i);
-    cur.P = Pi;
-    if (act) {
-      Soil s = load_soil<SAT_T, true>(ca, i);
-      cur = auxvar_compute<JAC, SAT_T, DEN_T>(ca.sat_func, ca.eos, s, Pi, frac_of(ca, i));
-      if (owned) {
-        const double vol = ldnt(ca.vol + i);
-        if (RES) f_cur = s.por * cur.den * cur.sat * vol * a.dtInv;
-        if (JAC) dacc_cur = (s.por * cur.dden * cur.sat + s.por * cur.den * cur.dsat) * vol * a.dtInv;
+    // row ip = (kp, c) is complete: boundary contribution, store, reductions, elimination step
+    auto finish_row = [&](int kp, size_t ip, bool last) {
+      const int js = (kp == 0) ? jb : (last ? jt : -1);
+      if (RES) {
+        double f = f_prev;
+        if (a.src) f -= ldnt(a.src + ip);
+        if (FUSE && js >= 0) f += a.side_f[js];
+        stnt(f, a.F + ip);
+        if (FUSE) accF += f * f;
       }
-    }
-    if (RES && owned) f_cur = f_cur - ldnt(a.accum_prev + i);
-    double dconn_cur = 0.0, lo_cur = 0.0;
-    if (k > kstart) {
-      if (prev_act && act) {
-        const size_t ic = i - tw;
-        ConnGeom g;
-        g.Dq = ldnt(a.conn.Dq + ic); g.upweight = ldnt(a.conn.upw + ic); g.dist_gravity = ldnt(a.conn.dgrav + ic); g.area = ldnt(a.conn.area + ic);
-        double Jup = 0.0, Jdn = 0.0;
-        const double flux = richards_flux<JAC>(prev, cur, g, 0, Jup, Jdn);
-        if (RES) { f_prev -= flux; f_cur += flux; }
-        if (JAC) { dconn_prev += Jup; up_prev = Jdn; lo_cur = -Jup; dconn_cur += -Jdn; }
-      }
-      const int kp = k - 1;
-      if (kp >= k0) {  // row kp is owned and now complete
-        const size_t ip = i - tw;
-        if (RES) {
-          double f = f_prev;
-          if (a.src) f -= ldnt(a.src + ip);
-          stnt(f, a.F + ip);
-        }
-        if (JAC) {
-          int slot = ldnt(rowptr + ip);
-          if (kp > 0) a.val[slot++] = lo_prev;
-          a.val[slot++] = dconn_prev + dacc_prev;
-          a.val[slot] = up_prev;  // kp < nz-1 always holds here
+      if (JAC) {
+        double di = dconn_prev + dacc_prev;
+        if (FUSE && js >= 0) di += a.side_d[js];
+        int slot = ldnt(rowptr + ip);
+        if (kp > 0) a.val[slot++] = lo_prev;
+        a.val[slot++] = di;
+        if (!last) a.val[slot] = up_prev;
+        if (factor) {
+          const double l = lo_prev * inv_pp;
+          const double piv = di - l * c_pp;
+          const double inv = 1.0 / piv;
+          stnt(l, a.tl + ip); stnt(inv, a.tinvb + ip); stnt(up_prev, a.tc + ip);
+          inv_pp = inv; c_pp = up_prev;
         }
       }
+    };
+
+    for (int k = kstart; k < kend; ++k) {
+      const size_t i = cbase + (size_t)k * tw;
+      const bool act = is_active(ca, i);
+      const bool owned = (k >= k0 && k < k1);
+      Aux cur = {};
+      double f_cur = 0.0, dacc_cur = 1.0;  // inactive cell: diagonal 1 (GE:1682-1684)
+      const double Pi = ldnt(ca.P + i);
+      cur.P = Pi;
+      if (FUSE && RES) accP += Pi * Pi;
+      if (act) {
+        Soil s = load_soil<SAT_T, true>(ca, i);
+        cur = auxvar_compute<JAC, SAT_T, DEN_T>(ca.sat_func, ca.eos, s, Pi, frac_of(ca, i));
+        if (owned) {
+          const double vol = ldnt(ca.vol + i);
+          if (RES) f_cur = s.por * cur.den * cur.sat * vol * a.dtInv;
+          if (JAC) dacc_cur = (s.por * cur.dden * cur.sat + s.por * cur.den * cur.dsat) * vol * a.dtInv;
+        }
+      }
+      if (RES && owned) f_cur = f_cur - ldnt(a.accum_prev + i);
+      double dconn_cur = 0.0, lo_cur = 0.0;
+      if (k > kstart) {
+        if (prev_act && act) {
+          const size_t ic = i - tw;
+          ConnGeom g;
+          g.Dq = ldnt(a.conn.Dq + ic); g.upweight = ldnt(a.conn.upw + ic); g.dist_gravity = ldnt(a.conn.dgrav + ic); g.area = ldnt(a.conn.area + ic);
+          double Jup = 0.0, Jdn = 0.0;
+          const double flux = richards_flux<JAC>(prev, cur, g, 0, Jup, Jdn);
+          if (RES) { f_prev -= flux; f_cur += flux; }
+          if (JAC) { dconn_prev += Jup; up_prev = Jdn; lo_cur = -Jup; dconn_cur += -Jdn; }
+        }
+        const int kp = k - 1;
+        if (kp >= k0) finish_row(kp, i - tw, false);  // row kp is owned and now complete (kp < nz-1 holds here)
+      }
+      prev = cur; prev_act = act;
+      f_prev = f_cur; dconn_prev = dconn_cur; dacc_prev = dacc_cur; lo_prev = lo_cur; up_prev = 0.0;
     }
-    prev = cur; prev_act = act;
-    f_prev = f_cur; dconn_prev = dconn_cur; dacc_prev = dacc_cur; lo_prev = lo_cur; up_prev = 0.0;
+    if (kend == nz && k1 == nz) finish_row(nz - 1, cbase + (size_t)(nz - 1) * tw, true);  // top row of the column
   }
-  if (kend == nz && k1 == nz) {  // top row of the column
-    const size_t ip = cbase + (size_t)(nz - 1) * tw;
-    if (RES) {
-      double f = f_prev;
-      if (a.src) f -= a.src[ip];
-      a.F[ip] = f;
-    }
-    if (JAC) {
-      int slot = rowptr[ip];
-      if (nz > 1) a.val[slot++] = lo_prev;
-      a.val[slot] = dconn_prev + dacc_prev;
-    }
+  if (FUSE && RES) {
+    double t = block_sum(accF, red);
+    if (threadIdx.x == 0) a.partials[blockIdx.x] = t;
+    t = block_sum(accP, red);
+    if (threadIdx.x == 0) a.partials[(size_t)gridDim.x + blockIdx.x] = t;
   }
 }
 
@@ -251,10 +292,14 @@ __global__ __launch_bounds__(kBlock) void k_bc(BcArgs a) {
   if (j >= a.ncond_cells) return;
   const CellArrays &ca = a.cell;
   const size_t cell = a.cc_cell[j];
-  if (!owns_row(ca, cell)) return;
+  if (!owns_row(ca, cell)) {   // inactive (or ghost) cell: no boundary flux
+    if (a.side_f) { if (RES) a.side_f[j] = 0.0; if (JAC) a.side_d[j] = 0.0; }
+    return;
+  }
   Soil s = load_soil(ca, cell);
   const Aux in = auxvar_compute<JAC>(ca.sat_func, ca.eos, s, ca.P[cell], frac_of(ca, cell));
-  double f = RES ? a.F[cell] : 0.0;
+  const bool side = a.side_f != nullptr;   // fluxes into per-condition-cell side arrays (complete-row column march)
+  double f = (RES && !side) ? a.F[cell] : 0.0;
   double d = 0.0;
   for (int e = a.cc_ptr[j]; e < a.cc_ptr[j + 1]; ++e) {
     const int t = a.type[e];
@@ -274,6 +319,11 @@ __global__ __launch_bounds__(kBlock) void k_bc(BcArgs a) {
     if (RES) f += flux;
     if (JAC) d += -jdn_outer;
     if (OUT) a.flux_out[e] = flux * kFMWH2O;
+  }
+  if (side) {
+    if (RES) a.side_f[j] = f;
+    if (JAC) a.side_d[j] = d;
+    return;
   }
   if (RES) a.F[cell] = f;
   if (JAC) a.val[a.diag_slot[cell]] += d;
@@ -666,6 +716,93 @@ __global__ __launch_bounds__(kBlock) void k_spmv_pipe_c(int n, int tpw, const in
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// the same product with the line search's reductions fused in and y never written: leaves the partial sums of x.x, f.(A x)
+// and (xx != nullptr) xx.xx, layout partials[j*gridDim.x + b] -- SNESLineSearchApply_BT needs only ||Y||, F.(J Y) and ||X||
+template <int J>
+__global__ __launch_bounds__(kBlock) void k_spmv_pipe_c_dots(int n, int tpw, const int *__restrict__ tileptr,
+                                                             const unsigned short *__restrict__ roff,
+                                                             const short *__restrict__ dcol, const double *__restrict__ val,
+                                                             const double *__restrict__ x, const double *__restrict__ f,
+                                                             const double *__restrict__ xx, double *__restrict__ partials) {
+  __shared__ double prod[kBlock / 64][64 * J];
+  __shared__ double red[kBlock / 64];
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  double *lp = prod[w];
+  const int ntiles = (n + 63) >> 6;
+  const int tile0 = (blockIdx.x * (kBlock / 64) + w) * tpw;
+  const bool live = tile0 < ntiles;             // wave-uniform; idle waves still take part in the block sums
+  const int tend = live ? min(tile0 + tpw, ntiles) : tile0;
+  int sA = 0, sB = 0;
+  double vn[J], fn = 0.0, xn = 0.0, qn = 0.0;
+  int cn[J], rsn = 0;
+  auto prefetch = [&](int tile, int s0, int cnt) {
+    const int r = (tile << 6) + lane;
+    const bool row = r < n;
+    rsn = row ? (int)__builtin_nontemporal_load(roff + r) : cnt;
+    fn = row ? __builtin_nontemporal_load(f + r) : 0.0;
+    xn = row ? x[r] : 0.0;
+    qn = (row && xx) ? __builtin_nontemporal_load(xx + r) : 0.0;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int k = lane + 64 * j;
+      const bool ok = k < cnt;
+      vn[j] = ok ? __builtin_nontemporal_load(val + s0 + k) : 0.0;
+      cn[j] = ok ? (int)__builtin_nontemporal_load(dcol + s0 + k) : 0;
+    }
+  };
+  if (live) {
+    sA = tileptr[tile0]; sB = tileptr[tile0 + 1];
+    prefetch(tile0, sA, sB - sA);
+  }
+  double acc_xx = 0.0, acc_fw = 0.0, acc_qq = 0.0;
+  for (int tile = tile0; tile < tend; ++tile) {
+    const int cnt = sB - sA;
+    const int base = tile << 6;
+    double vc[J];
+    int cc[J];
+    const int rs = rsn;
+    const double fc = fn, xc = xn, qc = qn;
+#pragma unroll
+    for (int j = 0; j < J; ++j) { vc[j] = vn[j]; cc[j] = cn[j]; }
+    double xs[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) xs[j] = (lane + 64 * j < cnt) ? x[base + cc[j]] : 0.0;
+    __builtin_amdgcn_sched_barrier(0);
+    if (tile + 1 < tend) {
+      sA = sB;
+      sB = tileptr[tile + 2];
+      prefetch(tile + 1, sA, sB - sA);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int nxt = __shfl_down(rs, 1, 64);
+    const int re = (lane == 63) ? cnt : nxt;
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+      if (lane + 64 * j < cnt) lp[lane + 64 * j] = vc[j] * xs[j];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (base + lane < n) {
+      double sum = 0.0;
+      for (int k = rs; k < re; ++k) sum += lp[k];
+      acc_fw += fc * sum;
+      acc_xx += xc * xc;
+      acc_qq += qc * qc;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  double t = block_sum(acc_xx, red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+  t = block_sum(acc_fw, red);
+  if (threadIdx.x == 0) partials[(size_t)gridDim.x + blockIdx.x] = t;
+  if (xx) {
+    t = block_sum(acc_qq, red);
+    if (threadIdx.x == 0) partials[(size_t)2 * gridDim.x + blockIdx.x] = t;
   }
 }
 
@@ -1062,26 +1199,6 @@ __global__ __launch_bounds__(kBlock) void k_bcgs_p(int n, double *P, const doubl
             }, [&](size_t i) { P[i] = 1.0 * R[i] + ob * V[i] + beta * Pold[i]; });
 }
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;
-}
-// block-wide sum in a fixed order (lanes -> wave leaders -> thread 0); valid result in thread 0
-__device__ __forceinline__ double block_sum(double v, double *lds) {
-  v = wave_sum(v);
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  __syncthreads();
-  if (lane == 0) lds[w] = v;
-  __syncthreads();
-  double t = 0.0;
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int k = 0; k < kBlock / 64; ++k) t += lds[k];
-  }
-  return t;
-}
-
 inline int red_grid(int n) {
   long long b = ((long long)n / 2 + kRedPairs - 1) / kRedPairs;
   return (int)(b < 1 ? 1 : (b > kMaxPartialBlocks ? kMaxPartialBlocks : b));
@@ -1285,13 +1402,19 @@ void launch_accum(const CellArrays &cell, int n, double dtInv, double *out, hipS
 
 template <int SAT_T, int DEN_T>
 static void launch_cols_mode(int mode, const ColsArgs &a, dim3 grid, hipStream_t stream) {
-  if (mode == 0) LAUNCH((k_assemble_cols<0, SAT_T, DEN_T>), grid, a);
-  else if (mode == 1) LAUNCH((k_assemble_cols<1, SAT_T, DEN_T>), grid, a);
-  else LAUNCH((k_assemble_cols<2, SAT_T, DEN_T>), grid, a);
+  if (a.col_bc) {   // complete-row variant (grid.y == 1)
+    if (mode == 0) LAUNCH((k_assemble_cols<0, SAT_T, DEN_T, true>), grid, a);
+    else if (mode == 1) LAUNCH((k_assemble_cols<1, SAT_T, DEN_T, true>), grid, a);
+    else LAUNCH((k_assemble_cols<2, SAT_T, DEN_T, true>), grid, a);
+    return;
+  }
+  if (mode == 0) LAUNCH((k_assemble_cols<0, SAT_T, DEN_T, false>), grid, a);
+  else if (mode == 1) LAUNCH((k_assemble_cols<1, SAT_T, DEN_T, false>), grid, a);
+  else LAUNCH((k_assemble_cols<2, SAT_T, DEN_T, false>), grid, a);
 }
 void launch_assemble_cols(int mode, const ColsArgs &a, hipStream_t stream) {
   if (a.ncols <= 0) return;
-  dim3 grid(nblk(a.ncols), a.nseg);
+  dim3 grid(nblk(a.ncols), a.col_bc ? 1 : a.nseg);
   const bool ifc = a.cell.eos.density_type == kDenIFC67;
   switch (a.cell.sat_func) {
     case kSatVG:
@@ -1345,6 +1468,21 @@ void launch_spmv_compact(int tpw, int n, int max_row_nnz, const int *tileptr, co
   if (max_row_nnz <= 3) LAUNCH(k_spmv_pipe_c<3>, grid, n, tpw, tileptr, roff, dcol, val, x, y);
   else if (max_row_nnz <= 7) LAUNCH(k_spmv_pipe_c<7>, grid, n, tpw, tileptr, roff, dcol, val, x, y);
   else LAUNCH(k_spmv_pipe_c<8>, grid, n, tpw, tileptr, roff, dcol, val, x, y);
+}
+
+int spmv_compact_dots_blocks(int tpw, int n) {
+  const long long tiles = ((long long)n + 63) / 64, waves = (tiles + tpw - 1) / tpw;
+  return (int)((waves + 3) / 4);
+}
+int launch_spmv_compact_dots(int tpw, int n, int max_row_nnz, const int *tileptr, const unsigned short *roff, const short *dcol,
+                             const double *val, const double *x, const double *f, const double *xx, double *partials,
+                             hipStream_t stream) {
+  if (n <= 0) return 0;
+  const dim3 grid(spmv_compact_dots_blocks(tpw, n));
+  if (max_row_nnz <= 3) LAUNCH(k_spmv_pipe_c_dots<3>, grid, n, tpw, tileptr, roff, dcol, val, x, f, xx, partials);
+  else if (max_row_nnz <= 7) LAUNCH(k_spmv_pipe_c_dots<7>, grid, n, tpw, tileptr, roff, dcol, val, x, f, xx, partials);
+  else LAUNCH(k_spmv_pipe_c_dots<8>, grid, n, tpw, tileptr, roff, dcol, val, x, f, xx, partials);
+  return (int)grid.x;
 }
 
 void launch_spmv(int variant, int n, int max_row_nnz, const int *rowptr, const int *col, const double *val,

@@ -46,6 +46,13 @@ struct ColsArgs {
   const int *rowptr;     // CSR row pointers (level-major rows)
   int ncols, nz, nseg;
   double dtInv;
+  // complete-row variant (col_bc != nullptr; nseg is taken as 1): side-array entry of the boundary cell at level 0 /
+  // level nz-1 of every column (col_bc[c], col_bc[ncols + c]; -1 none), the boundary flux and diagonal contributions
+  // k_bc left there, the column LU factors to write (tl may be nullptr) and the partial sums of F.F, P.P (mode 0, 2)
+  const int *col_bc = nullptr;
+  const double *side_f = nullptr, *side_d = nullptr;
+  double *tl = nullptr, *tinvb = nullptr, *tc = nullptr;
+  double *partials = nullptr;
 };
 // mode 0 residual, 1 Jacobian, 2 both
 void launch_assemble_cols(int mode, const ColsArgs &a, hipStream_t stream);
@@ -78,6 +85,7 @@ struct BcArgs {
   const int *diag_slot;
   double *F, *val;
   double *flux_out;                     // optional per-BC-connection flux [kg/s] (mode 4)
+  double *side_f = nullptr, *side_d = nullptr;   // when set: per-condition-cell sums go here instead of into F / val
 };
 void launch_bc(int mode, const BcArgs &a, hipStream_t stream);
 
@@ -111,6 +119,12 @@ void launch_spmv(int variant, int n, int max_row_nnz, const int *rowptr, const i
 // row, int32 tile pointers): needs max_row_nnz <= 8; `tpw` tiles per wave
 void launch_spmv_compact(int tpw, int n, int max_row_nnz, const int *tileptr, const unsigned short *roff, const short *dcol,
                          const double *val, const double *x, double *y, hipStream_t stream);
+// x.x, f.(A x) and optionally xx.xx without writing A x: partial sums in partials[j*nb + b], nb = the return value
+// (= spmv_compact_dots_blocks, which sizes the buffer: 3*nb doubles); finish with launch_finalize_partials
+int spmv_compact_dots_blocks(int tpw, int n);
+int launch_spmv_compact_dots(int tpw, int n, int max_row_nnz, const int *tileptr, const unsigned short *roff, const short *dcol,
+                             const double *val, const double *x, const double *f, const double *xx, double *partials,
+                             hipStream_t stream);
 // per-column tridiagonal (block-Jacobi): factor from CSR slots, then apply
 struct TriArgs {
   int ncols, nz;

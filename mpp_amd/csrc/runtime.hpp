@@ -147,6 +147,9 @@ struct Options {
   bool fused_assembly = true;  // F and J of a line-search trial point in one kernel ...
   bool track_mass_exchange = false;  // accumulate VAR_LATERAL_MASS_EXCHANGED / VAR_BC_MASS_EXCHANGED after every sub-step
   bool ilu_graph = true;       // replay the level launches of the ILU(0) triangular solves from a hipGraph
+  bool fused_ls_dots = true;   // line search: ||Y||, F.(J Y), ||X|| reduced inside the SpMV (compact-index kernels)
+  bool fused_rows = true;      // column march with the boundary fluxes folded in: complete rows -> ||F||, ||X|| and the
+                               // column LU come out of the assembly pass (see Solver::rows_complete)
   bool fused_predict = true;   // skip the fused Jacobian at the first trial when the previous line search backtracked
   int fused_trials = 2;        // ... for the first `fused_trials` trial points of a line search (later ones: F only)
 };

@@ -141,7 +141,12 @@ struct Solver {
   DevBuf<double> soln, soln_prev, accum_prev, F, Y, W, G, R, RP, V, T, S, Pv, Wk, tmp_ext, tmp_int;
   DevBuf<double> aux_kr, aux_dkr, aux_den, aux_dden;
   DevBuf<double> tri_l, tri_invb, tri_c, jac_invd;
-  DevBuf<double> partials, sc;
+  DevBuf<double> partials, sc, spmv_partials;
+  // complete-row column march (plan_complete_rows): boundary cells sit on column ends only
+  bool rows_plan = false, asm_sums = false;
+  DevBuf<int> d_col_bc;
+  DevBuf<double> bc_side_f, bc_side_d;
+  std::vector<int> h_cc_cell;
   double *h_sc = nullptr;  // pinned mirror of sc
   std::vector<DevBuf<double>> vv;
 
@@ -534,6 +539,7 @@ struct Solver {
       }
       cc_ptr.push_back(nb);
       ncond_cells = (int)cc_cell.size();
+      h_cc_cell = cc_cell;
       d_cc_cell.upload(cc_cell, stream); d_cc_ptr.upload(cc_ptr, stream); d_bc_type.upload(type, stream);
       d_bc_value.alloc(nb); d_bc_value.zero(stream);
       d_bc_flux.alloc(nb); d_bc_flux.zero(stream);
@@ -594,6 +600,7 @@ struct Solver {
       th_liq.assign(n, 0.0); th_ice.assign(n, 0.0); th_snow.assign(n, 0.0); th_tuning.assign(n, 1.0); th_nsnow.assign(n, 0);
     }
     build_compact_index();
+    plan_complete_rows();
     if (nghost > 0) {
       halo.d_send_idx.upload(halo.send_cells, stream);
       halo.sendbuf.alloc(std::max<size_t>(halo.send_cells.size(), 1));
@@ -603,6 +610,29 @@ struct Solver {
     soil_dirty = true;
     check_ilu();
   }
+
+  // The column march can finish every row itself (boundary fluxes included) when the cells that carry boundary
+  // conditions are the end cells of their columns and nothing else touches F or the diagonal afterwards: then ||F||,
+  // ||X|| and the block-Jacobi factors come out of the assembly pass (k_assemble_cols<.., FUSE>).
+  void plan_complete_rows() {
+    rows_plan = false;
+    if (th || thermal || !vertical_only || !columns || nghost > 0 || ndr_cells > 0 || nz < 2) return;
+    if ((ncols + 255) / 256 > kMaxPartialBlocks) return;
+    std::vector<int> cb(2 * (size_t)ncols, -1);
+    for (int j = 0; j < ncond_cells; ++j) {
+      const long long cell = h_cc_cell[j];
+      const int tile = (int)(cell / (64LL * nz)), tw = std::min(64, ncols - tile * 64);
+      const long long rem = cell - (long long)tile * 64 * nz;
+      const int k = (int)(rem / tw), col = tile * 64 + (int)(rem % tw);
+      if (k == 0) cb[col] = j;
+      else if (k == nz - 1) cb[(size_t)ncols + col] = j;
+      else return;
+    }
+    d_col_bc.upload(cb, stream);
+    bc_side_f.alloc(std::max(ncond_cells, 1)); bc_side_d.alloc(std::max(ncond_cells, 1));
+    rows_plan = true;
+  }
+  bool rows_complete() const { return rows_plan && opt.fused_rows && use_cols() && pick_nseg() == 1; }
 
   void upload_sink_params() {
     for (auto &c : sss)
@@ -853,6 +883,8 @@ struct Solver {
     halo_exchange(P);
     ProfScope ps(prof, KC_RESIDUAL);
     if (th) { launch_th_assemble(0, th_args(P, Fout), stream); ++nfuncs; ++cum_funcs; return; }
+    asm_sums = false;
+    if (rows_complete()) { assemble_complete_rows(0, P, Fout); ++nfuncs; ++cum_funcs; return; }
     if (use_cols()) launch_assemble_cols(0, cols_args(P, Fout), stream);
     else {
       if (!d_rc_ptr.p) throw Error("option assembly=general must be set before mppgpu_setup");
@@ -862,12 +894,37 @@ struct Solver {
     launch_sinks(0, sink_args(P, Fout), stream);
     ++nfuncs; ++cum_funcs;
   }
+  // boundary fluxes first (into the side arrays), then the march that finishes every row; mode 0 / 2 leave ||F||^2 and
+  // ||P||^2 in sc[S_SUM0], sc[S_SUM0+1] (asm_sums), mode 1 / 2 with the column preconditioner leave its factors (pc_ready)
+  void assemble_complete_rows(int mode, const double *P, double *Fout) {
+    BcArgs b = bc_args(P, Fout);
+    b.side_f = bc_side_f.p; b.side_d = bc_side_d.p;
+    launch_bc(mode, b, stream);
+    ColsArgs a = cols_args(P, Fout);
+    a.col_bc = d_col_bc.p; a.side_f = bc_side_f.p; a.side_d = bc_side_d.p; a.partials = partials.p;
+    const bool factor = mode != 0 && opt.pc_type == 2;
+    if (factor) { a.tl = tri_l.p; a.tinvb = tri_invb.p; a.tc = tri_c.p; }
+    launch_assemble_cols(mode, a, stream);
+    if (mode != 1) {
+      launch_finalize_partials((ncols + 255) / 256, 2, partials.p, sc.p, stream);
+      if (comm.active()) comm.allreduce_sum(sc.p + S_SUM0, 2, stream);
+      asm_sums = true;
+    }
+    if (mode != 0) pc_ready = factor;
+  }
+  // ||F||^2 and ||P||^2 of the state just assembled: from the assembly pass when it produced them, else by reduction
+  void residual_sums(const double *P, const double *Fv, double *out) {
+    if (asm_sums) { fetch_scalars(); out[0] = h_sc[S_SUM0]; out[1] = h_sc[S_SUM0 + 1]; }
+    else dots_host({{Fv, Fv}, {P, P}}, out);
+  }
   // residual and Jacobian of the same state in one pass: the auxvars (the expensive part) are evaluated once
   void op_residual_jacobian(const double *P, double *Fout) {
     if (dtime <= 0.0) throw Error("time step not set");
     halo_exchange(P);
     ProfScope ps(prof, KC_JACOBIAN);
     if (th) { launch_th_assemble(2, th_args(P, Fout), stream); ++nfuncs; ++cum_funcs; pc_ready = false; return; }
+    asm_sums = false;
+    if (rows_complete()) { assemble_complete_rows(2, P, Fout); ++nfuncs; ++cum_funcs; return; }
     if (use_cols()) launch_assemble_cols(2, cols_args(P, Fout), stream);
     else {
       if (!d_rc_ptr.p) throw Error("option assembly=general must be set before mppgpu_setup");
@@ -883,6 +940,7 @@ struct Solver {
     halo_exchange(P);
     ProfScope ps(prof, KC_JACOBIAN);
     if (th) { launch_th_assemble(2, th_args(P, th_scratch.p), stream); pc_ready = false; return; }
+    if (rows_complete()) { assemble_complete_rows(1, P, F.p); return; }
     if (use_cols()) launch_assemble_cols(1, cols_args(P, F.p), stream);
     else launch_assemble_general(1, gen_args(P, F.p), stream);
     launch_bc(1, bc_args(P, F.p), stream);
@@ -903,6 +961,25 @@ struct Solver {
       if (!compact_index) throw Error("spmv_variant 20/21 need the compact index (rows of <= 8 entries whose columns lie within 2^15 of their 64-row tile)");
       launch_spmv_compact(v == 20 ? 4 : 8, nred, max_row_nnz, d_tileptr.p, d_roff.p, d_dcol.p, d_val.p, x, y, stream);
     } else launch_spmv(v, nred, max_row_nnz, d_rowptr.p, d_col.p, d_val.p, x, y, stream);
+  }
+  // the line search's first reductions in one pass over the matrix: out = {y.y, f.(A y), x.x (x != nullptr)}
+  bool spmv_dots_fused() const {
+    const int v = spmv_variant();
+    return opt.fused_ls_dots && (v == 20 || v == 21) && compact_index && nghost == 0;
+  }
+  void op_spmv_dots(const double *y, const double *f, const double *x, double *out) {
+    const int tpw = spmv_variant() == 20 ? 4 : 8, nv = x ? 3 : 2;
+    {
+      ProfScope ps(prof, KC_REDUCE);
+      const size_t need = 3 * (size_t)spmv_compact_dots_blocks(tpw, nred);
+      if (spmv_partials.n < need) spmv_partials.alloc(need);
+      const int nbk = launch_spmv_compact_dots(tpw, nred, max_row_nnz, d_tileptr.p, d_roff.p, d_dcol.p, d_val.p, y, f, x,
+                                               spmv_partials.p, stream);
+      launch_finalize_partials(nbk, nv, spmv_partials.p, sc.p, stream);
+      if (comm.active()) comm.allreduce_sum(sc.p + S_SUM0, nv, stream);
+    }
+    fetch_scalars();
+    for (int j = 0; j < nv; ++j) out[j] = h_sc[S_SUM0 + j];
   }
   // 16-bit in-tile row offsets + 16-bit column offsets from the tile's first row (the pattern is fixed after setup)
   void build_compact_index() {
@@ -1307,14 +1384,16 @@ struct Solver {
     const double alpha = 1e-4, maxstep = 1e8, minlambda = 1e-12;
     const int max_its = 40;
     double lambda = 1.0, lambdatemp, lambdaprev, gprev, g, gnorm = 0.0, wnorm2 = 0.0;
-    op_spmv(Yv, Wv);  // initslope = F . (J Y)
-    double r3[3];
-    if (xnorm_known) {  // ||X|| was reduced together with ||F(X)|| when X was the accepted trial point
-      dots_host({{Yv, Yv}, {Fv, Wv}}, r3);
+    double r3[3];   // initslope = F . (J Y), ||Y||, ||X||
+    // ||X|| was reduced together with ||F(X)|| when X was the accepted trial point of the previous line search
+    if (spmv_dots_fused()) {
+      op_spmv_dots(Yv, Fv, xnorm_known ? nullptr : X, r3);
     } else {
-      dots_host({{Yv, Yv}, {Fv, Wv}, {X, X}}, r3);
-      xnorm = std::sqrt(r3[2]);
+      op_spmv(Yv, Wv);
+      if (xnorm_known) dots_host({{Yv, Yv}, {Fv, Wv}}, r3);
+      else dots_host({{Yv, Yv}, {Fv, Wv}, {X, X}}, r3);
     }
+    if (!xnorm_known) xnorm = std::sqrt(r3[2]);
     ynorm = std::sqrt(r3[0]);
     double initslope = r3[1];
     if (ynorm == 0.0) return 1;
@@ -1339,7 +1418,7 @@ struct Solver {
       ++trial;
       if (last_fused) op_residual_jacobian(Wv, Gv); else op_residual(Wv, Gv);
       double r2[2];
-      dots_host({{Gv, Gv}, {Wv, Wv}}, r2);
+      residual_sums(Wv, Gv, r2);
       gnorm = std::sqrt(r2[0]); wnorm2 = r2[1];
       return gnorm * gnorm;
     };
@@ -1398,7 +1477,8 @@ struct Solver {
     *newton_its = 0; *linear_its = 0;
     bool jac_valid = false;
     if (opt.fused_assembly) { op_residual_jacobian(X, Fv); jac_valid = true; } else op_residual(X, Fv);
-    double fnorm = norm_host(Fv);
+    double fnorm;
+    if (asm_sums) { double r2[2]; residual_sums(X, Fv, r2); fnorm = std::sqrt(r2[0]); } else fnorm = norm_host(Fv);
     int reason = snes_converged(0, 0.0, 0.0, fnorm, ttol, rnorm0);
     for (int i = 0; !reason && i < opt.snes_max_it; ++i) {
       if (!jac_valid) op_jacobian(X);
@@ -1910,6 +1990,8 @@ struct Solver {
     else if (key == "ilu_graph") opt.ilu_graph = num() != 0;
     else if (key == "fused_trials") opt.fused_trials = (int)num();
     else if (key == "fused_predict") opt.fused_predict = num() != 0;
+    else if (key == "fused_ls_dots") opt.fused_ls_dots = num() != 0;
+    else if (key == "fused_rows") opt.fused_rows = num() != 0;
     else if (key == "track_mass_exchange") opt.track_mass_exchange = num() != 0;
     else if (key == "temperature") temperature = num();
     else if (key == "problem_type") {

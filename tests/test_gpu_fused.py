@@ -1,0 +1,102 @@
+"""GPU parity of the fused passes of the VSFM path: the complete-row column march (boundary
+fluxes folded in, ||F|| / ||X|| and the column LU produced by the assembly pass) and the line-search reductions inside the
+SpMV.  Every case is checked against the oracle and against the unfused kernels of the same library."""
+import numpy as np
+import pytest
+
+from mpp_amd import constants as C
+
+import problems as P
+from test_gpu_parity import _hetero, _operator_parity
+
+pytestmark = pytest.mark.gpu
+
+ROWS = {"assembly": "columns", "nseg": 1, "pc_type": "bjacobi", "ksp_type": "bcgs"}   # complete rows need nseg == 1
+
+
+def _two_bcs_on_top(prob):
+    """a second condition on the top cells (seepage next to the Dirichlet one): two entries in one side-array slot"""
+    t, cs, vals = prob.bcs[0]
+    prob.bcs.append((C.COND_SEEPAGE_BC, cs, np.full(vals.size, 101325.0)))
+    return prob
+
+
+@pytest.mark.parametrize("variant", ["plain", "two_bcs", "inactive_sources", "ragged_tile"])
+def test_complete_rows_operators(variant):
+    prob, x = _hetero(ncols=130 if variant == "ragged_tile" else 70, nz=19, seed=21)
+    n = x.size
+    if variant == "two_bcs":
+        _two_bcs_on_top(prob)
+    if variant == "inactive_sources":
+        act = np.ones(n, dtype=np.int32)
+        act[[0, 18, 19, 40, 700]] = 0          # column ends included: a boundary cell that is inactive
+        prob.mesh.is_active = act
+        from mpp_amd import mesh as M
+        ids = np.arange(1, n + 1)
+        z = np.zeros(n)
+        ss = M.ConnectionSet(np.full(n, -1), ids, z, z, np.ones(n), np.zeros((n, 3)))
+        prob.sss = [(C.COND_MASS_RATE, ss, np.random.default_rng(1).uniform(-1e-6, 1e-6, n))]
+    o, g, (rp, cj, val), v = _operator_parity(prob, x, ROWS)
+    # the column LU left behind by the Jacobian pass
+    z_o = o.pc_apply(C.PC_BJACOBI, rp, cj, val, v)
+    z_g = g.soe.PCApply(v)
+    assert np.abs(z_g - z_o).max() <= 1e-10 * np.abs(z_o).max()
+    # and the unfused kernels of the same library, bit for bit where only one boundary entry sits on a cell
+    h = P.to_gpu(prob, dict(ROWS, fused_rows=0))
+    h.soe.SetDtime(prob.dt); h.soe.PreSolve()
+    f_g, f_h = g.soe.ComputeResidual(x), h.soe.ComputeResidual(x)
+    val_g, val_h = g.soe.ComputeJacobian(x)[2], h.soe.ComputeJacobian(x)[2]
+    if variant == "two_bcs":
+        assert np.abs(f_g - f_h).max() <= 1e-14 * np.abs(f_h).max()
+        assert np.abs(val_g - val_h).max() <= 1e-14 * np.abs(val_h).max()
+    else:
+        assert np.array_equal(f_g, f_h) and np.array_equal(val_g, val_h)
+        assert np.array_equal(g.soe.PCApply(v), h.soe.PCApply(v))
+
+
+def test_boundary_on_a_middle_cell_falls_back():
+    """a condition on a cell that is not a column end: the march cannot finish that row, the separate kernels run"""
+    prob, x = _hetero(ncols=70, nz=19, seed=4)
+    from mpp_amd import mesh as M
+    t, cs, vals = prob.bcs[0]
+    ids = np.asarray(cs.id_dn).copy()
+    ids[3] -= 5                                            # move one top-cell condition five levels down its column
+    prob.bcs[0] = (t, M.ConnectionSet(cs.id_up, ids, cs.dist_up, cs.dist_dn, cs.area, cs.unit_vec), vals)
+    _operator_parity(prob, x, ROWS)
+
+
+@pytest.mark.parametrize("ksp,pc", [("bcgs", "bjacobi"), ("gmres", "ilu")])
+def test_fused_and_unfused_steps_agree(ksp, pc):
+    """three celia steps with every fused pass on and off: same Newton / Krylov counts, solutions equal to rounding,
+    and both equal to the oracle"""
+    prob = P.celia1990(ncols=70, nz=40, perm_mult=np.exp(0.4 * np.random.default_rng(5).standard_normal(70)))
+    base = {"assembly": "columns", "nseg": 1, "ksp_type": ksp, "pc_type": pc, "spmv_variant": 20}
+    on = P.to_gpu(prob, base)
+    off = P.to_gpu(prob, dict(base, fused_rows=0, fused_ls_dots=0))
+    o = P.to_oracle(prob)
+    o.set_solver(C.KSP_BCGS if ksp == "bcgs" else C.KSP_GMRES, C.PC_BJACOBI if pc == "bjacobi" else C.PC_ILU0)
+    for s in range(3):
+        r_on, r_off, r_o = on.soe.StepDT(prob.dt, s + 1), off.soe.StepDT(prob.dt, s + 1), o.step_dt(prob.dt, s + 1)
+        assert r_on == r_off == tuple(r_o)
+    c_on, c_off, c_o = on.soe.counters(), off.soe.counters(), o.counters()
+    assert c_on["newton"] == c_off["newton"] == c_o["newton"]
+    assert c_on["linear"] == c_off["linear"]
+    p_on = on.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1)
+    p_off = off.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1)
+    p_o = o.get(C.AUXVAR_INTERNAL, C.VAR_PRESSURE)
+    assert np.abs(p_on - p_off).max() <= 1e-10 * np.abs(p_off).max()
+    assert np.abs(p_on - p_o).max() <= 1e-8 * np.abs(p_o).max()
+
+
+def test_complete_rows_time_step_cut():
+    """dt halving with the fused passes: identical branch sequence to the oracle"""
+    prob = P.celia1990(ncols=66, nz=40)
+    opts = dict(ROWS, ksp_type="preonly", snes_max_it=6)
+    g = P.to_gpu(prob, opts)
+    o = P.to_oracle(prob)
+    o.set_solver(C.KSP_PREONLY, C.PC_BJACOBI, snes_max_it=6)
+    assert g.soe.StepDT(86400.0, 1) == tuple(o.step_dt(86400.0, 1))
+    cg, co = g.soe.counters(), o.counters()
+    assert cg["time_cuts"] == co["time_cuts"] > 0 and cg["newton"] == co["newton"]
+    np.testing.assert_allclose(g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1),
+                               o.get(C.AUXVAR_INTERNAL, C.VAR_PRESSURE), rtol=1e-8)
