@@ -161,7 +161,11 @@ __global__ __launch_bounds__(kBlock) void k_assemble_cols(ColsArgs a) {
       const bool owned = (k >= k0 && k < k1);
       Aux cur = {};
       double f_cur = 0.0, dacc_cur = 1.0;  // inactive cell: diagonal 1 (GE:1682-1684)
-      const double Pi = ldnt(ca.P + i);
+      double Pi;
+      if (FUSE && a.trial_x) {   // the line search's trial point W = X + a Y, formed here and stored for the next pass
+        Pi = fma(a.trial_a, ldnt(a.trial_y + i), ldnt(a.trial_x + i));
+        stnt(Pi, a.trial_w + i);
+      } else Pi = ldnt(ca.P + i);
       cur.P = Pi;
       if (FUSE && RES) accP += Pi * Pi;
       if (act) {
@@ -297,7 +301,8 @@ __global__ __launch_bounds__(kBlock) void k_bc(BcArgs a) {
     return;
   }
   Soil s = load_soil(ca, cell);
-  const Aux in = auxvar_compute<JAC>(ca.sat_func, ca.eos, s, ca.P[cell], frac_of(ca, cell));
+  const double Pc = a.trial_x ? fma(a.trial_a, a.trial_y[cell], a.trial_x[cell]) : ca.P[cell];
+  const Aux in = auxvar_compute<JAC>(ca.sat_func, ca.eos, s, Pc, frac_of(ca, cell));
   const bool side = a.side_f != nullptr;   // fluxes into per-condition-cell side arrays (complete-row column march)
   double f = (RES && !side) ? a.F[cell] : 0.0;
   double d = 0.0;
@@ -1187,7 +1192,7 @@ __global__ __launch_bounds__(kBlock) void k_pmult(int n, const double *a, const 
 __global__ __launch_bounds__(kBlock) void k_waxpy(int n, double *w, const double *sc, int slot, double sign, double aval,
                                                   const double *x, const double *y) {
   const double a = slot >= 0 ? sign * sc[slot] : aval;
-  vec2_loop(n, [&](size_t q) { const double2 u = CD2(x)[q], v = CD2(y)[q]; D2(w)[q] = make_double2(v.x + a * u.x, v.y + a * u.y); }, [&](size_t i) { w[i] = y[i] + a * x[i]; });
+  vec2_loop(n, [&](size_t q) { const double2 u = CD2(x)[q], v = CD2(y)[q]; D2(w)[q] = make_double2(fma(a, u.x, v.x), fma(a, u.y, v.y)); }, [&](size_t i) { w[i] = fma(a, x[i], y[i]); });
 }
 // p <- r - omegaold*beta*v + beta*p  (VecAXPBYPCZ(P,1.0,-omegaold*beta,beta,R,V), bcgs.c)
 __global__ __launch_bounds__(kBlock) void k_bcgs_p(int n, double *P, const double *Pold, const double *R, const double *V,

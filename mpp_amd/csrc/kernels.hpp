@@ -53,6 +53,10 @@ struct ColsArgs {
   const double *side_f = nullptr, *side_d = nullptr;
   double *tl = nullptr, *tinvb = nullptr, *tc = nullptr;
   double *partials = nullptr;
+  // optional trial point (complete-row variant): the state is trial_x + trial_a * trial_y, written to trial_w
+  const double *trial_x = nullptr, *trial_y = nullptr;
+  double trial_a = 0.0;
+  double *trial_w = nullptr;
 };
 // mode 0 residual, 1 Jacobian, 2 both
 void launch_assemble_cols(int mode, const ColsArgs &a, hipStream_t stream);
@@ -86,6 +90,8 @@ struct BcArgs {
   double *F, *val;
   double *flux_out;                     // optional per-BC-connection flux [kg/s] (mode 4)
   double *side_f = nullptr, *side_d = nullptr;   // when set: per-condition-cell sums go here instead of into F / val
+  const double *trial_x = nullptr, *trial_y = nullptr;   // when set: the state is trial_x + trial_a * trial_y, not cell.P
+  double trial_a = 0.0;
 };
 void launch_bc(int mode, const BcArgs &a, hipStream_t stream);
 

@@ -144,6 +144,7 @@ struct Solver {
   DevBuf<double> partials, sc, spmv_partials;
   // complete-row column march (plan_complete_rows): boundary cells sit on column ends only
   bool rows_plan = false, asm_sums = false;
+  struct Trial { const double *x = nullptr, *y = nullptr; double a = 0.0; } ls_point;   // pending X + a Y of the line search
   DevBuf<int> d_col_bc;
   DevBuf<double> bc_side_f, bc_side_d;
   std::vector<int> h_cc_cell;
@@ -899,8 +900,11 @@ struct Solver {
   void assemble_complete_rows(int mode, const double *P, double *Fout) {
     BcArgs b = bc_args(P, Fout);
     b.side_f = bc_side_f.p; b.side_d = bc_side_d.p;
+    b.trial_x = ls_point.x; b.trial_y = ls_point.y; b.trial_a = ls_point.a;
     launch_bc(mode, b, stream);
     ColsArgs a = cols_args(P, Fout);
+    a.trial_x = ls_point.x; a.trial_y = ls_point.y; a.trial_a = ls_point.a; a.trial_w = const_cast<double *>(P);
+    ls_point = Trial{};
     a.col_bc = d_col_bc.p; a.side_f = bc_side_f.p; a.side_d = bc_side_d.p; a.partials = partials.p;
     const bool factor = mode != 0 && opt.pc_type == 2;
     if (factor) { a.tl = tri_l.p; a.tinvb = tri_invb.p; a.tc = tri_c.p; }
@@ -1411,7 +1415,8 @@ struct Solver {
     bool last_fused = false;
     jac_valid = false;
     auto eval = [&](double lam) {
-      vec_waxpy(Wv, -lam, Yv, X);
+      // W = X - lam Y: formed inside the assembly pass when the column march finishes the rows itself
+      if (rows_complete()) ls_point = Trial{X, Yv, -lam}; else vec_waxpy(Wv, -lam, Yv, X);
       // a trial point's Jacobian is assembled together with its residual when the point is likely to be accepted:
       // the full step unless the previous line search of this solve had to backtrack, and always the second trial
       last_fused = opt.fused_assembly && trial < opt.fused_trials && !(trial == 0 && opt.fused_predict && ls_backtracked_last);
