@@ -155,35 +155,57 @@ __global__ __launch_bounds__(kBlock) void k_assemble_cols(ColsArgs a) {
       }
     };
 
+    // the streamed operands of one level (and of the connection below it), fetched one level ahead of their use so
+    // that a wave's memory latency overlaps its own arithmetic (the march runs at 2-4 waves per SIMD)
+    struct Level { double P, sat_res, alpha, m, por, vol, accp, Dq, upw, dgrav, area; };
+    auto fetch = [&](int k) {
+      Level L;
+      const size_t i = cbase + (size_t)k * tw;
+      if (FUSE && a.trial_x) {   // the line search's trial point W = X + a Y, formed here and stored for the next pass
+        L.P = fma(a.trial_a, ldnt(a.trial_y + i), ldnt(a.trial_x + i));
+        stnt(L.P, a.trial_w + i);
+      } else L.P = ldnt(ca.P + i);
+      L.sat_res = ldnt(ca.sat_res + i); L.alpha = ldnt(ca.alpha + i); L.por = ldnt(ca.por + i);
+      L.m = (SAT_T == kSatVGHalf) ? 0.5 : ldnt(ca.m + i);
+      L.vol = ldnt(ca.vol + i);
+      L.accp = RES ? ldnt(a.accum_prev + i) : 0.0;
+      if (k > kstart) {
+        const size_t ic = i - tw;
+        L.Dq = ldnt(a.conn.Dq + ic); L.upw = ldnt(a.conn.upw + ic); L.dgrav = ldnt(a.conn.dgrav + ic); L.area = ldnt(a.conn.area + ic);
+      } else { L.Dq = L.upw = L.dgrav = L.area = 0.0; }
+      return L;
+    };
+    Level nxt = fetch(kstart);
     for (int k = kstart; k < kend; ++k) {
       const size_t i = cbase + (size_t)k * tw;
+      const Level L = nxt;
+      if (k + 1 < kend) nxt = fetch(k + 1);
       const bool act = is_active(ca, i);
       const bool owned = (k >= k0 && k < k1);
       Aux cur = {};
       double f_cur = 0.0, dacc_cur = 1.0;  // inactive cell: diagonal 1 (GE:1682-1684)
-      double Pi;
-      if (FUSE && a.trial_x) {   // the line search's trial point W = X + a Y, formed here and stored for the next pass
-        Pi = fma(a.trial_a, ldnt(a.trial_y + i), ldnt(a.trial_x + i));
-        stnt(Pi, a.trial_w + i);
-      } else Pi = ldnt(ca.P + i);
+      const double Pi = L.P;
       cur.P = Pi;
       if (FUSE && RES) accP += Pi * Pi;
       if (act) {
-        Soil s = load_soil<SAT_T, true>(ca, i);
+        Soil s;
+        s.sat_res = L.sat_res; s.alpha = L.alpha; s.m = L.m; s.por = L.por;
+        if ((SAT_T >= 0 ? SAT_T : ca.sat_func) == kSatSBC) {
+          s.pu = ca.sbc_pu[i]; s.ps = ca.sbc_ps[i]; s.b2 = ca.sbc_b2[i]; s.b3 = ca.sbc_b3[i];
+        } else s.pu = s.ps = s.b2 = s.b3 = 0.0;
         cur = auxvar_compute<JAC, SAT_T, DEN_T>(ca.sat_func, ca.eos, s, Pi, frac_of(ca, i));
         if (owned) {
-          const double vol = ldnt(ca.vol + i);
+          const double vol = L.vol;
           if (RES) f_cur = s.por * cur.den * cur.sat * vol * a.dtInv;
           if (JAC) dacc_cur = (s.por * cur.dden * cur.sat + s.por * cur.den * cur.dsat) * vol * a.dtInv;
         }
       }
-      if (RES && owned) f_cur = f_cur - ldnt(a.accum_prev + i);
+      if (RES && owned) f_cur = f_cur - L.accp;
       double dconn_cur = 0.0, lo_cur = 0.0;
       if (k > kstart) {
         if (prev_act && act) {
-          const size_t ic = i - tw;
           ConnGeom g;
-          g.Dq = ldnt(a.conn.Dq + ic); g.upweight = ldnt(a.conn.upw + ic); g.dist_gravity = ldnt(a.conn.dgrav + ic); g.area = ldnt(a.conn.area + ic);
+          g.Dq = L.Dq; g.upweight = L.upw; g.dist_gravity = L.dgrav; g.area = L.area;
           double Jup = 0.0, Jdn = 0.0;
           const double flux = richards_flux<JAC>(prev, cur, g, 0, Jup, Jdn);
           if (RES) { f_prev -= flux; f_cur += flux; }

@@ -20,6 +20,10 @@ constexpr double kGravity = 9.80665;          // :201
 constexpr double kFMWH2O = 18.01534;          // :202
 constexpr double kDenH2O = 1.0e3;             // mpp_varcon.F90:17
 constexpr double kViscosity = 8.904156e-4;    // EOSWaterMod.F90:582
+// fp64 division is ~10 instructions around a quarter-rate v_rcp_f64 and the assembly kernels are issue-bound: divisions
+// by constants are multiplications by the (correctly rounded) reciprocal, <= 1 ulp from the quotient
+constexpr double kInvViscosity = 1.0 / kViscosity;
+constexpr double kInvFMWH2O = 1.0 / kFMWH2O;
 
 enum SatFunc : int { kSatVG = 0, kSatBC = 1, kSatSBC = 2,
                      kSatVGHalf = 3 /* compile-time specialisation only: van Genuchten with m == 1/2 in every cell */ };
@@ -116,10 +120,10 @@ __host__ __device__ inline void density(const EosParams &e, double p, double &de
       kappa = 1.0;
       dkappa_dp = 0.0;
     }
-    den = e.dent * kappa / kFMWH2O;
-    dden = (e.dent * dkappa_dp) / kFMWH2O;
+    den = e.dent * kappa * kInvFMWH2O;
+    dden = (e.dent * dkappa_dp) * kInvFMWH2O;
   } else if (e.density_type == kDenConstant) {
-    den = kDenH2O / kFMWH2O;
+    den = kDenH2O * kInvFMWH2O;
     dden = 0.0;
   } else if (DEN_T == -1) {
     density_ifc67(e.t_C, p, den, dden);
@@ -138,27 +142,49 @@ __host__ __device__ inline void sat_relperm(int sat_func_rt, const Soil &s, doub
   const double sat_res = s.sat_res, alpha = s.alpha;
   if (sat_func == kSatVG) {
     if (pc < 0.0) {
-      const double mm = s.m;
-      const double nn = 1.0 / (1.0 - mm);  // SatFunc_Set_VG, SaturationFunction.F90:157
       const double t = -alpha * pc;
       // m == 1/2 (n == 2, the reference's celia/vchannel soil): every real power below is a square, a square
-      // root or their reciprocal -- exact or correctly rounded, so results stay within an ulp of pow()
-      const bool half = (SAT_T == kSatVGHalf) ? true : (mm == 0.5);
-      const double pc_alpha_n = half ? t * t : pow(t, nn);
-      const double one_plus = 1.0 + pc_alpha_n;
-      const double Se = half ? 1.0 / sqrt(one_plus) : pow(one_plus, -mm);
-      sat = sat_res + (1.0 - sat_res) * Se;
-      const double AA = pc_alpha_n / one_plus;
-      const double AAm = half ? sqrt(AA) : pow(AA, mm);
-      const double BB = 1.0 - AAm;
-      kr = sqrt(Se) * BB * BB;
-      if (DERIV) {
-        const double dSe_dpc = -mm * nn * Se * AA / pc;
-        dsat = (1.0 - sat_res) * dSe_dpc;
-        const double p1 = half ? Se * sqrt(Se) : pow(Se, 1.0 / mm - 0.5);
-        const double p2 = half ? 1.0 / AAm : pow(AA, mm - 1.0);
-        const double dkr_dSe = 0.5 * kr / Se + 2.0 * p1 * p2 * BB;
-        dkr = dkr_dSe * dSe_dpc;
+      // root or their reciprocal -- exact or correctly rounded, so results stay within an ulp or two of pow();
+      // 1/(1+t^2) is formed once and serves Se = (1+t^2)^(-1/2), AA = t^2/(1+t^2) and 1/Se = (1+t^2) Se
+      const bool half = (SAT_T == kSatVGHalf) ? true : (s.m == 0.5);
+      if (half) {
+        const double a2 = t * t;
+        const double one_plus = 1.0 + a2;
+        const double r = 1.0 / one_plus;
+        const double Se = sqrt(r);
+        sat = sat_res + (1.0 - sat_res) * Se;
+        const double AA = a2 * r;
+        const double AAm = sqrt(AA);
+        const double BB = 1.0 - AAm;
+        const double q = sqrt(Se);
+        kr = q * BB * BB;
+        if (DERIV) {
+          const double dSe_dpc = -(Se * AA) / pc;          // m n == 1
+          dsat = (1.0 - sat_res) * dSe_dpc;
+          const double p1 = Se * q;                        // Se^(1/m - 1/2)
+          const double p2 = 1.0 / AAm;                     // AA^(m - 1)
+          const double dkr_dSe = 0.5 * kr * (one_plus * Se) + 2.0 * p1 * p2 * BB;
+          dkr = dkr_dSe * dSe_dpc;
+        }
+      } else {
+        const double mm = s.m;
+        const double nn = 1.0 / (1.0 - mm);  // SatFunc_Set_VG, SaturationFunction.F90:157
+        const double pc_alpha_n = pow(t, nn);
+        const double one_plus = 1.0 + pc_alpha_n;
+        const double Se = pow(one_plus, -mm);
+        sat = sat_res + (1.0 - sat_res) * Se;
+        const double AA = pc_alpha_n / one_plus;
+        const double AAm = pow(AA, mm);
+        const double BB = 1.0 - AAm;
+        kr = sqrt(Se) * BB * BB;
+        if (DERIV) {
+          const double dSe_dpc = -mm * nn * Se * AA / pc;
+          dsat = (1.0 - sat_res) * dSe_dpc;
+          const double p1 = pow(Se, 1.0 / mm - 0.5);
+          const double p2 = pow(AA, mm - 1.0);
+          const double dkr_dSe = 0.5 * kr / Se + 2.0 * p1 * p2 * BB;
+          dkr = dkr_dSe * dSe_dpc;
+        }
       }
     } else {
       sat = 1.0; kr = 1.0;
@@ -245,7 +271,7 @@ __host__ __device__ inline double richards_flux(const Aux &up, const Aux &dn, co
   }
   if (seepage_update) dphi = 0.0;
   const bool upwind_up = (dphi >= 0.0);
-  const double ukvr = upwind_up ? up.kr / kViscosity : dn.kr / kViscosity;
+  const double ukvr = (upwind_up ? up.kr : dn.kr) * kInvViscosity;
   const bool massflux = (bc_type == kCondMassFlux);
   const double v_darcy = massflux ? 0.0 : -g.Dq * ukvr * dphi;
   const double q = v_darcy * g.area;
@@ -259,8 +285,8 @@ __host__ __device__ inline double richards_flux(const Aux &up, const Aux &dn, co
     double dphi_dn = -1.0 + dgrav_dn * dn.dden;
     if (seepage_update) dphi_dn = 0.0;
     // dvis_dP == 0 (EOSWaterMod.F90:583): the kr/(vis*vis)*dvis_dP term is an exact zero
-    const double dukvr_up = upwind_up ? up.dkr / kViscosity : 0.0;
-    const double dukvr_dn = upwind_up ? 0.0 : dn.dkr / kViscosity;
+    const double dukvr_up = upwind_up ? up.dkr * kInvViscosity : 0.0;
+    const double dukvr_dn = upwind_up ? 0.0 : dn.dkr * kInvViscosity;
     const double dq_up = g.Dq * (dukvr_up * dphi + ukvr * dphi_up) * g.area;
     const double dq_dn = g.Dq * (dukvr_dn * dphi + ukvr * dphi_dn) * g.area;
     if (massflux) {
