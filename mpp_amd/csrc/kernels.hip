@@ -165,13 +165,14 @@ __global__ __launch_bounds__(kBlock) void k_assemble_cols(ColsArgs a) {
         L.P = fma(a.trial_a, ldnt(a.trial_y + i), ldnt(a.trial_x + i));
         stnt(L.P, a.trial_w + i);
       } else L.P = ldnt(ca.P + i);
-      L.sat_res = ldnt(ca.sat_res + i); L.alpha = ldnt(ca.alpha + i); L.por = ldnt(ca.por + i);
+      L.sat_res = ldnt(ca.sat_res + i); L.alpha = ldnt(ca.alpha + i);
       L.m = (SAT_T == kSatVGHalf) ? 0.5 : ldnt(ca.m + i);
-      L.vol = ldnt(ca.vol + i);
+      L.por = ldnt(a.porvol + i); L.vol = 1.0;     // porosity only ever multiplies the volume here
       L.accp = RES ? ldnt(a.accum_prev + i) : 0.0;
       if (k > kstart) {
         const size_t ic = i - tw;
-        L.Dq = ldnt(a.conn.Dq + ic); L.upw = ldnt(a.conn.upw + ic); L.dgrav = ldnt(a.conn.dgrav + ic); L.area = ldnt(a.conn.area + ic);
+        L.Dq = ldnt(a.DqA + ic); L.area = 1.0;     // the flux is linear in Dq * area
+        L.upw = ldnt(a.conn.upw + ic); L.dgrav = ldnt(a.conn.dgrav + ic);
       } else { L.Dq = L.upw = L.dgrav = L.area = 0.0; }
       return L;
     };

@@ -40,6 +40,7 @@ struct ConnArrays {   // internal connections, precomputed geometry
 struct ColsArgs {
   CellArrays cell;
   ConnArrays conn;       // vertical connection (k,c)->(k+1,c) stored at the index of cell (k,c)
+  const double *DqA, *porvol;       // conn.Dq * conn.area and cell.por * cell.vol, streamed instead of the four arrays
   const double *accum_prev, *src;   // src: dense mass-rate source [kmol/s], nullptr if none
   double *F;             // residual out (MODE 0,2)
   double *val;           // CSR values out (MODE 1,2), level-major analytic layout

@@ -146,7 +146,7 @@ struct Solver {
   bool rows_plan = false, asm_sums = false;
   struct Trial { const double *x = nullptr, *y = nullptr; double a = 0.0; } ls_point;   // pending X + a Y of the line search
   DevBuf<int> d_col_bc;
-  DevBuf<double> bc_side_f, bc_side_d;
+  DevBuf<double> bc_side_f, bc_side_d, d_DqA, d_porvol;
   std::vector<int> h_cc_cell;
   double *h_sc = nullptr;  // pinned mirror of sc
   std::vector<DevBuf<double>> vv;
@@ -697,6 +697,10 @@ struct Solver {
     std::vector<double> a(n), b(n), c(n), d(n);
     for (int i = 0; i < n; ++i) { const int e = int2ext[i]; a[i] = por[e]; b[i] = sat_res[e]; c[i] = alpha[e]; d[i] = lam[e]; }
     d_por.upload(a, stream); d_sat_res.upload(b, stream); d_alpha.upload(c, stream); d_m.upload(d, stream);
+    if (vertical_only && columns && !th) {   // the column march streams porosity x volume as one operand
+      for (int i = 0; i < n; ++i) a[i] = a[i] * vol[int2ext[i]];
+      d_porvol.upload(a, stream);
+    }
     if (sat_func == kSatSBC) {
       // SatFunc_Set_SBC_bz2 / _bz3 (SaturationFunction.F90:260-372), ps = -0.9/alpha (:1409,1412)
       std::vector<double> pu(n), ps(n), b2(n), b3(n);
@@ -724,6 +728,10 @@ struct Solver {
         Dq[ic] = g.Dq; upw[ic] = g.upweight; dg[ic] = g.dist_gravity; ar[ic] = g.area;
       }
       d_Dq.upload(Dq, stream); d_upw.upload(upw, stream); d_dgrav.upload(dg, stream); d_area.upload(ar, stream);
+      if (vertical_only && columns && !th) {   // ... and conductance x face area
+        for (int ic = 0; ic < nc_int; ++ic) Dq[ic] = Dq[ic] * ar[ic];
+        d_DqA.upload(Dq, stream);
+      }
     }
     // boundary geometry: the BC auxvar carries the soil of its id_dn cell (MultiPhysicsProbVSFM.F90:422-446)
     if (nb > 0) {
@@ -844,6 +852,7 @@ struct Solver {
     a.accum_prev = accum_prev.p; a.src = has_src ? d_src.p : nullptr;
     a.F = Fout; a.val = d_val.p; a.rowptr = d_rowptr.p;
     a.ncols = ncols; a.nz = nz; a.nseg = pick_nseg(); a.dtInv = 1.0 / dtime;
+    a.DqA = d_DqA.p; a.porvol = d_porvol.p;
     return a;
   }
   GenArgs gen_args(const double *P, double *Fout) const {
