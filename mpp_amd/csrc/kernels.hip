@@ -123,6 +123,7 @@ __global__ __launch_bounds__(kBlock) void k_assemble_cols(ColsArgs a) {
     const bool factor = FUSE && JAC && a.tl != nullptr;
     const int jb = FUSE ? a.col_bc[c] : -1, jt = FUSE ? a.col_bc[a.ncols + c] : -1;  // side entries of rows 0 / nz-1
     double inv_pp = 0.0, c_pp = 0.0;   // 1/pivot and super-diagonal of the row before the one being completed
+    double d_pp = 0.0;                 // ... and its forward-eliminated residual
 
     Aux prev = {};
     bool prev_act = false;
@@ -131,12 +132,14 @@ __global__ __launch_bounds__(kBlock) void k_assemble_cols(ColsArgs a) {
     // row ip = (kp, c) is complete: boundary contribution, store, reductions, elimination step
     auto finish_row = [&](int kp, size_t ip, bool last) {
       const int js = (kp == 0) ? jb : (last ? jt : -1);
+      double f_row = 0.0;
       if (RES) {
         double f = f_prev;
         if (a.src) f -= ldnt(a.src + ip);
         if (FUSE && js >= 0) f += a.side_f[js];
         stnt(f, a.F + ip);
         if (FUSE) accF += f * f;
+        f_row = f;
       }
       if (JAC) {
         double di = dconn_prev + dacc_prev;
@@ -151,6 +154,11 @@ __global__ __launch_bounds__(kBlock) void k_assemble_cols(ColsArgs a) {
           const double inv = 1.0 / piv;
           stnt(l, a.tl + ip); stnt(inv, a.tinvb + ip); stnt(up_prev, a.tc + ip);
           inv_pp = inv; c_pp = up_prev;
+          if (a.fwd) {   // forward elimination of the residual as well: the Krylov solver's first M^{-1} F starts from here
+            const double d = (RES ? f_row : ldnt(a.F + ip)) - l * d_pp;
+            stnt(d, a.fwd + ip);
+            d_pp = d;
+          }
         }
       }
     };
@@ -1295,6 +1303,30 @@ __global__ __launch_bounds__(kBlock) void k_tri_solve_dots(TriArgs a, const doub
   }
 }
 
+// backward substitution only, from a forward-eliminated right-hand side d (left by the assembly pass): z = U^{-1} d with
+// the partial sums of z.z
+__global__ __launch_bounds__(kBlock) void k_tri_back_dots(TriArgs a, const double *__restrict__ d, double *__restrict__ z,
+                                                          double *__restrict__ partials) {
+  __shared__ double lds[kBlock / 64];
+  const int c = blockIdx.x * kBlock + threadIdx.x;
+  double acc = 0.0;
+  if (c < a.ncols) {
+    const int tile = c >> 6, tw = min(64, a.ncols - (tile << 6));
+    const size_t cbase = (size_t)tile * 64 * a.nz + (c & 63);
+    double next = 0.0;
+#pragma unroll 4
+    for (int k = a.nz - 1; k >= 0; --k) {
+      const size_t i = cbase + (size_t)k * tw;
+      const double xk = (ldnt(d + i) - ldnt(a.c + i) * next) * ldnt(a.invb + i);
+      stnt(xk, z + i);
+      next = xk;
+      acc += xk * xk;
+    }
+  }
+  const double t = block_sum(acc, lds);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
 // dot-product patterns the solvers use; every distinct vector is streamed once
 //  PAT 0: a.a            PAT 1: a.b            PAT 2: a.b, b.b          PAT 3: a.a, b.b, c.d         PAT 4: a.a, b.b
 template <int PAT>
@@ -1565,6 +1597,11 @@ int launch_tri_solve_dots(const TriArgs &a, const double *r, double *z, const do
   const dim3 grid(nblk(a.ncols));
   if (w) LAUNCH(k_tri_solve_dots<2>, grid, a, r, z, w, partials);
   else LAUNCH(k_tri_solve_dots<1>, grid, a, r, z, w, partials);
+  return (int)grid.x;
+}
+int launch_tri_back_dots(const TriArgs &a, const double *d, double *z, double *partials, hipStream_t stream) {
+  const dim3 grid(nblk(a.ncols));
+  LAUNCH(k_tri_back_dots, grid, a, d, z, partials);
   return (int)grid.x;
 }
 void launch_jacobi_setup(int n, const int *diag_slot, const double *val, double *invd, hipStream_t stream) {

@@ -53,6 +53,7 @@ struct ColsArgs {
   const int *col_bc = nullptr;
   const double *side_f = nullptr, *side_d = nullptr;
   double *tl = nullptr, *tinvb = nullptr, *tc = nullptr;
+  double *fwd = nullptr;    // with tl: L^{-1} F as well (F = the residual of this pass, or the one in `F` in mode 1)
   double *partials = nullptr;
   // optional trial point (complete-row variant): the state is trial_x + trial_a * trial_y, written to trial_w
   const double *trial_x = nullptr, *trial_y = nullptr;
@@ -144,6 +145,8 @@ void launch_tri_solve(const TriArgs &a, const double *r, double *z, hipStream_t 
 // the same solve with fused dot products of the result: z.z (w == nullptr) or z.w and z.z; returns the number of partial
 // blocks (<= kMaxPartialBlocks is the caller's responsibility); finish with launch_finalize_partials
 int launch_tri_solve_dots(const TriArgs &a, const double *r, double *z, const double *w, double *partials, hipStream_t stream);
+// z = U^{-1} d for a right-hand side the assembly pass already forward-eliminated, with the partial sums of z.z
+int launch_tri_back_dots(const TriArgs &a, const double *d, double *z, double *partials, hipStream_t stream);
 void launch_jacobi_setup(int n, const int *diag_slot, const double *val, double *invd, hipStream_t stream);
 
 // ---- ILU(0), level-scheduled (PETSc's default PC for SeqAIJ; elimination order = the caller's natural ordering) ----

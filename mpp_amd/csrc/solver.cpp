@@ -146,7 +146,8 @@ struct Solver {
   bool rows_plan = false, asm_sums = false;
   struct Trial { const double *x = nullptr, *y = nullptr; double a = 0.0; } ls_point;   // pending X + a Y of the line search
   DevBuf<int> d_col_bc;
-  DevBuf<double> bc_side_f, bc_side_d, d_DqA, d_porvol;
+  DevBuf<double> bc_side_f, bc_side_d, d_DqA, d_porvol, fwd_elim;
+  const double *fwd_rhs = nullptr;   // the residual vector whose forward elimination fwd_elim holds (for the current factors)
   std::vector<int> h_cc_cell;
   double *h_sc = nullptr;  // pinned mirror of sc
   std::vector<DevBuf<double>> vv;
@@ -894,6 +895,7 @@ struct Solver {
     ProfScope ps(prof, KC_RESIDUAL);
     if (th) { launch_th_assemble(0, th_args(P, Fout), stream); ++nfuncs; ++cum_funcs; return; }
     asm_sums = false;
+    if (Fout == fwd_rhs) fwd_rhs = nullptr;
     if (rows_complete()) { assemble_complete_rows(0, P, Fout); ++nfuncs; ++cum_funcs; return; }
     if (use_cols()) launch_assemble_cols(0, cols_args(P, Fout), stream);
     else {
@@ -906,7 +908,8 @@ struct Solver {
   }
   // boundary fluxes first (into the side arrays), then the march that finishes every row; mode 0 / 2 leave ||F||^2 and
   // ||P||^2 in sc[S_SUM0], sc[S_SUM0+1] (asm_sums), mode 1 / 2 with the column preconditioner leave its factors (pc_ready)
-  void assemble_complete_rows(int mode, const double *P, double *Fout) {
+  // have_F (mode 1): Fout holds the residual of this very state, so its forward elimination can ride along
+  void assemble_complete_rows(int mode, const double *P, double *Fout, bool have_F = true) {
     BcArgs b = bc_args(P, Fout);
     b.side_f = bc_side_f.p; b.side_d = bc_side_d.p;
     b.trial_x = ls_point.x; b.trial_y = ls_point.y; b.trial_a = ls_point.a;
@@ -917,7 +920,13 @@ struct Solver {
     a.col_bc = d_col_bc.p; a.side_f = bc_side_f.p; a.side_d = bc_side_d.p; a.partials = partials.p;
     const bool factor = mode != 0 && opt.pc_type == 2;
     if (factor) { a.tl = tri_l.p; a.tinvb = tri_invb.p; a.tc = tri_c.p; }
+    if (mode != 1 || Fout == fwd_rhs) fwd_rhs = nullptr;   // the residual in Fout or the factors are being replaced
+    if (factor && have_F) {
+      if (!fwd_elim.p) fwd_elim.alloc(nrow);
+      a.fwd = fwd_elim.p;
+    }
     launch_assemble_cols(mode, a, stream);
+    if (a.fwd) fwd_rhs = Fout;
     if (mode != 1) {
       launch_finalize_partials((ncols + 255) / 256, 2, partials.p, sc.p, stream);
       if (comm.active()) comm.allreduce_sum(sc.p + S_SUM0, 2, stream);
@@ -937,6 +946,7 @@ struct Solver {
     ProfScope ps(prof, KC_JACOBIAN);
     if (th) { launch_th_assemble(2, th_args(P, Fout), stream); ++nfuncs; ++cum_funcs; pc_ready = false; return; }
     asm_sums = false;
+    fwd_rhs = nullptr;
     if (rows_complete()) { assemble_complete_rows(2, P, Fout); ++nfuncs; ++cum_funcs; return; }
     if (use_cols()) launch_assemble_cols(2, cols_args(P, Fout), stream);
     else {
@@ -948,12 +958,14 @@ struct Solver {
     ++nfuncs; ++cum_funcs;
     pc_ready = false;
   }
-  void op_jacobian(const double *P) {
+  // Fres: the residual of the same state when the caller has it (lets the column march forward-eliminate it), else nullptr
+  void op_jacobian(const double *P, double *Fres = nullptr) {
     if (dtime <= 0.0) throw Error("time step not set");
     halo_exchange(P);
     ProfScope ps(prof, KC_JACOBIAN);
+    fwd_rhs = nullptr;
     if (th) { launch_th_assemble(2, th_args(P, th_scratch.p), stream); pc_ready = false; return; }
-    if (rows_complete()) { assemble_complete_rows(1, P, F.p); return; }
+    if (rows_complete()) { assemble_complete_rows(1, P, Fres ? Fres : F.p, Fres != nullptr); return; }
     if (use_cols()) launch_assemble_cols(1, cols_args(P, F.p), stream);
     else launch_assemble_general(1, gen_args(P, F.p), stream);
     launch_bc(1, bc_args(P, F.p), stream);
@@ -1099,7 +1111,9 @@ struct Solver {
     }
     {
       ProfScope ps(prof, KC_PC_APPLY);
-      const int nbk = launch_tri_solve_dots(tri_args(), r, z, w, partials.p, stream);
+      int nbk;
+      if (!w && r == fwd_rhs && pc_ready) nbk = launch_tri_back_dots(tri_args(), fwd_elim.p, z, partials.p, stream);
+      else nbk = launch_tri_solve_dots(tri_args(), r, z, w, partials.p, stream);
       launch_finalize_partials(nbk, w ? 2 : 1, partials.p, sc.p, stream);
     }
     if (comm.active()) comm.allreduce_sum(sc.p + S_SUM0, w ? 2 : 1, stream);
@@ -1495,7 +1509,7 @@ struct Solver {
     if (asm_sums) { double r2[2]; residual_sums(X, Fv, r2); fnorm = std::sqrt(r2[0]); } else fnorm = norm_host(Fv);
     int reason = snes_converged(0, 0.0, 0.0, fnorm, ttol, rnorm0);
     for (int i = 0; !reason && i < opt.snes_max_it; ++i) {
-      if (!jac_valid) op_jacobian(X);
+      if (!jac_valid) op_jacobian(X, Fv);
       int its = 0;
       const int kreason = ksp_solve(Fv, Yv, &its);
       *linear_its += its;
