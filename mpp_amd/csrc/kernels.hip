@@ -1241,12 +1241,14 @@ inline int red_grid(int n) {
 }
 
 // x <- alpha p + omega s + x ; r <- s - omega t ; partial sums of r.r   (bcgs.c)
-template <bool FIRST>  // FIRST: x is known to be zero (first iteration, zero initial guess) and is not read
+// FIRST: x is known to be zero (first iteration, zero initial guess) and is not read.  Later iterations also reduce
+// (r,rp), the next iteration's rho, while r is in registers (partials row 1).
+template <bool FIRST>
 __global__ __launch_bounds__(kBlock) void k_bcgs_xr(int n, double *X, double *R, const double *P, const double *S,
-                                                    const double *T, const double *sc, double *partials) {
+                                                    const double *T, const double *RP, const double *sc, double *partials) {
   __shared__ double lds[kBlock / 64];
   const double alpha = sc[S_ALPHA], omega = sc[S_OMEGA];
-  double acc = 0.0;
+  double acc = 0.0, acc2 = 0.0;
   vec2_loop(n, [&](size_t q) {
               const double2 s = CD2(S)[q], p = CD2(P)[q], t = CD2(T)[q], x = FIRST ? make_double2(0.0, 0.0) : CD2(X)[q];
               D2(X)[q] = make_double2(alpha * p.x + omega * s.x + x.x, alpha * p.y + omega * s.y + x.y);
@@ -1254,15 +1256,21 @@ __global__ __launch_bounds__(kBlock) void k_bcgs_xr(int n, double *X, double *R,
               D2(R)[q] = make_double2(r0, r1);
               acc += r0 * r0;
               acc += r1 * r1;
+              if (!FIRST) { const double2 rp = CD2(RP)[q]; acc2 += r0 * rp.x; acc2 += r1 * rp.y; }
             }, [&](size_t i) {
               const double s = S[i];
               X[i] = alpha * P[i] + omega * s + (FIRST ? 0.0 : X[i]);
               const double r = s - omega * T[i];
               R[i] = r;
               acc += r * r;
+              if (!FIRST) acc2 += r * RP[i];
             });
-  const double t = block_sum(acc, lds);
+  double t = block_sum(acc, lds);
   if (threadIdx.x == 0) partials[blockIdx.x] = t;
+  if (!FIRST) {
+    t = block_sum(acc2, lds);
+    if (threadIdx.x == 0) partials[(size_t)gridDim.x + blockIdx.x] = t;
+  }
 }
 
 // block-Jacobi apply with the Krylov dot products of its result fused in (the solve holds z_k in a register when it
@@ -1403,10 +1411,22 @@ __global__ __launch_bounds__(kBlock) void k_finalize(int nb, const double *parti
   if (threadIdx.x == 0) sc[S_SUM0 + j] = t;
 }
 
+// first of two stages for long partial lists: block (c, j) sums chunk c of vector j's partials into out[j*nchunk + c]
+__global__ __launch_bounds__(kBlock) void k_finalize_chunks(int nb, int chunk, const double *partials, double *out) {
+  __shared__ double lds[kBlock / 64];
+  const int c = blockIdx.x, j = blockIdx.y;
+  const int b0 = c * chunk, b1 = min(nb, b0 + chunk);
+  double acc = 0.0;
+  for (int b = b0 + threadIdx.x; b < b1; b += kBlock) acc += partials[(size_t)j * nb + b];
+  const double t = block_sum(acc, lds);
+  if (threadIdx.x == 0) out[(size_t)j * gridDim.x + c] = t;
+}
+
 __global__ void k_bcgs_scalars(int step, double *sc) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  if (step == 0) {  // rhoold = alpha = omegaold = 1
+  if (step == 0) {  // rhoold = alpha = omegaold = 1; dp0 = ||M^{-1} b|| from the (rp,rp) just reduced
     sc[S_RHOOLD] = 1.0; sc[S_ALPHA] = 1.0; sc[S_OMEGAOLD] = 1.0; sc[S_FLAG] = 0.0;
+    sc[S_DP0] = sqrt(sc[S_SUM0]);
   } else if (step == 1) {  // rho <- (r,rp); beta = (rho/rhoold)*(alpha/omegaold)
     const double rho = sc[S_SUM0];
     sc[S_RHO] = rho;
@@ -1420,9 +1440,14 @@ __global__ void k_bcgs_scalars(int step, double *sc) {
     sc[S_ST] = d1; sc[S_D2] = d2;
     if (d2 == 0.0) { sc[S_OMEGA] = 0.0; sc[S_FLAG] = 1.0; }  // t == 0: x += alpha p is the candidate solution
     else sc[S_OMEGA] = d1 / d2;
-  } else if (step == 4) {  // end of iteration: dp^2 = (r,r); rhoold = rho; omegaold = omega
+  } else if (step == 4) {  // end of iteration: dp^2 = (r,r); rhoold = rho; omegaold = omega; (r,rp) if it was reduced
     sc[S_DP] = sqrt(sc[S_SUM0]);
+    sc[S_RRP] = sc[S_SUM0 + 1];
     sc[S_RHOOLD] = sc[S_RHO]; sc[S_OMEGAOLD] = sc[S_OMEGA];
+  } else if (step == 5) {  // step 1 with rho = the (r,rp) the previous iteration's update reduced
+    const double rho = sc[S_RRP];
+    sc[S_RHO] = rho;
+    sc[S_BETA] = (rho / sc[S_RHOOLD]) * (sc[S_ALPHA] / sc[S_OMEGAOLD]);
   }
 }
 
@@ -1685,10 +1710,10 @@ void launch_bcgs_p(int n, double *P, const double *Pold, const double *R, const 
   if (n > 0) LAUNCH(k_bcgs_p, dim3(vec_grid(n)), n, P, Pold, R, V, sc);
 }
 int launch_bcgs_xr(int n, bool first, double *X, double *R, const double *P, const double *S, const double *T,
-                   const double *sc, double *partials, hipStream_t stream) {
+                   const double *RP, const double *sc, double *partials, hipStream_t stream) {
   const int g = red_grid(n);
-  if (first) LAUNCH(k_bcgs_xr<true>, dim3(g), n, X, R, P, S, T, sc, partials);
-  else LAUNCH(k_bcgs_xr<false>, dim3(g), n, X, R, P, S, T, sc, partials);
+  if (first) LAUNCH(k_bcgs_xr<true>, dim3(g), n, X, R, P, S, T, RP, sc, partials);
+  else LAUNCH(k_bcgs_xr<false>, dim3(g), n, X, R, P, S, T, RP, sc, partials);
   return g;
 }
 int launch_dots(const DotArgs &a, double *partials, hipStream_t stream) {
@@ -1716,6 +1741,14 @@ int launch_dots(const DotArgs &a, double *partials, hipStream_t stream) {
 }
 void launch_finalize_partials(int nblocks, int nvec, const double *partials, double *sc, hipStream_t stream) {
   LAUNCH(k_finalize, dim3(nvec), nblocks, partials, sc);
+}
+void launch_finalize_partials_long(int nblocks, int nvec, double *partials, double *sc, hipStream_t stream) {
+  constexpr int chunk = 2048;
+  if (nblocks <= 2 * chunk) { launch_finalize_partials(nblocks, nvec, partials, sc, stream); return; }
+  const int nchunk = (nblocks + chunk - 1) / chunk;
+  double *stage = partials + (size_t)nvec * nblocks;
+  LAUNCH(k_finalize_chunks, dim3(nchunk, nvec), nblocks, chunk, partials, stage);
+  LAUNCH(k_finalize, dim3(nvec), nchunk, stage, sc);
 }
 void launch_maxpy_neg(const MaxpyArgs &a, const double *sc, double *y, hipStream_t stream) {
   if (a.n > 0 && a.nvec > 0) LAUNCH(k_maxpy_neg, dim3(nblk(a.n)), a, sc, y);

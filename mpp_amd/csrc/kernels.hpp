@@ -10,7 +10,7 @@ namespace mpp {
 
 // device-resident scalar block shared by the Krylov/Newton kernels (doubles)
 enum ScalarSlot : int {
-  S_RHO = 0, S_RHOOLD, S_ALPHA, S_OMEGA, S_OMEGAOLD, S_BETA, S_D1, S_D2, S_DP, S_FLAG, S_ST,
+  S_RHO = 0, S_RHOOLD, S_ALPHA, S_OMEGA, S_OMEGAOLD, S_BETA, S_D1, S_D2, S_DP, S_FLAG, S_ST, S_DP0, S_RRP,
   S_SUM0 = 16,  // reduction results land in S_SUM0 .. S_SUM0+63
   S_COUNT = 96
 };
@@ -260,14 +260,18 @@ void launch_waxpy(int n, double *w, const double *sc, int slot, double sign, dou
 void launch_bcgs_p(int n, double *P, const double *Pold, const double *R, const double *V, const double *sc,
                    hipStream_t stream);
 // x <- alpha p + omega s + x (x not read when `first`: zero initial guess), r <- s - omega t; also leaves the
-// partial sums of r.r in `partials`; returns the number of partial blocks
+// partial sums of r.r in `partials` and, unless `first`, those of r.rp in its second row (the next iteration's rho);
+// returns the number of partial blocks
 int launch_bcgs_xr(int n, bool first, double *X, double *R, const double *P, const double *S, const double *T,
-                   const double *sc, double *partials, hipStream_t stream);
+                   const double *RP, const double *sc, double *partials, hipStream_t stream);
 // multi-dot: sums[j] = x . ys[j], j < nvec; two-stage deterministic reduction (partials -> sc[S_SUM0+j])
 struct DotArgs { int n, nvec; const double *x[kMaxMultiDot]; const double *y[kMaxMultiDot]; };
 // stage 1 only (returns number of partial blocks); stage 2 is launch_finalize_partials
 int launch_dots(const DotArgs &a, double *partials, hipStream_t stream);
 void launch_finalize_partials(int nblocks, int nvec, const double *partials, double *sc, hipStream_t stream);
+// the same for long lists (one partial per SpMV block): two stages, the first into the tail of `partials`, which must hold
+// nvec * (nblocks + ceil(nblocks / 2048)) doubles; the order of summation is fixed by nblocks alone
+void launch_finalize_partials_long(int nblocks, int nvec, double *partials, double *sc, hipStream_t stream);
 // y -= sum_j h[j] * v_j  (h on device at sc[S_SUM0+j]); GMRES classical Gram-Schmidt update
 struct MaxpyArgs { int n, nvec; const double *v[kMaxMultiDot]; };
 void launch_maxpy_neg(const MaxpyArgs &a, const double *sc, double *y, hipStream_t stream);

@@ -996,11 +996,12 @@ struct Solver {
     const int tpw = spmv_variant() == 20 ? 4 : 8, nv = x ? 3 : 2;
     {
       ProfScope ps(prof, KC_REDUCE);
-      const size_t need = 3 * (size_t)spmv_compact_dots_blocks(tpw, nred);
+      const size_t nbmax = (size_t)spmv_compact_dots_blocks(tpw, nred);
+      const size_t need = 3 * (nbmax + nbmax / 2048 + 1);
       if (spmv_partials.n < need) spmv_partials.alloc(need);
       const int nbk = launch_spmv_compact_dots(tpw, nred, max_row_nnz, d_tileptr.p, d_roff.p, d_dcol.p, d_val.p, y, f, x,
                                                spmv_partials.p, stream);
-      launch_finalize_partials(nbk, nv, spmv_partials.p, sc.p, stream);
+      launch_finalize_partials_long(nbk, nv, spmv_partials.p, sc.p, stream);
       if (comm.active()) comm.allreduce_sum(sc.p + S_SUM0, nv, stream);
     }
     fetch_scalars();
@@ -1238,17 +1239,27 @@ struct Solver {
     // already reduced for the convergence test, so r0 is written once into RP and aliased as R and P.
     KspConv cv{opt.ksp_rtol, opt.ksp_atol, opt.ksp_dtol};
     op_pc_apply_dots(b, RP.p, nullptr);   // leaves (rp,rp) in sc[S_SUM0]
-    fetch_scalars();
-    double dp = std::sqrt(h_sc[S_SUM0]);
     *its = 0;
-    int reason = ksp_converged(cv, 0, dp);
-    if (reason) { vec_set(0.0, x); return reason; }
+    // The convergence test of iteration 0 needs ||rp|| on the host.  Rather than stall the queue for it, the first
+    // iteration is issued at once and the test is made when its scalars come back: had it fired, the answer is the zero
+    // initial guess (restored below) and nothing else of the speculative iteration is visible.
     launch_bcgs_scalars(0, sc.p, stream);
+    bool test0_pending = true;
+    double dp = 0.0;
+    int reason = 0;
+    if (!opt.defer_test0) {
+      fetch_scalars();
+      test0_pending = false;
+      reason = ksp_converged(cv, 0, h_sc[S_DP0]);
+      if (reason) { vec_set(0.0, x); return reason; }
+    }
     const double *Rcur = RP.p, *Pcur = RP.p;
     int i = 0;
     do {
-      if (i > 0) dots_dev({{Rcur, RP.p}});
-      launch_bcgs_scalars(1, sc.p, stream);
+      // rho = (r,rp): the initial (rp,rp) at i == 0; a separate reduction at i == 1 (the first update does not read rp:
+      // most solves of the column-structured problems end there); afterwards the update kernel reduces it on the way
+      if (i == 1) dots_dev({{Rcur, RP.p}});
+      launch_bcgs_scalars(i >= 2 ? 5 : 1, sc.p, stream);
       if (i > 0) {
         ProfScope ps(prof, KC_VEC);
         launch_bcgs_p(nred, Pv.p, Pcur, Rcur, V.p, sc.p, stream);
@@ -1263,13 +1274,18 @@ struct Solver {
       launch_bcgs_scalars(3, sc.p, stream);
       {
         ProfScope ps(prof, KC_REDUCE);
-        const int nbk = launch_bcgs_xr(nred, i == 0, x, R.p, Pcur, S.p, T.p, sc.p, partials.p, stream);
-        launch_finalize_partials(nbk, 1, partials.p, sc.p, stream);
-        if (comm.active()) comm.allreduce_sum(sc.p + S_SUM0, 1, stream);
+        const int nbk = launch_bcgs_xr(nred, i == 0, x, R.p, Pcur, S.p, T.p, RP.p, sc.p, partials.p, stream);
+        launch_finalize_partials(nbk, i == 0 ? 1 : 2, partials.p, sc.p, stream);
+        if (comm.active()) comm.allreduce_sum(sc.p + S_SUM0, i == 0 ? 1 : 2, stream);
       }
       Rcur = R.p;
       launch_bcgs_scalars(4, sc.p, stream);
       fetch_scalars();
+      if (test0_pending) {
+        test0_pending = false;
+        reason = ksp_converged(cv, 0, h_sc[S_DP0]);
+        if (reason) { vec_set(0.0, x); return reason; }
+      }
       const double rho = h_sc[S_RHO], d1 = h_sc[S_D1];
       if (d1 == 0.0) return -5;
       if (h_sc[S_FLAG] != 0.0) {  // t == 0: x += alpha p was applied (omega forced to 0)
@@ -2019,6 +2035,7 @@ struct Solver {
     else if (key == "fused_trials") opt.fused_trials = (int)num();
     else if (key == "fused_predict") opt.fused_predict = num() != 0;
     else if (key == "fused_ls_dots") opt.fused_ls_dots = num() != 0;
+    else if (key == "defer_test0") opt.defer_test0 = num() != 0;
     else if (key == "fused_rows") opt.fused_rows = num() != 0;
     else if (key == "track_mass_exchange") opt.track_mass_exchange = num() != 0;
     else if (key == "temperature") temperature = num();
@@ -2441,7 +2458,7 @@ int mppgpu_bench_kernel(mppgpu_handle h, const char *name, int variant, int reps
     else if (k == "residual") { cls = mpp::KC_RESIDUAL; S.op_residual(S.soln.p, S.G.p); }
     else if (k == "jacobian") { cls = mpp::KC_JACOBIAN; S.op_jacobian(S.soln.p); }
     else if (k == "assemble_both") { cls = mpp::KC_JACOBIAN; S.op_residual_jacobian(S.soln.p, S.G.p); }
-    else if (k == "bcgs_xr") { cls = mpp::KC_VEC; mpp::launch_bcgs_xr(S.n, false, S.Y.p, S.R.p, S.Pv.p, S.S.p, S.T.p, S.sc.p, S.partials.p, S.stream); }
+    else if (k == "bcgs_xr") { cls = mpp::KC_VEC; mpp::launch_bcgs_xr(S.n, false, S.Y.p, S.R.p, S.Pv.p, S.S.p, S.T.p, S.RP.p, S.sc.p, S.partials.p, S.stream); }
     else if (k == "waxpy") { cls = mpp::KC_VEC; mpp::launch_waxpy(S.n, S.W.p, S.sc.p, -1, 1.0, 0.5, S.soln.p, S.G.p, S.stream); }
     else if (k == "dots3") { cls = mpp::KC_REDUCE; S.dots_dev({{S.Y.p, S.Y.p}, {S.soln.p, S.soln.p}, {S.F.p, S.W.p}}); }
     else if (k == "copy") { cls = mpp::KC_VEC; mpp::launch_copy(S.n, S.soln.p, S.G.p, S.stream); }

@@ -101,7 +101,9 @@ def test_config3_1024x1024x100_every_column_reproduces_the_reference_baseline(go
         assert colv.max() - colv.min() <= 1e-12 * abs(colv.max())   # all columns agree with each other
 
 
-def test_sharded_global_solve_on_one_gpu_equals_the_unsharded_solve():
+@pytest.mark.parametrize("extra", [{}, {"assembly": "columns", "nseg": 1, "spmv_variant": 20}],
+                         ids=["default", "fused_rows"])
+def test_sharded_global_solve_on_one_gpu_equals_the_unsharded_solve(extra):
     """SURVEY 8(e) on real kernels: the column set split over 3 handles (ranks) of this process, one host thread each,
     forming ONE global Newton-Krylov solve through the in-process communicator (same call sites as the RCCL
     all-reduce) -- every rank must take the same Newton / Krylov decisions and the assembled result must equal the
@@ -111,7 +113,7 @@ def test_sharded_global_solve_on_one_gpu_equals_the_unsharded_solve():
     from mpp_amd import vsfm as V
     ncols, nz, nranks = 203, 30, 3
     mult = np.exp(0.5 * np.random.default_rng(11).standard_normal(ncols))
-    opts = {"ksp_type": "bcgs", "pc_type": "bjacobi"}
+    opts = dict({"ksp_type": "bcgs", "pc_type": "bjacobi"}, **extra)   # fused_rows: every fused pass under a communicator
     ref_prob = P.celia1990(ncols=ncols, nz=nz, perm_mult=mult)
     ref = P.to_gpu(ref_prob, opts)
     shards = []
