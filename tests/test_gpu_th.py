@@ -188,3 +188,60 @@ def test_th_block_jacobi_is_the_exact_column_solve(ncols, nz):
     for var, tol in ((C.VAR_PRESSURE, 1e-6), (605, 1e-7)):
         a = g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, var); b = ref.soe.GetDataForCLM(C.AUXVAR_INTERNAL, var)
         assert np.abs(a - b).max() <= tol * np.abs(b).max()
+
+
+@pytest.mark.parametrize("ksp,pc", [("bcgs", "bjacobi"), ("gmres", "ilu")])
+def test_th_columns_sharded_over_ranks_equals_the_single_handle_solve(ksp, pc):
+    """BASELINE config 5 is a multi-GPU run: the soil columns of the coupled problem split over 3 handles (ranks) of this
+    process, one host thread each, joined through the in-process communicator (the call sites of the RCCL all-reduce) --
+    every rank takes the same Newton / Krylov decisions and the pieces equal the single-handle solution"""
+    import threading
+    from mpp_amd import parallel as PAR
+    from mpp_amd import vsfm as V
+    ncols, nz, nranks = 150, 12, 3
+    mult = np.exp(0.4 * np.random.default_rng(8).standard_normal(ncols))
+    opts = {"ksp_type": ksp, "pc_type": pc}
+    ref_tp = P.th_columns(ncols=ncols, nz=nz, perm_mult=mult)
+    ref = P.to_th_gpu(ref_tp, opts)
+    shards = []
+    for r in range(nranks):
+        c0, nloc = PAR.shard_columns(ncols, nranks, r)
+        tp = P.th_columns(ncols=nloc, nz=nz, perm_mult=mult[c0:c0 + nloc])
+        shards.append((c0, nloc, tp, P.to_th_gpu(tp, opts)))
+    V.comm_init_local([s[3].soe for s in shards])
+    nsteps = 2
+    results, errors = [None] * nranks, []
+
+    def run(r):
+        try:
+            _c0, _nloc, tp, g = shards[r]
+            out = []
+            for s in range(nsteps):
+                P.th_gpu_set_conditions(tp, g)
+                out.append(g.soe.StepDT(tp.dt, s + 1))
+            results[r] = out
+        except Exception as e:   # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(nranks)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    assert all(not t.is_alive() for t in threads)
+    ref_out = []
+    for s in range(nsteps):
+        P.th_gpu_set_conditions(ref_tp, ref)
+        ref_out.append(ref.soe.StepDT(ref_tp.dt, s + 1))
+    p_ref = ref.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE).reshape(ncols, nz)
+    t_ref = ref.soe.GetDataForCLM(C.AUXVAR_INTERNAL, 605).reshape(ncols, nz)
+    for r in range(nranks):
+        c0, nloc, _tp, g = shards[r]
+        assert results[r] == ref_out
+        assert g.soe.counters()["newton"] == ref.soe.counters()["newton"]
+        assert g.soe.counters()["linear"] == ref.soe.counters()["linear"]
+        p = g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE).reshape(nloc, nz)
+        t = g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, 605).reshape(nloc, nz)
+        assert np.abs(p - p_ref[c0:c0 + nloc]).max() <= 1e-9 * np.abs(p_ref).max()
+        assert np.abs(t - t_ref[c0:c0 + nloc]).max() <= 1e-9 * np.abs(t_ref).max()

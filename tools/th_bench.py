@@ -46,20 +46,40 @@ def main():
     ap.add_argument("--cpu-cols", type=int, default=256, help="columns of the CPU-oracle sample (0 = skip)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="extra mppgpu_set_option pairs")
     a = ap.parse_args()
-    ncols = a.nx * a.ny
+    # one process per GPU under torch.distributed.run (BASELINE config 5 is an 8-GPU run): the columns shard across the
+    # ranks, RCCL all-reduces the Krylov / Newton scalars -- the same set-up as bench.py
+    from mpp_amd import parallel as PAR
+    from mpp_amd import vsfm as V
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ
+    group = PAR.HostGroup() if launched else PAR.HostGroup(rank=0, world=1)
+    ncols_global = a.nx * a.ny
+    col0, ncols = PAR.shard_columns(ncols_global, world, rank)
     t0 = time.perf_counter()
-    tp = P.th_columns(ncols=ncols, nz=a.nz, perm_mult=np.exp(0.5 * np.random.default_rng(12345).standard_normal(ncols)))
+    mult = np.exp(0.5 * np.random.default_rng(12345).standard_normal(ncols_global))[col0:col0 + ncols]
+    tp = P.th_columns(ncols=ncols, nz=a.nz, perm_mult=mult)
     t_build = time.perf_counter() - t0
     t0 = time.perf_counter()
     opts = {"ksp_type": a.ksp, "pc_type": a.pc}
     opts.update(kv.split("=", 1) for kv in a.opt)
-    g = P.to_th_gpu(tp, opts)
+    g = P.to_th_gpu(tp, opts, device_id=int(os.environ.get("LOCAL_RANK", "0")))
+    if launched:
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)            # RCCL's banner goes to stderr, stdout keeps the one JSON line
+        try:
+            uid = group.broadcast_bytes(V.comm_get_unique_id() if rank == 0 else b"")
+            g.soe.comm_init(world, rank, uid)
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
     t_setup = time.perf_counter() - t0
     conv, reason = g.soe.StepDT(tp.dt, 1)          # warm-up (ILU analysis, allocations)
     c0 = g.soe.counters()
     g.soe.SetOption("profile", 1)
     g.soe.reset_stats()
     g.soe.synchronize()
+    group.barrier()
     t0 = time.perf_counter()
     for s in range(a.steps):
         P.th_gpu_set_conditions(tp, g)
@@ -67,11 +87,15 @@ def main():
         if not conv:
             break
     g.soe.synchronize()
-    t_steps = time.perf_counter() - t0
+    group.barrier()
+    t_steps = group.allreduce([time.perf_counter() - t0], op="max")[0]
     c1 = g.soe.counters()
     stats = {k: g.soe.kernel_stats(k) for k in ("spmv", "pc_apply", "pc_setup", "residual", "jacobian", "vec", "reduce")}
     newton = c1["newton"] - c0["newton"]
-    out = {"columns": ncols, "nz": a.nz, "cells": ncols * a.nz, "unknowns": 2 * ncols * a.nz, "ksp": a.ksp, "pc": a.pc,
+    if rank != 0:
+        return
+    out = {"n_gpus": world, "columns": ncols_global, "columns_per_gpu": ncols, "nz": a.nz, "cells": ncols_global * a.nz,
+           "unknowns": 2 * ncols_global * a.nz, "ksp": a.ksp, "pc": a.pc,
            "converged": conv, "reason": reason, "steps": a.steps, "newton_iterations": newton,
            "linear_iterations": c1["linear"] - c0["linear"], "time_cuts": c1["time_cuts"] - c0["time_cuts"],
            "newton_its_per_s": newton / t_steps, "steps_s": t_steps, "setup_s": t_setup, "build_s": t_build,
@@ -88,8 +112,8 @@ def main():
         out["roofline"] = {"kernel": "k_th_cols<2> (residual + 2x2-block Jacobian)", "bound": "hbm", "unit": "GB/s", "peak": 8000.0,
                            "achieved": round(by / (jk["avg_ms"] * 1e-3) / 1e9, 1), "frac": round(by / (jk["avg_ms"] * 1e-3) / 1e9 / 8000.0, 4),
                            "bytes_per_launch": by, "note": "pow/div-bound at occupancy 1 (256 VGPRs), not bandwidth-bound"}
-    if a.cpu_cols > 0:
-        out["cpu_baseline"] = cpu_baseline(a.cpu_cols, a.nz, ncols)
+    if a.cpu_cols > 0 and world == 1:
+        out["cpu_baseline"] = cpu_baseline(a.cpu_cols, a.nz, ncols_global)
     print(json.dumps(out), flush=True)
     if a.out:
         json.dump(out, open(a.out, "w"), indent=1)
