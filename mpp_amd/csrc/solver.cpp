@@ -409,10 +409,21 @@ struct Solver {
     cext2int.assign(nc, -1);
     int nlat = 0;
     if (columns) {
+      // lateral connections: the j-th one whose upwind cell is u sits at n + j*n + u, so that the rows of a column tile
+      // (consecutive u) read consecutive geometry entries whichever end of the connection they are (holes carry zeros)
+      std::vector<int> seen(n, 0);
+      int jmax = 0;
       for (int c = 0; c < nc; ++c) {
-        if (is_vert[c]) cext2int[c] = ext2int[cup_e[c]]; else cext2int[c] = n + nlat++;
+        if (is_vert[c]) cext2int[c] = ext2int[cup_e[c]];
+        else {
+          const int u = ext2int[cup_e[c]], j = seen[u]++;
+          if ((long long)n * (j + 2) > 0x7fffffffLL) throw Error("too many lateral connections per cell for 32-bit connection ids");
+          cext2int[c] = n + j * n + u;
+          jmax = std::max(jmax, j + 1);
+          ++nlat;
+        }
       }
-      nc_int = n + nlat;
+      nc_int = n + jmax * n;
       vertical_only = (nlat == 0);
     } else {
       for (int c = 0; c < nc; ++c) cext2int[c] = c;
