@@ -314,6 +314,57 @@ __global__ __launch_bounds__(kBlock) void k_flux_rows(GenArgs a) {
   }
 }
 
+// The same pass on an ELL copy of the incidence lists (ell_*[k*n + row], k-th incident connection of the row in the caller's
+// connection order, -1 when the row has fewer): every index a row needs arrives with one coalesced load, so the loads of
+// all its neighbours are in flight together instead of a chain of dependent look-ups per connection; off-diagonal entries
+// are stored once (every pattern entry of a row belongs to exactly one incident connection: checked at set-up).
+template <int MODE, int K>
+__global__ __launch_bounds__(kBlock) void k_flux_rows_ell(GenArgs a) {
+  constexpr bool RES = (MODE == 0 || MODE == 2), JAC = (MODE == 1 || MODE == 2);
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= (size_t)a.n) return;
+  const CellArrays &ca = a.cell;
+  const size_t n = (size_t)a.n;
+  int enc[K], oth[K], slot[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    enc[k] = k < a.ell_k ? a.ell_enc[k * n + i] : -1;
+    oth[k] = enc[k] >= 0 ? a.ell_o[k * n + i] : (int)i;
+    slot[k] = (JAC && enc[k] >= 0) ? a.ell_slot[k * n + i] : -1;
+  }
+  const bool mine = owns_row(ca, i);
+  Aux me;
+  me.P = ca.P[i]; me.kr = a.aux.kr[i]; me.den = a.aux.den[i];
+  me.dkr = JAC ? a.aux.dkr[i] : 0.0; me.dden = JAC ? a.aux.dden[i] : 0.0;
+  me.sat = me.dsat = 0.0;
+  double f = RES ? a.F[i] : 0.0;
+  double dconn = 0.0;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int o = oth[k];
+    const bool live = mine && enc[k] >= 0 && is_active(ca, o);
+    const int ic = enc[k] >= 0 ? (enc[k] >> 1) : 0, side = enc[k] & 1;
+    Aux ot;
+    ot.P = ca.P[o]; ot.kr = a.aux.kr[o]; ot.den = a.aux.den[o];
+    ot.dkr = JAC ? a.aux.dkr[o] : 0.0; ot.dden = JAC ? a.aux.dden[o] : 0.0;
+    ot.sat = ot.dsat = 0.0;
+    ConnGeom g;
+    g.Dq = a.conn.Dq[ic]; g.upweight = a.conn.upw[ic]; g.dist_gravity = a.conn.dgrav[ic]; g.area = a.conn.area[ic];
+    double Jup = 0.0, Jdn = 0.0;
+    const double flux = side == 0 ? richards_flux<JAC>(me, ot, g, 0, Jup, Jdn) : richards_flux<JAC>(ot, me, g, 0, Jup, Jdn);
+    if (RES && live) f = side == 0 ? f - flux : f + flux;
+    if (JAC) {
+      if (live) dconn += side == 0 ? Jup : -Jdn;
+      if (slot[k] >= 0) a.val[slot[k]] = live ? (side == 0 ? Jdn : -Jup) : 0.0;
+    }
+  }
+  if (JAC && mine) a.val[a.diag_slot[i]] = dconn + a.val[a.diag_slot[i]];
+  if (RES) {
+    if (a.src) f -= a.src[i];
+    a.F[i] = f;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // boundary conditions (GE:1815-1877 residual, 2076-2139 Jacobian): the BC auxvar has the soil of its id_dn
 // cell (MultiPhysicsProbVSFM.F90:422-446) and pressure = condition value for Dirichlet/seepage, = P_dn for
@@ -1514,6 +1565,17 @@ void launch_assemble_cols(int mode, const ColsArgs &a, hipStream_t stream) {
 void launch_assemble_general(int mode, const GenArgs &a, hipStream_t stream) {
   if (a.n <= 0) return;
   dim3 grid(nblk(a.n));
+  if (a.ell_enc && a.ell_k <= 8) {
+    if (mode == 0) LAUNCH(k_auxvars<0>, grid, a); else if (mode == 1) LAUNCH(k_auxvars<1>, grid, a); else LAUNCH(k_auxvars<2>, grid, a);
+    if (a.ell_k <= 6) {
+      if (mode == 0) LAUNCH((k_flux_rows_ell<0, 6>), grid, a); else if (mode == 1) LAUNCH((k_flux_rows_ell<1, 6>), grid, a);
+      else LAUNCH((k_flux_rows_ell<2, 6>), grid, a);
+    } else {
+      if (mode == 0) LAUNCH((k_flux_rows_ell<0, 8>), grid, a); else if (mode == 1) LAUNCH((k_flux_rows_ell<1, 8>), grid, a);
+      else LAUNCH((k_flux_rows_ell<2, 8>), grid, a);
+    }
+    return;
+  }
   if (mode == 0) { LAUNCH(k_auxvars<0>, grid, a); LAUNCH(k_flux_rows<0>, grid, a); }
   else if (mode == 1) { LAUNCH(k_auxvars<1>, grid, a); LAUNCH(k_flux_rows<1>, grid, a); }
   else { LAUNCH(k_auxvars<2>, grid, a); LAUNCH(k_flux_rows<2>, grid, a); }

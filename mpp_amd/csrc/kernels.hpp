@@ -72,6 +72,10 @@ struct GenArgs {
   ConnArrays conn;
   const int *cup, *cdn;                 // connection end cells
   const int *rc_ptr, *rc_conn, *rc_slot; // per-row incident connections ((conn<<1)|side), off-diagonal slot
+  // the same lists in ELL form, [k*n + row] (enc = (conn<<1)|side or -1, the other end cell, the off-diagonal slot);
+  // nullptr when a row has more than 8 incident connections or two connections share a matrix entry
+  const int *ell_enc = nullptr, *ell_o = nullptr, *ell_slot = nullptr;
+  int ell_k = 0;
   const int *diag_slot, *rowptr;
   const double *accum_prev, *src;
   AuxOut aux;

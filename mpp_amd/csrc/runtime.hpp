@@ -151,6 +151,7 @@ struct Options {
   bool fused_rows = true;      // column march with the boundary fluxes folded in: complete rows -> ||F||, ||X|| and the
                                // column LU come out of the assembly pass (see Solver::rows_complete)
   bool defer_test0 = true;     // bcgs: iteration 0's convergence test is made when the first iteration's scalars come back
+  bool ell_assembly = true;    // general assembly on the ELL copy of the incidence lists (k_flux_rows_ell)
   bool fused_predict = true;   // skip the fused Jacobian at the first trial when the previous line search backtracked
   int fused_trials = 2;        // ... for the first `fused_trials` trial points of a line search (later ones: F only)
 };

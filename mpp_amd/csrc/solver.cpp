@@ -115,7 +115,8 @@ struct Solver {
   DevBuf<signed char> d_active;
   DevBuf<double> d_Dq, d_upw, d_dgrav, d_area;
   DevBuf<int> d_cup, d_cdn;
-  DevBuf<int> d_rowptr, d_col, d_diag, d_rc_ptr, d_rc_conn, d_rc_slot, d_tri_lo, d_tri_up;
+  DevBuf<int> d_rowptr, d_col, d_diag, d_rc_ptr, d_rc_conn, d_rc_slot, d_tri_lo, d_tri_up, d_ell_enc, d_ell_o, d_ell_slot;
+  int ell_k = 0;   // incident connections per row in the ELL copy (0: none)
   DevBuf<double> d_val;
   // compact SpMV index (see k_spmv_pipe_c): built when the pattern allows it
   DevBuf<int> d_tileptr;
@@ -417,7 +418,7 @@ struct Solver {
         if (is_vert[c]) cext2int[c] = ext2int[cup_e[c]];
         else {
           const int u = ext2int[cup_e[c]], j = seen[u]++;
-          if ((long long)n * (j + 2) > 0x7fffffffLL) throw Error("too many lateral connections per cell for 32-bit connection ids");
+          if ((long long)n * (j + 2) > 0x3fffffffLL) throw Error("too many lateral connections per cell for 32-bit connection ids");
           cext2int[c] = n + j * n + u;
           jmax = std::max(jmax, j + 1);
           ++nlat;
@@ -510,6 +511,33 @@ struct Solver {
       }
       d_rc_ptr.upload(ptr, stream); d_rc_conn.upload(rconn, stream); d_rc_slot.upload(rslot, stream);
       aux_kr.alloc(n); aux_dkr.alloc(n); aux_den.alloc(n); aux_dden.alloc(n);
+      // ELL copy for k_flux_rows_ell (rows of <= 8 incident connections, one connection per matrix entry)
+      ell_k = 0;
+      if (!thermal && !th) {
+        int kmax = 0;
+        bool one_to_one = true;
+        for (int i = 0; i < n; ++i) {
+          kmax = std::max(kmax, ptr[i + 1] - ptr[i]);
+          for (int e = ptr[i]; e < ptr[i + 1] && one_to_one; ++e)
+            for (int e2 = ptr[i]; e2 < e; ++e2)
+              if (rslot[e2] == rslot[e]) { one_to_one = false; break; }
+        }
+        if (kmax > 0 && kmax <= 8 && one_to_one) {
+          std::vector<int> enc((size_t)kmax * n, -1), oth((size_t)kmax * n, 0), slt((size_t)kmax * n, -1);
+          for (int i = 0; i < n; ++i)
+            for (int e = ptr[i], k = 0; e < ptr[i + 1]; ++e, ++k) {
+              const size_t q = (size_t)k * n + i;
+              enc[q] = rconn[e]; slt[q] = rslot[e];
+            }
+          // the other end of every incidence: from the connection end cells (internal numbering)
+          std::vector<int> upc(nc_int, 0), dnc(nc_int, 0);
+          for (int c = 0; c < nc; ++c) { upc[cext2int[c]] = ext2int[cup_e[c]]; dnc[cext2int[c]] = ext2int[cdn_e[c]]; }
+          for (size_t q = 0; q < enc.size(); ++q)
+            if (enc[q] >= 0) oth[q] = (enc[q] & 1) ? upc[enc[q] >> 1] : dnc[enc[q] >> 1];
+          d_ell_enc.upload(enc, stream); d_ell_o.upload(oth, stream); d_ell_slot.upload(slt, stream);
+          ell_k = kmax;
+        }
+      }
     }
     // tridiagonal slots of the per-column blocks
     {
@@ -872,6 +900,7 @@ struct Solver {
     a.cell = cells(P); a.conn = conns();
     a.cup = d_cup.p; a.cdn = d_cdn.p;
     a.rc_ptr = d_rc_ptr.p; a.rc_conn = d_rc_conn.p; a.rc_slot = d_rc_slot.p;
+    if (ell_k > 0 && opt.ell_assembly) { a.ell_enc = d_ell_enc.p; a.ell_o = d_ell_o.p; a.ell_slot = d_ell_slot.p; a.ell_k = ell_k; }
     a.diag_slot = d_diag.p; a.rowptr = d_rowptr.p;
     a.accum_prev = accum_prev.p; a.src = has_src ? d_src.p : nullptr;
     a.aux = AuxOut{aux_kr.p, aux_dkr.p, aux_den.p, aux_dden.p};
@@ -2046,6 +2075,7 @@ struct Solver {
     else if (key == "fused_trials") opt.fused_trials = (int)num();
     else if (key == "fused_predict") opt.fused_predict = num() != 0;
     else if (key == "fused_ls_dots") opt.fused_ls_dots = num() != 0;
+    else if (key == "ell_assembly") opt.ell_assembly = num() != 0;
     else if (key == "defer_test0") opt.defer_test0 = num() != 0;
     else if (key == "fused_rows") opt.fused_rows = num() != 0;
     else if (key == "track_mass_exchange") opt.track_mass_exchange = num() != 0;
