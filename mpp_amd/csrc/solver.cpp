@@ -1073,7 +1073,7 @@ struct Solver {
   }
   int spmv_variant() const {
     if (opt.spmv_variant >= 0) return opt.spmv_variant;
-    if (compact_index && nrow >= (1 << 23)) return 20;
+    if (compact_index && nrow >= (1 << 21)) return 20;   // measured: ahead of the stream kernel from ~2 M rows (3- and 7-point)
     // measured on MI355X (profiles/): the software-pipelined wave kernel wins once there are enough row tiles to
     // fill the chip several times over; the block CSR-stream kernel wins on small, cache-resident matrices
     return (max_row_nnz <= 8 && nrow >= (1 << 23)) ? 17 : 1;
