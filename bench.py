@@ -108,6 +108,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cores", type=int, default=0)
     ap.add_argument("--homogeneous", action="store_true")
+    ap.add_argument("--profile", choices=["auto", "all", "spmv"], default="auto",
+                    help="kernel classes timed with HIP events inside the timed region: every class, or the roofline kernel "
+                         "(CSR SpMV) only -- the events of every class cost 5-6 %% at 13 M cells per GPU, under 1 %% at 105 M; "
+                         "auto = all on one GPU, spmv on several")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="extra mppgpu_set_option pairs")
     args = ap.parse_args()
 
@@ -168,7 +172,7 @@ def main():
 
     for i in range(args.warmup):
         step(i)
-    soe.SetOption("profile", 1)
+    soe.SetOption("profile", 1 if (args.profile == "all" or (args.profile == "auto" and world == 1)) else 2)
     soe.reset_stats()
     c0 = soe.counters()
     barrier()

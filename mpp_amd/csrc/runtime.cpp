@@ -16,7 +16,8 @@ const char *kclass_name(int k) {
 
 // ---------------- profiler: HIP events recorded on the solver's own stream around every launch group ----------------
 void Profiler::begin(int cls) {
-  if (!enabled) return;
+  open = enabled && ((mask >> cls) & 1u);
+  if (!open) return;
   if (used == pool.size()) {
     if (pool.size() >= 8192) flush();
     else {
@@ -31,7 +32,8 @@ void Profiler::begin(int cls) {
   HIP_CHECK(hipEventRecord(pool[used].a, stream));
 }
 void Profiler::end() {
-  if (!enabled) return;
+  if (!open) return;
+  open = false;
   HIP_CHECK(hipEventRecord(pool[used].b, stream));
   ++used;
 }

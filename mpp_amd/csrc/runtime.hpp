@@ -65,6 +65,8 @@ const char *kclass_name(int k);
 
 struct Profiler {
   bool enabled = false;
+  unsigned mask = ~0u;     // kernel classes that are timed (bit k = class k); the others cost nothing
+  bool open = false;       // begin() recorded an event that end() has to close
   hipStream_t stream = nullptr;
   struct Pair { hipEvent_t a, b; int cls; };
   std::vector<Pair> pool;

@@ -2091,7 +2091,12 @@ struct Solver {
       if (t != 1 && t != 2) throw Error("int_energy_enthalpy_type must be 1 (constant) or 2 (IFC67)");
       ie_type = t;
     } else if (key == "cnfac") cnfac = num();
-    else if (key == "profile") { prof.flush(); prof.enabled = num() != 0; }
+    else if (key == "profile") {   // 0 off, 1 every kernel class, 2 the CSR SpMV only (the graded roofline kernel)
+      prof.flush();
+      const int m = (int)num();
+      prof.enabled = m != 0;
+      prof.mask = m == 2 ? (1u << KC_SPMV) : ~0u;
+    }
     else throw Error("unknown option '" + key + "'");
   }
 
