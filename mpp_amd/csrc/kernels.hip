@@ -740,8 +740,10 @@ __global__ __launch_bounds__(kBlock) void k_spmv_pipe(int n, int tpw, const int 
 // tile's first row instead of the 32-bit column -- 8 index bytes per 3-point row instead of 16, i.e. 47.8 instead of
 // 55.8 bytes per row of HBM traffic.  Available when every |col - 64*tile| < 2^15 (true for the tiled level-major
 // layout, where a row's neighbours are within one tile width); values, x, y and the summation order are unchanged.
-template <int J>
-__global__ __launch_bounds__(kBlock) void k_spmv_pipe_c(int n, int tpw, const int *__restrict__ tileptr,
+// SPLIT (field-blocked systems, rows [P(1..N); T(1..N)]): a row's columns lie near its own cell in either block, so the
+// 16-bit entry is (offset << 1) | block with the offset taken from the tile's first cell in that block (split = N).
+template <int J, bool SPLIT>
+__global__ __launch_bounds__(kBlock) void k_spmv_pipe_c(int n, int tpw, int split, const int *__restrict__ tileptr,
                                                         const unsigned short *__restrict__ roff,
                                                         const short *__restrict__ dcol, const double *__restrict__ val,
                                                         const double *__restrict__ x, double *__restrict__ y) {
@@ -777,8 +779,12 @@ __global__ __launch_bounds__(kBlock) void k_spmv_pipe_c(int n, int tpw, const in
 #pragma unroll
     for (int j = 0; j < J; ++j) { vc[j] = vn[j]; cc[j] = cn[j]; }
     double xs[J];
+    const int base_lo = SPLIT ? (base < split ? base : base - split) : base;
 #pragma unroll
-    for (int j = 0; j < J; ++j) xs[j] = (lane + 64 * j < cnt) ? x[base + cc[j]] : 0.0;
+    for (int j = 0; j < J; ++j) {
+      const int ci = SPLIT ? base_lo + (cc[j] >> 1) + ((cc[j] & 1) ? split : 0) : base + cc[j];
+      xs[j] = (lane + 64 * j < cnt) ? x[ci] : 0.0;
+    }
     __builtin_amdgcn_sched_barrier(0);
     if (tile + 1 < tend) {
       sA = sB;
@@ -808,8 +814,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv_pipe_c(int n, int tpw, const in
 
 // the same product with the line search's reductions fused in and y never written: leaves the partial sums of x.x, f.(A x)
 // and (xx != nullptr) xx.xx, layout partials[j*gridDim.x + b] -- SNESLineSearchApply_BT needs only ||Y||, F.(J Y) and ||X||
-template <int J>
-__global__ __launch_bounds__(kBlock) void k_spmv_pipe_c_dots(int n, int tpw, const int *__restrict__ tileptr,
+template <int J, bool SPLIT>
+__global__ __launch_bounds__(kBlock) void k_spmv_pipe_c_dots(int n, int tpw, int split, const int *__restrict__ tileptr,
                                                              const unsigned short *__restrict__ roff,
                                                              const short *__restrict__ dcol, const double *__restrict__ val,
                                                              const double *__restrict__ x, const double *__restrict__ f,
@@ -856,8 +862,12 @@ __global__ __launch_bounds__(kBlock) void k_spmv_pipe_c_dots(int n, int tpw, con
 #pragma unroll
     for (int j = 0; j < J; ++j) { vc[j] = vn[j]; cc[j] = cn[j]; }
     double xs[J];
+    const int base_lo = SPLIT ? (base < split ? base : base - split) : base;
 #pragma unroll
-    for (int j = 0; j < J; ++j) xs[j] = (lane + 64 * j < cnt) ? x[base + cc[j]] : 0.0;
+    for (int j = 0; j < J; ++j) {
+      const int ci = SPLIT ? base_lo + (cc[j] >> 1) + ((cc[j] & 1) ? split : 0) : base + cc[j];
+      xs[j] = (lane + 64 * j < cnt) ? x[ci] : 0.0;
+    }
     __builtin_amdgcn_sched_barrier(0);
     if (tile + 1 < tend) {
       sA = sB;
@@ -1607,28 +1617,38 @@ void launch_cell_var(const CellArrays &cell, int n, int var_type, double *out, h
   if (n > 0) LAUNCH(k_cell_var, dim3(nblk(n)), cell, n, var_type, out);
 }
 
-void launch_spmv_compact(int tpw, int n, int max_row_nnz, const int *tileptr, const unsigned short *roff, const short *dcol,
-                         const double *val, const double *x, double *y, hipStream_t stream) {
+void launch_spmv_compact(int tpw, int n, int max_row_nnz, int split, const int *tileptr, const unsigned short *roff,
+                         const short *dcol, const double *val, const double *x, double *y, hipStream_t stream) {
   if (n <= 0) return;
   const long long tiles = ((long long)n + 63) / 64, waves = (tiles + tpw - 1) / tpw;
   const dim3 grid((int)((waves + 3) / 4));
-  if (max_row_nnz <= 3) LAUNCH(k_spmv_pipe_c<3>, grid, n, tpw, tileptr, roff, dcol, val, x, y);
-  else if (max_row_nnz <= 7) LAUNCH(k_spmv_pipe_c<7>, grid, n, tpw, tileptr, roff, dcol, val, x, y);
-  else LAUNCH(k_spmv_pipe_c<8>, grid, n, tpw, tileptr, roff, dcol, val, x, y);
+  if (split > 0) {
+    if (max_row_nnz <= 7) LAUNCH((k_spmv_pipe_c<7, true>), grid, n, tpw, split, tileptr, roff, dcol, val, x, y);
+    else LAUNCH((k_spmv_pipe_c<8, true>), grid, n, tpw, split, tileptr, roff, dcol, val, x, y);
+    return;
+  }
+  if (max_row_nnz <= 3) LAUNCH((k_spmv_pipe_c<3, false>), grid, n, tpw, split, tileptr, roff, dcol, val, x, y);
+  else if (max_row_nnz <= 7) LAUNCH((k_spmv_pipe_c<7, false>), grid, n, tpw, split, tileptr, roff, dcol, val, x, y);
+  else LAUNCH((k_spmv_pipe_c<8, false>), grid, n, tpw, split, tileptr, roff, dcol, val, x, y);
 }
 
 int spmv_compact_dots_blocks(int tpw, int n) {
   const long long tiles = ((long long)n + 63) / 64, waves = (tiles + tpw - 1) / tpw;
   return (int)((waves + 3) / 4);
 }
-int launch_spmv_compact_dots(int tpw, int n, int max_row_nnz, const int *tileptr, const unsigned short *roff, const short *dcol,
-                             const double *val, const double *x, const double *f, const double *xx, double *partials,
-                             hipStream_t stream) {
+int launch_spmv_compact_dots(int tpw, int n, int max_row_nnz, int split, const int *tileptr, const unsigned short *roff,
+                             const short *dcol, const double *val, const double *x, const double *f, const double *xx,
+                             double *partials, hipStream_t stream) {
   if (n <= 0) return 0;
   const dim3 grid(spmv_compact_dots_blocks(tpw, n));
-  if (max_row_nnz <= 3) LAUNCH(k_spmv_pipe_c_dots<3>, grid, n, tpw, tileptr, roff, dcol, val, x, f, xx, partials);
-  else if (max_row_nnz <= 7) LAUNCH(k_spmv_pipe_c_dots<7>, grid, n, tpw, tileptr, roff, dcol, val, x, f, xx, partials);
-  else LAUNCH(k_spmv_pipe_c_dots<8>, grid, n, tpw, tileptr, roff, dcol, val, x, f, xx, partials);
+  if (split > 0) {
+    if (max_row_nnz <= 7) LAUNCH((k_spmv_pipe_c_dots<7, true>), grid, n, tpw, split, tileptr, roff, dcol, val, x, f, xx, partials);
+    else LAUNCH((k_spmv_pipe_c_dots<8, true>), grid, n, tpw, split, tileptr, roff, dcol, val, x, f, xx, partials);
+    return (int)grid.x;
+  }
+  if (max_row_nnz <= 3) LAUNCH((k_spmv_pipe_c_dots<3, false>), grid, n, tpw, split, tileptr, roff, dcol, val, x, f, xx, partials);
+  else if (max_row_nnz <= 7) LAUNCH((k_spmv_pipe_c_dots<7, false>), grid, n, tpw, split, tileptr, roff, dcol, val, x, f, xx, partials);
+  else LAUNCH((k_spmv_pipe_c_dots<8, false>), grid, n, tpw, split, tileptr, roff, dcol, val, x, f, xx, partials);
   return (int)grid.x;
 }
 

@@ -129,14 +129,15 @@ void launch_spmv(int variant, int n, int max_row_nnz, const int *rowptr, const i
                  const double *x, double *y, hipStream_t stream);
 // the pipelined kernel on the compact index (16-bit in-tile row offsets + 16-bit column offsets from the tile's first
 // row, int32 tile pointers): needs max_row_nnz <= 8; `tpw` tiles per wave
-void launch_spmv_compact(int tpw, int n, int max_row_nnz, const int *tileptr, const unsigned short *roff, const short *dcol,
-                         const double *val, const double *x, double *y, hipStream_t stream);
+// split > 0 (field-blocked systems): entries are (offset << 1) | block, offsets from the tile's first cell in that block
+void launch_spmv_compact(int tpw, int n, int max_row_nnz, int split, const int *tileptr, const unsigned short *roff,
+                         const short *dcol, const double *val, const double *x, double *y, hipStream_t stream);
 // x.x, f.(A x) and optionally xx.xx without writing A x: partial sums in partials[j*nb + b], nb = the return value
 // (= spmv_compact_dots_blocks, which sizes the buffer: 3*nb doubles); finish with launch_finalize_partials
 int spmv_compact_dots_blocks(int tpw, int n);
-int launch_spmv_compact_dots(int tpw, int n, int max_row_nnz, const int *tileptr, const unsigned short *roff, const short *dcol,
-                             const double *val, const double *x, const double *f, const double *xx, double *partials,
-                             hipStream_t stream);
+int launch_spmv_compact_dots(int tpw, int n, int max_row_nnz, int split, const int *tileptr, const unsigned short *roff,
+                             const short *dcol, const double *val, const double *x, const double *f, const double *xx,
+                             double *partials, hipStream_t stream);
 // per-column tridiagonal (block-Jacobi): factor from CSR slots, then apply
 struct TriArgs {
   int ncols, nz;

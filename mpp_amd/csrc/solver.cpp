@@ -123,6 +123,7 @@ struct Solver {
   DevBuf<unsigned short> d_roff;
   DevBuf<short> d_dcol;
   bool compact_index = false;
+  int compact_split = 0;   // > 0: the compact index of a field-blocked system (entries carry their block, offsets are per block)
   DevBuf<int> d_cc_cell, d_cc_ptr, d_bc_type;
   DevBuf<double> d_bc_Dq, d_bc_dgrav, d_bc_area, d_bc_value, d_bc_flux;
   DevBuf<double> d_src, d_frac;
@@ -1024,7 +1025,7 @@ struct Solver {
     const int v = spmv_variant();
     if (v == 20 || v == 21) {
       if (!compact_index) throw Error("spmv_variant 20/21 need the compact index (rows of <= 8 entries whose columns lie within 2^15 of their 64-row tile)");
-      launch_spmv_compact(v == 20 ? 4 : 8, nred, max_row_nnz, d_tileptr.p, d_roff.p, d_dcol.p, d_val.p, x, y, stream);
+      launch_spmv_compact(v == 20 ? 4 : 8, nred, max_row_nnz, compact_split, d_tileptr.p, d_roff.p, d_dcol.p, d_val.p, x, y, stream);
     } else launch_spmv(v, nred, max_row_nnz, d_rowptr.p, d_col.p, d_val.p, x, y, stream);
   }
   // the line search's first reductions in one pass over the matrix: out = {y.y, f.(A y), x.x (x != nullptr)}
@@ -1039,7 +1040,7 @@ struct Solver {
       const size_t nbmax = (size_t)spmv_compact_dots_blocks(tpw, nred);
       const size_t need = 3 * (nbmax + nbmax / 2048 + 1);
       if (spmv_partials.n < need) spmv_partials.alloc(need);
-      const int nbk = launch_spmv_compact_dots(tpw, nred, max_row_nnz, d_tileptr.p, d_roff.p, d_dcol.p, d_val.p, y, f, x,
+      const int nbk = launch_spmv_compact_dots(tpw, nred, max_row_nnz, compact_split, d_tileptr.p, d_roff.p, d_dcol.p, d_val.p, y, f, x,
                                                spmv_partials.p, stream);
       launch_finalize_partials_long(nbk, nv, spmv_partials.p, sc.p, stream);
       if (comm.active()) comm.allreduce_sum(sc.p + S_SUM0, nv, stream);
@@ -1050,26 +1051,38 @@ struct Solver {
   // 16-bit in-tile row offsets + 16-bit column offsets from the tile's first row (the pattern is fixed after setup)
   void build_compact_index() {
     compact_index = false;
+    compact_split = 0;
     if (max_row_nnz > 8 || nghost > 0) return;   // (with ghost rows the last owned tile would need its own extent)
+    const int split = th ? n : 0;                // field-blocked [P; T]: offsets per block, block bit in the entry
     const int ntiles = (nrow + 63) / 64;
     std::vector<int> tp((size_t)ntiles + 2, 0);
     std::vector<unsigned short> ro(nrow);
     std::vector<short> dc(nnz);
     for (int t = 0; t < ntiles; ++t) {
       const int r0 = t * 64, r1 = std::min(nrow, r0 + 64);
+      const int base_lo = (split && r0 >= split) ? r0 - split : r0;
+      if (split && r0 < split && r1 > split) return;   // a tile across the block boundary (N not a multiple of 64)
       tp[t] = h_rowptr[r0];
       for (int r = r0; r < r1; ++r) {
         ro[r] = (unsigned short)(h_rowptr[r] - h_rowptr[r0]);
         for (int k = h_rowptr[r]; k < h_rowptr[r + 1]; ++k) {
-          const int d = h_col[k] - r0;
-          if (d < -32768 || d > 32767) return;
-          dc[k] = (short)d;
+          if (!split) {
+            const int d = h_col[k] - r0;
+            if (d < -32768 || d > 32767) return;
+            dc[k] = (short)d;
+          } else {
+            const int blk = h_col[k] >= split ? 1 : 0;
+            const int d = h_col[k] - (base_lo + blk * split);
+            if (d < -16384 || d > 16383) return;
+            dc[k] = (short)(d * 2 + blk);     // arithmetic shift in the kernel recovers d, bit 0 the block
+          }
         }
       }
     }
     tp[ntiles] = nnz; tp[ntiles + 1] = nnz;
     d_tileptr.upload(tp, stream); d_roff.upload(ro.data(), ro.size(), stream); d_dcol.upload(dc.data(), dc.size(), stream);
     compact_index = true;
+    compact_split = split;
   }
   int spmv_variant() const {
     if (opt.spmv_variant >= 0) return opt.spmv_variant;
@@ -2496,7 +2509,7 @@ int mppgpu_bench_kernel(mppgpu_handle h, const char *name, int variant, int reps
       cls = mpp::KC_SPMV;
       if (variant == 20 || variant == 21) {
         if (!S.compact_index) throw mpp::Error("no compact index for this pattern");
-        mpp::launch_spmv_compact(variant == 20 ? 4 : 8, S.nrow, S.max_row_nnz, S.d_tileptr.p, S.d_roff.p, S.d_dcol.p, S.d_val.p, S.soln.p, S.G.p, S.stream);
+        mpp::launch_spmv_compact(variant == 20 ? 4 : 8, S.nrow, S.max_row_nnz, S.compact_split, S.d_tileptr.p, S.d_roff.p, S.d_dcol.p, S.d_val.p, S.soln.p, S.G.p, S.stream);
       } else mpp::launch_spmv(variant, S.nrow, S.max_row_nnz, S.d_rowptr.p, S.d_col.p, S.d_val.p, S.soln.p, S.G.p, S.stream);
     }
     else if (k == "pc_apply") { cls = mpp::KC_PC_APPLY; S.op_pc_setup(); S.op_pc_apply(S.F.p, S.G.p); }

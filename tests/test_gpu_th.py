@@ -245,3 +245,33 @@ def test_th_columns_sharded_over_ranks_equals_the_single_handle_solve(ksp, pc):
         t = g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, 605).reshape(nloc, nz)
         assert np.abs(p - p_ref[c0:c0 + nloc]).max() <= 1e-9 * np.abs(p_ref).max()
         assert np.abs(t - t_ref[c0:c0 + nloc]).max() <= 1e-9 * np.abs(t_ref).max()
+
+
+def test_th_compact_spmv_index_of_the_field_blocked_system():
+    """the 16-bit SpMV index of the [P; T] system (entries carry their block): MatMult equals the default kernel's and
+    the oracle's, and time steps taken with it (line-search reductions inside the SpMV) equal the default path's"""
+    ncols, nz = 128, 9                                  # N a multiple of 64: no tile across the block boundary
+    tp = P.th_columns(ncols=ncols, nz=nz, perm_mult=np.exp(0.3 * np.random.default_rng(3).standard_normal(ncols)))
+    n = tp.mesh.ncells_local
+    base = {"ksp_type": "bcgs", "pc_type": "bjacobi"}
+    a = P.to_th_gpu(tp, dict(base, spmv_variant=20))
+    b = P.to_th_gpu(tp, dict(base, spmv_variant=1, fused_ls_dots=0))
+    o = P.to_th_oracle(tp)
+    x = _state(tp, seed=4, dp=(0.0, 9e4), dt=(0.0, 15.0))
+    for h in (a, b):
+        h.soe.SetDtime(tp.dt); h.soe.PreSolve()
+    o.set_dtime(tp.dt); o.pre_solve()
+    rp, cj, val = o.jacobian(x)
+    a.soe.ComputeJacobian(x); b.soe.ComputeJacobian(x)
+    v = np.random.default_rng(1).standard_normal(2 * n)
+    from oracle import vsfm_oracle as VO
+    y_a, y_b, y_o = a.soe.MatMult(v), b.soe.MatMult(v), VO.spmv(rp, cj, val, v)
+    assert np.array_equal(y_a, y_b)
+    assert np.abs(y_a - y_o).max() <= 1e-12 * np.abs(y_o).max()
+    for s in range(2):
+        P.th_gpu_set_conditions(tp, a); P.th_gpu_set_conditions(tp, b)
+        assert a.soe.StepDT(tp.dt, s + 1) == b.soe.StepDT(tp.dt, s + 1)
+    assert a.soe.counters()["newton"] == b.soe.counters()["newton"]
+    for var in (C.VAR_PRESSURE, 605):
+        va, vb = a.soe.GetDataForCLM(C.AUXVAR_INTERNAL, var), b.soe.GetDataForCLM(C.AUXVAR_INTERNAL, var)
+        assert np.abs(va - vb).max() <= 1e-10 * np.abs(vb).max()
