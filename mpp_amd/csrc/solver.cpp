@@ -143,7 +143,7 @@ struct Solver {
   DevBuf<double> soln, soln_prev, accum_prev, F, Y, W, G, R, RP, V, T, S, Pv, Wk, tmp_ext, tmp_int;
   DevBuf<double> aux_kr, aux_dkr, aux_den, aux_dden;
   DevBuf<double> tri_l, tri_invb, tri_c, jac_invd;
-  DevBuf<double> partials, sc, spmv_partials;
+  DevBuf<double> partials, sc, spmv_partials, col_partials;
   // complete-row column march (plan_complete_rows): boundary cells sit on column ends only
   bool rows_plan = false, asm_sums = false;
   struct Trial { const double *x = nullptr, *y = nullptr; double a = 0.0; } ls_point;   // pending X + a Y of the line search
@@ -617,6 +617,10 @@ struct Solver {
       b->alloc(nrow); b->zero(stream);
     }
     partials.alloc((size_t)kMaxPartialBlocks * kMaxMultiDot);
+    {  // one partial sum per block of 256 columns (column solves, complete-row march): two vectors + the staging tail
+      const size_t nbc = ((size_t)ncols + 255) / 256;
+      col_partials.alloc(2 * (nbc + nbc / 2048 + 1));
+    }
     sc.alloc(S_COUNT); sc.zero(stream);
     HIP_CHECK(hipHostMalloc(&h_sc, S_COUNT * sizeof(double), hipHostMallocDefault));
     d_Dq.alloc(nc_int); d_upw.alloc(nc_int); d_dgrav.alloc(nc_int); d_area.alloc(nc_int);
@@ -659,7 +663,6 @@ struct Solver {
   void plan_complete_rows() {
     rows_plan = false;
     if (th || thermal || !vertical_only || !columns || nghost > 0 || ndr_cells > 0 || nz < 2) return;
-    if ((ncols + 255) / 256 > kMaxPartialBlocks) return;
     std::vector<int> cb(2 * (size_t)ncols, -1);
     for (int j = 0; j < ncond_cells; ++j) {
       const long long cell = h_cc_cell[j];
@@ -958,7 +961,7 @@ struct Solver {
     ColsArgs a = cols_args(P, Fout);
     a.trial_x = ls_point.x; a.trial_y = ls_point.y; a.trial_a = ls_point.a; a.trial_w = const_cast<double *>(P);
     ls_point = Trial{};
-    a.col_bc = d_col_bc.p; a.side_f = bc_side_f.p; a.side_d = bc_side_d.p; a.partials = partials.p;
+    a.col_bc = d_col_bc.p; a.side_f = bc_side_f.p; a.side_d = bc_side_d.p; a.partials = col_partials.p;
     const bool factor = mode != 0 && opt.pc_type == 2;
     if (factor) { a.tl = tri_l.p; a.tinvb = tri_invb.p; a.tc = tri_c.p; }
     if (mode != 1 || Fout == fwd_rhs) fwd_rhs = nullptr;   // the residual in Fout or the factors are being replaced
@@ -969,7 +972,7 @@ struct Solver {
     launch_assemble_cols(mode, a, stream);
     if (a.fwd) fwd_rhs = Fout;
     if (mode != 1) {
-      launch_finalize_partials((ncols + 255) / 256, 2, partials.p, sc.p, stream);
+      launch_finalize_partials_long((ncols + 255) / 256, 2, col_partials.p, sc.p, stream);
       if (comm.active()) comm.allreduce_sum(sc.p + S_SUM0, 2, stream);
       asm_sums = true;
     }
@@ -1155,7 +1158,7 @@ struct Solver {
   // z = M^{-1} r together with the dot products (z.z) or (z.w, z.z) of the result, left in sc[S_SUM0..]: one pass less
   // over z (and w) when the preconditioner is the column solver; otherwise the apply followed by the reduction kernels
   bool fused_pc_dots() const {
-    return opt.pc_type == 2 && !th && nghost == 0 && (ncols + 255) / 256 <= kMaxPartialBlocks;
+    return opt.pc_type == 2 && !th && nghost == 0;
   }
   void op_pc_apply_dots(const double *r, double *z, const double *w) {
     if (!fused_pc_dots()) {
@@ -1166,9 +1169,9 @@ struct Solver {
     {
       ProfScope ps(prof, KC_PC_APPLY);
       int nbk;
-      if (!w && r == fwd_rhs && pc_ready) nbk = launch_tri_back_dots(tri_args(), fwd_elim.p, z, partials.p, stream);
-      else nbk = launch_tri_solve_dots(tri_args(), r, z, w, partials.p, stream);
-      launch_finalize_partials(nbk, w ? 2 : 1, partials.p, sc.p, stream);
+      if (!w && r == fwd_rhs && pc_ready) nbk = launch_tri_back_dots(tri_args(), fwd_elim.p, z, col_partials.p, stream);
+      else nbk = launch_tri_solve_dots(tri_args(), r, z, w, col_partials.p, stream);
+      launch_finalize_partials_long(nbk, w ? 2 : 1, col_partials.p, sc.p, stream);
     }
     if (comm.active()) comm.allreduce_sum(sc.p + S_SUM0, w ? 2 : 1, stream);
   }

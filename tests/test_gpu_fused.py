@@ -100,3 +100,21 @@ def test_complete_rows_time_step_cut():
     assert cg["time_cuts"] == co["time_cuts"] > 0 and cg["newton"] == co["newton"]
     np.testing.assert_allclose(g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1),
                                o.get(C.AUXVAR_INTERNAL, C.VAR_PRESSURE), rtol=1e-8)
+
+
+def test_more_column_blocks_than_one_reduction_stage_holds():
+    """1,048,832 columns = 4097 blocks of 256: the per-block partial sums of the column solves and of the complete-row march
+    go through the two-stage finalisation; fused and unfused solves must agree"""
+    ncols, nz = 4097 * 256, 4
+    prob = P.celia1990(ncols=ncols, nz=nz, perm_mult=np.exp(0.3 * np.random.default_rng(2).standard_normal(ncols)))
+    base = {"ksp_type": "bcgs", "pc_type": "bjacobi", "spmv_variant": 20}
+    on = P.to_gpu(prob, base)
+    off = P.to_gpu(prob, dict(base, fused_rows=0, fused_ls_dots=0))
+    for s in range(2):
+        assert on.soe.StepDT(prob.dt, s + 1) == off.soe.StepDT(prob.dt, s + 1)
+    c_on, c_off = on.soe.counters(), off.soe.counters()
+    assert c_on["newton"] == c_off["newton"] and c_on["linear"] == c_off["linear"]
+    p_on = on.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1)
+    p_off = off.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1)
+    assert np.isfinite(p_on).all()
+    assert np.abs(p_on - p_off).max() <= 1e-9 * np.abs(p_off).max()
