@@ -108,16 +108,17 @@ class HostGroup:
                 for p in range(base, base + 16):
                     try:
                         c = socket.create_connection((addr, p), timeout=5.0)
-                        c.settimeout(timeout)
+                        c.settimeout(10.0)     # a foreign listener on this port must not stall the scan
                         c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                         c.sendall(self.MAGIC + struct.pack("<i", self.rank))
                         reply = self._recv_exact(c, len(self.MAGIC) + 4)
                         if reply[:len(self.MAGIC)] == self.MAGIC and \
                                 struct.unpack("<i", reply[len(self.MAGIC):])[0] == self.world:
+                            c.settimeout(timeout)
                             self.sock = c
                             break
                         c.close()
-                    except OSError:
+                    except (OSError, RuntimeError):
                         pass
                 if self.sock is None:
                     if time.time() > deadline:
