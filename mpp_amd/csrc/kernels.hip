@@ -983,66 +983,9 @@ __global__ __launch_bounds__(kBlock) void k_jacobi_setup(int n, const int *diag_
 }
 
 // ------------------------------------------------------------------------------------------------
-// ILU(0), level scheduled.  Same arithmetic as the sequential IKJ factorisation in elimination order `ord`
-// (PETSc MatLUFactorNumeric_SeqAIJ with levels = 0): rows of one level only read rows of earlier levels.
-// Rows have <= ~7 entries on stencil matrices, so position look-ups are short linear searches.
+// ILU(0), level scheduled, in the elimination order `ord` (PETSc MatLUFactorNumeric_SeqAIJ with levels = 0): rows of one
+// level only read rows of earlier levels.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_ilu_factor_level(IluArgs a, const int *__restrict__ rows, int count) {
-  const int t = blockIdx.x * kBlock + threadIdx.x;
-  if (t >= count) return;
-  const int i = rows[t];
-  const int oi = a.ord[i];
-  const int rs = a.rowptr[i], re = a.rowptr[i + 1];
-  // process the L-part pivots in increasing elimination order (selection by `ord`, rows are tiny)
-  int last = -1;
-  for (;;) {
-    int kslot = -1, kord = 0x7fffffff;
-    for (int s = rs; s < re; ++s) {
-      const int o = a.ord[a.col[s]];
-      if (o < oi && o > last && o < kord) { kord = o; kslot = s; }
-    }
-    if (kslot < 0) break;
-    last = kord;
-    const int k = a.col[kslot];
-    const double mult = a.lu[kslot] * a.idiag[k];
-    a.lu[kslot] = mult;
-    for (int q = a.rowptr[k]; q < a.rowptr[k + 1]; ++q) {
-      const int j = a.col[q];
-      if (a.ord[j] <= kord) continue;  // U-part of row k only
-      for (int s = rs; s < re; ++s)
-        if (a.col[s] == j) { a.lu[s] -= mult * a.lu[q]; break; }
-    }
-  }
-  a.idiag[i] = 1.0 / a.lu[a.diag_slot[i]];
-}
-
-__global__ __launch_bounds__(kBlock) void k_ilu_lower_level(IluArgs a, const int *__restrict__ rows, int count,
-                                                            const double *__restrict__ r, double *__restrict__ y) {
-  const int t = blockIdx.x * kBlock + threadIdx.x;
-  if (t >= count) return;
-  const int i = rows[t];
-  const int oi = a.ord[i];
-  double s = r[i];
-  for (int q = a.rowptr[i]; q < a.rowptr[i + 1]; ++q) {
-    const int j = a.col[q];
-    if (a.ord[j] < oi) s -= a.lu[q] * y[j];
-  }
-  y[i] = s;
-}
-__global__ __launch_bounds__(kBlock) void k_ilu_upper_level(IluArgs a, const int *__restrict__ rows, int count,
-                                                            double *__restrict__ x) {
-  const int t = blockIdx.x * kBlock + threadIdx.x;
-  if (t >= count) return;
-  const int i = rows[t];
-  const int oi = a.ord[i];
-  double s = x[i];
-  for (int q = a.rowptr[i]; q < a.rowptr[i + 1]; ++q) {
-    const int j = a.col[q];
-    if (a.ord[j] > oi) s -= a.lu[q] * x[j];
-  }
-  x[i] = s * a.idiag[i];
-}
-
 // ILU(0) numeric factorisation of the rows at positions [lo, hi) of the level order (PETSc MatLUFactorNumeric_SeqAIJ,
 // levels = 0): the symbolic part -- which entries meet -- was resolved on the host into a per-row program
 __global__ __launch_bounds__(kBlock) void k_ilu_factor_program(const long long *__restrict__ ptr, const int *__restrict__ prog,
@@ -1273,10 +1216,6 @@ __global__ __launch_bounds__(kBlock) void k_set(int n, double v, double *__restr
 __global__ __launch_bounds__(kBlock) void k_gather(int n, const int *idx, const double *in, double *out) {
   const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (i < (size_t)n) out[i] = in[idx[i]];
-}
-__global__ __launch_bounds__(kBlock) void k_scatter(int n, const int *idx, const double *in, double *out) {
-  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i < (size_t)n) out[idx[i]] = in[i];
 }
 __global__ __launch_bounds__(kBlock) void k_pmult(int n, const double *a, const double *x, double *y) {
   vec2_loop(n, [&](size_t q) { const double2 u = CD2(a)[q], v = CD2(x)[q]; D2(y)[q] = make_double2(u.x * v.x, u.y * v.y); }, [&](size_t i) { y[i] = a[i] * x[i]; });
@@ -1715,15 +1654,6 @@ void launch_jacobi_setup(int n, const int *diag_slot, const double *val, double 
   if (n > 0) LAUNCH(k_jacobi_setup, dim3(nblk(n)), n, diag_slot, val, invd);
 }
 
-void launch_ilu_factor_level(const IluArgs &a, const int *rows, int count, hipStream_t stream) {
-  if (count > 0) LAUNCH(k_ilu_factor_level, dim3(nblk(count)), a, rows, count);
-}
-void launch_ilu_lower_level(const IluArgs &a, const int *rows, int count, const double *r, double *y, hipStream_t stream) {
-  if (count > 0) LAUNCH(k_ilu_lower_level, dim3(nblk(count)), a, rows, count, r, y);
-}
-void launch_ilu_upper_level(const IluArgs &a, const int *rows, int count, double *x, hipStream_t stream) {
-  if (count > 0) LAUNCH(k_ilu_upper_level, dim3(nblk(count)), a, rows, count, x);
-}
 void launch_ilu_factor_program(const long long *ptr, const int *prog, const int *rows, const int *diag_slot, int lo, int hi,
                                double *lu, double *idiag, hipStream_t stream) {
   if (hi > lo) LAUNCH(k_ilu_factor_program, dim3(nblk(hi - lo)), ptr, prog, rows, diag_slot, lo, hi, lu, idiag);
@@ -1776,9 +1706,6 @@ void launch_set(int n, double v, double *y, hipStream_t stream) {
 }
 void launch_gather(int n, const int *idx, const double *in, double *out, hipStream_t stream) {
   if (n > 0) LAUNCH(k_gather, dim3(nblk(n)), n, idx, in, out);
-}
-void launch_scatter(int n, const int *idx, const double *in, double *out, hipStream_t stream) {
-  if (n > 0) LAUNCH(k_scatter, dim3(nblk(n)), n, idx, in, out);
 }
 void launch_pointwise_mult(int n, const double *a, const double *x, double *y, hipStream_t stream) {
   if (n > 0) LAUNCH(k_pmult, dim3(vec_grid(n)), n, a, x, y);

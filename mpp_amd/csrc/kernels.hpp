@@ -155,18 +155,6 @@ int launch_tri_back_dots(const TriArgs &a, const double *d, double *z, double *p
 void launch_jacobi_setup(int n, const int *diag_slot, const double *val, double *invd, hipStream_t stream);
 
 // ---- ILU(0), level-scheduled (PETSc's default PC for SeqAIJ; elimination order = the caller's natural ordering) ----
-struct IluArgs {
-  int n;
-  const int *rowptr, *col, *diag_slot;
-  const int *ord;        // elimination position of every row (a permutation of 0..n-1)
-  double *lu;            // factors in A's pattern: L strictly below (in `ord` order), U on and above
-  double *idiag;         // 1 / u_ii
-};
-// one launch per level: rows[level_ptr[l] .. level_ptr[l+1]) are mutually independent
-void launch_ilu_factor_level(const IluArgs &a, const int *rows, int count, hipStream_t stream);
-void launch_ilu_lower_level(const IluArgs &a, const int *rows, int count, const double *r, double *y, hipStream_t stream);
-void launch_ilu_upper_level(const IluArgs &a, const int *rows, int count, double *x, hipStream_t stream);
-
 // Level-ordered triangular solves.  The factors are repacked (after every numeric factorisation) into two ELL blocks
 // whose rows are sorted by dependency level -- `n` positions, entry k of position p at [k*n + p], columns are
 // positions of the same ordering, padding entries have value 0 and point at the row itself -- so a level is one
@@ -256,7 +244,6 @@ void launch_th_tri_solve(const ThTriArgs &a, const double *r, double *z, hipStre
 void launch_copy(int n, const double *x, double *y, hipStream_t stream);
 void launch_set(int n, double v, double *y, hipStream_t stream);
 void launch_gather(int n, const int *idx, const double *in, double *out, hipStream_t stream);   // out[i] = in[idx[i]]
-void launch_scatter(int n, const int *idx, const double *in, double *out, hipStream_t stream);  // out[idx[i]] = in[i]
 void launch_pointwise_mult(int n, const double *a, const double *x, double *y, hipStream_t stream);
 // w = y + a*x with a = sign * sc[slot] (or the literal `aval` when slot < 0)
 void launch_waxpy(int n, double *w, const double *sc, int slot, double sign, double aval, const double *x,

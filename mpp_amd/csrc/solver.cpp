@@ -1112,8 +1112,6 @@ struct Solver {
     else if (opt.pc_type == 1) {
       ilu_analyse();
       launch_copy(nnz, d_val.p, d_lu.p, stream);
-      const IluArgs a = ilu_args();
-      (void)a;
       for (size_t l = 0; l + 1 < h_lptr.size(); ++l)
         launch_ilu_factor_program(d_fptr.p, d_fprog.p, d_lrows.p, d_diag.p, h_lptr[l], h_lptr[l + 1], d_lu.p, d_idiag.p, stream);
       // repack into the level-ordered ELL blocks the solves stream through
@@ -2037,7 +2035,6 @@ struct Solver {
     ilu_y.alloc(N); ilu_x.alloc(N);
     HIP_CHECK(hipStreamSynchronize(stream));
   }
-  IluArgs ilu_args() const { return IluArgs{nrow, d_rowptr.p, d_col.p, d_diag.p, d_ord.p, d_lu.p, d_idiag.p}; }
 
   // current matrix values in the caller's ordering, columns sorted
   void export_csr(int *rowptr, int *col, double *val) {
