@@ -1055,6 +1055,55 @@ __global__ __launch_bounds__(kBlock) void k_ell_upper(int n, int Kdyn, const int
   x[p] = s * id;
 }
 
+// chained triangular solve (see ChainArgs): one workgroup per tile, flags instead of kernel boundaries.  Values other
+// workgroups wrote during this launch are read and written with agent-scope atomics (they bypass the non-coherent caches).
+template <int K, bool UPPER>
+__global__ __launch_bounds__(kBlock) void k_ell_chain(ChainArgs a) {
+  const int t = blockIdx.x;
+  const int lo = a.tile_lo[t], hi = a.tile_hi[t];
+  const int p = lo + threadIdx.x;
+  const bool row = p < hi;
+  const int kk = K > 0 ? K : a.K;
+  constexpr int KR = K > 0 ? K : 1;
+  int c[KR];
+  double w[KR];
+  if (K > 0 && row) {   // the tile's own matrix entries do not depend on anybody: fetch them before waiting
+#pragma unroll
+    for (int k = 0; k < K; ++k) { c[k] = a.col[(size_t)k * a.n + p]; w[k] = a.val[(size_t)k * a.n + p]; }
+  }
+  double s = row ? a.v[p] : 0.0;
+  const double id = (UPPER && row) ? a.idiag[p] : 1.0;
+  if ((int)threadIdx.x < a.dmax) {
+    const int d = a.dep[(size_t)threadIdx.x * a.ntiles + t];
+    if (d >= 0) {
+      unsigned spins = 0;
+      // Flags and solution entries travel as agent-scope (sc1) accesses, which are served at the device's coherence
+      // point; no cache-wide invalidate / write-back (what an acquire / release fence costs, ~30 us per level here).
+      while (__hip_atomic_load(a.flags + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1u << 22)) { a.sc[S_ERR] = 1.0; break; }
+      }
+    }
+  }
+  __syncthreads();
+  if (row) {
+    if (K > 0) {
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+        s -= w[k] * (c[k] == p ? 0.0 : __hip_atomic_load(a.v + c[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    } else {
+      for (int k = 0; k < kk; ++k) {
+        const int ck = a.col[(size_t)k * a.n + p];
+        if (ck != p) s -= a.val[(size_t)k * a.n + p] * __hip_atomic_load(a.v + ck, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    __hip_atomic_store(a.v + p, UPPER ? s * id : s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's sc1 stores have been acknowledged at the coherence point ...
+  __syncthreads();                      // ... and so have every other wave's, before the tile is declared done
+  if (threadIdx.x == 0) __hip_atomic_store(a.flags + t, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ------------------------------------------------------------------------------------------------
 // soil heat diffusion.  ThermKSPTempSoilAuxVarCompute
 // (src/mpp/auxvar/ThermalKSPTemperatureSoilAuxType.F90:66-168): itype 1 soil/crop, 2 wetland, 3 land ice
@@ -1660,6 +1709,17 @@ void launch_ilu_factor_program(const long long *ptr, const int *prog, const int 
 }
 void launch_ilu_repack(long long total, const int *slot, const double *lu, double *out, hipStream_t stream) {
   if (total > 0) LAUNCH(k_ilu_repack, dim3(nblk(total)), total, slot, lu, out);
+}
+void launch_ell_chain(const ChainArgs &a, hipStream_t stream) {
+  if (a.ntiles <= 0) return;
+  const dim3 grid(a.ntiles);
+  const bool up = a.idiag != nullptr;
+  switch (a.K) {
+    case 1: if (up) LAUNCH((k_ell_chain<1, true>), grid, a); else LAUNCH((k_ell_chain<1, false>), grid, a); break;
+    case 2: if (up) LAUNCH((k_ell_chain<2, true>), grid, a); else LAUNCH((k_ell_chain<2, false>), grid, a); break;
+    case 3: if (up) LAUNCH((k_ell_chain<3, true>), grid, a); else LAUNCH((k_ell_chain<3, false>), grid, a); break;
+    default: if (up) LAUNCH((k_ell_chain<0, true>), grid, a); else LAUNCH((k_ell_chain<0, false>), grid, a);
+  }
 }
 void launch_ell_lower_level(int n, int K, const int *col, const double *val, int lo, int hi, double *y, hipStream_t stream) {
   if (hi <= lo) return;

@@ -10,7 +10,7 @@ namespace mpp {
 
 // device-resident scalar block shared by the Krylov/Newton kernels (doubles)
 enum ScalarSlot : int {
-  S_RHO = 0, S_RHOOLD, S_ALPHA, S_OMEGA, S_OMEGAOLD, S_BETA, S_D1, S_D2, S_DP, S_FLAG, S_ST, S_DP0, S_RRP,
+  S_RHO = 0, S_RHOOLD, S_ALPHA, S_OMEGA, S_OMEGAOLD, S_BETA, S_D1, S_D2, S_DP, S_FLAG, S_ST, S_DP0, S_RRP, S_ERR,
   S_SUM0 = 16,  // reduction results land in S_SUM0 .. S_SUM0+63
   S_COUNT = 96
 };
@@ -164,6 +164,25 @@ void launch_jacobi_setup(int n, const int *diag_slot, const double *val, double 
 void launch_ilu_factor_program(const long long *ptr, const int *prog, const int *rows, const int *diag_slot, int lo, int hi,
                                double *lu, double *idiag, hipStream_t stream);
 void launch_ilu_repack(long long total, const int *slot, const double *lu, double *out, hipStream_t stream);  // out[e] = slot[e] >= 0 ? lu[slot[e]] : 0
+// The same solves as ONE launch per triangle: a workgroup owns a tile of <= 256 consecutive rows of one level and waits
+// (spinning on per-tile flags) only for the tiles that hold its rows' dependencies, so the tail of a level overlaps the
+// head of the next and no per-level launch gap is paid.  Workgroups are dispatched in tile order, a tile depends on
+// lower-numbered tiles only, so the lowest unfinished tile is always resident and can finish.  A wait that exceeds its
+// spin budget sets sc[S_ERR] (checked at the next scalar read-back) instead of hanging.
+struct ChainArgs {
+  int n, K;                        // rows; ELL width
+  const int *col;                  // [K][n] positions (in this triangle's level order) of the dependencies; self = padding
+  const double *val;               // [K][n]
+  const double *idiag;             // upper triangle: 1/u_pp; nullptr for the (unit) lower triangle
+  const int *tile_lo, *tile_hi;    // rows [tile_lo[t], tile_hi[t]) of tile t
+  const int *dep;                  // [dmax][ntiles] tiles to wait for (-1 none)
+  int ntiles, dmax;
+  unsigned *flags;                 // flags[t] == epoch: tile t is done in this application
+  unsigned epoch;
+  double *v;                       // solved in place
+  double *sc;                      // sc[S_ERR] receives 1.0 on a timed-out wait
+};
+void launch_ell_chain(const ChainArgs &a, hipStream_t stream);
 void launch_ell_lower_level(int n, int K, const int *col, const double *val, int lo, int hi, double *y, hipStream_t stream);
 void launch_ell_upper_level(int n, int K, const int *col, const double *val, const double *idiag, int lo, int hi, double *x,
                             hipStream_t stream);

@@ -154,6 +154,8 @@ struct Options {
                                // column LU come out of the assembly pass (see Solver::rows_complete)
   bool defer_test0 = true;     // bcgs: iteration 0's convergence test is made when the first iteration's scalars come back
   bool ell_assembly = true;    // general assembly on the ELL copy of the incidence lists (k_flux_rows_ell)
+  int ilu_chain = 1;           // ILU(0) solves: one launch per triangle, tiles chained by flags (1: where it pays, 2: always;
+                               // 0: one launch per level)
   bool fused_predict = true;   // skip the fused Jacobian at the first trial when the previous line search backtracked
   int fused_trials = 2;        // ... for the first `fused_trials` trial points of a line search (later ones: F only)
 };

@@ -188,6 +188,15 @@ struct Solver {
   DevBuf<int> d_Lslot, d_Uslot, d_Lcol, d_Ucol, d_l2u, d_posU, d_fprog;
   DevBuf<long long> d_fptr;
   DevBuf<double> d_Lval, d_Uval, d_Uidiag, ilu_y, ilu_x;
+  // chained triangular solves (ChainArgs): tiles of one level, the tiles each waits for, completion flags
+  struct Chain {
+    DevBuf<int> tile_lo, tile_hi, dep;
+    DevBuf<unsigned> flags;
+    int ntiles = 0;
+    bool ok = false;
+  } chainL, chainU;
+  static constexpr int kChainDeps = 8;
+  unsigned chain_epoch = 0;
   hipGraph_t ilu_graph = nullptr;
   hipGraphExec_t ilu_graph_exec = nullptr;
 
@@ -1137,7 +1146,8 @@ struct Solver {
     else if (opt.pc_type == 3) launch_pointwise_mult(nred, jac_invd.p, r, z, stream);
     else if (opt.pc_type == 1) {
       launch_gather(nrow, d_lrows.p, r, ilu_y.p, stream);            // r into the L level order
-      if (opt.ilu_graph) {
+      if (ilu_chained()) ilu_solve_chained();
+      else if (opt.ilu_graph) {
         if (!ilu_graph_exec) {
           HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
           ilu_solve_levels();
@@ -1187,6 +1197,11 @@ struct Solver {
   void fetch_scalars() {
     HIP_CHECK(hipMemcpyAsync(h_sc, sc.p, S_COUNT * sizeof(double), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
+    if (h_sc[S_ERR] != 0.0) {   // a chained triangular solve gave up waiting: its result is not to be used
+      opt.ilu_chain = 0;
+      sc.zero(stream);
+      throw Error("ILU(0) chained triangular solve: a dependency wait timed out (falling back to per-level launches: set ilu_chain=0)");
+    }
   }
   void dots_host(std::initializer_list<std::pair<const double *, const double *>> pairs, double *out) {
     dots_dev(pairs);
@@ -1934,6 +1949,82 @@ struct Solver {
   // caller's (natural) position of an internal row and back; coupled TH: field-blocked [P(1..N); T(1..N)] both ways
   int row_int2ext(int r) const { return r < n ? int2ext[r] : n + int2ext[r - n]; }
   int row_ext2int(int pos) const { return pos < n ? ext2int[pos] : n + ext2int[pos - n]; }
+  // Tiles (<= 256 consecutive positions of one level) and, per tile, the tiles that hold the dependencies of its rows.
+  // skip_level0: rows of level 0 are final before the solve starts (unit lower triangle), so they get no tile and
+  // nobody waits for them.  More than kChainDeps distinct dependency tiles anywhere: no chain (per-level launches).
+  void build_chain(Chain &ch, const std::vector<int> &lptr, const std::vector<int> &col, int K, bool skip_level0) {
+    ch.ok = false; ch.ntiles = 0;
+    const int N = nrow, nlev = (int)lptr.size() - 1;
+    if (nlev <= 0 || K <= 0) return;
+    const int first = skip_level0 ? 1 : 0;
+    std::vector<int> base(nlev + 1, 0);           // first tile of every level
+    for (int l = 0; l < nlev; ++l) base[l + 1] = base[l] + (l < first ? 0 : (lptr[l + 1] - lptr[l] + 255) / 256);
+    const int nt = base[nlev];
+    if (nt <= 0) return;
+    std::vector<int> tlo(nt), thi(nt), dep((size_t)kChainDeps * nt, -1);
+    auto tile_of = [&](int pos, int hint_level) {   // dependencies sit in the previous level almost always
+      int l = hint_level;
+      if (!(pos >= lptr[l] && pos < lptr[l + 1])) l = (int)(std::upper_bound(lptr.begin(), lptr.end(), pos) - lptr.begin()) - 1;
+      return l < first ? -1 : base[l] + (pos - lptr[l]) / 256;
+    };
+    for (int l = first; l < nlev; ++l)
+      for (int lo = lptr[l], t = base[l]; lo < lptr[l + 1]; lo += 256, ++t) {
+        const int hi = std::min(lo + 256, lptr[l + 1]);
+        tlo[t] = lo; thi[t] = hi;
+        int nd = 0;
+        int *d = &dep[0];
+        for (int k = 0; k < K; ++k)
+          for (int p = lo; p < hi; ++p) {
+            const int c = col[(size_t)k * N + p];
+            if (c == p) continue;
+            const int tt = tile_of(c, l > 0 ? l - 1 : 0);
+            if (tt < 0) continue;
+            if (tt >= t) return;                    // not a triangular dependency: never for a level schedule
+            bool seen = false;
+            for (int q = 0; q < nd; ++q) seen |= (d[(size_t)q * nt + t] == tt);
+            if (seen) continue;
+            if (nd == kChainDeps) return;
+            d[(size_t)nd++ * nt + t] = tt;
+          }
+      }
+    ch.tile_lo.upload(tlo, stream); ch.tile_hi.upload(thi, stream); ch.dep.upload(dep, stream);
+    ch.flags.alloc(nt); ch.flags.zero(stream);
+    ch.ntiles = nt;
+    ch.ok = true;
+  }
+  // The chain pays per dependency with an uncached (agent-scope) load; a per-level launch pays ~1.5-4.5 us per level.
+  // Measured on MI355X: thermal 256^3 (22 K rows per level, 3 entries per row) 4.5 -> 3.8 ms per application, 3-D VSFM
+  // 128x128x64 (3 K rows per level) 1.48 -> 1.15 ms, thermal 512^3 (87 K) no change, the TH columns (65 K rows per level,
+  // 6 entries per row) 0.89 -> 1.03 ms: chain when rows-per-level x entries-per-row stays under ~10^5.
+  // entry points that apply the preconditioner without a scalar read-back check the chain's error flag themselves
+  void check_chain_error() {
+    if (opt.pc_type != 1 || !opt.ilu_chain) return;
+    double e = 0.0;
+    HIP_CHECK(hipMemcpyAsync(&e, sc.p + S_ERR, sizeof(double), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    if (e != 0.0) {
+      opt.ilu_chain = 0;
+      sc.zero(stream);
+      throw Error("ILU(0) chained triangular solve: a dependency wait timed out (falling back to per-level launches: set ilu_chain=0)");
+    }
+  }
+  bool ilu_chained() const {
+    if (!opt.ilu_chain || !chainL.ok || !chainU.ok) return false;
+    if (opt.ilu_chain == 2) return true;
+    const double nlev = (double)std::max<size_t>(h_lptr.size(), 2) - 1.0;
+    return (double)nrow / nlev * std::max(ell_KL, ell_KU) < 1.0e5;
+  }
+  void ilu_solve_chained() {
+    const unsigned ep = ++chain_epoch;
+    ChainArgs a{nrow, ell_KL, d_Lcol.p, d_Lval.p, nullptr, chainL.tile_lo.p, chainL.tile_hi.p, chainL.dep.p, chainL.ntiles,
+                kChainDeps, chainL.flags.p, ep, ilu_y.p, sc.p};
+    launch_ell_chain(a, stream);
+    launch_gather(nrow, d_l2u.p, ilu_y.p, ilu_x.p, stream);
+    ChainArgs b{nrow, ell_KU, d_Ucol.p, d_Uval.p, d_Uidiag.p, chainU.tile_lo.p, chainU.tile_hi.p, chainU.dep.p, chainU.ntiles,
+                kChainDeps, chainU.flags.p, ep, ilu_x.p, sc.p};
+    launch_ell_chain(b, stream);
+  }
+
   void ilu_analyse() {
     if (d_ord.p) return;
     const int N = nrow;
@@ -1998,6 +2089,8 @@ struct Solver {
       }
       l2u[pu] = pl;
     }
+    build_chain(chainL, h_lptr, Lcol, ell_KL, /*skip_level0=*/true);
+    build_chain(chainU, h_uptr, Ucol, ell_KU, /*skip_level0=*/false);
     d_Lslot.upload(Lslot, stream); d_Lcol.upload(Lcol, stream); d_Uslot.upload(Uslot, stream); d_Ucol.upload(Ucol, stream);
     d_l2u.upload(l2u, stream); d_posU.upload(posU, stream);
     {  // elimination program of the numeric factorisation, rows in L level order (see k_ilu_factor_program)
@@ -2085,6 +2178,7 @@ struct Solver {
     } else if (key == "nseg") opt.nseg = (int)num();
     else if (key == "fused_assembly") opt.fused_assembly = num() != 0;
     else if (key == "ilu_graph") opt.ilu_graph = num() != 0;
+    else if (key == "ilu_chain") opt.ilu_chain = (int)num();   // 0 per-level launches, 1 chained where it pays, 2 always chained
     else if (key == "fused_trials") opt.fused_trials = (int)num();
     else if (key == "fused_predict") opt.fused_predict = num() != 0;
     else if (key == "fused_ls_dots") opt.fused_ls_dots = num() != 0;
@@ -2397,6 +2491,7 @@ int mppgpu_pc_apply(mppgpu_handle h, const double *r, double *z) {
   S.put_state(r, S.W.p);
   S.op_pc_setup();
   S.op_pc_apply(S.W.p, S.G.p);
+  S.check_chain_error();
   S.get_state(S.G.p, z);
   API_END()
 }

@@ -91,3 +91,25 @@ def test_vchannel_baseline_with_petsc_default_solver(golden_dir):
     for key in ("min", "max", "mean"):
         assert st[key] == pytest.approx(gold["liquid_pressure"][key], rel=1e-9)
     assert g.soe.counters()["newton"] == o.counters()["newton"]
+
+
+def test_chained_and_per_level_ilu_solves_agree_bit_for_bit():
+    """ILU(0) triangular solves as one launch per triangle (tiles of a level chained by completion flags) against one
+    launch per level: the arithmetic per row is the same, so every application must give the same bits -- applied many
+    times in a row, because a synchronisation slip would show up as an occasional stale operand"""
+    prob = P.vchannel(nx=40, ny=36, nz=44)                  # 63 K rows, 118 dependency levels, ragged tiles
+    n = prob.mesh.ncells_local
+    x = prob.press_ic - np.random.default_rng(2).uniform(0, 2.5e5, n)
+    chain = P.to_gpu(prob, {"ksp_type": "gmres", "pc_type": "ilu", "ilu_chain": 2})
+    level = P.to_gpu(prob, {"ksp_type": "gmres", "pc_type": "ilu", "ilu_chain": 0, "ilu_graph": 0})
+    for g in (chain, level):
+        g.soe.SetDtime(prob.dt); g.soe.PreSolve()
+        g.soe.ComputeJacobian(x)
+    rng = np.random.default_rng(17)
+    for rep in range(40):
+        v = rng.standard_normal(n)
+        assert np.array_equal(chain.soe.PCApply(v), level.soe.PCApply(v)), rep
+    assert chain.soe.StepDT(prob.dt, 1) == level.soe.StepDT(prob.dt, 1)
+    assert chain.soe.counters() == level.soe.counters()
+    assert np.array_equal(chain.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1),
+                          level.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1))
