@@ -167,7 +167,8 @@ int mppgpu_set_source_sink_auxvar(mppgpu_handle h, int var_type, int n, const do
  * Tuning keys (results unchanged): "spmv_variant", "assembly" (auto|general|columns), "nseg", "fused_assembly"
  * (0|1), "fused_trials" (line-search trial points whose Jacobian is assembled together with the residual),
  * "fused_predict", "fused_rows" (0|1: column march that folds the boundary fluxes in and also leaves ||F||, ||X|| and
- * the column LU), "fused_ls_dots" (0|1: line-search reductions inside the SpMV), "ilu_graph", "track_mass_exchange". */
+ * the column LU), "fused_ls_dots" (0|1: line-search reductions inside the SpMV), "ilu_graph", "ilu_chain" (0|1|2), "ell_assembly",
+ * "track_mass_exchange". */
 int mppgpu_set_option(mppgpu_handle h, const char *key, const char *value);
 
 /* mpp%AllocateAuxVars + mpp%SetupProblem (src/mpp/mpp/MultiPhysicsProbVSFM.F90:710-1015): builds the CSR
