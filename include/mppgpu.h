@@ -163,12 +163,13 @@ int mppgpu_set_source_sink_auxvar(mppgpu_handle h, int var_type, int n, const do
  * "pc_type" (bjacobi|ilu|jacobi|none; ilu = PETSc's default ILU(0) in the caller's natural ordering -- on
  * vertical-only grids it coincides with the exact per-column LU and is served by the same kernels),
  * "ksp_rtol", "ksp_atol", "ksp_dtol", "ksp_max_it", "snes_rtol", "snes_atol", "snes_stol", "snes_max_it",
- * "profile" (0|1: HIP-event timing of every kernel class), "problem_type" (vsfm|thermal), "cnfac" (thermal).
+ * "profile" (0 | 1: HIP-event timing of every kernel class | 2: of the CSR SpMV only), "problem_type" (vsfm|thermal|th),
+ * "cnfac" (thermal).
  * Tuning keys (results unchanged): "spmv_variant", "assembly" (auto|general|columns), "nseg", "fused_assembly"
  * (0|1), "fused_trials" (line-search trial points whose Jacobian is assembled together with the residual),
  * "fused_predict", "fused_rows" (0|1: column march that folds the boundary fluxes in and also leaves ||F||, ||X|| and
- * the column LU), "fused_ls_dots" (0|1: line-search reductions inside the SpMV), "ilu_graph", "ilu_chain" (0|1|2), "ell_assembly",
- * "track_mass_exchange". */
+ * the column LU), "fused_ls_dots" (0|1: line-search reductions inside the SpMV), "ilu_graph", "ilu_chain" (0 one launch
+ * per level | 1 chained tiles where they pay | 2 always chained), "ell_assembly", "defer_test0", "track_mass_exchange". */
 int mppgpu_set_option(mppgpu_handle h, const char *key, const char *value);
 
 /* mpp%AllocateAuxVars + mpp%SetupProblem (src/mpp/mpp/MultiPhysicsProbVSFM.F90:710-1015): builds the CSR
