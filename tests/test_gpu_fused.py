@@ -118,3 +118,16 @@ def test_more_column_blocks_than_one_reduction_stage_holds():
     p_off = off.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1)
     assert np.isfinite(p_on).all()
     assert np.abs(p_on - p_off).max() <= 1e-9 * np.abs(p_off).max()
+
+
+@pytest.mark.parametrize("ncols,nz", [(1, 2), (65, 2), (3, 3), (64, 1)])
+def test_complete_rows_smallest_columns(ncols, nz):
+    """columns of one to three cells: every row is a boundary row (nz == 1 is left to the general kernels)"""
+    prob, x = _hetero(ncols=ncols, nz=nz, seed=31)
+    o, g, (rp, cj, val), v = _operator_parity(prob, x, ROWS)
+    z_o = o.pc_apply(C.PC_BJACOBI, rp, cj, val, v)
+    z_g = g.soe.PCApply(v)
+    assert np.abs(z_g - z_o).max() <= 1e-10 * np.abs(z_o).max()
+    assert g.soe.StepDT(prob.dt, 1) == tuple(o.step_dt(prob.dt, 1))
+    np.testing.assert_allclose(g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1),
+                               o.get(C.AUXVAR_INTERNAL, C.VAR_PRESSURE), rtol=1e-8)
