@@ -1385,13 +1385,16 @@ struct Solver {
     int reason = 0;
     bool first = true;
     while (!reason) {
-      if (first) op_pc_apply(b, vv[0].p);
+      // r0 = M^{-1}(b - A x) and its norm; with the column solver the norm comes out of the solve (and the first solve of
+      // a Newton iteration starts from the right-hand side the assembly pass already forward-eliminated)
+      if (first) op_pc_apply_dots(b, vv[0].p, nullptr);
       else {
         op_spmv(x, Wk.p);
         vec_waxpy(Wk.p, -1.0, Wk.p, b);
-        op_pc_apply(Wk.p, vv[0].p);
+        op_pc_apply_dots(Wk.p, vv[0].p, nullptr);
       }
-      double res = norm_host(vv[0].p);
+      fetch_scalars();
+      double res = std::sqrt(h_sc[S_SUM0]);
       reason = ksp_converged(cv, first ? 0 : *its, res);
       first = false;
       if (reason) break;
