@@ -1404,8 +1404,12 @@ struct Solver {
       int it = 0;
       while (it < m && *its < opt.ksp_max_it) {
         double *vnew = vv[it + 1].p;
-        op_BA(vv[it].p, vnew);
-        {  // classical Gram-Schmidt: all dots, then one fused update
+        const bool dots_in_solve = it == 0 && fused_pc_dots();   // (w, v0) reduced by the column solve that produces w
+        if (dots_in_solve) {
+          op_spmv(vv[0].p, Wk.p);
+          op_pc_apply_dots(Wk.p, vnew, vv[0].p);
+        } else op_BA(vv[it].p, vnew);
+        if (!dots_in_solve) {  // classical Gram-Schmidt: all dots, then one fused update
           ProfScope ps(prof, KC_REDUCE);
           DotArgs a;
           a.n = nred; a.nvec = it + 1;
