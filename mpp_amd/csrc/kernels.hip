@@ -1511,7 +1511,7 @@ __global__ __launch_bounds__(kBlock) void k_maxpy_neg(MaxpyArgs a, const double 
 __global__ __launch_bounds__(kBlock) void k_maxpy_val(MaxpyValArgs a, double *x) {
   const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (i < (size_t)a.n) {
-    double v = x[i];
+    double v = a.zero_x ? 0.0 : x[i];
     for (int j = 0; j < a.nvec; ++j) v += a.c[j] * a.v[j][i];
     x[i] = v;
   }

@@ -288,7 +288,7 @@ struct MaxpyArgs { int n, nvec; const double *v[kMaxMultiDot]; };
 void launch_maxpy_neg(const MaxpyArgs &a, const double *sc, double *y, hipStream_t stream);
 void launch_scale(int n, double *x, const double *sc, int slot_inv_of, hipStream_t stream);  // x *= 1/sc[slot]
 // x += sum_j yv[j]*v_j with yv passed by value
-struct MaxpyValArgs { int n, nvec; const double *v[kMaxMultiDot]; double c[kMaxMultiDot]; };
+struct MaxpyValArgs { int n, nvec; const double *v[kMaxMultiDot]; double c[kMaxMultiDot]; bool zero_x = false; /* x = sum (x not read) */ };
 void launch_maxpy_val(const MaxpyValArgs &a, double *x, hipStream_t stream);
 // single-thread scalar updates of the BiCGStab recurrence; step = 0 init, 1 rho/beta, 2 alpha, 3 omega
 void launch_bcgs_scalars(int step, double *sc, hipStream_t stream);

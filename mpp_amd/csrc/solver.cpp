@@ -1380,7 +1380,7 @@ struct Solver {
     }
     KspConv cv{opt.ksp_rtol, opt.ksp_atol, opt.ksp_dtol};
     std::vector<double> H((size_t)(m + 1) * m, 0.0), cs(m), sn(m), rs(m + 1), y(m), hh(m + 1);
-    vec_set(0.0, x);
+    bool x_is_zero = true;   // zero initial guess: x is first written by the update of the first cycle
     *its = 0;
     int reason = 0;
     bool first = true;
@@ -1428,8 +1428,7 @@ struct Solver {
         fetch_scalars();
         for (int j = 0; j <= it; ++j) hh[j] = h_sc[S_SUM0 + j];
         const double tt = norm_host(vnew);
-        bool hapend = false;
-        if (tt == 0.0) hapend = true; else scale_host(vnew, tt);
+        const bool hapend = tt == 0.0;   // v_{it+1} = vnew / tt is formed below, and only if another step will use it
         double *hcol = H.data() + (size_t)it * (m + 1);
         for (int j = 0; j <= it; ++j) hcol[j] = hh[j];
         hcol[it + 1] = tt;
@@ -1449,6 +1448,7 @@ struct Solver {
         ++it; ++*its;
         reason = ksp_converged(cv, *its, res);
         if (reason || hapend) break;
+        if (it < m && *its < opt.ksp_max_it) scale_host(vnew, tt);
       }
       for (int i = it - 1; i >= 0; --i) {
         double s = rs[i];
@@ -1460,10 +1460,13 @@ struct Solver {
         MaxpyValArgs ma;
         ma.n = nred; ma.nvec = it;
         for (int j = 0; j < it; ++j) { ma.v[j] = vv[j].p; ma.c[j] = y[j]; }
+        ma.zero_x = x_is_zero;
         launch_maxpy_val(ma, x, stream);
+        x_is_zero = false;
       }
       if (!reason && *its >= opt.ksp_max_it) reason = -3;
     }
+    if (x_is_zero) vec_set(0.0, x);   // converged before the first step: the answer is the initial guess
     return reason;
   }
   void scale_host(double *x, double divisor) {  // x <- x / divisor
