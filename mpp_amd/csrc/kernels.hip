@@ -1493,6 +1493,13 @@ __global__ void k_bcgs_scalars(int step, double *sc) {
     sc[S_DP] = sqrt(sc[S_SUM0]);
     sc[S_RRP] = sc[S_SUM0 + 1];
     sc[S_RHOOLD] = sc[S_RHO]; sc[S_OMEGAOLD] = sc[S_OMEGA];
+  } else if (step == 6) {  // step 0 when the initial (rp,rp) was all-reduced together with the first (v,rp): it sits in S_SUM0+2
+    sc[S_RHOOLD] = 1.0; sc[S_ALPHA] = 1.0; sc[S_OMEGAOLD] = 1.0; sc[S_FLAG] = 0.0;
+    sc[S_DP0] = sqrt(sc[S_SUM0 + 2]);
+  } else if (step == 7) {  // step 1 of that case
+    const double rho = sc[S_SUM0 + 2];
+    sc[S_RHO] = rho;
+    sc[S_BETA] = (rho / sc[S_RHOOLD]) * (sc[S_ALPHA] / sc[S_OMEGAOLD]);
   } else if (step == 5) {  // step 1 with rho = the (r,rp) the previous iteration's update reduced
     const double rho = sc[S_RRP];
     sc[S_RHO] = rho;

@@ -1168,7 +1168,10 @@ struct Solver {
   bool fused_pc_dots() const {
     return opt.pc_type == 2 && !th && nghost == 0;
   }
-  void op_pc_apply_dots(const double *r, double *z, const double *w) {
+  // slot: the sums land in sc[S_SUM0 + slot ..]; nreduce: how many values from sc[S_SUM0] on are all-reduced afterwards
+  // (-1: just this call's; 0: none -- the caller folds them into a later all-reduce).  slot / nreduce other than the
+  // defaults are for the fused path only.
+  void op_pc_apply_dots(const double *r, double *z, const double *w, int slot = 0, int nreduce = -1) {
     if (!fused_pc_dots()) {
       op_pc_apply(r, z);
       if (w) dots_dev({{w, z}, {z, z}}); else dots_dev({{z, z}});
@@ -1179,9 +1182,10 @@ struct Solver {
       int nbk;
       if (!w && r == fwd_rhs && pc_ready) nbk = launch_tri_back_dots(tri_args(), fwd_elim.p, z, col_partials.p, stream);
       else nbk = launch_tri_solve_dots(tri_args(), r, z, w, col_partials.p, stream);
-      launch_finalize_partials_long(nbk, w ? 2 : 1, col_partials.p, sc.p, stream);
+      launch_finalize_partials_long(nbk, w ? 2 : 1, col_partials.p, sc.p + slot, stream);
     }
-    if (comm.active()) comm.allreduce_sum(sc.p + S_SUM0, w ? 2 : 1, stream);
+    if (nreduce < 0) nreduce = w ? 2 : 1;
+    if (comm.active() && nreduce > 0) comm.allreduce_sum(sc.p + S_SUM0, nreduce, stream);
   }
 
   // ---- reductions: deterministic two-stage sums, RCCL all-reduce across ranks, results on device and host ----
@@ -1307,12 +1311,16 @@ struct Solver {
     // r0 = rp = M^{-1} b, p0 = r0 (beta*p and omega*beta*v vanish) and rho0 = (r0,r0) is the squared norm
     // already reduced for the convergence test, so r0 is written once into RP and aliased as R and P.
     KspConv cv{opt.ksp_rtol, opt.ksp_atol, opt.ksp_dtol};
-    op_pc_apply_dots(b, RP.p, nullptr);   // leaves (rp,rp) in sc[S_SUM0]
+    // Across ranks the initial (rp,rp) is not needed (rho, the iteration-0 test) before the first (v,rp) is: both travel in
+    // one all-reduce, (rp,rp) parked in sc[S_SUM0+2] meanwhile.
+    const bool merge0 = comm.active() && fused_pc_dots() && opt.defer_test0;
+    if (merge0) op_pc_apply_dots(b, RP.p, nullptr, 2, 0);
+    else op_pc_apply_dots(b, RP.p, nullptr);   // leaves (rp,rp) in sc[S_SUM0]
     *its = 0;
     // The convergence test of iteration 0 needs ||rp|| on the host.  Rather than stall the queue for it, the first
     // iteration is issued at once and the test is made when its scalars come back: had it fired, the answer is the zero
     // initial guess (restored below) and nothing else of the speculative iteration is visible.
-    launch_bcgs_scalars(0, sc.p, stream);
+    if (!merge0) launch_bcgs_scalars(0, sc.p, stream);
     bool test0_pending = true;
     double dp = 0.0;
     int reason = 0;
@@ -1328,14 +1336,18 @@ struct Solver {
       // rho = (r,rp): the initial (rp,rp) at i == 0; a separate reduction at i == 1 (the first update does not read rp:
       // most solves of the column-structured problems end there); afterwards the update kernel reduces it on the way
       if (i == 1) dots_dev({{Rcur, RP.p}});
-      launch_bcgs_scalars(i >= 2 ? 5 : 1, sc.p, stream);
+      if (!(merge0 && i == 0)) launch_bcgs_scalars(i >= 2 ? 5 : 1, sc.p, stream);
       if (i > 0) {
         ProfScope ps(prof, KC_VEC);
         launch_bcgs_p(nred, Pv.p, Pcur, Rcur, V.p, sc.p, stream);
         Pcur = Pv.p;
       }
       op_spmv(Pcur, Wk.p);
-      op_pc_apply_dots(Wk.p, V.p, RP.p);   // (v,rp) in sc[S_SUM0]  [(v,v) in S_SUM0+1 is not used]
+      if (merge0 && i == 0) {
+        op_pc_apply_dots(Wk.p, V.p, RP.p, 0, 3);   // (v,rp), (v,v) and the parked (rp,rp) in one all-reduce
+        launch_bcgs_scalars(6, sc.p, stream);
+        launch_bcgs_scalars(7, sc.p, stream);
+      } else op_pc_apply_dots(Wk.p, V.p, RP.p);   // (v,rp) in sc[S_SUM0]  [(v,v) in S_SUM0+1 is not used]
       launch_bcgs_scalars(2, sc.p, stream);
       { ProfScope ps(prof, KC_VEC); launch_waxpy(nred, S.p, sc.p, S_ALPHA, -1.0, 0.0, V.p, Rcur, stream); }
       op_spmv(S.p, Wk.p);
