@@ -146,7 +146,12 @@ struct Solver {
   DevBuf<double> partials, sc, spmv_partials, col_partials;
   // complete-row column march (plan_complete_rows): boundary cells sit on column ends only
   bool rows_plan = false, asm_sums = false;
-  struct Trial { const double *x = nullptr, *y = nullptr; double a = 0.0; } ls_point;   // pending X + a Y of the line search
+  struct Trial { const double *x = nullptr, *y = nullptr; double a = 0.0; } ls_point;
+  // The line search's first reductions (||Y||, F.(J Y), ||X||) issued by the Krylov solver itself, behind the update of what
+  // is expected to be its last iteration: one read-back and one all-reduce serve both.  Armed when the previous solve of
+  // this handle converged in one iteration (the column-structured problems); a solve that goes on discards them.
+  struct LsAhead { bool armed = false, done = false; const double *F = nullptr, *X = nullptr; double r3[3] = {0, 0, 0}; } ls_ahead;
+  bool ksp_one_shot = false;   // pending X + a Y of the line search
   DevBuf<int> d_col_bc;
   DevBuf<double> bc_side_f, bc_side_d, d_DqA, d_porvol, fwd_elim;
   const double *fwd_rhs = nullptr;   // the residual vector whose forward elimination fwd_elim holds (for the current factors)
@@ -1045,18 +1050,21 @@ struct Solver {
     const int v = spmv_variant();
     return opt.fused_ls_dots && (v == 20 || v == 21) && compact_index && nghost == 0;
   }
-  void op_spmv_dots(const double *y, const double *f, const double *x, double *out) {
+  // launches only: the sums go to sc[S_SUM0 + slot ..]; nreduce values from sc[S_SUM0] on are all-reduced (0: none)
+  int op_spmv_dots_launch(const double *y, const double *f, const double *x, int slot, int nreduce) {
     const int tpw = spmv_variant() == 20 ? 4 : 8, nv = x ? 3 : 2;
-    {
-      ProfScope ps(prof, KC_REDUCE);
-      const size_t nbmax = (size_t)spmv_compact_dots_blocks(tpw, nred);
-      const size_t need = 3 * (nbmax + nbmax / 2048 + 1);
-      if (spmv_partials.n < need) spmv_partials.alloc(need);
-      const int nbk = launch_spmv_compact_dots(tpw, nred, max_row_nnz, compact_split, d_tileptr.p, d_roff.p, d_dcol.p, d_val.p, y, f, x,
-                                               spmv_partials.p, stream);
-      launch_finalize_partials_long(nbk, nv, spmv_partials.p, sc.p, stream);
-      if (comm.active()) comm.allreduce_sum(sc.p + S_SUM0, nv, stream);
-    }
+    ProfScope ps(prof, KC_REDUCE);
+    const size_t nbmax = (size_t)spmv_compact_dots_blocks(tpw, nred);
+    const size_t need = 3 * (nbmax + nbmax / 2048 + 1);
+    if (spmv_partials.n < need) spmv_partials.alloc(need);
+    const int nbk = launch_spmv_compact_dots(tpw, nred, max_row_nnz, compact_split, d_tileptr.p, d_roff.p, d_dcol.p, d_val.p, y, f, x,
+                                             spmv_partials.p, stream);
+    launch_finalize_partials_long(nbk, nv, spmv_partials.p, sc.p + slot, stream);
+    if (comm.active() && nreduce > 0) comm.allreduce_sum(sc.p + S_SUM0, nreduce, stream);
+    return nv;
+  }
+  void op_spmv_dots(const double *y, const double *f, const double *x, double *out) {
+    const int nv = op_spmv_dots_launch(y, f, x, 0, x ? 3 : 2);
     fetch_scalars();
     for (int j = 0; j < nv; ++j) out[j] = h_sc[S_SUM0 + j];
   }
@@ -1357,8 +1365,11 @@ struct Solver {
         ProfScope ps(prof, KC_REDUCE);
         const int nbk = launch_bcgs_xr(nred, i == 0, x, R.p, Pcur, S.p, T.p, RP.p, sc.p, partials.p, stream);
         launch_finalize_partials(nbk, i == 0 ? 1 : 2, partials.p, sc.p, stream);
-        if (comm.active()) comm.allreduce_sum(sc.p + S_SUM0, i == 0 ? 1 : 2, stream);
+        if (!(ls_ahead.armed && i == 0) && comm.active()) comm.allreduce_sum(sc.p + S_SUM0, i == 0 ? 1 : 2, stream);
       }
+      const bool ahead = ls_ahead.armed && i == 0;
+      int ahead_nv = 0;
+      if (ahead) ahead_nv = op_spmv_dots_launch(x, ls_ahead.F, ls_ahead.X, 1, 1 + (ls_ahead.X ? 3 : 2));   // x is final if we stop here
       Rcur = R.p;
       launch_bcgs_scalars(4, sc.p, stream);
       fetch_scalars();
@@ -1377,6 +1388,10 @@ struct Solver {
       dp = h_sc[S_DP];
       ++*its;
       reason = ksp_converged(cv, i + 1, dp);
+      if (reason > 0 && ahead) {
+        ls_ahead.done = true;
+        for (int j = 0; j < ahead_nv; ++j) ls_ahead.r3[j] = h_sc[S_SUM0 + 1 + j];
+      }
       if (reason) return reason;
       if (rho == 0.0) return -5;
       ++i;
@@ -1520,7 +1535,10 @@ struct Solver {
     double lambda = 1.0, lambdatemp, lambdaprev, gprev, g, gnorm = 0.0, wnorm2 = 0.0;
     double r3[3];   // initslope = F . (J Y), ||Y||, ||X||
     // ||X|| was reduced together with ||F(X)|| when X was the accepted trial point of the previous line search
-    if (spmv_dots_fused()) {
+    if (ls_ahead.done) {            // reduced by the Krylov solver behind its last update
+      ls_ahead.done = false;
+      r3[0] = ls_ahead.r3[0]; r3[1] = ls_ahead.r3[1]; r3[2] = ls_ahead.r3[2];
+    } else if (spmv_dots_fused()) {
       op_spmv_dots(Yv, Fv, xnorm_known ? nullptr : X, r3);
     } else {
       op_spmv(Yv, Wv);
@@ -1618,7 +1636,12 @@ struct Solver {
     for (int i = 0; !reason && i < opt.snes_max_it; ++i) {
       if (!jac_valid) op_jacobian(X, Fv);
       int its = 0;
+      ls_ahead.armed = opt.ls_ahead && ksp_one_shot && opt.ksp_type == 2 && spmv_dots_fused();
+      ls_ahead.done = false;
+      ls_ahead.F = Fv; ls_ahead.X = i > 0 ? nullptr : X;
       const int kreason = ksp_solve(Fv, Yv, &its);
+      ls_ahead.armed = false;
+      ksp_one_shot = kreason > 0 && its == 1;
       *linear_its += its;
       if (kreason < 0) { reason = -3; break; }
       const int lsfail = linesearch_bt(X, Fv, Yv, Wv, Gv, fnorm, xnorm, ynorm, jac_valid, i > 0);
@@ -2205,6 +2228,7 @@ struct Solver {
     else if (key == "fused_predict") opt.fused_predict = num() != 0;
     else if (key == "fused_ls_dots") opt.fused_ls_dots = num() != 0;
     else if (key == "ell_assembly") opt.ell_assembly = num() != 0;
+    else if (key == "ls_ahead") opt.ls_ahead = num() != 0;
     else if (key == "defer_test0") opt.defer_test0 = num() != 0;
     else if (key == "fused_rows") opt.fused_rows = num() != 0;
     else if (key == "track_mass_exchange") opt.track_mass_exchange = num() != 0;
