@@ -1785,9 +1785,12 @@ void launch_bcgs_p(int n, double *P, const double *Pold, const double *R, const 
                    hipStream_t stream) {
   if (n > 0) LAUNCH(k_bcgs_p, dim3(vec_grid(n)), n, P, Pold, R, V, sc);
 }
-int launch_bcgs_xr(int n, bool first, double *X, double *R, const double *P, const double *S, const double *T,
+int bcgs_xr_blocks(int n, bool wide) { return wide ? vec_grid(n) : red_grid(n); }
+int launch_bcgs_xr(int n, bool first, bool wide, double *X, double *R, const double *P, const double *S, const double *T,
                    const double *RP, const double *sc, double *partials, hipStream_t stream) {
-  const int g = red_grid(n);
+  // a kernel that writes two vectors wants one pair per lane (a capped grid streams ~20 % slower, tools/membench.hip);
+  // its many partial sums go through the two-stage finalisation
+  const int g = wide ? vec_grid(n) : red_grid(n);
   if (first) LAUNCH(k_bcgs_xr<true>, dim3(g), n, X, R, P, S, T, RP, sc, partials);
   else LAUNCH(k_bcgs_xr<false>, dim3(g), n, X, R, P, S, T, RP, sc, partials);
   return g;

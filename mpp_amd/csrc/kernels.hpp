@@ -273,7 +273,10 @@ void launch_bcgs_p(int n, double *P, const double *Pold, const double *R, const 
 // x <- alpha p + omega s + x (x not read when `first`: zero initial guess), r <- s - omega t; also leaves the
 // partial sums of r.r in `partials` and, unless `first`, those of r.rp in its second row (the next iteration's rho);
 // returns the number of partial blocks
-int launch_bcgs_xr(int n, bool first, double *X, double *R, const double *P, const double *S, const double *T,
+// wide: one 16-byte pair per lane (bcgs_xr_blocks(n, true) partial sums per vector: finish with
+// launch_finalize_partials_long) instead of the capped reduction grid
+int bcgs_xr_blocks(int n, bool wide);
+int launch_bcgs_xr(int n, bool first, bool wide, double *X, double *R, const double *P, const double *S, const double *T,
                    const double *RP, const double *sc, double *partials, hipStream_t stream);
 // multi-dot: sums[j] = x . ys[j], j < nvec; two-stage deterministic reduction (partials -> sc[S_SUM0+j])
 struct DotArgs { int n, nvec; const double *x[kMaxMultiDot]; const double *y[kMaxMultiDot]; };

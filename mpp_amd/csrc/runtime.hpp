@@ -157,6 +157,7 @@ struct Options {
   int ilu_chain = 1;           // ILU(0) solves: one launch per triangle, tiles chained by flags (1: where it pays, 2: always;
                                // 0: one launch per level)
   bool ls_ahead = true;        // the line search's first reductions ride behind the Krylov solver's last update
+  bool wide_xr = true;         // BiCGStab update kernel on a one-pair-per-lane grid (large vectors)
   bool fused_predict = true;   // skip the fused Jacobian at the first trial when the previous line search backtracked
   int fused_trials = 2;        // ... for the first `fused_trials` trial points of a line search (later ones: F only)
 };

@@ -143,7 +143,7 @@ struct Solver {
   DevBuf<double> soln, soln_prev, accum_prev, F, Y, W, G, R, RP, V, T, S, Pv, Wk, tmp_ext, tmp_int;
   DevBuf<double> aux_kr, aux_dkr, aux_den, aux_dden;
   DevBuf<double> tri_l, tri_invb, tri_c, jac_invd;
-  DevBuf<double> partials, sc, spmv_partials, col_partials;
+  DevBuf<double> partials, sc, spmv_partials, col_partials, xr_partials;
   // complete-row column march (plan_complete_rows): boundary cells sit on column ends only
   bool rows_plan = false, asm_sums = false;
   struct Trial { const double *x = nullptr, *y = nullptr; double a = 0.0; } ls_point;
@@ -1363,8 +1363,15 @@ struct Solver {
       launch_bcgs_scalars(3, sc.p, stream);
       {
         ProfScope ps(prof, KC_REDUCE);
-        const int nbk = launch_bcgs_xr(nred, i == 0, x, R.p, Pcur, S.p, T.p, RP.p, sc.p, partials.p, stream);
-        launch_finalize_partials(nbk, i == 0 ? 1 : 2, partials.p, sc.p, stream);
+        const bool wide = opt.wide_xr && nred >= (1 << 22);
+        double *pbuf = partials.p;
+        if (wide) {
+          const size_t nb = (size_t)bcgs_xr_blocks(nred, true), need = 2 * (nb + nb / 2048 + 1);
+          if (xr_partials.n < need) xr_partials.alloc(need);
+          pbuf = xr_partials.p;
+        }
+        const int nbk = launch_bcgs_xr(nred, i == 0, wide, x, R.p, Pcur, S.p, T.p, RP.p, sc.p, pbuf, stream);
+        launch_finalize_partials_long(nbk, i == 0 ? 1 : 2, pbuf, sc.p, stream);
         if (!(ls_ahead.armed && i == 0) && comm.active()) comm.allreduce_sum(sc.p + S_SUM0, i == 0 ? 1 : 2, stream);
       }
       const bool ahead = ls_ahead.armed && i == 0;
@@ -2229,6 +2236,7 @@ struct Solver {
     else if (key == "fused_ls_dots") opt.fused_ls_dots = num() != 0;
     else if (key == "ell_assembly") opt.ell_assembly = num() != 0;
     else if (key == "ls_ahead") opt.ls_ahead = num() != 0;
+    else if (key == "wide_xr") opt.wide_xr = num() != 0;
     else if (key == "defer_test0") opt.defer_test0 = num() != 0;
     else if (key == "fused_rows") opt.fused_rows = num() != 0;
     else if (key == "track_mass_exchange") opt.track_mass_exchange = num() != 0;
@@ -2658,7 +2666,7 @@ int mppgpu_bench_kernel(mppgpu_handle h, const char *name, int variant, int reps
     else if (k == "residual") { cls = mpp::KC_RESIDUAL; S.op_residual(S.soln.p, S.G.p); }
     else if (k == "jacobian") { cls = mpp::KC_JACOBIAN; S.op_jacobian(S.soln.p); }
     else if (k == "assemble_both") { cls = mpp::KC_JACOBIAN; S.op_residual_jacobian(S.soln.p, S.G.p); }
-    else if (k == "bcgs_xr") { cls = mpp::KC_VEC; mpp::launch_bcgs_xr(S.n, false, S.Y.p, S.R.p, S.Pv.p, S.S.p, S.T.p, S.RP.p, S.sc.p, S.partials.p, S.stream); }
+    else if (k == "bcgs_xr") { cls = mpp::KC_VEC; mpp::launch_bcgs_xr(S.n, false, false, S.Y.p, S.R.p, S.Pv.p, S.S.p, S.T.p, S.RP.p, S.sc.p, S.partials.p, S.stream); }
     else if (k == "waxpy") { cls = mpp::KC_VEC; mpp::launch_waxpy(S.n, S.W.p, S.sc.p, -1, 1.0, 0.5, S.soln.p, S.G.p, S.stream); }
     else if (k == "dots3") { cls = mpp::KC_REDUCE; S.dots_dev({{S.Y.p, S.Y.p}, {S.soln.p, S.soln.p}, {S.F.p, S.W.p}}); }
     else if (k == "copy") { cls = mpp::KC_VEC; mpp::launch_copy(S.n, S.soln.p, S.G.p, S.stream); }
