@@ -169,7 +169,7 @@ int mppgpu_set_source_sink_auxvar(mppgpu_handle h, int var_type, int n, const do
  * (0|1), "fused_trials" (line-search trial points whose Jacobian is assembled together with the residual),
  * "fused_predict", "fused_rows" (0|1: column march that folds the boundary fluxes in and also leaves ||F||, ||X|| and
  * the column LU), "fused_ls_dots" (0|1: line-search reductions inside the SpMV), "ilu_graph", "ilu_chain" (0 one launch
- * per level | 1 chained tiles where they pay | 2 always chained), "ell_assembly", "defer_test0", "track_mass_exchange". */
+ * per level | 1 chained tiles where they pay | 2 always chained), "ell_assembly", "defer_test0", "ls_ahead", "wide_xr", "track_mass_exchange". */
 int mppgpu_set_option(mppgpu_handle h, const char *key, const char *value);
 
 /* mpp%AllocateAuxVars + mpp%SetupProblem (src/mpp/mpp/MultiPhysicsProbVSFM.F90:710-1015): builds the CSR
