@@ -158,6 +158,7 @@ struct Options {
                                // 0: one launch per level)
   bool ls_ahead = true;        // the line search's first reductions ride behind the Krylov solver's last update
   bool wide_xr = true;         // BiCGStab update kernel on a one-pair-per-lane grid (large vectors)
+  int spmv_tpw = 0;            // > 0: 64-row tiles per wave of the compact-index SpMV (default 4 / 8 by variant)
   bool fused_predict = true;   // skip the fused Jacobian at the first trial when the previous line search backtracked
   int fused_trials = 2;        // ... for the first `fused_trials` trial points of a line search (later ones: F only)
 };

@@ -1042,7 +1042,7 @@ struct Solver {
     const int v = spmv_variant();
     if (v == 20 || v == 21) {
       if (!compact_index) throw Error("spmv_variant 20/21 need the compact index (rows of <= 8 entries whose columns lie within 2^15 of their 64-row tile)");
-      launch_spmv_compact(v == 20 ? 4 : 8, nred, max_row_nnz, compact_split, d_tileptr.p, d_roff.p, d_dcol.p, d_val.p, x, y, stream);
+      launch_spmv_compact(opt.spmv_tpw > 0 ? opt.spmv_tpw : (v == 20 ? 4 : 8), nred, max_row_nnz, compact_split, d_tileptr.p, d_roff.p, d_dcol.p, d_val.p, x, y, stream);
     } else launch_spmv(v, nred, max_row_nnz, d_rowptr.p, d_col.p, d_val.p, x, y, stream);
   }
   // the line search's first reductions in one pass over the matrix: out = {y.y, f.(A y), x.x (x != nullptr)}
@@ -2237,6 +2237,7 @@ struct Solver {
     else if (key == "ell_assembly") opt.ell_assembly = num() != 0;
     else if (key == "ls_ahead") opt.ls_ahead = num() != 0;
     else if (key == "wide_xr") opt.wide_xr = num() != 0;
+    else if (key == "spmv_tpw") opt.spmv_tpw = (int)num();
     else if (key == "defer_test0") opt.defer_test0 = num() != 0;
     else if (key == "fused_rows") opt.fused_rows = num() != 0;
     else if (key == "track_mass_exchange") opt.track_mass_exchange = num() != 0;
