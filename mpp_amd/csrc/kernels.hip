@@ -339,23 +339,30 @@ __global__ __launch_bounds__(kBlock) void k_flux_rows_ell(GenArgs a) {
   me.sat = me.dsat = 0.0;
   double f = RES ? a.F[i] : 0.0;
   double dconn = 0.0;
+  // every operand of every neighbour is requested before the first flux is evaluated: one memory round trip per row
+  Aux ot[K];
+  ConnGeom g[K];
+  bool live[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     const int o = oth[k];
-    const bool live = mine && enc[k] >= 0 && is_active(ca, o);
-    const int ic = enc[k] >= 0 ? (enc[k] >> 1) : 0, side = enc[k] & 1;
-    Aux ot;
-    ot.P = ca.P[o]; ot.kr = a.aux.kr[o]; ot.den = a.aux.den[o];
-    ot.dkr = JAC ? a.aux.dkr[o] : 0.0; ot.dden = JAC ? a.aux.dden[o] : 0.0;
-    ot.sat = ot.dsat = 0.0;
-    ConnGeom g;
-    g.Dq = a.conn.Dq[ic]; g.upweight = a.conn.upw[ic]; g.dist_gravity = a.conn.dgrav[ic]; g.area = a.conn.area[ic];
+    const int ic = enc[k] >= 0 ? (enc[k] >> 1) : 0;
+    live[k] = mine && enc[k] >= 0 && is_active(ca, o);
+    ot[k].P = ca.P[o]; ot[k].kr = a.aux.kr[o]; ot[k].den = a.aux.den[o];
+    ot[k].dkr = JAC ? a.aux.dkr[o] : 0.0; ot[k].dden = JAC ? a.aux.dden[o] : 0.0;
+    ot[k].sat = ot[k].dsat = 0.0;
+    g[k].Dq = a.conn.Dq[ic]; g[k].upweight = a.conn.upw[ic]; g[k].dist_gravity = a.conn.dgrav[ic]; g[k].area = a.conn.area[ic];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int side = enc[k] & 1;
     double Jup = 0.0, Jdn = 0.0;
-    const double flux = side == 0 ? richards_flux<JAC>(me, ot, g, 0, Jup, Jdn) : richards_flux<JAC>(ot, me, g, 0, Jup, Jdn);
-    if (RES && live) f = side == 0 ? f - flux : f + flux;
+    const double flux = side == 0 ? richards_flux<JAC>(me, ot[k], g[k], 0, Jup, Jdn) : richards_flux<JAC>(ot[k], me, g[k], 0, Jup, Jdn);
+    if (RES && live[k]) f = side == 0 ? f - flux : f + flux;
     if (JAC) {
-      if (live) dconn += side == 0 ? Jup : -Jdn;
-      if (slot[k] >= 0) a.val[slot[k]] = live ? (side == 0 ? Jdn : -Jup) : 0.0;
+      if (live[k]) dconn += side == 0 ? Jup : -Jdn;
+      if (slot[k] >= 0) a.val[slot[k]] = live[k] ? (side == 0 ? Jdn : -Jup) : 0.0;
     }
   }
   if (JAC && mine) a.val[a.diag_slot[i]] = dconn + a.val[a.diag_slot[i]];
