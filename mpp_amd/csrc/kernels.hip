@@ -819,6 +819,81 @@ __global__ __launch_bounds__(kBlock) void k_spmv_pipe_c(int n, int tpw, int spli
   }
 }
 
+// variants 22/23: the compact index for patterns whose columns lie further than 2^15 rows from their tile (3-D grids: the
+// y-neighbour of a cell sits nx/64 column tiles away).  A tile's columns cluster around a few places -- its own rows, the
+// tiles next to it, the two y-neighbour tiles -- so each tile carries up to 8 window bases (int32) and an entry is
+// (window << 13) | offset, 13-bit offset from its window's base.  Same 8 index bytes per 3-point row (+0.5 byte per row
+// for the bases), same values, x, y and summation order as every other variant.
+template <int J>
+__global__ __launch_bounds__(kBlock) void k_spmv_pipe_mb(int n, int tpw, const int *__restrict__ tileptr,
+                                                         const unsigned short *__restrict__ roff,
+                                                         const unsigned short *__restrict__ mcol, const int *__restrict__ tbase,
+                                                         const double *__restrict__ val, const double *__restrict__ x,
+                                                         double *__restrict__ y) {
+  __shared__ double prod[kBlock / 64][64 * J];
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  double *lp = prod[w];
+  const int ntiles = (n + 63) >> 6;
+  const int tile0 = (blockIdx.x * (kBlock / 64) + w) * tpw;
+  if (tile0 >= ntiles) return;
+  const int tend = min(tile0 + tpw, ntiles);
+  int sA = tileptr[tile0], sB = tileptr[tile0 + 1];
+  double vn[J];
+  int cn[J], rsn = 0, tbn = 0;
+  auto prefetch = [&](int tile, int s0, int cnt) {
+    const int r = (tile << 6) + lane;
+    rsn = (r < n) ? (int)__builtin_nontemporal_load(roff + r) : cnt;
+    tbn = tbase[(size_t)tile * 8 + (lane & 7)];          // lanes 0..7 hold the tile's window bases
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int k = lane + 64 * j;
+      const bool ok = k < cnt;
+      vn[j] = ok ? __builtin_nontemporal_load(val + s0 + k) : 0.0;
+      cn[j] = ok ? (int)__builtin_nontemporal_load(mcol + s0 + k) : 0;
+    }
+  };
+  prefetch(tile0, sA, sB - sA);
+  for (int tile = tile0; tile < tend; ++tile) {
+    const int cnt = sB - sA;
+    const int base = tile << 6;
+    double vc[J];
+    int cc[J];
+    const int rs = rsn, tbc = tbn;
+#pragma unroll
+    for (int j = 0; j < J; ++j) { vc[j] = vn[j]; cc[j] = cn[j]; }
+    double xs[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int wb = __shfl(tbc, cc[j] >> 13, 64);         // base of the entry's window
+      xs[j] = (lane + 64 * j < cnt) ? x[wb + (cc[j] & 8191)] : 0.0;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (tile + 1 < tend) {
+      sA = sB;
+      sB = tileptr[tile + 2];
+      prefetch(tile + 1, sA, sB - sA);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int nxt = __shfl_down(rs, 1, 64);
+    const int re = (lane == 63) ? cnt : nxt;
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+      if (lane + 64 * j < cnt) lp[lane + 64 * j] = vc[j] * xs[j];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int r = base + lane;
+    if (r < n) {
+      double sum = 0.0;
+      for (int k = rs; k < re; ++k) sum += lp[k];
+      __builtin_nontemporal_store(sum, y + r);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // the same product with the line search's reductions fused in and y never written: leaves the partial sums of x.x, f.(A x)
 // and (xx != nullptr) xx.xx, layout partials[j*gridDim.x + b] -- SNESLineSearchApply_BT needs only ||Y||, F.(J Y) and ||X||
 template <int J, bool SPLIT>
@@ -1632,6 +1707,17 @@ void launch_spmv_compact(int tpw, int n, int max_row_nnz, int split, const int *
   if (max_row_nnz <= 3) LAUNCH((k_spmv_pipe_c<3, false>), grid, n, tpw, split, tileptr, roff, dcol, val, x, y);
   else if (max_row_nnz <= 7) LAUNCH((k_spmv_pipe_c<7, false>), grid, n, tpw, split, tileptr, roff, dcol, val, x, y);
   else LAUNCH((k_spmv_pipe_c<8, false>), grid, n, tpw, split, tileptr, roff, dcol, val, x, y);
+}
+
+void launch_spmv_multibase(int tpw, int n, int max_row_nnz, const int *tileptr, const unsigned short *roff,
+                           const unsigned short *mcol, const int *tbase, const double *val, const double *x, double *y,
+                           hipStream_t stream) {
+  if (n <= 0) return;
+  const long long tiles = ((long long)n + 63) / 64, waves = (tiles + tpw - 1) / tpw;
+  const dim3 grid((int)((waves + 3) / 4));
+  if (max_row_nnz <= 3) LAUNCH(k_spmv_pipe_mb<3>, grid, n, tpw, tileptr, roff, mcol, tbase, val, x, y);
+  else if (max_row_nnz <= 7) LAUNCH(k_spmv_pipe_mb<7>, grid, n, tpw, tileptr, roff, mcol, tbase, val, x, y);
+  else LAUNCH(k_spmv_pipe_mb<8>, grid, n, tpw, tileptr, roff, mcol, tbase, val, x, y);
 }
 
 int spmv_compact_dots_blocks(int tpw, int n) {

@@ -132,6 +132,11 @@ void launch_spmv(int variant, int n, int max_row_nnz, const int *rowptr, const i
 // split > 0 (field-blocked systems): entries are (offset << 1) | block, offsets from the tile's first cell in that block
 void launch_spmv_compact(int tpw, int n, int max_row_nnz, int split, const int *tileptr, const unsigned short *roff,
                          const short *dcol, const double *val, const double *x, double *y, hipStream_t stream);
+// the compact index with up to 8 window bases per tile (tbase[8*tile + w]) and entries (window << 13) | offset: for patterns
+// whose columns lie further than 2^15 rows from their tile (3-D grids)
+void launch_spmv_multibase(int tpw, int n, int max_row_nnz, const int *tileptr, const unsigned short *roff,
+                           const unsigned short *mcol, const int *tbase, const double *val, const double *x, double *y,
+                           hipStream_t stream);
 // x.x, f.(A x) and optionally xx.xx without writing A x: partial sums in partials[j*nb + b], nb = the return value
 // (= spmv_compact_dots_blocks, which sizes the buffer: 3*nb doubles); finish with launch_finalize_partials
 int spmv_compact_dots_blocks(int tpw, int n);

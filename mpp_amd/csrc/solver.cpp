@@ -122,6 +122,9 @@ struct Solver {
   DevBuf<int> d_tileptr;
   DevBuf<unsigned short> d_roff;
   DevBuf<short> d_dcol;
+  DevBuf<unsigned short> d_mcol;   // multi-base entries (window << 13) | offset
+  DevBuf<int> d_tbase;             // 8 window bases per 64-row tile
+  bool multibase_index = false;    // variants 22/23 available (built when the single-base compact index is not)
   bool compact_index = false;
   int compact_split = 0;   // > 0: the compact index of a field-blocked system (entries carry their block, offsets are per block)
   DevBuf<int> d_cc_cell, d_cc_ptr, d_bc_type;
@@ -660,6 +663,7 @@ struct Solver {
       th_liq.assign(n, 0.0); th_ice.assign(n, 0.0); th_snow.assign(n, 0.0); th_tuning.assign(n, 1.0); th_nsnow.assign(n, 0);
     }
     build_compact_index();
+    build_multibase_index();
     plan_complete_rows();
     if (nghost > 0) {
       halo.d_send_idx.upload(halo.send_cells, stream);
@@ -1040,7 +1044,11 @@ struct Solver {
     halo_exchange(x);
     ProfScope ps(prof, KC_SPMV);
     const int v = spmv_variant();
-    if (v == 20 || v == 21) {
+    if (v == 22 || v == 23) {
+      if (!multibase_index) throw Error("spmv_variant 22/23 need the multi-base compact index (built when 20/21 are not available: rows of <= 8 entries, at most 8 windows of 8192 rows per tile)");
+      launch_spmv_multibase(opt.spmv_tpw > 0 ? opt.spmv_tpw : (v == 22 ? 4 : 8), nred, max_row_nnz, d_tileptr.p, d_roff.p, d_mcol.p,
+                            d_tbase.p, d_val.p, x, y, stream);
+    } else if (v == 20 || v == 21) {
       if (!compact_index) throw Error("spmv_variant 20/21 need the compact index (rows of <= 8 entries whose columns lie within 2^15 of their 64-row tile)");
       launch_spmv_compact(opt.spmv_tpw > 0 ? opt.spmv_tpw : (v == 20 ? 4 : 8), nred, max_row_nnz, compact_split, d_tileptr.p, d_roff.p, d_dcol.p, d_val.p, x, y, stream);
     } else launch_spmv(v, nred, max_row_nnz, d_rowptr.p, d_col.p, d_val.p, x, y, stream);
@@ -1104,9 +1112,46 @@ struct Solver {
     compact_index = true;
     compact_split = split;
   }
+  // the windowed index for patterns the single-base one cannot hold (see k_spmv_pipe_mb): per tile the sorted columns are
+  // covered greedily by windows of 8192 rows; more than 8 windows in any tile: no index
+  void build_multibase_index() {
+    multibase_index = false;
+    const bool asked = opt.spmv_variant == 22 || opt.spmv_variant == 23;   // (also on request, next to the single-base index)
+    if ((compact_index && !asked) || th || max_row_nnz > 8 || nghost > 0) return;
+    const int ntiles = (nrow + 63) / 64;
+    std::vector<int> tp((size_t)ntiles + 2, 0), tb((size_t)ntiles * 8, 0), cols;
+    std::vector<unsigned short> ro(nrow), mc(nnz);
+    for (int t = 0; t < ntiles; ++t) {
+      const int r0 = t * 64, r1 = std::min(nrow, r0 + 64);
+      tp[t] = h_rowptr[r0];
+      cols.assign(h_col.begin() + h_rowptr[r0], h_col.begin() + h_rowptr[r1]);
+      std::sort(cols.begin(), cols.end());
+      int nb = 0;
+      int *b = &tb[(size_t)t * 8];
+      for (int c : cols)
+        if (nb == 0 || c >= b[nb - 1] + 8192) {
+          if (nb == 8) return;
+          b[nb++] = c;
+        }
+      for (int k = nb; k < 8; ++k) b[k] = nb ? b[nb - 1] : 0;
+      for (int r = r0; r < r1; ++r) {
+        ro[r] = (unsigned short)(h_rowptr[r] - h_rowptr[r0]);
+        for (int k = h_rowptr[r]; k < h_rowptr[r + 1]; ++k) {
+          int wdw = nb - 1;
+          while (wdw > 0 && h_col[k] < b[wdw]) --wdw;
+          mc[k] = (unsigned short)((wdw << 13) | (h_col[k] - b[wdw]));
+        }
+      }
+    }
+    tp[ntiles] = nnz; tp[ntiles + 1] = nnz;
+    d_tileptr.upload(tp, stream); d_roff.upload(ro.data(), ro.size(), stream); d_mcol.upload(mc.data(), mc.size(), stream);
+    d_tbase.upload(tb, stream);
+    multibase_index = true;
+  }
   int spmv_variant() const {
     if (opt.spmv_variant >= 0) return opt.spmv_variant;
     if (compact_index && nrow >= (1 << 21)) return 20;   // measured: ahead of the stream kernel from ~2 M rows (3- and 7-point)
+    if (multibase_index && nrow >= (1 << 21)) return 22;
     // measured on MI355X (profiles/): the software-pipelined wave kernel wins once there are enough row tiles to
     // fill the chip several times over; the block CSR-stream kernel wins on small, cache-resident matrices
     return (max_row_nnz <= 8 && nrow >= (1 << 23)) ? 17 : 1;
@@ -2657,7 +2702,10 @@ int mppgpu_bench_kernel(mppgpu_handle h, const char *name, int variant, int reps
   auto once = [&]() {
     if (k == "spmv") {
       cls = mpp::KC_SPMV;
-      if (variant == 20 || variant == 21) {
+      if (variant == 22 || variant == 23) {
+        if (!S.multibase_index) throw mpp::Error("no multi-base index for this pattern");
+        mpp::launch_spmv_multibase(variant == 22 ? 4 : 8, S.nrow, S.max_row_nnz, S.d_tileptr.p, S.d_roff.p, S.d_mcol.p, S.d_tbase.p, S.d_val.p, S.soln.p, S.G.p, S.stream);
+      } else if (variant == 20 || variant == 21) {
         if (!S.compact_index) throw mpp::Error("no compact index for this pattern");
         mpp::launch_spmv_compact(variant == 20 ? 4 : 8, S.nrow, S.max_row_nnz, S.compact_split, S.d_tileptr.p, S.d_roff.p, S.d_dcol.p, S.d_val.p, S.soln.p, S.G.p, S.stream);
       } else mpp::launch_spmv(variant, S.nrow, S.max_row_nnz, S.d_rowptr.p, S.d_col.p, S.d_val.p, S.soln.p, S.G.p, S.stream);

@@ -133,7 +133,7 @@ def test_operators_vchannel_7pt():
     assert np.abs(xs - exact).max() <= 1e-7 * np.abs(exact).max()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 13, 14, 17, 18, 20, 21])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 13, 14, 17, 18, 20, 21, 22, 23])
 def test_spmv_variants(variant):
     """every SpMV kernel variant sums each row in entry order (only FMA contraction differs between them):
     3-point and 7-point patterns, ragged sizes (rows not a multiple of 64, last column tile narrower than 64)"""

@@ -113,3 +113,26 @@ def test_chained_and_per_level_ilu_solves_agree_bit_for_bit():
     assert chain.soe.counters() == level.soe.counters()
     assert np.array_equal(chain.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1),
                           level.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1))
+
+
+def test_multibase_spmv_index_on_a_grid_with_far_neighbours():
+    """a 3-D grid whose y-neighbours lie further than 2^15 rows from their tile (the single-base 16-bit index gives up):
+    the windowed index is picked automatically from 2 M rows; here it is forced on a smaller grid with the same property
+    and must reproduce the 32-bit kernels"""
+    prob = P.vchannel(nx=640, ny=3, nz=100)            # y-neighbour 10 column tiles = 64 000 rows away
+    n = prob.mesh.ncells_local
+    x = prob.press_ic - np.random.default_rng(2).uniform(0, 2.5e5, n)
+    ref = P.to_gpu(prob, {"spmv_variant": 0})
+    mb = P.to_gpu(prob, {"spmv_variant": 22})
+    mb8 = P.to_gpu(prob, {"spmv_variant": 23})
+    for g in (ref, mb, mb8):
+        g.soe.SetDtime(prob.dt); g.soe.PreSolve()
+        g.soe.ComputeJacobian(x)
+    v = np.random.default_rng(5).standard_normal(n)
+    y0, y1, y2 = ref.soe.MatMult(v), mb.soe.MatMult(v), mb8.soe.MatMult(v)
+    assert np.abs(y1 - y0).max() <= 4e-16 * np.abs(y0).max() + 1e-300
+    assert np.array_equal(y1, y2)
+    bad = P.to_gpu(prob, {"spmv_variant": 20})
+    bad.soe.SetDtime(prob.dt); bad.soe.PreSolve(); bad.soe.ComputeJacobian(x)
+    with pytest.raises(Exception):
+        bad.soe.MatMult(v)                               # no single-base index for this pattern
