@@ -1512,19 +1512,22 @@ __global__ __launch_bounds__(kBlock) void k_dots_pat(int n, const double *__rest
   }
 }
 
-// multi-dot x . y_j, j0 <= j < j0+nv (nv <= 4): x streamed once per group (GMRES Gram-Schmidt)
+// multi-dot x . y_j, j0 <= j < j0+nv (nv <= kMdotGroup): x streamed once per group (GMRES Gram-Schmidt)
+constexpr int kMdotGroup = 8;
 __global__ __launch_bounds__(kBlock) void k_mdot(DotArgs a, int j0, int nv, double *partials) {
   __shared__ double lds[kBlock / 64];
-  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  double acc[kMdotGroup];
+#pragma unroll
+  for (int j = 0; j < kMdotGroup; ++j) acc[j] = 0.0;
   const double *x = a.x[j0];
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < (size_t)a.n; i += (size_t)gridDim.x * kBlock) {
     const double xv = x[i];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < kMdotGroup; ++j)
       if (j < nv) acc[j] += xv * a.y[j0 + j][i];
   }
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < kMdotGroup; ++j) {
     if (j < nv) {
       const double t = block_sum(acc[j], lds);
       if (threadIdx.x == 0) partials[(size_t)(j0 + j) * gridDim.x + blockIdx.x] = t;
@@ -1901,8 +1904,8 @@ int launch_dots(const DotArgs &a, double *partials, hipStream_t stream) {
     bool same_x = true;
     for (int j = 1; j < a.nvec; ++j) same_x &= (x[j] == x[0]);
     (void)same_x;  // k_mdot reads a.x[j0] once per group; correct for any x, optimal when all x are equal
-    for (int j0 = 0; j0 < a.nvec; j0 += 4) {
-      const int nv = a.nvec - j0 < 4 ? a.nvec - j0 : 4;
+    for (int j0 = 0; j0 < a.nvec; j0 += kMdotGroup) {
+      const int nv = a.nvec - j0 < kMdotGroup ? a.nvec - j0 : kMdotGroup;
       bool grp_same = true;
       for (int j = 1; j < nv; ++j) grp_same &= (x[j0 + j] == x[j0]);
       if (grp_same) LAUNCH(k_mdot, dim3(g), a, j0, nv, partials);
