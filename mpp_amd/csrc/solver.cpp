@@ -2089,27 +2089,16 @@ struct Solver {
     ch.ntiles = nt;
     ch.ok = true;
   }
-  // The chain pays per dependency with an uncached (agent-scope) load; a per-level launch pays ~1.5-4.5 us per level.
-  // Measured on MI355X: thermal 256^3 (22 K rows per level, 3 entries per row) 4.5 -> 3.8 ms per application, 3-D VSFM
-  // 128x128x64 (3 K rows per level) 1.48 -> 1.15 ms, thermal 512^3 (87 K) no change, the TH columns (65 K rows per level,
-  // 6 entries per row) 0.89 -> 1.03 ms: chain when rows-per-level x entries-per-row stays under ~10^5.
-  // entry points that apply the preconditioner without a scalar read-back check the chain's error flag themselves
-  void check_chain_error() {
-    if (opt.pc_type != 1 || !opt.ilu_chain) return;
-    double e = 0.0;
-    HIP_CHECK(hipMemcpyAsync(&e, sc.p + S_ERR, sizeof(double), hipMemcpyDeviceToHost, stream));
-    HIP_CHECK(hipStreamSynchronize(stream));
-    if (e != 0.0) {
-      opt.ilu_chain = 0;
-      sc.zero(stream);
-      throw Error("ILU(0) chained triangular solve: a dependency wait timed out (falling back to per-level launches: set ilu_chain=0)");
-    }
-  }
+  // The chain pays per dependency with an uncached (agent-scope) load and the waiting tiles poll (every ~0.4 us: polling
+  // faster floods the fabric once thousands of tiles wait); a per-level launch pays ~1.5-4.7 us per level.  Measured on
+  // MI355X, per application: thermal 256^3 (22 K rows per level, 3 entries per row) 4.5 -> 3.6 ms, 384^3 8.2 -> 7.3 ms,
+  // 512^3 (87 K) 14.5 -> 13.5 ms, 3-D VSFM 128x128x64 (3 K rows per level) 1.51 -> 1.10 ms; the TH columns (65 K rows per
+  // level, 6 entries per row, 160 levels) 0.89 -> 0.98 ms: chain when rows-per-level x entries-per-row stays under 3x10^5.
   bool ilu_chained() const {
     if (!opt.ilu_chain || !chainL.ok || !chainU.ok) return false;
     if (opt.ilu_chain == 2) return true;
     const double nlev = (double)std::max<size_t>(h_lptr.size(), 2) - 1.0;
-    return (double)nrow / nlev * std::max(ell_KL, ell_KU) < 1.0e5;
+    return (double)nrow / nlev * std::max(ell_KL, ell_KU) < 3.0e5;
   }
   void ilu_solve_chained() {
     const unsigned ep = ++chain_epoch;
