@@ -2089,6 +2089,18 @@ struct Solver {
     ch.ntiles = nt;
     ch.ok = true;
   }
+  // entry points that apply the preconditioner without a scalar read-back check the chain's error flag themselves
+  void check_chain_error() {
+    if (opt.pc_type != 1 || !opt.ilu_chain) return;
+    double e = 0.0;
+    HIP_CHECK(hipMemcpyAsync(&e, sc.p + S_ERR, sizeof(double), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    if (e != 0.0) {
+      opt.ilu_chain = 0;
+      sc.zero(stream);
+      throw Error("ILU(0) chained triangular solve: a dependency wait timed out (falling back to per-level launches: set ilu_chain=0)");
+    }
+  }
   // The chain pays per dependency with an uncached (agent-scope) load and the waiting tiles poll (every ~0.4 us: polling
   // faster floods the fabric once thousands of tiles wait); a per-level launch pays ~1.5-4.7 us per level.  Measured on
   // MI355X, per application: thermal 256^3 (22 K rows per level, 3 entries per row) 4.5 -> 3.6 ms, 384^3 8.2 -> 7.3 ms,
