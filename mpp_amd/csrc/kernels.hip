@@ -1592,12 +1592,19 @@ __global__ void k_bcgs_scalars(int step, double *sc) {
   }
 }
 
-__global__ __launch_bounds__(kBlock) void k_maxpy_neg(MaxpyArgs a, const double *sc, double *y) {
+// partials != nullptr: also the partial sums of y.y of the result (the norm GMRES takes next), one per block
+__global__ __launch_bounds__(kBlock) void k_maxpy_neg(MaxpyArgs a, const double *sc, double *y, double *partials) {
+  __shared__ double lds[kBlock / 64];
   const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  double v = 0.0;
   if (i < (size_t)a.n) {
-    double v = y[i];
+    v = y[i];
     for (int j = 0; j < a.nvec; ++j) v -= sc[S_SUM0 + j] * a.v[j][i];
     y[i] = v;
+  }
+  if (partials) {
+    const double t = block_sum(v * v, lds);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
   }
 }
 __global__ __launch_bounds__(kBlock) void k_maxpy_val(MaxpyValArgs a, double *x) {
@@ -1925,8 +1932,12 @@ void launch_finalize_partials_long(int nblocks, int nvec, double *partials, doub
   LAUNCH(k_finalize_chunks, dim3(nchunk, nvec), nblocks, chunk, partials, stage);
   LAUNCH(k_finalize, dim3(nvec), nchunk, stage, sc);
 }
-void launch_maxpy_neg(const MaxpyArgs &a, const double *sc, double *y, hipStream_t stream) {
-  if (a.n > 0 && a.nvec > 0) LAUNCH(k_maxpy_neg, dim3(nblk(a.n)), a, sc, y);
+int maxpy_blocks(int n) { return nblk(n); }
+int launch_maxpy_neg(const MaxpyArgs &a, const double *sc, double *y, double *partials, hipStream_t stream) {
+  if (a.n <= 0 || a.nvec <= 0) return 0;
+  const dim3 grid(nblk(a.n));
+  LAUNCH(k_maxpy_neg, grid, a, sc, y, partials);
+  return (int)grid.x;
 }
 void launch_maxpy_val(const MaxpyValArgs &a, double *x, hipStream_t stream) {
   if (a.n > 0 && a.nvec > 0) LAUNCH(k_maxpy_val, dim3(nblk(a.n)), a, x);

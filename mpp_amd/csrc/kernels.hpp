@@ -293,7 +293,10 @@ void launch_finalize_partials(int nblocks, int nvec, const double *partials, dou
 void launch_finalize_partials_long(int nblocks, int nvec, double *partials, double *sc, hipStream_t stream);
 // y -= sum_j h[j] * v_j  (h on device at sc[S_SUM0+j]); GMRES classical Gram-Schmidt update
 struct MaxpyArgs { int n, nvec; const double *v[kMaxMultiDot]; };
-void launch_maxpy_neg(const MaxpyArgs &a, const double *sc, double *y, hipStream_t stream);
+// partials (maxpy_blocks(n) doubles + the staging tail of launch_finalize_partials_long, or nullptr): also y.y of the result;
+// returns the number of blocks
+int maxpy_blocks(int n);
+int launch_maxpy_neg(const MaxpyArgs &a, const double *sc, double *y, double *partials, hipStream_t stream);
 void launch_scale(int n, double *x, const double *sc, int slot_inv_of, hipStream_t stream);  // x *= 1/sc[slot]
 // x += sum_j yv[j]*v_j with yv passed by value
 struct MaxpyValArgs { int n, nvec; const double *v[kMaxMultiDot]; double c[kMaxMultiDot]; bool zero_x = false; /* x = sum (x not read) */ };

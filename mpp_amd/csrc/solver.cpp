@@ -1451,6 +1451,7 @@ struct Solver {
     return -3;
   }
 
+  static constexpr int kNormSlot = 44;   // sc[S_SUM0 + 44]: beyond the <= 31 Gram-Schmidt coefficients
   int ksp_gmres(const double *b, double *x, int *its) {
     const int m = opt.gmres_restart;
     if ((int)vv.size() < m + 1) {
@@ -1502,11 +1503,16 @@ struct Solver {
           MaxpyArgs ma;
           ma.n = nred; ma.nvec = it + 1;
           for (int j = 0; j <= it; ++j) ma.v[j] = vv[j].p;
-          launch_maxpy_neg(ma, sc.p, vnew, stream);
+          // the update also reduces ||vnew||^2 (slot kNormSlot, clear of the h_j it reads): one pass and one read-back fewer
+          const size_t nb = (size_t)maxpy_blocks(nred), need = nb + nb / 2048 + 1;
+          if (xr_partials.n < need) xr_partials.alloc(need);
+          const int nbk = launch_maxpy_neg(ma, sc.p, vnew, xr_partials.p, stream);
+          launch_finalize_partials_long(nbk, 1, xr_partials.p, sc.p + kNormSlot, stream);
+          if (comm.active()) comm.allreduce_sum(sc.p + S_SUM0 + kNormSlot, 1, stream);
         }
         fetch_scalars();
         for (int j = 0; j <= it; ++j) hh[j] = h_sc[S_SUM0 + j];
-        const double tt = norm_host(vnew);
+        const double tt = std::sqrt(h_sc[S_SUM0 + kNormSlot]);
         const bool hapend = tt == 0.0;   // v_{it+1} = vnew / tt is formed below, and only if another step will use it
         double *hcol = H.data() + (size_t)it * (m + 1);
         for (int j = 0; j <= it; ++j) hcol[j] = hh[j];
