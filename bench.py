@@ -9,10 +9,13 @@ block-Jacobi, ksp_rtol 1e-5, Newton rtol 1e-8 / stol 1e-10.  One "step" = one so
 
     python bench.py --gpus N --steps K --warmup W
 
-N > 1: launched by torch.distributed.run, one rank per GPU; the columns are sharded across ranks (strong
-scaling: the global grid is fixed) and the only inter-GPU traffic is the RCCL all-reduce of the Newton/Krylov
-norms and dot products inside libmppgpu.so.  Host coordination (unique-id broadcast, barrier, max-over-ranks) is a
-small TCP group built from the RANK / WORLD_SIZE / MASTER_* variables the launcher exports.
+N > 1: one rank process per GPU.  Either a launcher starts them (python -m torch.distributed.run --nproc-per-node N ...:
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) or, when bench.py is invoked directly, it starts the N rank
+processes itself -- plain child processes, before anything in this process has touched the GPU -- waits for them with a
+bound, and exits non-zero with the failing rank's stderr if any of them fails.  The columns are sharded across ranks
+(strong scaling: the global grid is fixed); the only inter-GPU traffic is the RCCL all-reduce of the Newton/Krylov norms
+and dot products inside libmppgpu.so.  Host coordination (unique-id broadcast, barrier, max-over-ranks) is a small TCP
+group (mpp_amd.parallel.HostGroup).
 
 Prints ONE JSON line (rank 0).
 """
@@ -21,7 +24,10 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 import threading
 import time
 
@@ -29,33 +35,52 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
+def perm_multipliers(ncols_global):
+    return np.exp(0.5 * np.random.default_rng(12345).standard_normal(ncols_global))
+
+
 def build_problem(ncols_global, nz, col0, ncols_local, hetero=True):
-    import problems as P
-    mult = None
-    if hetero:
-        mult = np.exp(0.5 * np.random.default_rng(12345).standard_normal(ncols_global))[col0:col0 + ncols_local]
+    from mpp_amd import workloads as P
+    mult = perm_multipliers(ncols_global)[col0:col0 + ncols_local] if hetero else None
     return P.celia1990(ncols=ncols_local, nz=nz, perm_mult=mult)
 
 
-def cpu_baseline(ncols_global, nz, nsteps, warmup, cores, cols_per_core, budget_s=30.0):
+# ------------------------------------------------------------------------------------------------------------
+# CPU legs (rank 0, N = 1): the oracle as baseline and as checker of the benchmark's own answer
+# ------------------------------------------------------------------------------------------------------------
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(ncols_global, nz, nsteps, warmup, cores, cols_per_core, ksp="gmres", pc="ilu"):
     """The CPU oracle ("port") on a bounded sample of the same workload: `cores` independent shards (the way
-    MPP+ELM scales on CPUs: every MPI rank solves its own columns with its own serial SNES), GMRES+ILU(0) as
-    the reference's PETSc defaults; reported as full-grid-equivalent Newton iterations/s."""
-    import problems as P
+    MPP+ELM scales on CPUs: every MPI rank solves its own columns with its own serial SNES); reported as
+    full-grid-equivalent Newton iterations/s.  ksp/pc: gmres+ilu = the reference's PETSc defaults, bcgs+bjacobi = the
+    configuration the GPU run uses."""
+    from mpp_amd import constants as C
+    from mpp_amd import workloads as P
+    from oracle import adapters as A
     from oracle import vsfm_oracle as VO
     VO.lib()
     rng_cols = np.random.default_rng(99).choice(ncols_global, size=cores * cols_per_core, replace=False)
-    mult_all = np.exp(0.5 * np.random.default_rng(12345).standard_normal(ncols_global))
+    mult_all = perm_multipliers(ncols_global)
     shards = []
     for c in range(cores):
         cols = np.sort(rng_cols[c * cols_per_core:(c + 1) * cols_per_core])
         prob = P.celia1990(ncols=cols_per_core, nz=nz, perm_mult=mult_all[cols])
-        shards.append((prob, P.to_oracle(prob, with_blocks=False)))
+        o = A.to_oracle(prob, with_blocks=(pc == "bjacobi"))
+        o.set_solver(C.KSP_BCGS if ksp == "bcgs" else C.KSP_GMRES, C.PC_BJACOBI if pc == "bjacobi" else C.PC_ILU0)
+        shards.append((prob, o))
     work = [0.0] * cores
 
     def run(i, steps, count):
@@ -79,19 +104,164 @@ def cpu_baseline(ncols_global, nz, nsteps, warmup, cores, cols_per_core, budget_
     dt = run_all(nsteps, True)
     cell_its_per_s = sum(work) / dt
     n_full = ncols_global * nz
-    # the reference itself is serial (PETSC_COMM_SELF, one rank): the same measure on ONE core, one more step of shard 0
-    work[0] = 0.0
+    return {"value": cell_its_per_s / n_full, "cores": cores, "solver": "%s+%s" % (ksp, pc), "seconds": round(dt, 2),
+            "sample": "%d of %d columns (%d threads x %d columns x %d layers), %d timed steps after %d warm-up; "
+                      "%.3g cell-Newton-updates/s scaled by 1/%d cells" %
+                      (cores * cols_per_core, ncols_global, cores, cols_per_core, nz, nsteps, warmup, cell_its_per_s, n_full),
+            "_shards": shards, "_work0": work}
+
+
+def cpu_one_core(shards, n_full):
+    """the reference itself is serial (PETSC_COMM_SELF, one rank): the same measure on ONE core, two more steps of shard 0"""
+    prob, o = shards[0]
+    before = o.counters()["newton"]
     t0 = time.perf_counter()
-    run(0, 1, True)
-    one_core = work[0] / (time.perf_counter() - t0) / n_full
-    return {
-        "value": cell_its_per_s / n_full, "unit": "Newton iters/s", "cores": cores, "kind": "port",
-        "value_one_core": one_core,
-        "sample": "%d of %d columns (%d threads x %d columns x %d layers), %d timed steps after %d warm-up, "
-                  "GMRES(30)+ILU(0); %.3g cell-Newton-updates/s scaled by 1/%d cells" %
-                  (cores * cols_per_core, ncols_global, cores, cols_per_core, nz, nsteps, warmup, cell_its_per_s, n_full),
-        "seconds": dt,
-    }
+    for s in range(2):
+        o.step_dt(prob.dt, s + 1)
+    dt = time.perf_counter() - t0
+    return (o.counters()["newton"] - before) * prob.mesh.ncells_local / dt / n_full
+
+
+def verify_answer(pressure, ncols_global, nz, col0, ncols_local, nsteps_total, hetero, nsample=64):
+    """The benchmark's own answer against the oracle: `nsample` columns of this rank's shard, each solved alone by the CPU
+    oracle over the same `nsteps_total` time steps at tight Newton tolerances (columns are independent, so a column's
+    converged answer does not depend on its neighbours); returns the largest pressure difference relative to the largest
+    pressure.  What it measures is the Newton truncation of the GPU's *global* solve (rtol 1e-8 on the global norm)."""
+    from mpp_amd import constants as C
+    from mpp_amd import workloads as P
+    from oracle import adapters as A
+    mult = perm_multipliers(ncols_global) if hetero else np.ones(ncols_global)
+    pick = np.sort(np.random.default_rng(7).choice(ncols_local, size=min(nsample, ncols_local), replace=False))
+    worst, scale = 0.0, 0.0
+    # one oracle problem per column: each column converges by itself, as tightly as the arithmetic allows
+    for j, c in enumerate(pick):
+        one = P.celia1990(ncols=1, nz=nz, perm_mult=mult[col0 + c:col0 + c + 1])
+        o = A.to_oracle(one, with_blocks=False)
+        o.set_solver(C.KSP_GMRES, C.PC_ILU0, ksp_rtol=1e-12, snes_rtol=1e-13, snes_stol=1e-14)
+        for s in range(nsteps_total):
+            o.step_dt(one.dt, s + 1)
+        po = o.get(C.AUXVAR_INTERNAL, C.VAR_PRESSURE)
+        pg = pressure[c * nz:(c + 1) * nz]
+        worst = max(worst, float(np.abs(pg - po).max()))
+        scale = max(scale, float(np.abs(po).max()))
+    return {"columns_checked": int(pick.size), "max_abs_err_Pa": worst, "max_rel_err": worst / scale,
+            "against": "CPU oracle, one column at a time, snes_rtol 1e-13 / stol 1e-14, %d steps" % nsteps_total}
+
+
+# ------------------------------------------------------------------------------------------------------------
+# rank launcher: `python bench.py --gpus N` invoked directly
+# ------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(nranks, argv, timeout_s):
+    """Start `nranks` copies of this script as child processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* exported: the
+    contract of torch.distributed.run), pass rank 0's stdout through, and return the exit code: 0 when every rank exits 0;
+    otherwise a failing rank's code, after the stderr of every failed rank has been shown and the ranks still waiting for
+    them have been stopped (124 when the time limit ends the run).  This process never initialises the GPU."""
+    port = _free_port()
+    procs, logs = [], []
+    for r in range(nranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nranks), LOCAL_WORLD_SIZE=str(nranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MPPGPU_BENCH_RANK_PROCESS="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        err = tempfile.TemporaryFile(mode="w+")
+        logs.append(err)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=(None if r == 0 else subprocess.DEVNULL), stderr=err))
+    deadline = time.time() + timeout_s
+    first_bad, timed_out = None, False
+    while True:
+        codes = [p.poll() for p in procs]
+        if first_bad is None and any(c not in (None, 0) for c in codes):
+            first_bad = time.time()
+        if all(c is not None for c in codes):
+            break
+        # a rank failed: the ranks that depend on it usually fail by themselves within moments (closed sockets); give them
+        # that long, so that what is reported below are exit codes of their own making
+        if first_bad is not None and time.time() > first_bad + 2.0:
+            break
+        if time.time() > deadline:
+            timed_out = True
+            break
+        time.sleep(0.1)
+    codes = [p.poll() for p in procs]
+    stopped = [r for r, c in enumerate(codes) if c is None]
+    if stopped:
+        # blocked in a collective a failed rank will never join (or over the time limit): stop exactly the processes started here
+        for r in stopped:
+            procs[r].terminate()
+        grace = time.time() + 5.0
+        for r in stopped:
+            while procs[r].poll() is None and time.time() < grace:
+                time.sleep(0.1)
+            if procs[r].poll() is None:
+                procs[r].kill()
+                procs[r].wait()
+    failed = [r for r, c in enumerate(codes) if c not in (None, 0)]
+    rc = 0
+    if timed_out:
+        rc = 124
+        sys.stderr.write("bench.py: rank(s) %s still running after %.0f s (launcher time limit); stopped\n" % (stopped, timeout_s))
+    elif failed:
+        rc = codes[failed[0]] if codes[failed[0]] > 0 else 1
+    for r, f in enumerate(logs):
+        f.seek(0)
+        text = f.read()
+        f.close()
+        if r in failed:
+            sys.stderr.write("bench.py: rank %d exited with code %d; its stderr:\n%s\n" % (r, codes[r], text[-4000:]))
+        elif (timed_out and r in stopped) or (rc == 0 and text.strip()):
+            sys.stderr.write("".join("[rank %d] %s\n" % (r, l) for l in text.splitlines()[-20:]))
+    if failed and stopped:
+        sys.stderr.write("bench.py: stopped rank(s) %s, which were waiting for the failed one(s)\n" % stopped)
+    return rc
+
+
+class Watchdog:
+    """ends THIS rank process when a phase that involves the other ranks (rendezvous, ncclCommInitRank, the first solve
+    with its first all-reduces) does not finish in time -- a rank that never arrives must not leave the others waiting
+    forever; the launcher (or torch.distributed.run) then stops the remaining ranks"""
+
+    def __init__(self, seconds, what, rank):
+        self.t = threading.Timer(seconds, self._fire)
+        self.t.daemon = True
+        self.what, self.rank, self.seconds = what, rank, seconds
+        self.t.start()
+
+    def _fire(self):
+        sys.stderr.write("bench.py: rank %d: %s did not finish within %.0f s; giving up\n" % (self.rank, self.what, self.seconds))
+        sys.stderr.flush()
+        os._exit(3)
+
+    def done(self):
+        self.t.cancel()
+
+
+def dry_run_rank(args, group, rank, world):
+    """the multi-rank host path without any GPU call (CPU tests): rendezvous, shard, id broadcast, barrier, reductions"""
+    from mpp_amd import parallel as PAR
+    ncols_global = args.nx * args.ny
+    col0, ncols_local = PAR.shard_columns(ncols_global, world, rank)
+    if args.fail_rank == rank:
+        raise SystemExit("bench.py: rank %d: injected failure (--fail-rank)" % rank)
+    if args.fail_rank == -2 and rank == world - 1:   # a rank that never joins the first collective
+        time.sleep(3600)
+    uid = group.broadcast_bytes(bytes(range(128)) if rank == 0 else b"")
+    group.barrier()
+    elapsed = group.allreduce([1.0 + rank], op="max")[0]
+    total_cols = group.allreduce([float(ncols_local)], op="sum")[0]
+    gathered = group.allreduce([float(col0) if r == rank else 0.0 for r in range(world)], op="sum")
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "elapsed_max": elapsed, "columns": total_cols,
+                          "first_column_of_rank": gathered, "unique_id_ok": uid == bytes(range(128))}), flush=True)
+    group.barrier()
+    group.close()
 
 
 def main():
@@ -106,35 +276,47 @@ def main():
     ap.add_argument("--pc", default="bjacobi")
     ap.add_argument("--spmv-variant", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-cores", type=int, default=0)
+    ap.add_argument("--no-verify", action="store_true", help="skip the comparison of sampled columns with the CPU oracle")
+    ap.add_argument("--cpu-cores", type=int, default=0, help="threads of the CPU baseline (default: every core of the box)")
     ap.add_argument("--homogeneous", action="store_true")
     ap.add_argument("--profile", choices=["auto", "all", "spmv"], default="auto",
                     help="kernel classes timed with HIP events inside the timed region: every class, or the roofline kernel "
                          "(CSR SpMV) only -- the events of every class cost 5-6 %% at 13 M cells per GPU, under 1 %% at 105 M; "
                          "auto = all on one GPU, spmv on several")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="extra mppgpu_set_option pairs")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="direct --gpus N launch: time limit of the rank processes [s]")
+    ap.add_argument("--init-timeout", type=float, default=600.0,
+                    help="multi-rank: time limit for rendezvous + ncclCommInitRank + the first solve (first all-reduces) [s]")
+    ap.add_argument("--dry-run-ranks", action="store_true", help="multi-rank host path only, no GPU call (CPU tests)")
+    ap.add_argument("--fail-rank", type=int, default=-1, help="with --dry-run-ranks: this rank exits with an error")
     args = ap.parse_args()
+
+    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ
+    if not launched and args.gpus > 1:
+        # invoked directly: become the launcher.  Nothing above or below this line has touched the GPU in this process.
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:], args.launch_timeout))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d" %
-                             (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world
 
-    # the HIP extension first (fails loudly if missing), torch only for multi-rank host coordination
+    # Host-side rendezvous over plain TCP (mpp_amd.parallel.HostGroup) from the RANK / WORLD_SIZE / MASTER_* variables.
+    # torch itself is not imported: a rank process then loads exactly one ROCm runtime and one RCCL (those of the ROCm
+    # installation), the configuration the GPU tests run.
+    from mpp_amd import parallel as PAR
+    dog = Watchdog(args.init_timeout, "rendezvous / communicator set-up / first solve", rank) if launched and world > 1 else None
+    group = PAR.HostGroup(timeout=args.init_timeout) if launched else PAR.HostGroup(rank=0, world=1)
+    if args.dry_run_ranks:
+        dry_run_rank(args, group, rank, world)
+        if dog:
+            dog.done()
+        return
+
+    # the HIP extension (fails loudly if missing)
     from mpp_amd import constants as C
     from mpp_amd import vsfm as V
-    import problems as P
-
-    # Launched by torch.distributed.run: host-side rendezvous over plain TCP (mpp_amd.parallel.HostGroup) from the
-    # RANK / WORLD_SIZE / MASTER_* variables it exports.  torch itself is not imported: a rank process then loads
-    # exactly one ROCm runtime and one RCCL (those of the ROCm installation), the configuration the GPU tests run.
-    from mpp_amd import parallel as PAR
-    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ
-    group = PAR.HostGroup() if launched else PAR.HostGroup(rank=0, world=1)
+    from mpp_amd import workloads as P
 
     ncols_global = args.nx * args.ny
     col0, ncols_local = PAR.shard_columns(ncols_global, world, rank)
@@ -172,6 +354,9 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    if dog and args.warmup > 0:
+        dog.done()
+        dog = None
     soe.SetOption("profile", 1 if (args.profile == "all" or (args.profile == "auto" and world == 1)) else 2)
     soe.reset_stats()
     c0 = soe.counters()
@@ -179,28 +364,39 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
+        if dog:
+            dog.done()
+            dog = None
     barrier()
     elapsed = time.perf_counter() - t0
     elapsed = group.allreduce([elapsed], op="max")[0]
     c1 = soe.counters()
     newton = c1["newton"] - c0["newton"]
     linear = c1["linear"] - c0["linear"]
+    comm = soe.comm_stats()
 
     stats = {k: soe.kernel_stats(k) for k in ("spmv", "pc_apply", "pc_setup", "residual", "jacobian", "vec", "reduce")}
     soe.SetOption("profile", 0)
 
+    # rank-local SpMV of every rank (the roofline kernel): average launch time, gathered on the host
+    sp = stats["spmv"]
+    avg_ms = sp["total_ms"] / max(sp["launches"], 1)
+    all_ms = group.allreduce([avg_ms if r == rank else 0.0 for r in range(world)], op="sum")
+    all_bytes = group.allreduce([sp["bytes_per_launch"] if r == rank else 0.0 for r in range(world)], op="sum")
+
     if rank == 0:
         n_global = ncols_global * args.nz
-        sp = stats["spmv"]
-        avg_ms = sp["total_ms"] / max(sp["launches"], 1)
+        n_local = ncols_local * args.nz
         achieved = sp["bytes_per_launch"] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = None
+        compact = n_local >= (1 << 21) and args.spmv_variant < 0
+        traffic, traffic_src = None, None
         tfile = os.path.join(ROOT, "profiles", "spmv_traffic.json")
         if os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile))
-                if tj.get("cells_per_gpu") == ncols_local * args.nz:
+                if tj.get("cells_per_gpu") == n_local:
                     traffic = tj.get("hbm_bytes_per_launch")
+                    traffic_src = "profiles/spmv_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel at this size)"
             except Exception:
                 traffic = None
         kernels = {}
@@ -211,6 +407,21 @@ def main():
                               "share_of_step_time": round(s["total_ms"] * 1e-3 / elapsed, 4)}
                 if s["bytes_per_launch"] > 0:
                     kernels[k]["GBps"] = round(s["bytes_per_launch"] / (ms * 1e-3) / 1e9, 1)
+        roof = {"kernel": "csr_spmv_fp64 (k_spmv_pipe_c: CSR values + compact 16-bit index, see DESIGN.md section 4)"
+                          if compact else "csr_spmv_fp64",
+                "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "achieved_is": "algorithmic CSR bytes (12 nnz + 20 N + 4, SURVEY 8d) / HIP-event average launch time",
+                "bytes_per_launch": sp["bytes_per_launch"], "avg_launch_ms": round(avg_ms, 5), "launches": sp["launches"]}
+        if traffic:
+            phys = traffic / (avg_ms * 1e-3) / 1e9
+            roof["achieved_physical"] = round(phys, 1)        # bytes the kernel really moves (16-bit index) / the same time
+            roof["frac_physical"] = round(phys / HBM_PEAK_GBS, 4)
+            roof["traffic_source"] = traffic_src
+        if world > 1:
+            roof["per_rank"] = [{"rank": r, "avg_launch_ms": round(all_ms[r], 5),
+                                 "achieved": round(all_bytes[r] / (all_ms[r] * 1e-3) / 1e9, 1) if all_ms[r] > 0 else None}
+                                for r in range(world)]
         out = {
             "metric": "Newton iters/sec (VSFM %dx%dx%d)" % (args.nx, args.ny, args.nz),
             "value": newton / elapsed, "unit": "Newton iters/s",
@@ -219,26 +430,50 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "VSFM celia-extruded %dx%d columns x %d layers, %s+%s, per-column perm multiplier"
                                    % (args.nx, args.ny, args.nz, args.ksp, args.pc),
-                       "cells": n_global, "cells_per_gpu": ncols_local * args.nz, "dt_s": prob.dt,
+                       "cells": n_global, "cells_per_gpu": n_local, "dt_s": prob.dt,
                        "parallelism": "columns sharded over %d GPU(s), RCCL all-reduce of Krylov/Newton scalars" % world},
             "newton_iterations": newton, "linear_iterations": linear, "setup_s": round(t_setup, 2),
-            "roofline": {"kernel": "csr_spmv_fp64 (k_spmv_pipe_c: CSR values + compact 16-bit index, see DESIGN.md section 4)"
-                                   if ncols_local * args.nz >= (1 << 23) and args.spmv_variant < 0 else "csr_spmv_fp64",
-                         "bound": "hbm", "achieved": round(achieved, 1),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "bytes_per_launch": sp["bytes_per_launch"],
-                         "avg_launch_ms": round(avg_ms, 5), "launches": sp["launches"]},
+            "allreduces_per_newton_iteration": round(comm["allreduces"] / max(newton, 1), 2) if world > 1 else 0.0,
+            "roofline": roof,
             "kernels": kernels,
         }
+    # ---- outside the timed region: the benchmark's own answer against the oracle (every rank checks its own shard) ----
+    check = None
+    if not args.no_verify:
+        try:
+            pg = soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1)
+            check = verify_answer(pg, ncols_global, args.nz, col0, ncols_local, args.warmup + args.steps, not args.homogeneous,
+                                  nsample=64 if world == 1 else max(8, 64 // world))
+            del pg
+        except Exception as e:   # the check must never hide the measurement; its failure is reported in the line
+            check = {"error": repr(e)}
+    if not args.no_verify:
+        worst = group.allreduce([check.get("max_rel_err", float("inf")) if check else float("inf")], op="max")[0]
+        ncheck = group.allreduce([float(check.get("columns_checked", 0)) if check else 0.0], op="sum")[0]
+        if rank == 0:
+            out["answer_check"] = dict(check or {}, max_rel_err=worst, columns_checked=int(ncheck))
+    if rank == 0:
         if not args.no_cpu_baseline and world == 1:   # the CPU baseline is reported at N = 1 only
-            cores = args.cpu_cores or min(16, os.cpu_count() or 1)
+            cores = args.cpu_cores or (os.cpu_count() or 1)
+            n_full = ncols_global * args.nz
+            cpc = max(64, min(819200 // args.nz, ncols_global // cores))   # 8192 columns x 100 layers per thread
             try:
-                # ~10-30 s of CPU work: 16 x 8192 columns x 100 layers = 13 M cells (1/8 of the grid), 3+1 steps
-                out["cpu_baseline"] = cpu_baseline(ncols_global, args.nz, 3, 1, cores,
-                                                   cols_per_core=max(64, min(819200 // args.nz, ncols_global // cores)))
+                # ~10-15 s of CPU work per leg: cores x 8192 columns x 100 layers, 3 timed steps after 1 warm-up
+                ref = cpu_baseline(ncols_global, args.nz, 3, 1, cores, cols_per_core=cpc, ksp="gmres", pc="ilu")
+                one = cpu_one_core(ref.pop("_shards"), n_full)
+                ref.pop("_work0")
+                same = cpu_baseline(ncols_global, args.nz, 3, 1, cores, cols_per_core=cpc, ksp=args.ksp,
+                                    pc="bjacobi" if args.pc in ("bjacobi", "ilu") and args.ksp == "bcgs" else "ilu")
+                same.pop("_shards"); same.pop("_work0")
+                out["cpu_baseline"] = {"value": ref["value"], "unit": "Newton iters/s", "cores": cores, "kind": "port",
+                                       "sample": ref["sample"] + "; GMRES(30)+ILU(0) = the reference's PETSc defaults",
+                                       "cpu_model": cpu_model(), "host_cores": os.cpu_count(),
+                                       "value_one_core": one, "seconds": ref["seconds"],
+                                       "same_solver_as_gpu": {"value": same["value"], "solver": same["solver"],
+                                                              "seconds": same["seconds"]}}
             except Exception as e:  # the baseline must never hide the GPU measurement
                 out["cpu_baseline"] = {"value": None, "unit": "Newton iters/s", "cores": cores, "kind": "port",
-                                       "sample": "failed: %r" % (e,)}
+                                       "cpu_model": cpu_model(), "sample": "failed: %r" % (e,)}
         print(json.dumps(out), flush=True)
     group.barrier()
     group.close()

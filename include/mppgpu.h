@@ -280,6 +280,10 @@ int mppgpu_thermal_compute_operators(mppgpu_handle h, double dt, int *rowptr, in
 int mppgpu_kernel_stats(mppgpu_handle h, const char *name, long long *launches, double *total_ms,
                         double *algorithmic_bytes_per_launch);
 int mppgpu_reset_stats(mppgpu_handle h);
+/* collectives this handle issued since the last mppgpu_reset_stats: all-reduces (RCCL ncclAllReduce or the in-process
+ * group) and halo exchanges; and how many chained ILU(0) applications had to be redone with per-level launches because a
+ * dependency wait exhausted its spin budget (since mppgpu_setup).  No counterpart in the reference (PETSC_COMM_SELF). */
+int mppgpu_get_comm_stats(mppgpu_handle h, long long *allreduces, long long *halo_exchanges, long long *chain_fallbacks);
 /* device-resident micro-benchmark of one kernel class on the current state: `reps` launches, average ms */
 int mppgpu_bench_kernel(mppgpu_handle h, const char *name, int variant, int reps, double *avg_ms,
                         double *algorithmic_bytes);

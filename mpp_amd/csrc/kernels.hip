@@ -1163,7 +1163,7 @@ __global__ __launch_bounds__(kBlock) void k_ell_chain(ChainArgs a) {
       // point; no cache-wide invalidate / write-back (what an acquire / release fence costs, ~30 us per level here).
       while (__hip_atomic_load(a.flags + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) {
         __builtin_amdgcn_s_sleep(16);   // ~0.4 us between polls: thousands of waiting tiles must not flood the fabric
-        if (++spins > (1u << 22)) { a.sc[S_ERR] = 1.0; break; }
+        if (++spins > a.max_spins) { a.sc[S_ERR] = 1.0; break; }
       }
     }
   }

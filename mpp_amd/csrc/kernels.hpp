@@ -186,6 +186,7 @@ struct ChainArgs {
   unsigned epoch;
   double *v;                       // solved in place
   double *sc;                      // sc[S_ERR] receives 1.0 on a timed-out wait
+  unsigned max_spins;              // polls (~0.4 us apart) before a wait gives up
 };
 void launch_ell_chain(const ChainArgs &a, hipStream_t stream);
 void launch_ell_lower_level(int n, int K, const int *col, const double *val, int lo, int hi, double *y, hipStream_t stream);

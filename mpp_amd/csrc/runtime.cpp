@@ -107,8 +107,14 @@ void Comm::init(int nr, int r, const void *id128) {
   nranks = nr;
   rank = r;
 }
+void LocalGroup::abort() {
+  std::lock_guard<std::mutex> lk(m);
+  aborted = true;
+  cv.notify_all();
+}
 void LocalGroup::allreduce(int rank, double *v, int count, bool is_max) {
   std::unique_lock<std::mutex> lk(m);
+  if (aborted) throw Error("in-process group: another rank failed");
   for (int i = 0; i < count; ++i) slots[(size_t)rank * 64 + i] = v[i];
   const long long gen = generation;
   if (++arrived == nranks) {
@@ -122,7 +128,8 @@ void LocalGroup::allreduce(int rank, double *v, int count, bool is_max) {
     ++generation;
     cv.notify_all();
   } else {
-    cv.wait(lk, [&] { return generation != gen; });
+    cv.wait(lk, [&] { return generation != gen || aborted; });
+    if (generation == gen) throw Error("in-process group: another rank failed");
   }
   for (int i = 0; i < count; ++i) v[i] = slots[(size_t)rank * 64 + i];
 }
@@ -141,7 +148,11 @@ static void local_allreduce(Comm &c, double *dev, int count, hipStream_t s, bool
   HIP_CHECK(hipMemcpyAsync(dev, c.h_buf, count * sizeof(double), hipMemcpyHostToDevice, s));
   HIP_CHECK(hipStreamSynchronize(s));
 }
+void Comm::abort_peers() {
+  if (local) local->abort();
+}
 void Comm::allreduce_sum(double *dev, int count, hipStream_t s) {
+  ++n_allreduce;
   if (local) { local_allreduce(*this, dev, count, s, false); return; }
   if (!comm) return;
   static fn_allreduce f = nullptr;
@@ -158,6 +169,7 @@ void Comm::register_sendbuf(const double *sendbuf, const std::vector<int> &peer,
 void Comm::exchange(const double *sendbuf, const std::vector<int> &peer, const std::vector<int> &send_ptr, double *recv,
                     const std::vector<int> &recv_ptr, hipStream_t s) {
   const int nn = (int)peer.size();
+  ++n_exchange;
   if (local) {
     register_sendbuf(sendbuf, peer, send_ptr);
     HIP_CHECK(hipStreamSynchronize(s));   // my packed values are in place
@@ -190,6 +202,7 @@ void Comm::exchange(const double *sendbuf, const std::vector<int> &peer, const s
   nccl_check(lib, gend(), "ncclGroupEnd");
 }
 void Comm::allreduce_max(double *dev, int count, hipStream_t s) {
+  ++n_allreduce;
   if (local) { local_allreduce(*this, dev, count, s, true); return; }
   if (!comm) return;
   static fn_allreduce f = nullptr;

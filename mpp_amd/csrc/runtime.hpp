@@ -98,6 +98,8 @@ struct LocalGroup {
   // halo exchange: every rank publishes its packed send buffer and where each destination's part starts
   std::vector<const double *> sendbuf;
   std::vector<std::vector<std::pair<int, int>>> send_off;   // per rank: (destination, offset)
+  bool aborted = false;        // a rank failed: every waiter (now or later) leaves with an error instead of blocking
+  void abort();
   explicit LocalGroup(int n) : nranks(n), slots((size_t)n * 64, 0.0), sendbuf(n, nullptr), send_off(n) {}
   void barrier(int rank) { double d = 0.0; allreduce(rank, &d, 0, false); }
   // every rank contributes `count` (<= 64) values; returns, in rank order (deterministic), the sum or max in `v`
@@ -111,6 +113,7 @@ struct Comm {
   std::shared_ptr<LocalGroup> local;
   double *h_buf = nullptr;     // pinned staging of the in-process path
   int nranks = 1, rank = 0;
+  long long n_allreduce = 0, n_exchange = 0;   // collectives issued since the last mppgpu_reset_stats
   bool active() const { return comm != nullptr || local != nullptr; }
   void init_local(std::shared_ptr<LocalGroup> g, int rank);
   static void get_unique_id(void *id128);
@@ -122,6 +125,9 @@ struct Comm {
   void exchange(const double *sendbuf, const std::vector<int> &peer, const std::vector<int> &send_ptr, double *recv,
                 const std::vector<int> &recv_ptr, hipStream_t s);
   void allreduce_max(double *dev, int count, hipStream_t s);
+  // a failure on this rank: wake the in-process peers with an error (RCCL peers cannot be reached from here: the
+  // launcher ends the other rank processes when one exits with an error, see bench.py)
+  void abort_peers();
   ~Comm();
 };
 
@@ -156,6 +162,7 @@ struct Options {
   bool ell_assembly = true;    // general assembly on the ELL copy of the incidence lists (k_flux_rows_ell)
   int ilu_chain = 1;           // ILU(0) solves: one launch per triangle, tiles chained by flags (1: where it pays, 2: always;
                                // 0: one launch per level)
+  unsigned ilu_chain_spins = 1u << 22;   // polls (~0.4 us apart) before a chained wait gives up and the apply is redone per level
   bool ls_ahead = true;        // the line search's first reductions ride behind the Krylov solver's last update
   bool wide_xr = true;         // BiCGStab update kernel on a one-pair-per-lane grid (large vectors)
   int spmv_tpw = 0;            // > 0: 64-row tiles per wave of the compact-index SpMV (default 4 / 8 by variant)

@@ -155,6 +155,8 @@ struct Solver {
   // this handle converged in one iteration (the column-structured problems); a solve that goes on discards them.
   struct LsAhead { bool armed = false, done = false; const double *F = nullptr, *X = nullptr; double r3[3] = {0, 0, 0}; } ls_ahead;
   bool ksp_one_shot = false;   // pending X + a Y of the line search
+  int debug_fail_at_fetch = 0; // test hook: the n-th scalar read-back from now throws (multi-rank failure handling)
+  long long chain_fallbacks = 0;   // chained ILU(0) applications redone with per-level launches after a dependency timeout
   DevBuf<int> d_col_bc;
   DevBuf<double> bc_side_f, bc_side_d, d_DqA, d_porvol, fwd_elim;
   const double *fwd_rhs = nullptr;   // the residual vector whose forward elimination fwd_elim holds (for the current factors)
@@ -1199,7 +1201,16 @@ struct Solver {
     else if (opt.pc_type == 3) launch_pointwise_mult(nred, jac_invd.p, r, z, stream);
     else if (opt.pc_type == 1) {
       launch_gather(nrow, d_lrows.p, r, ilu_y.p, stream);            // r into the L level order
-      if (ilu_chained()) ilu_solve_chained();
+      bool solved = false;
+      if (ilu_chained()) {
+        ilu_solve_chained();
+        // A tile that gave up waiting for a dependency (spin budget) has computed from unready values: the whole
+        // application is redone, on this rank alone, with one launch per level.  The answer is then the one every other
+        // rank expects, so nothing has to be agreed across ranks; the chain stays off for this handle afterwards.
+        solved = !chain_timed_out();
+        if (!solved) launch_gather(nrow, d_lrows.p, r, ilu_y.p, stream);
+      }
+      if (solved) {}
       else if (opt.ilu_graph) {
         if (!ilu_graph_exec) {
           HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
@@ -1254,11 +1265,7 @@ struct Solver {
   void fetch_scalars() {
     HIP_CHECK(hipMemcpyAsync(h_sc, sc.p, S_COUNT * sizeof(double), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
-    if (h_sc[S_ERR] != 0.0) {   // a chained triangular solve gave up waiting: its result is not to be used
-      opt.ilu_chain = 0;
-      sc.zero(stream);
-      throw Error("ILU(0) chained triangular solve: a dependency wait timed out (falling back to per-level launches: set ilu_chain=0)");
-    }
+    if (debug_fail_at_fetch > 0 && --debug_fail_at_fetch == 0) throw Error("injected failure (option debug_fail_at_fetch)");
   }
   void dots_host(std::initializer_list<std::pair<const double *, const double *>> pairs, double *out) {
     dots_dev(pairs);
@@ -2095,17 +2102,16 @@ struct Solver {
     ch.ntiles = nt;
     ch.ok = true;
   }
-  // entry points that apply the preconditioner without a scalar read-back check the chain's error flag themselves
-  void check_chain_error() {
-    if (opt.pc_type != 1 || !opt.ilu_chain) return;
+  // one 8-byte read-back behind every chained application (the queue drains once per application: < 1 % of a 1-14 ms solve)
+  bool chain_timed_out() {
     double e = 0.0;
     HIP_CHECK(hipMemcpyAsync(&e, sc.p + S_ERR, sizeof(double), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
-    if (e != 0.0) {
-      opt.ilu_chain = 0;
-      sc.zero(stream);
-      throw Error("ILU(0) chained triangular solve: a dependency wait timed out (falling back to per-level launches: set ilu_chain=0)");
-    }
+    if (e == 0.0) return false;
+    opt.ilu_chain = 0;
+    ++chain_fallbacks;
+    launch_set(1, 0.0, sc.p + S_ERR, stream);
+    return true;
   }
   // The chain pays per dependency with an uncached (agent-scope) load and the waiting tiles poll (every ~0.4 us: polling
   // faster floods the fabric once thousands of tiles wait); a per-level launch pays ~1.5-4.7 us per level.  Measured on
@@ -2121,11 +2127,11 @@ struct Solver {
   void ilu_solve_chained() {
     const unsigned ep = ++chain_epoch;
     ChainArgs a{nrow, ell_KL, d_Lcol.p, d_Lval.p, nullptr, chainL.tile_lo.p, chainL.tile_hi.p, chainL.dep.p, chainL.ntiles,
-                kChainDeps, chainL.flags.p, ep, ilu_y.p, sc.p};
+                kChainDeps, chainL.flags.p, ep, ilu_y.p, sc.p, opt.ilu_chain_spins};
     launch_ell_chain(a, stream);
     launch_gather(nrow, d_l2u.p, ilu_y.p, ilu_x.p, stream);
     ChainArgs b{nrow, ell_KU, d_Ucol.p, d_Uval.p, d_Uidiag.p, chainU.tile_lo.p, chainU.tile_hi.p, chainU.dep.p, chainU.ntiles,
-                kChainDeps, chainU.flags.p, ep, ilu_x.p, sc.p};
+                kChainDeps, chainU.flags.p, ep, ilu_x.p, sc.p, opt.ilu_chain_spins};
     launch_ell_chain(b, stream);
   }
 
@@ -2270,7 +2276,14 @@ struct Solver {
     } else if (key == "ksp_rtol") opt.ksp_rtol = num();
     else if (key == "ksp_atol") opt.ksp_atol = num();
     else if (key == "ksp_max_it") opt.ksp_max_it = (int)num();
-    else if (key == "ksp_gmres_restart") { opt.gmres_restart = std::min((int)num(), kMaxMultiDot - 1); vv.clear(); }
+    else if (key == "ksp_gmres_restart") {
+      const int m = (int)num();
+      if (m < 1 || m > kMaxMultiDot - 1)
+        throw Error("ksp_gmres_restart must lie in [1, " + std::to_string(kMaxMultiDot - 1) + "] (the Gram-Schmidt kernels take up to " +
+                    std::to_string(kMaxMultiDot) + " vectors per launch)");
+      opt.gmres_restart = m; vv.clear();
+    }
+    else if (key == "debug_fail_at_fetch") debug_fail_at_fetch = (int)num();
     else if (key == "snes_rtol") opt.snes_rtol = num();
     else if (key == "snes_atol") opt.snes_atol = num();
     else if (key == "snes_stol") opt.snes_stol = num();
@@ -2283,6 +2296,7 @@ struct Solver {
     else if (key == "fused_assembly") opt.fused_assembly = num() != 0;
     else if (key == "ilu_graph") opt.ilu_graph = num() != 0;
     else if (key == "ilu_chain") opt.ilu_chain = (int)num();   // 0 per-level launches, 1 chained where it pays, 2 always chained
+    else if (key == "ilu_chain_spins") opt.ilu_chain_spins = (unsigned)num();   // polls before a chained wait gives up (tests: 0)
     else if (key == "fused_trials") opt.fused_trials = (int)num();
     else if (key == "fused_predict") opt.fused_predict = num() != 0;
     else if (key == "fused_ls_dots") opt.fused_ls_dots = num() != 0;
@@ -2349,6 +2363,16 @@ static thread_local std::string g_create_error;
   }                                     \
   catch (const std::exception &e) {     \
     S.err = e.what();                   \
+    return 2;                           \
+  }                                     \
+  return 0;
+// entry points that take part in collectives: a failure on this rank releases the in-process peers that are (or will be)
+// waiting for it, each with an error of its own, instead of leaving them blocked
+#define API_END_COLLECTIVE()            \
+  }                                     \
+  catch (const std::exception &e) {     \
+    S.err = e.what();                   \
+    S.comm.abort_peers();               \
     return 2;                           \
   }                                     \
   return 0;
@@ -2531,7 +2555,7 @@ int mppgpu_step_dt(mppgpu_handle h, double dt, int nstep, int *converged, int *c
   S.step_dt(dt, &c, &r);
   if (converged) *converged = c;
   if (converged_reason) *converged_reason = r;
-  API_END()
+  API_END_COLLECTIVE()
 }
 int mppgpu_get_data(mppgpu_handle h, int auxvar_type, int var_type, int cond_id, int n, double *data) {
   API_BEGIN(h)
@@ -2560,7 +2584,7 @@ int mppgpu_pre_solve(mppgpu_handle h) {
   if (S.dtime <= 0.0) throw mpp::Error("time step not set");
   S.op_pre_solve();
   HIP_CHECK(hipStreamSynchronize(S.stream));
-  API_END()
+  API_END_COLLECTIVE()
 }
 int mppgpu_residual(mppgpu_handle h, const double *x, double *f) {
   API_BEGIN(h)
@@ -2568,7 +2592,7 @@ int mppgpu_residual(mppgpu_handle h, const double *x, double *f) {
   S.put_state(x, S.W.p);
   S.op_residual(S.W.p, S.G.p);
   S.get_state(S.G.p, f);
-  API_END()
+  API_END_COLLECTIVE()
 }
 int mppgpu_jacobian_nnz(mppgpu_handle h, int *nnz) {
   API_BEGIN(h)
@@ -2582,7 +2606,7 @@ int mppgpu_jacobian(mppgpu_handle h, const double *x, int *rowptr, int *col, dou
   S.put_state(x, S.W.p);
   S.op_jacobian(S.W.p);
   S.export_csr(rowptr, col, val);
-  API_END()
+  API_END_COLLECTIVE()
 }
 int mppgpu_spmv(mppgpu_handle h, const double *x, double *y) {
   API_BEGIN(h)
@@ -2590,7 +2614,7 @@ int mppgpu_spmv(mppgpu_handle h, const double *x, double *y) {
   S.put_state(x, S.W.p);
   S.op_spmv(S.W.p, S.G.p);
   S.get_state(S.G.p, y);
-  API_END()
+  API_END_COLLECTIVE()
 }
 int mppgpu_pc_apply(mppgpu_handle h, const double *r, double *z) {
   API_BEGIN(h)
@@ -2598,9 +2622,8 @@ int mppgpu_pc_apply(mppgpu_handle h, const double *r, double *z) {
   S.put_state(r, S.W.p);
   S.op_pc_setup();
   S.op_pc_apply(S.W.p, S.G.p);
-  S.check_chain_error();
   S.get_state(S.G.p, z);
-  API_END()
+  API_END_COLLECTIVE()
 }
 int mppgpu_ksp_solve(mppgpu_handle h, const double *b, double *x, int *its, int *reason) {
   API_BEGIN(h)
@@ -2611,7 +2634,7 @@ int mppgpu_ksp_solve(mppgpu_handle h, const double *b, double *x, int *its, int 
   S.get_state(S.Y.p, x);
   if (its) *its = it;
   if (reason) *reason = r;
-  API_END()
+  API_END_COLLECTIVE()
 }
 
 /* ---- thermal KSP path ---- */
@@ -2652,7 +2675,7 @@ int mppgpu_thermal_step_dt(mppgpu_handle h, double dt, int *converged, int *line
   S.thermal_step_dt(dt, &c, &it);
   if (converged) *converged = c;
   if (linear_its) *linear_its = it;
-  API_END()
+  API_END_COLLECTIVE()
 }
 int mppgpu_thermal_get_soln(mppgpu_handle h, int n, double *temperature) {
   API_BEGIN(h)
@@ -2692,6 +2715,14 @@ int mppgpu_kernel_stats(mppgpu_handle h, const char *name, long long *launches, 
 int mppgpu_reset_stats(mppgpu_handle h) {
   API_BEGIN(h)
   S.prof.reset();
+  S.comm.n_allreduce = 0; S.comm.n_exchange = 0;
+  API_END()
+}
+int mppgpu_get_comm_stats(mppgpu_handle h, long long *allreduces, long long *halo_exchanges, long long *chain_fallbacks) {
+  API_BEGIN(h)
+  if (allreduces) *allreduces = S.comm.n_allreduce;
+  if (halo_exchanges) *halo_exchanges = S.comm.n_exchange;
+  if (chain_fallbacks) *chain_fallbacks = S.chain_fallbacks;
   API_END()
 }
 

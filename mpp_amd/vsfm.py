@@ -223,6 +223,11 @@ class SystemOfEquationsVSFM:
     def reset_stats(self):
         self._chk(self.L.mppgpu_reset_stats(self.h))
 
+    def comm_stats(self):
+        a, b, c = ct.c_longlong(), ct.c_longlong(), ct.c_longlong()
+        self._chk(self.L.mppgpu_get_comm_stats(self.h, ct.byref(a), ct.byref(b), ct.byref(c)))
+        return dict(allreduces=a.value, halo_exchanges=b.value, chain_fallbacks=c.value)
+
     def bench_kernel(self, name, variant=0, reps=20):
         ms, by = ct.c_double(), ct.c_double()
         self._chk(self.L.mppgpu_bench_kernel(self.h, name.encode(), int(variant), int(reps), ct.byref(ms), ct.byref(by)))

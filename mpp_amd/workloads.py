@@ -1,0 +1,500 @@
+"""Workload builders of the VSFM / thermal / coupled-TH solve path: inputs only, numbers quoted from the reference drivers.
+
+celia1990 : src/driver/standalone/vsfm/vsfm_celia1990_problem.F90 (nz=100, dt=3600 s x 24, VG, TGDPB01,
+            Dirichlet top 93991 Pa / bottom 3535.5 Pa, IC 3535.5 Pa); `ncols` copies = the "celia-extruded" grid of
+            SURVEY.md section 8(d), which bench.py times
+vchannel  : src/driver/standalone/vsfm/vsfm_vchannel_problem.F90 (20x10x30, 7-pt, no BC, dt=8640 s x 3)
+thermal_mms / mass_and_heat / th_mms / th_columns : the thermal and thermal-hydrology drivers (see each function)
+
+`to_gpu` / `to_thermal_gpu` / `to_th_gpu` build a problem on the GPU through the reference-shaped host API
+(mpp_amd.vsfm / thermal / th).  Nothing here touches the CPU checker used by the tests (its adapters live beside it, outside this package).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import constants as C
+from . import mesh as M
+
+
+@dataclass
+class Problem:
+    name: str
+    mesh: M.Mesh
+    perm: np.ndarray            # (n,3)
+    por: np.ndarray
+    satfunc_type: np.ndarray
+    alpha: np.ndarray
+    lam: np.ndarray
+    sat_res: np.ndarray
+    density_type: int
+    press_ic: np.ndarray
+    bcs: list = field(default_factory=list)   # [(cond_type, ConnectionSet, values)]
+    sss: list = field(default_factory=list)
+    lateral: object = None                    # ConnectionSet of the explicit (operator-split) lateral connections
+    sink_pressure: np.ndarray = None          # down-regulated sinks: over the concatenated source-sink connections
+    sink_exponent: np.ndarray = None
+    dt: float = 3600.0
+    nstep: int = 1
+
+
+def clm_soil_conversion(perm, alpha, lam, sucsat_grav):
+    """The CLM-unit round trip every reference driver does before VSFMMPPSetSoils, then
+    VSFMMPPSetSoilsCLM's inverse (MultiPhysicsProbVSFM.F90:374-381): two different gravity constants and
+    two different viscosities are involved, so the numbers are reproduced step by step."""
+    vish2o = 0.001002
+    hksat = perm / vish2o * (C.DENH2O * C.GRAV_CLM) / 0.001          # celia1990_problem.F90:325
+    bsw = 1.0 / lam
+    sucsat = 1.0 / (alpha * sucsat_grav)                             # :327 uses GRAVITY_CONSTANT; vchannel uses grav
+    perm_eff = hksat * vish2o / (C.DENH2O * C.GRAV_CLM) * 0.001      # MultiPhysicsProbVSFM.F90:374
+    alpha_eff = 1.0 / (sucsat * C.GRAV_CLM)                          # :378
+    lam_eff = 1.0 / bsw                                              # :381
+    return perm_eff, alpha_eff, lam_eff
+
+
+def celia1990(ncols=1, nz=100, perm_mult=None) -> Problem:
+    """`ncols` copies of the celia1990 column on a CLM-style (z-fastest) mesh: the 'celia-extruded' grid of
+    SURVEY.md section 8(d).  perm_mult: optional per-column permeability multiplier."""
+    z_column = 1.0
+    m = M.mesh_create_soil_columns("Soil mesh", ncols, nz, z_column / nz, area=1.0)
+    n = m.ncells_local
+    perm, alpha, lam = clm_soil_conversion(8.3913e-12, 3.4257e-4, 0.5, C.GRAVITY_CONSTANT)
+    perm_arr = np.full((n, 3), perm)
+    if perm_mult is not None:
+        perm_arr = perm_arr * np.repeat(np.asarray(perm_mult, dtype=np.float64), nz)[:, None]
+    top = M.create_region_connection_set(m, C.SOIL_TOP_CELLS)
+    bot = M.create_region_connection_set(m, C.SOIL_BOTTOM_CELLS)
+    return Problem(
+        name="vsfm_celia1990", mesh=m, perm=perm_arr, por=np.full(n, 0.368),
+        satfunc_type=np.full(n, C.SAT_FUNC_VAN_GENUCHTEN, dtype=np.int32), alpha=np.full(n, alpha),
+        lam=np.full(n, lam), sat_res=np.full(n, 0.2772), density_type=C.DENSITY_TGDPB01,
+        press_ic=np.full(n, 3.5355e3),
+        bcs=[(C.COND_DIRICHLET, top, np.full(ncols, 9.3991e4)), (C.COND_DIRICHLET, bot, np.full(ncols, 3.5355e3))],
+        dt=3600.0, nstep=24)
+
+
+def vchannel(nx=20, ny=10, nz=30) -> Problem:
+    dx, dy, dz, slope_x, slope_y = 10.0, 10.0, 0.5, 0.1, 0.2
+    n = nx * ny * nz
+    zv_x = np.zeros(nx + 1)
+    for ii in range(1, nx // 2 + 2):
+        zv_x[ii - 1] = slope_x * dx * (nx // 2) - (ii - 1) * slope_x * dx
+    for ii in range(nx // 2 + 2, nx + 2):
+        zv_x[ii - 1] = (ii - nx // 2 - 1) * slope_x * dx
+    zv_y = (np.arange(1, ny + 2) - 1) * slope_y * dy
+    zv = zv_x[:, None] + zv_y[None, :]                      # (nx+1, ny+1)
+    xv = ((np.arange(1, nx + 2) - 1) * dx)[:, None] + np.zeros((1, ny + 1))
+    yv = np.zeros((nx + 1, 1)) + ((np.arange(1, ny + 2) - 1) * dy)[None, :]
+
+    def c4(a):
+        return (a[:-1, :-1] + a[1:, :-1] + a[:-1, 1:] + a[1:, 1:]) / 4.0
+
+    xc2, yc2, zc2 = c4(xv), c4(yv), c4(zv)                  # (nx, ny)
+    kk = np.arange(1, nz + 1)
+    # ids are x-fastest: count over kk, jj, ii  -> arrays shaped [kk, jj, ii]
+    xc = np.broadcast_to(xc2.T[None, :, :], (nz, ny, nx)).ravel()
+    yc = np.broadcast_to(yc2.T[None, :, :], (nz, ny, nx)).ravel()
+    zc = (zc2.T[None, :, :] - (dz / 2.0 + (nz - kk)[:, None, None] * dz)).ravel()
+    m = M.Mesh(name="Soil mesh", ncells_local=n, nlev=nz, orientation=C.MESH_AGAINST_GRAVITY)
+    m.x, m.y, m.z = xc.copy(), yc.copy(), zc.copy()
+    m.dx, m.dy, m.dz = np.full(n, dx), np.full(n, dy), np.full(n, dz)
+    m.area_xy = np.full(n, dx * dy)
+    m.is_active = np.ones(n, dtype=np.int32)
+    m.compute_volume()
+    ids = (np.arange(n, dtype=np.int64) + 1).reshape(nz, ny, nx)
+    ups, dns, dus, dds, areas = [], [], [], [], []
+    # vertical: do kk, ii, jj
+    up = ids[:-1].transpose(0, 2, 1).ravel(); dn = ids[1:].transpose(0, 2, 1).ravel()
+    ups.append(up); dns.append(dn)
+    dus.append(np.full(up.size, 0.5 * dz)); dds.append(np.full(up.size, 0.5 * dz)); areas.append(np.full(up.size, dx * dy))
+
+    def dist_of(u, d):
+        ddx = m.x[u - 1] - m.x[d - 1]; ddy = m.y[u - 1] - m.y[d - 1]; ddz = m.z[u - 1] - m.z[d - 1]
+        return (ddx ** 2.0 + ddy ** 2.0 + ddz ** 2.0) ** 0.5
+
+    # horizontal x: do ii, kk, jj
+    up = ids[:, :, :-1].transpose(2, 0, 1).ravel(); dn = ids[:, :, 1:].transpose(2, 0, 1).ravel()
+    dist = dist_of(up, dn)
+    ups.append(up); dns.append(dn); dus.append(0.5 * dist); dds.append(0.5 * dist); areas.append(np.full(up.size, dz * dy))
+    # horizontal y: do jj, kk, ii
+    up = ids[:, :-1, :].transpose(1, 0, 2).ravel(); dn = ids[:, 1:, :].transpose(1, 0, 2).ravel()
+    dist = dist_of(up, dn)
+    ups.append(up); dns.append(dn); dus.append(0.5 * dist); dds.append(0.5 * dist); areas.append(np.full(up.size, dz * dx))
+    up, dn = np.concatenate(ups), np.concatenate(dns)
+    cs = M.ConnectionSet(up, dn, np.concatenate(dus), np.concatenate(dds), np.concatenate(areas), None, None)
+    cs.unit_vec = M.unit_vec_from_centroids(m, up, dn)
+    m.intrn_conn_sets.append(cs)
+    m.ncols, m.ordering = nx * ny, "x-fastest"
+    perm, alpha, lam = clm_soil_conversion(8.3913e-12, 3.4257e-4, 0.5, C.GRAV_CLM)
+    jj = np.repeat(np.arange(1, nz + 1), nx * ny)
+    press_ic = (18.75 - 0.5 * (jj - 1) - 2.0) * 997.18 * 9.8 + 101325.0
+    return Problem(
+        name="vsfm_vchannel", mesh=m, perm=np.full((n, 3), perm), por=np.full(n, 0.368),
+        satfunc_type=np.full(n, C.SAT_FUNC_VAN_GENUCHTEN, dtype=np.int32), alpha=np.full(n, alpha),
+        lam=np.full(n, lam), sat_res=np.full(n, 0.2772), density_type=C.DENSITY_TGDPB01, press_ic=press_ic,
+        dt=8640.0, nstep=3)
+
+
+def vchannel_operator_split(nx=6, ny=5, nz=7) -> Problem:
+    """the v-channel grid in ELM's operator-split form: only the vertical connections are implicit (mesh%intrn_conn_set_list),
+    the horizontal ones form mesh%lateral_conn_set_list and enter through the 'Lateral_flux' mass-rate source
+    (VSFMComputeLateralFlux, SystemOfEquationsVSFMType.F90:848-889)"""
+    prob = vchannel(nx, ny, nz)
+    cs = prob.mesh.intrn_conn_sets[0]
+    nv = nx * ny * (nz - 1)
+    pick = lambda a, sl: None if a is None else a[sl]
+    vert = M.ConnectionSet(cs.id_up[:nv], cs.id_dn[:nv], cs.dist_up[:nv], cs.dist_dn[:nv], cs.area[:nv], cs.unit_vec[:nv], pick(cs.itype, slice(0, nv)))
+    lat = M.ConnectionSet(cs.id_up[nv:], cs.id_dn[nv:], cs.dist_up[nv:], cs.dist_dn[nv:], cs.area[nv:], cs.unit_vec[nv:], pick(cs.itype, slice(nv, None)))
+    prob.mesh.intrn_conn_sets = [vert]
+    prob.lateral = lat
+    n = prob.mesh.ncells_local
+    z = np.zeros(n)
+    allcells = M.ConnectionSet(np.full(n, -1), np.arange(1, n + 1), z, z, np.ones(n), np.zeros((n, 3)))
+    prob.sss = [(C.COND_MASS_RATE, allcells, np.zeros(n))]
+    prob.name = "vsfm_vchannel_operator_split"
+    return prob
+
+
+def regression_stats(data, num_cells=5):
+    """min / max / mean / every k-th cell, as regression_mod%WriteData (src/driver/standalone/util/regression.F90:76-124)."""
+    data = np.asarray(data)
+    inc = data.size // min(num_cells, data.size)
+    cells = list(range(1, data.size + 1, inc))
+    return dict(min=float(data.min()), max=float(data.max()), mean=float(data.sum() / data.size),
+                cells={c: float(data[c - 1]) for c in cells})
+
+
+def to_gpu(prob: Problem, options=None, device_id=0):
+    """Build the problem on the GPU through the reference-shaped host API (mpp_amd.vsfm), following the
+    call order of the reference drivers (vsfm_celia1990_problem.F90:106-137)."""
+    from mpp_amd import vsfm as V
+    mpp = V.MultiPhysicsProbVSFM(device_id)
+    mpp.Init()
+    mpp.SetName("Variably-Saturated-Flow-Model")
+    mpp.SetID(C.MPP_VSFM_SNES_CLM)
+    mpp.SetMPIRank(0)
+    mpp.SetNumMeshes(1)
+    mpp.AddMesh(1, prob.mesh)
+    mpp.AddGovEqn(C.GE_RE, "Richards Equation ODE", C.MESH_CLM_SOIL_COL)
+    mpp.SetMeshesOfGoveqns()
+    for cond_type, cs, _vals in prob.bcs:
+        mpp.soe.AddConditionInGovEqn(1, C.COND_BC, "bc", "Pa", cond_type, conn_set=cs)
+    for cond_type, cs, _vals in prob.sss:
+        mpp.soe.AddConditionInGovEqn(1, C.COND_SS, "ss", "kg/s", cond_type, conn_set=cs)
+    for k, v in (options or {}).items():
+        mpp.soe.SetOption(k, v)
+    mpp.AllocateAuxVars()
+    mpp.SetupProblem()
+    V.VSFMMPPSetSoilPermeability(mpp, 1, prob.perm[:, 0], prob.perm[:, 1], prob.perm[:, 2])
+    V.VSFMMPPSetSoilPorosity(mpp, 1, prob.por)
+    V.VSFMMPPSetSaturationFunction(mpp, 1, prob.satfunc_type, prob.alpha, prob.lam, prob.sat_res)
+    V.VSFMMPPSetDensityType(mpp, 1, prob.density_type)
+    for i, (_t, _cs, vals) in enumerate(prob.bcs):
+        mpp.soe.SetDataFromCLM(C.AUXVAR_BC, C.VAR_BC_SS_CONDITION, i + 1, vals)
+    for i, (_t, _cs, vals) in enumerate(prob.sss):
+        mpp.soe.SetDataFromCLM(C.AUXVAR_SS, C.VAR_BC_SS_CONDITION, i + 1, vals)
+    if prob.lateral is not None:
+        mpp.soe.SetLateralConnections(prob.lateral)
+    if prob.sink_pressure is not None:
+        V.VSFMMPPSetSourceSinkAuxVarRealValue(mpp, 1, C.VAR_POT_MASS_SINK_PRESSURE, prob.sink_pressure)
+        V.VSFMMPPSetSourceSinkAuxVarRealValue(mpp, 1, C.VAR_POT_MASS_SINK_EXPONENT, prob.sink_exponent)
+    mpp.Restart(prob.press_ic)
+    return mpp
+
+
+# ------------------------------------------------------------------------------------------------------------
+# thermal MMS problems (src/driver/standalone/thermal/thermal_mms_problem.F90 and
+# thermal_mms_steady_state_problem_{1D,2D,3D}.F90): steady heat conduction on the unit cube, Dirichlet faces,
+# manufactured source; cnfac = 0, csol = 0, one StepDT(1.0)
+# ------------------------------------------------------------------------------------------------------------
+@dataclass
+class ThermalProblem:
+    name: str
+    mesh: M.Mesh
+    tkdry: np.ndarray          # per cell, in the cell numbering the reference ends up using (see below)
+    bc: M.ConnectionSet
+    bc_temperature: np.ndarray
+    heat_source: np.ndarray
+    exact: np.ndarray
+    t_init: float = 290.0
+    cnfac: float = 0.0
+    dt: float = 1.0
+
+
+def _mms_funcs(ptype):
+    pi = 4.0 * np.arctan(1.0)
+    if ptype == 1:
+        T = lambda x, y, z: 10 * np.sin(pi * x) + 270.0
+        lam = lambda x, y, z: np.exp(x)
+        src = lambda x, y, z: -np.exp(x) * (10.0 * pi * np.cos(pi * x)) - np.exp(x) * (-10.0 * pi * pi * np.sin(pi * x))
+    elif ptype == 2:
+        T = lambda x, y, z: 10.0 * np.sin(x * pi) * np.cos(2.0 * y * pi) + 270.0
+        lam = lambda x, y, z: (x + 0.5) * np.exp(x + y - 1.0)
+
+        def src(x, y, z):
+            l = (x + 0.5) * np.exp(x + y - 1.0)
+            dl_dx = ((x + 0.5) + 1.0) * np.exp(x + y - 1.0)
+            dl_dy = (x + 0.5) * np.exp(x + y - 1.0)
+            dT_dx = 10.0 * pi * np.cos(x * pi) * np.cos(2.0 * pi * y)
+            dT_dy = -20.0 * pi * np.sin(x * pi) * np.sin(2.0 * pi * y)
+            d2x = -10.0 * pi * pi * np.sin(x * pi) * np.cos(2.0 * pi * y)
+            d2y = -40.0 * pi * pi * np.sin(x * pi) * np.cos(2.0 * pi * y)
+            return -dl_dx * dT_dx - l * d2x - dl_dy * dT_dy - l * d2y
+    else:
+        T = lambda x, y, z: 10.0 * np.sin(x * pi) * np.cos(2.0 * pi * y) * np.sin(3.0 * pi * z) + 270.0
+        lam = lambda x, y, z: np.exp(x + y + z - 1.0)
+
+        def src(x, y, z):
+            a = np.exp(x + y + z - 1.0)
+            sx, cx = np.sin(x * pi), np.cos(x * pi)
+            sy, cy = np.sin(2.0 * pi * y), np.cos(2.0 * pi * y)
+            sz, cz = np.sin(3.0 * pi * z), np.cos(3.0 * pi * z)
+            dT_dx, dT_dy, dT_dz = 10.0 * pi * cx * cy * sz, -20.0 * pi * sx * sy * sz, 30.0 * pi * sx * cy * cz
+            d2x, d2y, d2z = -10.0 * pi * pi * sx * cy * sz, -40.0 * pi * pi * sx * cy * sz, -90.0 * pi * pi * sx * cy * sz
+            return -a * dT_dx - a * d2x - a * dT_dy - a * d2y - a * dT_dz - a * d2z
+    return T, lam, src
+
+
+def thermal_mms(ptype=3, nx=3, ny=3, nz=3, replicate_reference_soil_indexing=True) -> ThermalProblem:
+    """ptype 1/2/3 = STEADY_STATE_1D/2D/3D.  The reference fills the soil arrays as data_2D(c, kk) with
+    c = ii + (jj-1)*nx and MPPThermalSetSoils reads them as cell (c-1)*nlevgrnd + kk (z-fastest) although the mesh is
+    numbered x-fastest: for nz > 1 cell ids and conductivities are permuted against each other (invisible on the
+    3x3x3 baseline, whose conductivity is symmetric in x, y, z; reproduced by default for fidelity)."""
+    m = M.mesh_create("Soil mesh", 1.0, 1.0, 1.0, nx, ny, nz, C.CONN_IN_XYZ_DIR)
+    dx, dy, dz = 1.0 / nx, 1.0 / ny, 1.0 / nz
+    n = nx * ny * nz
+    T, lam, src = _mms_funcs(ptype)
+    ids = (np.arange(n) + 1).reshape(nz, ny, nx)           # [kk, jj, ii] -> x-fastest id
+    X, Y, Z = m.x.reshape(nz, ny, nx), m.y.reshape(nz, ny, nx), m.z.reshape(nz, ny, nx)
+    lam_pos = lam(X, Y, Z)                                 # conductivity at the position of cell [kk,jj,ii]
+    if replicate_reference_soil_indexing:
+        tk = np.zeros(n)
+        c = (np.arange(ny)[:, None] * nx + np.arange(nx)[None, :])           # c-1 for (jj,ii)
+        for kk in range(nz):
+            tk[(c * nz + kk).ravel()] = lam_pos[kk].ravel()                  # cell (c-1)*nz + kk (0-based)
+    else:
+        tk = lam_pos.ravel().copy()
+    # boundary connections in the driver's order (thermal_mms_problem.F90:365-452)
+    idd, du, dd, ar, tb = [], [], [], [], []
+
+    def face(cell, x, y, z, dist, area):
+        idd.append(cell); du.append(0.0); dd.append(dist); ar.append(area); tb.append(T(x, y, z))
+
+    if nx > 1:
+        for kk in range(nz):
+            for jj in range(ny):
+                face(ids[kk, jj, 0], X[kk, jj, 0] - dx / 2, Y[kk, jj, 0], Z[kk, jj, 0], dx / 2, dy * dz)
+                face(ids[kk, jj, nx - 1], X[kk, jj, nx - 1] + dx / 2, Y[kk, jj, nx - 1], Z[kk, jj, nx - 1], dx / 2, dy * dz)
+    if ny > 1:
+        for kk in range(nz):
+            for ii in range(nx):
+                face(ids[kk, 0, ii], X[kk, 0, ii], Y[kk, 0, ii] - dy / 2, Z[kk, 0, ii], dy / 2, dx * dz)
+                face(ids[kk, ny - 1, ii], X[kk, ny - 1, ii], Y[kk, ny - 1, ii] + dy / 2, Z[kk, ny - 1, ii], dy / 2, dx * dz)
+    if nz > 1:
+        for jj in range(ny):
+            for ii in range(nx):
+                face(ids[0, jj, ii], X[0, jj, ii], Y[0, jj, ii], Z[0, jj, ii] - dz / 2, dz / 2, dx * dy)
+                face(ids[nz - 1, jj, ii], X[nz - 1, jj, ii], Y[nz - 1, jj, ii], Z[nz - 1, jj, ii] + dz / 2, dz / 2, dx * dy)
+    nb = len(idd)
+    uv = np.zeros((nb, 3)); uv[:, 0] = 1.0
+    bc = M.ConnectionSet(np.zeros(nb, dtype=np.int64), np.asarray(idd, dtype=np.int64), np.asarray(du), np.asarray(dd),
+                         np.asarray(ar), uv)
+    return ThermalProblem(name="thermal_mms_%dd" % ptype, mesh=m, tkdry=tk, bc=bc, bc_temperature=np.asarray(tb),
+                          heat_source=(src(X, Y, Z) * dx * dy * dz).ravel(), exact=T(X, Y, Z).ravel())
+
+
+def to_thermal_gpu(tp: ThermalProblem, options=None, device_id=0):
+    """the call sequence of thermal_mms_problem.F90:236-262 / :603-705 through the reference-shaped host API"""
+    from mpp_amd import thermal as T
+    n = tp.mesh.ncells_local
+    mpp = T.MultiPhysicsProbThermal(device_id)
+    mpp.Init(); mpp.SetName("Thermal model for MMS"); mpp.SetID(T.MPP_THERMAL_TBASED_KSP_CLM); mpp.SetMPIRank(0)
+    mpp.SetNumMeshes(1)
+    mpp.AddMesh(1, tp.mesh)
+    mpp.AddGovEqn(T.GE_THERM_SOIL_TBASED, "Thermal equation using temprature formulation in soil (KSP formulation)", 302)
+    mpp.SetMeshesOfGoveqns()
+    mpp.soe.AddConditionInGovEqn(1, C.COND_BC, "Temp BC", "T", C.COND_DIRICHLET, conn_set=tp.bc)
+    mpp.soe.AddConditionInGovEqn(1, C.COND_SS, "Source term for MMS", "W/m^2", T.COND_HEAT_RATE, region_type=T.ALL_CELLS)
+    mpp.soe.SetOption("cnfac", tp.cnfac)
+    for k, v in (options or {}).items():
+        mpp.soe.SetOption(k, v)
+    mpp.AllocateAuxVars()
+    mpp.SetupProblem()
+    T.MPPThermalSetSoils(mpp, T.ISTSOIL, 1, 0.1, 0.0, 0.0, tp.tkdry)
+    mpp.soe.SetSolnPrevCLM(np.full(n, tp.t_init))
+    mpp.soe.SetRDataFromCLM(C.AUXVAR_INTERNAL, T.VAR_TUNING_FACTOR, 1, np.ones(n))
+    mpp.soe.SetRDataFromCLM(C.AUXVAR_INTERNAL, T.VAR_LIQ_AREAL_DEN, 1, np.zeros(n))
+    mpp.soe.SetRDataFromCLM(C.AUXVAR_BC, C.VAR_BC_SS_CONDITION, 1, tp.bc_temperature)
+    mpp.soe.SetRDataFromCLM(C.AUXVAR_SS, C.VAR_BC_SS_CONDITION, 1, tp.heat_source)
+    mpp.soe.PreStepDT()
+    return mpp
+
+
+# ======================================================================================================
+# coupled thermal-hydrology: Richards mass equation + enthalpy-based heat equation
+# ======================================================================================================
+@dataclass
+class THProblem:
+    name: str
+    mesh: M.Mesh
+    # mass equation (goveqn_richards_ode_pressure_type)
+    perm: np.ndarray
+    por: np.ndarray
+    satfunc_type: np.ndarray
+    alpha: np.ndarray
+    lam: np.ndarray
+    sat_res: np.ndarray
+    density_type: int
+    ie_type: int
+    # heat equation (goveqn_thermal_enthalpy_soil_type)
+    heat_cap: np.ndarray
+    tcond_wet: np.ndarray
+    tcond_dry: np.ndarray
+    talpha: np.ndarray
+    den_soil: np.ndarray
+    energy_perm: object = None          # None: the auxvar default 8.3913e-12 (MPPTHSetSoils never sets it)
+    press_ic: np.ndarray = None
+    temp_ic: np.ndarray = None
+    mass_bcs: list = field(default_factory=list)     # [(cond_type, ConnectionSet, values, bc_temperature or None)]
+    mass_sss: list = field(default_factory=list)     # [(cond_type, ConnectionSet, values)]
+    energy_bcs: list = field(default_factory=list)   # [(cond_type, ConnectionSet, values, bc_pressure)]
+    energy_sss: list = field(default_factory=list)
+    dt: float = 3600.0
+    nstep: int = 1
+
+
+def mass_and_heat(nx=100) -> THProblem:
+    """src/driver/standalone/thermal-e/mass_and_heat_model_problem.F90: nx x 1 x 1 cells along x (no gravity term),
+    VG + IFC67 density + IFC67 enthalpy, P = 91325 Pa, T = 283.15 K initially, heat equation held at 303.15 K / 293.15 K
+    at the two ends (with boundary pressure 91325 Pa), no condition on the mass equation, one step of 3600 s."""
+    m = M.mesh_create("Soil mesh", 1.0, 1.0, 1.0, nx, 1, 1, C.CONN_IN_X_DIR)
+    n = m.ncells_local
+    dx = 1.0 / nx
+    perm_eff, alpha_eff, lam_eff = clm_soil_conversion(8.3913e-12, 3.4257e-4, 0.5, C.GRAVITY_CONSTANT)  # :361-366; MPPTH :505-513
+
+    def end_face(cell, ux):
+        return M.ConnectionSet(np.array([0]), np.array([cell]), np.array([0.0]), np.array([0.5 * dx]), np.array([1.0 * 1.0]),
+                               np.array([[ux, 0.0, 0.0]]))
+    return THProblem(
+        name="mass_and_heat", mesh=m, perm=np.full((n, 3), perm_eff), por=np.full(n, 0.368),
+        satfunc_type=np.full(n, C.SAT_FUNC_VAN_GENUCHTEN, dtype=np.int32), alpha=np.full(n, alpha_eff),
+        lam=np.full(n, lam_eff), sat_res=np.full(n, 0.2772), density_type=C.DENSITY_IFC67, ie_type=2,
+        heat_cap=np.full(n, 837.0), tcond_wet=np.full(n, 1.3), tcond_dry=np.full(n, 0.25), talpha=np.full(n, 0.45),
+        den_soil=np.full(n, 2700.0), press_ic=np.full(n, 91325.0), temp_ic=np.full(n, 283.15),
+        energy_bcs=[(C.COND_DIRICHLET, end_face(1, 1.0), np.array([303.15]), np.array([91325.0])),
+                    (C.COND_DIRICHLET, end_face(nx, -1.0), np.array([293.15]), np.array([91325.0]))],
+        dt=3600.0, nstep=1)
+
+
+def to_th_gpu(tp: THProblem, options=None, device_id=0):
+    """the reference drivers' call sequence (mass_and_heat_model_problem.F90:112-139) through the Python mirror"""
+    from mpp_amd import th as TH
+    mpp = TH.MultiPhysicsProbTH(device_id)
+    mpp.Init(); mpp.SetName(tp.name); mpp.SetID(TH.MPP_TH_SNES_CLM); mpp.SetMPIRank(0)
+    mpp.SetNumMeshes(1); mpp.AddMesh(1, tp.mesh)
+    mpp.AddGovEqn(C.GE_RE, "Mass equation", 0)
+    mpp.AddGovEqn(TH.GE_THERM_SOIL_EBASED, "Heat transport based on enthalpy", 0)
+    mpp.SetMeshesOfGoveqns()
+    ids = {"mass_bc": [], "mass_ss": [], "energy_bc": [], "energy_ss": []}
+    for bc in tp.mass_bcs:
+        ids["mass_bc"].append(mpp.soe.AddConditionInGovEqn(1, C.COND_BC, "bc", "Pa", bc[0], conn_set=bc[1]))
+    for ss in tp.mass_sss:
+        ids["mass_ss"].append(mpp.soe.AddConditionInGovEqn(1, C.COND_SS, "ss", "kg/s", ss[0], conn_set=ss[1]))
+    for bc in tp.energy_bcs:
+        ids["energy_bc"].append(mpp.soe.AddConditionInGovEqn(2, C.COND_BC, "bc", "K", bc[0], conn_set=bc[1]))
+    for ss in tp.energy_sss:
+        ids["energy_ss"].append(mpp.soe.AddConditionInGovEqn(2, C.COND_SS, "ss", "W", ss[0], conn_set=ss[1]))
+    mpp.GovEqnSetInternalCouplingVars(1, 1, [TH.VAR_TEMPERATURE], [2])
+    mpp.GovEqnSetInternalCouplingVars(2, 1, [C.VAR_PRESSURE], [1])
+    mpp.AllocateAuxVars()
+    for k, v in (options or {}).items():
+        mpp.soe.SetOption(k, v)
+    mpp.SetupProblem()
+    TH.MPPTHSetSoilsSI(mpp, tp.perm, tp.por, tp.satfunc_type, tp.alpha, tp.lam, tp.sat_res, tp.density_type, tp.ie_type,
+                       tp.heat_cap, tp.tcond_wet, tp.tcond_dry, tp.talpha, tp.den_soil, energy_perm=tp.energy_perm)
+    mpp.Restart(tp.press_ic, tp.temp_ic)
+    mpp.cond_ids = ids
+    th_gpu_set_conditions(tp, mpp)
+    return mpp
+
+
+def th_gpu_set_conditions(tp: THProblem, mpp):
+    ids = mpp.cond_ids
+    for i, bc in enumerate(tp.mass_bcs):
+        mpp.soe.SetDataFromCLM(C.AUXVAR_BC, C.VAR_BC_SS_CONDITION, ids["mass_bc"][i], bc[2])
+        if len(bc) > 3 and bc[3] is not None:
+            mpp.soe.SetBoundaryAuxVarTemperature(ids["mass_bc"][i], bc[3])
+    for i, ss in enumerate(tp.mass_sss):
+        mpp.soe.SetDataFromCLM(C.AUXVAR_SS, C.VAR_BC_SS_CONDITION, ids["mass_ss"][i], ss[2])
+    for i, bc in enumerate(tp.energy_bcs):
+        mpp.soe.SetDataFromCLM(C.AUXVAR_BC, C.VAR_BC_SS_CONDITION, ids["energy_bc"][i], bc[2])
+        mpp.soe.SetBoundaryAuxVarPressure(ids["energy_bc"][i], bc[3])
+    for i, ss in enumerate(tp.energy_sss):
+        mpp.soe.SetDataFromCLM(C.AUXVAR_SS, C.VAR_BC_SS_CONDITION, ids["energy_ss"][i], ss[2])
+
+
+def th_columns(ncols=1, nz=100, perm_mult=None, density_type=None, ie_type=2) -> THProblem:
+    """'TH-extruded' grid (BASELINE.json configs[4] shape): `ncols` celia1990 soil columns (vertical connections,
+    gravity) carrying the coupled mass + heat equations: the celia soil and pressure boundary values, 283.15 K initially,
+    303.15 K at the wet top boundary and 283.15 K at the bottom."""
+    vs = celia1990(ncols=ncols, nz=nz, perm_mult=perm_mult)
+    m = vs.mesh
+    n = m.ncells_local
+    (ttype, tcs, tvals), (btype, bcs_, bvals) = vs.bcs
+    one = lambda cs, v: np.full(cs.num_connections, v)
+    return THProblem(
+        name="th_columns", mesh=m, perm=vs.perm, por=vs.por, satfunc_type=vs.satfunc_type, alpha=vs.alpha, lam=vs.lam,
+        sat_res=vs.sat_res, density_type=C.DENSITY_IFC67 if density_type is None else density_type, ie_type=ie_type,
+        heat_cap=np.full(n, 837.0), tcond_wet=np.full(n, 1.3), tcond_dry=np.full(n, 0.25), talpha=np.full(n, 0.45),
+        den_soil=np.full(n, 2700.0), press_ic=vs.press_ic.copy(), temp_ic=np.full(n, 283.15),
+        mass_bcs=[(ttype, tcs, tvals, one(tcs, 303.15)), (btype, bcs_, bvals, one(bcs_, 283.15))],
+        energy_bcs=[(C.COND_DIRICHLET, tcs, one(tcs, 303.15), tvals.copy()), (C.COND_DIRICHLET, bcs_, one(bcs_, 283.15), bvals.copy())],
+        dt=vs.dt, nstep=1)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# a problem split across ranks: owned cells + ghost cells per rank (mpp_amd.parallel.partition_mesh)
+# ------------------------------------------------------------------------------------------------------------
+def _restrict_conn_set(cs, vals, part, g2l):
+    """the entries of a boundary / source connection set whose cell this rank owns (cells renumbered locally)"""
+    cells = np.asarray(cs.id_dn) - 1
+    loc = g2l[cells]
+    keep = (loc >= 0) & (loc < part.nowned)
+    sub = M.ConnectionSet(np.asarray(cs.id_up)[keep], loc[keep] + 1, np.asarray(cs.dist_up)[keep], np.asarray(cs.dist_dn)[keep],
+                          np.asarray(cs.area)[keep], np.asarray(cs.unit_vec)[keep], None if cs.itype is None else np.asarray(cs.itype)[keep])
+    return sub, np.asarray(vals)[keep]
+
+
+def split_problem(prob: Problem, nranks):
+    """per-rank VSFM problems of a 3-D problem (no column structure is assumed); returns [(part, local problem)]"""
+    from mpp_amd import parallel as PAR
+    out = []
+    n = prob.mesh.ncells_local
+    for part in PAR.partition_mesh(prob.mesh, nranks):
+        g2l = np.full(n, -1, dtype=np.int64)
+        g2l[part.l2g] = np.arange(part.l2g.size)
+        l = part.l2g
+        lp = Problem(name=prob.name, mesh=part.mesh, perm=prob.perm[l], por=prob.por[l], satfunc_type=prob.satfunc_type[l],
+                     alpha=prob.alpha[l], lam=prob.lam[l], sat_res=prob.sat_res[l], density_type=prob.density_type,
+                     press_ic=prob.press_ic[l], dt=prob.dt, nstep=prob.nstep)
+        lp.bcs = [(t,) + _restrict_conn_set(cs, v, part, g2l) for (t, cs, v) in prob.bcs]
+        lp.sss = [(t,) + _restrict_conn_set(cs, v, part, g2l) for (t, cs, v) in prob.sss]
+        out.append((part, lp))
+    return out
+
+
+def split_thermal_problem(tp: ThermalProblem, nranks):
+    from mpp_amd import parallel as PAR
+    out = []
+    n = tp.mesh.ncells_local
+    for part in PAR.partition_mesh(tp.mesh, nranks):
+        g2l = np.full(n, -1, dtype=np.int64)
+        g2l[part.l2g] = np.arange(part.l2g.size)
+        l = part.l2g
+        bc, bct = _restrict_conn_set(tp.bc, tp.bc_temperature, part, g2l)
+        out.append((part, ThermalProblem(name=tp.name, mesh=part.mesh, tkdry=np.asarray(tp.tkdry)[l], bc=bc, bc_temperature=bct,
+                                         heat_source=np.asarray(tp.heat_source)[l], exact=np.asarray(tp.exact)[l], t_init=tp.t_init,
+                                         cnfac=tp.cnfac, dt=tp.dt)))
+    return out

@@ -151,3 +151,45 @@ def test_partition_mesh_halo_plans_are_consistent():
             assert (up_owned | dn_owned).all()
             nconn_owned_both += int((up_owned & dn_owned).sum()) * 2 + int((up_owned ^ dn_owned).sum())
         assert nconn_owned_both == 2 * prob.mesh.internal_connections().num_connections
+
+
+# ------------------------------------------------------------------------------------------------------------
+# bench.py's own rank launcher (`python bench.py --gpus N` invoked directly): the host path up to, not including,
+# mppgpu_create -- rendezvous, column sharding, id broadcast, barrier, max-over-ranks; and failure propagation
+# ------------------------------------------------------------------------------------------------------------
+def _run_bench(*argv, timeout=120):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + list(argv), env=env, capture_output=True,
+                          text=True, timeout=timeout)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_launcher_starts_its_own_ranks(world):
+    import json
+    r = _run_bench("--gpus", str(world), "--dry-run-ranks", "--nx", "10", "--ny", "7")
+    assert r.returncode == 0, r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout          # ONE JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["dry_run"] and out["n_gpus"] == world and out["unique_id_ok"]
+    assert out["columns"] == 70.0 and out["elapsed_max"] == float(world)
+    assert out["first_column_of_rank"] == [float(PAR.shard_columns(70, world, k)[0]) for k in range(world)]
+
+
+def test_bench_launcher_reports_a_failed_rank_and_stops_the_others():
+    r = _run_bench("--gpus", "2", "--dry-run-ranks", "--nx", "4", "--ny", "4", "--fail-rank", "1")
+    assert r.returncode != 0
+    assert "rank 1 exited with code" in r.stderr and "injected failure" in r.stderr
+    assert r.stdout.strip() == ""             # no JSON line from a failed run
+
+
+def test_bench_launcher_time_limit():
+    """a rank that never arrives: the other one is stopped at the launcher's time limit (exit code 124), nothing hangs"""
+    import time
+    t0 = time.time()
+    r = _run_bench("--gpus", "2", "--dry-run-ranks", "--nx", "4", "--ny", "4", "--fail-rank", "-2", "--launch-timeout", "3")
+    assert time.time() - t0 < 60
+    assert r.returncode == 124 and "launcher time limit" in r.stderr

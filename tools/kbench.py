@@ -9,10 +9,9 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import bench  # noqa: E402
-import problems as P  # noqa: E402
+from mpp_amd import workloads as P  # noqa: E402
 
 
 def main():

@@ -9,9 +9,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
-import problems as P  # noqa: E402
+from mpp_amd import workloads as P  # noqa: E402
 from mpp_amd import constants as C  # noqa: E402
 from mpp_amd import parallel as PAR  # noqa: E402
 from mpp_amd import vsfm as V  # noqa: E402

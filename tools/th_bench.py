@@ -10,22 +10,22 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
-import problems as P  # noqa: E402
+from mpp_amd import workloads as P  # noqa: E402
 
 
 def cpu_baseline(cols, nz, ncols_full):
     """the CPU oracle ("port": th_oracle.c, GMRES(30)+ILU(0) as the reference's PETSc defaults, one core -- the reference is
     serial) on a bounded sample of the same workload, scaled to full-grid Newton iterations/s"""
+    from oracle import adapters as A   # the CPU oracle: baseline leg only
     mult = np.exp(0.5 * np.random.default_rng(12345).standard_normal(ncols_full))[:cols]
     tp = P.th_columns(ncols=cols, nz=nz, perm_mult=mult)
-    o = P.to_th_oracle(tp)
+    o = A.to_th_oracle(tp)
     o.step_dt(tp.dt)
     c0 = o.counters()["newton"]
     t0 = time.perf_counter()
     for s in range(2):
-        P.th_set_conditions(tp, o)
+        A.th_set_conditions(tp, o)
         o.step_dt(tp.dt)
     dt = time.perf_counter() - t0
     its = o.counters()["newton"] - c0

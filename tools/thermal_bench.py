@@ -9,16 +9,16 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
-import problems as P  # noqa: E402
+from mpp_amd import workloads as P  # noqa: E402
 
 
 def cpu_baseline(n, n_full, rtol):
     """the CPU oracle ("port": thermal_oracle.c + the restated GMRES(30)+ILU(0), one core) on a smaller grid of the same
     problem; reported as cell-iterations per second so that it can be set against the GPU's"""
+    from oracle import adapters as A   # the CPU oracle: baseline leg only
     tp = P.thermal_mms(3, n, n, n, replicate_reference_soil_indexing=False)
-    o = P.to_thermal_oracle(tp, ksp_rtol=rtol)
+    o = A.to_thermal_oracle(tp, ksp_rtol=rtol)
     t0 = time.perf_counter()
     o.step_dt(tp.dt)
     dt = time.perf_counter() - t0

@@ -11,8 +11,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
-import problems as P  # noqa: E402
+from mpp_amd import workloads as P  # noqa: E402
 
 
 def main():
