@@ -23,7 +23,8 @@ module mppgpu_mod
 
   ! the raw bindings are public too: one per entry point of include/mppgpu.h
   public :: mppgpu_create, mppgpu_destroy, mppgpu_last_error, mppgpu_set_mesh, mppgpu_set_connections, &
-        mppgpu_add_condition, mppgpu_set_soil_permeability, mppgpu_set_soil_porosity, mppgpu_set_saturation_function, &
+        mppgpu_add_condition, mppgpu_set_soil_permeability, mppgpu_set_soil_porosity, mppgpu_set_soil_porosity_linear, &
+        mppgpu_set_saturation_function, &
         mppgpu_set_density_type, mppgpu_set_option, mppgpu_setup, mppgpu_restart, mppgpu_set_data, mppgpu_step_dt, &
         mppgpu_get_data, mppgpu_get_counters, mppgpu_set_dtime, mppgpu_pre_solve, mppgpu_residual, &
         mppgpu_jacobian_nnz, mppgpu_jacobian, mppgpu_synchronize, mppgpu_spmv, mppgpu_pc_apply, mppgpu_ksp_solve, &
@@ -82,6 +83,12 @@ module mppgpu_mod
        import :: c_int, c_ptr, c_double
        type(c_ptr), value :: h
        real(c_double) :: por(*)
+     end function
+     integer(c_int) function mppgpu_set_soil_porosity_linear(h, por_base, pressure_reference, slope) &
+          bind(C, name='mppgpu_set_soil_porosity_linear')
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: h
+       real(c_double) :: por_base(*), pressure_reference(*), slope(*)
      end function
      integer(c_int) function mppgpu_set_saturation_function(h, satfunc_type, alpha, lambda, sat_res) &
           bind(C, name='mppgpu_set_saturation_function')

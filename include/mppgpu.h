@@ -109,6 +109,14 @@ int mppgpu_add_condition(mppgpu_handle h, int kind, int cond_type, int nconn, co
  * Boundary-condition auxvars take their soil parameters from their id_dn cell (:422-471). */
 int mppgpu_set_soil_permeability(mppgpu_handle h, const double *perm_x, const double *perm_y, const double *perm_z);
 int mppgpu_set_soil_porosity(mppgpu_handle h, const double *por);
+/* PorosityFunctionSetLinearModel for every cell (src/mpp/util/PorosityFunctionMod.F90:75-96, evaluated :144-163):
+ * por = por_base + (P - pressure_reference) * slope, dpor_dP = slope (enters RichardsODEPressureAccumDeriv,
+ * src/mpp/ge/GoveqnRichardsODEPressureType.F90:1675-1677).  No MPP-level routine sets it in the reference (the
+ * porParams of an auxvar are reachable through the auxvar only); mppgpu_set_soil_porosity returns to the constant model. */
+int mppgpu_set_soil_porosity_linear(mppgpu_handle h, const double *por_base, const double *pressure_reference,
+                                    const double *slope);
+/* satfunc_type is per cell (satParams of every auxvar, src/mpp/auxvar/RichardsODEPressureAuxType.F90:18-67; dispatch
+ * src/mpp/util/SaturationFunction.F90:564-650): one mesh may mix van Genuchten, Brooks-Corey and smoothed Brooks-Corey cells */
 int mppgpu_set_saturation_function(mppgpu_handle h, const int *satfunc_type, const double *alpha, const double *lambda,
                                    const double *sat_res);
 int mppgpu_set_density_type(mppgpu_handle h, int density_type);

@@ -29,6 +29,7 @@ SIGNATURES = {
     "mppgpu_add_condition": (ct.c_int, [_h, ct.c_int, ct.c_int, ct.c_int, _ip, _dp, _dp, _dp, _dp, ct.c_int, _ip]),
     "mppgpu_set_soil_permeability": (ct.c_int, [_h, _dp, _dp, _dp]),
     "mppgpu_set_soil_porosity": (ct.c_int, [_h, _dp]),
+    "mppgpu_set_soil_porosity_linear": (ct.c_int, [_h, _dp, _dp, _dp]),
     "mppgpu_set_saturation_function": (ct.c_int, [_h, _ip, _dp, _dp, _dp]),
     "mppgpu_set_density_type": (ct.c_int, [_h, ct.c_int]),
     "mppgpu_pre_step_dt": (ct.c_int, [_h]),

@@ -15,6 +15,8 @@
 // runs at 6.3 TB/s that way versus 4.8 TB/s with a 4096-block grid-stride loop (tools/membench.hip).
 #include "kernels.hpp"
 
+#include <algorithm>
+
 namespace mpp {
 
 namespace {
@@ -55,11 +57,13 @@ __device__ __forceinline__ Soil load_soil(const CellArrays &ca, size_t i) {
   s.alpha = NT ? ldnt(ca.alpha + i) : ca.alpha[i];
   s.m = NT ? ldnt(ca.m + i) : ca.m[i];
   s.por = NT ? ldnt(ca.por + i) : ca.por[i];
-  if ((SAT_T >= 0 ? SAT_T : ca.sat_func) == kSatSBC) {
+  s.sf = SAT_T >= 0 ? SAT_T : (ca.satf ? (int)ca.satf[i] : ca.sat_func);   // per-cell dispatch (SaturationFunction.F90:564-650)
+  if (s.sf == kSatSBC) {
     s.pu = ca.sbc_pu[i]; s.ps = ca.sbc_ps[i]; s.b2 = ca.sbc_b2[i]; s.b3 = ca.sbc_b3[i];
   } else {
     s.pu = s.ps = s.b2 = s.b3 = 0.0;
   }
+  if (ca.por_slope) { s.por_pref = ca.por_pref[i]; s.por_slope = ca.por_slope[i]; } else { s.por_pref = s.por_slope = 0.0; }
   return s;
 }
 
@@ -82,8 +86,10 @@ __global__ __launch_bounds__(kBlock) void k_accum(CellArrays ca, int n, double d
   double acc = 0.0;
   if (owns_row(ca, i)) {
     Soil s = load_soil(ca, i);
-    Aux a = auxvar_compute<false>(ca.sat_func, ca.eos, s, ca.P[i], frac_of(ca, i));
-    acc = s.por * a.den * a.sat * ca.vol[i] * dtInv;
+    Aux a = auxvar_compute<false>(s.sf, ca.eos, s, ca.P[i], frac_of(ca, i));
+    double por, dpor;
+    porosity(s, ca.por_slope != nullptr, ca.P[i], por, dpor);
+    acc = por * a.den * a.sat * ca.vol[i] * dtInv;
   }
   out[i] = acc;
 }
@@ -165,7 +171,9 @@ __global__ __launch_bounds__(kBlock) void k_assemble_cols(ColsArgs a) {
 
     // the streamed operands of one level (and of the connection below it), fetched one level ahead of their use so
     // that a wave's memory latency overlaps its own arithmetic (the march runs at 2-4 waves per SIMD)
-    struct Level { double P, sat_res, alpha, m, por, vol, accp, Dq, upw, dgrav, area; };
+    struct Level { double P, sat_res, alpha, m, por, vol, accp, Dq, upw, dgrav, area, pref, slope; int sf; };
+    constexpr bool GEN = SAT_T < 0;   // general soil: per-cell saturation functions and / or the linear porosity model
+    const bool lin_por = GEN && ca.por_slope != nullptr;
     auto fetch = [&](int k) {
       Level L;
       const size_t i = cbase + (size_t)k * tw;
@@ -175,7 +183,14 @@ __global__ __launch_bounds__(kBlock) void k_assemble_cols(ColsArgs a) {
       } else L.P = ldnt(ca.P + i);
       L.sat_res = ldnt(ca.sat_res + i); L.alpha = ldnt(ca.alpha + i);
       L.m = (SAT_T == kSatVGHalf) ? 0.5 : ldnt(ca.m + i);
-      L.por = ldnt(a.porvol + i); L.vol = 1.0;     // porosity only ever multiplies the volume here
+      if (GEN) {
+        L.por = ldnt(ca.por + i); L.vol = ldnt(ca.vol + i);
+        L.sf = ca.satf ? (int)ca.satf[i] : ca.sat_func;
+        if (lin_por) { L.pref = ldnt(ca.por_pref + i); L.slope = ldnt(ca.por_slope + i); } else { L.pref = L.slope = 0.0; }
+      } else {
+        L.por = ldnt(a.porvol + i); L.vol = 1.0;   // (constant) porosity only ever multiplies the volume here
+        L.pref = L.slope = 0.0; L.sf = SAT_T;
+      }
       L.accp = RES ? ldnt(a.accum_prev + i) : 0.0;
       if (k > kstart) {
         const size_t ic = i - tw;
@@ -199,14 +214,22 @@ __global__ __launch_bounds__(kBlock) void k_assemble_cols(ColsArgs a) {
       if (act) {
         Soil s;
         s.sat_res = L.sat_res; s.alpha = L.alpha; s.m = L.m; s.por = L.por;
-        if ((SAT_T >= 0 ? SAT_T : ca.sat_func) == kSatSBC) {
+        s.por_pref = L.pref; s.por_slope = L.slope; s.sf = L.sf;
+        if (L.sf == kSatSBC) {
           s.pu = ca.sbc_pu[i]; s.ps = ca.sbc_ps[i]; s.b2 = ca.sbc_b2[i]; s.b3 = ca.sbc_b3[i];
         } else s.pu = s.ps = s.b2 = s.b3 = 0.0;
-        cur = auxvar_compute<JAC, SAT_T, DEN_T>(ca.sat_func, ca.eos, s, Pi, frac_of(ca, i));
+        cur = auxvar_compute<JAC, SAT_T, DEN_T>(L.sf, ca.eos, s, Pi, frac_of(ca, i));
         if (owned) {
           const double vol = L.vol;
-          if (RES) f_cur = s.por * cur.den * cur.sat * vol * a.dtInv;
-          if (JAC) dacc_cur = (s.por * cur.dden * cur.sat + s.por * cur.den * cur.dsat) * vol * a.dtInv;
+          if (lin_por) {
+            double por, dpor;
+            porosity(s, true, Pi, por, dpor);
+            if (RES) f_cur = por * cur.den * cur.sat * vol * a.dtInv;
+            if (JAC) dacc_cur = (dpor * cur.den * cur.sat + por * cur.dden * cur.sat + por * cur.den * cur.dsat) * vol * a.dtInv;
+          } else {
+            if (RES) f_cur = s.por * cur.den * cur.sat * vol * a.dtInv;
+            if (JAC) dacc_cur = (s.por * cur.dden * cur.sat + s.por * cur.den * cur.dsat) * vol * a.dtInv;
+          }
         }
       }
       if (RES && owned) f_cur = f_cur - L.accp;
@@ -249,11 +272,18 @@ __global__ __launch_bounds__(kBlock) void k_auxvars(GenArgs a) {
   Aux x = {};
   if (is_active(ca, i)) {
     Soil s = load_soil(ca, i);
-    x = auxvar_compute<JAC>(ca.sat_func, ca.eos, s, ca.P[i], frac_of(ca, i));
+    x = auxvar_compute<JAC>(s.sf, ca.eos, s, ca.P[i], frac_of(ca, i));
     if (owns_row(ca, i)) {
       const double vol = ca.vol[i];
-      if (RES) f = s.por * x.den * x.sat * vol * a.dtInv;
-      if (JAC) dacc = (s.por * x.dden * x.sat + s.por * x.den * x.dsat) * vol * a.dtInv;
+      if (ca.por_slope) {   // linear porosity model: all three terms of RichardsODEPressureAccumDeriv (GE:1675-1677)
+        double por, dpor;
+        porosity(s, true, ca.P[i], por, dpor);
+        if (RES) f = por * x.den * x.sat * vol * a.dtInv;
+        if (JAC) dacc = (dpor * x.den * x.sat + por * x.dden * x.sat + por * x.den * x.dsat) * vol * a.dtInv;
+      } else {
+        if (RES) f = s.por * x.den * x.sat * vol * a.dtInv;
+        if (JAC) dacc = (s.por * x.dden * x.sat + s.por * x.den * x.dsat) * vol * a.dtInv;
+      }
     }
   }
   a.aux.kr[i] = x.kr;
@@ -391,7 +421,7 @@ __global__ __launch_bounds__(kBlock) void k_bc(BcArgs a) {
   }
   Soil s = load_soil(ca, cell);
   const double Pc = a.trial_x ? fma(a.trial_a, a.trial_y[cell], a.trial_x[cell]) : ca.P[cell];
-  const Aux in = auxvar_compute<JAC>(ca.sat_func, ca.eos, s, Pc, frac_of(ca, cell));
+  const Aux in = auxvar_compute<JAC>(s.sf, ca.eos, s, Pc, frac_of(ca, cell));
   const bool side = a.side_f != nullptr;   // fluxes into per-condition-cell side arrays (complete-row column march)
   double f = (RES && !side) ? a.F[cell] : 0.0;
   double d = 0.0;
@@ -399,7 +429,7 @@ __global__ __launch_bounds__(kBlock) void k_bc(BcArgs a) {
     const int t = a.type[e];
     const int ctype = t & 0xffff, swap = t >> 16;
     const double pb = (ctype == kCondMassFlux) ? in.P : a.value[e];
-    const Aux bc = auxvar_compute<JAC>(ca.sat_func, ca.eos, s, pb, ca.frac_liq);
+    const Aux bc = auxvar_compute<JAC>(s.sf, ca.eos, s, pb, ca.frac_liq);
     ConnGeom g;
     g.Dq = a.Dq[e]; g.upweight = 0.0; g.dist_gravity = a.dgrav[e]; g.area = a.area[e];
     double Jup = 0.0, Jdn = 0.0, flux, jdn_outer;
@@ -462,8 +492,8 @@ __global__ __launch_bounds__(kBlock) void k_conn_flux(CellArrays ca, ConnArrays 
   double flux = 0.0;
   if (is_active(ca, u) && is_active(ca, d)) {
     Soil su = load_soil(ca, u), sd = load_soil(ca, d);
-    Aux au = auxvar_compute<false>(ca.sat_func, ca.eos, su, ca.P[u], frac_of(ca, u));
-    Aux ad = auxvar_compute<false>(ca.sat_func, ca.eos, sd, ca.P[d], frac_of(ca, d));
+    Aux au = auxvar_compute<false>(su.sf, ca.eos, su, ca.P[u], frac_of(ca, u));
+    Aux ad = auxvar_compute<false>(sd.sf, ca.eos, sd, ca.P[d], frac_of(ca, d));
     ConnGeom g;
     g.Dq = cn.Dq[ic]; g.upweight = cn.upw[ic]; g.dist_gravity = cn.dgrav[ic]; g.area = cn.area[ic];
     double j1, j2;
@@ -478,10 +508,11 @@ __global__ __launch_bounds__(kBlock) void k_cell_var(CellArrays ca, int n, int v
   if (i >= (size_t)n) return;
   Soil s = load_soil(ca, i);
   const double P = ca.P[i];
-  Aux a = auxvar_compute<false>(ca.sat_func, ca.eos, s, P, frac_of(ca, i));
-  double v;
+  Aux a = auxvar_compute<false>(s.sf, ca.eos, s, P, frac_of(ca, i));
+  double v, por, dpor;
+  porosity(s, ca.por_slope != nullptr, P, por, dpor);
   if (var_type == 608) v = a.sat;
-  else if (var_type == 610) v = s.por * a.den * kFMWH2O * a.sat * ca.vol[i];
+  else if (var_type == 610) v = por * a.den * kFMWH2O * a.sat * ca.vol[i];
   else v = (P - kPressureRef) / (a.den * kFMWH2O * kGravity);
   out[i] = v;
 }
@@ -1442,6 +1473,122 @@ __global__ __launch_bounds__(kBlock) void k_tri_solve_dots(TriArgs a, const doub
   }
 }
 
+// The same solve with the forward-swept right-hand side kept on chip.  k_tri_solve_dots writes L^{-1} r to z and reads it
+// back in the second sweep (16 of its 64 bytes per cell, PMC: profiles/r01_pmc_solver.md); here ONE WAVE owns a tile of 64
+// columns and parks L^{-1} r in its own LDS slab (nz x 512 bytes: a 100-level column tile takes 51 KB, three waves per CU).
+// At three waves per CU the memory system is kept busy by depth instead of by occupancy: the operands travel through a
+// ring of R register groups of G levels each (2-3 streams, one 512-byte wave load per stream and level); a group is
+// refilled as soon as it has been consumed, and consuming a group waits for that group only (vector-memory operations
+// retire in order), so (R-1) G .. R G levels of every stream are in flight per wave at all times.  The loop bodies are
+// straight-line code -- every path issues the same loads and stores (addresses clamped, idle lanes of a ragged last tile
+// store to a scratch line) -- so that the compiler can count the outstanding operations instead of draining them.
+// Arithmetic per column is the one of k_tri_solve_dots (same order, same roundings); the dot products are summed per lane
+// over the column, then over the 64 lanes: one partial sum per tile, layout partials[j*nb + tile].
+template <int ND, int G, int RF, int RB>
+__global__ __launch_bounds__(64) void k_tri_solve_lds(TriArgs a, const double *__restrict__ r, double *__restrict__ z,
+                                                      const double *__restrict__ w, double *__restrict__ partials,
+                                                      double *__restrict__ scratch64) {
+  extern __shared__ __attribute__((aligned(16))) double dsl[];   // [nz][64]
+  const int lane = threadIdx.x, tile = blockIdx.x;
+  const int nz = a.nz;
+  const int tw = min(64, a.ncols - (tile << 6));
+  const bool valid = lane < tw;
+  const size_t cbase = (size_t)tile * 64 * nz + (valid ? lane : 0);   // idle lanes of the last tile shadow lane 0 ...
+  double *zs = valid ? z + cbase : scratch64 + lane;                  // ... and store into a scratch line
+  const size_t tws = valid ? (size_t)tw : 0;
+  {
+    double rb[RF][G], lb[RF][G];
+    auto fetch = [&](int q, int kfirst) {   // levels kfirst .. kfirst+G-1 (clamped) into group q
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        const size_t i = cbase + (size_t)min(kfirst + j, nz - 1) * tw;
+        rb[q][j] = ldnt(r + i); lb[q][j] = ldnt(a.l + i);
+      }
+    };
+#pragma unroll
+    for (int q = 0; q < RF; ++q) { fetch(q, q * G); __builtin_amdgcn_sched_barrier(0); }
+    double prev = 0.0;
+    int k0 = 0;
+    for (; k0 + RF * G <= nz; k0 += RF * G) {
+#pragma unroll
+      for (int q = 0; q < RF; ++q) {
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+          const double d = rb[q][j] - lb[q][j] * prev;
+          prev = d;
+          dsl[(k0 + q * G + j) * 64 + lane] = d;
+        }
+        __builtin_amdgcn_sched_barrier(0);   // program order = issue order: a group is refilled right after its use
+        fetch(q, k0 + (RF + q) * G);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // the last, partial round: its operands are in the ring already (the refills above were clamped to the last level)
+#pragma unroll
+    for (int q = 0; q < RF; ++q)
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        const int k = k0 + q * G + j;
+        if (k < nz) {
+          const double d = rb[q][j] - lb[q][j] * prev;
+          prev = d;
+          dsl[k * 64 + lane] = d;
+        }
+      }
+  }
+  double acc0 = 0.0, acc1 = 0.0;
+  {
+    double cb[RB][G], ib[RB][G], wb[RB][G];
+    auto fetch = [&](int q, int ktop) {   // levels ktop, ktop-1, ..., ktop-G+1 (clamped at 0) into group q
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        const size_t i = cbase + (size_t)max(ktop - j, 0) * tw;
+        cb[q][j] = ldnt(a.c + i); ib[q][j] = ldnt(a.invb + i);
+        if (ND == 2) wb[q][j] = ldnt(w + i);
+      }
+    };
+#pragma unroll
+    for (int q = 0; q < RB; ++q) { fetch(q, nz - 1 - q * G); __builtin_amdgcn_sched_barrier(0); }
+    double next = 0.0;
+    int k0 = nz - 1;
+    for (; k0 - RB * G + 1 >= 0; k0 -= RB * G) {
+#pragma unroll
+      for (int q = 0; q < RB; ++q) {
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+          const int k = k0 - q * G - j;
+          const double xk = (dsl[k * 64 + lane] - cb[q][j] * next) * ib[q][j];
+          next = xk;
+          stnt(xk, zs + (size_t)k * tws);
+          if (ND == 2) { acc0 += xk * wb[q][j]; acc1 += xk * xk; } else acc0 += xk * xk;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(q, k0 - (RB + q) * G);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < RB; ++q)
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        const int k = k0 - q * G - j;
+        if (k >= 0) {
+          const double xk = (dsl[k * 64 + lane] - cb[q][j] * next) * ib[q][j];
+          next = xk;
+          stnt(xk, zs + (size_t)k * tws);
+          if (ND == 2) { acc0 += xk * wb[q][j]; acc1 += xk * xk; } else acc0 += xk * xk;
+        }
+      }
+  }
+  if (!valid) acc0 = acc1 = 0.0;
+  const double t0 = wave_sum(acc0);
+  if (lane == 0) partials[tile] = t0;
+  if (ND == 2) {
+    const double t1 = wave_sum(acc1);
+    if (lane == 0) partials[(size_t)gridDim.x + tile] = t1;
+  }
+}
+
 // backward substitution only, from a forward-eliminated right-hand side d (left by the assembly pass): z = U^{-1} d with
 // the partial sums of z.z
 __global__ __launch_bounds__(kBlock) void k_tri_back_dots(TriArgs a, const double *__restrict__ d, double *__restrict__ z,
@@ -1649,6 +1796,10 @@ void launch_assemble_cols(int mode, const ColsArgs &a, hipStream_t stream) {
   if (a.ncols <= 0) return;
   dim3 grid(nblk(a.ncols), a.col_bc ? 1 : a.nseg);
   const bool ifc = a.cell.eos.density_type == kDenIFC67;
+  if (a.cell.satf || a.cell.por_slope) {   // per-cell saturation functions / linear porosity: the general-soil march
+    ifc ? launch_cols_mode<-1, 1>(mode, a, grid, stream) : launch_cols_mode<-1, 0>(mode, a, grid, stream);
+    return;
+  }
   switch (a.cell.sat_func) {
     case kSatVG:
       if (a.cell.all_vg_half && !ifc) launch_cols_mode<kSatVGHalf, 0>(mode, a, grid, stream);
@@ -1802,6 +1953,18 @@ int launch_tri_solve_dots(const TriArgs &a, const double *r, double *z, const do
   const dim3 grid(nblk(a.ncols));
   if (w) LAUNCH(k_tri_solve_dots<2>, grid, a, r, z, w, partials);
   else LAUNCH(k_tri_solve_dots<1>, grid, a, r, z, w, partials);
+  return (int)grid.x;
+}
+int tri_solve_lds_blocks(int ncols) { return (ncols + 63) / 64; }
+int launch_tri_solve_lds(const TriArgs &a, const double *r, double *z, const double *w, double *partials, double *scratch64,
+                         int group, hipStream_t stream) {
+  const dim3 grid(tri_solve_lds_blocks(a.ncols));
+  const size_t shmem = (size_t)a.nz * 64 * sizeof(double);
+#define TRI_LDS(ND, G, RF, RB) hipLaunchKernelGGL((k_tri_solve_lds<ND, G, RF, RB>), grid, dim3(64), shmem, stream, a, r, z, w, partials, scratch64)
+  // `group` = levels in flight per stream: rings of 4-level groups
+  if (w) { if (group <= 8) TRI_LDS(2, 4, 2, 2); else if (group <= 16) TRI_LDS(2, 4, 4, 3); else TRI_LDS(2, 4, 6, 4); }
+  else { if (group <= 8) TRI_LDS(1, 4, 2, 2); else if (group <= 16) TRI_LDS(1, 4, 4, 4); else TRI_LDS(1, 4, 6, 5); }
+#undef TRI_LDS
   return (int)grid.x;
 }
 int launch_tri_back_dots(const TriArgs &a, const double *d, double *z, double *partials, hipStream_t stream) {

@@ -25,7 +25,9 @@ struct CellArrays {
   const double *por, *sat_res, *alpha, *m, *vol;     // soil (internal ordering)
   const double *sbc_pu, *sbc_ps, *sbc_b2, *sbc_b3;   // smoothed Brooks-Corey only (else nullptr)
   const signed char *active;                         // nullptr = every cell active
-  int sat_func;
+  const signed char *satf;                           // per-cell saturation function (SatFunc ids) when the mesh mixes them, else nullptr
+  const double *por_pref, *por_slope;                // POROSITY_LINEAR: pressure_reference, lin_mod_slope per cell; nullptr = constant model
+  int sat_func;                                      // the mesh's saturation function when satf == nullptr
   int all_vg_half;                                   // every cell is van Genuchten with m == 1/2 (host-verified)
   double frac_liq;                                   // frac_liq_sat of boundary auxvars (1.0) and of every cell when ...
   const double *frac_cell;                           // ... no per-cell values were set (VAR_FRAC_LIQ_SAT), else per cell
@@ -155,6 +157,13 @@ void launch_tri_solve(const TriArgs &a, const double *r, double *z, hipStream_t 
 // the same solve with fused dot products of the result: z.z (w == nullptr) or z.w and z.z; returns the number of partial
 // blocks (<= kMaxPartialBlocks is the caller's responsibility); finish with launch_finalize_partials
 int launch_tri_solve_dots(const TriArgs &a, const double *r, double *z, const double *w, double *partials, hipStream_t stream);
+// the same with L^{-1} r parked in LDS between the sweeps (one wave per 64-column tile, nz <= kTriLdsMaxLevels; `group` levels
+// are kept in flight per stream; scratch64: 64 doubles the idle lanes of a ragged last tile may write); one partial sum per
+// tile: tri_solve_lds_blocks(ncols)
+constexpr int kTriLdsMaxLevels = 120;   // 120 x 512 B = 60 KB of LDS per wave
+int tri_solve_lds_blocks(int ncols);
+int launch_tri_solve_lds(const TriArgs &a, const double *r, double *z, const double *w, double *partials, double *scratch64,
+                         int group, hipStream_t stream);
 // z = U^{-1} d for a right-hand side the assembly pass already forward-eliminated, with the partial sums of z.z
 int launch_tri_back_dots(const TriArgs &a, const double *d, double *z, double *partials, hipStream_t stream);
 void launch_jacobi_setup(int n, const int *diag_slot, const double *val, double *invd, hipStream_t stream);

@@ -4,7 +4,7 @@
 //   saturation / relative permeability  src/mpp/util/SaturationFunction.F90:747-857 (VG), 900-990 (BC), 1027-1140 (SBC)
 //   water density                       src/mpp/util/EOSWaterMod.F90:80-99, 102-178, 181-344
 //   viscosity                           src/mpp/util/EOSWaterMod.F90:568-586
-//   porosity                            src/mpp/util/PorosityFunctionMod.F90:99-140 (constant model)
+//   porosity                            src/mpp/util/PorosityFunctionMod.F90:99-163 (constant and linear models)
 //   flux + dflux                        src/mpp/ge/RichardsMod.F90:118-340
 // Branch conditions (`pc < 0`, `p > p0`, `dphi >= 0`, seepage switch) are kept exactly; arithmetic is fp64.
 #pragma once
@@ -42,8 +42,16 @@ struct EosParams {
 struct Soil {
   double sat_res, alpha, m;        // m = vg_m (VG) or bc_lambda (BC/SBC)
   double pu, ps, b2, b3;           // SBC only
-  double por;
+  double por;                      // porosity_base
+  double por_pref, por_slope;      // POROSITY_LINEAR only (pressure_reference, lin_mod_slope)
+  int sf;                          // this cell's saturation function (kernels that dispatch per cell)
 };
+
+// PorosityFunctionComputation (src/mpp/util/PorosityFunctionMod.F90:99-163): constant model, or linear in pressure
+__host__ __device__ inline void porosity(const Soil &s, bool linear, double P, double &por, double &dpor) {
+  if (linear) { por = s.por + (P - s.por_pref) * s.por_slope; dpor = s.por_slope; }
+  else { por = s.por; dpor = 0.0; }
+}
 
 struct Aux {
   double P, kr, dkr, den, dden, sat, dsat;

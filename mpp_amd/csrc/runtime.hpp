@@ -149,6 +149,9 @@ struct Options {
   int ksp_max_it = 10000, gmres_restart = 30;
   double snes_rtol = 1e-8, snes_atol = 1e-50, snes_stol = 1e-10, snes_divtol = 1e4;  // stol: MultiPhysicsProbBaseType.F90:1112
   int snes_max_it = 50, snes_max_funcs = 10000;
+  int linesearch_type = 2;             // -snes_linesearch_type: 1 basic, 2 bt (PETSc's default for newtonls), 3 l2, 4 cp
+  bool use_dynamic_linesearch = false; // solver%use_dynamic_linesearch (src/mpp/dtypes/SolverType.F90:43): other line searches
+                                       // are tried before a time-step cut (SystemOfEquationsBaseType.F90:432-506)
   int spmv_variant = -1;   // -1 auto: pipelined wave CSR-stream for large matrices, block CSR-stream for small ones
   int assembly = -1;       // -1 auto, 0 general kernels, 1 fused column kernels
   int nseg = 0;            // column segments per thread block row (0 = auto)
@@ -165,6 +168,8 @@ struct Options {
   unsigned ilu_chain_spins = 1u << 22;   // polls (~0.4 us apart) before a chained wait gives up and the apply is redone per level
   bool ls_ahead = true;        // the line search's first reductions ride behind the Krylov solver's last update
   bool wide_xr = true;         // BiCGStab update kernel on a one-pair-per-lane grid (large vectors)
+  int tri_lds = -1;            // column solve with L^{-1} r parked in LDS between the sweeps: 0 off, 1 on, -1 auto (Solver::tri_lds)
+  int tri_group = 24;          // ... and levels kept in flight per stream and wave (8, 16, 24)
   int spmv_tpw = 0;            // > 0: 64-row tiles per wave of the compact-index SpMV (default 4 / 8 by variant)
   bool fused_predict = true;   // skip the fused Jacobian at the first trial when the previous line search backtracked
   int fused_trials = 2;        // ... for the first `fused_trials` trial points of a line search (later ones: F only)

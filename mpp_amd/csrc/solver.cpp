@@ -94,7 +94,11 @@ struct Solver {
   std::vector<double> permx, permy, permz, por, alpha, lam, sat_res;
   std::vector<int> satf;
   int sat_func = -1;
+  bool mixed_satf = false;     // cells of one mesh use different saturation functions (satParams are per cell in the reference)
   bool all_vg_half = false;
+  std::vector<double> por_pref, por_slope;   // POROSITY_LINEAR (PorosityFunctionMod.F90:75-96); empty = constant model
+  DevBuf<signed char> d_satf;
+  DevBuf<double> d_por_pref, d_por_slope;
   int density_type = MPPGPU_DENSITY_CONSTANT;  // RichODEPressureAuxVarInit default (AuxType :120)
   double temperature = 273.15 + 25.0, frac_liq = 1.0;
   bool soil_dirty = true;
@@ -146,7 +150,7 @@ struct Solver {
   DevBuf<double> soln, soln_prev, accum_prev, F, Y, W, G, R, RP, V, T, S, Pv, Wk, tmp_ext, tmp_int;
   DevBuf<double> aux_kr, aux_dkr, aux_den, aux_dden;
   DevBuf<double> tri_l, tri_invb, tri_c, jac_invd;
-  DevBuf<double> partials, sc, spmv_partials, col_partials, xr_partials;
+  DevBuf<double> partials, sc, spmv_partials, col_partials, xr_partials, tri_scratch;
   // complete-row column march (plan_complete_rows): boundary cells sit on column ends only
   bool rows_plan = false, asm_sums = false;
   struct Trial { const double *x = nullptr, *y = nullptr; double a = 0.0; } ls_point;
@@ -214,6 +218,8 @@ struct Solver {
   long long cum_newton = 0, cum_linear = 0, cum_cuts = 0, cum_funcs = 0;
   int nfuncs = 0;
   bool ls_backtracked_last = false;
+  double ls_ynorm = -1.0;         // linesearch->ynorm as the previous application left it (cp reads it at entry)
+  long long cum_ls_switches = 0;  // line searches swapped in by use_dynamic_linesearch
   bool pc_ready = false;
   std::vector<double> h_bc_value, h_ss_value;
 
@@ -349,24 +355,34 @@ struct Solver {
     permx.assign(px, px + n); permy.assign(py, py + n); permz.assign(pz, pz + n);
     soil_dirty = true;
   }
-  void set_por(const double *p) {
+  void set_por(const double *p) {   // PorosityFunctionSetConstantModel
     if (!n) throw Error("mesh not set");
     por.assign(p, p + n);
+    por_pref.clear(); por_slope.clear();
+    soil_dirty = true;
+  }
+  void set_por_linear(const double *base, const double *pref, const double *slope) {   // PorosityFunctionSetLinearModel
+    if (!n) throw Error("mesh not set");
+    if (th || thermal) throw Error("the linear porosity model is available for the VSFM only");
+    por.assign(base, base + n); por_pref.assign(pref, pref + n); por_slope.assign(slope, slope + n);
     soil_dirty = true;
   }
   void set_satfunc(const int *type, const double *a, const double *l, const double *sr) {
     if (!n) throw Error("mesh not set");
+    bool mixed = false;
     for (int i = 0; i < n; ++i) {
-      if (type[i] != type[0]) throw Error("mixed saturation-function types in one mesh are not supported");
+      if (map_sat_func(type[i]) < 0) throw Error("unsupported saturation function " + std::to_string(type[i]) + " at cell " + std::to_string(i + 1));
+      mixed |= map_sat_func(type[i]) != map_sat_func(type[0]);
       const double alpha_i = a[i], lam_i = l[i], sr_i = sr[i];
       bool bad = sr_i < 0.0 || sr_i > 0.5 || alpha_i <= 0.0 || alpha_i > 2.0 || lam_i <= 0.0;
-      if (type[0] == MPPGPU_SAT_FUNC_VAN_GENUCHTEN) bad |= lam_i >= 1.0; else bad |= lam_i >= 2.0;
+      if (type[i] == MPPGPU_SAT_FUNC_VAN_GENUCHTEN) bad |= lam_i >= 1.0; else bad |= lam_i >= 2.0;
       if (bad) throw Error("bad saturation parameters at cell " + std::to_string(i + 1));  // SatFunc_Set_* argument checks
     }
-    if (map_sat_func(type[0]) < 0) throw Error("unsupported saturation function " + std::to_string(type[0]));
+    if (mixed && th) throw Error("mixed saturation-function types are available for the VSFM only");
     satf.assign(type, type + n); alpha.assign(a, a + n); lam.assign(l, l + n); sat_res.assign(sr, sr + n);
-    sat_func = map_sat_func(type[0]);
-    all_vg_half = (sat_func == kSatVG);
+    mixed_satf = mixed;
+    sat_func = map_sat_func(type[0]);   // the mesh's function when !mixed_satf
+    all_vg_half = !mixed && (sat_func == kSatVG);
     for (int i = 0; i < n && all_vg_half; ++i) all_vg_half = (l[i] == 0.5);
     soil_dirty = true;
   }
@@ -637,8 +653,9 @@ struct Solver {
     }
     partials.alloc((size_t)kMaxPartialBlocks * kMaxMultiDot);
     {  // one partial sum per block of 256 columns (column solves, complete-row march): two vectors + the staging tail
-      const size_t nbc = ((size_t)ncols + 255) / 256;
+      const size_t nbc = ((size_t)ncols + 63) / 64;   // (the LDS column solve leaves one per 64-column tile)
       col_partials.alloc(2 * (nbc + nbc / 2048 + 1));
+      tri_scratch.alloc(64);
     }
     sc.alloc(S_COUNT); sc.zero(stream);
     HIP_CHECK(hipHostMalloc(&h_sc, S_COUNT * sizeof(double), hipHostMallocDefault));
@@ -765,11 +782,23 @@ struct Solver {
       for (int i = 0; i < n; ++i) a[i] = a[i] * vol[int2ext[i]];
       d_porvol.upload(a, stream);
     }
-    if (sat_func == kSatSBC) {
+    if (mixed_satf) {
+      std::vector<signed char> t(n);
+      for (int i = 0; i < n; ++i) t[i] = (signed char)map_sat_func(satf[int2ext[i]]);
+      d_satf.upload(t.data(), t.size(), stream);
+    } else d_satf.release();
+    if (!por_slope.empty()) {
+      for (int i = 0; i < n; ++i) { a[i] = por_pref[int2ext[i]]; b[i] = por_slope[int2ext[i]]; }
+      d_por_pref.upload(a, stream); d_por_slope.upload(b, stream);
+    } else { d_por_pref.release(); d_por_slope.release(); }
+    bool any_sbc = false;
+    for (int i = 0; i < n && !any_sbc; ++i) any_sbc = map_sat_func(satf[i]) == kSatSBC;
+    if (any_sbc) {
       // SatFunc_Set_SBC_bz2 / _bz3 (SaturationFunction.F90:260-372), ps = -0.9/alpha (:1409,1412)
-      std::vector<double> pu(n), ps(n), b2(n), b3(n);
+      std::vector<double> pu(n, 0.0), ps(n, 0.0), b2(n, 0.0), b3(n, 0.0);
       for (int i = 0; i < n; ++i) {
         const int e = int2ext[i];
+        if (map_sat_func(satf[e]) != kSatSBC) continue;
         const bool bz2 = satf[e] == MPPGPU_SAT_FUNC_SMOOTHED_BROOKS_COREY_BZ2;
         const double al = alpha[e], la = lam[e];
         const double p_s = -0.9 / al;
@@ -896,6 +925,8 @@ struct Solver {
     ca.P = P; ca.por = d_por.p; ca.sat_res = d_sat_res.p; ca.alpha = d_alpha.p; ca.m = d_m.p; ca.vol = d_vol.p;
     ca.sbc_pu = d_pu.p; ca.sbc_ps = d_ps.p; ca.sbc_b2 = d_b2.p; ca.sbc_b3 = d_b3.p;
     ca.active = any_inactive ? d_active.p : nullptr;
+    ca.satf = mixed_satf ? d_satf.p : nullptr;
+    ca.por_pref = d_por_pref.p; ca.por_slope = d_por_slope.p;
     ca.sat_func = sat_func; ca.all_vg_half = all_vg_half ? 1 : 0; ca.frac_liq = frac_liq;
     ca.frac_cell = d_frac.p;   // nullptr until VAR_FRAC_LIQ_SAT is set
     ca.eos = make_eos(density_type, temperature);
@@ -1232,6 +1263,14 @@ struct Solver {
   bool fused_pc_dots() const {
     return opt.pc_type == 2 && !th && nghost == 0;
   }
+  // the column solve that parks L^{-1} r in LDS between its sweeps (k_tri_solve_lds) instead of going through z
+  bool tri_lds() const {
+    if (nz > kTriLdsMaxLevels || nz < 2) return false;
+    if (opt.tri_lds >= 0) return opt.tri_lds != 0;
+    // auto: when a column tile's slab leaves three waves per CU (<= 53 KB) and the grid fills the chip with them several
+    // times over; measured on MI355X (profiles/r02_kbench_tri_lds.json)
+    return ncols >= (1 << 16) && nz <= 104;
+  }
   // slot: the sums land in sc[S_SUM0 + slot ..]; nreduce: how many values from sc[S_SUM0] on are all-reduced afterwards
   // (-1: just this call's; 0: none -- the caller folds them into a later all-reduce).  slot / nreduce other than the
   // defaults are for the fused path only.
@@ -1245,6 +1284,7 @@ struct Solver {
       ProfScope ps(prof, KC_PC_APPLY);
       int nbk;
       if (!w && r == fwd_rhs && pc_ready) nbk = launch_tri_back_dots(tri_args(), fwd_elim.p, z, col_partials.p, stream);
+      else if (tri_lds()) nbk = launch_tri_solve_lds(tri_args(), r, z, w, col_partials.p, tri_scratch.p, opt.tri_group, stream);
       else nbk = launch_tri_solve_dots(tri_args(), r, z, w, col_partials.p, stream);
       launch_finalize_partials_long(nbk, w ? 2 : 1, col_partials.p, sc.p + slot, stream);
     }
@@ -1686,6 +1726,125 @@ struct Solver {
     return 0;
   }
 
+  // ---- the other line searches SOEBaseStepDT_SNES can select (SystemOfEquationsBaseType.F90:432-475): PETSc v3.16.2
+  // SNESLineSearchApply_Basic / _L2 / _CP restated from the published algorithms (defaults: damping 1, steptol 1e-12,
+  // maxstep 1e8, rtol 1e-8, atol 1e-15, max_its 1, cp order linear); same statement order as the oracle's.  They always move
+  // X; l2 and cp report a failure when the step length ends at or below steptol.  X, F change by pointer exchange.
+  double trial_norm2(double *Wv, double *Gv) {   // ||F(W)||^2 the way PETSc forms it: VecNorm, then squared
+    op_residual(Wv, Gv);
+    double r2[2];
+    residual_sums(Wv, Gv, r2);
+    const double nr = std::sqrt(r2[0]);
+    return nr * nr;
+  }
+  // X <- W, F <- F(X) (evaluated again, as PETSc does), SNESLineSearchComputeNorms
+  void ls_finish(double *&X, double *&Fv, double *Yv, double *&Wv, double &fnorm, double &xnorm, double &ynorm, bool &jac_valid) {
+    std::swap(X, Wv);
+    if (opt.fused_assembly) { op_residual_jacobian(X, Fv); jac_valid = true; } else { op_residual(X, Fv); jac_valid = false; }
+    double r2[2], yy;
+    residual_sums(X, Fv, r2);
+    dots_host({{Yv, Yv}}, &yy);
+    fnorm = std::sqrt(r2[0]); xnorm = std::sqrt(r2[1]); ynorm = std::sqrt(yy);
+    ls_ynorm = ynorm;
+  }
+  int linesearch_basic(double *&X, double *&Fv, double *Yv, double *&Wv, double *&Gv, double &fnorm, double &xnorm,
+                       double &ynorm, bool &jac_valid) {
+    vec_waxpy(Wv, -1.0, Yv, X);
+    if (opt.fused_assembly) { op_residual_jacobian(Wv, Gv); jac_valid = true; } else { op_residual(Wv, Gv); jac_valid = false; }
+    double r2[2], yy;
+    residual_sums(Wv, Gv, r2);
+    dots_host({{Yv, Yv}}, &yy);
+    fnorm = std::sqrt(r2[0]); xnorm = std::sqrt(r2[1]); ynorm = std::sqrt(yy);
+    ls_ynorm = ynorm;
+    std::swap(X, Wv);
+    std::swap(Fv, Gv);
+    return 0;
+  }
+  int linesearch_l2(double *&X, double *&Fv, double *Yv, double *&Wv, double *&Gv, double &fnorm, double &xnorm,
+                    double &ynorm, bool &jac_valid) {
+    const double steptol = 1e-12;
+    double maxstep = 1e8;
+    const int max_its = 1;
+    double lambda = 1.0, lambda_old = 0.0, lambda_mid, lambda_update, delLambda;
+    double fnrm = 0.0, fnrm_old = fnorm * fnorm, fnrm_mid = 0.0, delFnrm, delFnrm_old, del2Fnrm;
+    lambda_mid = 0.5 * (lambda + lambda_old);
+    jac_valid = false;
+    for (int i = 0; i < max_its; ++i) {
+      for (;;) {
+        vec_waxpy(Wv, -lambda_mid, Yv, X);
+        fnrm_mid = trial_norm2(Wv, Gv);
+        vec_waxpy(Wv, -lambda, Yv, X);
+        fnrm = trial_norm2(Wv, Gv);
+        if (std::isfinite(fnrm)) break;
+        if (lambda <= steptol) {
+          double r2[2];
+          dots_host({{X, X}, {Yv, Yv}}, r2);
+          xnorm = std::sqrt(r2[0]); ynorm = std::sqrt(r2[1]);
+          return 1;
+        }
+        maxstep = .95 * lambda;
+        lambda = .5 * (lambda + lambda_old);
+        lambda_mid = .5 * (lambda + lambda_old);
+      }
+      delLambda = lambda - lambda_old;
+      delFnrm = (3. * fnrm - 4. * fnrm_mid + 1. * fnrm_old) / delLambda;
+      delFnrm_old = (-3. * fnrm_old + 4. * fnrm_mid - 1. * fnrm) / delLambda;
+      del2Fnrm = (delFnrm - delFnrm_old) / delLambda;
+      if (del2Fnrm > 0.) lambda_update = lambda - delFnrm / del2Fnrm;
+      else if (del2Fnrm < 0.) lambda_update = lambda + delFnrm / del2Fnrm;
+      else break;
+      if (lambda_update < steptol) lambda_update = 0.5 * (lambda + lambda_old);
+      if (!std::isfinite(lambda_update)) break;
+      if (lambda_update > maxstep) break;
+      lambda_old = lambda;
+      lambda = lambda_update;
+      fnrm_old = fnrm;
+      lambda_mid = 0.5 * (lambda + lambda_old);
+    }
+    vec_waxpy(Wv, -lambda, Yv, X);
+    ls_finish(X, Fv, Yv, Wv, fnorm, xnorm, ynorm, jac_valid);
+    return lambda <= steptol ? 1 : 0;
+  }
+  int linesearch_cp(double *&X, double *&Fv, double *Yv, double *&Wv, double *&Gv, double &fnorm, double &xnorm,
+                    double &ynorm, bool &jac_valid, int &snes_reason) {
+    const double steptol = 1e-12, maxstep = 1e8, rtol = 1e-8, atol = 1e-15;
+    const int max_its = 1;
+    double lambda = 1.0, lambda_old = 0.0, lambda_update, delLambda, fty, fty_init, fty_old, s;
+    const double ynorm_in = ls_ynorm;
+    jac_valid = false;
+    dots_host({{Fv, Yv}}, &fty_old);
+    if (std::fabs(fty_old) < atol * ynorm_in) {
+      snes_reason = 2;
+      double xx;
+      dots_host({{X, X}}, &xx);
+      xnorm = std::sqrt(xx); ynorm = ynorm_in;
+      return 0;
+    }
+    fty_init = fty_old;
+    for (int i = 0; i < max_its; ++i) {
+      vec_waxpy(Wv, -lambda, Yv, X);
+      op_residual(Wv, Gv);
+      dots_host({{Gv, Yv}}, &fty);
+      delLambda = lambda - lambda_old;
+      if (std::fabs(delLambda) < steptol * lambda) break;
+      if (std::fabs(fty) / std::fabs(fty_init) < rtol) break;
+      if (std::fabs(fty) < atol * ynorm_in && i > 0) break;
+      s = (fty - fty_old) / delLambda;
+      if (s > 0.) s = -s;
+      if (s == 0.0) break;
+      lambda_update = lambda - fty / s;
+      if (lambda_update < steptol) lambda_update = lambda + fty / s;
+      if (!std::isfinite(lambda_update)) break;
+      if (lambda_update > maxstep) break;
+      lambda_old = lambda;
+      lambda = lambda_update;
+      fty_old = fty;
+    }
+    vec_waxpy(Wv, -lambda, Yv, X);
+    ls_finish(X, Fv, Yv, Wv, fnorm, xnorm, ynorm, jac_valid);
+    return lambda <= steptol ? 1 : 0;
+  }
+
   int snes_solve(int *newton_its, int *linear_its) {
     // working pointers; `X` must end up in soln
     double *X = soln.p, *Fv = F.p, *Wv = W.p, *Gv = G.p, *Yv = Y.p;
@@ -1701,7 +1860,7 @@ struct Solver {
     for (int i = 0; !reason && i < opt.snes_max_it; ++i) {
       if (!jac_valid) op_jacobian(X, Fv);
       int its = 0;
-      ls_ahead.armed = opt.ls_ahead && ksp_one_shot && opt.ksp_type == 2 && spmv_dots_fused();
+      ls_ahead.armed = opt.ls_ahead && ksp_one_shot && opt.ksp_type == 2 && spmv_dots_fused() && opt.linesearch_type == 2;
       ls_ahead.done = false;
       ls_ahead.F = Fv; ls_ahead.X = i > 0 ? nullptr : X;
       const int kreason = ksp_solve(Fv, Yv, &its);
@@ -1709,7 +1868,15 @@ struct Solver {
       ksp_one_shot = kreason > 0 && its == 1;
       *linear_its += its;
       if (kreason < 0) { reason = -3; break; }
-      const int lsfail = linesearch_bt(X, Fv, Yv, Wv, Gv, fnorm, xnorm, ynorm, jac_valid, i > 0);
+      int lsfail, ls_reason = 0;
+      switch (opt.linesearch_type) {
+        case 1: lsfail = linesearch_basic(X, Fv, Yv, Wv, Gv, fnorm, xnorm, ynorm, jac_valid); break;
+        case 3: lsfail = linesearch_l2(X, Fv, Yv, Wv, Gv, fnorm, xnorm, ynorm, jac_valid); break;
+        case 4: lsfail = linesearch_cp(X, Fv, Yv, Wv, Gv, fnorm, xnorm, ynorm, jac_valid, ls_reason); break;
+        default: lsfail = linesearch_bt(X, Fv, Yv, Wv, Gv, fnorm, xnorm, ynorm, jac_valid, i > 0); ls_ynorm = ynorm; break;
+      }
+      if (ls_reason) { reason = ls_reason; break; }                 // if (snes->reason) break;
+      if (!std::isfinite(fnorm)) { reason = -4; break; }            // SNESCheckFunctionNorm
       if (lsfail) {
         reason = (opt.snes_stol * xnorm > ynorm) ? 4 : -6;
         break;
@@ -1777,14 +1944,20 @@ struct Solver {
   void step_dt(double dt, int *converged, int *converged_reason) {
     ensure_ready();
     const int max_num_time_cuts = 20;
-    int num_time_cuts = 0;
+    int num_time_cuts = 0, linesearch_iter = 0;
     const double target_time = dt;
     double dt_iter = dt;
+    // the line searches tried, in this order, before the time step is cut (SystemOfEquationsBaseType.F90:432-453)
+    const int ls_default = opt.linesearch_type;
+    int ls_types[3] = {ls_default, 3, 2}, max_linesearch_iter = 3;   // basic or cp: then l2, then bt
+    if (ls_default == 2 || ls_default == 3) { max_linesearch_iter = 2; ls_types[1] = ls_default == 2 ? 3 : 2; }
+    struct Restore { int &t; int v; ~Restore() { t = v; } } restore{opt.linesearch_type, ls_default};   // :539-550
     time = 0.0;
     *converged = 0;
     for (;;) {
       dtime = dt_iter;
       op_pre_solve();
+      opt.linesearch_type = ls_types[linesearch_iter];
       int nit = 0, lit = 0;
       int reason = snes_solve(&nit, &lit);
       if (comm.active()) {  // every rank must take the same branch: worst reason wins
@@ -1797,8 +1970,13 @@ struct Solver {
       }
       *converged_reason = reason;
       if (reason < 0) {
-        ++num_time_cuts; ++cum_cuts;
-        dt_iter = 0.5 * dt_iter;
+        ++linesearch_iter;
+        if (opt.use_dynamic_linesearch && linesearch_iter < max_linesearch_iter) ++cum_ls_switches;   // another line search, same dt
+        else {
+          linesearch_iter = 0;
+          ++num_time_cuts; ++cum_cuts;
+          dt_iter = 0.5 * dt_iter;
+        }
         vec_copy(soln_prev.p, soln.p);
       } else {
         *converged = 1;
@@ -2288,6 +2466,11 @@ struct Solver {
     else if (key == "snes_atol") opt.snes_atol = num();
     else if (key == "snes_stol") opt.snes_stol = num();
     else if (key == "snes_max_it") opt.snes_max_it = (int)num();
+    else if (key == "snes_linesearch_type") {
+      if (val == "basic") opt.linesearch_type = 1; else if (val == "bt") opt.linesearch_type = 2; else if (val == "l2") opt.linesearch_type = 3;
+      else if (val == "cp") opt.linesearch_type = 4;
+      else throw Error("Unknown default linesearch option '" + val + "' (basic | bt | l2 | cp)");   // SystemOfEquationsBaseType.F90:424-430
+    } else if (key == "use_dynamic_linesearch") opt.use_dynamic_linesearch = num() != 0;
     else if (key == "spmv_variant") opt.spmv_variant = (int)num();
     else if (key == "assembly") {
       if (val == "auto") opt.assembly = -1; else if (val == "general") opt.assembly = 0; else if (val == "columns") opt.assembly = 1;
@@ -2304,6 +2487,8 @@ struct Solver {
     else if (key == "ls_ahead") opt.ls_ahead = num() != 0;
     else if (key == "wide_xr") opt.wide_xr = num() != 0;
     else if (key == "spmv_tpw") opt.spmv_tpw = (int)num();
+    else if (key == "tri_lds") opt.tri_lds = (int)num();
+    else if (key == "tri_group") opt.tri_group = (int)num();
     else if (key == "defer_test0") opt.defer_test0 = num() != 0;
     else if (key == "fused_rows") opt.fused_rows = num() != 0;
     else if (key == "track_mass_exchange") opt.track_mass_exchange = num() != 0;
@@ -2509,6 +2694,11 @@ int mppgpu_set_soil_permeability(mppgpu_handle h, const double *px, const double
 int mppgpu_set_soil_porosity(mppgpu_handle h, const double *por) {
   API_BEGIN(h)
   S.set_por(por);
+  API_END()
+}
+int mppgpu_set_soil_porosity_linear(mppgpu_handle h, const double *por_base, const double *pressure_reference, const double *slope) {
+  API_BEGIN(h)
+  S.set_por_linear(por_base, pressure_reference, slope);
   API_END()
 }
 int mppgpu_set_saturation_function(mppgpu_handle h, const int *satfunc_type, const double *alpha, const double *lambda,
@@ -2749,6 +2939,13 @@ int mppgpu_bench_kernel(mppgpu_handle h, const char *name, int variant, int reps
       } else mpp::launch_spmv(variant, S.nrow, S.max_row_nnz, S.d_rowptr.p, S.d_col.p, S.d_val.p, S.soln.p, S.G.p, S.stream);
     }
     else if (k == "pc_apply") { cls = mpp::KC_PC_APPLY; S.op_pc_setup(); S.op_pc_apply(S.F.p, S.G.p); }
+    else if (k == "pc_apply_dots") {   // the column solve with its dot products; variant: -1 as configured, else tri_lds levels
+      cls = mpp::KC_PC_APPLY; S.op_pc_setup();
+      const int keep = S.opt.tri_lds;
+      if (variant >= 0) S.opt.tri_lds = variant;       // 0: sweeps through z (k_tri_solve_dots), 1: LDS
+      S.op_pc_apply_dots(S.F.p, S.G.p, S.W.p, 0, 0);
+      S.opt.tri_lds = keep;
+    }
     else if (k == "pc_setup") { cls = mpp::KC_PC_SETUP; S.pc_ready = false; S.op_pc_setup(); }
     else if (k == "residual") { cls = mpp::KC_RESIDUAL; S.op_residual(S.soln.p, S.G.p); }
     else if (k == "jacobian") { cls = mpp::KC_JACOBIAN; S.op_jacobian(S.soln.p); }
@@ -2779,7 +2976,7 @@ int mppgpu_bench_kernel(mppgpu_handle h, const char *name, int variant, int reps
   if (algorithmic_bytes) {
     const double N = S.n;
     *algorithmic_bytes = (k == "copy" || k == "dot") ? 16.0 * N : (k == "waxpy") ? 24.0 * N : (k == "bcgs_xr") ? 48.0 * N
-                         : (k == "dots3") ? 32.0 * N : (k == "assemble_both") ? 92.0 * N + 8.0 * S.nnz : S.algorithmic_bytes(cls);
+                         : (k == "dots3") ? 32.0 * N : (k == "pc_apply_dots") ? 48.0 * N : (k == "assemble_both") ? 92.0 * N + 8.0 * S.nnz : S.algorithmic_bytes(cls);
   }
   API_END()
 }

@@ -330,6 +330,13 @@ def VSFMMPPSetSoilPorosity(vsfm_mpp, igoveqn, por):
     vsfm_mpp.soe._chk(vsfm_mpp.soe.L.mppgpu_set_soil_porosity(vsfm_mpp.soe.h, pa))
 
 
+def VSFMMPPSetSoilPorosityLinearModel(vsfm_mpp, igoveqn, por_base, pressure_reference, slope):
+    """PorosityFunctionSetLinearModel for every cell (src/mpp/util/PorosityFunctionMod.F90:75-96); the reference has
+    the model but no MPP-level setter for it."""
+    a, pa = _d(por_base); b, pb = _d(pressure_reference); c, pc = _d(slope)
+    vsfm_mpp.soe._chk(vsfm_mpp.soe.L.mppgpu_set_soil_porosity_linear(vsfm_mpp.soe.h, pa, pb, pc))
+
+
 def VSFMMPPSetSaturationFunction(vsfm_mpp, igoveqn, vsfm_satfunc_type, alpha, lam, sat_res):
     t, pt = _i(vsfm_satfunc_type); a, pa = _d(alpha); l, pl = _d(lam); s, ps = _d(sat_res)
     vsfm_mpp.soe._chk(vsfm_mpp.soe.L.mppgpu_set_saturation_function(vsfm_mpp.soe.h, pt, pa, pl, ps))

@@ -34,6 +34,8 @@ class Problem:
     bcs: list = field(default_factory=list)   # [(cond_type, ConnectionSet, values)]
     sss: list = field(default_factory=list)
     lateral: object = None                    # ConnectionSet of the explicit (operator-split) lateral connections
+    por_pressure_reference: np.ndarray = None  # linear porosity model (PorosityFunctionMod.F90:75-96): por is then porosity_base
+    por_slope: np.ndarray = None
     sink_pressure: np.ndarray = None          # down-regulated sinks: over the concatenated source-sink connections
     sink_exponent: np.ndarray = None
     dt: float = 3600.0
@@ -188,7 +190,10 @@ def to_gpu(prob: Problem, options=None, device_id=0):
     mpp.AllocateAuxVars()
     mpp.SetupProblem()
     V.VSFMMPPSetSoilPermeability(mpp, 1, prob.perm[:, 0], prob.perm[:, 1], prob.perm[:, 2])
-    V.VSFMMPPSetSoilPorosity(mpp, 1, prob.por)
+    if prob.por_slope is not None:
+        V.VSFMMPPSetSoilPorosityLinearModel(mpp, 1, prob.por, prob.por_pressure_reference, prob.por_slope)
+    else:
+        V.VSFMMPPSetSoilPorosity(mpp, 1, prob.por)
     V.VSFMMPPSetSaturationFunction(mpp, 1, prob.satfunc_type, prob.alpha, prob.lam, prob.sat_res)
     V.VSFMMPPSetDensityType(mpp, 1, prob.density_type)
     for i, (_t, _cs, vals) in enumerate(prob.bcs):

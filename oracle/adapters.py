@@ -19,7 +19,10 @@ def to_oracle(prob: Problem, with_blocks=True):
     for cond_type, cs, _vals in prob.sss:
         o.add_condition(C.COND_SS, cond_type, cs)
     o.set_soil_permeability(prob.perm[:, 0], prob.perm[:, 1], prob.perm[:, 2])
-    o.set_soil_porosity(prob.por)
+    if prob.por_slope is not None:
+        o.set_soil_porosity_linear(prob.por, prob.por_pressure_reference, prob.por_slope)
+    else:
+        o.set_soil_porosity(prob.por)
     o.set_saturation_function(prob.satfunc_type, prob.alpha, prob.lam, prob.sat_res)
     o.set_density_type(prob.density_type)
     for i, (_t, _cs, vals) in enumerate(prob.bcs):

@@ -358,8 +358,14 @@ static void auxvar_compute(auxvar *a, int density_type) {
   press_to_relperm(&a->sp, a->pressure, a->frac_liq_sat, &a->kr, &a->dkr_dP);
   vo_density(a->pressure, a->temperature, density_type, &a->den, &a->dden_dP, &a->dden_dT);
   vo_viscosity(a->pressure, a->temperature, &a->vis, &a->dvis_dP, &dvis_dT);
-  a->por = a->por_base; /* PorosityFunctionComputationConstantModel */
-  a->dpor_dP = 0.0;
+  /* PorosityFunctionComputation, PorosityFunctionMod.F90:99-163 */
+  if (a->por_model == 2) { /* PorosityFunctionComputationLinearModel :144-163 */
+    a->por = a->por_base + (a->pressure - a->por_pressure_reference) * a->por_lin_mod_slope;
+    a->dpor_dP = a->por_lin_mod_slope;
+  } else { /* PorosityFunctionComputationConstantModel :126-141 */
+    a->por = a->por_base;
+    a->dpor_dP = 0.0;
+  }
 }
 
 void vo_auxvar_compute(int sat_func_type, double sat_res, double alpha, double lambda_or_m, double por_base,
@@ -508,6 +514,7 @@ vo_problem *vo_create(int ncells) {
   p->ksp_rtol = 1e-5; p->ksp_atol = 1e-50; p->ksp_dtol = 1e4; p->ksp_max_it = 10000; p->gmres_restart = 30;
   p->snes_rtol = 1e-8; p->snes_atol = 1e-50; p->snes_stol = 1e-10; p->snes_divtol = 1e4;
   p->snes_max_it = 50; p->snes_max_funcs = 10000;
+  p->linesearch_type = 2; p->use_dynamic_linesearch = 0; p->ls_ynorm = -1.0;
   return p;
 }
 
@@ -710,7 +717,9 @@ static void copy_soil_to_conditions(vo_problem *p) {
   for (int b = 0; b < p->nbc; b++)
     for (int i = 0; i < p->bc[b].n; i++) {
       auxvar *a = &p->bc[b].aux[i]; const auxvar *s = &p->aux[p->bc[b].id_dn[i]];
-      memcpy(a->perm, s->perm, sizeof a->perm); a->por_base = s->por_base; a->sp = s->sp;
+      memcpy(a->perm, s->perm, sizeof a->perm); a->sp = s->sp;
+      a->por_model = s->por_model; a->por_base = s->por_base;
+      a->por_pressure_reference = s->por_pressure_reference; a->por_lin_mod_slope = s->por_lin_mod_slope;
     }
 }
 
@@ -719,8 +728,18 @@ int vo_set_soil_permeability(vo_problem *p, const double *px, const double *py, 
   copy_soil_to_conditions(p);
   return 0;
 }
-int vo_set_soil_porosity(vo_problem *p, const double *por) {
-  for (int i = 0; i < p->n; i++) p->aux[i].por_base = por[i];
+int vo_set_soil_porosity(vo_problem *p, const double *por) { /* PorosityFunctionSetConstantModel :57-72 */
+  for (int i = 0; i < p->n; i++) { p->aux[i].por_model = 1; p->aux[i].por_base = por[i]; }
+  copy_soil_to_conditions(p);
+  return 0;
+}
+/* PorosityFunctionSetLinearModel (PorosityFunctionMod.F90:75-96) for every cell; no MPP driver calls it (the porParams of
+ * an auxvar are reachable through the auxvar only), so this entry point has no MPP-level counterpart */
+int vo_set_soil_porosity_linear(vo_problem *p, const double *por_base, const double *press_ref, const double *slope) {
+  for (int i = 0; i < p->n; i++) {
+    p->aux[i].por_model = 2; p->aux[i].por_base = por_base[i];
+    p->aux[i].por_pressure_reference = press_ref[i]; p->aux[i].por_lin_mod_slope = slope[i];
+  }
   copy_soil_to_conditions(p);
   return 0;
 }
@@ -1389,6 +1408,122 @@ static int linesearch_bt(vo_problem *p, double *X, double *F, double *Y, double 
   return 0;
 }
 
+/* The other line searches SOEBaseStepDT_SNES can select (SystemOfEquationsBaseType.F90:432-475): PETSc v3.16.2
+ * src/snes/linesearch/impls/{basic,l2,cp}; third-party, restated from the published algorithms.  Defaults of
+ * SNESLineSearchCreate: damping (initial lambda) 1, steptol 1e-12, maxstep 1e8, rtol 1e-8, atol 1e-15, max_its 1 (l2, cp),
+ * cp order linear.  All of them always move X (no sufficient-decrease test); l2 and cp report FAILED_REDUCT when the step
+ * length ends at or below steptol.  No reference fixture exercises them: "parity unpinned by the reference".
+ * Return value: 0 ok, 1 failed (the caller then applies newtonls' stol / maxFailures logic). */
+static void ls_axpy(int n, double *W, const double *X, double lambda, const double *Y) {
+  for (int i = 0; i < n; i++) W[i] = X[i] - lambda * Y[i];   /* VecCopy(X,W); VecAXPY(W,-lambda,Y) */
+}
+static void ls_finish(vo_problem *p, double *X, double *F, const double *Y, const double *W, double *fnorm_io,
+                      double *xnorm_o, double *ynorm_o) {
+  /* VecCopy(W,X); snesfunc(X,F); SNESLineSearchComputeNorms: ||X||, ||F||, ||Y|| (Y unscaled) */
+  int n = p->n;
+  memcpy(X, W, n * sizeof(double));
+  p->residual_fn(p, X, F);
+  *xnorm_o = vnorm(n, X); *fnorm_io = vnorm(n, F); *ynorm_o = vnorm(n, Y);
+  p->ls_ynorm = *ynorm_o;
+}
+/* SNESLineSearchApply_Basic: X <- X - lambda Y with the damping lambda = 1 */
+static int linesearch_basic(vo_problem *p, double *X, double *F, double *Y, double *W, double *G, double *fnorm_io,
+                            double *xnorm_o, double *ynorm_o) {
+  int n = p->n;
+  ls_axpy(n, W, X, 1.0, Y);
+  p->residual_fn(p, W, G);
+  *fnorm_io = vnorm(n, G); *ynorm_o = vnorm(n, Y); *xnorm_o = vnorm(n, W);
+  p->ls_ynorm = *ynorm_o;
+  memcpy(X, W, n * sizeof(double));
+  memcpy(F, G, n * sizeof(double));
+  return 0;
+}
+/* SNESLineSearchApply_L2: secant iteration on ||F(X - lambda Y)||^2 through the points lambda_old, lambda_mid, lambda */
+static int linesearch_l2(vo_problem *p, double *X, double *F, double *Y, double *W, double *G, double *fnorm_io,
+                         double *xnorm_o, double *ynorm_o) {
+  (void)G;
+  const double steptol = 1e-12;
+  double maxstep = 1e8;
+  const int max_its = 1;
+  int n = p->n;
+  double lambda = 1.0, lambda_old = 0.0, lambda_mid, lambda_update, delLambda;
+  double fnrm = 0.0, fnrm_old = (*fnorm_io) * (*fnorm_io), fnrm_mid = 0.0, delFnrm, delFnrm_old, del2Fnrm;
+  lambda_mid = 0.5 * (lambda + lambda_old);
+  for (int i = 0; i < max_its; i++) {
+    for (;;) {
+      ls_axpy(n, W, X, lambda_mid, Y);
+      p->residual_fn(p, W, F);
+      fnrm_mid = vnorm(n, F);
+      ls_axpy(n, W, X, lambda, Y);
+      p->residual_fn(p, W, F);
+      fnrm = vnorm(n, F);
+      fnrm_mid = fnrm_mid * fnrm_mid;
+      fnrm = fnrm * fnrm;
+      if (isfinite(fnrm)) break;
+      if (lambda <= steptol) {   /* FAILED_REDUCT; X unchanged, F holds the last trial's residual as in PETSc */
+        *xnorm_o = vnorm(n, X); *ynorm_o = vnorm(n, Y);
+        return 1;
+      }
+      maxstep = .95 * lambda;
+      lambda = .5 * (lambda + lambda_old);
+      lambda_mid = .5 * (lambda + lambda_old);
+    }
+    delLambda = lambda - lambda_old;
+    delFnrm = (3. * fnrm - 4. * fnrm_mid + 1. * fnrm_old) / delLambda;
+    delFnrm_old = (-3. * fnrm_old + 4. * fnrm_mid - 1. * fnrm) / delLambda;
+    del2Fnrm = (delFnrm - delFnrm_old) / delLambda;
+    if (del2Fnrm > 0.) lambda_update = lambda - delFnrm / del2Fnrm;
+    else if (del2Fnrm < 0.) lambda_update = lambda + delFnrm / del2Fnrm;
+    else break;
+    if (lambda_update < steptol) lambda_update = 0.5 * (lambda + lambda_old);
+    if (!isfinite(lambda_update)) break;
+    if (lambda_update > maxstep) break;
+    lambda_old = lambda;
+    lambda = lambda_update;
+    fnrm_old = fnrm;
+    lambda_mid = 0.5 * (lambda + lambda_old);
+  }
+  ls_axpy(n, W, X, lambda, Y);
+  ls_finish(p, X, F, Y, W, fnorm_io, xnorm_o, ynorm_o);
+  return lambda <= steptol ? 1 : 0;
+}
+/* SNESLineSearchApply_CP: secant iteration on F(X - lambda Y) . Y (order linear); *snes_reason receives
+ * CONVERGED_FNORM_ABS (2) when |F.Y| < atol * ynorm at entry (ynorm: the previous application's) */
+static int linesearch_cp(vo_problem *p, double *X, double *F, double *Y, double *W, double *G, double *fnorm_io,
+                         double *xnorm_o, double *ynorm_o, int *snes_reason) {
+  (void)G;
+  const double steptol = 1e-12, maxstep = 1e8, rtol = 1e-8, atol = 1e-15;
+  const int max_its = 1;
+  int n = p->n;
+  double lambda = 1.0, lambda_old = 0.0, lambda_update, delLambda, fty, fty_init, fty_old, s;
+  const double ynorm_in = p->ls_ynorm;
+  fty_old = vdot(n, F, Y);
+  if (fabs(fty_old) < atol * ynorm_in) { *snes_reason = 2; *xnorm_o = vnorm(n, X); *ynorm_o = ynorm_in; return 0; }
+  fty_init = fty_old;
+  for (int i = 0; i < max_its; i++) {
+    ls_axpy(n, W, X, lambda, Y);
+    p->residual_fn(p, W, F);
+    fty = vdot(n, F, Y);
+    delLambda = lambda - lambda_old;
+    if (fabs(delLambda) < steptol * lambda) break;
+    if (fabs(fty) / fabs(fty_init) < rtol) break;
+    if (fabs(fty) < atol * ynorm_in && i > 0) break;
+    s = (fty - fty_old) / delLambda;
+    if (s > 0.) s = -s;
+    if (s == 0.0) break;
+    lambda_update = lambda - fty / s;
+    if (lambda_update < steptol) lambda_update = lambda + fty / s;
+    if (!isfinite(lambda_update)) break;
+    if (lambda_update > maxstep) break;
+    lambda_old = lambda;
+    lambda = lambda_update;
+    fty_old = fty;
+  }
+  ls_axpy(n, W, X, lambda, Y);
+  ls_finish(p, X, F, Y, W, fnorm_io, xnorm_o, ynorm_o);
+  return lambda <= steptol ? 1 : 0;
+}
+
 /* SNESSolve_NEWTONLS; returns SNESConvergedReason */
 static int snes_solve(vo_problem *p, double *X, int *newton_its, int *linear_its) {
   int n = p->n, reason = 0;
@@ -1407,7 +1542,15 @@ static int snes_solve(vo_problem *p, double *X, int *newton_its, int *linear_its
     int kreason = ksp_solve(p, p->ksp_type, p->pc_type, p->ksp_rtol, p->rowptr, p->col, p->val, F, Y, &its);
     *linear_its += its;
     if (kreason < 0) { reason = -3; break; } /* DIVERGED_LINEAR_SOLVE (maxLinearSolveFailures = 1) */
-    int lsfail = linesearch_bt(p, X, F, Y, W, G, &fnorm, &xnorm, &ynorm);
+    int lsfail, ls_reason = 0;
+    switch (p->linesearch_type) {
+      case 1: lsfail = linesearch_basic(p, X, F, Y, W, G, &fnorm, &xnorm, &ynorm); break;
+      case 3: lsfail = linesearch_l2(p, X, F, Y, W, G, &fnorm, &xnorm, &ynorm); break;
+      case 4: lsfail = linesearch_cp(p, X, F, Y, W, G, &fnorm, &xnorm, &ynorm, &ls_reason); break;
+      default: lsfail = linesearch_bt(p, X, F, Y, W, G, &fnorm, &xnorm, &ynorm); p->ls_ynorm = ynorm; break;
+    }
+    if (ls_reason) { reason = ls_reason; break; }              /* if (snes->reason) break; */
+    if (!isfinite(fnorm)) { reason = -4; break; }              /* SNESCheckFunctionNorm */
     if (lsfail) {
       if (p->snes_stol * xnorm > ynorm) { reason = 4; break; }
       reason = -6; break; /* DIVERGED_LINE_SEARCH (maxFailures = 1) */
@@ -1420,24 +1563,41 @@ static int snes_solve(vo_problem *p, double *X, int *newton_its, int *linear_its
   return reason;
 }
 
-/* SOEBaseStepDT_SNES (SystemOfEquationsBaseType.F90:368-552) with VSFMSOEPreSolve/PostSolve; default bt line search only */
+/* SOEBaseStepDT_SNES (SystemOfEquationsBaseType.F90:368-552) with VSFMSOEPreSolve/PostSolve, including the list of line
+ * searches tried before a time-step cut when solver%use_dynamic_linesearch is set (:432-453, 462-475, 486-506, 539-550) */
 int vo_step_dt(vo_problem *p, double dt, int nstep, int *converged, int *converged_reason) {
   (void)nstep;
   if (!p->rowptr) FAIL("connections not set");
   const int max_num_time_cuts = 20;
-  int num_time_cuts = 0;
+  int num_time_cuts = 0, linesearch_iter = 0;
   double target_time = dt, dt_iter = dt;
+  const int ls_default = p->linesearch_type;
+  int types[3], max_linesearch_iter;
+  if (ls_default == 2 || ls_default == 3) {   /* bt or l2: the other one is the alternative */
+    max_linesearch_iter = 2;
+    types[0] = ls_default; types[1] = ls_default == 2 ? 3 : 2; types[2] = 0;
+  } else {                                    /* basic or cp: then l2, then bt */
+    max_linesearch_iter = 3;
+    types[0] = ls_default; types[1] = 3; types[2] = 2;
+  }
   p->time = 0.0;
   *converged = 0;
   for (;;) {
     vo_set_dtime(p, dt_iter);
     vo_pre_solve(p);
+    p->linesearch_type = types[linesearch_iter];
     int nit, lit;
     int reason = snes_solve(p, p->soln, &nit, &lit);
     *converged_reason = reason;
     if (reason < 0) {
-      num_time_cuts++; p->cum_cuts++;
-      dt_iter = 0.5 * dt_iter;
+      linesearch_iter++;
+      if (p->use_dynamic_linesearch && linesearch_iter < max_linesearch_iter) {
+        p->cum_linesearch_switches++;         /* try another line search at the same dt */
+      } else {
+        linesearch_iter = 0;
+        num_time_cuts++; p->cum_cuts++;
+        dt_iter = 0.5 * dt_iter;
+      }
       memcpy(p->soln, p->soln_prev, p->n * sizeof(double));
     } else {
       *converged = 1;
@@ -1453,11 +1613,19 @@ int vo_step_dt(vo_problem *p, double dt, int nstep, int *converged, int *converg
       for (int b = 0; b < p->nbc; b++)
         for (int i = 0; i < p->bc[b].n; i++) p->bc[b].mass_exc[i] = p->bc[b].mass_exc[i] + p->bc[b].flux[i] * p->dtime;
     }
-    if (num_time_cuts > max_num_time_cuts) { *converged = 0; return 0; }
+    if (num_time_cuts > max_num_time_cuts) { *converged = 0; p->linesearch_type = ls_default; return 0; }
     if (p->time >= target_time) break;
   }
+  p->linesearch_type = ls_default;   /* "Set the linsearch type to be the default setting" :539-550 */
   return 0;
 }
+/* -snes_linesearch_type basic|bt|l2|cp (1..4) and solver%use_dynamic_linesearch */
+int vo_set_linesearch(vo_problem *p, int type, int use_dynamic) {
+  if (type < 1 || type > 4) FAIL("Unknown default linesearch option");
+  p->linesearch_type = type; p->use_dynamic_linesearch = use_dynamic != 0;
+  return 0;
+}
+long long vo_linesearch_switches(const vo_problem *p) { return p->cum_linesearch_switches; }
 
 /* VSFMSOEGetDataForCLM after RichardsODEPressureSetDataInSOEAuxVar (GE:1170-1195); auxvars as of the last residual */
 int vo_get(vo_problem *p, int auxvar_type, int var_type, int cond_id, int n, double *out) {

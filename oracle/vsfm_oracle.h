@@ -80,6 +80,7 @@ int vo_add_condition(vo_problem *p, int kind /* COND_BC|COND_SS */, int cond_typ
                      int swap_order);
 int vo_set_soil_permeability(vo_problem *p, const double *perm_x, const double *perm_y, const double *perm_z);
 int vo_set_soil_porosity(vo_problem *p, const double *por);
+int vo_set_soil_porosity_linear(vo_problem *p, const double *por_base, const double *press_ref, const double *slope);
 int vo_set_saturation_function(vo_problem *p, const int *satfunc_type, const double *alpha,
                                const double *lambda, const double *sat_res);
 int vo_set_density_type(vo_problem *p, int density_type);
@@ -104,6 +105,9 @@ int vo_post_step_dt(vo_problem *p);
 int vo_set_frac_liq_sat(vo_problem *p, const double *frac);
 /* column blocks for PC bjacobi: block b holds cells block_cells[block_ptr[b]..block_ptr[b+1]) (1-based ids, bottom->top) */
 int vo_set_blocks(vo_problem *p, int nblocks, const int *block_ptr, const int *block_cells);
+/* -snes_linesearch_type: 1 basic, 2 bt (default), 3 l2, 4 cp; use_dynamic: solver%use_dynamic_linesearch */
+int vo_set_linesearch(vo_problem *p, int type, int use_dynamic);
+long long vo_linesearch_switches(const vo_problem *p);
 int vo_set_solver(vo_problem *p, int ksp_type, int pc_type, double ksp_rtol, double snes_rtol,
                   double snes_atol, double snes_stol, int snes_max_it);
 void vo_set_num_threads(int n);

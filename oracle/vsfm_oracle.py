@@ -52,8 +52,8 @@ def lib():
         L.vo_create.argtypes = [ct.c_int]
         L.vo_last_error.restype = ct.c_char_p
         for name in ("vo_destroy", "vo_set_mesh", "vo_set_connections", "vo_add_condition", "vo_set_soil_permeability",
-                     "vo_set_soil_porosity", "vo_set_saturation_function", "vo_set_density_type",
-                     "vo_set_condition_values", "vo_set_source_sink_auxvar", "vo_set_lateral_connections", "vo_get_condition_values", "vo_pre_step_dt", "vo_post_step_dt", "vo_set_frac_liq_sat", "vo_restart", "vo_set_blocks", "vo_set_solver", "vo_set_dtime",
+                     "vo_set_soil_porosity", "vo_set_soil_porosity_linear", "vo_set_saturation_function", "vo_set_density_type",
+                     "vo_set_condition_values", "vo_set_source_sink_auxvar", "vo_set_lateral_connections", "vo_get_condition_values", "vo_pre_step_dt", "vo_post_step_dt", "vo_set_frac_liq_sat", "vo_restart", "vo_set_blocks", "vo_set_solver", "vo_set_linesearch", "vo_set_dtime",
                      "vo_pre_solve", "vo_residual", "vo_jacobian_nnz", "vo_jacobian", "vo_pc_setup_apply",
                      "vo_ksp_solve", "vo_step_dt", "vo_get", "vo_get_counters"):
             getattr(L, name).argtypes = None
@@ -68,6 +68,8 @@ def lib():
                                         ct.c_double, ct.c_double, ct.c_double, _dp]
         L.vo_richards_flux.argtypes = [_dp, _dp, _dp, _dp, ct.c_double, ct.c_double, ct.c_double, _dp, ct.c_int,
                                        ct.c_int, ct.c_int, _dp, _dp, _dp]
+        L.vo_linesearch_switches.restype = ct.c_longlong
+        L.vo_linesearch_switches.argtypes = [ct.c_void_p]
         L.vo_set_num_threads.argtypes = [ct.c_int]
         L.vo_set_num_threads(1)
         _lib = L
@@ -161,6 +163,10 @@ class OracleProblem:
         a, pa = _d(por)
         _chk(self.L.vo_set_soil_porosity(self.h, pa))
 
+    def set_soil_porosity_linear(self, por_base, press_ref, slope):
+        a, pa = _d(por_base); b, pb = _d(press_ref); c, pc = _d(slope)
+        _chk(self.L.vo_set_soil_porosity_linear(self.h, pa, pb, pc))
+
     def set_saturation_function(self, satfunc_type, alpha, lam, sat_res):
         t, pt = _i(np.broadcast_to(satfunc_type, (self.n,)))
         a, pa = _d(np.broadcast_to(alpha, (self.n,))); l, pl = _d(np.broadcast_to(lam, (self.n,)))
@@ -213,6 +219,14 @@ class OracleProblem:
         _chk(self.L.vo_set_solver(self.h, ksp_type, pc_type, ksp_rtol, snes_rtol, snes_atol, snes_stol, snes_max_it))
 
     # operator level
+    LINESEARCH = {"basic": 1, "bt": 2, "l2": 3, "cp": 4}
+
+    def set_linesearch(self, name="bt", use_dynamic=False):
+        _chk(self.L.vo_set_linesearch(self.h, self.LINESEARCH[name], int(bool(use_dynamic))))
+
+    def linesearch_switches(self):
+        return int(self.L.vo_linesearch_switches(self.h))
+
     def set_dtime(self, dt):
         _chk(self.L.vo_set_dtime(self.h, float(dt)))
 

@@ -24,7 +24,9 @@ typedef struct {
   /* state + parameters (RichardsODEPressureAuxType.F90:18-60) */
   double pressure, temperature, frac_liq_sat, condition_value;
   double perm[3];
-  double por_base;   /* constant porosity model only (PorosityFunctionMod.F90:99-140) */
+  /* porosity_params_type (PorosityFunctionMod.F90:18-29): POROSITY_CONSTANT (1) or POROSITY_LINEAR (2) */
+  int por_model;
+  double por_base, por_pressure_reference, por_lin_mod_slope;
   satparams sp;
   /* derived */
   double vis, kr, sat, den, por;
@@ -80,6 +82,10 @@ struct vo_problem {
   /* counters (SolverType.F90:40-41,140-169) */
   long cum_newton, cum_linear, cum_cuts, cum_funcs;
   int nfuncs;
+  /* SNESLineSearch: 1 basic, 2 bt (PETSc's default for newtonls), 3 l2, 4 cp; solver%use_dynamic_linesearch (SolverType.F90:43) */
+  int linesearch_type, use_dynamic_linesearch;
+  double ls_ynorm;   /* linesearch->ynorm as the previous application left it (cp reads it before computing its own) */
+  long long cum_linesearch_switches;
   /* the nonlinear system SNES solves: VSFM by default; th_oracle.c installs the coupled TH system */
   int (*residual_fn)(vo_problem *p, const double *x, double *f);
   void (*jacobian_fn)(vo_problem *p); /* at the state of the last residual evaluation, into rowptr/col/val */

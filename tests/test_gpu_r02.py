@@ -1,0 +1,209 @@
+"""GPU tests of the round-2 kernels and failure paths, through the C ABI:
+  * the column solve that parks L^{-1} r in LDS (k_tri_solve_lds) against dense algebra, the oracle and the through-memory
+    solve, on ragged tiles and column heights from 2 to 120 levels;
+  * a chained ILU(0) application whose dependency waits time out is redone with per-level launches (same answer);
+  * a failure on one rank of an in-process group ends every rank with an error instead of blocking the others;
+  * the benchmark's own workload (heterogeneous celia-extruded columns) against per-column oracle solves.
+"""
+import threading
+
+import numpy as np
+import pytest
+
+import problems as P
+from mpp_amd import constants as C
+from test_gpu_parity import _dense, _hetero, _operator_parity
+from test_oracle_operators import _mixed_soil_problem
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("ncols,nz", [(1, 2), (63, 5), (64, 23), (70, 24), (130, 100), (65, 120), (200, 47)])
+@pytest.mark.parametrize("group", [8, 16, 24])
+def test_lds_column_solve_against_dense_algebra(ncols, nz, group):
+    """M^{-1} through k_tri_solve_lds inside BiCGStab / GMRES: the block-Jacobi solve of a vertical-only grid is exact, so one
+    Krylov iteration must return the dense solution; ring sizes 2x4 .. 6x4 levels against every column height"""
+    prob, x = _hetero(ncols=ncols, nz=nz, seed=5)
+    opts = {"assembly": "columns", "pc_type": "bjacobi", "ksp_type": "bcgs", "tri_lds": 1, "tri_group": group}
+    o, g, (rp, cj, val), v = _operator_parity(prob, x, opts)
+    exact = np.linalg.solve(_dense(rp, cj, val, v.size), v) if v.size <= 4000 else None
+    for ksp in ("bcgs", "gmres"):
+        g.soe.SetOption("ksp_type", ksp)
+        xs_lds, its, reason = g.soe.KSPSolve(v)
+        assert reason > 0 and its <= 2
+        g.soe.SetOption("tri_lds", 0)
+        xs_mem, its2, reason2 = g.soe.KSPSolve(v)
+        g.soe.SetOption("tri_lds", 1)
+        assert (its, reason) == (its2, reason2)
+        # same arithmetic per column; only the order in which the dot products are summed differs
+        assert np.abs(xs_lds - xs_mem).max() <= 1e-12 * np.abs(xs_mem).max()
+        if exact is not None:
+            assert np.abs(xs_lds - exact).max() <= 1e-8 * np.abs(exact).max()
+
+
+def test_lds_column_solve_steps_agree_with_the_oracle():
+    prob = P.celia1990(ncols=70, nz=40, perm_mult=np.exp(0.4 * np.random.default_rng(5).standard_normal(70)))
+    base = {"assembly": "columns", "nseg": 1, "ksp_type": "bcgs", "pc_type": "bjacobi", "spmv_variant": 20}
+    on, off = P.to_gpu(prob, dict(base, tri_lds=1)), P.to_gpu(prob, dict(base, tri_lds=0))
+    o = P.to_oracle(prob)
+    o.set_solver(C.KSP_BCGS, C.PC_BJACOBI)
+    for s in range(3):
+        r_on, r_off, r_o = on.soe.StepDT(prob.dt, s + 1), off.soe.StepDT(prob.dt, s + 1), o.step_dt(prob.dt, s + 1)
+        assert r_on == r_off == tuple(r_o)
+    assert on.soe.counters() == off.soe.counters()
+    assert on.soe.counters()["newton"] == o.counters()["newton"]
+    p_on = on.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1)
+    p_off = off.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1)
+    assert np.abs(p_on - p_off).max() <= 1e-10 * np.abs(p_off).max()
+    assert np.abs(p_on - o.get(C.AUXVAR_INTERNAL, C.VAR_PRESSURE)).max() <= 1e-8 * np.abs(p_off).max()
+
+
+def test_chained_ilu_timeout_is_redone_with_level_launches():
+    """spin budget 0: every dependency wait of the chained triangular solves gives up at once, the application is redone
+    per level on the spot and the step's answer is the one of the per-level solve; the fallback is counted"""
+    tp = P.thermal_mms(3, 12, 10, 9, replicate_reference_soil_indexing=False)
+    ref = P.to_thermal_gpu(tp, {"ksp_type": "gmres", "pc_type": "ilu", "ilu_chain": 0})
+    bad = P.to_thermal_gpu(tp, {"ksp_type": "gmres", "pc_type": "ilu", "ilu_chain": 2, "ilu_chain_spins": 0})
+    ok = P.to_thermal_gpu(tp, {"ksp_type": "gmres", "pc_type": "ilu", "ilu_chain": 2})
+    for g in (ref, bad, ok):
+        conv, _ = g.soe.StepDT(tp.dt, 1)
+        assert conv
+    assert bad.soe.comm_stats()["chain_fallbacks"] == 1        # the first application; the chain is off afterwards
+    assert ok.soe.comm_stats()["chain_fallbacks"] == 0 and ref.soe.comm_stats()["chain_fallbacks"] == 0
+    assert bad.soe.last_linear_iterations == ref.soe.last_linear_iterations == ok.soe.last_linear_iterations
+    assert np.array_equal(bad.soe.GetSoln(), ref.soe.GetSoln())
+    assert np.array_equal(ok.soe.GetSoln(), ref.soe.GetSoln())
+
+
+def test_failure_on_one_rank_ends_every_rank_of_an_in_process_group():
+    """rank 1 fails at its third scalar read-back (injected); ranks 0 and 2 are, or soon will be, waiting for it in a
+    reduction: all three calls must return with an error, none may block"""
+    from mpp_amd import parallel as PAR
+    from mpp_amd import vsfm as V
+    ncols, nz, nranks = 150, 20, 3
+    mult = np.exp(0.5 * np.random.default_rng(11).standard_normal(ncols))
+    shards = []
+    for r in range(nranks):
+        c0, nloc = PAR.shard_columns(ncols, nranks, r)
+        prob = P.celia1990(ncols=nloc, nz=nz, perm_mult=mult[c0:c0 + nloc])
+        shards.append((prob, P.to_gpu(prob, {"ksp_type": "bcgs", "pc_type": "bjacobi"})))
+    V.comm_init_local([g.soe for _p, g in shards])
+    shards[1][1].soe.SetOption("debug_fail_at_fetch", 3)
+    errors = [None] * nranks
+
+    def run(r):
+        prob, g = shards[r]
+        try:
+            g.soe.StepDT(prob.dt, 1)
+        except V.MPPError as e:
+            errors[r] = str(e)
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(nranks)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert all(not t.is_alive() for t in th), "a rank is still blocked"
+    assert "injected failure" in errors[1]
+    assert errors[0] and "another rank failed" in errors[0]
+    assert errors[2] and "another rank failed" in errors[2]
+
+
+def test_gmres_restart_is_validated():
+    from mpp_amd import vsfm as V
+    prob = P.celia1990(ncols=3, nz=10)
+    g = P.to_gpu(prob, {"ksp_type": "gmres"})
+    for bad in (0, -3, 32, 200):
+        with pytest.raises(V.MPPError, match="ksp_gmres_restart"):
+            g.soe.SetOption("ksp_gmres_restart", bad)
+    g.soe.SetOption("ksp_gmres_restart", 5)
+    assert g.soe.StepDT(prob.dt, 1)[0]
+
+
+@pytest.mark.parametrize("nx,ny,nz,steps", [(64, 48, 100, 3), (1024, 1024, 100, 2)], ids=["3072_columns", "bench_workload"])
+def test_bench_workload_answer_against_per_column_oracle_solves(nx, ny, nz, steps):
+    """bench.py's workload -- heterogeneous celia-extruded columns, BiCGStab + block-Jacobi, default tolerances -- with
+    sampled columns compared with the CPU oracle solving each of them alone at tight tolerances.  What separates the two is
+    the Newton truncation of the global solve (rtol 1e-8 on the global norm): stated tolerance 1e-6 relative on pressure."""
+    import bench
+    ncols = nx * ny
+    prob = bench.build_problem(ncols, nz, 0, ncols)
+    g = P.to_gpu(prob, {"ksp_type": "bcgs", "pc_type": "bjacobi"})
+    for s in range(steps):
+        conv, reason = g.soe.StepDT(prob.dt, s + 1)
+        assert conv and reason > 0
+    p = g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1)
+    chk = bench.verify_answer(p, ncols, nz, 0, ncols, steps, True, nsample=64)
+    assert chk["columns_checked"] == 64
+    assert chk["max_rel_err"] <= 1e-6, chk
+
+
+@pytest.mark.parametrize("linear_porosity,mixed", [(True, False), (False, True), (True, True)], ids=["linear_por", "mixed_sat", "both"])
+@pytest.mark.parametrize("route", [{"assembly": "general"}, {"assembly": "columns", "nseg": 1}, {"assembly": "columns", "nseg": 3},
+                                   {"assembly": "columns", "nseg": 1, "fused_rows": 0}],
+                         ids=["general", "march_complete_rows", "march_segments", "march_plain"])
+def test_linear_porosity_and_mixed_saturation_functions(route, linear_porosity, mixed):
+    """a5 / a3': PorosityFunctionMod.F90:144-163 in the accumulation term and its derivative (GE:1603-1693), and cells of
+    one mesh with different saturation functions (SaturationFunction.F90:564-650), on every assembly route: operators
+    against the oracle, then two time steps with the oracle's Newton counts"""
+    prob, x = _mixed_soil_problem(ncols=70, nz=19, seed=9, linear_porosity=linear_porosity, mixed=mixed)
+    opts = dict({"ksp_type": "bcgs", "pc_type": "bjacobi"}, **route)
+    o, g, _csr, _v = _operator_parity(prob, x, opts)
+    mass_o, mass_g = o.get(C.AUXVAR_INTERNAL, C.VAR_MASS), g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_MASS, -1)
+    assert np.abs(mass_g - mass_o).max() <= 1e-12 * np.abs(mass_o).max()
+    o.set_solver(C.KSP_BCGS, C.PC_BJACOBI)
+    for s in range(2):
+        assert g.soe.StepDT(prob.dt, s + 1) == tuple(o.step_dt(prob.dt, s + 1))
+    assert g.soe.counters()["newton"] == o.counters()["newton"]
+    np.testing.assert_allclose(g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1),
+                               o.get(C.AUXVAR_INTERNAL, C.VAR_PRESSURE), rtol=1e-8)
+
+
+def test_linear_porosity_is_refused_where_it_is_not_built():
+    from mpp_amd import vsfm as V
+    tp = P.th_columns(ncols=2, nz=6)
+    g = P.to_th_gpu(tp)
+    n = tp.mesh.ncells_local
+    with pytest.raises(V.MPPError, match="VSFM only"):
+        V.VSFMMPPSetSoilPorosityLinearModel(g, 1, np.full(n, 0.4), np.full(n, 101325.0), np.full(n, 1e-7))
+
+
+@pytest.mark.parametrize("ls", ["basic", "l2", "cp", "bt"])
+@pytest.mark.parametrize("route", [{"assembly": "columns", "nseg": 1, "spmv_variant": 20}, {"assembly": "general"}],
+                         ids=["march", "general"])
+def test_other_line_searches_follow_the_oracle(ls, route):
+    """a13: -snes_linesearch_type basic | l2 | cp (PETSc v3.16.2, restated) on the GPU driver: same accept / reject decisions,
+    time-step cuts and Newton counts as the oracle over three celia steps, pressures equal to Newton tolerance"""
+    prob = P.celia1990(ncols=70, nz=40, perm_mult=np.exp(0.4 * np.random.default_rng(5).standard_normal(70)))
+    g = P.to_gpu(prob, dict({"ksp_type": "bcgs", "pc_type": "bjacobi", "snes_linesearch_type": ls}, **route))
+    o = P.to_oracle(prob)
+    o.set_solver(C.KSP_BCGS, C.PC_BJACOBI)
+    o.set_linesearch(ls)
+    for s in range(3):
+        assert g.soe.StepDT(prob.dt, s + 1) == tuple(o.step_dt(prob.dt, s + 1))
+    cg, co = g.soe.counters(), o.counters()
+    assert (cg["newton"], cg["time_cuts"], cg["func_evals"]) == (co["newton"], co["time_cuts"], co["func_evals"])
+    np.testing.assert_allclose(g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1),
+                               o.get(C.AUXVAR_INTERNAL, C.VAR_PRESSURE), rtol=1e-8)
+
+
+@pytest.mark.parametrize("ls", ["bt", "basic", "cp", "l2"])
+def test_dynamic_linesearch_sequence_before_a_time_step_cut(ls):
+    """solver%use_dynamic_linesearch (SystemOfEquationsBaseType.F90:432-506): a day-long step with six Newton iterations
+    allowed fails repeatedly; the alternatives (bt <-> l2; basic / cp -> l2 -> bt) are tried at the same dt before it is
+    halved, the alternative stays selected until every one has failed, and the default is restored at the end"""
+    prob = P.celia1990(ncols=66, nz=40)
+    opts = {"assembly": "columns", "nseg": 1, "ksp_type": "preonly", "pc_type": "bjacobi", "snes_max_it": 6,
+            "snes_linesearch_type": ls, "use_dynamic_linesearch": 1}
+    g = P.to_gpu(prob, opts)
+    o = P.to_oracle(prob)
+    o.set_solver(C.KSP_PREONLY, C.PC_BJACOBI, snes_max_it=6)
+    o.set_linesearch(ls, True)
+    assert g.soe.StepDT(86400.0, 1) == tuple(o.step_dt(86400.0, 1))
+    cg, co = g.soe.counters(), o.counters()
+    assert cg["time_cuts"] == co["time_cuts"] > 0 and cg["newton"] == co["newton"]
+    assert o.linesearch_switches() > 0
+    np.testing.assert_allclose(g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1),
+                               o.get(C.AUXVAR_INTERNAL, C.VAR_PRESSURE), rtol=1e-7)
+    with pytest.raises(Exception, match="linesearch"):
+        g.soe.SetOption("snes_linesearch_type", "secant")

@@ -169,3 +169,50 @@ def test_lateral_flux_operator_split_equals_the_implicit_lateral_terms():
     f_full, f_split = of.residual(x), os_.residual(x)
     scale = np.abs(lat) / 18.01534 + np.abs(f_full)
     assert (np.abs(f_split - f_full) <= 1e-12 * scale + 1e-25).all()
+
+
+def _mixed_soil_problem(ncols=3, nz=14, seed=4, linear_porosity=True, mixed=True):
+    """celia columns whose cells mix van Genuchten, Brooks-Corey and both smoothed Brooks-Corey variants (satParams are per
+    cell in the reference, RichardsODEPressureAuxType.F90:18-67) and / or carry the linear porosity model"""
+    rng = np.random.default_rng(seed)
+    prob = P.celia1990(ncols=ncols, nz=nz, perm_mult=np.exp(0.5 * rng.standard_normal(ncols)))
+    n = prob.mesh.ncells_local
+    if mixed:
+        kinds = np.array([C.SAT_FUNC_VAN_GENUCHTEN, C.SAT_FUNC_BROOKS_COREY, C.SAT_FUNC_SMOOTHED_BROOKS_COREY_BZ2,
+                          C.SAT_FUNC_SMOOTHED_BROOKS_COREY_BZ3], dtype=np.int32)
+        prob.satfunc_type = kinds[rng.integers(0, 4, n)]
+        prob.lam = np.where(prob.satfunc_type == C.SAT_FUNC_VAN_GENUCHTEN, rng.uniform(0.3, 0.7, n), rng.uniform(0.4, 1.6, n))
+        prob.alpha = prob.alpha * rng.uniform(0.8, 1.2, n)
+    if linear_porosity:
+        prob.por_pressure_reference = np.full(n, 101325.0) + rng.uniform(-2e4, 2e4, n)
+        prob.por_slope = rng.uniform(1e-7, 6e-7, n)            # a few percent of porosity over the pressure range
+    x = prob.press_ic + rng.uniform(0, 1.3e5, n)
+    return prob, x
+
+
+@pytest.mark.parametrize("linear_porosity,mixed", [(True, False), (False, True), (True, True)])
+def test_linear_porosity_and_mixed_saturation_functions_jacobian_vs_finite_differences(linear_porosity, mixed):
+    """PorosityFunctionComputationLinearModel (PorosityFunctionMod.F90:144-163) inside Accum / AccumDeriv (GE:1603-1693) and
+    the per-cell dispatch of SaturationFunction.F90:564-650: no reference fixture exercises either, so the restated
+    derivative is checked against central differences of the restated residual"""
+    prob, x = _mixed_soil_problem(linear_porosity=linear_porosity, mixed=mixed)
+    o = P.to_oracle(prob)
+    o.set_dtime(prob.dt)
+    o.pre_solve()
+    n = x.size
+    rp, cj, val = o.jacobian(x)
+    J = _dense(rp, cj, val, n)
+    for j in range(n):
+        h = 1e-2
+        xp = x.copy(); xp[j] += h
+        xm = x.copy(); xm[j] -= h
+        col = (o.residual(xp) - o.residual(xm)) / (2 * h)
+        scale = np.abs(J[:, j]).max() + 1e-30
+        assert np.abs(col - J[:, j]).max() / scale < 5e-5, j
+    if linear_porosity:   # the model really is in: porosity follows the pressure
+        mass = o.get(C.AUXVAR_INTERNAL, C.VAR_MASS)
+        o2 = P.to_oracle(prob)
+        o2.restart(prob.press_ic + 5.0e4)
+        assert not np.allclose(o2.get(C.AUXVAR_INTERNAL, C.VAR_MASS), mass)
+    conv, reason = o.step_dt(prob.dt, 1)
+    assert conv and reason > 0
