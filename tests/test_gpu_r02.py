@@ -207,3 +207,35 @@ def test_dynamic_linesearch_sequence_before_a_time_step_cut(ls):
                                o.get(C.AUXVAR_INTERNAL, C.VAR_PRESSURE), rtol=1e-7)
     with pytest.raises(Exception, match="linesearch"):
         g.soe.SetOption("snes_linesearch_type", "secant")
+
+
+@pytest.mark.parametrize("name,cfg,loosen", [
+    ("vsfm_celia1990", "vsfm.cfg", {"pressure": "1.0e-9 relative", "general": "1.0e-9 absolute"}),
+    ("vsfm_vchannel", "vsfm.cfg", {"pressure": "1.0e-9 relative", "general": "1.0e-9 absolute"}),
+    ("thermal_mms", "thermal.cfg", {"general": "1.0e-9 relative"}),
+    ("thermal_mms_2d", "thermal.cfg", {"general": "1.0e-9 relative"}),
+    ("thermal_mms_3d", "thermal.cfg", {"general": "1.0e-9 relative"}),
+    ("mass_and_heat", "th.cfg", {"pressure": "1.0e-9 relative"}),
+])
+def test_standalone_driver_from_namelist_to_regression_file(golden_dir, tmp_path, name, cfg, loosen):
+    """f-3 end to end on the GPU: the reference's own .namelist -> mpp_amd.standalone (problem on the GPU, PETSc's default
+    GMRES(30) + ILU(0)) -> RegressionWriter -> compare() against the reference's .regression.baseline with the reference's
+    .cfg tolerances, loosened only where DESIGN.md section 5 says so: the cfg's 1e-10 / 1e-12 / 1e-16 absolute tolerances are
+    same-binary reproducibility bounds of a PETSc run; this is a different implementation of the same arithmetic, held to
+    1e-9 relative (pressure, temperature of the KSP problems) -- the TH temperature keeps the cfg's own 1e-8 K."""
+    import os
+    import shutil
+    from mpp_amd import regression as R
+    from mpp_amd import standalone as S
+    nl_path = tmp_path / (name + ".namelist")
+    shutil.copy(os.path.join(golden_dir, "namelists", name + ".namelist"), nl_path)
+    S.main(["-namelist", str(nl_path)])
+    out = (tmp_path / (name + ".regression")).read_text()
+    gold = open(os.path.join(golden_dir, name + ".regression.baseline")).read()
+    tol = R.Tolerances.from_cfg(open(os.path.join(golden_dir, cfg)).read(), name)
+    for cat, spec in loosen.items():
+        tol.update_from_name(cat, spec)
+    status, msgs = R.compare(out, gold, tol)
+    assert status == "pass", msgs
+    # sections, keys and their order are the reference file's
+    assert [l.split("=")[0] for l in out.splitlines()] == [l.split("=")[0] for l in gold.splitlines()]

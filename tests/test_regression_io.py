@@ -66,3 +66,61 @@ def test_comparator_semantics(golden_dir):
     assert R.compare(bad, gold_text, rel)[0] == "pass"
     with pytest.raises(RuntimeError):
         rel.update_from_name("salinity", "1 absolute")
+
+
+# ------------------------------------------------------------------------------------------------------------
+# namelist inputs (standalone_mpp.F90:69-70, 93-122; thermal_mms_problem.F90:59, 99-119), pinned on the reference's own
+# .namelist files (tests/golden/namelists: data files, verbatim)
+# ------------------------------------------------------------------------------------------------------------
+def _nl(golden_dir, name):
+    return open(os.path.join(golden_dir, "namelists", name + ".namelist")).read()
+
+
+def test_namelist_reader_on_the_reference_inputs(golden_dir):
+    from mpp_amd import namelist as NL
+    from mpp_amd import standalone as S
+    expect = {"vsfm_celia1990": ("vsfm_celia1990", 5), "vsfm_vchannel": ("vsfm_vchannel", 5), "thermal_mms": ("thermal_mms", 5),
+              "thermal_mms_2d": ("thermal_mms", 2), "thermal_mms_3d": ("thermal_mms", 3), "mass_and_heat": ("mass_and_heat", 5),
+              "th_mms": ("th_mms", 5), "vsfm_spac_campbell_multi_goveqns": ("vsfm_spac_campbell", 5)}
+    for name, (ptype, ncell) in expect.items():
+        nl = NL.read_driver_namelist(_nl(golden_dir, name))
+        assert nl["problem_type"] == ptype and nl["num_cells"] == ncell and nl["write_regression_output"] is True
+    # &problem_options of the thermal problems: defaults by problem type, then the file's values
+    assert S._thermal_mms_dims(NL.parse(_nl(golden_dir, "thermal_mms"))) == (1, (20, 1, 1))
+    assert S._thermal_mms_dims(NL.parse(_nl(golden_dir, "thermal_mms_2d"))) == (2, (3, 3, 1))
+    assert S._thermal_mms_dims(NL.parse(_nl(golden_dir, "thermal_mms_3d"))) == (3, (3, 3, 3))
+    # "/" directly followed by the next group, a logical in a group this path does not read
+    g = NL.parse(_nl(golden_dir, "vsfm_spac_campbell_multi_goveqns"))
+    assert g["problem_options"]["multi_goveqns_formulation"] is True
+    with pytest.raises(S.DriverError, match="outside the GPU solve path"):
+        S.run_problem("vsfm_spac_campbell", g)
+
+
+def test_namelist_syntax():
+    from mpp_amd import namelist as NL
+    text = """! a comment line
+ &A  x = 1.5d0, y=-2 , name = 'it''s' ! trailing comment with a / and a &
+   flag=.FALSE.  list = 1, 2,3   big = 1.0E+3
+ /
+&b
+  s = "a / in a string"
+  t = T
+&end
+"""
+    g = NL.parse(text)
+    assert g["a"] == {"x": 1.5, "y": -2, "name": "it's", "flag": False, "list": [1, 2, 3], "big": 1000.0}
+    assert g["b"] == {"s": "a / in a string", "t": True}
+    assert NL.read_group(g, "a", {"x": 0.0, "y": 0, "name": "", "flag": True, "list": [], "big": 0.0})["y"] == -2
+    assert NL.read_group(g, "zz", {"k": 3}) == {"k": 3}                  # a missing optional group leaves the defaults
+    with pytest.raises(NL.NamelistError):
+        NL.read_group(g, "zz", {"k": 3}, required=True)
+    with pytest.raises(NL.NamelistError, match="not a member"):
+        NL.read_group(g, "b", {"s": ""})                                 # `t` is not declared
+    with pytest.raises(NL.NamelistError, match="expects int"):
+        NL.read_group(g, "a", dict(x=0, y=0, name="", flag=True, list=[], big=0.0))
+    with pytest.raises(NL.NamelistError, match="not terminated"):
+        NL.parse("&a x = 1")
+    with pytest.raises(NL.NamelistError):
+        NL.parse("&a x = 1.2.3 /")
+    with pytest.raises(NL.NamelistError, match="mpp_driver"):
+        NL.read_driver_namelist("&regression_test num_cells = 2 /")
