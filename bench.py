@@ -52,6 +52,29 @@ def build_problem(ncols_global, nz, col0, ncols_local, hetero=True):
 # ------------------------------------------------------------------------------------------------------------
 # CPU legs (rank 0, N = 1): the oracle as baseline and as checker of the benchmark's own answer
 # ------------------------------------------------------------------------------------------------------------
+def usable_cores():
+    """cores this process may really use: the affinity mask, capped by the cgroup CPU quota (a GPU box exposes every core of
+    the host but grants a share of them)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:   # cgroup v2
+        q = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q[0] != "max":
+            n = min(n, max(1, int(float(q[0]) / float(q[1]))))
+    except (OSError, ValueError, IndexError):
+        pass
+    try:   # cgroup v1
+        quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if quota > 0 and period > 0:
+            n = min(n, max(1, quota // period))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -122,30 +145,39 @@ def cpu_one_core(shards, n_full):
     return (o.counters()["newton"] - before) * prob.mesh.ncells_local / dt / n_full
 
 
-def verify_answer(pressure, ncols_global, nz, col0, ncols_local, nsteps_total, hetero, nsample=64):
+def verify_answer(pressure, ncols_global, nz, col0, ncols_local, substeps, hetero, nsample=64):
     """The benchmark's own answer against the oracle: `nsample` columns of this rank's shard, each solved alone by the CPU
-    oracle over the same `nsteps_total` time steps at tight Newton tolerances (columns are independent, so a column's
-    converged answer does not depend on its neighbours); returns the largest pressure difference relative to the largest
-    pressure.  What it measures is the Newton truncation of the GPU's *global* solve (rtol 1e-8 on the global norm)."""
+    oracle at tight Newton tolerances over the same sequence of (sub-)steps the GPU run accepted -- `substeps` is the list,
+    per StepDT call, of the step sizes mppgpu_get_step_history reported: a global solve that cuts its time step applies the
+    halved step to every column (SystemOfEquationsBaseType.F90:486-506), so the backward-Euler discretisation to compare
+    with is that one.  Columns are independent, so a column's converged answer does not depend on its neighbours: what is
+    left between the two is the Newton truncation of the GPU's global solve (rtol 1e-8 on the global norm).  Returns the
+    largest pressure difference, absolute and relative to the largest pressure."""
     from mpp_amd import constants as C
     from mpp_amd import workloads as P
     from oracle import adapters as A
     mult = perm_multipliers(ncols_global) if hetero else np.ones(ncols_global)
     pick = np.sort(np.random.default_rng(7).choice(ncols_local, size=min(nsample, ncols_local), replace=False))
-    worst, scale = 0.0, 0.0
+    worst, scale, oracle_cuts = 0.0, 0.0, 0
     # one oracle problem per column: each column converges by itself, as tightly as the arithmetic allows
-    for j, c in enumerate(pick):
+    for c in pick:
         one = P.celia1990(ncols=1, nz=nz, perm_mult=mult[col0 + c:col0 + c + 1])
         o = A.to_oracle(one, with_blocks=False)
         o.set_solver(C.KSP_GMRES, C.PC_ILU0, ksp_rtol=1e-12, snes_rtol=1e-13, snes_stol=1e-14)
-        for s in range(nsteps_total):
-            o.step_dt(one.dt, s + 1)
+        k = 0
+        for subs in substeps:
+            for dt_sub in subs:
+                k += 1
+                o.step_dt(dt_sub, k)
+        oracle_cuts += o.counters()["time_cuts"]
         po = o.get(C.AUXVAR_INTERNAL, C.VAR_PRESSURE)
         pg = pressure[c * nz:(c + 1) * nz]
         worst = max(worst, float(np.abs(pg - po).max()))
         scale = max(scale, float(np.abs(po).max()))
     return {"columns_checked": int(pick.size), "max_abs_err_Pa": worst, "max_rel_err": worst / scale,
-            "against": "CPU oracle, one column at a time, snes_rtol 1e-13 / stol 1e-14, %d steps" % nsteps_total}
+            "oracle_time_step_cuts": int(oracle_cuts),
+            "against": "CPU oracle, one column at a time, snes_rtol 1e-13 / stol 1e-14, the %d (sub-)steps the GPU run accepted"
+                       % sum(len(x) for x in substeps)}
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -345,6 +377,8 @@ def main():
         soe.synchronize()
         group.barrier()
 
+    substeps = []   # per StepDT call: the sub-steps it accepted ([dt] unless the time step was cut); read outside the timed region
+
     def step(i):
         for b, (_t, _cs, vals) in enumerate(prob.bcs):
             soe.SetDataFromCLM(C.AUXVAR_BC, C.VAR_BC_SS_CONDITION, b + 1, vals)
@@ -354,6 +388,7 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+        substeps.append(soe.step_history())
     if dog and args.warmup > 0:
         dog.done()
         dog = None
@@ -364,6 +399,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
+        substeps.append(soe.step_history())   # a host-side copy of a few doubles (no device work)
         if dog:
             dog.done()
             dog = None
@@ -433,6 +469,8 @@ def main():
                        "cells": n_global, "cells_per_gpu": n_local, "dt_s": prob.dt,
                        "parallelism": "columns sharded over %d GPU(s), RCCL all-reduce of Krylov/Newton scalars" % world},
             "newton_iterations": newton, "linear_iterations": linear, "setup_s": round(t_setup, 2),
+            "time_step_cuts": c1["time_cuts"] - c0["time_cuts"],
+            "accepted_substeps_s": substeps[args.warmup:],
             "allreduces_per_newton_iteration": round(comm["allreduces"] / max(newton, 1), 2) if world > 1 else 0.0,
             "roofline": roof,
             "kernels": kernels,
@@ -442,7 +480,7 @@ def main():
     if not args.no_verify:
         try:
             pg = soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1)
-            check = verify_answer(pg, ncols_global, args.nz, col0, ncols_local, args.warmup + args.steps, not args.homogeneous,
+            check = verify_answer(pg, ncols_global, args.nz, col0, ncols_local, substeps, not args.homogeneous,
                                   nsample=64 if world == 1 else max(8, 64 // world))
             del pg
         except Exception as e:   # the check must never hide the measurement; its failure is reported in the line
@@ -454,12 +492,15 @@ def main():
             out["answer_check"] = dict(check or {}, max_rel_err=worst, columns_checked=int(ncheck))
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:   # the CPU baseline is reported at N = 1 only
-            cores = args.cpu_cores or (os.cpu_count() or 1)
+            # every core this process may use (affinity and cgroup quota), at most 64 shards of 8192 columns
+            cores = args.cpu_cores or min(usable_cores(), 64)
             n_full = ncols_global * args.nz
             cpc = max(64, min(819200 // args.nz, ncols_global // cores))   # 8192 columns x 100 layers per thread
             try:
                 # ~10-15 s of CPU work per leg: cores x 8192 columns x 100 layers, 3 timed steps after 1 warm-up
+                sys.stderr.write("bench.py: CPU baseline on %d threads ...\n" % cores); sys.stderr.flush()
                 ref = cpu_baseline(ncols_global, args.nz, 3, 1, cores, cols_per_core=cpc, ksp="gmres", pc="ilu")
+                sys.stderr.write("bench.py: CPU baseline, same solver as the GPU ...\n"); sys.stderr.flush()
                 one = cpu_one_core(ref.pop("_shards"), n_full)
                 ref.pop("_work0")
                 same = cpu_baseline(ncols_global, args.nz, 3, 1, cores, cols_per_core=cpc, ksp=args.ksp,
@@ -467,7 +508,7 @@ def main():
                 same.pop("_shards"); same.pop("_work0")
                 out["cpu_baseline"] = {"value": ref["value"], "unit": "Newton iters/s", "cores": cores, "kind": "port",
                                        "sample": ref["sample"] + "; GMRES(30)+ILU(0) = the reference's PETSc defaults",
-                                       "cpu_model": cpu_model(), "host_cores": os.cpu_count(),
+                                       "cpu_model": cpu_model(), "host_cores": os.cpu_count(), "usable_cores": usable_cores(),
                                        "value_one_core": one, "seconds": ref["seconds"],
                                        "same_solver_as_gpu": {"value": same["value"], "solver": same["solver"],
                                                               "seconds": same["seconds"]}}

@@ -26,7 +26,7 @@ module mppgpu_mod
         mppgpu_add_condition, mppgpu_set_soil_permeability, mppgpu_set_soil_porosity, mppgpu_set_soil_porosity_linear, &
         mppgpu_set_saturation_function, &
         mppgpu_set_density_type, mppgpu_set_option, mppgpu_setup, mppgpu_restart, mppgpu_set_data, mppgpu_step_dt, &
-        mppgpu_get_data, mppgpu_get_counters, mppgpu_set_dtime, mppgpu_pre_solve, mppgpu_residual, &
+        mppgpu_get_data, mppgpu_get_counters, mppgpu_get_step_history, mppgpu_set_dtime, mppgpu_pre_solve, mppgpu_residual, &
         mppgpu_jacobian_nnz, mppgpu_jacobian, mppgpu_synchronize, mppgpu_spmv, mppgpu_pc_apply, mppgpu_ksp_solve, &
         mppgpu_set_lateral_connections, mppgpu_compute_lateral_flux, mppgpu_get_condition_values, &
         mppgpu_set_source_sink_auxvar, mppgpu_thermal_set_soils, mppgpu_thermal_set_soln_prev_clm, &
@@ -304,6 +304,13 @@ module mppgpu_mod
        import :: c_int, c_ptr
        type(c_ptr), value :: h
      end function
+     integer(c_int) function mppgpu_get_step_history(h, max_n, dt_sub, n) bind(C, name='mppgpu_get_step_history')
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: h
+       integer(c_int), value :: max_n
+       real(c_double) :: dt_sub(*)
+       integer(c_int) :: n
+     end function
      integer(c_int) function mppgpu_get_comm_stats(h, allreduces, halo_exchanges, chain_fallbacks) &
           bind(C, name='mppgpu_get_comm_stats')
        import :: c_int, c_ptr, c_long_long
@@ -334,14 +341,45 @@ module mppgpu_mod
      end function
   end interface
 
-  !> sysofeqns_vsfm_type stand-in: same method names as the reference's SoE
+  integer(c_int), parameter, public :: VAR_LIQ_AREAL_DEN = 615, VAR_TUNING_FACTOR = 630
+
+  !> sysofeqns_vsfm_type stand-in: same method names as the reference's SoE and governing equation
+  !! (SoE: SetDataFromCLM / GetDataForCLM / PreStepDT / StepDT / PostStepDT / ComputeLateralFlux,
+  !!  src/mpp/soe/SystemOfEquationsVSFMType.F90:663-940; goveqn_base_type: ComputeResidual / ComputeJacobian / SetDtime /
+  !!  PreSolve, src/mpp/dtypes/GoverningEquationBaseType.F90:46-71)
   type, public :: sysofeqns_vsfm_gpu_type
      type(c_ptr) :: h = c_null_ptr
      integer     :: ncells = 0
    contains
      procedure :: Create, Destroy, SetMesh, SetConnections, AddConditionInGovEqn, SetOption, SetupProblem
-     procedure :: SetSoilPermeability, SetSoilPorosity, SetSaturationFunction, SetDensityType, Restart
+     procedure :: SetSoilPermeability, SetSoilPorosity, SetSoilPorosityLinear, SetSaturationFunction, SetDensityType, Restart
      procedure :: SetDataFromCLM, StepDT, GetDataForCLM, SetDtime, PreSolve, ComputeResidual, LastError
+     procedure :: JacobianNNZ, ComputeJacobian, MatMult, PCApply, KSPSolve
+     procedure :: PreStepDT, PostStepDT, SetLateralConnections, ComputeLateralFlux, SetSourceSinkAuxVarRealValue
+     procedure :: GetCounters, GetStepHistory
+  end type
+
+  !> sysofeqns_thermal_type stand-in (soil heat diffusion, KSP): src/mpp/soe/SystemOfEquationsThermalType.F90:234-759,
+  !! goveqn ComputeRHS / ComputeOperatorsDiag (src/mpp/ge/GoveqnThermalKSPTemperatureSoilType.F90:646-1229)
+  type, public, extends(sysofeqns_vsfm_gpu_type) :: sysofeqns_thermal_gpu_type
+   contains
+     procedure :: Create => ThermalCreate
+     procedure :: SetSoils => ThermalSetSoils
+     procedure :: SetSolnPrevCLM => ThermalSetSolnPrevCLM
+     procedure :: PreStepDT => ThermalPreStepDT
+     procedure :: StepDTKSP => ThermalStepDT
+     procedure :: GetSoln => ThermalGetSoln
+     procedure :: ComputeRHS => ThermalComputeRHS
+     procedure :: ComputeOperatorsDiag => ThermalComputeOperators
+  end type
+
+  !> sysofeqns_th_type stand-in (Richards mass equation + enthalpy-based heat equation, unknowns [P; T]):
+  !! src/mpp/soe/SystemOfEquationsTHType.F90:736-1003
+  type, public, extends(sysofeqns_vsfm_gpu_type) :: sysofeqns_th_gpu_type
+   contains
+     procedure :: Create => THCreate
+     procedure :: AddConditionInGovEqnTH
+     procedure :: SetSoilsTH
   end type
 
 contains
@@ -486,6 +524,177 @@ contains
     real(8), intent(inout) :: F(:)
     integer, intent(out) :: ierr
     ierr = mppgpu_residual(this%h, X, F)
+  end subroutine
+
+  subroutine SetSoilPorosityLinear(this, por_base, pressure_reference, slope, ierr)
+    class(sysofeqns_vsfm_gpu_type) :: this
+    real(8), intent(in) :: por_base(:), pressure_reference(:), slope(:)
+    integer, intent(out) :: ierr
+    ierr = mppgpu_set_soil_porosity_linear(this%h, por_base, pressure_reference, slope)
+  end subroutine
+  subroutine JacobianNNZ(this, nnz, ierr)
+    class(sysofeqns_vsfm_gpu_type) :: this
+    integer, intent(out) :: nnz, ierr
+    ierr = mppgpu_jacobian_nnz(this%h, nnz)
+  end subroutine
+  !> goveqn%ComputeJacobian(X, A, B): the CSR matrix in the caller's ordering, 0-based rowptr / col (PETSc's convention)
+  subroutine ComputeJacobian(this, X, rowptr, col, val, ierr)
+    class(sysofeqns_vsfm_gpu_type) :: this
+    real(8), intent(in) :: X(:)
+    integer, intent(inout) :: rowptr(:), col(:)
+    real(8), intent(inout) :: val(:)
+    integer, intent(out) :: ierr
+    ierr = mppgpu_jacobian(this%h, X, rowptr, col, val)
+  end subroutine
+  subroutine MatMult(this, x, y, ierr)
+    class(sysofeqns_vsfm_gpu_type) :: this
+    real(8), intent(in) :: x(:)
+    real(8), intent(inout) :: y(:)
+    integer, intent(out) :: ierr
+    ierr = mppgpu_spmv(this%h, x, y)
+  end subroutine
+  subroutine PCApply(this, r, z, ierr)
+    class(sysofeqns_vsfm_gpu_type) :: this
+    real(8), intent(in) :: r(:)
+    real(8), intent(inout) :: z(:)
+    integer, intent(out) :: ierr
+    ierr = mppgpu_pc_apply(this%h, r, z)
+  end subroutine
+  subroutine KSPSolve(this, b, x, its, reason, ierr)
+    class(sysofeqns_vsfm_gpu_type) :: this
+    real(8), intent(in) :: b(:)
+    real(8), intent(inout) :: x(:)
+    integer, intent(out) :: its, reason, ierr
+    ierr = mppgpu_ksp_solve(this%h, b, x, its, reason)
+  end subroutine
+  subroutine PreStepDT(this, ierr)
+    class(sysofeqns_vsfm_gpu_type) :: this
+    integer, intent(out) :: ierr
+    ierr = mppgpu_pre_step_dt(this%h)
+  end subroutine
+  subroutine PostStepDT(this, ierr)
+    class(sysofeqns_vsfm_gpu_type) :: this
+    integer, intent(out) :: ierr
+    ierr = mppgpu_post_step_dt(this%h)
+  end subroutine
+  subroutine SetLateralConnections(this, nconn, id_up, id_dn, dist_up, dist_dn, area, unit_vec, ierr)
+    class(sysofeqns_vsfm_gpu_type) :: this
+    integer, intent(in) :: nconn, id_up(:), id_dn(:)
+    real(8), intent(in) :: dist_up(:), dist_dn(:), area(:), unit_vec(:)
+    integer, intent(out) :: ierr
+    ierr = mppgpu_set_lateral_connections(this%h, nconn, id_up, id_dn, dist_up, dist_dn, area, unit_vec)
+  end subroutine
+  subroutine ComputeLateralFlux(this, dt, ss_cond_id, ierr)
+    class(sysofeqns_vsfm_gpu_type) :: this
+    real(8), intent(in) :: dt
+    integer, intent(in) :: ss_cond_id
+    integer, intent(out) :: ierr
+    ierr = mppgpu_compute_lateral_flux(this%h, dt, ss_cond_id)
+  end subroutine
+  subroutine SetSourceSinkAuxVarRealValue(this, var_type, values, ierr)
+    class(sysofeqns_vsfm_gpu_type) :: this
+    integer, intent(in) :: var_type
+    real(8), intent(in) :: values(:)
+    integer, intent(out) :: ierr
+    ierr = mppgpu_set_source_sink_auxvar(this%h, var_type, size(values), values)
+  end subroutine
+  subroutine GetCounters(this, newton, linear, cuts, funcs, ierr)
+    class(sysofeqns_vsfm_gpu_type) :: this
+    integer(8), intent(out) :: newton, linear, cuts, funcs
+    integer, intent(out) :: ierr
+    integer(c_long_long) :: a, b, c, d
+    ierr = mppgpu_get_counters(this%h, a, b, c, d)
+    newton = a; linear = b; cuts = c; funcs = d
+  end subroutine
+  subroutine GetStepHistory(this, dt_sub, n, ierr)
+    class(sysofeqns_vsfm_gpu_type) :: this
+    real(8), intent(inout) :: dt_sub(:)
+    integer, intent(out) :: n, ierr
+    ierr = mppgpu_get_step_history(this%h, size(dt_sub), dt_sub, n)
+  end subroutine
+
+  ! ---- thermal (KSP) ----
+  subroutine ThermalCreate(this, device_id, ierr)
+    class(sysofeqns_thermal_gpu_type) :: this
+    integer, intent(in) :: device_id
+    integer, intent(out) :: ierr
+    ierr = mppgpu_create(int(device_id, c_int), this%h)
+    if (ierr == 0) ierr = mppgpu_set_option(this%h, cstr('problem_type'), cstr('thermal'))
+  end subroutine
+  subroutine ThermalSetSoils(this, itype, is_soil_shallow, watsat, csol, tkmg, tkdry, dz, ierr)
+    class(sysofeqns_thermal_gpu_type) :: this
+    integer, intent(in) :: itype(:), is_soil_shallow(:)
+    real(8), intent(in) :: watsat(:), csol(:), tkmg(:), tkdry(:), dz(:)
+    integer, intent(out) :: ierr
+    ierr = mppgpu_thermal_set_soils(this%h, itype, is_soil_shallow, watsat, csol, tkmg, tkdry, dz)
+  end subroutine
+  subroutine ThermalSetSolnPrevCLM(this, temperature, ierr)
+    class(sysofeqns_thermal_gpu_type) :: this
+    real(8), intent(in) :: temperature(:)
+    integer, intent(out) :: ierr
+    ierr = mppgpu_thermal_set_soln_prev_clm(this%h, size(temperature), temperature)
+  end subroutine
+  subroutine ThermalPreStepDT(this, ierr)
+    class(sysofeqns_thermal_gpu_type) :: this
+    integer, intent(out) :: ierr
+    ierr = mppgpu_thermal_pre_step_dt(this%h)
+  end subroutine
+  !> soe%StepDT of the KSP path (SOEBaseStepDT_KSP, SystemOfEquationsBaseType.F90:555-647)
+  subroutine ThermalStepDT(this, dt, converged, linear_its, ierr)
+    class(sysofeqns_thermal_gpu_type) :: this
+    real(8), intent(in) :: dt
+    logical, intent(out) :: converged
+    integer, intent(out) :: linear_its, ierr
+    integer(c_int) :: c
+    ierr = mppgpu_thermal_step_dt(this%h, dt, c, linear_its)
+    converged = (c /= 0)
+  end subroutine
+  subroutine ThermalGetSoln(this, temperature, ierr)
+    class(sysofeqns_thermal_gpu_type) :: this
+    real(8), intent(inout) :: temperature(:)
+    integer, intent(out) :: ierr
+    ierr = mppgpu_thermal_get_soln(this%h, size(temperature), temperature)
+  end subroutine
+  subroutine ThermalComputeRHS(this, dt, b, ierr)
+    class(sysofeqns_thermal_gpu_type) :: this
+    real(8), intent(in) :: dt
+    real(8), intent(inout) :: b(:)
+    integer, intent(out) :: ierr
+    ierr = mppgpu_thermal_compute_rhs(this%h, dt, b)
+  end subroutine
+  subroutine ThermalComputeOperators(this, dt, rowptr, col, val, ierr)
+    class(sysofeqns_thermal_gpu_type) :: this
+    real(8), intent(in) :: dt
+    integer, intent(inout) :: rowptr(:), col(:)
+    real(8), intent(inout) :: val(:)
+    integer, intent(out) :: ierr
+    ierr = mppgpu_thermal_compute_operators(this%h, dt, rowptr, col, val)
+  end subroutine
+
+  ! ---- coupled thermal-hydrology ----
+  subroutine THCreate(this, device_id, ierr)
+    class(sysofeqns_th_gpu_type) :: this
+    integer, intent(in) :: device_id
+    integer, intent(out) :: ierr
+    ierr = mppgpu_create(int(device_id, c_int), this%h)
+    if (ierr == 0) ierr = mppgpu_set_option(this%h, cstr('problem_type'), cstr('th'))
+  end subroutine
+  subroutine AddConditionInGovEqnTH(this, igoveqn, ss_or_bc_type, cond_type, nconn, id_dn, dist_up, dist_dn, area, unit_vec, &
+                                    cond_id, ierr)
+    class(sysofeqns_th_gpu_type) :: this
+    integer, intent(in) :: igoveqn, ss_or_bc_type, cond_type, nconn, id_dn(:)
+    real(8), intent(in) :: dist_up(:), dist_dn(:), area(:), unit_vec(:)
+    integer, intent(out) :: cond_id, ierr
+    ierr = mppgpu_th_add_condition(this%h, igoveqn, ss_or_bc_type, cond_type, nconn, id_dn, dist_up, dist_dn, area, unit_vec, &
+                                   0, cond_id)
+  end subroutine
+  !> MPPTHSetSoils (src/mpp/mpp/MultiPhysicsProbTH.F90:211-300): the heat equation keeps its default permeability
+  subroutine SetSoilsTH(this, heat_cap, therm_cond_wet, therm_cond_dry, therm_alpha, den_soil, ierr)
+    class(sysofeqns_th_gpu_type) :: this
+    real(8), intent(in) :: heat_cap(:), therm_cond_wet(:), therm_cond_dry(:), therm_alpha(:), den_soil(:)
+    integer, intent(out) :: ierr
+    ierr = mppgpu_th_set_soils(this%h, heat_cap, therm_cond_wet, therm_cond_dry, therm_alpha, den_soil, c_null_ptr, c_null_ptr, &
+                               c_null_ptr)
   end subroutine
 
 end module mppgpu_mod

@@ -204,6 +204,11 @@ int mppgpu_step_dt(mppgpu_handle h, double dt, int nstep, int *converged, int *c
  * AUXVAR_BC / AUXVAR_SS / AUXVAR_CONN_INTERNAL: VAR_MASS_FLUX. */
 int mppgpu_get_data(mppgpu_handle h, int auxvar_type, int var_type, int cond_id, int n, double *data);
 
+/* The sub-steps the most recent mppgpu_step_dt accepted, in order: {dt} without a time-step cut, else the halved steps the
+ * loop of SOEBaseStepDT_SNES went on with (src/mpp/soe/SystemOfEquationsBaseType.F90:454-536: after a cut the loop keeps
+ * the halved dt_iter until time >= target, so the steps may add up to more than dt).  *n = their number (all of them,
+ * also when max_n is smaller); the reference only logs the cuts (write(iulog,*) ... 'cutting dt to'). */
+int mppgpu_get_step_history(mppgpu_handle h, int max_n, double *dt_sub, int *n);
 /* solver_type counters (src/mpp/dtypes/SolverType.F90:40-41,140-169) */
 int mppgpu_get_counters(mppgpu_handle h, long long *newton_its, long long *linear_its, long long *time_cuts,
                         long long *function_evals);

@@ -46,6 +46,7 @@ SIGNATURES = {
     "mppgpu_set_data": (ct.c_int, [_h, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _dp]),
     "mppgpu_step_dt": (ct.c_int, [_h, ct.c_double, ct.c_int, _ip, _ip]),
     "mppgpu_get_data": (ct.c_int, [_h, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _dp]),
+    "mppgpu_get_step_history": (ct.c_int, [_h, ct.c_int, _dp, _ip]),
     "mppgpu_get_counters": (ct.c_int, [_h, _llp, _llp, _llp, _llp]),
     "mppgpu_set_dtime": (ct.c_int, [_h, ct.c_double]),
     "mppgpu_pre_solve": (ct.c_int, [_h]),

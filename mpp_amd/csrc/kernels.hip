@@ -104,20 +104,33 @@ __global__ __launch_bounds__(kBlock) void k_accum(CellArrays ca, int n, double d
 // FUSE (nseg == 1, boundary conditions only on the end cells of a column, their fluxes evaluated beforehand by k_bc
 // into side arrays): every row is complete when the march leaves it, so the kernel also leaves the partial sums of
 // F.F and P.P (the line search's ||F||, ||X||) and, when a.tl is set, the column's LU factors (k_tri_factor's arithmetic).
+// Software pipeline (round 2; profiles/r02_pmc_sq_march.md): a wave spends most of its life waiting on memory at 3-4 waves
+// per SIMD, so the march keeps the operands of TWO levels in flight, in two named register sets that alternate -- no copies,
+// so using one set waits for that set only (vector-memory operations retire in order) while the other stays in flight.
+// Everything a level needs from memory is part of its fetch (pressure or the two vectors of a trial point, soil, geometry,
+// cell state, source, the residual to eliminate); fetches are unconditional loads with the level index clamped, so every
+// path issues the same number of operations and the compiler can count them instead of draining the queue.  The first CSR
+// slot of a row is computed, not loaded: rows of a column tile are level-major with 2 entries in the end rows and 3 between.
 template <int MODE, int SAT_T, int DEN_T, bool FUSE>  // MODE 0 residual, 1 Jacobian, 2 both; SAT_T / DEN_T: see physics.hpp
 __global__ __launch_bounds__(kBlock) void k_assemble_cols(ColsArgs a) {
   __shared__ double red[kBlock / 64];
-  const int *__restrict__ rowptr = a.rowptr;
+  extern __shared__ __attribute__((aligned(16))) double cls_lds[];   // [7][ncls] when soil classes are in use
   constexpr bool RES = (MODE == 0 || MODE == 2), JAC = (MODE == 1 || MODE == 2);
+  constexpr bool GEN = SAT_T < 0;   // general soil: per-cell saturation functions and / or the linear porosity model
   const int c = blockIdx.x * kBlock + threadIdx.x;
   const bool valid = c < a.ncols;
+  const bool classes = !GEN && a.soil_cls != nullptr;
+  if (classes) {
+    for (int q = threadIdx.x; q < 7 * a.ncls; q += kBlock) cls_lds[q] = a.cls_table[q];
+    __syncthreads();
+  }
   if (!FUSE && !valid) return;
   double accF = 0.0, accP = 0.0;
   if (valid) {
     const int nz = a.nz;
-    const int tile = c >> 6;
+    const int tile = c >> 6, lane = c & 63;
     const int tw = min(64, a.ncols - (tile << 6));          // width of this column tile
-    const size_t cbase = (size_t)tile * 64 * nz + (c & 63);  // cell (k,c) = cbase + k*tw
+    const size_t cbase = (size_t)tile * 64 * nz + lane;      // cell (k,c) = cbase + k*tw
     const int seg = FUSE ? 0 : blockIdx.y;
     const int nseg = FUSE ? 1 : a.nseg;
     const int k0 = (int)((long long)nz * seg / nseg);
@@ -127,13 +140,23 @@ __global__ __launch_bounds__(kBlock) void k_assemble_cols(ColsArgs a) {
     const int kend = k1 < nz ? k1 + 1 : nz;
     const CellArrays &ca = a.cell;
     const bool factor = FUSE && JAC && a.tl != nullptr;
+    const bool trial = FUSE && a.trial_x != nullptr;
+    const bool lin_por = GEN && ca.por_slope != nullptr;
+    const bool need_Fin = factor && !RES && a.fwd != nullptr;   // mode 1: the residual to forward-eliminate is in a.F
     const int jb = FUSE ? a.col_bc[c] : -1, jt = FUSE ? a.col_bc[a.ncols + c] : -1;  // side entries of rows 0 / nz-1
+    // first CSR slot of row (k, c) -- the pattern of a vertical-only grid in the tiled level-major order (checked on the host)
+    const int slot_tile = tile * 64 * (3 * nz - 2);
+    auto row_slot = [&](int k) -> int {
+      if (k == 0) return slot_tile + 2 * lane;
+      if (k == nz - 1) return slot_tile + 2 * tw + 3 * (nz - 2) * tw + 2 * lane;
+      return slot_tile + 2 * tw + 3 * ((k - 1) * tw + lane);
+    };
     double inv_pp = 0.0, c_pp = 0.0;   // 1/pivot and super-diagonal of the row before the one being completed
     double d_pp = 0.0;                 // ... and its forward-eliminated residual
 
     Aux prev = {};
     bool prev_act = false;
-    double f_prev = 0.0, dconn_prev = 0.0, dacc_prev = 0.0, lo_prev = 0.0, up_prev = 0.0;
+    double f_prev = 0.0, dconn_prev = 0.0, dacc_prev = 0.0, lo_prev = 0.0, up_prev = 0.0, src_prev = 0.0, Fin_prev = 0.0;
 
     // row ip = (kp, c) is complete: boundary contribution, store, reductions, elimination step
     auto finish_row = [&](int kp, size_t ip, bool last) {
@@ -141,7 +164,7 @@ __global__ __launch_bounds__(kBlock) void k_assemble_cols(ColsArgs a) {
       double f_row = 0.0;
       if (RES) {
         double f = f_prev;
-        if (a.src) f -= ldnt(a.src + ip);
+        if (a.src) f -= src_prev;
         if (FUSE && js >= 0) f += a.side_f[js];
         stnt(f, a.F + ip);
         if (FUSE) accF += f * f;
@@ -150,7 +173,7 @@ __global__ __launch_bounds__(kBlock) void k_assemble_cols(ColsArgs a) {
       if (JAC) {
         double di = dconn_prev + dacc_prev;
         if (FUSE && js >= 0) di += a.side_d[js];
-        int slot = ldnt(rowptr + ip);
+        int slot = row_slot(kp);
         if (kp > 0) a.val[slot++] = lo_prev;
         a.val[slot++] = di;
         if (!last) a.val[slot] = up_prev;
@@ -161,7 +184,7 @@ __global__ __launch_bounds__(kBlock) void k_assemble_cols(ColsArgs a) {
           stnt(l, a.tl + ip); stnt(inv, a.tinvb + ip); stnt(up_prev, a.tc + ip);
           inv_pp = inv; c_pp = up_prev;
           if (a.fwd) {   // forward elimination of the residual as well: the Krylov solver's first M^{-1} F starts from here
-            const double d = (RES ? f_row : ldnt(a.F + ip)) - l * d_pp;
+            const double d = (RES ? f_row : Fin_prev) - l * d_pp;
             stnt(d, a.fwd + ip);
             d_pp = d;
           }
@@ -169,20 +192,22 @@ __global__ __launch_bounds__(kBlock) void k_assemble_cols(ColsArgs a) {
       }
     };
 
-    // the streamed operands of one level (and of the connection below it), fetched one level ahead of their use so
-    // that a wave's memory latency overlaps its own arithmetic (the march runs at 2-4 waves per SIMD)
-    struct Level { double P, sat_res, alpha, m, por, vol, accp, Dq, upw, dgrav, area, pref, slope; int sf; };
-    constexpr bool GEN = SAT_T < 0;   // general soil: per-cell saturation functions and / or the linear porosity model
-    const bool lin_por = GEN && ca.por_slope != nullptr;
-    auto fetch = [&](int k) {
+    // the streamed operands of one level and of the connection below it
+    struct Level { double P, y, sat_res, alpha, m, por, vol, accp, Dq, upw, dgrav, pref, slope, frac, src, Fin, pu, ps, b2, b3;
+                   int sf, cls; signed char act; };
+    const bool lev_geo = a.lev_upw != nullptr;
+    auto fetch = [&](int kreq) {
       Level L;
+      const int k = min(kreq, kend - 1);   // past the end: a harmless repeat of the last level (never used)
       const size_t i = cbase + (size_t)k * tw;
-      if (FUSE && a.trial_x) {   // the line search's trial point W = X + a Y, formed here and stored for the next pass
-        L.P = fma(a.trial_a, ldnt(a.trial_y + i), ldnt(a.trial_x + i));
-        stnt(L.P, a.trial_w + i);
-      } else L.P = ldnt(ca.P + i);
-      L.sat_res = ldnt(ca.sat_res + i); L.alpha = ldnt(ca.alpha + i);
-      L.m = (SAT_T == kSatVGHalf) ? 0.5 : ldnt(ca.m + i);
+      if (trial) { L.P = ldnt(a.trial_x + i); L.y = ldnt(a.trial_y + i); }   // W = X + a Y is formed when the level is used
+      else { L.P = ldnt(ca.P + i); L.y = 0.0; }
+      L.cls = 0;
+      if (classes) { L.cls = ldnt(a.soil_cls + i); L.sat_res = L.alpha = L.m = 0.0; }   // the parameters come from LDS at use
+      else {
+        L.sat_res = ldnt(ca.sat_res + i); L.alpha = ldnt(ca.alpha + i);
+        L.m = (SAT_T == kSatVGHalf) ? 0.5 : ldnt(ca.m + i);
+      }
       if (GEN) {
         L.por = ldnt(ca.por + i); L.vol = ldnt(ca.vol + i);
         L.sf = ca.satf ? (int)ca.satf[i] : ca.sat_func;
@@ -191,34 +216,48 @@ __global__ __launch_bounds__(kBlock) void k_assemble_cols(ColsArgs a) {
         L.por = ldnt(a.porvol + i); L.vol = 1.0;   // (constant) porosity only ever multiplies the volume here
         L.pref = L.slope = 0.0; L.sf = SAT_T;
       }
+      if (L.sf == kSatSBC && !classes) { L.pu = ca.sbc_pu[i]; L.ps = ca.sbc_ps[i]; L.b2 = ca.sbc_b2[i]; L.b3 = ca.sbc_b3[i]; }
+      else L.pu = L.ps = L.b2 = L.b3 = 0.0;
       L.accp = RES ? ldnt(a.accum_prev + i) : 0.0;
+      L.act = ca.active ? ca.active[i] : (signed char)1;
+      L.frac = ca.frac_cell ? ca.frac_cell[i] : ca.frac_liq;
+      L.src = (RES && a.src) ? ldnt(a.src + i) : 0.0;
+      L.Fin = need_Fin ? ldnt(a.F + i) : 0.0;
       if (k > kstart) {
         const size_t ic = i - tw;
-        L.Dq = ldnt(a.DqA + ic); L.area = 1.0;     // the flux is linear in Dq * area
-        L.upw = ldnt(a.conn.upw + ic); L.dgrav = ldnt(a.conn.dgrav + ic);
-      } else { L.Dq = L.upw = L.dgrav = L.area = 0.0; }
+        L.Dq = ldnt(a.DqA + ic);                 // conductance x face area: the flux is linear in it
+        if (lev_geo) { L.upw = a.lev_upw[k]; L.dgrav = a.lev_dgrav[k]; }   // wave-uniform: scalar loads
+        else { L.upw = ldnt(a.conn.upw + ic); L.dgrav = ldnt(a.conn.dgrav + ic); }
+      } else { L.Dq = L.upw = L.dgrav = 0.0; }
       return L;
     };
-    Level nxt = fetch(kstart);
-    for (int k = kstart; k < kend; ++k) {
+
+    auto process = [&](int k, const Level &L) {
       const size_t i = cbase + (size_t)k * tw;
-      const Level L = nxt;
-      if (k + 1 < kend) nxt = fetch(k + 1);
-      const bool act = is_active(ca, i);
+      const bool act = L.act != 0;
       const bool owned = (k >= k0 && k < k1);
       Aux cur = {};
       double f_cur = 0.0, dacc_cur = 1.0;  // inactive cell: diagonal 1 (GE:1682-1684)
-      const double Pi = L.P;
+      double Pi = L.P;
+      if (trial) {   // the line search's trial point W = X + a Y, formed here and stored for the next pass
+        Pi = fma(a.trial_a, L.y, L.P);
+        stnt(Pi, a.trial_w + i);
+      }
       cur.P = Pi;
       if (FUSE && RES) accP += Pi * Pi;
       if (act) {
         Soil s;
         s.sat_res = L.sat_res; s.alpha = L.alpha; s.m = L.m; s.por = L.por;
         s.por_pref = L.pref; s.por_slope = L.slope; s.sf = L.sf;
-        if (L.sf == kSatSBC) {
-          s.pu = ca.sbc_pu[i]; s.ps = ca.sbc_ps[i]; s.b2 = ca.sbc_b2[i]; s.b3 = ca.sbc_b3[i];
-        } else s.pu = s.ps = s.b2 = s.b3 = 0.0;
-        cur = auxvar_compute<JAC, SAT_T, DEN_T>(L.sf, ca.eos, s, Pi, frac_of(ca, i));
+        s.pu = L.pu; s.ps = L.ps; s.b2 = L.b2; s.b3 = L.b3;
+        if (classes) {
+          const double *t = cls_lds + L.cls;
+          const int nc = a.ncls;
+          s.sat_res = t[0]; s.alpha = t[nc];
+          s.m = (SAT_T == kSatVGHalf) ? 0.5 : t[2 * nc];
+          if (SAT_T == kSatSBC) { s.pu = t[3 * nc]; s.ps = t[4 * nc]; s.b2 = t[5 * nc]; s.b3 = t[6 * nc]; }
+        }
+        cur = auxvar_compute<JAC, SAT_T, DEN_T>(L.sf, ca.eos, s, Pi, L.frac);
         if (owned) {
           const double vol = L.vol;
           if (lin_por) {
@@ -237,7 +276,7 @@ __global__ __launch_bounds__(kBlock) void k_assemble_cols(ColsArgs a) {
       if (k > kstart) {
         if (prev_act && act) {
           ConnGeom g;
-          g.Dq = L.Dq; g.upweight = L.upw; g.dist_gravity = L.dgrav; g.area = L.area;
+          g.Dq = L.Dq; g.upweight = L.upw; g.dist_gravity = L.dgrav; g.area = 1.0;
           double Jup = 0.0, Jdn = 0.0;
           const double flux = richards_flux<JAC>(prev, cur, g, 0, Jup, Jdn);
           if (RES) { f_prev -= flux; f_cur += flux; }
@@ -248,6 +287,24 @@ __global__ __launch_bounds__(kBlock) void k_assemble_cols(ColsArgs a) {
       }
       prev = cur; prev_act = act;
       f_prev = f_cur; dconn_prev = dconn_cur; dacc_prev = dacc_cur; lo_prev = lo_cur; up_prev = 0.0;
+      src_prev = L.src; Fin_prev = L.Fin;
+    };
+
+    Level LA = fetch(kstart);
+    __builtin_amdgcn_sched_barrier(0);
+    Level LB = fetch(kstart + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int k = kstart; k < kend; k += 2) {
+      process(k, LA);
+      __builtin_amdgcn_sched_barrier(0);   // program order = issue order: a register set is refilled right after its use
+      LA = fetch(k + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      if (k + 1 < kend) {
+        process(k + 1, LB);
+        __builtin_amdgcn_sched_barrier(0);
+        LB = fetch(k + 3);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     if (kend == nz && k1 == nz) finish_row(nz - 1, cbase + (size_t)(nz - 1) * tw, true);  // top row of the column
   }
@@ -1782,15 +1839,14 @@ void launch_accum(const CellArrays &cell, int n, double dtInv, double *out, hipS
 
 template <int SAT_T, int DEN_T>
 static void launch_cols_mode(int mode, const ColsArgs &a, dim3 grid, hipStream_t stream) {
+  const size_t lds = (SAT_T >= 0 && a.soil_cls) ? (size_t)7 * a.ncls * sizeof(double) : 0;   // the class table, staged per block
+#define COLS(M, F) hipLaunchKernelGGL((k_assemble_cols<M, SAT_T, DEN_T, F>), grid, dim3(kBlock), lds, stream, a)
   if (a.col_bc) {   // complete-row variant (grid.y == 1)
-    if (mode == 0) LAUNCH((k_assemble_cols<0, SAT_T, DEN_T, true>), grid, a);
-    else if (mode == 1) LAUNCH((k_assemble_cols<1, SAT_T, DEN_T, true>), grid, a);
-    else LAUNCH((k_assemble_cols<2, SAT_T, DEN_T, true>), grid, a);
-    return;
+    if (mode == 0) COLS(0, true); else if (mode == 1) COLS(1, true); else COLS(2, true);
+  } else {
+    if (mode == 0) COLS(0, false); else if (mode == 1) COLS(1, false); else COLS(2, false);
   }
-  if (mode == 0) LAUNCH((k_assemble_cols<0, SAT_T, DEN_T, false>), grid, a);
-  else if (mode == 1) LAUNCH((k_assemble_cols<1, SAT_T, DEN_T, false>), grid, a);
-  else LAUNCH((k_assemble_cols<2, SAT_T, DEN_T, false>), grid, a);
+#undef COLS
 }
 void launch_assemble_cols(int mode, const ColsArgs &a, hipStream_t stream) {
   if (a.ncols <= 0) return;

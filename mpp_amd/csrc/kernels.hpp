@@ -43,6 +43,15 @@ struct ColsArgs {
   CellArrays cell;
   ConnArrays conn;       // vertical connection (k,c)->(k+1,c) stored at the index of cell (k,c)
   const double *DqA, *porvol;       // conn.Dq * conn.area and cell.por * cell.vol, streamed instead of the four arrays
+  // byte savers of structured inputs (both optional, nullptr = the per-cell / per-connection arrays are streamed):
+  //  * soil classes: when the mesh holds at most 256 distinct (sat_res, alpha, m, smoothing coefficients) tuples, one byte
+  //    per cell selects a row of cls_table ([7][ncls]: sat_res, alpha, m, pu, ps, b2, b3), staged in LDS by every block
+  //  * per-level geometry: when upwind weight and gravity distance of the connection below level k are the same in every
+  //    column (extruded grids), lev_upw[k] / lev_dgrav[k] (k = 1 .. nz-1) replace the two per-connection streams
+  const unsigned char *soil_cls = nullptr;
+  const double *cls_table = nullptr;
+  int ncls = 0;
+  const double *lev_upw = nullptr, *lev_dgrav = nullptr;
   const double *accum_prev, *src;   // src: dense mass-rate source [kmol/s], nullptr if none
   double *F;             // residual out (MODE 0,2)
   double *val;           // CSR values out (MODE 1,2), level-major analytic layout

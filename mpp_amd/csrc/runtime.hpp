@@ -168,6 +168,8 @@ struct Options {
   unsigned ilu_chain_spins = 1u << 22;   // polls (~0.4 us apart) before a chained wait gives up and the apply is redone per level
   bool ls_ahead = true;        // the line search's first reductions ride behind the Krylov solver's last update
   bool wide_xr = true;         // BiCGStab update kernel on a one-pair-per-lane grid (large vectors)
+  bool soil_classes = true;    // column march: one byte per cell + a class table when the mesh has <= 256 distinct soil tuples
+  bool level_geometry = true;  // column march: per-level upwind weight / gravity distance when they are the same in every column
   int tri_lds = -1;            // column solve with L^{-1} r parked in LDS between the sweeps: 0 off, 1 on, -1 auto (Solver::tri_lds)
   int tri_group = 24;          // ... and levels kept in flight per stream and wave (8, 16, 24)
   int spmv_tpw = 0;            // > 0: 64-row tiles per wave of the compact-index SpMV (default 4 / 8 by variant)

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <tuple>
 
 #include "../../include/mppgpu.h"
 #include "runtime.hpp"
@@ -98,6 +99,11 @@ struct Solver {
   bool all_vg_half = false;
   std::vector<double> por_pref, por_slope;   // POROSITY_LINEAR (PorosityFunctionMod.F90:75-96); empty = constant model
   DevBuf<signed char> d_satf;
+  // byte savers of the column march (ColsArgs): soil classes and per-level connection geometry
+  DevBuf<unsigned char> d_soil_cls;
+  DevBuf<double> d_cls_table, d_lev_upw, d_lev_dgrav;
+  int ncls = 0;
+  bool lev_geo = false;
   DevBuf<double> d_por_pref, d_por_slope;
   int density_type = MPPGPU_DENSITY_CONSTANT;  // RichODEPressureAuxVarInit default (AuxType :120)
   double temperature = 273.15 + 25.0, frac_liq = 1.0;
@@ -220,6 +226,7 @@ struct Solver {
   bool ls_backtracked_last = false;
   double ls_ynorm = -1.0;         // linesearch->ynorm as the previous application left it (cp reads it at entry)
   long long cum_ls_switches = 0;  // line searches swapped in by use_dynamic_linesearch
+  std::vector<double> last_substeps;   // sub-steps the most recent StepDT accepted (dt, dt/2 ... after time-step cuts)
   bool pc_ready = false;
   std::vector<double> h_bc_value, h_ss_value;
 
@@ -681,6 +688,16 @@ struct Solver {
       if (ns > 0 && !has_src) { d_src.alloc(n); d_src.zero(stream); has_src = true; }
       th_liq.assign(n, 0.0); th_ice.assign(n, 0.0); th_snow.assign(n, 0.0); th_tuning.assign(n, 1.0); th_nsnow.assign(n, 0);
     }
+    if (vertical_only && columns && nz >= 2) {   // the column march computes the first slot of a row instead of loading it
+      for (int col = 0; col < ncols; col += std::max(1, ncols / 257)) {
+        const int tile = col >> 6, lane = col & 63, tw = std::min(64, ncols - (tile << 6));
+        const long long st = (long long)tile * 64 * (3LL * nz - 2);
+        for (int k = 0; k < nz; ++k) {
+          const long long want = k == 0 ? st + 2 * lane : (k == nz - 1 ? st + 2 * tw + 3LL * (nz - 2) * tw + 2 * lane : st + 2 * tw + 3LL * ((k - 1) * (long long)tw + lane));
+          if (h_rowptr[cell_index(k, col)] != want) throw Error("internal: CSR pattern of the column layout is not the expected one");
+        }
+      }
+    }
     build_compact_index();
     build_multibase_index();
     plan_complete_rows();
@@ -782,6 +799,7 @@ struct Solver {
       for (int i = 0; i < n; ++i) a[i] = a[i] * vol[int2ext[i]];
       d_porvol.upload(a, stream);
     }
+    build_soil_classes();
     if (mixed_satf) {
       std::vector<signed char> t(n);
       for (int i = 0; i < n; ++i) t[i] = (signed char)map_sat_func(satf[int2ext[i]]);
@@ -799,14 +817,7 @@ struct Solver {
       for (int i = 0; i < n; ++i) {
         const int e = int2ext[i];
         if (map_sat_func(satf[e]) != kSatSBC) continue;
-        const bool bz2 = satf[e] == MPPGPU_SAT_FUNC_SMOOTHED_BROOKS_COREY_BZ2;
-        const double al = alpha[e], la = lam[e];
-        const double p_s = -0.9 / al;
-        const double p_u = find_gu_sbc_zero_coeff(la, bz2 ? 3 : 2, -al * p_s) / (-al);
-        const double bcAtPu = std::pow(-al * p_u, -la), ldp = la * (1.0 - p_s / p_u), inv = 1.0 / (p_u - p_s);
-        ps[i] = p_s; pu[i] = p_u;
-        if (bz2) { b2[i] = 0.0; b3[i] = (2.0 - bcAtPu * (2.0 + ldp)) * inv * inv * inv; }
-        else { b2[i] = -(3.0 - bcAtPu * (3.0 + ldp)) * inv * inv; b3[i] = 0.0; }
+        sbc_coefficients(satf[e], alpha[e], lam[e], pu[i], ps[i], b2[i], b3[i]);
       }
       d_pu.upload(pu, stream); d_ps.upload(ps, stream); d_b2.upload(b2, stream); d_b3.upload(b3, stream);
     }
@@ -824,6 +835,18 @@ struct Solver {
       if (vertical_only && columns && !th) {   // ... and conductance x face area
         for (int ic = 0; ic < nc_int; ++ic) Dq[ic] = Dq[ic] * ar[ic];
         d_DqA.upload(Dq, stream);
+        // extruded grids: the connection below level k has the same upwind weight and gravity distance in every column
+        lev_geo = opt.level_geometry && nz >= 2;
+        std::vector<double> lu(nz, 0.0), lg(nz, 0.0);
+        for (int k = 1; k < nz && lev_geo; ++k) {
+          const int i0 = cell_index(k - 1, 0);
+          lu[k] = upw[i0]; lg[k] = dg[i0];
+          for (int col = 1; col < ncols; ++col) {
+            const int ic = cell_index(k - 1, col);
+            if (upw[ic] != lu[k] || dg[ic] != lg[k]) { lev_geo = false; break; }
+          }
+        }
+        if (lev_geo) { d_lev_upw.upload(lu, stream); d_lev_dgrav.upload(lg, stream); }
       }
     }
     // boundary geometry: the BC auxvar carries the soil of its id_dn cell (MultiPhysicsProbVSFM.F90:422-446)
@@ -884,6 +907,54 @@ struct Solver {
     }
     HIP_CHECK(hipStreamSynchronize(stream));
     soil_dirty = false;
+  }
+  // soil classes of the column march: at most 256 distinct (saturation function, sat_res, alpha, m) tuples in the mesh ->
+  // one byte per cell + a table (the smoothed Brooks-Corey coefficients are functions of the tuple)
+  void build_soil_classes() {
+    ncls = 0;
+    d_soil_cls.release();
+    if (!opt.soil_classes || !(vertical_only && columns) || th || thermal || mixed_satf) return;
+    struct Key { int f; double a, b, c; bool operator<(const Key &o) const { return std::tie(f, a, b, c) < std::tie(o.f, o.a, o.b, o.c); } };
+    std::vector<Key> keys;             // sorted, <= 256 entries: binary search per cell, early exit on the 257th tuple
+    std::vector<unsigned char> cls(n);
+    int last = -1;
+    for (int i = 0; i < n; ++i) {
+      const int e = int2ext[i];
+      const Key k{satf[e], sat_res[e], alpha[e], lam[e]};
+      if (last >= 0 && !(k < keys[last]) && !(keys[last] < k)) continue;   // same tuple as the previous cell: the common case
+      auto it = std::lower_bound(keys.begin(), keys.end(), k);
+      if (it == keys.end() || k < *it) {
+        if (keys.size() == 256) return;
+        it = keys.insert(it, k);
+      }
+      last = (int)(it - keys.begin());
+    }
+    for (int i = 0; i < n; ++i) {
+      const int e = int2ext[i];
+      const Key k{satf[e], sat_res[e], alpha[e], lam[e]};
+      cls[i] = (unsigned char)(std::lower_bound(keys.begin(), keys.end(), k) - keys.begin());
+    }
+    ncls = (int)keys.size();
+    std::vector<double> tab(7 * (size_t)ncls, 0.0);
+    for (int q = 0; q < ncls; ++q) {
+      tab[q] = keys[q].a; tab[ncls + q] = keys[q].b; tab[2 * ncls + q] = keys[q].c;
+      if (map_sat_func(keys[q].f) == kSatSBC) {
+        double pu, ps, b2, b3;
+        sbc_coefficients(keys[q].f, keys[q].b, keys[q].c, pu, ps, b2, b3);
+        tab[3 * ncls + q] = pu; tab[4 * ncls + q] = ps; tab[5 * ncls + q] = b2; tab[6 * ncls + q] = b3;
+      }
+    }
+    d_soil_cls.upload(cls.data(), cls.size(), stream);
+    d_cls_table.upload(tab, stream);
+  }
+  // SatFunc_Set_SBC_bz2 / _bz3 (SaturationFunction.F90:260-372), ps = -0.9/alpha (:1409,1412)
+  static void sbc_coefficients(int satf_ext, double al, double la, double &p_u, double &p_s, double &b2, double &b3) {
+    const bool bz2 = satf_ext == MPPGPU_SAT_FUNC_SMOOTHED_BROOKS_COREY_BZ2;
+    p_s = -0.9 / al;
+    p_u = find_gu_sbc_zero_coeff(la, bz2 ? 3 : 2, -al * p_s) / (-al);
+    const double bcAtPu = std::pow(-al * p_u, -la), ldp = la * (1.0 - p_s / p_u), inv = 1.0 / (p_u - p_s);
+    if (bz2) { b2 = 0.0; b3 = (2.0 - bcAtPu * (2.0 + ldp)) * inv * inv * inv; }
+    else { b2 = -(3.0 - bcAtPu * (3.0 + ldp)) * inv * inv; b3 = 0.0; }
   }
   // permeability of the heat equation's auxvars: 8.3913e-12 unless set (ThermEnthalpyAuxVarInit,
   // ThermalEnthalpySoilAuxType.F90:93; MPPTHSetSoils leaves it, MultiPhysicsProbTH.F90:293)
@@ -948,6 +1019,8 @@ struct Solver {
     a.F = Fout; a.val = d_val.p; a.rowptr = d_rowptr.p;
     a.ncols = ncols; a.nz = nz; a.nseg = pick_nseg(); a.dtInv = 1.0 / dtime;
     a.DqA = d_DqA.p; a.porvol = d_porvol.p;
+    if (ncls > 0) { a.soil_cls = d_soil_cls.p; a.cls_table = d_cls_table.p; a.ncls = ncls; }
+    if (lev_geo) { a.lev_upw = d_lev_upw.p; a.lev_dgrav = d_lev_dgrav.p; }
     return a;
   }
   GenArgs gen_args(const double *P, double *Fout) const {
@@ -1954,6 +2027,7 @@ struct Solver {
     struct Restore { int &t; int v; ~Restore() { t = v; } } restore{opt.linesearch_type, ls_default};   // :539-550
     time = 0.0;
     *converged = 0;
+    last_substeps.clear();
     for (;;) {
       dtime = dt_iter;
       op_pre_solve();
@@ -1981,6 +2055,7 @@ struct Solver {
       } else {
         *converged = 1;
         time += dt_iter;
+        last_substeps.push_back(dt_iter);
         cum_newton += nit; cum_linear += lit;
         vec_copy(soln.p, soln_prev.p);  // VSFMSOEPostSolve (SystemOfEquationsVSFMType.F90:600)
         if (opt.track_mass_exchange && !th) accumulate_mass_exchange(dt_iter);
@@ -2487,6 +2562,8 @@ struct Solver {
     else if (key == "ls_ahead") opt.ls_ahead = num() != 0;
     else if (key == "wide_xr") opt.wide_xr = num() != 0;
     else if (key == "spmv_tpw") opt.spmv_tpw = (int)num();
+    else if (key == "soil_classes") { opt.soil_classes = num() != 0; soil_dirty = true; }
+    else if (key == "level_geometry") { opt.level_geometry = num() != 0; soil_dirty = true; }
     else if (key == "tri_lds") opt.tri_lds = (int)num();
     else if (key == "tri_group") opt.tri_group = (int)num();
     else if (key == "defer_test0") opt.defer_test0 = num() != 0;
@@ -2759,6 +2836,14 @@ int mppgpu_get_counters(mppgpu_handle h, long long *newton_its, long long *linea
   if (linear_its) *linear_its = S.cum_linear;
   if (time_cuts) *time_cuts = S.cum_cuts;
   if (function_evals) *function_evals = S.cum_funcs;
+  API_END()
+}
+
+int mppgpu_get_step_history(mppgpu_handle h, int max_n, double *dt_sub, int *n) {
+  API_BEGIN(h)
+  const int have = (int)S.last_substeps.size();
+  if (n) *n = have;
+  for (int i = 0; i < have && i < max_n; ++i) dt_sub[i] = S.last_substeps[i];
   API_END()
 }
 

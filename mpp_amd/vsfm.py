@@ -164,6 +164,13 @@ class SystemOfEquationsVSFM:
         self._chk(self.L.mppgpu_get_condition_values(self.h, kind, cond_id, n, out.ctypes.data_as(ct.POINTER(ct.c_double))))
         return out
 
+    def step_history(self):
+        """sub-steps the last StepDT accepted ([dt] unless the time step was cut)"""
+        n = ct.c_int()
+        buf = (ct.c_double * 64)()
+        self._chk(self.L.mppgpu_get_step_history(self.h, 64, buf, ct.byref(n)))
+        return [buf[i] for i in range(min(n.value, 64))]
+
     def counters(self):
         a, b, c, d = ct.c_longlong(), ct.c_longlong(), ct.c_longlong(), ct.c_longlong()
         self._chk(self.L.mppgpu_get_counters(self.h, ct.byref(a), ct.byref(b), ct.byref(c), ct.byref(d)))

@@ -123,17 +123,23 @@ def test_gmres_restart_is_validated():
 @pytest.mark.parametrize("nx,ny,nz,steps", [(64, 48, 100, 3), (1024, 1024, 100, 2)], ids=["3072_columns", "bench_workload"])
 def test_bench_workload_answer_against_per_column_oracle_solves(nx, ny, nz, steps):
     """bench.py's workload -- heterogeneous celia-extruded columns, BiCGStab + block-Jacobi, default tolerances -- with
-    sampled columns compared with the CPU oracle solving each of them alone at tight tolerances.  What separates the two is
-    the Newton truncation of the global solve (rtol 1e-8 on the global norm): stated tolerance 1e-6 relative on pressure."""
+    sampled columns compared with the CPU oracle solving each of them alone at tight tolerances over the (sub-)steps the GPU
+    run accepted.  What separates the two is the Newton truncation of the global solve (rtol 1e-8 on the global norm):
+    stated tolerance 1e-6 relative on pressure."""
     import bench
     ncols = nx * ny
     prob = bench.build_problem(ncols, nz, 0, ncols)
     g = P.to_gpu(prob, {"ksp_type": "bcgs", "pc_type": "bjacobi"})
+    history = []
     for s in range(steps):
         conv, reason = g.soe.StepDT(prob.dt, s + 1)
         assert conv and reason > 0
+        history.append(g.soe.step_history())
+        assert abs(sum(history[-1]) - prob.dt) <= 1e-9 * prob.dt
+    # (at a million heterogeneous columns the first step is cut to 4 x 900 s: some column fails Newton at 3600 s, and a global
+    # solve applies the cut to every column -- the oracle columns replay exactly those sub-steps)
     p = g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1)
-    chk = bench.verify_answer(p, ncols, nz, 0, ncols, steps, True, nsample=64)
+    chk = bench.verify_answer(p, ncols, nz, 0, ncols, history, True, nsample=64)
     assert chk["columns_checked"] == 64
     assert chk["max_rel_err"] <= 1e-6, chk
 
@@ -239,3 +245,74 @@ def test_standalone_driver_from_namelist_to_regression_file(golden_dir, tmp_path
     assert status == "pass", msgs
     # sections, keys and their order are the reference file's
     assert [l.split("=")[0] for l in out.splitlines()] == [l.split("=")[0] for l in gold.splitlines()]
+
+
+@pytest.mark.parametrize("sf,lam", [(C.SAT_FUNC_VAN_GENUCHTEN, 0.5), (C.SAT_FUNC_VAN_GENUCHTEN, None), (C.SAT_FUNC_BROOKS_COREY, None),
+                                    (C.SAT_FUNC_SMOOTHED_BROOKS_COREY_BZ2, None), (C.SAT_FUNC_SMOOTHED_BROOKS_COREY_BZ3, None)],
+                         ids=["vg_half", "vg", "bc", "sbc_bz2", "sbc_bz3"])
+@pytest.mark.parametrize("nseg", [1, 3])
+def test_soil_classes_and_level_geometry_change_no_bit(sf, lam, nseg):
+    """the byte savers of the column march -- one class byte per cell instead of the soil-parameter streams, per-level
+    upwind weight / gravity distance instead of the per-connection streams -- feed the same numbers into the same
+    arithmetic: residual and Jacobian are bit-identical with them on and off, and equal to the oracle's"""
+    rng = np.random.default_rng(21)
+    ncols, nz = 130, 23
+    prob = P.celia1990(ncols=ncols, nz=nz, perm_mult=np.exp(0.5 * rng.standard_normal(ncols)))
+    n = prob.mesh.ncells_local
+    classes = [(prob.alpha[0] * a, (lam if lam else l), sr) for a, l, sr in ((1.0, 0.45, 0.2772), (1.15, 0.6, 0.21), (0.9, 0.8, 0.3))]
+    pick = rng.integers(0, 3, n)
+    prob.satfunc_type = np.full(n, sf, dtype=np.int32)
+    prob.alpha = np.array([classes[q][0] for q in pick]); prob.lam = np.array([classes[q][1] for q in pick])
+    prob.sat_res = np.array([classes[q][2] for q in pick])
+    x = prob.press_ic + rng.uniform(0, 1.2e5, n)
+    base = {"assembly": "columns", "nseg": nseg, "ksp_type": "bcgs", "pc_type": "bjacobi"}
+    _operator_parity(prob, x, base)                                   # against the oracle, byte savers on (the default)
+    out = {}
+    for cls in (0, 1):
+        for geo in (0, 1):
+            g = P.to_gpu(prob, dict(base, soil_classes=cls, level_geometry=geo))
+            g.soe.SetDtime(prob.dt); g.soe.PreSolve()
+            out[cls, geo] = (g.soe.ComputeResidual(x), g.soe.ComputeJacobian(x)[2])
+    for key in ((0, 1), (1, 0), (1, 1)):
+        assert np.array_equal(out[key][0], out[0, 0][0]) and np.array_equal(out[key][1], out[0, 0][1]), key
+
+
+def test_level_geometry_falls_back_when_columns_differ():
+    """one column with a different layer spacing: the per-connection streams are used (and the answer is the oracle's)"""
+    prob, x = _hetero(ncols=70, nz=19, seed=12)
+    cs = prob.mesh.internal_connections()
+    cs.dist_up = np.asarray(cs.dist_up, dtype=np.float64).copy(); cs.dist_dn = np.asarray(cs.dist_dn, dtype=np.float64).copy()
+    cs.dist_up[5] *= 1.3; cs.dist_dn[40] *= 0.7
+    _operator_parity(prob, x, {"assembly": "columns", "nseg": 1})
+    _operator_parity(prob, x, {"assembly": "columns", "nseg": 3})
+
+
+@pytest.mark.parametrize("name,ptype,dims,ncell", [("thermal_mms_3d", 3, (3, 3, 3), 3), ("thermal_mms_2d", 2, (3, 3, 1), 2)])
+def test_fortran_hosted_thermal_mms(golden_dir, name, ptype, dims, ncell):
+    """fortran/thermal_mms_gpu.F90: the thermal KSP problem driven from Fortran through sysofeqns_thermal_gpu_type (the type-bound
+    Create / SetSoils / SetSolnPrevCLM / PreStepDT / StepDTKSP / GetSoln of fortran/mppgpu_mod.F90); mesh, soil and condition
+    arrays are handed over on standard input; the printed regression block is compared with the reference's baseline"""
+    import os
+    import subprocess
+    from mpp_amd import regression as R
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "fortran", "_build", "thermal_mms_gpu")
+    if not os.path.exists(exe):
+        pytest.skip("no Fortran compiler was available at build time")
+    tp = P.thermal_mms(ptype, *dims)
+    m, cs, bc = tp.mesh, tp.mesh.internal_connections(), tp.bc
+    lines = ["%d %d %d %d %d" % (m.ncells_local, m.nlev, cs.num_connections, bc.num_connections, ncell),
+             "%r %r %r" % (float(tp.t_init), float(tp.cnfac), float(tp.dt))]
+    for arr in (m.vol, m.dz, cs.id_up, cs.id_dn, cs.dist_up, cs.dist_dn, cs.area, np.asarray(cs.unit_vec).ravel(),
+                bc.id_dn, bc.dist_up, bc.dist_dn, bc.area, np.asarray(bc.unit_vec).ravel(), tp.bc_temperature, tp.tkdry, tp.heat_source):
+        a = np.asarray(arr)
+        lines.append(" ".join(("%d" % v) if a.dtype.kind in "iu" else repr(float(v)) for v in a.ravel()))
+    run = subprocess.run([exe], input="\n".join(lines) + "\n", capture_output=True, text=True, timeout=300)
+    if run.returncode != 0 and "error while loading shared libraries" in run.stderr:
+        pytest.skip("Fortran runtime libraries are not installed on this box: " + run.stderr.strip())
+    assert run.returncode == 0, run.stdout + run.stderr
+    gold = open(os.path.join(golden_dir, name + ".regression.baseline")).read()
+    tol = R.Tolerances()
+    tol.update_from_name("general", "1.0e-9 relative")
+    status, msgs = R.compare(run.stdout, gold, tol)
+    assert status == "pass", msgs
