@@ -1225,53 +1225,67 @@ __global__ __launch_bounds__(kBlock) void k_ell_upper(int n, int Kdyn, const int
   x[p] = s * id;
 }
 
-// chained triangular solve (see ChainArgs): one workgroup per tile, flags instead of kernel boundaries.  Values other
-// workgroups wrote during this launch are read and written with agent-scope atomics (they bypass the non-coherent caches).
+// chained triangular solve (see ChainArgs): flags instead of kernel boundaries.  Values other workgroups wrote during this
+// launch are read and written with agent-scope atomics (they bypass the non-coherent caches).
+// Liveness does not rest on the order in which the hardware dispatches workgroups: a workgroup takes a TICKET when it starts
+// running (one returning atomic add) and owns the tiles [ticket * tpb, (ticket + 1) * tpb), in ascending order.  A tile
+// depends on lower-numbered tiles only, tickets are handed out in ascending order to workgroups that are already running,
+// so the workgroup that owns the lowest unfinished tile is always resident and never waits for a tile that nobody runs.
+// The counter is never reset: launch number L of a chain hands out [L * nblocks, (L + 1) * nblocks), ticket_base = L * nblocks
+// (unsigned arithmetic, wrap-around included).  A wait still has a spin budget; exhausting it flags the application,
+// which the host then redoes with per-level launches (Solver::op_pc_apply).
+// waitcnt immediate 0x0F70 = vmcnt(0) with expcnt / lgkmcnt left at their maxima in the gfx9 encoding this file targets
+// (gfx950: vmcnt = bits [3:0] and [15:14], expcnt [6:4], lgkmcnt [11:8]).
 template <int K, bool UPPER>
 __global__ __launch_bounds__(kBlock) void k_ell_chain(ChainArgs a) {
-  const int t = blockIdx.x;
-  const int lo = a.tile_lo[t], hi = a.tile_hi[t];
-  const int p = lo + threadIdx.x;
-  const bool row = p < hi;
+  __shared__ unsigned s_first;
+  if (threadIdx.x == 0) s_first = (atomicAdd(a.ticket, 1u) - a.ticket_base) * (unsigned)a.tiles_per_block;
+  __syncthreads();
+  const int tfirst = (int)s_first, tlast = min(tfirst + a.tiles_per_block, a.ntiles);
   const int kk = K > 0 ? K : a.K;
   constexpr int KR = K > 0 ? K : 1;
-  int c[KR];
-  double w[KR];
-  if (K > 0 && row) {   // the tile's own matrix entries do not depend on anybody: fetch them before waiting
+  for (int t = tfirst; t < tlast; ++t) {
+    const int lo = a.tile_lo[t], hi = a.tile_hi[t];
+    const int p = lo + threadIdx.x;
+    const bool row = p < hi;
+    int c[KR];
+    double w[KR];
+    if (K > 0 && row) {   // the tile's own matrix entries do not depend on anybody: fetch them before waiting
 #pragma unroll
-    for (int k = 0; k < K; ++k) { c[k] = a.col[(size_t)k * a.n + p]; w[k] = a.val[(size_t)k * a.n + p]; }
-  }
-  double s = row ? a.v[p] : 0.0;
-  const double id = (UPPER && row) ? a.idiag[p] : 1.0;
-  if ((int)threadIdx.x < a.dmax) {
-    const int d = a.dep[(size_t)threadIdx.x * a.ntiles + t];
-    if (d >= 0) {
-      unsigned spins = 0;
-      // Flags and solution entries travel as agent-scope (sc1) accesses, which are served at the device's coherence
-      // point; no cache-wide invalidate / write-back (what an acquire / release fence costs, ~30 us per level here).
-      while (__hip_atomic_load(a.flags + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) {
-        __builtin_amdgcn_s_sleep(16);   // ~0.4 us between polls: thousands of waiting tiles must not flood the fabric
-        if (++spins > a.max_spins) { a.sc[S_ERR] = 1.0; break; }
+      for (int k = 0; k < K; ++k) { c[k] = a.col[(size_t)k * a.n + p]; w[k] = a.val[(size_t)k * a.n + p]; }
+    }
+    double s = row ? a.v[p] : 0.0;
+    const double id = (UPPER && row) ? a.idiag[p] : 1.0;
+    if ((int)threadIdx.x < a.dmax) {
+      const int d = a.dep[(size_t)threadIdx.x * a.ntiles + t];
+      if (d >= 0) {
+        unsigned spins = 0;
+        // Flags and solution entries travel as agent-scope (sc1) accesses, which are served at the device's coherence
+        // point; no cache-wide invalidate / write-back (what an acquire / release fence costs, ~30 us per level here).
+        while (__hip_atomic_load(a.flags + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) {
+          __builtin_amdgcn_s_sleep(16);   // ~0.4 us between polls: thousands of waiting tiles must not flood the fabric
+          if (++spins > a.max_spins) { a.sc[S_ERR] = 1.0; break; }
+        }
       }
     }
-  }
-  __syncthreads();
-  if (row) {
-    if (K > 0) {
+    __syncthreads();
+    if (row) {
+      if (K > 0) {
 #pragma unroll
-      for (int k = 0; k < K; ++k)
-        s -= w[k] * (c[k] == p ? 0.0 : __hip_atomic_load(a.v + c[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    } else {
-      for (int k = 0; k < kk; ++k) {
-        const int ck = a.col[(size_t)k * a.n + p];
-        if (ck != p) s -= a.val[(size_t)k * a.n + p] * __hip_atomic_load(a.v + ck, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int k = 0; k < K; ++k)
+          s -= w[k] * (c[k] == p ? 0.0 : __hip_atomic_load(a.v + c[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      } else {
+        for (int k = 0; k < kk; ++k) {
+          const int ck = a.col[(size_t)k * a.n + p];
+          if (ck != p) s -= a.val[(size_t)k * a.n + p] * __hip_atomic_load(a.v + ck, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
+      __hip_atomic_store(a.v + p, UPPER ? s * id : s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __hip_atomic_store(a.v + p, UPPER ? s * id : s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's sc1 stores have been acknowledged at the coherence point ...
+    __syncthreads();                      // ... and so have every other wave's, before the tile is declared done
+    if (threadIdx.x == 0) __hip_atomic_store(a.flags + t, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's sc1 stores have been acknowledged at the coherence point ...
-  __syncthreads();                      // ... and so have every other wave's, before the tile is declared done
-  if (threadIdx.x == 0) __hip_atomic_store(a.flags + t, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2041,7 +2055,7 @@ void launch_ilu_repack(long long total, const int *slot, const double *lu, doubl
 }
 void launch_ell_chain(const ChainArgs &a, hipStream_t stream) {
   if (a.ntiles <= 0) return;
-  const dim3 grid(a.ntiles);
+  const dim3 grid((a.ntiles + a.tiles_per_block - 1) / a.tiles_per_block);
   const bool up = a.idiag != nullptr;
   switch (a.K) {
     case 1: if (up) LAUNCH((k_ell_chain<1, true>), grid, a); else LAUNCH((k_ell_chain<1, false>), grid, a); break;

@@ -187,11 +187,11 @@ void launch_jacobi_setup(int n, const int *diag_slot, const double *val, double 
 void launch_ilu_factor_program(const long long *ptr, const int *prog, const int *rows, const int *diag_slot, int lo, int hi,
                                double *lu, double *idiag, hipStream_t stream);
 void launch_ilu_repack(long long total, const int *slot, const double *lu, double *out, hipStream_t stream);  // out[e] = slot[e] >= 0 ? lu[slot[e]] : 0
-// The same solves as ONE launch per triangle: a workgroup owns a tile of <= 256 consecutive rows of one level and waits
-// (spinning on per-tile flags) only for the tiles that hold its rows' dependencies, so the tail of a level overlaps the
-// head of the next and no per-level launch gap is paid.  Workgroups are dispatched in tile order, a tile depends on
-// lower-numbered tiles only, so the lowest unfinished tile is always resident and can finish.  A wait that exceeds its
-// spin budget sets sc[S_ERR] (checked at the next scalar read-back) instead of hanging.
+// The same solves as ONE launch per triangle: a tile is <= 256 consecutive rows of one level; its workgroup waits (spinning
+// on per-tile flags) only for the tiles that hold its rows' dependencies, so the tail of a level overlaps the head of the
+// next and no per-level launch gap is paid.  Workgroups take their tiles by ticket (see k_ell_chain), so the lowest
+// unfinished tile always belongs to a running workgroup whatever the dispatch order.  A wait that exceeds its spin
+// budget sets sc[S_ERR]; the host checks it behind every chained application and redoes that application per level.
 struct ChainArgs {
   int n, K;                        // rows; ELL width
   const int *col;                  // [K][n] positions (in this triangle's level order) of the dependencies; self = padding
@@ -205,6 +205,9 @@ struct ChainArgs {
   double *v;                       // solved in place
   double *sc;                      // sc[S_ERR] receives 1.0 on a timed-out wait
   unsigned max_spins;              // polls (~0.4 us apart) before a wait gives up
+  unsigned *ticket;                // monotonic ticket counter of this chain (never reset)
+  unsigned ticket_base;            // tickets handed out by earlier launches of this chain (mod 2^32)
+  int tiles_per_block;             // consecutive tiles a workgroup owns per ticket
 };
 void launch_ell_chain(const ChainArgs &a, hipStream_t stream);
 void launch_ell_lower_level(int n, int K, const int *col, const double *val, int lo, int hi, double *y, hipStream_t stream);

@@ -211,8 +211,9 @@ struct Solver {
   // chained triangular solves (ChainArgs): tiles of one level, the tiles each waits for, completion flags
   struct Chain {
     DevBuf<int> tile_lo, tile_hi, dep;
-    DevBuf<unsigned> flags;
-    int ntiles = 0;
+    DevBuf<unsigned> flags, ticket;
+    int ntiles = 0, tiles_per_block = 1, nblocks = 0;
+    unsigned launches = 0;
     bool ok = false;
   } chainL, chainU;
   static constexpr int kChainDeps = 8;
@@ -688,7 +689,7 @@ struct Solver {
       if (ns > 0 && !has_src) { d_src.alloc(n); d_src.zero(stream); has_src = true; }
       th_liq.assign(n, 0.0); th_ice.assign(n, 0.0); th_snow.assign(n, 0.0); th_tuning.assign(n, 1.0); th_nsnow.assign(n, 0);
     }
-    if (vertical_only && columns && nz >= 2) {   // the column march computes the first slot of a row instead of loading it
+    if (vertical_only && columns && nz >= 2 && !th && !thermal) {   // the column march computes the first slot of a row instead of loading it
       for (int col = 0; col < ncols; col += std::max(1, ncols / 257)) {
         const int tile = col >> 6, lane = col & 63, tw = std::min(64, ncols - (tile << 6));
         const long long st = (long long)tile * 64 * (3LL * nz - 2);
@@ -1315,7 +1316,7 @@ struct Solver {
         if (!solved) launch_gather(nrow, d_lrows.p, r, ilu_y.p, stream);
       }
       if (solved) {}
-      else if (opt.ilu_graph) {
+      else if (opt.ilu_graph && !under_rocprofiler()) {
         if (!ilu_graph_exec) {
           HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
           ilu_solve_levels();
@@ -1326,6 +1327,16 @@ struct Solver {
       } else ilu_solve_levels();
       launch_gather(nrow, d_posU.p, ilu_x.p, z, stream);             // back to the internal row order
     } else launch_copy(nred, r, z, stream);
+  }
+  // rocprofv3's kernel tracing (rocprofiler-sdk of ROCm 7.2) segfaults inside its interception of a hipGraph launch with
+  // several hundred kernel nodes (764 at 128^3; 141 nodes at 24^3 are fine): profiles/r02_rocprofv3_graph_replay_128.log.
+  // Under the profiler the level solves are therefore launched one by one -- the same kernels, visible in the trace.
+  static bool under_rocprofiler() {
+    static const bool yes = [] {
+      const char *pre = std::getenv("LD_PRELOAD"), *tool = std::getenv("ROCP_TOOL_LIBRARIES");
+      return (pre && std::strstr(pre, "rocprofiler")) || (tool && *tool);
+    }();
+    return yes;
   }
   void op_BA(const double *v, double *t) {  // t = M^{-1} A v  (left preconditioning)
     op_spmv(v, Wk.p);
@@ -2352,7 +2363,13 @@ struct Solver {
       }
     ch.tile_lo.upload(tlo, stream); ch.tile_hi.upload(thi, stream); ch.dep.upload(dep, stream);
     ch.flags.alloc(nt); ch.flags.zero(stream);
+    ch.ticket.alloc(1); ch.ticket.zero(stream);
     ch.ntiles = nt;
+    // one returning atomic per ticket: a single counter serves ~88 of them per microsecond (MI355X_MICROARCH.md, dequeue), so
+    // long chains hand out several consecutive tiles per ticket
+    ch.tiles_per_block = nt >= (1 << 18) ? 4 : (nt >= (1 << 16) ? 2 : 1);
+    ch.nblocks = (nt + ch.tiles_per_block - 1) / ch.tiles_per_block;
+    ch.launches = 0;
     ch.ok = true;
   }
   // one 8-byte read-back behind every chained application (the queue drains once per application: < 1 % of a 1-14 ms solve)
@@ -2380,11 +2397,13 @@ struct Solver {
   void ilu_solve_chained() {
     const unsigned ep = ++chain_epoch;
     ChainArgs a{nrow, ell_KL, d_Lcol.p, d_Lval.p, nullptr, chainL.tile_lo.p, chainL.tile_hi.p, chainL.dep.p, chainL.ntiles,
-                kChainDeps, chainL.flags.p, ep, ilu_y.p, sc.p, opt.ilu_chain_spins};
+                kChainDeps, chainL.flags.p, ep, ilu_y.p, sc.p, opt.ilu_chain_spins, chainL.ticket.p,
+                chainL.launches++ * (unsigned)chainL.nblocks, chainL.tiles_per_block};
     launch_ell_chain(a, stream);
     launch_gather(nrow, d_l2u.p, ilu_y.p, ilu_x.p, stream);
     ChainArgs b{nrow, ell_KU, d_Ucol.p, d_Uval.p, d_Uidiag.p, chainU.tile_lo.p, chainU.tile_hi.p, chainU.dep.p, chainU.ntiles,
-                kChainDeps, chainU.flags.p, ep, ilu_x.p, sc.p, opt.ilu_chain_spins};
+                kChainDeps, chainU.flags.p, ep, ilu_x.p, sc.p, opt.ilu_chain_spins, chainU.ticket.p,
+                chainU.launches++ * (unsigned)chainU.nblocks, chainU.tiles_per_block};
     launch_ell_chain(b, stream);
   }
 

@@ -57,8 +57,9 @@ def _operator_parity(prob, x, options):
     np.maximum.at(rowscale, np.repeat(np.arange(n), np.diff(rp)), np.abs(val))
     assert np.abs(val_g - val).max() <= RTOL_OP * np.abs(val).max()
     assert (np.abs(val_g - val) <= 1e-10 * np.repeat(rowscale, np.diff(rp))).all()
-    # residual: compare against the size of the cancelling terms ~ |J| |x - x0| + |F|
-    fscale = np.abs(f_o) + rowscale * 1.0
+    # residual: compare against the size of the cancelling terms ~ |J| |x - x0| + |F| (the fluxes of a row are each of the
+    # order |J| |dP| and cancel to |F|; x0 = the state the accumulation term was taken at)
+    fscale = np.abs(f_o) + rowscale * max(1.0, float(np.abs(x - prob.press_ic).max()) * 1e-3)
     assert (np.abs(f_g - f_o) <= 1e-11 * fscale + 1e-25).all(), np.abs(f_g - f_o).max()
     v = np.random.default_rng(7).standard_normal(n)
     from oracle import vsfm_oracle as VO

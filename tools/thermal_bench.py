@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--cpu-n", type=int, default=64, help="grid size of the CPU-oracle sample (0 = skip)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="extra mppgpu_set_option pairs")
+    ap.add_argument("--rtol-sweep", default="", help="comma-separated ksp_rtol values solved one after the other on the same problem "
+                                                     "(time, iterations and error against the manufactured solution for each)")
     a = ap.parse_args()
     t0 = time.perf_counter()
     tp = P.thermal_mms(3, a.n, a.n, a.n, replicate_reference_soil_indexing=False)
@@ -74,6 +76,23 @@ def main():
                            "peak": 8000.0, "achieved": round(by / (ms * 1e-3) / 1e9, 1), "frac": round(by / (ms * 1e-3) / 1e9 / 8000.0, 4),
                            "bytes_per_launch": by, "avg_apply_ms": round(ms, 4), "levels": 2 * (3 * a.n - 2),
                            "note": "latency-bound by the number of dependency levels"}
+    if a.rtol_sweep:
+        # time to a given accuracy: PETSc's default rtol 1e-5 (on the preconditioned residual) stops far above the discretisation
+        # error on fine grids, so every timing is reported next to the error it bought
+        sweep = []
+        for r in [float(x) for x in a.rtol_sweep.split(",")]:
+            g.soe.SetOption("ksp_rtol", r)
+            g.soe.PreStepDT()
+            g.soe.synchronize()
+            t0 = time.perf_counter()
+            conv_r, _ = g.soe.StepDT(tp.dt, 1)
+            g.soe.synchronize()
+            dt_r = time.perf_counter() - t0
+            sweep.append({"ksp_rtol": r, "converged": conv_r, "linear_iterations": g.soe.last_linear_iterations, "step_s": round(dt_r, 4),
+                          "max_error_vs_manufactured_solution": float(np.abs(g.soe.GetSoln() - tp.exact).max())})
+            print("rtol %.1e: %d its, %.3f s, error %.4g K" % (r, sweep[-1]["linear_iterations"], dt_r,
+                                                                sweep[-1]["max_error_vs_manufactured_solution"]), file=sys.stderr, flush=True)
+        out["rtol_sweep"] = sweep
     if a.cpu_n > 0:
         out["cpu_baseline"] = cpu_baseline(a.cpu_n, a.n, a.rtol)
     print(json.dumps(out), flush=True)
