@@ -147,6 +147,7 @@ __global__ __launch_bounds__(kBlock) void k_assemble_cols(ColsArgs a) {
     // first CSR slot of row (k, c) -- the pattern of a vertical-only grid in the tiled level-major order (checked on the host)
     const int slot_tile = tile * 64 * (3 * nz - 2);
     auto row_slot = [&](int k) -> int {
+      if (nz == 1) return slot_tile + lane;          // one-cell columns: a diagonal matrix
       if (k == 0) return slot_tile + 2 * lane;
       if (k == nz - 1) return slot_tile + 2 * tw + 3 * (nz - 2) * tw + 2 * lane;
       return slot_tile + 2 * tw + 3 * ((k - 1) * tw + lane);
@@ -213,7 +214,8 @@ __global__ __launch_bounds__(kBlock) void k_assemble_cols(ColsArgs a) {
         L.sf = ca.satf ? (int)ca.satf[i] : ca.sat_func;
         if (lin_por) { L.pref = ldnt(ca.por_pref + i); L.slope = ldnt(ca.por_slope + i); } else { L.pref = L.slope = 0.0; }
       } else {
-        L.por = ldnt(a.porvol + i); L.vol = 1.0;   // (constant) porosity only ever multiplies the volume here
+        L.por = a.lev_porvol ? a.lev_porvol[k] : ldnt(a.porvol + i);   // (constant) porosity only ever multiplies the volume here
+        L.vol = 1.0;
         L.pref = L.slope = 0.0; L.sf = SAT_T;
       }
       if (L.sf == kSatSBC && !classes) { L.pu = ca.sbc_pu[i]; L.ps = ca.sbc_ps[i]; L.b2 = ca.sbc_b2[i]; L.b3 = ca.sbc_b3[i]; }
@@ -591,18 +593,6 @@ __global__ __launch_bounds__(kBlock) void k_spmv_row(int n, const int *__restric
   y[i] = sum;
 }
 
-// variant 7: variant 0 with every once-streamed access (rowptr, val, col, y) marked non-temporal
-__global__ __launch_bounds__(kBlock) void k_spmv_row_nt(int n, const int *__restrict__ rowptr, const int *__restrict__ col,
-                                                        const double *__restrict__ val, const double *__restrict__ x,
-                                                        double *__restrict__ y) {
-  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= (size_t)n) return;
-  const int s = __builtin_nontemporal_load(rowptr + i), e = __builtin_nontemporal_load(rowptr + i + 1);
-  double sum = 0.0;
-  for (int k = s; k < e; ++k) sum += __builtin_nontemporal_load(val + k) * x[__builtin_nontemporal_load(col + k)];
-  __builtin_nontemporal_store(sum, y + i);
-}
-
 // variant 1: CSR-stream.  The block's val/col segment is read with fully coalesced loads, the products are
 // staged in LDS, then each lane sums its row from LDS in row order (same sum order as variant 0).
 constexpr int kStreamCap = 256 * 8;  // products per block in LDS (16 KiB); larger blocks fall back to variant 0
@@ -632,135 +622,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_stream(int n, const int *__rest
   }
 }
 
-// variant 2: wave-level CSR-stream.  Each 64-lane wave owns 64-row tiles (grid-stride); the tile's val/col
-// segment is read with perfectly coalesced 512 B / 256 B wave loads marked non-temporal (streamed once, do not
-// displace x in L2), products go through a private 4 KiB LDS slab (no block barrier, DS ops of one wave execute
-// in order), then lane r sums row r in entry order -- bitwise the same sums as variant 0.
-constexpr int kWaveCap = 64 * 8;
-template <int kRowTilesPerWave, bool NT>
-__global__ __launch_bounds__(kBlock) void k_spmv_wave(int n, const int *__restrict__ rowptr,
-                                                      const int *__restrict__ col, const double *__restrict__ val,
-                                                      const double *__restrict__ x, double *__restrict__ y) {
-  __shared__ double prod[kBlock / 64][kWaveCap];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  double *lp = prod[w];
-  const int ntiles = (n + 63) >> 6;
-  // kRowTilesPerWave consecutive 64-row tiles per wave: contiguous streams, x re-use in L1 across neighbouring levels
-  const int tile0 = (blockIdx.x * (kBlock / 64) + w) * kRowTilesPerWave;
-  for (int tile = tile0; tile < min(tile0 + kRowTilesPerWave, ntiles); ++tile) {
-    const int r0 = tile << 6;
-    const int nrows = min(64, n - r0);
-    int rs = 0, re = 0;
-    if (lane < nrows) {
-      rs = NT ? __builtin_nontemporal_load(rowptr + r0 + lane) : rowptr[r0 + lane];
-      re = NT ? __builtin_nontemporal_load(rowptr + r0 + lane + 1) : rowptr[r0 + lane + 1];
-    }
-    const int s0 = __shfl(rs, 0, 64);
-    const int e0 = __shfl(re, nrows - 1, 64);
-    const int cnt = e0 - s0;
-    if (cnt <= kWaveCap) {
-#pragma unroll 4
-      for (int k = lane; k < cnt; k += 64) {
-        const double v = NT ? __builtin_nontemporal_load(val + s0 + k) : val[s0 + k];
-        const int c = NT ? __builtin_nontemporal_load(col + s0 + k) : col[s0 + k];
-        lp[k] = v * x[c];
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      if (lane < nrows) {
-        double sum = 0.0;
-        for (int k = rs - s0; k < re - s0; ++k) sum += lp[k];
-        if (NT) __builtin_nontemporal_store(sum, y + r0 + lane); else y[r0 + lane] = sum;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-    } else if (lane < nrows) {
-      double sum = 0.0;
-      for (int k = rs; k < re; ++k) sum += val[k] * x[col[k]];
-      y[r0 + lane] = sum;
-    }
-  }
-}
-
-// variant 4: batched wave-level CSR-stream.  Variant 2 is latency-bound: each 64-row tile costs three dependent
-// memory round trips (row extents -> val/col -> x).  Here one wave takes T consecutive tiles and issues each phase
-// for all T tiles before consuming any of it, so ~T times more bytes are in flight per round trip:
-//   A  tile extents by scalar loads (wave-uniform addresses) + per-lane row extents (consumed only in phase D)
-//   B  val/col segments of all T tiles: fully coalesced, non-temporal (streamed once)
-//   C  x gathers for all T tiles (+-tw rows away in the tiled layout: L1/L2 hits after first touch)
-//   D  per tile: products -> 4 KiB LDS slab of the wave -> lane r sums row r in entry order (same sums as variant 0)
-// J = max entries per lane and tile = longest row of the matrix (host-checked, <= 8).
-template <int T, int J>
-__global__ __launch_bounds__(kBlock) void k_spmv_batch(int n, const int *__restrict__ rowptr,
-                                                       const int *__restrict__ col, const double *__restrict__ val,
-                                                       const double *__restrict__ x, double *__restrict__ y) {
-  __shared__ double prod[kBlock / 64][64 * J];
-  const int lane = threadIdx.x & 63;
-  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  double *lp = prod[w];
-  const int ntiles = (n + 63) >> 6;
-  const int tile0 = (blockIdx.x * (kBlock / 64) + w) * T;
-  if (tile0 >= ntiles) return;
-  // phase A
-  int s0[T + 1];
-#pragma unroll
-  for (int t = 0; t <= T; ++t) s0[t] = rowptr[min((tile0 + t) << 6, n)];
-  int rs[T], re[T];
-#pragma unroll
-  for (int t = 0; t < T; ++t) {
-    const int r = ((tile0 + t) << 6) + lane;
-    const bool ok = r < n;
-    rs[t] = ok ? __builtin_nontemporal_load(rowptr + r) : 0;
-    re[t] = ok ? __builtin_nontemporal_load(rowptr + r + 1) : 0;
-  }
-  // phase B
-  double v[T][J];
-  int c[T][J];
-#pragma unroll
-  for (int t = 0; t < T; ++t) {
-    const int cnt = s0[t + 1] - s0[t];
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-      const int k = lane + 64 * j;
-      const bool ok = k < cnt;
-      v[t][j] = ok ? __builtin_nontemporal_load(val + s0[t] + k) : 0.0;
-      c[t][j] = ok ? __builtin_nontemporal_load(col + s0[t] + k) : 0;
-    }
-  }
-  // phase C
-#pragma unroll
-  for (int t = 0; t < T; ++t) {
-    const int cnt = s0[t + 1] - s0[t];
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-      const bool ok = lane + 64 * j < cnt;
-      v[t][j] = ok ? v[t][j] * x[c[t][j]] : 0.0;
-    }
-  }
-  // phase D
-#pragma unroll
-  for (int t = 0; t < T; ++t) {
-    const int cnt = s0[t + 1] - s0[t];
-    if (cnt <= 0) continue;  // wave-uniform: tiles past the end
-#pragma unroll
-    for (int j = 0; j < J; ++j)
-      if (lane + 64 * j < cnt) lp[lane + 64 * j] = v[t][j];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int r = ((tile0 + t) << 6) + lane;
-    if (r < n) {
-      double sum = 0.0;
-      for (int k = rs[t] - s0[t]; k < re[t] - s0[t]; ++k) sum += lp[k];
-      __builtin_nontemporal_store(sum, y + r);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-  }
-}
-
-// variant 8: software-pipelined wave-level CSR-stream.  One wave walks TPW consecutive 64-row tiles; while the x
+// variant 17: software-pipelined wave-level CSR-stream.  One wave walks TPW consecutive 64-row tiles; while the x
 // gathers, the LDS row sums and the y store of tile t run, the val/col/rowptr loads of tile t+1 are already in
 // flight (issued AFTER the gathers of tile t: vmcnt retires in order, so the gathers can be waited for while the
 // younger prefetch stays outstanding).  Steady state costs one memory round trip per tile instead of three.
@@ -1073,32 +935,6 @@ __global__ __launch_bounds__(kBlock) void k_spmv_pipe_c_dots(int n, int tpw, int
   }
 }
 
-// variant 3: one lane per row with all loads of a row issued up front (rows of <= 8 entries; longer rows finish
-// in a tail loop).  Padding entries multiply x[i] by +0.0, which leaves the sum unchanged.
-__global__ __launch_bounds__(kBlock) void k_spmv_row8(int n, const int *__restrict__ rowptr,
-                                                      const int *__restrict__ col, const double *__restrict__ val,
-                                                      const double *__restrict__ x, double *__restrict__ y) {
-  const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
-  const int s = rowptr[i], e = rowptr[i + 1];
-  double v[8];
-  int c[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const bool ok = s + j < e;
-    v[j] = ok ? __builtin_nontemporal_load(val + s + j) : 0.0;
-    c[j] = ok ? __builtin_nontemporal_load(col + s + j) : i;
-  }
-  double xs[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) xs[j] = x[c[j]];
-  double sum = 0.0;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) sum += v[j] * xs[j];
-  for (int k = s + 8; k < e; ++k) sum += val[k] * x[col[k]];
-  y[i] = sum;
-}
-
 // ------------------------------------------------------------------------------------------------
 // block-Jacobi preconditioner, one block per soil column = exact LU of the column's tridiagonal (Thomas).
 // factor: l_k = a_k / b'_{k-1}, b'_k = b_k - l_k c_{k-1};  stored: l, 1/b', c   (level-major, coalesced)
@@ -1239,9 +1075,13 @@ __global__ __launch_bounds__(kBlock) void k_ell_upper(int n, int Kdyn, const int
 template <int K, bool UPPER>
 __global__ __launch_bounds__(kBlock) void k_ell_chain(ChainArgs a) {
   __shared__ unsigned s_first;
-  if (threadIdx.x == 0) s_first = (atomicAdd(a.ticket, 1u) - a.ticket_base) * (unsigned)a.tiles_per_block;
-  __syncthreads();
-  const int tfirst = (int)s_first, tlast = min(tfirst + a.tiles_per_block, a.ntiles);
+  int tfirst = blockIdx.x * a.tiles_per_block;      // a.ticket == nullptr: tiles in dispatch order (see ChainArgs::ticket)
+  if (a.ticket) {
+    if (threadIdx.x == 0) s_first = (atomicAdd(a.ticket, 1u) - a.ticket_base) * (unsigned)a.tiles_per_block;
+    __syncthreads();
+    tfirst = (int)s_first;
+  }
+  const int tlast = min(tfirst + a.tiles_per_block, a.ntiles);
   const int kk = K > 0 ? K : a.K;
   constexpr int KR = K > 0 ? K : 1;
   for (int t = tfirst; t < tlast; ++t) {
@@ -1975,42 +1815,15 @@ void launch_spmv(int variant, int n, int max_row_nnz, const int *rowptr, const i
                  const double *x, double *y, hipStream_t stream) {
   if (n <= 0) return;
   if (variant == 1) LAUNCH(k_spmv_stream, dim3(nblk(n)), n, rowptr, col, val, x, y);
-  else if (variant == 2 || (variant >= 10 && variant <= 16)) {
-    const int T = variant == 10 ? 1 : variant == 11 ? 2 : variant == 12 ? 8 : variant == 13 ? 16 : variant == 15 ? 32 : 4;
-    const long long tiles = ((long long)n + 63) / 64, waves = (tiles + T - 1) / T;
-    const dim3 grid((int)((waves + 3) / 4));
-    switch (variant) {
-      case 10: LAUNCH((k_spmv_wave<1, true>), grid, n, rowptr, col, val, x, y); break;
-      case 11: LAUNCH((k_spmv_wave<2, true>), grid, n, rowptr, col, val, x, y); break;
-      case 12: LAUNCH((k_spmv_wave<8, true>), grid, n, rowptr, col, val, x, y); break;
-      case 13: LAUNCH((k_spmv_wave<16, true>), grid, n, rowptr, col, val, x, y); break;
-      case 14: LAUNCH((k_spmv_wave<4, false>), grid, n, rowptr, col, val, x, y); break;
-      case 15: LAUNCH((k_spmv_wave<32, true>), grid, n, rowptr, col, val, x, y); break;
-      case 16: LAUNCH((k_spmv_wave<4, true>), grid, n, rowptr, col, val, x, y); break;
-      default: LAUNCH((k_spmv_wave<4, true>), grid, n, rowptr, col, val, x, y);
-    }
-  } else if (variant == 3) LAUNCH(k_spmv_row8, dim3(nblk(n)), n, rowptr, col, val, x, y);
-  else if (variant == 7) LAUNCH(k_spmv_row_nt, dim3(nblk(n)), n, rowptr, col, val, x, y);
-  else if ((variant == 8 || variant == 9 || variant == 17 || variant == 18) && max_row_nnz <= 8) {
-    const int tpw = variant == 8 ? 8 : variant == 9 ? 16 : variant == 17 ? 4 : 32;
+  else if (variant == 17 && max_row_nnz <= 8) {
+    const int tpw = 4;
     const long long tiles = ((long long)n + 63) / 64, waves = (tiles + tpw - 1) / tpw;
     const dim3 grid((int)((waves + 3) / 4));
     if (max_row_nnz <= 3) LAUNCH(k_spmv_pipe<3>, grid, n, tpw, rowptr, col, val, x, y);
     else if (max_row_nnz <= 7) LAUNCH(k_spmv_pipe<7>, grid, n, tpw, rowptr, col, val, x, y);
     else LAUNCH(k_spmv_pipe<8>, grid, n, tpw, rowptr, col, val, x, y);
   }
-  else if (variant >= 4 && variant <= 6 && max_row_nnz <= 8) {
-    // 4: T=4, 5: T=2, 6: T=8 (J picked from the longest row)
-    const int T = variant == 5 ? 2 : (variant == 6 ? 8 : 4);
-    const long long tiles = ((long long)n + 63) / 64, waves = (tiles + T - 1) / T;
-    const dim3 grid((int)((waves + 3) / 4));
-#define SPMV_BATCH(TT, JJ) LAUNCH((k_spmv_batch<TT, JJ>), grid, n, rowptr, col, val, x, y)
-    if (max_row_nnz <= 3) { if (T == 2) SPMV_BATCH(2, 3); else if (T == 8) SPMV_BATCH(8, 3); else SPMV_BATCH(4, 3); }
-    else if (max_row_nnz <= 7) { if (T == 2) SPMV_BATCH(2, 7); else SPMV_BATCH(4, 7); }
-    else { if (T == 2) SPMV_BATCH(2, 8); else SPMV_BATCH(4, 8); }
-#undef SPMV_BATCH
-  }
-  else LAUNCH(k_spmv_row, dim3(nblk(n)), n, rowptr, col, val, x, y);
+  else LAUNCH(k_spmv_row, dim3(nblk(n)), n, rowptr, col, val, x, y);   // variant 0, and rows of more than 8 entries
 }
 
 void launch_tri_factor(const TriArgs &a, hipStream_t stream) {

@@ -52,6 +52,7 @@ struct ColsArgs {
   const double *cls_table = nullptr;
   int ncls = 0;
   const double *lev_upw = nullptr, *lev_dgrav = nullptr;
+  const double *lev_porvol = nullptr;   // likewise porosity x volume per level when every column agrees (constant-porosity soils)
   const double *accum_prev, *src;   // src: dense mass-rate source [kmol/s], nullptr if none
   double *F;             // residual out (MODE 0,2)
   double *val;           // CSR values out (MODE 1,2), level-major analytic layout
@@ -134,8 +135,9 @@ void launch_conn_flux(const CellArrays &cell, const ConnArrays &conn, const int 
 void launch_cell_var(const CellArrays &cell, int n, int var_type, double *out, hipStream_t stream);
 
 // ---- sparse linear algebra ----
-// variants: 0 lane-per-row, 1 block CSR-stream, 2 wave CSR-stream, 3 lane-per-row unrolled, 4/5/6 batched wave
-// CSR-stream with 4/2/8 tiles per wave (needs max_row_nnz <= 8, else falls back to variant 0)
+// the 32-bit CSR kernels: variant 0 lane-per-row (any row length), 1 block CSR-stream (small, cache-resident matrices),
+// 17 software-pipelined wave CSR-stream (rows of <= 8 entries, else variant 0); the solver's default at scale is the compact
+// index below (20 / 21) or its windowed form (22 / 23).  Every variant sums a row in entry order.
 void launch_spmv(int variant, int n, int max_row_nnz, const int *rowptr, const int *col, const double *val,
                  const double *x, double *y, hipStream_t stream);
 // the pipelined kernel on the compact index (16-bit in-tile row offsets + 16-bit column offsets from the tile's first

@@ -165,6 +165,7 @@ struct Options {
   bool ell_assembly = true;    // general assembly on the ELL copy of the incidence lists (k_flux_rows_ell)
   int ilu_chain = 1;           // ILU(0) solves: one launch per triangle, tiles chained by flags (1: where it pays, 2: always;
                                // 0: one launch per level)
+  bool ilu_chain_tickets = false;  // chained ILU(0): tiles handed out by an atomic ticket instead of in dispatch order (kernels.hpp)
   unsigned ilu_chain_spins = 1u << 22;   // polls (~0.4 us apart) before a chained wait gives up and the apply is redone per level
   bool ls_ahead = true;        // the line search's first reductions ride behind the Krylov solver's last update
   bool wide_xr = true;         // BiCGStab update kernel on a one-pair-per-lane grid (large vectors)

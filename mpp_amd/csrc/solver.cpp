@@ -101,9 +101,9 @@ struct Solver {
   DevBuf<signed char> d_satf;
   // byte savers of the column march (ColsArgs): soil classes and per-level connection geometry
   DevBuf<unsigned char> d_soil_cls;
-  DevBuf<double> d_cls_table, d_lev_upw, d_lev_dgrav;
+  DevBuf<double> d_cls_table, d_lev_upw, d_lev_dgrav, d_lev_porvol;
   int ncls = 0;
-  bool lev_geo = false;
+  bool lev_geo = false, lev_pv = false;
   DevBuf<double> d_por_pref, d_por_slope;
   int density_type = MPPGPU_DENSITY_CONSTANT;  // RichODEPressureAuxVarInit default (AuxType :120)
   double temperature = 273.15 + 25.0, frac_liq = 1.0;
@@ -689,12 +689,12 @@ struct Solver {
       if (ns > 0 && !has_src) { d_src.alloc(n); d_src.zero(stream); has_src = true; }
       th_liq.assign(n, 0.0); th_ice.assign(n, 0.0); th_snow.assign(n, 0.0); th_tuning.assign(n, 1.0); th_nsnow.assign(n, 0);
     }
-    if (vertical_only && columns && nz >= 2 && !th && !thermal) {   // the column march computes the first slot of a row instead of loading it
+    if (vertical_only && columns && !th && !thermal) {   // the column march computes the first slot of a row instead of loading it
       for (int col = 0; col < ncols; col += std::max(1, ncols / 257)) {
         const int tile = col >> 6, lane = col & 63, tw = std::min(64, ncols - (tile << 6));
         const long long st = (long long)tile * 64 * (3LL * nz - 2);
         for (int k = 0; k < nz; ++k) {
-          const long long want = k == 0 ? st + 2 * lane : (k == nz - 1 ? st + 2 * tw + 3LL * (nz - 2) * tw + 2 * lane : st + 2 * tw + 3LL * ((k - 1) * (long long)tw + lane));
+          const long long want = nz == 1 ? st + lane : k == 0 ? st + 2 * lane : (k == nz - 1 ? st + 2 * tw + 3LL * (nz - 2) * tw + 2 * lane : st + 2 * tw + 3LL * ((k - 1) * (long long)tw + lane));
           if (h_rowptr[cell_index(k, col)] != want) throw Error("internal: CSR pattern of the column layout is not the expected one");
         }
       }
@@ -799,6 +799,14 @@ struct Solver {
     if (vertical_only && columns && !th) {   // the column march streams porosity x volume as one operand
       for (int i = 0; i < n; ++i) a[i] = a[i] * vol[int2ext[i]];
       d_porvol.upload(a, stream);
+      lev_pv = opt.level_geometry && por_slope.empty();   // ... or reads it per level when every column agrees
+      std::vector<double> lp(nz, 0.0);
+      for (int k = 0; k < nz && lev_pv; ++k) {
+        lp[k] = a[cell_index(k, 0)];
+        for (int col = 1; col < ncols; ++col)
+          if (a[cell_index(k, col)] != lp[k]) { lev_pv = false; break; }
+      }
+      if (lev_pv) d_lev_porvol.upload(lp, stream);
     }
     build_soil_classes();
     if (mixed_satf) {
@@ -1022,6 +1030,7 @@ struct Solver {
     a.DqA = d_DqA.p; a.porvol = d_porvol.p;
     if (ncls > 0) { a.soil_cls = d_soil_cls.p; a.cls_table = d_cls_table.p; a.ncls = ncls; }
     if (lev_geo) { a.lev_upw = d_lev_upw.p; a.lev_dgrav = d_lev_dgrav.p; }
+    if (lev_pv) a.lev_porvol = d_lev_porvol.p;
     return a;
   }
   GenArgs gen_args(const double *P, double *Fout) const {
@@ -2397,13 +2406,15 @@ struct Solver {
   void ilu_solve_chained() {
     const unsigned ep = ++chain_epoch;
     ChainArgs a{nrow, ell_KL, d_Lcol.p, d_Lval.p, nullptr, chainL.tile_lo.p, chainL.tile_hi.p, chainL.dep.p, chainL.ntiles,
-                kChainDeps, chainL.flags.p, ep, ilu_y.p, sc.p, opt.ilu_chain_spins, chainL.ticket.p,
-                chainL.launches++ * (unsigned)chainL.nblocks, chainL.tiles_per_block};
+                kChainDeps, chainL.flags.p, ep, ilu_y.p, sc.p, opt.ilu_chain_spins, opt.ilu_chain_tickets ? chainL.ticket.p : nullptr,
+                chainL.launches * (unsigned)chainL.nblocks, opt.ilu_chain_tickets ? chainL.tiles_per_block : 1};
+    if (opt.ilu_chain_tickets) ++chainL.launches;
     launch_ell_chain(a, stream);
     launch_gather(nrow, d_l2u.p, ilu_y.p, ilu_x.p, stream);
     ChainArgs b{nrow, ell_KU, d_Ucol.p, d_Uval.p, d_Uidiag.p, chainU.tile_lo.p, chainU.tile_hi.p, chainU.dep.p, chainU.ntiles,
-                kChainDeps, chainU.flags.p, ep, ilu_x.p, sc.p, opt.ilu_chain_spins, chainU.ticket.p,
-                chainU.launches++ * (unsigned)chainU.nblocks, chainU.tiles_per_block};
+                kChainDeps, chainU.flags.p, ep, ilu_x.p, sc.p, opt.ilu_chain_spins, opt.ilu_chain_tickets ? chainU.ticket.p : nullptr,
+                chainU.launches * (unsigned)chainU.nblocks, opt.ilu_chain_tickets ? chainU.tiles_per_block : 1};
+    if (opt.ilu_chain_tickets) ++chainU.launches;
     launch_ell_chain(b, stream);
   }
 
@@ -2565,7 +2576,12 @@ struct Solver {
       else if (val == "cp") opt.linesearch_type = 4;
       else throw Error("Unknown default linesearch option '" + val + "' (basic | bt | l2 | cp)");   // SystemOfEquationsBaseType.F90:424-430
     } else if (key == "use_dynamic_linesearch") opt.use_dynamic_linesearch = num() != 0;
-    else if (key == "spmv_variant") opt.spmv_variant = (int)num();
+    else if (key == "spmv_variant") {
+      const int v = (int)num();
+      if (!(v == -1 || v == 0 || v == 1 || v == 17 || (v >= 20 && v <= 23)))
+        throw Error("spmv_variant: -1 auto, 0 lane per row, 1 block CSR-stream, 17 pipelined wave CSR-stream, 20 / 21 compact index, 22 / 23 windowed compact index");
+      opt.spmv_variant = v;
+    }
     else if (key == "assembly") {
       if (val == "auto") opt.assembly = -1; else if (val == "general") opt.assembly = 0; else if (val == "columns") opt.assembly = 1;
       else throw Error("unknown assembly '" + val + "'");
@@ -2573,6 +2589,7 @@ struct Solver {
     else if (key == "fused_assembly") opt.fused_assembly = num() != 0;
     else if (key == "ilu_graph") opt.ilu_graph = num() != 0;
     else if (key == "ilu_chain") opt.ilu_chain = (int)num();   // 0 per-level launches, 1 chained where it pays, 2 always chained
+    else if (key == "ilu_chain_tickets") opt.ilu_chain_tickets = num() != 0;
     else if (key == "ilu_chain_spins") opt.ilu_chain_spins = (unsigned)num();   // polls before a chained wait gives up (tests: 0)
     else if (key == "fused_trials") opt.fused_trials = (int)num();
     else if (key == "fused_predict") opt.fused_predict = num() != 0;

@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from mpp_amd import workloads as P  # noqa: E402
 
-DEFAULT_PLAN = ["copy", "dot", "waxpy", "dots3", "bcgs_xr", "spmv:1", "spmv:17", "spmv:20", "spmv:21",
+DEFAULT_PLAN = ["copy", "dot", "waxpy", "dots3", "bcgs_xr", "spmv:0", "spmv:1", "spmv:17", "spmv:20", "spmv:21",
                 "pc_setup", "pc_apply", "pc_apply_dots:0", "pc_apply_dots:1:tri_group=8", "pc_apply_dots:1:tri_group=16",
                 "pc_apply_dots:1:tri_group=24", "residual", "jacobian", "assemble_both"]
 
