@@ -442,7 +442,9 @@ def main():
                 kernels[k] = {"launches": s["launches"], "avg_ms": round(ms, 5),
                               "share_of_step_time": round(s["total_ms"] * 1e-3 / elapsed, 4)}
                 if s["bytes_per_launch"] > 0:
-                    kernels[k]["GBps"] = round(s["bytes_per_launch"] / (ms * 1e-3) / 1e9, 1)
+                    # SURVEY 8(d)'s algorithmic byte counts / time: the assembly passes move fewer bytes than that (soil
+                    # classes, per-level geometry: DESIGN.md section 4), so this figure may exceed the HBM peak for them
+                    kernels[k]["GBps_algorithmic"] = round(s["bytes_per_launch"] / (ms * 1e-3) / 1e9, 1)
         roof = {"kernel": "csr_spmv_fp64 (k_spmv_pipe_c: CSR values + compact 16-bit index, see DESIGN.md section 4)"
                           if compact else "csr_spmv_fp64",
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -692,80 +692,106 @@ __global__ __launch_bounds__(kBlock) void k_spmv_pipe(int n, int tpw, const int 
   }
 }
 
-// variants 20/21: the pipelined kernel on a COMPACT INDEX built once from the (fixed) CSR pattern: per row a 16-bit
-// start offset inside its 64-row tile instead of the 32-bit row pointer, per entry a 16-bit column offset from the
-// tile's first row instead of the 32-bit column -- 8 index bytes per 3-point row instead of 16, i.e. 47.8 instead of
-// 55.8 bytes per row of HBM traffic.  Available when every |col - 64*tile| < 2^15 (true for the tiled level-major
-// layout, where a row's neighbours are within one tile width); values, x, y and the summation order are unchanged.
+// variants 20/21: CSR SpMV on a COMPACT INDEX built once from the (fixed) CSR pattern: per row a 16-bit start offset
+// inside its 64-row tile instead of the 32-bit row pointer, per entry a 16-bit column offset from the tile's first row instead
+// of the 32-bit column -- 8 index bytes per 3-point row instead of 16, i.e. 47.8 instead of 55.8 bytes per row of HBM traffic.
+// Available when every |col - 64*tile| < 2^15 (true for the tiled level-major layout, where a row's neighbours are within
+// one tile width); values, x, y and the summation order are unchanged.
 // SPLIT (field-blocked systems, rows [P(1..N); T(1..N)]): a row's columns lie near its own cell in either block, so the
 // 16-bit entry is (offset << 1) | block with the offset taken from the tile's first cell in that block (split = N).
-template <int J, bool SPLIT>
-__global__ __launch_bounds__(kBlock) void k_spmv_pipe_c(int n, int tpw, int split, const int *__restrict__ tileptr,
-                                                        const unsigned short *__restrict__ roff,
-                                                        const short *__restrict__ dcol, const double *__restrict__ val,
-                                                        const double *__restrict__ x, double *__restrict__ y) {
+// DOTS: the same product with the line search's reductions fused in and y never written: leaves the partial sums of x.x,
+// f.(A x) and (xx != nullptr) xx.xx, layout partials[j*gridDim.x + b] -- SNESLineSearchApply_BT needs only ||Y||, F.(J Y), ||X||.
+// Schedule (round 2; profiles/r02_kbench_spmv_depth.json): a wave owns `tpw` consecutive tiles and keeps the index, values and
+// row data of up to THREE of them in flight in three named register sets that rotate -- no copies, so using a set waits for
+// that set only; the set two tiles ahead is requested right behind a tile's x gathers.  With 2 tiles per wave (the default)
+// every load of a wave is in flight at once: 0.880 -> 0.812 ms at 105 M rows against the one-tile look-ahead of round 1
+// (3 tiles 0.833, 4: 0.842, 6: 0.875, 12: 0.90; 1 tile per wave 0.996: too many waves for too little work each).
+template <int J, bool SPLIT, bool DOTS>
+__global__ __launch_bounds__(kBlock) void k_spmv_c(int n, int tpw, int split, const int *__restrict__ tileptr,
+                                                   const unsigned short *__restrict__ roff, const short *__restrict__ dcol,
+                                                   const double *__restrict__ val, const double *__restrict__ x,
+                                                   double *__restrict__ y, const double *__restrict__ f,
+                                                   const double *__restrict__ xx, double *__restrict__ partials) {
   __shared__ double prod[kBlock / 64][64 * J];
+  __shared__ double red[kBlock / 64];
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   double *lp = prod[w];
   const int ntiles = (n + 63) >> 6;
   const int tile0 = (blockIdx.x * (kBlock / 64) + w) * tpw;
-  if (tile0 >= ntiles) return;
-  const int tend = min(tile0 + tpw, ntiles);
-  int sA = tileptr[tile0], sB = tileptr[tile0 + 1];
-  double vn[J];
-  int cn[J], rsn = 0;
-  auto prefetch = [&](int tile, int s0, int cnt) {
-    const int r = (tile << 6) + lane;
-    rsn = (r < n) ? (int)__builtin_nontemporal_load(roff + r) : cnt;
+  if (!DOTS && tile0 >= ntiles) return;           // (with the dots, idle waves still take part in the block sums)
+  const int tend = min(tile0 + tpw, ntiles);      // tend <= tile0 for an idle wave
+  struct Set { double v[J], fr, xr, qr; int c[J]; int rs, cnt; };
+  auto fetch = [&](int tile) {
+    Set S;
+    const bool live = tile < tend;                 // wave-uniform; a dead set loads nothing (cnt = 0)
+    const int tc = live ? tile : max(tend - 1, 0);
+    const int s0 = live ? tileptr[tc] : 0;
+    S.cnt = live ? tileptr[tc + 1] - s0 : 0;
+    const int r = (tc << 6) + lane;
+    const bool row = live && r < n;
+    S.rs = row ? (int)__builtin_nontemporal_load(roff + r) : S.cnt;
+    if (DOTS) {
+      S.fr = row ? __builtin_nontemporal_load(f + r) : 0.0;
+      S.xr = row ? x[r] : 0.0;
+      S.qr = (row && xx) ? __builtin_nontemporal_load(xx + r) : 0.0;
+    } else S.fr = S.xr = S.qr = 0.0;
 #pragma unroll
     for (int j = 0; j < J; ++j) {
       const int k = lane + 64 * j;
-      const bool ok = k < cnt;
-      vn[j] = ok ? __builtin_nontemporal_load(val + s0 + k) : 0.0;
-      cn[j] = ok ? (int)__builtin_nontemporal_load(dcol + s0 + k) : 0;
+      const bool ok = k < S.cnt;
+      S.v[j] = ok ? __builtin_nontemporal_load(val + s0 + k) : 0.0;
+      S.c[j] = ok ? (int)__builtin_nontemporal_load(dcol + s0 + k) : 0;
     }
+    return S;
   };
-  prefetch(tile0, sA, sB - sA);
-  for (int tile = tile0; tile < tend; ++tile) {
-    const int cnt = sB - sA;
+  double acc_xx = 0.0, acc_fw = 0.0, acc_qq = 0.0;
+  auto body = [&](int tile, const Set &S, auto refill) {
     const int base = tile << 6;
-    double vc[J];
-    int cc[J];
-    const int rs = rsn;
-#pragma unroll
-    for (int j = 0; j < J; ++j) { vc[j] = vn[j]; cc[j] = cn[j]; }
-    double xs[J];
     const int base_lo = SPLIT ? (base < split ? base : base - split) : base;
+    double xs[J];
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-      const int ci = SPLIT ? base_lo + (cc[j] >> 1) + ((cc[j] & 1) ? split : 0) : base + cc[j];
-      xs[j] = (lane + 64 * j < cnt) ? x[ci] : 0.0;
+      const int ci = SPLIT ? base_lo + (S.c[j] >> 1) + ((S.c[j] & 1) ? split : 0) : base + S.c[j];
+      xs[j] = (lane + 64 * j < S.cnt) ? x[ci] : 0.0;
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (tile + 1 < tend) {
-      sA = sB;
-      sB = tileptr[tile + 2];
-      prefetch(tile + 1, sA, sB - sA);
-    }
+    refill();                                      // the set two tiles ahead goes out behind this tile's gathers
     __builtin_amdgcn_sched_barrier(0);
     // end of this lane's row = start of the next lane's (rows beyond n carry `cnt`)
-    const int nxt = __shfl_down(rs, 1, 64);
-    const int re = (lane == 63) ? cnt : nxt;
+    const int nxt = __shfl_down(S.rs, 1, 64);
+    const int re = (lane == 63) ? S.cnt : nxt;
 #pragma unroll
     for (int j = 0; j < J; ++j)
-      if (lane + 64 * j < cnt) lp[lane + 64 * j] = vc[j] * xs[j];
+      if (lane + 64 * j < S.cnt) lp[lane + 64 * j] = S.v[j] * xs[j];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int r = base + lane;
     if (r < n) {
       double sum = 0.0;
-      for (int k = rs; k < re; ++k) sum += lp[k];
-      __builtin_nontemporal_store(sum, y + r);
+      for (int k = S.rs; k < re; ++k) sum += lp[k];
+      if (DOTS) { acc_fw += S.fr * sum; acc_xx += S.xr * S.xr; acc_qq += S.qr * S.qr; }
+      else __builtin_nontemporal_store(sum, y + r);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+  };
+  Set A = fetch(tile0), B = fetch(tile0 + 1), C = fetch(tend);   // C starts dead (loads nothing)
+  for (int tile = tile0; tile < tend; tile += 3) {
+    body(tile, A, [&] { C = fetch(tile + 2); });
+    if (tile + 1 < tend) body(tile + 1, B, [&] { A = fetch(tile + 3); });
+    if (tile + 2 < tend) body(tile + 2, C, [&] { B = fetch(tile + 4); });
+  }
+  if (DOTS) {
+    double t = block_sum(acc_xx, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+    t = block_sum(acc_fw, red);
+    if (threadIdx.x == 0) partials[(size_t)gridDim.x + blockIdx.x] = t;
+    if (xx) {
+      t = block_sum(acc_qq, red);
+      if (threadIdx.x == 0) partials[(size_t)2 * gridDim.x + blockIdx.x] = t;
+    }
   }
 }
 
@@ -788,150 +814,58 @@ __global__ __launch_bounds__(kBlock) void k_spmv_pipe_mb(int n, int tpw, const i
   const int tile0 = (blockIdx.x * (kBlock / 64) + w) * tpw;
   if (tile0 >= ntiles) return;
   const int tend = min(tile0 + tpw, ntiles);
-  int sA = tileptr[tile0], sB = tileptr[tile0 + 1];
-  double vn[J];
-  int cn[J], rsn = 0, tbn = 0;
-  auto prefetch = [&](int tile, int s0, int cnt) {
-    const int r = (tile << 6) + lane;
-    rsn = (r < n) ? (int)__builtin_nontemporal_load(roff + r) : cnt;
-    tbn = tbase[(size_t)tile * 8 + (lane & 7)];          // lanes 0..7 hold the tile's window bases
+  struct Set { double v[J]; int c[J]; int rs, cnt, tb; };   // same three-set schedule as k_spmv_c
+  auto fetch = [&](int tile) {
+    Set S;
+    const bool live = tile < tend;
+    const int tc = live ? tile : tend - 1;
+    const int s0 = live ? tileptr[tc] : 0;
+    S.cnt = live ? tileptr[tc + 1] - s0 : 0;
+    const int r = (tc << 6) + lane;
+    S.rs = (live && r < n) ? (int)__builtin_nontemporal_load(roff + r) : S.cnt;
+    S.tb = live ? tbase[(size_t)tc * 8 + (lane & 7)] : 0;   // lanes 0..7 hold the tile's window bases
 #pragma unroll
     for (int j = 0; j < J; ++j) {
       const int k = lane + 64 * j;
-      const bool ok = k < cnt;
-      vn[j] = ok ? __builtin_nontemporal_load(val + s0 + k) : 0.0;
-      cn[j] = ok ? (int)__builtin_nontemporal_load(mcol + s0 + k) : 0;
+      const bool ok = k < S.cnt;
+      S.v[j] = ok ? __builtin_nontemporal_load(val + s0 + k) : 0.0;
+      S.c[j] = ok ? (int)__builtin_nontemporal_load(mcol + s0 + k) : 0;
     }
+    return S;
   };
-  prefetch(tile0, sA, sB - sA);
-  for (int tile = tile0; tile < tend; ++tile) {
-    const int cnt = sB - sA;
+  auto body = [&](int tile, const Set &S, auto refill) {
     const int base = tile << 6;
-    double vc[J];
-    int cc[J];
-    const int rs = rsn, tbc = tbn;
-#pragma unroll
-    for (int j = 0; j < J; ++j) { vc[j] = vn[j]; cc[j] = cn[j]; }
     double xs[J];
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-      const int wb = __shfl(tbc, cc[j] >> 13, 64);         // base of the entry's window
-      xs[j] = (lane + 64 * j < cnt) ? x[wb + (cc[j] & 8191)] : 0.0;
+      const int wb = __shfl(S.tb, S.c[j] >> 13, 64);         // base of the entry's window
+      xs[j] = (lane + 64 * j < S.cnt) ? x[wb + (S.c[j] & 8191)] : 0.0;
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (tile + 1 < tend) {
-      sA = sB;
-      sB = tileptr[tile + 2];
-      prefetch(tile + 1, sA, sB - sA);
-    }
+    refill();
     __builtin_amdgcn_sched_barrier(0);
-    const int nxt = __shfl_down(rs, 1, 64);
-    const int re = (lane == 63) ? cnt : nxt;
+    const int nxt = __shfl_down(S.rs, 1, 64);
+    const int re = (lane == 63) ? S.cnt : nxt;
 #pragma unroll
     for (int j = 0; j < J; ++j)
-      if (lane + 64 * j < cnt) lp[lane + 64 * j] = vc[j] * xs[j];
+      if (lane + 64 * j < S.cnt) lp[lane + 64 * j] = S.v[j] * xs[j];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int r = base + lane;
     if (r < n) {
       double sum = 0.0;
-      for (int k = rs; k < re; ++k) sum += lp[k];
+      for (int k = S.rs; k < re; ++k) sum += lp[k];
       __builtin_nontemporal_store(sum, y + r);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-  }
-}
-
-// the same product with the line search's reductions fused in and y never written: leaves the partial sums of x.x, f.(A x)
-// and (xx != nullptr) xx.xx, layout partials[j*gridDim.x + b] -- SNESLineSearchApply_BT needs only ||Y||, F.(J Y) and ||X||
-template <int J, bool SPLIT>
-__global__ __launch_bounds__(kBlock) void k_spmv_pipe_c_dots(int n, int tpw, int split, const int *__restrict__ tileptr,
-                                                             const unsigned short *__restrict__ roff,
-                                                             const short *__restrict__ dcol, const double *__restrict__ val,
-                                                             const double *__restrict__ x, const double *__restrict__ f,
-                                                             const double *__restrict__ xx, double *__restrict__ partials) {
-  __shared__ double prod[kBlock / 64][64 * J];
-  __shared__ double red[kBlock / 64];
-  const int lane = threadIdx.x & 63;
-  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  double *lp = prod[w];
-  const int ntiles = (n + 63) >> 6;
-  const int tile0 = (blockIdx.x * (kBlock / 64) + w) * tpw;
-  const bool live = tile0 < ntiles;             // wave-uniform; idle waves still take part in the block sums
-  const int tend = live ? min(tile0 + tpw, ntiles) : tile0;
-  int sA = 0, sB = 0;
-  double vn[J], fn = 0.0, xn = 0.0, qn = 0.0;
-  int cn[J], rsn = 0;
-  auto prefetch = [&](int tile, int s0, int cnt) {
-    const int r = (tile << 6) + lane;
-    const bool row = r < n;
-    rsn = row ? (int)__builtin_nontemporal_load(roff + r) : cnt;
-    fn = row ? __builtin_nontemporal_load(f + r) : 0.0;
-    xn = row ? x[r] : 0.0;
-    qn = (row && xx) ? __builtin_nontemporal_load(xx + r) : 0.0;
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-      const int k = lane + 64 * j;
-      const bool ok = k < cnt;
-      vn[j] = ok ? __builtin_nontemporal_load(val + s0 + k) : 0.0;
-      cn[j] = ok ? (int)__builtin_nontemporal_load(dcol + s0 + k) : 0;
-    }
   };
-  if (live) {
-    sA = tileptr[tile0]; sB = tileptr[tile0 + 1];
-    prefetch(tile0, sA, sB - sA);
-  }
-  double acc_xx = 0.0, acc_fw = 0.0, acc_qq = 0.0;
-  for (int tile = tile0; tile < tend; ++tile) {
-    const int cnt = sB - sA;
-    const int base = tile << 6;
-    double vc[J];
-    int cc[J];
-    const int rs = rsn;
-    const double fc = fn, xc = xn, qc = qn;
-#pragma unroll
-    for (int j = 0; j < J; ++j) { vc[j] = vn[j]; cc[j] = cn[j]; }
-    double xs[J];
-    const int base_lo = SPLIT ? (base < split ? base : base - split) : base;
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-      const int ci = SPLIT ? base_lo + (cc[j] >> 1) + ((cc[j] & 1) ? split : 0) : base + cc[j];
-      xs[j] = (lane + 64 * j < cnt) ? x[ci] : 0.0;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (tile + 1 < tend) {
-      sA = sB;
-      sB = tileptr[tile + 2];
-      prefetch(tile + 1, sA, sB - sA);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    const int nxt = __shfl_down(rs, 1, 64);
-    const int re = (lane == 63) ? cnt : nxt;
-#pragma unroll
-    for (int j = 0; j < J; ++j)
-      if (lane + 64 * j < cnt) lp[lane + 64 * j] = vc[j] * xs[j];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (base + lane < n) {
-      double sum = 0.0;
-      for (int k = rs; k < re; ++k) sum += lp[k];
-      acc_fw += fc * sum;
-      acc_xx += xc * xc;
-      acc_qq += qc * qc;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-  }
-  double t = block_sum(acc_xx, red);
-  if (threadIdx.x == 0) partials[blockIdx.x] = t;
-  t = block_sum(acc_fw, red);
-  if (threadIdx.x == 0) partials[(size_t)gridDim.x + blockIdx.x] = t;
-  if (xx) {
-    t = block_sum(acc_qq, red);
-    if (threadIdx.x == 0) partials[(size_t)2 * gridDim.x + blockIdx.x] = t;
+  Set A = fetch(tile0), B = fetch(tile0 + 1), C = fetch(tend);
+  for (int tile = tile0; tile < tend; tile += 3) {
+    body(tile, A, [&] { C = fetch(tile + 2); });
+    if (tile + 1 < tend) body(tile + 1, B, [&] { A = fetch(tile + 3); });
+    if (tile + 2 < tend) body(tile + 2, C, [&] { B = fetch(tile + 4); });
   }
 }
 
@@ -1770,14 +1704,12 @@ void launch_spmv_compact(int tpw, int n, int max_row_nnz, int split, const int *
   if (n <= 0) return;
   const long long tiles = ((long long)n + 63) / 64, waves = (tiles + tpw - 1) / tpw;
   const dim3 grid((int)((waves + 3) / 4));
-  if (split > 0) {
-    if (max_row_nnz <= 7) LAUNCH((k_spmv_pipe_c<7, true>), grid, n, tpw, split, tileptr, roff, dcol, val, x, y);
-    else LAUNCH((k_spmv_pipe_c<8, true>), grid, n, tpw, split, tileptr, roff, dcol, val, x, y);
-    return;
-  }
-  if (max_row_nnz <= 3) LAUNCH((k_spmv_pipe_c<3, false>), grid, n, tpw, split, tileptr, roff, dcol, val, x, y);
-  else if (max_row_nnz <= 7) LAUNCH((k_spmv_pipe_c<7, false>), grid, n, tpw, split, tileptr, roff, dcol, val, x, y);
-  else LAUNCH((k_spmv_pipe_c<8, false>), grid, n, tpw, split, tileptr, roff, dcol, val, x, y);
+#define SPMV_C(JJ, SP) LAUNCH((k_spmv_c<JJ, SP, false>), grid, n, tpw, split, tileptr, roff, dcol, val, x, y, nullptr, nullptr, nullptr)
+  if (split > 0) { if (max_row_nnz <= 7) SPMV_C(7, true); else SPMV_C(8, true); }
+  else if (max_row_nnz <= 3) SPMV_C(3, false);
+  else if (max_row_nnz <= 7) SPMV_C(7, false);
+  else SPMV_C(8, false);
+#undef SPMV_C
 }
 
 void launch_spmv_multibase(int tpw, int n, int max_row_nnz, const int *tileptr, const unsigned short *roff,
@@ -1798,17 +1730,16 @@ int spmv_compact_dots_blocks(int tpw, int n) {
 int launch_spmv_compact_dots(int tpw, int n, int max_row_nnz, int split, const int *tileptr, const unsigned short *roff,
                              const short *dcol, const double *val, const double *x, const double *f, const double *xx,
                              double *partials, hipStream_t stream) {
+  const int nb = spmv_compact_dots_blocks(tpw, n);
   if (n <= 0) return 0;
-  const dim3 grid(spmv_compact_dots_blocks(tpw, n));
-  if (split > 0) {
-    if (max_row_nnz <= 7) LAUNCH((k_spmv_pipe_c_dots<7, true>), grid, n, tpw, split, tileptr, roff, dcol, val, x, f, xx, partials);
-    else LAUNCH((k_spmv_pipe_c_dots<8, true>), grid, n, tpw, split, tileptr, roff, dcol, val, x, f, xx, partials);
-    return (int)grid.x;
-  }
-  if (max_row_nnz <= 3) LAUNCH((k_spmv_pipe_c_dots<3, false>), grid, n, tpw, split, tileptr, roff, dcol, val, x, f, xx, partials);
-  else if (max_row_nnz <= 7) LAUNCH((k_spmv_pipe_c_dots<7, false>), grid, n, tpw, split, tileptr, roff, dcol, val, x, f, xx, partials);
-  else LAUNCH((k_spmv_pipe_c_dots<8, false>), grid, n, tpw, split, tileptr, roff, dcol, val, x, f, xx, partials);
-  return (int)grid.x;
+  const dim3 grid(nb);
+#define SPMV_CD(JJ, SP) LAUNCH((k_spmv_c<JJ, SP, true>), grid, n, tpw, split, tileptr, roff, dcol, val, x, nullptr, f, xx, partials)
+  if (split > 0) { if (max_row_nnz <= 7) SPMV_CD(7, true); else SPMV_CD(8, true); }
+  else if (max_row_nnz <= 3) SPMV_CD(3, false);
+  else if (max_row_nnz <= 7) SPMV_CD(7, false);
+  else SPMV_CD(8, false);
+#undef SPMV_CD
+  return nb;
 }
 
 void launch_spmv(int variant, int n, int max_row_nnz, const int *rowptr, const int *col, const double *val,

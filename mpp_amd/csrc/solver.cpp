@@ -1162,11 +1162,11 @@ struct Solver {
     const int v = spmv_variant();
     if (v == 22 || v == 23) {
       if (!multibase_index) throw Error("spmv_variant 22/23 need the multi-base compact index (built when 20/21 are not available: rows of <= 8 entries, at most 8 windows of 8192 rows per tile)");
-      launch_spmv_multibase(opt.spmv_tpw > 0 ? opt.spmv_tpw : (v == 22 ? 4 : 8), nred, max_row_nnz, d_tileptr.p, d_roff.p, d_mcol.p,
+      launch_spmv_multibase(opt.spmv_tpw > 0 ? opt.spmv_tpw : (v == 22 ? 2 : 4), nred, max_row_nnz, d_tileptr.p, d_roff.p, d_mcol.p,
                             d_tbase.p, d_val.p, x, y, stream);
     } else if (v == 20 || v == 21) {
       if (!compact_index) throw Error("spmv_variant 20/21 need the compact index (rows of <= 8 entries whose columns lie within 2^15 of their 64-row tile)");
-      launch_spmv_compact(opt.spmv_tpw > 0 ? opt.spmv_tpw : (v == 20 ? 4 : 8), nred, max_row_nnz, compact_split, d_tileptr.p, d_roff.p, d_dcol.p, d_val.p, x, y, stream);
+      launch_spmv_compact(opt.spmv_tpw > 0 ? opt.spmv_tpw : (v == 20 ? 2 : 4), nred, max_row_nnz, compact_split, d_tileptr.p, d_roff.p, d_dcol.p, d_val.p, x, y, stream);
     } else launch_spmv(v, nred, max_row_nnz, d_rowptr.p, d_col.p, d_val.p, x, y, stream);
   }
   // the line search's first reductions in one pass over the matrix: out = {y.y, f.(A y), x.x (x != nullptr)}
@@ -1176,7 +1176,7 @@ struct Solver {
   }
   // launches only: the sums go to sc[S_SUM0 + slot ..]; nreduce values from sc[S_SUM0] on are all-reduced (0: none)
   int op_spmv_dots_launch(const double *y, const double *f, const double *x, int slot, int nreduce) {
-    const int tpw = spmv_variant() == 20 ? 4 : 8, nv = x ? 3 : 2;
+    const int tpw = opt.spmv_tpw > 0 ? opt.spmv_tpw : (spmv_variant() == 20 ? 2 : 4), nv = x ? 3 : 2;
     ProfScope ps(prof, KC_REDUCE);
     const size_t nbmax = (size_t)spmv_compact_dots_blocks(tpw, nred);
     const size_t need = 3 * (nbmax + nbmax / 2048 + 1);
@@ -3053,10 +3053,10 @@ int mppgpu_bench_kernel(mppgpu_handle h, const char *name, int variant, int reps
       cls = mpp::KC_SPMV;
       if (variant == 22 || variant == 23) {
         if (!S.multibase_index) throw mpp::Error("no multi-base index for this pattern");
-        mpp::launch_spmv_multibase(variant == 22 ? 4 : 8, S.nrow, S.max_row_nnz, S.d_tileptr.p, S.d_roff.p, S.d_mcol.p, S.d_tbase.p, S.d_val.p, S.soln.p, S.G.p, S.stream);
+        mpp::launch_spmv_multibase(S.opt.spmv_tpw > 0 ? S.opt.spmv_tpw : (variant == 22 ? 2 : 4), S.nrow, S.max_row_nnz, S.d_tileptr.p, S.d_roff.p, S.d_mcol.p, S.d_tbase.p, S.d_val.p, S.soln.p, S.G.p, S.stream);
       } else if (variant == 20 || variant == 21) {
         if (!S.compact_index) throw mpp::Error("no compact index for this pattern");
-        mpp::launch_spmv_compact(variant == 20 ? 4 : 8, S.nrow, S.max_row_nnz, S.compact_split, S.d_tileptr.p, S.d_roff.p, S.d_dcol.p, S.d_val.p, S.soln.p, S.G.p, S.stream);
+        mpp::launch_spmv_compact(S.opt.spmv_tpw > 0 ? S.opt.spmv_tpw : (variant == 20 ? 2 : 4), S.nrow, S.max_row_nnz, S.compact_split, S.d_tileptr.p, S.d_roff.p, S.d_dcol.p, S.d_val.p, S.soln.p, S.G.p, S.stream);
       } else mpp::launch_spmv(variant, S.nrow, S.max_row_nnz, S.d_rowptr.p, S.d_col.p, S.d_val.p, S.soln.p, S.G.p, S.stream);
     }
     else if (k == "pc_apply") { cls = mpp::KC_PC_APPLY; S.op_pc_setup(); S.op_pc_apply(S.F.p, S.G.p); }
