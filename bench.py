@@ -319,6 +319,9 @@ def main():
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="direct --gpus N launch: time limit of the rank processes [s]")
     ap.add_argument("--init-timeout", type=float, default=600.0,
                     help="multi-rank: time limit for rendezvous + ncclCommInitRank + the first solve (first all-reduces) [s]")
+    ap.add_argument("--share-gpus", action="store_true",
+                    help="multi-rank: map LOCAL_RANK onto the visible devices modulo their number (a one-GPU box then reaches "
+                         "ncclCommInitRank, which refuses two ranks on one device: the whole path up to RCCL, exercised)")
     ap.add_argument("--dry-run-ranks", action="store_true", help="multi-rank host path only, no GPU call (CPU tests)")
     ap.add_argument("--fail-rank", type=int, default=-1, help="with --dry-run-ranks: this rank exits with an error")
     args = ap.parse_args()
@@ -356,7 +359,13 @@ def main():
     prob = build_problem(ncols_global, args.nz, col0, ncols_local, hetero=not args.homogeneous)
     opts = {"ksp_type": args.ksp, "pc_type": args.pc, "spmv_variant": args.spmv_variant}
     opts.update(kv.split("=", 1) for kv in args.opt)
-    mpp = P.to_gpu(prob, opts, device_id=local_rank)
+    device_id = local_rank
+    if args.share_gpus:
+        import ctypes
+        ndev = ctypes.c_int(0)
+        ctypes.CDLL("libamdhip64.so").hipGetDeviceCount(ctypes.byref(ndev))
+        device_id = local_rank % max(ndev.value, 1)
+    mpp = P.to_gpu(prob, opts, device_id=device_id)
     soe = mpp.soe
     if launched:
         # RCCL prints a version banner on stdout at communicator creation: keep stdout for the ONE JSON line
@@ -445,7 +454,7 @@ def main():
                     # SURVEY 8(d)'s algorithmic byte counts / time: the assembly passes move fewer bytes than that (soil
                     # classes, per-level geometry: DESIGN.md section 4), so this figure may exceed the HBM peak for them
                     kernels[k]["GBps_algorithmic"] = round(s["bytes_per_launch"] / (ms * 1e-3) / 1e9, 1)
-        roof = {"kernel": "csr_spmv_fp64 (k_spmv_pipe_c: CSR values + compact 16-bit index, see DESIGN.md section 4)"
+        roof = {"kernel": "csr_spmv_fp64 (k_spmv_c: CSR values + compact 16-bit index, see DESIGN.md section 4)"
                           if compact else "csr_spmv_fp64",
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

@@ -1527,33 +1527,13 @@ __global__ __launch_bounds__(kBlock) void k_mdot(DotArgs a, int j0, int nv, doub
   }
 }
 
-// second stage: block j sums partials[j*nb .. j*nb+nb) in a fixed order into sc[S_SUM0+j]
-__global__ __launch_bounds__(kBlock) void k_finalize(int nb, const double *partials, double *sc) {
-  __shared__ double lds[kBlock / 64];
-  const int j = blockIdx.x;
-  double acc = 0.0;
-  for (int b = threadIdx.x; b < nb; b += kBlock) acc += partials[(size_t)j * nb + b];
-  const double t = block_sum(acc, lds);
-  if (threadIdx.x == 0) sc[S_SUM0 + j] = t;
-}
-
-// first of two stages for long partial lists: block (c, j) sums chunk c of vector j's partials into out[j*nchunk + c]
-__global__ __launch_bounds__(kBlock) void k_finalize_chunks(int nb, int chunk, const double *partials, double *out) {
-  __shared__ double lds[kBlock / 64];
-  const int c = blockIdx.x, j = blockIdx.y;
-  const int b0 = c * chunk, b1 = min(nb, b0 + chunk);
-  double acc = 0.0;
-  for (int b = b0 + threadIdx.x; b < b1; b += kBlock) acc += partials[(size_t)j * nb + b];
-  const double t = block_sum(acc, lds);
-  if (threadIdx.x == 0) out[(size_t)j * gridDim.x + c] = t;
-}
-
-__global__ void k_bcgs_scalars(int step, double *sc) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  if (step == 0) {  // rhoold = alpha = omegaold = 1; dp0 = ||M^{-1} b|| from the (rp,rp) just reduced
+// the scalar recurrences of BiCGStab between its vector kernels (one thread): the step codes of launch_bcgs_scalars
+__device__ void bcgs_scalar_step(int step, double *sc) {
+  if (step == 0 || step == 10) {  // rhoold = alpha = omegaold = 1; dp0 = ||M^{-1} b|| from the (rp,rp) just reduced
     sc[S_RHOOLD] = 1.0; sc[S_ALPHA] = 1.0; sc[S_OMEGAOLD] = 1.0; sc[S_FLAG] = 0.0;
     sc[S_DP0] = sqrt(sc[S_SUM0]);
-  } else if (step == 1) {  // rho <- (r,rp); beta = (rho/rhoold)*(alpha/omegaold)
+  }
+  if (step == 1 || step == 10) {  // rho <- (r,rp); beta = (rho/rhoold)*(alpha/omegaold)   [10 = 0 then 1, the first iteration]
     const double rho = sc[S_SUM0];
     sc[S_RHO] = rho;
     sc[S_BETA] = (rho / sc[S_RHOOLD]) * (sc[S_ALPHA] / sc[S_OMEGAOLD]);
@@ -1566,21 +1546,65 @@ __global__ void k_bcgs_scalars(int step, double *sc) {
     sc[S_ST] = d1; sc[S_D2] = d2;
     if (d2 == 0.0) { sc[S_OMEGA] = 0.0; sc[S_FLAG] = 1.0; }  // t == 0: x += alpha p is the candidate solution
     else sc[S_OMEGA] = d1 / d2;
-  } else if (step == 4) {  // end of iteration: dp^2 = (r,r); rhoold = rho; omegaold = omega; (r,rp) if it was reduced
+  } else if (step == 6) {  // steps 0 and 1 when the initial (rp,rp) was all-reduced together with the first (v,rp): it sits in S_SUM0+2
+    sc[S_RHOOLD] = 1.0; sc[S_ALPHA] = 1.0; sc[S_OMEGAOLD] = 1.0; sc[S_FLAG] = 0.0;
+    const double rho = sc[S_SUM0 + 2];
+    sc[S_DP0] = sqrt(rho);
+    sc[S_RHO] = rho;
+    sc[S_BETA] = (rho / sc[S_RHOOLD]) * (sc[S_ALPHA] / sc[S_OMEGAOLD]);
+  }
+  if (step == 4 || step == 45) {  // end of iteration: dp^2 = (r,r); rhoold = rho; omegaold = omega; (r,rp) if it was reduced
     sc[S_DP] = sqrt(sc[S_SUM0]);
     sc[S_RRP] = sc[S_SUM0 + 1];
     sc[S_RHOOLD] = sc[S_RHO]; sc[S_OMEGAOLD] = sc[S_OMEGA];
-  } else if (step == 6) {  // step 0 when the initial (rp,rp) was all-reduced together with the first (v,rp): it sits in S_SUM0+2
-    sc[S_RHOOLD] = 1.0; sc[S_ALPHA] = 1.0; sc[S_OMEGAOLD] = 1.0; sc[S_FLAG] = 0.0;
-    sc[S_DP0] = sqrt(sc[S_SUM0 + 2]);
-  } else if (step == 7) {  // step 1 of that case
-    const double rho = sc[S_SUM0 + 2];
-    sc[S_RHO] = rho;
-    sc[S_BETA] = (rho / sc[S_RHOOLD]) * (sc[S_ALPHA] / sc[S_OMEGAOLD]);
-  } else if (step == 5) {  // step 1 with rho = the (r,rp) the previous iteration's update reduced
+  }
+  if (step == 5 || step == 45) {  // step 1 with rho = the (r,rp) the iteration's update reduced   [45 = 4 then 5]
     const double rho = sc[S_RRP];
     sc[S_RHO] = rho;
     sc[S_BETA] = (rho / sc[S_RHOOLD]) * (sc[S_ALPHA] / sc[S_OMEGAOLD]);
+  }
+}
+__global__ void k_bcgs_scalars(int step, double *sc) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  bcgs_scalar_step(step, sc);
+}
+
+// Second stage of every reduction, in one launch: block (c, j) sums chunk c of vector j's partials in a fixed order into
+// stage[j*nchunk + c]; the block whose ticket comes last sums the chunk sums (again in a fixed order, so the result does not
+// depend on which block that is) into sums[S_SUM0 + j] and, step >= 0, runs the BiCGStab scalar recurrence that consumes them.
+// Hand-off: chunk sums are agent-scope stores, acknowledged (vmcnt(0)) before the storing wave takes its ticket; the last
+// block reads them with agent-scope loads after a workgroup barrier behind the returned ticket.  It leaves the counter at 0.
+__global__ __launch_bounds__(kBlock) void k_finalize(int nb, int chunk, const double *partials, double *stage, double *sums,
+                                                     unsigned *counter, double *sc, int step) {
+  __shared__ double lds[kBlock / 64];
+  __shared__ int last;
+  const int c = blockIdx.x, j = blockIdx.y, nchunk = gridDim.x, nvec = gridDim.y;
+  const int b0 = c * chunk, b1 = min(nb, b0 + chunk);
+  double acc = 0.0;
+  for (int b = b0 + threadIdx.x; b < b1; b += kBlock) acc += partials[(size_t)j * nb + b];
+  const double t = block_sum(acc, lds);
+  if (nchunk * nvec == 1) {   // nothing to wait for
+    if (threadIdx.x == 0) { sums[S_SUM0] = t; if (step >= 0) bcgs_scalar_step(step, sc); }
+    return;
+  }
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(stage + (size_t)j * nchunk + c, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+    const unsigned ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last = (ticket == (unsigned)(nchunk * nvec) - 1u);
+  }
+  __syncthreads();
+  if (!last) return;
+  for (int jj = 0; jj < nvec; ++jj) {
+    double a2 = 0.0;
+    for (int b = threadIdx.x; b < nchunk; b += kBlock)
+      a2 += __hip_atomic_load(stage + (size_t)jj * nchunk + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double tt = nchunk == 1 ? a2 : block_sum(a2, lds);   // one chunk: thread 0 holds it (the sum of the first stage, as is)
+    if (threadIdx.x == 0) sums[S_SUM0 + jj] = tt;
+  }
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (step >= 0) bcgs_scalar_step(step, sc);
   }
 }
 
@@ -1898,16 +1922,13 @@ int launch_dots(const DotArgs &a, double *partials, hipStream_t stream) {
   }
   return g;
 }
-void launch_finalize_partials(int nblocks, int nvec, const double *partials, double *sc, hipStream_t stream) {
-  LAUNCH(k_finalize, dim3(nvec), nblocks, partials, sc);
-}
-void launch_finalize_partials_long(int nblocks, int nvec, double *partials, double *sc, hipStream_t stream) {
-  constexpr int chunk = 2048;
-  if (nblocks <= 2 * chunk) { launch_finalize_partials(nblocks, nvec, partials, sc, stream); return; }
-  const int nchunk = (nblocks + chunk - 1) / chunk;
-  double *stage = partials + (size_t)nvec * nblocks;
-  LAUNCH(k_finalize_chunks, dim3(nchunk, nvec), nblocks, chunk, partials, stage);
-  LAUNCH(k_finalize, dim3(nvec), nchunk, stage, sc);
+constexpr int kFinalizeChunk = 2048;
+// up to two chunks' worth goes through one block per vector (the sums' order is then that of a single pass)
+int finalize_chunks(int nblocks) { return nblocks <= 2 * kFinalizeChunk ? 1 : (nblocks + kFinalizeChunk - 1) / kFinalizeChunk; }
+void launch_finalize(int nblocks, int nvec, const double *partials, double *sums, const Finalize &f, hipStream_t stream) {
+  if (nvec <= 0) return;
+  const int nchunk = finalize_chunks(nblocks);
+  LAUNCH(k_finalize, dim3(nchunk, nvec), nblocks, nchunk == 1 ? nblocks : kFinalizeChunk, partials, f.stage, sums, f.counter, f.sc, f.step);
 }
 int maxpy_blocks(int n) { return nblk(n); }
 int launch_maxpy_neg(const MaxpyArgs &a, const double *sc, double *y, double *partials, hipStream_t stream) {

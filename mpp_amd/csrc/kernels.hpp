@@ -151,7 +151,7 @@ void launch_spmv_multibase(int tpw, int n, int max_row_nnz, const int *tileptr, 
                            const unsigned short *mcol, const int *tbase, const double *val, const double *x, double *y,
                            hipStream_t stream);
 // x.x, f.(A x) and optionally xx.xx without writing A x: partial sums in partials[j*nb + b], nb = the return value
-// (= spmv_compact_dots_blocks, which sizes the buffer: 3*nb doubles); finish with launch_finalize_partials
+// (= spmv_compact_dots_blocks, which sizes the buffer: 3*nb doubles); finish with launch_finalize
 int spmv_compact_dots_blocks(int tpw, int n);
 int launch_spmv_compact_dots(int tpw, int n, int max_row_nnz, int split, const int *tileptr, const unsigned short *roff,
                              const short *dcol, const double *val, const double *x, const double *f, const double *xx,
@@ -166,7 +166,7 @@ struct TriArgs {
 void launch_tri_factor(const TriArgs &a, hipStream_t stream);
 void launch_tri_solve(const TriArgs &a, const double *r, double *z, hipStream_t stream);
 // the same solve with fused dot products of the result: z.z (w == nullptr) or z.w and z.z; returns the number of partial
-// blocks (<= kMaxPartialBlocks is the caller's responsibility); finish with launch_finalize_partials
+// blocks (<= kMaxPartialBlocks is the caller's responsibility); finish with launch_finalize
 int launch_tri_solve_dots(const TriArgs &a, const double *r, double *z, const double *w, double *partials, hipStream_t stream);
 // the same with L^{-1} r parked in LDS between the sweeps (one wave per 64-column tile, nz <= kTriLdsMaxLevels; `group` levels
 // are kept in flight per stream; scratch64: 64 doubles the idle lanes of a ragged last tile may write); one partial sum per
@@ -303,21 +303,25 @@ void launch_bcgs_p(int n, double *P, const double *Pold, const double *R, const 
 // partial sums of r.r in `partials` and, unless `first`, those of r.rp in its second row (the next iteration's rho);
 // returns the number of partial blocks
 // wide: one 16-byte pair per lane (bcgs_xr_blocks(n, true) partial sums per vector: finish with
-// launch_finalize_partials_long) instead of the capped reduction grid
+// launch_finalize) instead of the capped reduction grid
 int bcgs_xr_blocks(int n, bool wide);
 int launch_bcgs_xr(int n, bool first, bool wide, double *X, double *R, const double *P, const double *S, const double *T,
                    const double *RP, const double *sc, double *partials, hipStream_t stream);
 // multi-dot: sums[j] = x . ys[j], j < nvec; two-stage deterministic reduction (partials -> sc[S_SUM0+j])
 struct DotArgs { int n, nvec; const double *x[kMaxMultiDot]; const double *y[kMaxMultiDot]; };
-// stage 1 only (returns number of partial blocks); stage 2 is launch_finalize_partials
+// stage 1 only (returns number of partial blocks); stage 2 is launch_finalize
 int launch_dots(const DotArgs &a, double *partials, hipStream_t stream);
-void launch_finalize_partials(int nblocks, int nvec, const double *partials, double *sc, hipStream_t stream);
-// the same for long lists (one partial per SpMV block): two stages, the first into the tail of `partials`, which must hold
-// nvec * (nblocks + ceil(nblocks / 2048)) doubles; the order of summation is fixed by nblocks alone
-void launch_finalize_partials_long(int nblocks, int nvec, double *partials, double *sc, hipStream_t stream);
+// Stage 2 of every reduction, one launch: sums[S_SUM0 + j] = sum of partials[j*nblocks .. +nblocks), j < nvec, in an order fixed
+// by nblocks alone (chunks of 2048 partials, then the chunk sums; up to 4096 partials in one pass).  The chunk sums go through
+// `stage` (kFinalizeStage doubles) and the block that takes the last ticket of `counter` (one word, zero between launches) adds
+// them up; step >= 0: that block then runs BiCGStab's scalar recurrence `step` (launch_bcgs_scalars' codes) on `sc`.
+constexpr int kFinalizeStage = 8192;
+struct Finalize { double *stage; unsigned *counter; double *sc; int step; };
+int finalize_chunks(int nblocks);   // per vector; nvec * finalize_chunks(nblocks) <= kFinalizeStage is the caller's responsibility
+void launch_finalize(int nblocks, int nvec, const double *partials, double *sums, const Finalize &f, hipStream_t stream);
 // y -= sum_j h[j] * v_j  (h on device at sc[S_SUM0+j]); GMRES classical Gram-Schmidt update
 struct MaxpyArgs { int n, nvec; const double *v[kMaxMultiDot]; };
-// partials (maxpy_blocks(n) doubles + the staging tail of launch_finalize_partials_long, or nullptr): also y.y of the result;
+// partials (maxpy_blocks(n) doubles + maxpy_blocks(n) / 2048 + 1 more, or nullptr): also y.y of the result;
 // returns the number of blocks
 int maxpy_blocks(int n);
 int launch_maxpy_neg(const MaxpyArgs &a, const double *sc, double *y, double *partials, hipStream_t stream);

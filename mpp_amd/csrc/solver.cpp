@@ -156,7 +156,8 @@ struct Solver {
   DevBuf<double> soln, soln_prev, accum_prev, F, Y, W, G, R, RP, V, T, S, Pv, Wk, tmp_ext, tmp_int;
   DevBuf<double> aux_kr, aux_dkr, aux_den, aux_dden;
   DevBuf<double> tri_l, tri_invb, tri_c, jac_invd;
-  DevBuf<double> partials, sc, spmv_partials, col_partials, xr_partials, tri_scratch;
+  DevBuf<double> partials, sc, spmv_partials, col_partials, xr_partials, tri_scratch, fin_stage;
+  DevBuf<unsigned> fin_counter;   // the ticket of the reductions' second stage (zero between launches)
   // complete-row column march (plan_complete_rows): boundary cells sit on column ends only
   bool rows_plan = false, asm_sums = false;
   struct Trial { const double *x = nullptr, *y = nullptr; double a = 0.0; } ls_point;
@@ -666,6 +667,7 @@ struct Solver {
       tri_scratch.alloc(64);
     }
     sc.alloc(S_COUNT); sc.zero(stream);
+    fin_stage.alloc(kFinalizeStage); fin_counter.alloc(1); fin_counter.zero(stream);
     HIP_CHECK(hipHostMalloc(&h_sc, S_COUNT * sizeof(double), hipHostMallocDefault));
     d_Dq.alloc(nc_int); d_upw.alloc(nc_int); d_dgrav.alloc(nc_int); d_area.alloc(nc_int);
     if (thermal || th) {
@@ -1106,7 +1108,7 @@ struct Solver {
     launch_assemble_cols(mode, a, stream);
     if (a.fwd) fwd_rhs = Fout;
     if (mode != 1) {
-      launch_finalize_partials_long((ncols + 255) / 256, 2, col_partials.p, sc.p, stream);
+      finalize((ncols + 255) / 256, 2, col_partials.p);
       if (comm.active()) comm.allreduce_sum(sc.p + S_SUM0, 2, stream);
       asm_sums = true;
     }
@@ -1176,14 +1178,16 @@ struct Solver {
   }
   // launches only: the sums go to sc[S_SUM0 + slot ..]; nreduce values from sc[S_SUM0] on are all-reduced (0: none)
   int op_spmv_dots_launch(const double *y, const double *f, const double *x, int slot, int nreduce) {
-    const int tpw = opt.spmv_tpw > 0 ? opt.spmv_tpw : (spmv_variant() == 20 ? 2 : 4), nv = x ? 3 : 2;
+    // (with the reductions the kernel carries three more streams and one partial sum per block: 6 tiles per wave measured best,
+    // 0.958 ms against 1.07 at 2 and 0.977 at 4: profiles/r02_kbench_spmv_dots_tpw.json)
+    const int tpw = opt.spmv_tpw > 0 ? opt.spmv_tpw : 6, nv = x ? 3 : 2;
     ProfScope ps(prof, KC_REDUCE);
     const size_t nbmax = (size_t)spmv_compact_dots_blocks(tpw, nred);
     const size_t need = 3 * (nbmax + nbmax / 2048 + 1);
     if (spmv_partials.n < need) spmv_partials.alloc(need);
     const int nbk = launch_spmv_compact_dots(tpw, nred, max_row_nnz, compact_split, d_tileptr.p, d_roff.p, d_dcol.p, d_val.p, y, f, x,
                                              spmv_partials.p, stream);
-    launch_finalize_partials_long(nbk, nv, spmv_partials.p, sc.p + slot, stream);
+    finalize(nbk, nv, spmv_partials.p, slot);
     if (comm.active() && nreduce > 0) comm.allreduce_sum(sc.p + S_SUM0, nreduce, stream);
     return nv;
   }
@@ -1367,33 +1371,48 @@ struct Solver {
   // slot: the sums land in sc[S_SUM0 + slot ..]; nreduce: how many values from sc[S_SUM0] on are all-reduced afterwards
   // (-1: just this call's; 0: none -- the caller folds them into a later all-reduce).  slot / nreduce other than the
   // defaults are for the fused path only.
-  void op_pc_apply_dots(const double *r, double *z, const double *w, int slot = 0, int nreduce = -1) {
+  // step >= 0: BiCGStab's scalar recurrence that consumes the sums follows (bcgs_step)
+  void op_pc_apply_dots(const double *r, double *z, const double *w, int slot = 0, int nreduce = -1, int step = -1) {
     if (!fused_pc_dots()) {
       op_pc_apply(r, z);
-      if (w) dots_dev({{w, z}, {z, z}}); else dots_dev({{z, z}});
+      if (w) dots_dev({{w, z}, {z, z}}, step); else dots_dev({{z, z}}, step);
       return;
     }
     {
       ProfScope ps(prof, KC_PC_APPLY);
       int nbk;
-      if (!w && r == fwd_rhs && pc_ready) nbk = launch_tri_back_dots(tri_args(), fwd_elim.p, z, col_partials.p, stream);
+      if (!w && r == fwd_rhs && pc_ready)
+        nbk = launch_tri_back_dots(tri_args(), fwd_elim.p, z, col_partials.p, stream);
       else if (tri_lds()) nbk = launch_tri_solve_lds(tri_args(), r, z, w, col_partials.p, tri_scratch.p, opt.tri_group, stream);
       else nbk = launch_tri_solve_dots(tri_args(), r, z, w, col_partials.p, stream);
-      launch_finalize_partials_long(nbk, w ? 2 : 1, col_partials.p, sc.p + slot, stream);
+      finalize(nbk, w ? 2 : 1, col_partials.p, slot, step);
     }
     if (nreduce < 0) nreduce = w ? 2 : 1;
     if (comm.active() && nreduce > 0) comm.allreduce_sum(sc.p + S_SUM0, nreduce, stream);
+    bcgs_step(step);
   }
 
   // ---- reductions: deterministic two-stage sums, RCCL all-reduce across ranks, results on device and host ----
-  void dots_dev(std::initializer_list<std::pair<const double *, const double *>> pairs) {
+  // Second stage of a reduction: sc[S_SUM0 + slot + j] = the sum of partials[j*nbk ..], one launch.  Without a communicator
+  // the block that finishes the sums also runs the BiCGStab scalar step that consumes them; across ranks that step waits for
+  // the all-reduce (bcgs_step, after it).
+  void finalize(int nbk, int nvec, const double *partials_, int slot = 0, int step = -1) {
+    if ((size_t)nvec * finalize_chunks(nbk) > (size_t)kFinalizeStage)
+      throw Error(std::to_string(nvec) + " sums of " + std::to_string(nbk) + " partial sums exceed the reductions' staging buffer");
+    launch_finalize(nbk, nvec, partials_, sc.p + slot, Finalize{fin_stage.p, fin_counter.p, sc.p, comm.active() ? -1 : step}, stream);
+  }
+  void bcgs_step(int step) {
+    if (step >= 0 && comm.active()) launch_bcgs_scalars(step, sc.p, stream);
+  }
+  void dots_dev(std::initializer_list<std::pair<const double *, const double *>> pairs, int step = -1) {
     ProfScope ps(prof, KC_REDUCE);
     DotArgs a;
     a.n = nred; a.nvec = 0;
     for (auto &p : pairs) { a.x[a.nvec] = p.first; a.y[a.nvec] = p.second; ++a.nvec; }
     const int nbk = launch_dots(a, partials.p, stream);
-    launch_finalize_partials(nbk, a.nvec, partials.p, sc.p, stream);
+    finalize(nbk, a.nvec, partials.p, 0, step);
     if (comm.active()) comm.allreduce_sum(sc.p + S_SUM0, a.nvec, stream);
+    bcgs_step(step);
   }
   void fetch_scalars() {
     HIP_CHECK(hipMemcpyAsync(h_sc, sc.p, S_COUNT * sizeof(double), hipMemcpyDeviceToHost, stream));
@@ -1508,12 +1527,11 @@ struct Solver {
     // one all-reduce, (rp,rp) parked in sc[S_SUM0+2] meanwhile.
     const bool merge0 = comm.active() && fused_pc_dots() && opt.defer_test0;
     if (merge0) op_pc_apply_dots(b, RP.p, nullptr, 2, 0);
-    else op_pc_apply_dots(b, RP.p, nullptr);   // leaves (rp,rp) in sc[S_SUM0]
+    else op_pc_apply_dots(b, RP.p, nullptr, 0, -1, 10);   // (rp,rp) in sc[S_SUM0]; scalar steps 0 and 1 (rho = (rp,rp), beta)
     *its = 0;
     // The convergence test of iteration 0 needs ||rp|| on the host.  Rather than stall the queue for it, the first
     // iteration is issued at once and the test is made when its scalars come back: had it fired, the answer is the zero
     // initial guess (restored below) and nothing else of the speculative iteration is visible.
-    if (!merge0) launch_bcgs_scalars(0, sc.p, stream);
     bool test0_pending = true;
     double dp = 0.0;
     int reason = 0;
@@ -1528,8 +1546,8 @@ struct Solver {
     do {
       // rho = (r,rp): the initial (rp,rp) at i == 0; a separate reduction at i == 1 (the first update does not read rp:
       // most solves of the column-structured problems end there); afterwards the update kernel reduces it on the way
-      if (i == 1) dots_dev({{Rcur, RP.p}});
-      if (!(merge0 && i == 0)) launch_bcgs_scalars(i >= 2 ? 5 : 1, sc.p, stream);
+      // (the scalar step that follows, rho and beta, rides with the reduction that produces rho: see the end of the loop for i >= 2)
+      if (i == 1) dots_dev({{Rcur, RP.p}}, 1);
       if (i > 0) {
         ProfScope ps(prof, KC_VEC);
         launch_bcgs_p(nred, Pv.p, Pcur, Rcur, V.p, sc.p, stream);
@@ -1539,13 +1557,12 @@ struct Solver {
       if (merge0 && i == 0) {
         op_pc_apply_dots(Wk.p, V.p, RP.p, 0, 3);   // (v,rp), (v,v) and the parked (rp,rp) in one all-reduce
         launch_bcgs_scalars(6, sc.p, stream);
-        launch_bcgs_scalars(7, sc.p, stream);
-      } else op_pc_apply_dots(Wk.p, V.p, RP.p);   // (v,rp) in sc[S_SUM0]  [(v,v) in S_SUM0+1 is not used]
-      launch_bcgs_scalars(2, sc.p, stream);
+        launch_bcgs_scalars(2, sc.p, stream);
+      } else op_pc_apply_dots(Wk.p, V.p, RP.p, 0, -1, 2);   // (v,rp) in sc[S_SUM0]  [(v,v) in S_SUM0+1 is not used]; alpha
       { ProfScope ps(prof, KC_VEC); launch_waxpy(nred, S.p, sc.p, S_ALPHA, -1.0, 0.0, V.p, Rcur, stream); }
       op_spmv(S.p, Wk.p);
-      op_pc_apply_dots(Wk.p, T.p, S.p);    // (t,s), (t,t) in sc[S_SUM0], sc[S_SUM0+1]
-      launch_bcgs_scalars(3, sc.p, stream);
+      int end_step = 4;
+      op_pc_apply_dots(Wk.p, T.p, S.p, 0, -1, 3);    // (t,s), (t,t) in sc[S_SUM0], sc[S_SUM0+1]; omega
       {
         ProfScope ps(prof, KC_REDUCE);
         const bool wide = opt.wide_xr && nred >= (1 << 22);
@@ -1556,21 +1573,24 @@ struct Solver {
           pbuf = xr_partials.p;
         }
         const int nbk = launch_bcgs_xr(nred, i == 0, wide, x, R.p, Pcur, S.p, T.p, RP.p, sc.p, pbuf, stream);
-        launch_finalize_partials_long(nbk, i == 0 ? 1 : 2, pbuf, sc.p, stream);
+        // end of the iteration: dp, rhoold, omegaold (step 4) and, from the second iteration on, the next one's rho = (r,rp)
+        // and beta (step 5) -- harmless when the test below ends the solve
+        end_step = i == 0 ? 4 : 45;
+        finalize(nbk, i == 0 ? 1 : 2, pbuf, 0, end_step);
         if (!(ls_ahead.armed && i == 0) && comm.active()) comm.allreduce_sum(sc.p + S_SUM0, i == 0 ? 1 : 2, stream);
       }
       const bool ahead = ls_ahead.armed && i == 0;
       int ahead_nv = 0;
       if (ahead) ahead_nv = op_spmv_dots_launch(x, ls_ahead.F, ls_ahead.X, 1, 1 + (ls_ahead.X ? 3 : 2));   // x is final if we stop here
       Rcur = R.p;
-      launch_bcgs_scalars(4, sc.p, stream);
+      bcgs_step(end_step);
       fetch_scalars();
       if (test0_pending) {
         test0_pending = false;
         reason = ksp_converged(cv, 0, h_sc[S_DP0]);
         if (reason) { vec_set(0.0, x); return reason; }
       }
-      const double rho = h_sc[S_RHO], d1 = h_sc[S_D1];
+      const double rho = h_sc[S_RHOOLD], d1 = h_sc[S_D1];   // this iteration's rho (step 4 has just moved it there)
       if (d1 == 0.0) return -5;
       if (h_sc[S_FLAG] != 0.0) {  // t == 0: x += alpha p was applied (omega forced to 0)
         const double ss = std::sqrt(h_sc[S_SUM0]);  // r == s here
@@ -1635,7 +1655,7 @@ struct Solver {
           a.n = nred; a.nvec = it + 1;
           for (int j = 0; j <= it; ++j) { a.x[j] = vnew; a.y[j] = vv[j].p; }
           const int nbk = launch_dots(a, partials.p, stream);
-          launch_finalize_partials(nbk, a.nvec, partials.p, sc.p, stream);
+          finalize(nbk, a.nvec, partials.p);
           if (comm.active()) comm.allreduce_sum(sc.p + S_SUM0, a.nvec, stream);
         }
         {
@@ -1647,7 +1667,7 @@ struct Solver {
           const size_t nb = (size_t)maxpy_blocks(nred), need = nb + nb / 2048 + 1;
           if (xr_partials.n < need) xr_partials.alloc(need);
           const int nbk = launch_maxpy_neg(ma, sc.p, vnew, xr_partials.p, stream);
-          launch_finalize_partials_long(nbk, 1, xr_partials.p, sc.p + kNormSlot, stream);
+          finalize(nbk, 1, xr_partials.p, kNormSlot);
           if (comm.active()) comm.allreduce_sum(sc.p + S_SUM0 + kNormSlot, 1, stream);
         }
         fetch_scalars();
@@ -3060,6 +3080,19 @@ int mppgpu_bench_kernel(mppgpu_handle h, const char *name, int variant, int reps
       } else mpp::launch_spmv(variant, S.nrow, S.max_row_nnz, S.d_rowptr.p, S.d_col.p, S.d_val.p, S.soln.p, S.G.p, S.stream);
     }
     else if (k == "pc_apply") { cls = mpp::KC_PC_APPLY; S.op_pc_setup(); S.op_pc_apply(S.F.p, S.G.p); }
+    else if (k == "tri_back") {   // back substitution of a forward-eliminated right-hand side
+      cls = mpp::KC_PC_APPLY; S.op_pc_setup();
+      if (!S.fwd_elim.p) S.fwd_elim.alloc(S.nrow);
+      mpp::launch_tri_back_dots(S.tri_args(), S.fwd_elim.p, S.G.p, S.col_partials.p, S.stream);
+    }
+    else if (k == "spmv_dots") {   // the line search's SpMV with its three reductions; variant > 0: tiles per wave
+      cls = mpp::KC_REDUCE;
+      if (!S.spmv_dots_fused()) throw mpp::Error("the fused SpMV + reductions kernel is not in use for this problem");
+      const int keep = S.opt.spmv_tpw;
+      if (variant > 0) S.opt.spmv_tpw = variant;
+      S.op_spmv_dots_launch(S.Y.p, S.F.p, S.soln.p, 0, 0);
+      S.opt.spmv_tpw = keep;
+    }
     else if (k == "pc_apply_dots") {   // the column solve with its dot products; variant: -1 as configured, else tri_lds levels
       cls = mpp::KC_PC_APPLY; S.op_pc_setup();
       const int keep = S.opt.tri_lds;
@@ -3097,7 +3130,7 @@ int mppgpu_bench_kernel(mppgpu_handle h, const char *name, int variant, int reps
   if (algorithmic_bytes) {
     const double N = S.n;
     *algorithmic_bytes = (k == "copy" || k == "dot") ? 16.0 * N : (k == "waxpy") ? 24.0 * N : (k == "bcgs_xr") ? 48.0 * N
-                         : (k == "dots3") ? 32.0 * N : (k == "pc_apply_dots") ? 48.0 * N : (k == "assemble_both") ? 92.0 * N + 8.0 * S.nnz : S.algorithmic_bytes(cls);
+                         : (k == "dots3") ? 32.0 * N : (k == "pc_apply_dots") ? 48.0 * N : (k == "tri_back") ? 32.0 * N : (k == "spmv_dots") ? 12.0 * S.nnz + 28.0 * N : (k == "assemble_both") ? 92.0 * N + 8.0 * S.nnz : S.algorithmic_bytes(cls);
   }
   API_END()
 }
