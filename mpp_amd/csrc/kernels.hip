@@ -29,6 +29,7 @@ template <class T>
 __device__ __forceinline__ T ldnt(const T *p) { return __builtin_nontemporal_load(p); }
 template <class T>
 __device__ __forceinline__ void stnt(T v, T *p) { __builtin_nontemporal_store(v, p); }
+typedef double dpair __attribute__((ext_vector_type(2)));   // two doubles, one 16-byte access
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -1220,6 +1221,194 @@ __global__ __launch_bounds__(kBlock) void k_copy(int n, const double *__restrict
 __global__ __launch_bounds__(kBlock) void k_set(int n, double v, double *__restrict__ y) {
   vec2_loop(n, [&](size_t q) { D2(y)[q] = make_double2(v, v); }, [&](size_t i) { y[i] = v; });
 }
+// ---- ILU(0) solves of a structured 7-point grid by box wavefronts (BoxGrid in kernels.hpp) ----
+// Factor values and the diagonal's reciprocals into the box layout: slot t holds internal cell cellmap[t] (-1: padding, all zero).
+// An entry is told apart by the distance of its column from the row in the caller's numbering.
+__global__ __launch_bounds__(kBlock) void k_box_fill(long long nslots, BoxGrid g, const int *__restrict__ cellmap, const int *__restrict__ int2ext,
+                                                     const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ lu,
+                                                     const double *__restrict__ idiag, double *Ld, double *Ls, double *Lw, double *Ue, double *Un,
+                                                     double *Uu, double *Di) {
+  const long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= nslots) return;
+  double ld = 0.0, ls = 0.0, lw = 0.0, ue = 0.0, un = 0.0, uu = 0.0, di = 0.0;
+  const int r = cellmap[t];
+  if (r >= 0) {
+    const int e = int2ext[r], s3 = g.n1 * g.n2;
+    di = idiag[r];
+    for (int q = rowptr[r]; q < rowptr[r + 1]; ++q) {
+      const int d = int2ext[col[q]] - e;
+      const double v = lu[q];
+      if (d == -1) lw = v;
+      else if (d == 1) ue = v;
+      else if (g.n2 > 1 && d == -g.n1) ls = v;
+      else if (g.n2 > 1 && d == g.n1) un = v;
+      else if (g.n3 > 1 && d == -s3) ld = v;
+      else if (g.n3 > 1 && d == s3) uu = v;
+    }
+  }
+  Ld[t] = ld; Ls[t] = ls; Lw[t] = lw; Ue[t] = ue; Un[t] = un; Uu[t] = uu; Di[t] = di;
+}
+__global__ __launch_bounds__(kBlock) void k_gather_or_zero(long long n, const int *idx, const double *in, double *out) {
+  const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) { const int j = idx[i]; out[i] = j >= 0 ? in[j] : 0.0; }
+}
+
+// One wave solves one box; lane (j', k') walks its line of the box in i', one step row per step: at step h it holds cell
+// i' = h - j' - k'.  The west neighbour's value is the lane's own previous result, south and down come from lanes -1 and -B2 one
+// step earlier; across a box face they come from the finished neighbour box, whose face the wave copies into LDS before it
+// starts.  Padding slots carry zero coefficients and a zero right-hand side, so every lane computes every step (no branches).
+// Operands arrive as 16-byte loads (two step rows per lane and instruction, see box_slot) through a ring of DP row pairs: five
+// memory instructions per pair, DP = 12 keeps 60 of the 63 the counter can hold in flight -- a box of 32 is fetched whole.
+// Per row the entries are eliminated in the order of the level-scheduled kernels (ascending column): the same bits.
+template <int DP>
+__global__ __launch_bounds__(64) void k_box_lower(BoxGrid g, const int *__restrict__ boxes, const double *__restrict__ Ld,
+                                                  const double *__restrict__ Ls, const double *__restrict__ Lw, double *y,
+                                                  double *scratch) {
+  extern __shared__ double face[];                              // [B1][B3] south face, then [B1][B2] lower face
+  const int b = boxes[blockIdx.x], lane = threadIdx.x, S = g.S, NP = S >> 1;
+  const int jp = lane & (g.B2 - 1), kp = lane >> g.lg2;
+  const int I = b % g.NB1, J = (b / g.NB1) % g.NB2, K = b / (g.NB1 * g.NB2);
+  double *fS = face, *fD = face + g.B1 * g.B3;
+  const size_t own = box_slot(g, b, 0, lane);                   // the lane's slot in row 0; row pair p is 128 * p further on
+  // faces of the boxes behind: element (i', k') of the south face is cell (i', B2-1, k') of box J-1, (i', j') of the lower
+  // face cell (i', j', B3-1) of box K-1; no box there: zeros
+  {
+    const int nS = g.B1 * g.B3, nD = g.B1 * g.B2;
+    const long long bS = J > 0 ? b - g.NB1 : b, bD = K > 0 ? b - g.NB1 * g.NB2 : b;
+    for (int e0 = 0; e0 < max(nS, nD); e0 += 64 * 4) {
+      double vS[4], vD[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int eS = min(e0 + q * 64 + lane, nS - 1), eD = min(e0 + q * 64 + lane, nD - 1);
+        const int iS = eS / g.B3, kS = eS - iS * g.B3, iD = eD >> g.lg2, jD = eD & (g.B2 - 1);
+        vS[q] = y[box_slot(g, bS, iS + g.B2 - 1 + kS, g.B2 - 1 + g.B2 * kS)];
+        vD[q] = y[box_slot(g, bD, iD + jD + g.B3 - 1, jD + g.B2 * (g.B3 - 1))];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int e = e0 + q * 64 + lane;
+        if (e < nS) fS[e] = J > 0 ? vS[q] : 0.0;
+        if (e < nD) fD[e] = K > 0 ? vD[q] : 0.0;
+      }
+    }
+  }
+  const int hW = jp + kp;                                       // the step at which the lane is on the west face
+  double yW = 0.0;
+  if (I > 0) yW = y[box_slot(g, b - 1, g.B1 - 1 + hW, lane)];
+  const dpair *Ld2 = reinterpret_cast<const dpair *>(Ld + own), *Ls2 = reinterpret_cast<const dpair *>(Ls + own),
+                *Lw2 = reinterpret_cast<const dpair *>(Lw + own);
+  dpair *y2 = reinterpret_cast<dpair *>(y + own), *sink = reinterpret_cast<dpair *>(scratch) + lane;
+  dpair ld[DP], ls[DP], lw[DP], rr[DP];
+  auto fetch = [&](int u, int p) {
+    const size_t o = (size_t)min(p, NP - 1) * 64;               // in double2 units: 128 doubles per row pair
+    ld[u] = ldnt(Ld2 + o); ls[u] = ldnt(Ls2 + o); lw[u] = ldnt(Lw2 + o);
+    rr[u] = y2[o];
+  };
+#pragma unroll
+  for (int u = 0; u < DP; ++u) { fetch(u, u); __builtin_amdgcn_sched_barrier(0); }
+  __syncthreads();                                              // (one wave: orders the LDS writes above before the reads)
+  auto faceS = [&](int h) { return fS[min(max(h - kp, 0), g.B1 - 1) * g.B3 + kp]; };
+  auto faceD = [&](int h) { return fD[(min(max(h - jp, 0), g.B1 - 1) << g.lg2) + jp]; };
+  double yprev = 0.0, nS = faceS(0), nD = faceD(0);
+  auto step = [&](int h, double r, double cd, double cs, double cw) {
+    const double a1 = __shfl_up(yprev, 1, 64), aB = __shfl_up(yprev, g.B2, 64);
+    const double yd = kp == 0 ? nD : aB, ys = jp == 0 ? nS : a1, yw = h == hW ? yW : yprev;
+    nS = faceS(h + 1); nD = faceD(h + 1);                        // the next step's face values, off the dependency chain
+    double s = r;
+    s -= cd * yd;
+    s -= cs * ys;
+    s -= cw * yw;
+    yprev = s;
+    return s;
+  };
+  for (int p0 = 0; p0 < NP; p0 += DP) {
+#pragma unroll
+    for (int u = 0; u < DP; ++u) {
+      const int p = p0 + u;
+      dpair out;
+      out.x = step(2 * p, rr[u].x, ld[u].x, ls[u].x, lw[u].x);
+      out.y = step(2 * p + 1, rr[u].y, ld[u].y, ls[u].y, lw[u].y);
+      *(p < NP ? y2 + (size_t)p * 64 : sink) = out;             // past the box: a scratch row (keeps the loop body straight)
+      fetch(u, p + DP);
+      __builtin_amdgcn_sched_barrier(0);   // keep the issue order pair by pair: the wait of a pair then counts the younger loads
+    }
+  }
+}
+template <int DP>
+__global__ __launch_bounds__(64) void k_box_upper(BoxGrid g, const int *__restrict__ boxes, const double *__restrict__ Ue,
+                                                  const double *__restrict__ Un, const double *__restrict__ Uu,
+                                                  const double *__restrict__ Di, double *x, double *scratch) {
+  extern __shared__ double face[];                              // [B1][B3] north face, then [B1][B2] upper face
+  const int b = boxes[blockIdx.x], lane = threadIdx.x, S = g.S, NP = S >> 1;
+  const int jp = lane & (g.B2 - 1), kp = lane >> g.lg2;
+  const int I = b % g.NB1, J = (b / g.NB1) % g.NB2, K = b / (g.NB1 * g.NB2);
+  double *fN = face, *fU = face + g.B1 * g.B3;
+  const size_t own = box_slot(g, b, 0, lane);
+  {  // (i', k') of the north face: cell (i', 0, k') of box J+1; (i', j') of the upper face: cell (i', j', 0) of box K+1
+    const int nN = g.B1 * g.B3, nU = g.B1 * g.B2;
+    const bool hasN = J < g.NB2 - 1, hasU = K < g.NB3 - 1;
+    const long long bN = hasN ? b + g.NB1 : b, bU = hasU ? b + g.NB1 * g.NB2 : b;
+    for (int e0 = 0; e0 < max(nN, nU); e0 += 64 * 4) {
+      double vN[4], vU[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int eN = min(e0 + q * 64 + lane, nN - 1), eU = min(e0 + q * 64 + lane, nU - 1);
+        const int iN = eN / g.B3, kN = eN - iN * g.B3, iU = eU >> g.lg2, jU = eU & (g.B2 - 1);
+        vN[q] = x[box_slot(g, bN, iN + kN, g.B2 * kN)];
+        vU[q] = x[box_slot(g, bU, iU + jU, jU)];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int e = e0 + q * 64 + lane;
+        if (e < nN) fN[e] = hasN ? vN[q] : 0.0;
+        if (e < nU) fU[e] = hasU ? vU[q] : 0.0;
+      }
+    }
+  }
+  const int hE = g.B1 - 1 + jp + kp;                            // the step at which the lane is on the east face
+  double xE = 0.0;
+  if (I < g.NB1 - 1) xE = x[box_slot(g, b + 1, jp + kp, lane)];
+  const dpair *Ue2 = reinterpret_cast<const dpair *>(Ue + own), *Un2 = reinterpret_cast<const dpair *>(Un + own),
+                *Uu2 = reinterpret_cast<const dpair *>(Uu + own), *Di2 = reinterpret_cast<const dpair *>(Di + own);
+  dpair *x2 = reinterpret_cast<dpair *>(x + own), *sink = reinterpret_cast<dpair *>(scratch) + lane;
+  dpair ue[DP], un[DP], uu[DP], di[DP], rr[DP];
+  auto fetch = [&](int u, int p) {
+    const size_t o = (size_t)max(p, 0) * 64;
+    ue[u] = ldnt(Ue2 + o); un[u] = ldnt(Un2 + o); uu[u] = ldnt(Uu2 + o); di[u] = ldnt(Di2 + o);
+    rr[u] = x2[o];
+  };
+#pragma unroll
+  for (int u = 0; u < DP; ++u) { fetch(u, NP - 1 - u); __builtin_amdgcn_sched_barrier(0); }
+  __syncthreads();
+  auto faceN = [&](int h) { return fN[min(max(h - (g.B2 - 1) - kp, 0), g.B1 - 1) * g.B3 + kp]; };
+  auto faceU = [&](int h) { return fU[(min(max(h - jp - (g.B3 - 1), 0), g.B1 - 1) << g.lg2) + jp]; };
+  double xprev = 0.0, nN = faceN(S - 1), nU = faceU(S - 1);
+  auto step = [&](int h, double r, double ce, double cn, double cu, double d) {
+    const double a1 = __shfl_down(xprev, 1, 64), aB = __shfl_down(xprev, g.B2, 64);
+    const double xe = h == hE ? xE : xprev, xn = jp == g.B2 - 1 ? nN : a1, xu = kp == g.B3 - 1 ? nU : aB;
+    nN = faceN(h - 1); nU = faceU(h - 1);
+    double s = r;
+    s -= ce * xe;
+    s -= cn * xn;
+    s -= cu * xu;
+    s *= d;
+    xprev = s;
+    return s;
+  };
+  for (int p0 = NP - 1; p0 >= 0; p0 -= DP) {
+#pragma unroll
+    for (int u = 0; u < DP; ++u) {
+      const int p = p0 - u;
+      dpair out;
+      out.y = step(2 * p + 1, rr[u].y, ue[u].y, un[u].y, uu[u].y, di[u].y);
+      out.x = step(2 * p, rr[u].x, ue[u].x, un[u].x, uu[u].x, di[u].x);
+      *(p >= 0 ? x2 + (size_t)p * 64 : sink) = out;
+      fetch(u, p - DP);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void k_gather(int n, const int *idx, const double *in, double *out) {
   const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (i < (size_t)n) out[i] = in[idx[i]];
@@ -1874,6 +2063,22 @@ void launch_copy(int n, const double *x, double *y, hipStream_t stream) {
 }
 void launch_set(int n, double v, double *y, hipStream_t stream) {
   if (n > 0) LAUNCH(k_set, dim3(vec_grid(n)), n, v, y);
+}
+void launch_box_fill(long long nslots, const BoxGrid &g, const int *cellmap, const int *int2ext, const int *rowptr, const int *col,
+                     const double *lu, const double *idiag, double *const L[3], double *const U[3], double *Di, hipStream_t stream) {
+  if (nslots > 0) LAUNCH(k_box_fill, dim3(nblk(nslots)), nslots, g, cellmap, int2ext, rowptr, col, lu, idiag, L[0], L[1], L[2], U[0], U[1], U[2], Di);
+}
+void launch_gather_or_zero(long long n, const int *idx, const double *in, double *out, hipStream_t stream) {
+  if (n > 0) LAUNCH(k_gather_or_zero, dim3(nblk(n)), n, idx, in, out);
+}
+void launch_box_lower(const BoxGrid &g, const int *boxes, int nboxes, const double *const L[3], double *y, double *scratch, hipStream_t stream) {
+  const size_t lds = (size_t)g.B1 * (g.B2 + g.B3) * sizeof(double);
+  if (nboxes > 0) hipLaunchKernelGGL((k_box_lower<kBoxRing>), dim3(nboxes), dim3(64), lds, stream, g, boxes, L[0], L[1], L[2], y, scratch);
+}
+void launch_box_upper(const BoxGrid &g, const int *boxes, int nboxes, const double *const U[3], const double *Di, double *x, double *scratch,
+                      hipStream_t stream) {
+  const size_t lds = (size_t)g.B1 * (g.B2 + g.B3) * sizeof(double);
+  if (nboxes > 0) hipLaunchKernelGGL((k_box_upper<kBoxRingUpper>), dim3(nboxes), dim3(64), lds, stream, g, boxes, U[0], U[1], U[2], Di, x, scratch);
 }
 void launch_gather(int n, const int *idx, const double *in, double *out, hipStream_t stream) {
   if (n > 0) LAUNCH(k_gather, dim3(nblk(n)), n, idx, in, out);

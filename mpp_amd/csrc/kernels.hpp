@@ -216,6 +216,38 @@ void launch_ell_lower_level(int n, int K, const int *col, const double *val, int
 void launch_ell_upper_level(int n, int K, const int *col, const double *val, const double *idiag, int lo, int hi, double *x,
                             hipStream_t stream);
 
+// ---- the same ILU(0) solves when the pattern is a structured 7-point (5-, 3-point) grid in the caller's natural ordering ----
+// The grid (n1 fastest) is cut into boxes of B1 x B2 x B3 cells, B2 * B3 = 64.  A box is solved by one wave: lane (j', k') owns
+// the box's line in i' and at step h works on cell i' = h - j' - k', so the three dependencies of a cell are the lane's own
+// previous value and two values from neighbour lanes one step earlier -- registers and cross-lane moves instead of memory and
+// a kernel boundary per dependency level.  A box depends on its three lower (upper) neighbour boxes only: one launch per box
+// level I + J + K, NB1 + NB2 + NB3 - 2 of them instead of n1 + n2 + n3 - 2 cell levels.
+// Layout of everything the solves stream through (factor entries by direction, the reciprocal diagonal, the vector): step row
+// h = i' + j' + k' of a box, lane l = j' + B2 * k'; rows go in pairs so that a lane's operands of two consecutive steps are one
+// 16-byte load: slot = (box * S + (h & ~1)) * 64 + 2 * l + (h & 1), box = I + NB1 * (J + NB2 * K) (box_slot).  S = B1 + B2 + B3 - 2
+// rounded up to an even number; slots without a cell are zero.
+constexpr int kBoxRing = 12, kBoxRingUpper = 10;   // row pairs of operands a wave keeps in flight: 5 (upper solve: 6) memory
+                                                   // instructions each, and the counter holds 63
+constexpr int kBoxMaxLen = 256;   // B1 at most (B1 * (B2 + B3) doubles of faces in LDS)
+struct BoxGrid {
+  int n1, n2, n3;             // extents: caller's id = i + n1 * (j + n2 * k)
+  int B1, B2, B3, lg2;        // box extents (B2 = 1 << lg2, B2 * B3 = 64)
+  int NB1, NB2, NB3;          // boxes per direction
+  int S;                      // step rows per box
+};
+__host__ __device__ inline size_t box_slot(const BoxGrid &g, long long box, int row, int lane) {
+  return ((size_t)box * g.S + (size_t)(row & ~1)) * 64 + 2 * lane + (row & 1);
+}
+// L = {down, south, west}, U = {east, north, up} entries (ascending column order within a row), Di = 1 / u_ii
+void launch_box_fill(long long nslots, const BoxGrid &g, const int *cellmap, const int *int2ext, const int *rowptr, const int *col,
+                     const double *lu, const double *idiag, double *const L[3], double *const U[3], double *Di, hipStream_t stream);
+void launch_gather_or_zero(long long n, const int *idx, const double *in, double *out, hipStream_t stream);   // out[i] = idx[i] >= 0 ? in[idx[i]] : 0
+// the boxes of one box level (ids in boxes[0 .. nboxes)), in place on the vector in box layout
+// scratch: 128 doubles anybody may overwrite
+void launch_box_lower(const BoxGrid &g, const int *boxes, int nboxes, const double *const L[3], double *y, double *scratch, hipStream_t stream);
+void launch_box_upper(const BoxGrid &g, const int *boxes, int nboxes, const double *const U[3], const double *Di, double *x, double *scratch,
+                      hipStream_t stream);
+
 // ---- soil heat diffusion (thermal KSP path) ----
 struct ThermalArgs {
   int n;

@@ -221,6 +221,15 @@ struct Solver {
   unsigned chain_epoch = 0;
   hipGraph_t ilu_graph = nullptr;
   hipGraphExec_t ilu_graph_exec = nullptr;
+  // box wavefront solves on a structured grid (BoxGrid, kernels.hpp)
+  BoxGrid box{};
+  bool box_ok = false, box_tried = false, ell_built = false;
+  long long box_slots = 0;
+  DevBuf<int> box_cellmap, box_cellpos, box_order;
+  std::vector<int> box_lptr;                 // boxes of box level l: box_order[box_lptr[l] .. box_lptr[l+1])
+  DevBuf<double> box_L[3], box_U[3], box_Di, box_v, box_scratch;
+  hipGraph_t box_graph = nullptr;
+  hipGraphExec_t box_graph_exec = nullptr;
 
   double dtime = 0.0, time = 0.0;
   long long cum_newton = 0, cum_linear = 0, cum_cuts = 0, cum_funcs = 0;
@@ -235,6 +244,8 @@ struct Solver {
   ~Solver() {
     if (ilu_graph_exec) (void)hipGraphExecDestroy(ilu_graph_exec);
     if (ilu_graph) (void)hipGraphDestroy(ilu_graph);
+    if (box_graph_exec) (void)hipGraphExecDestroy(box_graph_exec);
+    if (box_graph) (void)hipGraphDestroy(box_graph);
     if (h_sc) (void)hipHostFree(h_sc);
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -1296,10 +1307,16 @@ struct Solver {
       launch_copy(nnz, d_val.p, d_lu.p, stream);
       for (size_t l = 0; l + 1 < h_lptr.size(); ++l)
         launch_ilu_factor_program(d_fptr.p, d_fprog.p, d_lrows.p, d_diag.p, h_lptr[l], h_lptr[l + 1], d_lu.p, d_idiag.p, stream);
-      // repack into the level-ordered ELL blocks the solves stream through
-      launch_ilu_repack((long long)ell_KL * nrow, d_Lslot.p, d_lu.p, d_Lval.p, stream);
-      launch_ilu_repack((long long)ell_KU * nrow, d_Uslot.p, d_lu.p, d_Uval.p, stream);
-      launch_gather(nrow, d_urows.p, d_idiag.p, d_Uidiag.p, stream);
+      if (opt.ilu_box == 2 && !box_ok) throw Error("ilu_box = 2: the matrix is not a structured grid in the caller's natural ordering");
+      if (box_active()) {   // into the box layout of the structured-grid solves
+        double *const L[3] = {box_L[0].p, box_L[1].p, box_L[2].p}, *const U[3] = {box_U[0].p, box_U[1].p, box_U[2].p};
+        launch_box_fill(box_slots, box, box_cellmap.p, d_int2ext.p, d_rowptr.p, d_col.p, d_lu.p, d_idiag.p, L, U, box_Di.p, stream);
+      } else {              // into the level-ordered ELL blocks the general solves stream through
+        ilu_build_ell();
+        launch_ilu_repack((long long)ell_KL * nrow, d_Lslot.p, d_lu.p, d_Lval.p, stream);
+        launch_ilu_repack((long long)ell_KU * nrow, d_Uslot.p, d_lu.p, d_Uval.p, stream);
+        launch_gather(nrow, d_urows.p, d_idiag.p, d_Uidiag.p, stream);
+      }
     }
     pc_ready = true;
   }
@@ -1311,13 +1328,33 @@ struct Solver {
     for (size_t l = 0; l + 1 < h_uptr.size(); ++l)
       launch_ell_upper_level(nrow, ell_KU, d_Ucol.p, d_Uval.p, d_Uidiag.p, h_uptr[l], h_uptr[l + 1], ilu_x.p, stream);
   }
+  // the box levels of both solves on the fixed buffer box_v
+  void box_solve_levels() {
+    const double *const L[3] = {box_L[0].p, box_L[1].p, box_L[2].p}, *const U[3] = {box_U[0].p, box_U[1].p, box_U[2].p};
+    const int nl = (int)box_lptr.size() - 1;
+    for (int l = 0; l < nl; ++l) launch_box_lower(box, box_order.p + box_lptr[l], box_lptr[l + 1] - box_lptr[l], L, box_v.p, box_scratch.p, stream);
+    for (int l = nl - 1; l >= 0; --l) launch_box_upper(box, box_order.p + box_lptr[l], box_lptr[l + 1] - box_lptr[l], U, box_Di.p, box_v.p, box_scratch.p, stream);
+  }
+  bool box_active() const { return box_ok && opt.ilu_box != 0; }
   void op_pc_apply(const double *r, double *z) {
     ProfScope ps(prof, KC_PC_APPLY);
     if (nghost > 0) launch_set(nghost, 0.0, const_cast<double *>(r) + nred, stream);   // block-Jacobi across ranks
     if (opt.pc_type == 2 && th) launch_th_tri_solve(th_tri_args(), r, z, stream);
     else if (opt.pc_type == 2) launch_tri_solve(tri_args(), r, z, stream);
     else if (opt.pc_type == 3) launch_pointwise_mult(nred, jac_invd.p, r, z, stream);
-    else if (opt.pc_type == 1) {
+    else if (opt.pc_type == 1 && box_active()) {
+      launch_gather_or_zero(box_slots, box_cellmap.p, r, box_v.p, stream);   // r into the box layout, padding zero
+      if (opt.ilu_graph && !under_rocprofiler()) {
+        if (!box_graph_exec) {
+          HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+          box_solve_levels();
+          HIP_CHECK(hipStreamEndCapture(stream, &box_graph));
+          HIP_CHECK(hipGraphInstantiate(&box_graph_exec, box_graph, nullptr, nullptr, 0));
+        }
+        HIP_CHECK(hipGraphLaunch(box_graph_exec, stream));
+      } else box_solve_levels();
+      launch_gather(nrow, box_cellpos.p, box_v.p, z, stream);                // back to the internal row order
+    } else if (opt.pc_type == 1) {
       launch_gather(nrow, d_lrows.p, r, ilu_y.p, stream);            // r into the L level order
       bool solved = false;
       if (ilu_chained()) {
@@ -2476,7 +2513,21 @@ struct Solver {
     d_lrows.upload(lrows, stream); d_urows.upload(urows, stream);
     d_ord.upload(ord, stream);
     d_lu.alloc(nnz); d_idiag.alloc(N);
-    // level-ordered ELL maps: position of every row in the L ordering (lrows) and in the U ordering (urows)
+    ilu_factor_program(lrows, ord);
+    ilu_box_analyse();
+    HIP_CHECK(hipStreamSynchronize(stream));
+  }
+  // level-ordered ELL maps of the general triangular solves: position of every row in the L ordering (lrows) and in the U
+  // ordering (urows); built when the box solves do not apply
+  void ilu_build_ell() {
+    if (ell_built) return;
+    ell_built = true;
+    const int N = nrow;
+    std::vector<int> lrows(N), urows(N), ord(N);
+    HIP_CHECK(hipMemcpyAsync(lrows.data(), d_lrows.p, (size_t)N * sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipMemcpyAsync(urows.data(), d_urows.p, (size_t)N * sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipMemcpyAsync(ord.data(), d_ord.p, (size_t)N * sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
     std::vector<int> posL(N), posU(N);
     for (int p = 0; p < N; ++p) { posL[lrows[p]] = p; posU[urows[p]] = p; }
     ell_KL = ell_KU = 0;
@@ -2490,13 +2541,17 @@ struct Solver {
     }
     std::vector<int> Lslot((size_t)ell_KL * N, -1), Lcol((size_t)ell_KL * N), Uslot((size_t)ell_KU * N, -1), Ucol((size_t)ell_KU * N);
     std::vector<int> l2u(N);
+    std::vector<std::pair<int, int>> ents;   // (caller's column, CSR slot)
     for (int i = 0; i < N; ++i) {
       const int pl = posL[i], pu = posU[i];
       for (int k = 0; k < ell_KL; ++k) Lcol[(size_t)k * N + pl] = pl;
       for (int k = 0; k < ell_KU; ++k) Ucol[(size_t)k * N + pu] = pu;
       int kl = 0, ku = 0;
-      for (int q = h_rowptr[i]; q < h_rowptr[i + 1]; ++q) {   // entries in column (= elimination) order of the sorted row
-        const int j = h_col[q], oj = ord[j];
+      ents.clear();
+      for (int q = h_rowptr[i]; q < h_rowptr[i + 1]; ++q) ents.emplace_back(ord[h_col[q]], q);
+      std::sort(ents.begin(), ents.end());   // a row's entries in the caller's column order, the order PETSc eliminates them in
+      for (auto &en : ents) {
+        const int q = en.second, j = h_col[q], oj = en.first;
         if (oj < ord[i]) { Lslot[(size_t)kl * N + pl] = q; Lcol[(size_t)kl * N + pl] = posL[j]; ++kl; }
         else if (oj > ord[i]) { Uslot[(size_t)ku * N + pu] = q; Ucol[(size_t)ku * N + pu] = posU[j]; ++ku; }
       }
@@ -2506,7 +2561,14 @@ struct Solver {
     build_chain(chainU, h_uptr, Ucol, ell_KU, /*skip_level0=*/false);
     d_Lslot.upload(Lslot, stream); d_Lcol.upload(Lcol, stream); d_Uslot.upload(Uslot, stream); d_Ucol.upload(Ucol, stream);
     d_l2u.upload(l2u, stream); d_posU.upload(posU, stream);
-    {  // elimination program of the numeric factorisation, rows in L level order (see k_ilu_factor_program)
+    d_Lval.alloc((size_t)ell_KL * N); d_Uval.alloc((size_t)ell_KU * N); d_Uidiag.alloc(N);
+    ilu_y.alloc(N); ilu_x.alloc(N);
+    HIP_CHECK(hipStreamSynchronize(stream));
+  }
+  // elimination program of the numeric factorisation, rows in L level order (see k_ilu_factor_program)
+  void ilu_factor_program(const std::vector<int> &lrows, const std::vector<int> &ord) {
+    const int N = nrow;
+    {
       std::vector<long long> fptr((size_t)N + 1, 0);
       std::vector<int> prog;
       prog.reserve((size_t)N * 16);
@@ -2537,9 +2599,80 @@ struct Solver {
       d_fptr.upload(fptr, stream); d_fprog.upload(prog, stream);
       HIP_CHECK(hipStreamSynchronize(stream));
     }
-    d_Lval.alloc((size_t)ell_KL * N); d_Uval.alloc((size_t)ell_KU * N); d_Uidiag.alloc(N);
-    ilu_y.alloc(N); ilu_x.alloc(N);
+  }
+  // Is the pattern a structured 7-point (5-, 3-point) grid in the caller's numbering?  Then the triangular solves run box by box
+  // (BoxGrid): extents from the distinct positive column distances {1, n1, n1*n2}, every row checked against the grid.
+  void ilu_box_analyse() {
+    if (box_tried) return;
+    box_tried = true; box_ok = false;
+    if (opt.ilu_box == 0 || th || nghost > 0 || nrow != n || n < 2) return;
+    const int N = n;
+    int offs[3], no = 0;
+    for (int r = 0; r < N; ++r) {
+      const int e = int2ext[r];
+      for (int q = h_rowptr[r]; q < h_rowptr[r + 1]; ++q) {
+        const int d = int2ext[h_col[q]] - e;
+        if (d <= 0) continue;
+        bool seen = false;
+        for (int k = 0; k < no; ++k) seen = seen || offs[k] == d;
+        if (seen) continue;
+        if (no == 3) return;
+        offs[no++] = d;
+      }
+    }
+    std::sort(offs, offs + no);
+    if (no == 0 || offs[0] != 1) return;
+    const long long n1 = no >= 2 ? offs[1] : N, s3 = no == 3 ? offs[2] : N;
+    if (N % n1 || s3 % n1 || N % s3) return;
+    const int n2 = (int)(s3 / n1), n3 = (int)(N / s3);
+    for (int r = 0; r < N; ++r) {   // the diagonal and exactly the grid neighbours in every row
+      const int e = int2ext[r], ci = (int)(e % n1), cj = (int)((e / n1) % n2), ck = (int)(e / s3);
+      const int expect = (ci > 0) + (ci < n1 - 1) + (cj > 0) + (cj < n2 - 1) + (ck > 0) + (ck < n3 - 1);
+      int cnt = 0;
+      bool diag = false;
+      for (int q = h_rowptr[r]; q < h_rowptr[r + 1]; ++q) {
+        const long long d = (long long)int2ext[h_col[q]] - e;
+        if (d == 0) diag = true;
+        else if ((d == -1 && ci > 0) || (d == 1 && ci < n1 - 1) || (n2 > 1 && ((d == -n1 && cj > 0) || (d == n1 && cj < n2 - 1))) ||
+                 (n3 > 1 && ((d == -s3 && ck > 0) || (d == s3 && ck < n3 - 1)))) ++cnt;
+        else return;
+      }
+      if (!diag || cnt != expect) return;
+    }
+    BoxGrid g{};
+    g.n1 = (int)n1; g.n2 = n2; g.n3 = n3;
+    g.B3 = 1;
+    while (g.B3 < 8 && g.B3 < n3) g.B3 *= 2;
+    g.B2 = 64 / g.B3;
+    g.lg2 = 0;
+    while ((1 << g.lg2) < g.B2) ++g.lg2;
+    g.B1 = opt.ilu_box_len > 0 ? opt.ilu_box_len : (N >= (1 << 25) ? 64 : 32);   // longer boxes: less padding, fewer levels
+    g.B1 = std::max(1, std::min(std::min(g.B1, g.n1), kBoxMaxLen));
+    g.NB1 = (g.n1 + g.B1 - 1) / g.B1; g.NB2 = (g.n2 + g.B2 - 1) / g.B2; g.NB3 = (g.n3 + g.B3 - 1) / g.B3;
+    g.S = (g.B1 + g.B2 + g.B3 - 2 + 1) / 2 * 2;
+    const long long nboxes = (long long)g.NB1 * g.NB2 * g.NB3, slots = nboxes * g.S * 64;
+    if (slots >= (1ll << 31)) return;
+    std::vector<int> cellmap((size_t)slots, -1), cellpos(N), order((size_t)nboxes);
+    for (int e = 0; e < N; ++e) {
+      const int i = (int)(e % n1), j = (int)((e / n1) % n2), k = (int)(e / s3);
+      const int I = i / g.B1, J = j / g.B2, K = k / g.B3, ip = i % g.B1, jp = j % g.B2, kp = k % g.B3;
+      const long long b = I + (long long)g.NB1 * (J + (long long)g.NB2 * K);
+      const long long t = (long long)box_slot(g, b, ip + jp + kp, jp + g.B2 * kp);
+      cellmap[(size_t)t] = ext2int[e];
+      cellpos[ext2int[e]] = (int)t;
+    }
+    const int nl = g.NB1 + g.NB2 + g.NB3 - 2;
+    box_lptr.assign(nl + 1, 0);
+    for (int K = 0; K < g.NB3; ++K) for (int J = 0; J < g.NB2; ++J) for (int I = 0; I < g.NB1; ++I) box_lptr[I + J + K + 1]++;
+    for (int l = 0; l < nl; ++l) box_lptr[l + 1] += box_lptr[l];
+    std::vector<int> fill(box_lptr.begin(), box_lptr.end() - 1);
+    for (int K = 0; K < g.NB3; ++K) for (int J = 0; J < g.NB2; ++J) for (int I = 0; I < g.NB1; ++I)
+      order[fill[I + J + K]++] = I + g.NB1 * (J + g.NB2 * K);
+    box_cellmap.upload(cellmap, stream); box_cellpos.upload(cellpos, stream); box_order.upload(order, stream);
+    for (int k = 0; k < 3; ++k) { box_L[k].alloc((size_t)slots); box_U[k].alloc((size_t)slots); }
+    box_Di.alloc((size_t)slots); box_v.alloc((size_t)slots); box_scratch.alloc(128);
     HIP_CHECK(hipStreamSynchronize(stream));
+    box = g; box_slots = slots; box_ok = true;
   }
 
   // current matrix values in the caller's ordering, columns sorted
@@ -2608,6 +2741,13 @@ struct Solver {
     } else if (key == "nseg") opt.nseg = (int)num();
     else if (key == "fused_assembly") opt.fused_assembly = num() != 0;
     else if (key == "ilu_graph") opt.ilu_graph = num() != 0;
+    else if (key == "ilu_box") { opt.ilu_box = (int)num(); pc_ready = false; }   // the factors are repacked for the other solve path
+    else if (key == "ilu_box_len") {
+      const int v = (int)num();
+      if (v < 0 || v > kBoxMaxLen) throw Error("ilu_box_len must be between 0 and " + std::to_string(kBoxMaxLen));
+      if (box_tried) throw Error("ilu_box_len must be set before the first preconditioner set-up");
+      opt.ilu_box_len = v;
+    }
     else if (key == "ilu_chain") opt.ilu_chain = (int)num();   // 0 per-level launches, 1 chained where it pays, 2 always chained
     else if (key == "ilu_chain_tickets") opt.ilu_chain_tickets = num() != 0;
     else if (key == "ilu_chain_spins") opt.ilu_chain_spins = (unsigned)num();   // polls before a chained wait gives up (tests: 0)

@@ -62,9 +62,9 @@ def test_chained_ilu_timeout_is_redone_with_level_launches():
     """spin budget 0: every dependency wait of the chained triangular solves gives up at once, the application is redone
     per level on the spot and the step's answer is the one of the per-level solve; the fallback is counted"""
     tp = P.thermal_mms(3, 12, 10, 9, replicate_reference_soil_indexing=False)
-    ref = P.to_thermal_gpu(tp, {"ksp_type": "gmres", "pc_type": "ilu", "ilu_chain": 0})
-    bad = P.to_thermal_gpu(tp, {"ksp_type": "gmres", "pc_type": "ilu", "ilu_chain": 2, "ilu_chain_spins": 0})
-    ok = P.to_thermal_gpu(tp, {"ksp_type": "gmres", "pc_type": "ilu", "ilu_chain": 2})
+    ref = P.to_thermal_gpu(tp, {"ksp_type": "gmres", "pc_type": "ilu", "ilu_chain": 0, "ilu_box": 0})
+    bad = P.to_thermal_gpu(tp, {"ksp_type": "gmres", "pc_type": "ilu", "ilu_chain": 2, "ilu_chain_spins": 0, "ilu_box": 0})
+    ok = P.to_thermal_gpu(tp, {"ksp_type": "gmres", "pc_type": "ilu", "ilu_chain": 2, "ilu_box": 0})
     for g in (ref, bad, ok):
         conv, _ = g.soe.StepDT(tp.dt, 1)
         assert conv
@@ -317,3 +317,67 @@ def test_fortran_hosted_thermal_mms(golden_dir, name, ptype, dims, ncell):
     tol.update_from_name("general", "1.0e-9 relative")
     status, msgs = R.compare(run.stdout, gold, tol)
     assert status == "pass", msgs
+
+
+@pytest.mark.parametrize("dims,box_len", [((37, 19, 11), 0), ((37, 19, 11), 5), ((70, 9, 3), 16), ((23, 17, 1), 0), ((20, 1, 1), 0),
+                                          ((64, 16, 8), 64), ((33, 40, 21), 32)])
+def test_box_ilu_solves_reproduce_the_level_scheduled_ones_bit_for_bit(dims, box_len):
+    """ILU(0) triangular solves of a structured grid box by box (one wave per box, dependencies through registers and cross-lane
+    moves) against one launch per dependency level: per row the entries are eliminated in the same order, so the Krylov
+    iterates, the iteration count and the answer must be the same bits; ragged extents, 1-D / 2-D / 3-D, several box lengths"""
+    ptype = 3 if dims[2] > 1 else 2 if dims[1] > 1 else 1
+    tp = P.thermal_mms(ptype, *dims, replicate_reference_soil_indexing=False)
+    box = P.to_thermal_gpu(tp, {"ksp_type": "gmres", "pc_type": "ilu", "ilu_box": 2, "ilu_box_len": box_len})
+    lev = P.to_thermal_gpu(tp, {"ksp_type": "gmres", "pc_type": "ilu", "ilu_box": 0, "ilu_chain": 0})
+    for g in (box, lev):
+        conv, _ = g.soe.StepDT(tp.dt, 1)
+        assert conv
+    assert box.soe.last_linear_iterations == lev.soe.last_linear_iterations
+    assert np.array_equal(box.soe.GetSoln(), lev.soe.GetSoln())
+
+
+def test_box_ilu_applications_on_the_3d_vsfm_jacobian():
+    """the same on the 7-point Jacobian of the v-channel problem (VSFM, z-fastest caller numbering, 63 K rows): forty
+    applications in a row (a stale operand would show up now and then), then a whole time step"""
+    prob = P.vchannel(nx=40, ny=36, nz=44)
+    n = prob.mesh.ncells_local
+    x = prob.press_ic - np.random.default_rng(2).uniform(0, 2.5e5, n)
+    box = P.to_gpu(prob, {"ksp_type": "gmres", "pc_type": "ilu", "ilu_box": 2})
+    lev = P.to_gpu(prob, {"ksp_type": "gmres", "pc_type": "ilu", "ilu_box": 0, "ilu_chain": 0})
+    for g in (box, lev):
+        g.soe.SetDtime(prob.dt); g.soe.PreSolve()
+        g.soe.ComputeJacobian(x)
+    rng = np.random.default_rng(17)
+    for rep in range(40):
+        v = rng.standard_normal(n)
+        assert np.array_equal(box.soe.PCApply(v), lev.soe.PCApply(v)), rep
+    assert box.soe.StepDT(prob.dt, 1) == lev.soe.StepDT(prob.dt, 1)
+    assert box.soe.counters() == lev.soe.counters()
+    assert np.array_equal(box.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1),
+                          lev.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1))
+
+
+def test_box_ilu_is_refused_by_name_on_a_pattern_that_is_not_a_grid():
+    """the v-channel grid with one lateral connection missing is not a grid any more: ilu_box = 2 must say so, the default
+    falls back to the level-scheduled solves"""
+    from mpp_amd import mesh as M
+    from mpp_amd import vsfm as V
+
+    def holed():
+        prob = P.vchannel(nx=6, ny=5, nz=7)
+        cs = prob.mesh.intrn_conn_sets[0]
+        prob.mesh.intrn_conn_sets = [M.ConnectionSet(cs.id_up[:-1], cs.id_dn[:-1], cs.dist_up[:-1], cs.dist_dn[:-1], cs.area[:-1],
+                                                     cs.unit_vec[:-1], None if cs.itype is None else cs.itype[:-1])]
+        return prob
+    prob = holed()
+    x = prob.press_ic - np.random.default_rng(3).uniform(0, 2e4, prob.press_ic.size)
+    strict = P.to_gpu(prob, {"ksp_type": "gmres", "pc_type": "ilu", "ilu_box": 2})
+    strict.soe.SetDtime(prob.dt); strict.soe.PreSolve(); strict.soe.ComputeJacobian(x)
+    with pytest.raises(V.MPPError, match="not a structured grid"):
+        strict.soe.PCApply(np.ones(x.size))
+    dflt = P.to_gpu(holed(), {"ksp_type": "gmres", "pc_type": "ilu"})
+    lev = P.to_gpu(holed(), {"ksp_type": "gmres", "pc_type": "ilu", "ilu_box": 0})
+    for g in (dflt, lev):
+        g.soe.SetDtime(prob.dt); g.soe.PreSolve(); g.soe.ComputeJacobian(x)
+    v = np.random.default_rng(5).standard_normal(x.size)
+    assert np.array_equal(dflt.soe.PCApply(v), lev.soe.PCApply(v))

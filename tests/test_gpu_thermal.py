@@ -100,8 +100,8 @@ def test_chained_and_per_level_ilu_solves_agree_bit_for_bit():
     prob = P.vchannel(nx=40, ny=36, nz=44)                  # 63 K rows, 118 dependency levels, ragged tiles
     n = prob.mesh.ncells_local
     x = prob.press_ic - np.random.default_rng(2).uniform(0, 2.5e5, n)
-    chain = P.to_gpu(prob, {"ksp_type": "gmres", "pc_type": "ilu", "ilu_chain": 2})
-    level = P.to_gpu(prob, {"ksp_type": "gmres", "pc_type": "ilu", "ilu_chain": 0, "ilu_graph": 0})
+    chain = P.to_gpu(prob, {"ksp_type": "gmres", "pc_type": "ilu", "ilu_chain": 2, "ilu_box": 0})
+    level = P.to_gpu(prob, {"ksp_type": "gmres", "pc_type": "ilu", "ilu_chain": 0, "ilu_graph": 0, "ilu_box": 0})
     for g in (chain, level):
         g.soe.SetDtime(prob.dt); g.soe.PreSolve()
         g.soe.ComputeJacobian(x)
