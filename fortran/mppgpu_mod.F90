@@ -32,7 +32,8 @@ module mppgpu_mod
         mppgpu_set_source_sink_auxvar, mppgpu_thermal_set_soils, mppgpu_thermal_set_soln_prev_clm, &
         mppgpu_thermal_pre_step_dt, mppgpu_thermal_step_dt, mppgpu_thermal_get_soln, mppgpu_thermal_compute_rhs, &
         mppgpu_thermal_compute_operators, mppgpu_th_add_condition, mppgpu_th_set_soils, mppgpu_kernel_stats, &
-        mppgpu_reset_stats, mppgpu_get_comm_stats, mppgpu_bench_kernel, mppgpu_comm_get_unique_id, mppgpu_comm_init, &
+        mppgpu_reset_stats, mppgpu_get_comm_stats, mppgpu_get_pc_info, mppgpu_bench_kernel, &
+        mppgpu_comm_get_unique_id, mppgpu_comm_init, &
         mppgpu_comm_init_local, mppgpu_set_ghost_cells, mppgpu_set_halo, &
         mppgpu_pre_step_dt, mppgpu_post_step_dt
 
@@ -316,6 +317,11 @@ module mppgpu_mod
        import :: c_int, c_ptr, c_long_long
        type(c_ptr), value :: h
        integer(c_long_long) :: allreduces, halo_exchanges, chain_fallbacks
+     end function
+     integer(c_int) function mppgpu_get_pc_info(h, path, launches, box_extents) bind(C, name='mppgpu_get_pc_info')
+       import :: c_int, c_ptr
+       type(c_ptr), value :: h
+       integer(c_int) :: path, launches, box_extents(3)
      end function
      integer(c_int) function mppgpu_bench_kernel(h, kernel, variant, reps, avg_ms, bytes) bind(C, name='mppgpu_bench_kernel')
        import :: c_int, c_ptr, c_double, c_char

@@ -297,6 +297,12 @@ int mppgpu_reset_stats(mppgpu_handle h);
  * group) and halo exchanges; and how many chained ILU(0) applications had to be redone with per-level launches because a
  * dependency wait exhausted its spin budget (since mppgpu_setup).  No counterpart in the reference (PETSC_COMM_SELF). */
 int mppgpu_get_comm_stats(mppgpu_handle h, long long *allreduces, long long *halo_exchanges, long long *chain_fallbacks);
+/* how the ILU(0) preconditioner (PETSc PCILU, MatSolve_SeqAIJ) applies its triangular solves on this handle, known once the
+ * preconditioner has been set up: path = 0 no ILU(0) in use (or not set up yet), 1 one launch per dependency level,
+ * 2 one launch per triangle with the tiles of a level chained by flags, 3 one launch per box level of a structured grid;
+ * launches = kernel launches per application of the preconditioner; box_extents[0..2] = cells per box in the caller's
+ * fastest, second and third direction (path 3; zeros otherwise).  Any output pointer may be NULL. */
+int mppgpu_get_pc_info(mppgpu_handle h, int *path, int *launches, int *box_extents);
 /* device-resident micro-benchmark of one kernel class on the current state: `reps` launches, average ms */
 int mppgpu_bench_kernel(mppgpu_handle h, const char *name, int variant, int reps, double *avg_ms,
                         double *algorithmic_bytes);

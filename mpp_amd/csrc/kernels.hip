@@ -16,6 +16,7 @@
 #include "kernels.hpp"
 
 #include <algorithm>
+#include <type_traits>
 
 namespace mpp {
 
@@ -1255,65 +1256,100 @@ __global__ __launch_bounds__(kBlock) void k_gather_or_zero(long long n, const in
 
 // One wave solves one box; lane (j', k') walks its line of the box in i', one step row per step: at step h it holds cell
 // i' = h - j' - k'.  The west neighbour's value is the lane's own previous result, south and down come from lanes -1 and -B2 one
-// step earlier; across a box face they come from the finished neighbour box, whose face the wave copies into LDS before it
-// starts.  Padding slots carry zero coefficients and a zero right-hand side, so every lane computes every step (no branches).
-// Operands arrive as 16-byte loads (two step rows per lane and instruction, see box_slot) through a ring of DP row pairs: five
-// memory instructions per pair, DP = 12 keeps 60 of the 63 the counter can hold in flight -- a box of 32 is fetched whole.
+// step earlier (a DPP shift and a bpermute); across a box face they come from the finished neighbour box, whose face the wave
+// copies into LDS before it starts.  Padding slots carry zero coefficients and a zero right-hand side, so every lane computes
+// every step (no branches).  Operands arrive as 16-byte loads (two step rows per lane and instruction, see box_slot) through a
+// ring of DP row pairs: five memory instructions per pair, DP = 12 keeps 60 of the 63 the counter can hold in flight.
+// The step is issue-bound (SQ counters, profiles/r02_pmc_sq_box_ilu_v2.md), so it is kept to ~15 vector instructions: row
+// addresses are scalar, the face values are read through pointers that advance by a constant (margins instead of clamps).
 // Per row the entries are eliminated in the order of the level-scheduled kernels (ascending column): the same bits.
+__device__ __forceinline__ double lane_shift(double v, int bperm_addr) {   // v of the lane bperm_addr / 4
+  const int lo = __builtin_amdgcn_ds_bpermute(bperm_addr, __double2loint(v)), hi = __builtin_amdgcn_ds_bpermute(bperm_addr, __double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+template <int CTRL>   // 0x138: from lane - 1, 0x130: from lane + 1 (whole-wave DPP shifts; the end lane keeps 0)
+__device__ __forceinline__ double lane_dpp(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false),
+            hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// LDS of a box solve: 8 zeros (what a lane reads for a face nobody is behind), then the two face arrays.  Element (i', c) of a
+// face with C lines is placed so that the lane of line c reads it at the step it works on the cell next to it, through a pointer
+// that advances by C per step; zero rows of margin either side for the steps at which the lane is outside the box.
+__host__ __device__ inline int box_face_doubles(const BoxGrid &g) {
+  return 8 + (g.NB2 > 1 ? (g.S + g.B3 + 1) * g.B3 : 0) + (g.NB3 > 1 ? (g.S + g.B2 + 1) * g.B2 : 0);
+}
+// uniform row pointer + the lane's byte offset (32 bits): the address form that keeps the row arithmetic scalar
+template <class T>
+__device__ __forceinline__ T *at_lane(T *row, unsigned lane_bytes) {
+  using B = std::conditional_t<std::is_const<T>::value, const char, char>;
+  return reinterpret_cast<T *>(reinterpret_cast<B *>(row) + lane_bytes);   // (pointer arithmetic: the address space stays known)
+}
+constexpr int kFaceBatch = 8;   // face elements per lane requested up front (B1 * 8 / 64 of a 3-D box: all of them up to B1 = 64)
 template <int DP>
 __global__ __launch_bounds__(64) void k_box_lower(BoxGrid g, const int *__restrict__ boxes, const double *__restrict__ Ld,
                                                   const double *__restrict__ Ls, const double *__restrict__ Lw, double *y,
                                                   double *scratch) {
-  extern __shared__ double face[];                              // [B1][B3] south face, then [B1][B2] lower face
+  extern __shared__ double face[];
   const int b = boxes[blockIdx.x], lane = threadIdx.x, S = g.S, NP = S >> 1;
   const int jp = lane & (g.B2 - 1), kp = lane >> g.lg2;
   const int I = b % g.NB1, J = (b / g.NB1) % g.NB2, K = b / (g.NB1 * g.NB2);
-  double *fS = face, *fD = face + g.B1 * g.B3;
-  const size_t own = box_slot(g, b, 0, lane);                   // the lane's slot in row 0; row pair p is 128 * p further on
-  // faces of the boxes behind: element (i', k') of the south face is cell (i', B2-1, k') of box J-1, (i', j') of the lower
-  // face cell (i', j', B3-1) of box K-1; no box there: zeros
-  {
-    const int nS = g.B1 * g.B3, nD = g.B1 * g.B2;
-    const long long bS = J > 0 ? b - g.NB1 : b, bD = K > 0 ? b - g.NB1 * g.NB2 : b;
-    for (int e0 = 0; e0 < max(nS, nD); e0 += 64 * 4) {
-      double vS[4], vD[4];
+  const bool useS = g.NB2 > 1, useD = g.NB3 > 1;
+  double *fS = face + 8, *fD = fS + (useS ? (S + g.B3 + 1) * g.B3 : 0);
+  for (int e = lane; e < box_face_doubles(g); e += 64) face[e] = 0.0;
+  // element (i', k') of the south face is cell (i', B2-1, k') of box J-1, (i', j') of the lower face cell (i', j', B3-1) of box K-1;
+  // the first kFaceBatch * 64 elements of either face are requested here and parked behind the ring's first fill (one round trip
+  // to memory for both), longer faces follow in a loop
+  const int nfS = J > 0 ? g.B1 * g.B3 : 0, nfD = K > 0 ? g.B1 * g.B2 : 0;
+  auto srcS = [&](int e) { const int i = e / g.B3, k = e - i * g.B3; return y + box_slot(g, b - g.NB1, i + g.B2 - 1 + k, g.B2 - 1 + g.B2 * k); };
+  auto srcD = [&](int e) { const int i = e >> g.lg2, j = e & (g.B2 - 1); return y + box_slot(g, b - g.NB1 * g.NB2, i + j + g.B3 - 1, j + g.B2 * (g.B3 - 1)); };
+  auto dstS = [&](int e) { const int i = e / g.B3, k = e - i * g.B3; return fS + (i + g.B3 - 1) * g.B3 + k; };
+  auto dstD = [&](int e) { const int i = e >> g.lg2, j = e & (g.B2 - 1); return fD + (i + g.B2 - 1) * g.B2 + j; };
+  double vS[kFaceBatch], vD[kFaceBatch];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int eS = min(e0 + q * 64 + lane, nS - 1), eD = min(e0 + q * 64 + lane, nD - 1);
-        const int iS = eS / g.B3, kS = eS - iS * g.B3, iD = eD >> g.lg2, jD = eD & (g.B2 - 1);
-        vS[q] = y[box_slot(g, bS, iS + g.B2 - 1 + kS, g.B2 - 1 + g.B2 * kS)];
-        vD[q] = y[box_slot(g, bD, iD + jD + g.B3 - 1, jD + g.B2 * (g.B3 - 1))];
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int e = e0 + q * 64 + lane;
-        if (e < nS) fS[e] = J > 0 ? vS[q] : 0.0;
-        if (e < nD) fD[e] = K > 0 ? vD[q] : 0.0;
-      }
-    }
+  for (int q = 0; q < kFaceBatch; ++q) {
+    const int e = q * 64 + lane;
+    vS[q] = *(e < nfS ? srcS(e) : y + (size_t)b * S * 64);      // (nobody behind, or past the face: any valid address)
+    vD[q] = *(e < nfD ? srcD(e) : y + (size_t)b * S * 64);
   }
   const int hW = jp + kp;                                       // the step at which the lane is on the west face
-  double yW = 0.0;
-  if (I > 0) yW = y[box_slot(g, b - 1, g.B1 - 1 + hW, lane)];
-  const dpair *Ld2 = reinterpret_cast<const dpair *>(Ld + own), *Ls2 = reinterpret_cast<const dpair *>(Ls + own),
-                *Lw2 = reinterpret_cast<const dpair *>(Lw + own);
-  dpair *y2 = reinterpret_cast<dpair *>(y + own), *sink = reinterpret_cast<dpair *>(scratch) + lane;
+  double yW = *(I > 0 ? y + box_slot(g, b - 1, g.B1 - 1 + hW, lane) : y + (size_t)b * S * 64);
+  if (I == 0) yW = 0.0;
+  const size_t row0 = (size_t)b * S * 64;                       // the box's first slot (uniform); row pair p is 64 dpairs further on
+  const dpair *Ld2 = reinterpret_cast<const dpair *>(Ld + row0), *Ls2 = reinterpret_cast<const dpair *>(Ls + row0),
+              *Lw2 = reinterpret_cast<const dpair *>(Lw + row0);
+  dpair *y2 = reinterpret_cast<dpair *>(y + row0), *sink = reinterpret_cast<dpair *>(scratch);
+  const unsigned lane16 = threadIdx.x * 16u;
   dpair ld[DP], ls[DP], lw[DP], rr[DP];
   auto fetch = [&](int u, int p) {
-    const size_t o = (size_t)min(p, NP - 1) * 64;               // in double2 units: 128 doubles per row pair
-    ld[u] = ldnt(Ld2 + o); ls[u] = ldnt(Ls2 + o); lw[u] = ldnt(Lw2 + o);
-    rr[u] = y2[o];
+    const size_t o = (size_t)min(p, NP - 1) * 64;               // uniform
+    ld[u] = ldnt(at_lane(Ld2 + o, lane16)); ls[u] = ldnt(at_lane(Ls2 + o, lane16)); lw[u] = ldnt(at_lane(Lw2 + o, lane16));
+    rr[u] = *at_lane(y2 + o, lane16);
   };
 #pragma unroll
   for (int u = 0; u < DP; ++u) { fetch(u, u); __builtin_amdgcn_sched_barrier(0); }
-  __syncthreads();                                              // (one wave: orders the LDS writes above before the reads)
-  auto faceS = [&](int h) { return fS[min(max(h - kp, 0), g.B1 - 1) * g.B3 + kp]; };
-  auto faceD = [&](int h) { return fD[(min(max(h - jp, 0), g.B1 - 1) << g.lg2) + jp]; };
-  double yprev = 0.0, nS = faceS(0), nD = faceD(0);
+  __syncthreads();                                              // (one wave: the zeros are in place before the face values)
+#pragma unroll
+  for (int q = 0; q < kFaceBatch; ++q) {
+    const int e = q * 64 + lane;
+    if (e < nfS) *dstS(e) = vS[q];
+    if (e < nfD) *dstD(e) = vD[q];
+  }
+  for (int e = kFaceBatch * 64 + lane; e < max(nfS, nfD); e += 64) {
+    if (e < nfS) *dstS(e) = *srcS(e);
+    if (e < nfD) *dstD(e) = *srcD(e);
+  }
+  __syncthreads();
+  const double *pS = useS ? fS + (g.B3 - 1 - kp) * g.B3 + kp : face, *pD = useD ? fD + (g.B2 - 1 - jp) * g.B2 + jp : face;   // (face[0] = 0)
+  const int incS = useS ? g.B3 : 0, incD = useD ? g.B2 : 0;
+  const bool inS = jp != 0, inD = kp != 0;
+  const int addrB = ((lane - g.B2) & 63) << 2;
+  double yprev = 0.0, nS = *pS, nD = *pD;
   auto step = [&](int h, double r, double cd, double cs, double cw) {
-    const double a1 = __shfl_up(yprev, 1, 64), aB = __shfl_up(yprev, g.B2, 64);
-    const double yd = kp == 0 ? nD : aB, ys = jp == 0 ? nS : a1, yw = h == hW ? yW : yprev;
-    nS = faceS(h + 1); nD = faceD(h + 1);                        // the next step's face values, off the dependency chain
+    const double a1 = lane_dpp<0x138>(yprev), aB = lane_shift(yprev, addrB);
+    const double yd = inD ? aB : nD, ys = inS ? a1 : nS, yw = h == hW ? yW : yprev;
+    pS += h + 1 < S ? incS : 0; pD += h + 1 < S ? incD : 0;     // (not past the last step: the loop's tail pairs compute nothing real)
+    nS = *pS; nD = *pD;                                         // the next step's face values, off the dependency chain
     double s = r;
     s -= cd * yd;
     s -= cs * ys;
@@ -1328,7 +1364,8 @@ __global__ __launch_bounds__(64) void k_box_lower(BoxGrid g, const int *__restri
       dpair out;
       out.x = step(2 * p, rr[u].x, ld[u].x, ls[u].x, lw[u].x);
       out.y = step(2 * p + 1, rr[u].y, ld[u].y, ls[u].y, lw[u].y);
-      *(p < NP ? y2 + (size_t)p * 64 : sink) = out;             // past the box: a scratch row (keeps the loop body straight)
+      dpair *dst = p < NP ? y2 + (size_t)p * 64 : sink;         // past the box: a scratch row (keeps the loop body straight)
+      *at_lane(dst, lane16) = out;
       fetch(u, p + DP);
       __builtin_amdgcn_sched_barrier(0);   // keep the issue order pair by pair: the wait of a pair then counts the younger loads
     }
@@ -1338,55 +1375,70 @@ template <int DP>
 __global__ __launch_bounds__(64) void k_box_upper(BoxGrid g, const int *__restrict__ boxes, const double *__restrict__ Ue,
                                                   const double *__restrict__ Un, const double *__restrict__ Uu,
                                                   const double *__restrict__ Di, double *x, double *scratch) {
-  extern __shared__ double face[];                              // [B1][B3] north face, then [B1][B2] upper face
+  extern __shared__ double face[];
   const int b = boxes[blockIdx.x], lane = threadIdx.x, S = g.S, NP = S >> 1;
   const int jp = lane & (g.B2 - 1), kp = lane >> g.lg2;
   const int I = b % g.NB1, J = (b / g.NB1) % g.NB2, K = b / (g.NB1 * g.NB2);
-  double *fN = face, *fU = face + g.B1 * g.B3;
-  const size_t own = box_slot(g, b, 0, lane);
-  {  // (i', k') of the north face: cell (i', 0, k') of box J+1; (i', j') of the upper face: cell (i', j', 0) of box K+1
-    const int nN = g.B1 * g.B3, nU = g.B1 * g.B2;
-    const bool hasN = J < g.NB2 - 1, hasU = K < g.NB3 - 1;
-    const long long bN = hasN ? b + g.NB1 : b, bU = hasU ? b + g.NB1 * g.NB2 : b;
-    for (int e0 = 0; e0 < max(nN, nU); e0 += 64 * 4) {
-      double vN[4], vU[4];
+  const bool useN = g.NB2 > 1, useU = g.NB3 > 1;
+  const int M = g.B2 + g.B3 - 2;
+  double *fN = face + 8, *fU = fN + (useN ? (S + g.B3 + 1) * g.B3 : 0);
+  for (int e = lane; e < box_face_doubles(g); e += 64) face[e] = 0.0;
+  // (i', k') of the north face: cell (i', 0, k') of box J+1, wanted by lane (B2-1, k') at step h = i' + B2-1 + k';
+  // (i', j') of the upper face: cell (i', j', 0) of box K+1, wanted by lane (j', B3-1) at step h = i' + j' + B3-1.
+  // Stored behind M = B2 + B3 - 2 rows of (zero) margin: the lanes run up to M steps outside the box on that side.
+  const int nfN = J < g.NB2 - 1 ? g.B1 * g.B3 : 0, nfU = K < g.NB3 - 1 ? g.B1 * g.B2 : 0;
+  auto srcN = [&](int e) { const int i = e / g.B3, k = e - i * g.B3; return x + box_slot(g, b + g.NB1, i + k, g.B2 * k); };
+  auto srcU = [&](int e) { const int i = e >> g.lg2, j = e & (g.B2 - 1); return x + box_slot(g, b + g.NB1 * g.NB2, i + j, j); };
+  auto dstN = [&](int e) { const int i = e / g.B3, k = e - i * g.B3; return fN + (i + M) * g.B3 + k; };
+  auto dstU = [&](int e) { const int i = e >> g.lg2, j = e & (g.B2 - 1); return fU + (i + M) * g.B2 + j; };
+  double vN[kFaceBatch], vU[kFaceBatch];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int eN = min(e0 + q * 64 + lane, nN - 1), eU = min(e0 + q * 64 + lane, nU - 1);
-        const int iN = eN / g.B3, kN = eN - iN * g.B3, iU = eU >> g.lg2, jU = eU & (g.B2 - 1);
-        vN[q] = x[box_slot(g, bN, iN + kN, g.B2 * kN)];
-        vU[q] = x[box_slot(g, bU, iU + jU, jU)];
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int e = e0 + q * 64 + lane;
-        if (e < nN) fN[e] = hasN ? vN[q] : 0.0;
-        if (e < nU) fU[e] = hasU ? vU[q] : 0.0;
-      }
-    }
+  for (int q = 0; q < kFaceBatch; ++q) {
+    const int e = q * 64 + lane;
+    vN[q] = *(e < nfN ? srcN(e) : x + (size_t)b * S * 64);
+    vU[q] = *(e < nfU ? srcU(e) : x + (size_t)b * S * 64);
   }
   const int hE = g.B1 - 1 + jp + kp;                            // the step at which the lane is on the east face
-  double xE = 0.0;
-  if (I < g.NB1 - 1) xE = x[box_slot(g, b + 1, jp + kp, lane)];
-  const dpair *Ue2 = reinterpret_cast<const dpair *>(Ue + own), *Un2 = reinterpret_cast<const dpair *>(Un + own),
-                *Uu2 = reinterpret_cast<const dpair *>(Uu + own), *Di2 = reinterpret_cast<const dpair *>(Di + own);
-  dpair *x2 = reinterpret_cast<dpair *>(x + own), *sink = reinterpret_cast<dpair *>(scratch) + lane;
+  double xE = *(I < g.NB1 - 1 ? x + box_slot(g, b + 1, jp + kp, lane) : x + (size_t)b * S * 64);
+  if (I == g.NB1 - 1) xE = 0.0;
+  const size_t row0 = (size_t)b * S * 64;
+  const dpair *Ue2 = reinterpret_cast<const dpair *>(Ue + row0), *Un2 = reinterpret_cast<const dpair *>(Un + row0),
+              *Uu2 = reinterpret_cast<const dpair *>(Uu + row0), *Di2 = reinterpret_cast<const dpair *>(Di + row0);
+  dpair *x2 = reinterpret_cast<dpair *>(x + row0), *sink = reinterpret_cast<dpair *>(scratch);
+  const unsigned lane16 = threadIdx.x * 16u;
   dpair ue[DP], un[DP], uu[DP], di[DP], rr[DP];
   auto fetch = [&](int u, int p) {
     const size_t o = (size_t)max(p, 0) * 64;
-    ue[u] = ldnt(Ue2 + o); un[u] = ldnt(Un2 + o); uu[u] = ldnt(Uu2 + o); di[u] = ldnt(Di2 + o);
-    rr[u] = x2[o];
+    ue[u] = ldnt(at_lane(Ue2 + o, lane16)); un[u] = ldnt(at_lane(Un2 + o, lane16)); uu[u] = ldnt(at_lane(Uu2 + o, lane16));
+    di[u] = ldnt(at_lane(Di2 + o, lane16));
+    rr[u] = *at_lane(x2 + o, lane16);
   };
 #pragma unroll
   for (int u = 0; u < DP; ++u) { fetch(u, NP - 1 - u); __builtin_amdgcn_sched_barrier(0); }
   __syncthreads();
-  auto faceN = [&](int h) { return fN[min(max(h - (g.B2 - 1) - kp, 0), g.B1 - 1) * g.B3 + kp]; };
-  auto faceU = [&](int h) { return fU[(min(max(h - jp - (g.B3 - 1), 0), g.B1 - 1) << g.lg2) + jp]; };
-  double xprev = 0.0, nN = faceN(S - 1), nU = faceU(S - 1);
+#pragma unroll
+  for (int q = 0; q < kFaceBatch; ++q) {
+    const int e = q * 64 + lane;
+    if (e < nfN) *dstN(e) = vN[q];
+    if (e < nfU) *dstU(e) = vU[q];
+  }
+  for (int e = kFaceBatch * 64 + lane; e < max(nfN, nfU); e += 64) {
+    if (e < nfN) *dstN(e) = *srcN(e);
+    if (e < nfU) *dstU(e) = *srcU(e);
+  }
+  __syncthreads();
+  // first step h = S - 1: i' = S - 1 - (B2 - 1) - kp on the north face, S - 1 - jp - (B3 - 1) on the upper one
+  const double *pN = useN ? fN + (S - 1 - (g.B2 - 1) - kp + M) * g.B3 + kp : face,
+               *pU = useU ? fU + (S - 1 - jp - (g.B3 - 1) + M) * g.B2 + jp : face;
+  const int incN = useN ? g.B3 : 0, incU = useU ? g.B2 : 0;
+  const bool inN = jp != g.B2 - 1, inU = kp != g.B3 - 1;
+  const int addrB = ((lane + g.B2) & 63) << 2;
+  double xprev = 0.0, nN = *pN, nU = *pU;
   auto step = [&](int h, double r, double ce, double cn, double cu, double d) {
-    const double a1 = __shfl_down(xprev, 1, 64), aB = __shfl_down(xprev, g.B2, 64);
-    const double xe = h == hE ? xE : xprev, xn = jp == g.B2 - 1 ? nN : a1, xu = kp == g.B3 - 1 ? nU : aB;
-    nN = faceN(h - 1); nU = faceU(h - 1);
+    const double a1 = lane_dpp<0x130>(xprev), aB = lane_shift(xprev, addrB);
+    const double xe = h == hE ? xE : xprev, xn = inN ? a1 : nN, xu = inU ? aB : nU;
+    pN -= h > 0 ? incN : 0; pU -= h > 0 ? incU : 0;
+    nN = *pN; nU = *pU;
     double s = r;
     s -= ce * xe;
     s -= cn * xn;
@@ -1402,7 +1454,8 @@ __global__ __launch_bounds__(64) void k_box_upper(BoxGrid g, const int *__restri
       dpair out;
       out.y = step(2 * p + 1, rr[u].y, ue[u].y, un[u].y, uu[u].y, di[u].y);
       out.x = step(2 * p, rr[u].x, ue[u].x, un[u].x, uu[u].x, di[u].x);
-      *(p >= 0 ? x2 + (size_t)p * 64 : sink) = out;
+      dpair *dst = p >= 0 ? x2 + (size_t)p * 64 : sink;
+      *at_lane(dst, lane16) = out;
       fetch(u, p - DP);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -2072,12 +2125,12 @@ void launch_gather_or_zero(long long n, const int *idx, const double *in, double
   if (n > 0) LAUNCH(k_gather_or_zero, dim3(nblk(n)), n, idx, in, out);
 }
 void launch_box_lower(const BoxGrid &g, const int *boxes, int nboxes, const double *const L[3], double *y, double *scratch, hipStream_t stream) {
-  const size_t lds = (size_t)g.B1 * (g.B2 + g.B3) * sizeof(double);
+  const size_t lds = (size_t)box_face_doubles(g) * sizeof(double);
   if (nboxes > 0) hipLaunchKernelGGL((k_box_lower<kBoxRing>), dim3(nboxes), dim3(64), lds, stream, g, boxes, L[0], L[1], L[2], y, scratch);
 }
 void launch_box_upper(const BoxGrid &g, const int *boxes, int nboxes, const double *const U[3], const double *Di, double *x, double *scratch,
                       hipStream_t stream) {
-  const size_t lds = (size_t)g.B1 * (g.B2 + g.B3) * sizeof(double);
+  const size_t lds = (size_t)box_face_doubles(g) * sizeof(double);
   if (nboxes > 0) hipLaunchKernelGGL((k_box_upper<kBoxRingUpper>), dim3(nboxes), dim3(64), lds, stream, g, boxes, U[0], U[1], U[2], Di, x, scratch);
 }
 void launch_gather(int n, const int *idx, const double *in, double *out, hipStream_t stream) {

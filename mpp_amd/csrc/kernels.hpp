@@ -228,7 +228,7 @@ void launch_ell_upper_level(int n, int K, const int *col, const double *val, con
 // rounded up to an even number; slots without a cell are zero.
 constexpr int kBoxRing = 12, kBoxRingUpper = 10;   // row pairs of operands a wave keeps in flight: 5 (upper solve: 6) memory
                                                    // instructions each, and the counter holds 63
-constexpr int kBoxMaxLen = 256;   // B1 at most (B1 * (B2 + B3) doubles of faces in LDS)
+constexpr int kBoxMaxLen = 128;   // B1 at most (the faces of a box live in LDS: about (B1 + 2 B2) * B2 doubles)
 struct BoxGrid {
   int n1, n2, n3;             // extents: caller's id = i + n1 * (j + n2 * k)
   int B1, B2, B3, lg2;        // box extents (B2 = 1 << lg2, B2 * B3 = 64)

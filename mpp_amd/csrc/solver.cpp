@@ -3197,6 +3197,22 @@ int mppgpu_get_comm_stats(mppgpu_handle h, long long *allreduces, long long *hal
   API_END()
 }
 
+int mppgpu_get_pc_info(mppgpu_handle h, int *path, int *launches, int *box_extents) {
+  API_BEGIN(h)
+  int p = 0, n = 0, ext[3] = {0, 0, 0};
+  if (S.opt.pc_type == 1 && S.pc_ready) {
+    if (S.box_active()) {
+      p = 3; n = 2 * ((int)S.box_lptr.size() - 1) + 2;
+      ext[0] = S.box.B1; ext[1] = S.box.B2; ext[2] = S.box.B3;
+    } else if (S.ilu_chained()) { p = 2; n = 5; }
+    else { p = 1; n = (int)S.h_lptr.size() - 2 + (int)S.h_uptr.size() - 1 + 3; }
+  }
+  if (path) *path = p;
+  if (launches) *launches = n;
+  if (box_extents) for (int k = 0; k < 3; ++k) box_extents[k] = ext[k];
+  API_END()
+}
+
 int mppgpu_bench_kernel(mppgpu_handle h, const char *name, int variant, int reps, double *avg_ms,
                         double *algorithmic_bytes) {
   API_BEGIN(h)

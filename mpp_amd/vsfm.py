@@ -235,6 +235,14 @@ class SystemOfEquationsVSFM:
         self._chk(self.L.mppgpu_get_comm_stats(self.h, ct.byref(a), ct.byref(b), ct.byref(c)))
         return dict(allreduces=a.value, halo_exchanges=b.value, chain_fallbacks=c.value)
 
+    def pc_info(self):
+        """how the ILU(0) triangular solves are applied (mppgpu_get_pc_info): path name, launches per application, box extents"""
+        path, n = ct.c_int(), ct.c_int()
+        ext = (ct.c_int * 3)()
+        self._chk(self.L.mppgpu_get_pc_info(self.h, ct.byref(path), ct.byref(n), ext))
+        names = {0: "none", 1: "levels", 2: "chained", 3: "boxes"}
+        return dict(path=names.get(path.value, str(path.value)), launches=n.value, box_extents=tuple(ext))
+
     def bench_kernel(self, name, variant=0, reps=20):
         ms, by = ct.c_double(), ct.c_double()
         self._chk(self.L.mppgpu_bench_kernel(self.h, name.encode(), int(variant), int(reps), ct.byref(ms), ct.byref(by)))

@@ -334,6 +334,9 @@ def test_box_ilu_solves_reproduce_the_level_scheduled_ones_bit_for_bit(dims, box
         assert conv
     assert box.soe.last_linear_iterations == lev.soe.last_linear_iterations
     assert np.array_equal(box.soe.GetSoln(), lev.soe.GetSoln())
+    bi, li = box.soe.pc_info(), lev.soe.pc_info()
+    assert bi["path"] == "boxes" and li["path"] == "levels" and bi["launches"] < li["launches"] or min(dims) == 1
+    assert bi["box_extents"][1] * bi["box_extents"][2] == 64
 
 
 def test_box_ilu_applications_on_the_3d_vsfm_jacobian():

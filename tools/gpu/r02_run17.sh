@@ -1,0 +1,10 @@
+#!/bin/bash
+# round 2, GPU run 17: box ILU solves on a diet (DPP shift, pointer-walk face reads, fewer selects): parity, thermal 128^3 .. 512^3
+set -o pipefail
+cd "$GRAFT_REPO_ROOT" || exit 1
+export TMPDIR=/tmp
+O=gpurun_out/r02_run17; mkdir -p $O
+python3 -c "import __graft_entry__ as g; g.build()" > $O/build.log 2>&1 || { tail -20 $O/build.log; exit 1; }
+echo "== pytest thermal, r02, more"; timeout -k 10 900 python3 -m pytest tests/test_gpu_r02.py tests/test_gpu_thermal.py tests/test_gpu_more.py -q -m gpu > $O/pytest.log 2>&1; echo "rc=$?"; tail -8 $O/pytest.log
+for n in 128 256; do echo "== thermal $n"; timeout -k 10 600 python3 tools/thermal_bench.py --n $n --cpu-n 0 --out $O/therm_${n}_box.json > $O/therm_${n}_box.log 2>&1; echo "rc=$?"; python3 -c "import json;j=json.load(open('$O/therm_${n}_box.json'));k=j['kernels']['pc_apply'];print(j['step_s'],j['linear_iterations'],k['total_ms']/k['launches'])"; done
+echo "== thermal 512"; timeout -k 10 900 python3 tools/thermal_bench.py --n 512 --cpu-n 0 --out $O/therm_512_box.json > $O/therm_512_box.log 2>&1; echo "rc=$?"; tail -2 $O/therm_512_box.log | cut -c1-400

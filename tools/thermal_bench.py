@@ -72,10 +72,14 @@ def main():
     if pa["launches"]:
         ms = pa["total_ms"] / pa["launches"]
         by = 12.0 * nnz + 24.0 * N
-        out["roofline"] = {"kernel": "ILU(0) triangular solves (level-ordered ELL, one launch per level)", "bound": "hbm", "unit": "GB/s",
+        info = g.soe.pc_info() if a.pc == "ilu" else {"path": "none", "launches": 0, "box_extents": (0, 0, 0)}
+        what = {"levels": "level-ordered ELL, one launch per dependency level", "chained": "level-ordered ELL, tiles chained by flags",
+                "boxes": "box wavefronts of %d x %d x %d cells, one launch per box level" % info["box_extents"]}.get(info["path"], a.pc)
+        out["roofline"] = {"kernel": "ILU(0) triangular solves (%s)" % what, "bound": "hbm", "unit": "GB/s",
                            "peak": 8000.0, "achieved": round(by / (ms * 1e-3) / 1e9, 1), "frac": round(by / (ms * 1e-3) / 1e9 / 8000.0, 4),
-                           "bytes_per_launch": by, "avg_apply_ms": round(ms, 4), "levels": 2 * (3 * a.n - 2),
-                           "note": "latency-bound by the number of dependency levels"}
+                           "bytes_per_launch": by, "avg_apply_ms": round(ms, 4), "dependency_levels": 2 * (3 * a.n - 2),
+                           "launches_per_application": info["launches"],
+                           "note": "algorithmic bytes 12 nnz + 24 N (SURVEY 8d) over the average application; latency-bound by the dependency levels"}
     if a.rtol_sweep:
         # time to a given accuracy: PETSc's default rtol 1e-5 (on the preconditioned residual) stops far above the discretisation
         # error on fine grids, so every timing is reported next to the error it bought
