@@ -17,7 +17,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "mpp_amd", "csrc")
-DEFAULT = ["k_assemble_cols", "k_tri_", "k_spmv_pipe_c", "k_bcgs_xr", "k_waxpy", "k_dots_pat", "k_bc<", "k_th_cols",
+DEFAULT = ["k_assemble_cols", "k_tri_", "k_spmv_c", "k_spmv_pipe_mb", "k_bcgs_xr", "k_waxpy", "k_dots_pat", "k_bc<", "k_th_cols", "k_box_", "k_finalize",
            "k_spmv_tri"]
 
 
