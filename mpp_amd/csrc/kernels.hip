@@ -1249,6 +1249,37 @@ __global__ __launch_bounds__(kBlock) void k_box_fill(long long nslots, BoxGrid g
   }
   Ld[t] = ld; Ls[t] = ls; Lw[t] = lw; Ue[t] = ue; Un[t] = un; Uu[t] = uu; Di[t] = di;
 }
+// The matrix itself into the box layout, for the numeric factorisation by boxes (k_box_factor): a row's lower entries, diagonal and
+// upper entries, and -- transposed -- the upper entries of its three lower neighbours that point back at it (T: a(c-1, c) etc.).
+// Padding slots: zeros and a unit diagonal (the factorisation divides by it).
+__global__ __launch_bounds__(kBlock) void k_box_load(long long nslots, BoxGrid g, const int *__restrict__ cellmap, const int *__restrict__ int2ext,
+                                                     const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val,
+                                                     double *Ld, double *Ls, double *Lw, double *Ue, double *Un, double *Uu, double *Di,
+                                                     double *Td, double *Ts, double *Tw) {
+  const long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= nslots) return;
+  double ld = 0.0, ls = 0.0, lw = 0.0, ue = 0.0, un = 0.0, uu = 0.0, di = 1.0, td = 0.0, ts = 0.0, tw = 0.0;
+  const int r = cellmap[t];
+  if (r >= 0) {
+    const int e = int2ext[r], s3 = g.n1 * g.n2;
+    auto back = [&](int rn) {   // a(rn, r)
+      for (int q = rowptr[rn]; q < rowptr[rn + 1]; ++q) if (col[q] == r) return val[q];
+      return 0.0;
+    };
+    for (int q = rowptr[r]; q < rowptr[r + 1]; ++q) {
+      const int c = col[q], d = int2ext[c] - e;
+      const double v = val[q];
+      if (d == 0) di = v;
+      else if (d == -1) { lw = v; tw = back(c); }
+      else if (d == 1) ue = v;
+      else if (g.n2 > 1 && d == -g.n1) { ls = v; ts = back(c); }
+      else if (g.n2 > 1 && d == g.n1) un = v;
+      else if (g.n3 > 1 && d == -s3) { ld = v; td = back(c); }
+      else if (g.n3 > 1 && d == s3) uu = v;
+    }
+  }
+  Ld[t] = ld; Ls[t] = ls; Lw[t] = lw; Ue[t] = ue; Un[t] = un; Uu[t] = uu; Di[t] = di; Td[t] = td; Ts[t] = ts; Tw[t] = tw;
+}
 __global__ __launch_bounds__(kBlock) void k_gather_or_zero(long long n, const int *idx, const double *in, double *out) {
   const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
   if (i < n) { const int j = idx[i]; out[i] = j >= 0 ? in[j] : 0.0; }
@@ -1457,6 +1488,94 @@ __global__ __launch_bounds__(64) void k_box_upper(BoxGrid g, const int *__restri
       dpair *dst = p >= 0 ? x2 + (size_t)p * 64 : sink;
       *at_lane(dst, lane16) = out;
       fetch(u, p - DP);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+// Numeric ILU(0) of the same grids, box by box.  On a 7-point pattern (extents other than 2) no upper entry of a pivot row meets
+// an off-diagonal entry of the row being eliminated, so only the diagonal changes: with the pivots in ascending order (down,
+// south, west) m = a(c,k) / u(k,k) replaces a(c,k) and u(c,c) -= m * a(k,c) -- the arithmetic of the elimination program of
+// the general kernel (k_ilu_factor_program), in its order: the same bits.  The recurrence runs on the reciprocal pivots,
+// which travel between cells exactly as the solution does in k_box_lower; in place: L <- multipliers, Di <- 1 / u(c,c).
+template <int DP>
+__global__ __launch_bounds__(64) void k_box_factor(BoxGrid g, const int *__restrict__ boxes, double *Ld, double *Ls, double *Lw,
+                                                   const double *__restrict__ Td, const double *__restrict__ Ts,
+                                                   const double *__restrict__ Tw, double *Di, double *scratch) {
+  extern __shared__ double face[];
+  const int b = boxes[blockIdx.x], lane = threadIdx.x, S = g.S, NP = S >> 1;
+  const int jp = lane & (g.B2 - 1), kp = lane >> g.lg2;
+  const int I = b % g.NB1, J = (b / g.NB1) % g.NB2, K = b / (g.NB1 * g.NB2);
+  const bool useS = g.NB2 > 1, useD = g.NB3 > 1;
+  double *fS = face + 8, *fD = fS + (useS ? (S + g.B3 + 1) * g.B3 : 0);
+  for (int e = lane; e < box_face_doubles(g); e += 64) face[e] = 0.0;
+  __syncthreads();
+  if (J > 0)     // reciprocal pivots on the faces of the boxes behind (as the faces of y in k_box_lower)
+    for (int e = lane; e < g.B1 * g.B3; e += 64) {
+      const int i = e / g.B3, k = e - i * g.B3;
+      fS[(i + g.B3 - 1) * g.B3 + k] = Di[box_slot(g, b - g.NB1, i + g.B2 - 1 + k, g.B2 - 1 + g.B2 * k)];
+    }
+  if (K > 0)
+    for (int e = lane; e < g.B1 * g.B2; e += 64) {
+      const int i = e >> g.lg2, j = e & (g.B2 - 1);
+      fD[(i + g.B2 - 1) * g.B2 + j] = Di[box_slot(g, b - g.NB1 * g.NB2, i + j + g.B3 - 1, j + g.B2 * (g.B3 - 1))];
+    }
+  const int hW = jp + kp;
+  double idW = 0.0;
+  if (I > 0) idW = Di[box_slot(g, b - 1, g.B1 - 1 + hW, lane)];
+  const size_t row0 = (size_t)b * S * 64;
+  dpair *Ld2 = reinterpret_cast<dpair *>(Ld + row0), *Ls2 = reinterpret_cast<dpair *>(Ls + row0), *Lw2 = reinterpret_cast<dpair *>(Lw + row0),
+        *Di2 = reinterpret_cast<dpair *>(Di + row0), *sink = reinterpret_cast<dpair *>(scratch);
+  const dpair *Td2 = reinterpret_cast<const dpair *>(Td + row0), *Ts2 = reinterpret_cast<const dpair *>(Ts + row0),
+              *Tw2 = reinterpret_cast<const dpair *>(Tw + row0);
+  const unsigned lane16 = threadIdx.x * 16u;
+  dpair ld[DP], ls[DP], lw[DP], td[DP], ts[DP], tw[DP], cc[DP];
+  auto fetch = [&](int u, int p) {
+    const size_t o = (size_t)min(p, NP - 1) * 64;
+    ld[u] = *at_lane(Ld2 + o, lane16); ls[u] = *at_lane(Ls2 + o, lane16); lw[u] = *at_lane(Lw2 + o, lane16);
+    td[u] = ldnt(at_lane(Td2 + o, lane16)); ts[u] = ldnt(at_lane(Ts2 + o, lane16)); tw[u] = ldnt(at_lane(Tw2 + o, lane16));
+    cc[u] = *at_lane(Di2 + o, lane16);
+  };
+#pragma unroll
+  for (int u = 0; u < DP; ++u) { fetch(u, u); __builtin_amdgcn_sched_barrier(0); }
+  __syncthreads();
+  const double *pS = useS ? fS + (g.B3 - 1 - kp) * g.B3 + kp : face, *pD = useD ? fD + (g.B2 - 1 - jp) * g.B2 + jp : face;   // (face[0] = 0)
+  const int incS = useS ? g.B3 : 0, incD = useD ? g.B2 : 0;
+  const bool inS = jp != 0, inD = kp != 0;
+  const int addrB = ((lane - g.B2) & 63) << 2;
+  double idprev = 0.0, nS = *pS, nD = *pD;
+  struct Out { double md, ms, mw, id; };
+  auto step = [&](int h, double acc, double cd, double cs, double cw, double xd, double xs, double xw) {
+    const double a1 = lane_dpp<0x138>(idprev), aB = lane_shift(idprev, addrB);
+    const double idd = inD ? aB : nD, ids = inS ? a1 : nS, idw = h == hW ? idW : idprev;
+    pS += h + 1 < S ? incS : 0; pD += h + 1 < S ? incD : 0;
+    nS = *pS; nD = *pD;
+    Out o;
+    double d = acc;
+    o.md = cd * idd;
+    d -= o.md * xd;
+    o.ms = cs * ids;
+    d -= o.ms * xs;
+    o.mw = cw * idw;
+    d -= o.mw * xw;
+    o.id = 1.0 / d;
+    idprev = o.id;
+    return o;
+  };
+  for (int p0 = 0; p0 < NP; p0 += DP) {
+#pragma unroll
+    for (int u = 0; u < DP; ++u) {
+      const int p = p0 + u;
+      const Out x = step(2 * p, cc[u].x, ld[u].x, ls[u].x, lw[u].x, td[u].x, ts[u].x, tw[u].x);
+      const Out y = step(2 * p + 1, cc[u].y, ld[u].y, ls[u].y, lw[u].y, td[u].y, ts[u].y, tw[u].y);
+      const bool real = p < NP;
+      const size_t o = (size_t)p * 64;
+      dpair v;
+      v.x = x.md; v.y = y.md; *at_lane(real ? Ld2 + o : sink, lane16) = v;
+      v.x = x.ms; v.y = y.ms; *at_lane(real ? Ls2 + o : sink, lane16) = v;
+      v.x = x.mw; v.y = y.mw; *at_lane(real ? Lw2 + o : sink, lane16) = v;
+      v.x = x.id; v.y = y.id; *at_lane(real ? Di2 + o : sink, lane16) = v;
+      fetch(u, p + DP);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -2120,6 +2239,17 @@ void launch_set(int n, double v, double *y, hipStream_t stream) {
 void launch_box_fill(long long nslots, const BoxGrid &g, const int *cellmap, const int *int2ext, const int *rowptr, const int *col,
                      const double *lu, const double *idiag, double *const L[3], double *const U[3], double *Di, hipStream_t stream) {
   if (nslots > 0) LAUNCH(k_box_fill, dim3(nblk(nslots)), nslots, g, cellmap, int2ext, rowptr, col, lu, idiag, L[0], L[1], L[2], U[0], U[1], U[2], Di);
+}
+void launch_box_load(long long nslots, const BoxGrid &g, const int *cellmap, const int *int2ext, const int *rowptr, const int *col,
+                     const double *val, double *const L[3], double *const U[3], double *Di, double *const T[3], hipStream_t stream) {
+  if (nslots > 0) LAUNCH(k_box_load, dim3(nblk(nslots)), nslots, g, cellmap, int2ext, rowptr, col, val, L[0], L[1], L[2], U[0], U[1], U[2], Di,
+                         T[0], T[1], T[2]);
+}
+void launch_box_factor(const BoxGrid &g, const int *boxes, int nboxes, double *const L[3], const double *const T[3], double *Di, double *scratch,
+                       hipStream_t stream) {
+  const size_t lds = (size_t)box_face_doubles(g) * sizeof(double);
+  if (nboxes > 0) hipLaunchKernelGGL((k_box_factor<kBoxRingFactor>), dim3(nboxes), dim3(64), lds, stream, g, boxes, L[0], L[1], L[2], T[0], T[1], T[2],
+                                     Di, scratch);
 }
 void launch_gather_or_zero(long long n, const int *idx, const double *in, double *out, hipStream_t stream) {
   if (n > 0) LAUNCH(k_gather_or_zero, dim3(nblk(n)), n, idx, in, out);

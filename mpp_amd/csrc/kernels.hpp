@@ -241,6 +241,16 @@ __host__ __device__ inline size_t box_slot(const BoxGrid &g, long long box, int 
 // L = {down, south, west}, U = {east, north, up} entries (ascending column order within a row), Di = 1 / u_ii
 void launch_box_fill(long long nslots, const BoxGrid &g, const int *cellmap, const int *int2ext, const int *rowptr, const int *col,
                      const double *lu, const double *idiag, double *const L[3], double *const U[3], double *Di, hipStream_t stream);
+// The numeric factorisation by boxes, when every extent of the grid differs from 2 (box_factor_applies): launch_box_load puts the
+// matrix into the box layout (L, U, Di = the diagonal, T = the upper entries of the lower neighbours that point back at a cell),
+// launch_box_factor then turns L into the multipliers and Di into the reciprocal pivots, one launch per box level in ascending
+// order -- the arithmetic and order of the elimination program of the general kernel.
+constexpr int kBoxRingFactor = 5;   // row pairs in flight there (11 memory instructions each)
+inline bool box_factor_applies(const BoxGrid &g) { return g.n1 != 2 && g.n2 != 2 && g.n3 != 2; }
+void launch_box_load(long long nslots, const BoxGrid &g, const int *cellmap, const int *int2ext, const int *rowptr, const int *col,
+                     const double *val, double *const L[3], double *const U[3], double *Di, double *const T[3], hipStream_t stream);
+void launch_box_factor(const BoxGrid &g, const int *boxes, int nboxes, double *const L[3], const double *const T[3], double *Di, double *scratch,
+                       hipStream_t stream);
 void launch_gather_or_zero(long long n, const int *idx, const double *in, double *out, hipStream_t stream);   // out[i] = idx[i] >= 0 ? in[idx[i]] : 0
 // the boxes of one box level (ids in boxes[0 .. nboxes)), in place on the vector in box layout
 // scratch: 128 doubles anybody may overwrite

@@ -227,9 +227,9 @@ struct Solver {
   long long box_slots = 0;
   DevBuf<int> box_cellmap, box_cellpos, box_order;
   std::vector<int> box_lptr;                 // boxes of box level l: box_order[box_lptr[l] .. box_lptr[l+1])
-  DevBuf<double> box_L[3], box_U[3], box_Di, box_v, box_scratch;
-  hipGraph_t box_graph = nullptr;
-  hipGraphExec_t box_graph_exec = nullptr;
+  DevBuf<double> box_L[3], box_U[3], box_Di, box_v, box_scratch, box_T[3];
+  hipGraph_t box_graph = nullptr, box_fgraph = nullptr;
+  hipGraphExec_t box_graph_exec = nullptr, box_fgraph_exec = nullptr;
 
   double dtime = 0.0, time = 0.0;
   long long cum_newton = 0, cum_linear = 0, cum_cuts = 0, cum_funcs = 0;
@@ -246,6 +246,8 @@ struct Solver {
     if (ilu_graph) (void)hipGraphDestroy(ilu_graph);
     if (box_graph_exec) (void)hipGraphExecDestroy(box_graph_exec);
     if (box_graph) (void)hipGraphDestroy(box_graph);
+    if (box_fgraph_exec) (void)hipGraphExecDestroy(box_fgraph_exec);
+    if (box_fgraph) (void)hipGraphDestroy(box_fgraph);
     if (h_sc) (void)hipHostFree(h_sc);
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -1303,13 +1305,25 @@ struct Solver {
     } else if (opt.pc_type == 2) launch_tri_factor(tri_args(), stream);
     else if (opt.pc_type == 3) launch_jacobi_setup(nrow, d_diag.p, d_val.p, jac_invd.p, stream);
     else if (opt.pc_type == 1) {
+      ilu_box_analyse();
+      if (opt.ilu_box == 2 && !box_ok) throw Error("ilu_box = 2: the matrix is not a structured grid in the caller's natural ordering");
+      double *const L[3] = {box_L[0].p, box_L[1].p, box_L[2].p}, *const U[3] = {box_U[0].p, box_U[1].p, box_U[2].p};
+      if (box_factored()) {   // structured grid: the factorisation itself runs box by box, no level analysis of the rows at all
+        if (!box_T[0].p) for (auto &t : box_T) t.alloc((size_t)box_slots);
+        double *const T[3] = {box_T[0].p, box_T[1].p, box_T[2].p};
+        launch_box_load(box_slots, box, box_cellmap.p, d_int2ext.p, d_rowptr.p, d_col.p, d_val.p, L, U, box_Di.p, T, stream);
+        run_graph(box_fgraph, box_fgraph_exec, [&] {
+          for (size_t l = 0; l + 1 < box_lptr.size(); ++l)
+            launch_box_factor(box, box_order.p + box_lptr[l], box_lptr[l + 1] - box_lptr[l], L, T, box_Di.p, box_scratch.p, stream);
+        });
+        pc_ready = true;
+        return;
+      }
       ilu_analyse();
       launch_copy(nnz, d_val.p, d_lu.p, stream);
       for (size_t l = 0; l + 1 < h_lptr.size(); ++l)
         launch_ilu_factor_program(d_fptr.p, d_fprog.p, d_lrows.p, d_diag.p, h_lptr[l], h_lptr[l + 1], d_lu.p, d_idiag.p, stream);
-      if (opt.ilu_box == 2 && !box_ok) throw Error("ilu_box = 2: the matrix is not a structured grid in the caller's natural ordering");
       if (box_active()) {   // into the box layout of the structured-grid solves
-        double *const L[3] = {box_L[0].p, box_L[1].p, box_L[2].p}, *const U[3] = {box_U[0].p, box_U[1].p, box_U[2].p};
         launch_box_fill(box_slots, box, box_cellmap.p, d_int2ext.p, d_rowptr.p, d_col.p, d_lu.p, d_idiag.p, L, U, box_Di.p, stream);
       } else {              // into the level-ordered ELL blocks the general solves stream through
         ilu_build_ell();
@@ -1336,6 +1350,19 @@ struct Solver {
     for (int l = nl - 1; l >= 0; --l) launch_box_upper(box, box_order.p + box_lptr[l], box_lptr[l + 1] - box_lptr[l], U, box_Di.p, box_v.p, box_scratch.p, stream);
   }
   bool box_active() const { return box_ok && opt.ilu_box != 0; }
+  bool box_factored() const { return box_active() && opt.ilu_box_factor && box_factor_applies(box); }
+  // a fixed sequence of launches, captured into a hipGraph the first time and replayed afterwards (one by one under rocprofv3)
+  template <class F>
+  void run_graph(hipGraph_t &graph, hipGraphExec_t &exec, F &&launches) {
+    if (!opt.ilu_graph || under_rocprofiler()) { launches(); return; }
+    if (!exec) {
+      HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+      launches();
+      HIP_CHECK(hipStreamEndCapture(stream, &graph));
+      HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    }
+    HIP_CHECK(hipGraphLaunch(exec, stream));
+  }
   void op_pc_apply(const double *r, double *z) {
     ProfScope ps(prof, KC_PC_APPLY);
     if (nghost > 0) launch_set(nghost, 0.0, const_cast<double *>(r) + nred, stream);   // block-Jacobi across ranks
@@ -1344,15 +1371,7 @@ struct Solver {
     else if (opt.pc_type == 3) launch_pointwise_mult(nred, jac_invd.p, r, z, stream);
     else if (opt.pc_type == 1 && box_active()) {
       launch_gather_or_zero(box_slots, box_cellmap.p, r, box_v.p, stream);   // r into the box layout, padding zero
-      if (opt.ilu_graph && !under_rocprofiler()) {
-        if (!box_graph_exec) {
-          HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-          box_solve_levels();
-          HIP_CHECK(hipStreamEndCapture(stream, &box_graph));
-          HIP_CHECK(hipGraphInstantiate(&box_graph_exec, box_graph, nullptr, nullptr, 0));
-        }
-        HIP_CHECK(hipGraphLaunch(box_graph_exec, stream));
-      } else box_solve_levels();
+      run_graph(box_graph, box_graph_exec, [&] { box_solve_levels(); });
       launch_gather(nrow, box_cellpos.p, box_v.p, z, stream);                // back to the internal row order
     } else if (opt.pc_type == 1) {
       launch_gather(nrow, d_lrows.p, r, ilu_y.p, stream);            // r into the L level order
@@ -1365,16 +1384,7 @@ struct Solver {
         solved = !chain_timed_out();
         if (!solved) launch_gather(nrow, d_lrows.p, r, ilu_y.p, stream);
       }
-      if (solved) {}
-      else if (opt.ilu_graph && !under_rocprofiler()) {
-        if (!ilu_graph_exec) {
-          HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-          ilu_solve_levels();
-          HIP_CHECK(hipStreamEndCapture(stream, &ilu_graph));
-          HIP_CHECK(hipGraphInstantiate(&ilu_graph_exec, ilu_graph, nullptr, nullptr, 0));
-        }
-        HIP_CHECK(hipGraphLaunch(ilu_graph_exec, stream));
-      } else ilu_solve_levels();
+      if (!solved) run_graph(ilu_graph, ilu_graph_exec, [&] { ilu_solve_levels(); });
       launch_gather(nrow, d_posU.p, ilu_x.p, z, stream);             // back to the internal row order
     } else launch_copy(nred, r, z, stream);
   }
@@ -2514,7 +2524,6 @@ struct Solver {
     d_ord.upload(ord, stream);
     d_lu.alloc(nnz); d_idiag.alloc(N);
     ilu_factor_program(lrows, ord);
-    ilu_box_analyse();
     HIP_CHECK(hipStreamSynchronize(stream));
   }
   // level-ordered ELL maps of the general triangular solves: position of every row in the L ordering (lrows) and in the U
@@ -2742,6 +2751,7 @@ struct Solver {
     else if (key == "fused_assembly") opt.fused_assembly = num() != 0;
     else if (key == "ilu_graph") opt.ilu_graph = num() != 0;
     else if (key == "ilu_box") { opt.ilu_box = (int)num(); pc_ready = false; }   // the factors are repacked for the other solve path
+    else if (key == "ilu_box_factor") { opt.ilu_box_factor = num() != 0; pc_ready = false; }
     else if (key == "ilu_box_len") {
       const int v = (int)num();
       if (v < 0 || v > kBoxMaxLen) throw Error("ilu_box_len must be between 0 and " + std::to_string(kBoxMaxLen));

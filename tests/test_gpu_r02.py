@@ -328,15 +328,35 @@ def test_box_ilu_solves_reproduce_the_level_scheduled_ones_bit_for_bit(dims, box
     ptype = 3 if dims[2] > 1 else 2 if dims[1] > 1 else 1
     tp = P.thermal_mms(ptype, *dims, replicate_reference_soil_indexing=False)
     box = P.to_thermal_gpu(tp, {"ksp_type": "gmres", "pc_type": "ilu", "ilu_box": 2, "ilu_box_len": box_len})
+    prg = P.to_thermal_gpu(tp, {"ksp_type": "gmres", "pc_type": "ilu", "ilu_box": 2, "ilu_box_len": box_len, "ilu_box_factor": 0})
     lev = P.to_thermal_gpu(tp, {"ksp_type": "gmres", "pc_type": "ilu", "ilu_box": 0, "ilu_chain": 0})
-    for g in (box, lev):
+    for g in (box, prg, lev):   # factorised and solved by boxes; factorised by the elimination program, solved by boxes; neither
         conv, _ = g.soe.StepDT(tp.dt, 1)
         assert conv
-    assert box.soe.last_linear_iterations == lev.soe.last_linear_iterations
+    assert box.soe.last_linear_iterations == lev.soe.last_linear_iterations == prg.soe.last_linear_iterations
     assert np.array_equal(box.soe.GetSoln(), lev.soe.GetSoln())
+    assert np.array_equal(prg.soe.GetSoln(), lev.soe.GetSoln())
     bi, li = box.soe.pc_info(), lev.soe.pc_info()
     assert bi["path"] == "boxes" and li["path"] == "levels" and bi["launches"] < li["launches"] or min(dims) == 1
     assert bi["box_extents"][1] * bi["box_extents"][2] == 64
+
+
+@pytest.mark.parametrize("dims", [(2, 9, 5), (9, 2, 5), (11, 7, 2), (13, 2, 1), (3, 3, 3)])
+def test_box_ilu_on_grids_with_an_extent_of_two(dims):
+    """with an extent of 2 an upper entry of a pivot row can meet an off-diagonal entry of the row being eliminated, so the
+    factorisation by boxes (diagonal updates only) does not apply: those grids are factorised by the general elimination program
+    and only solved box by box -- same bits either way; 3 x 3 x 3 is the smallest grid factorised by boxes"""
+    ptype = 3 if dims[2] > 1 else 2
+    tp = P.thermal_mms(ptype, *dims, replicate_reference_soil_indexing=False)
+    box = P.to_thermal_gpu(tp, {"ksp_type": "gmres", "pc_type": "ilu", "ilu_box": 2})
+    prg = P.to_thermal_gpu(tp, {"ksp_type": "gmres", "pc_type": "ilu", "ilu_box": 2, "ilu_box_factor": 0})
+    lev = P.to_thermal_gpu(tp, {"ksp_type": "gmres", "pc_type": "ilu", "ilu_box": 0, "ilu_chain": 0})
+    for g in (box, prg, lev):
+        conv, _ = g.soe.StepDT(tp.dt, 1)
+        assert conv
+    assert box.soe.last_linear_iterations == lev.soe.last_linear_iterations == prg.soe.last_linear_iterations
+    assert np.array_equal(box.soe.GetSoln(), lev.soe.GetSoln())
+    assert np.array_equal(prg.soe.GetSoln(), lev.soe.GetSoln())
 
 
 def test_box_ilu_applications_on_the_3d_vsfm_jacobian():
