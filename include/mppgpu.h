@@ -177,7 +177,12 @@ int mppgpu_set_source_sink_auxvar(mppgpu_handle h, int var_type, int n, const do
  * (0|1), "fused_trials" (line-search trial points whose Jacobian is assembled together with the residual),
  * "fused_predict", "fused_rows" (0|1: column march that folds the boundary fluxes in and also leaves ||F||, ||X|| and
  * the column LU), "fused_ls_dots" (0|1: line-search reductions inside the SpMV), "ilu_graph", "ilu_chain" (0 one launch
- * per level | 1 chained tiles where they pay | 2 always chained), "ell_assembly", "defer_test0", "ls_ahead", "wide_xr", "track_mass_exchange". */
+ * per level | 1 chained tiles where they pay | 2 always chained), "ilu_box" (ILU(0) of a structured grid in natural ordering
+ * factorised and solved box by box: 0 never | 1 when the pattern is such a grid | 2 or fail), "ilu_box_len" (box extent along the
+ * fastest direction), "ilu_box_factor" (0: factorise by the general elimination program, solve by boxes), "ell_assembly",
+ * "defer_test0", "ls_ahead", "wide_xr", "track_mass_exchange".
+ * Environment: MPPGPU_HOST_THREADS (threads of the set-up passes on the host; default: the cores the process may run on, at
+ * most 32), MPPGPU_TIMING (set: wall-clock of the set-up phases on stderr). */
 int mppgpu_set_option(mppgpu_handle h, const char *key, const char *value);
 
 /* mpp%AllocateAuxVars + mpp%SetupProblem (src/mpp/mpp/MultiPhysicsProbVSFM.F90:710-1015): builds the CSR

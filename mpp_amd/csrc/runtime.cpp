@@ -1,7 +1,14 @@
-// runtime.cpp -- HIP-event profiler and run-time RCCL binding.
+// runtime.cpp -- HIP-event profiler, run-time RCCL binding, host-side helpers of the set-up passes.
 #include "runtime.hpp"
 
+#include <sched.h>
+
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <exception>
+#include <thread>
 
 #include <dlfcn.h>
 
@@ -214,6 +221,41 @@ Comm::~Comm() {
   if (comm && lib) {
     if (void *p = dlsym(lib, "ncclCommDestroy")) (void)reinterpret_cast<fn_destroy>(p)(comm);
   }
+}
+
+
+// ---- host-side helpers of the set-up passes ----
+int host_threads() {
+  static const int n = [] {
+    if (const char *e = std::getenv("MPPGPU_HOST_THREADS")) { const int v = std::atoi(e); if (v > 0) return std::min(v, 256); }
+    int cores = (int)std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) cores = CPU_COUNT(&set);
+    return std::max(1, std::min(cores, 32));
+  }();
+  return n;
+}
+void host_parallel_ranges(long long n, const std::function<void(long long, long long)> &fn) {
+  if (n <= 0) return;
+  const int nt = (int)std::min<long long>(host_threads(), (n + 4095) / 4096);   // not worth a thread below a few thousand items
+  if (nt <= 1) { fn(0, n); return; }
+  std::vector<std::thread> pool;
+  std::exception_ptr err;
+  std::mutex m;
+  for (int t = 0; t < nt; ++t)
+    pool.emplace_back([&, t] {
+      try { fn(n * t / nt, n * (t + 1) / nt); }
+      catch (...) { std::lock_guard<std::mutex> g(m); if (!err) err = std::current_exception(); }
+    });
+  for (auto &th : pool) th.join();
+  if (err) std::rethrow_exception(err);
+}
+static double wall_seconds() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+PhaseTimer::PhaseTimer(const char *n) : name(n), t0(std::getenv("MPPGPU_TIMING") ? wall_seconds() : -1.0) {}
+PhaseTimer::~PhaseTimer() {
+  if (t0 >= 0.0) std::fprintf(stderr, "[mppgpu] %-28s %8.3f s (%d host threads)\n", name, wall_seconds() - t0, host_threads());
 }
 
 }  // namespace mpp

@@ -6,6 +6,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <functional>
 #include <stdexcept>
 #include <condition_variable>
 #include <memory>
@@ -28,6 +29,23 @@ struct Error : std::runtime_error {
       throw ::mpp::Error(std::string(#expr) + " failed: " + hipGetErrorString(_e) + " (" + __FILE__ + ":" + \
                          std::to_string(__LINE__) + ")");                                                 \
   } while (0)
+
+// ---- host-side helpers of the set-up passes (one-off O(N) / O(nnz) index work on the caller's mesh) ----
+// threads the set-up may use: the cores this process may run on, at most 32; MPPGPU_HOST_THREADS overrides
+int host_threads();
+// fn(begin, end) over [0, n) in contiguous chunks, one per thread; the first exception thrown is rethrown to the caller
+void host_parallel_ranges(long long n, const std::function<void(long long, long long)> &fn);
+template <class F>
+inline void host_parallel_for(long long n, F &&body) {   // body(i) for every i in [0, n); iterations must be independent
+  host_parallel_ranges(n, [&](long long b, long long e) { for (long long i = b; i < e; ++i) body(i); });
+}
+// wall-clock of a set-up phase on stderr when MPPGPU_TIMING is set
+struct PhaseTimer {
+  const char *name;
+  double t0;
+  explicit PhaseTimer(const char *n);
+  ~PhaseTimer();
+};
 
 template <typename T>
 struct DevBuf {

@@ -9,6 +9,7 @@
 // All arithmetic on vectors and matrices happens in HIP kernels (kernels.hip); the host only sequences launches
 // and reads back a handful of scalars per iteration.  There is no CPU compute path.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -498,6 +499,7 @@ struct Solver {
   }
 
   void build_pattern() {
+    PhaseTimer pt("setup: CSR pattern");
     // CSR pattern = diagonal + both directions of every internal connection: exactly the entries the reference
     // creates with MatSetValuesLocal (GoveqnRichardsODEPressureType.F90:1689, 2051-2069), rows in internal order
     std::vector<int> cnt((size_t)n + 1, 0);
@@ -510,19 +512,20 @@ struct Solver {
       const int u = ext2int[cup_e[c]], d = ext2int[cdn_e[c]];
       col[fill[u]++] = d; col[fill[d]++] = u;
     }
+    host_parallel_for(n, [&](long long i) { std::sort(col.begin() + cnt[i], col.begin() + cnt[i + 1]); });
     h_rowptr.assign((size_t)n + 1, 0);
     h_col.clear(); h_col.reserve(col.size());
     for (int i = 0; i < n; ++i) {
       h_rowptr[i] = (int)h_col.size();
-      std::sort(col.begin() + cnt[i], col.begin() + cnt[i + 1]);
       for (int k = cnt[i]; k < cnt[i + 1]; ++k)
         if (k == cnt[i] || col[k] != col[k - 1]) h_col.push_back(col[k]);
     }
     nnz = (int)h_col.size();
     h_rowptr[n] = nnz;
     h_diag.resize(n);
+    host_parallel_for(n, [&](long long i) { h_diag[i] = find_slot((int)i, (int)i); });
     max_row_nnz = 0;
-    for (int i = 0; i < n; ++i) { h_diag[i] = find_slot(i, i); max_row_nnz = std::max(max_row_nnz, h_rowptr[i + 1] - h_rowptr[i]); }
+    for (int i = 0; i < n; ++i) max_row_nnz = std::max(max_row_nnz, h_rowptr[i + 1] - h_rowptr[i]);
   }
 
   void setup() {
@@ -532,7 +535,7 @@ struct Solver {
     nrow = th ? 2 * n : n;
     nred = nrow - nghost;
     if (nghost > 0 && !halo.set) throw Error("ghost cells need a halo plan (mppgpu_set_halo)");
-    detect_columns();
+    { PhaseTimer pt("setup: column detection"); detect_columns(); }
     build_pattern();
     d_ext2int.upload(ext2int, stream);
     d_int2ext.upload(int2ext, stream);
@@ -561,37 +564,35 @@ struct Solver {
       std::vector<int> ptr((size_t)n + 1, 0);
       for (int c = 0; c < nc; ++c) { ptr[ext2int[cup_e[c]] + 1]++; ptr[ext2int[cdn_e[c]] + 1]++; }
       for (int i = 0; i < n; ++i) ptr[i + 1] += ptr[i];
-      std::vector<int> fill(ptr.begin(), ptr.end() - 1), rconn(ptr[n]), rslot(ptr[n]);
-      for (int c = 0; c < nc; ++c) {
+      PhaseTimer pt("setup: incidence lists");
+      std::vector<int> fill(ptr.begin(), ptr.end() - 1), rconn(ptr[n]), rslot(ptr[n]), roth(ptr[n]);
+      for (int c = 0; c < nc; ++c) {   // (serial: a row's list keeps the caller's connection order)
         const int u = ext2int[cup_e[c]], d = ext2int[cdn_e[c]], ic = cext2int[c];
-        rconn[fill[u]] = (ic << 1) | 0; rslot[fill[u]++] = find_slot(u, d);
-        rconn[fill[d]] = (ic << 1) | 1; rslot[fill[d]++] = find_slot(d, u);
+        rconn[fill[u]] = (ic << 1) | 0; roth[fill[u]++] = d;
+        rconn[fill[d]] = (ic << 1) | 1; roth[fill[d]++] = u;
       }
+      host_parallel_for(n, [&](long long i) { for (int e = ptr[i]; e < ptr[i + 1]; ++e) rslot[e] = find_slot((int)i, roth[e]); });
       d_rc_ptr.upload(ptr, stream); d_rc_conn.upload(rconn, stream); d_rc_slot.upload(rslot, stream);
       aux_kr.alloc(n); aux_dkr.alloc(n); aux_den.alloc(n); aux_dden.alloc(n);
       // ELL copy for k_flux_rows_ell (rows of <= 8 incident connections, one connection per matrix entry)
       ell_k = 0;
       if (!thermal && !th) {
         int kmax = 0;
-        bool one_to_one = true;
-        for (int i = 0; i < n; ++i) {
-          kmax = std::max(kmax, ptr[i + 1] - ptr[i]);
-          for (int e = ptr[i]; e < ptr[i + 1] && one_to_one; ++e)
+        for (int i = 0; i < n; ++i) kmax = std::max(kmax, ptr[i + 1] - ptr[i]);
+        std::atomic<bool> one_to_one{true};
+        host_parallel_for(n, [&](long long i) {
+          for (int e = ptr[i]; e < ptr[i + 1]; ++e)
             for (int e2 = ptr[i]; e2 < e; ++e2)
-              if (rslot[e2] == rslot[e]) { one_to_one = false; break; }
-        }
+              if (rslot[e2] == rslot[e]) one_to_one = false;
+        });
         if (kmax > 0 && kmax <= 8 && one_to_one) {
           std::vector<int> enc((size_t)kmax * n, -1), oth((size_t)kmax * n, 0), slt((size_t)kmax * n, -1);
-          for (int i = 0; i < n; ++i)
+          host_parallel_for(n, [&](long long i) {
             for (int e = ptr[i], k = 0; e < ptr[i + 1]; ++e, ++k) {
               const size_t q = (size_t)k * n + i;
-              enc[q] = rconn[e]; slt[q] = rslot[e];
+              enc[q] = rconn[e]; slt[q] = rslot[e]; oth[q] = roth[e];   // the other end of the incidence (internal numbering)
             }
-          // the other end of every incidence: from the connection end cells (internal numbering)
-          std::vector<int> upc(nc_int, 0), dnc(nc_int, 0);
-          for (int c = 0; c < nc; ++c) { upc[cext2int[c]] = ext2int[cup_e[c]]; dnc[cext2int[c]] = ext2int[cdn_e[c]]; }
-          for (size_t q = 0; q < enc.size(); ++q)
-            if (enc[q] >= 0) oth[q] = (enc[q] & 1) ? upc[enc[q] >> 1] : dnc[enc[q] >> 1];
+          });
           d_ell_enc.upload(enc, stream); d_ell_o.upload(oth, stream); d_ell_slot.upload(slt, stream);
           ell_k = kmax;
         }
@@ -601,12 +602,14 @@ struct Solver {
     {
       std::vector<int> lo(n, -1), up(n, -1);
       if (columns) {
-        for (int col = 0; col < ncols; ++col)
+        PhaseTimer pt("setup: column block slots");
+        host_parallel_for(ncols, [&](long long col) {
           for (int k = 0; k < nz; ++k) {
-            const int i = cell_index(k, col);
-            if (k > 0) lo[i] = find_slot(i, cell_index(k - 1, col));
-            if (k < nz - 1) up[i] = find_slot(i, cell_index(k + 1, col));
+            const int i = cell_index(k, (int)col);
+            if (k > 0) lo[i] = find_slot(i, cell_index(k - 1, (int)col));
+            if (k < nz - 1) up[i] = find_slot(i, cell_index(k + 1, (int)col));
           }
+        });
       }
       d_tri_lo.upload(lo, stream); d_tri_up.upload(up, stream);
       tri_l.alloc(n); tri_invb.alloc(n); tri_c.alloc(n); jac_invd.alloc(nrow);
@@ -714,8 +717,7 @@ struct Solver {
         }
       }
     }
-    build_compact_index();
-    build_multibase_index();
+    { PhaseTimer pt("setup: SpMV indices"); build_compact_index(); build_multibase_index(); }
     plan_complete_rows();
     if (nghost > 0) {
       halo.d_send_idx.upload(halo.send_cells, stream);
@@ -804,6 +806,7 @@ struct Solver {
 
   // soil parameters + connection geometry -> device (lazy: the reference sets soils after SetupProblem)
   void ensure_ready() {
+    PhaseTimer pt("ensure_ready");
     need_setup(true);
     if (!soil_dirty) return;
     if ((int)permx.size() != n || (int)por.size() != n || (int)alpha.size() != n)
@@ -1219,27 +1222,30 @@ struct Solver {
     std::vector<int> tp((size_t)ntiles + 2, 0);
     std::vector<unsigned short> ro(nrow);
     std::vector<short> dc(nnz);
-    for (int t = 0; t < ntiles; ++t) {
-      const int r0 = t * 64, r1 = std::min(nrow, r0 + 64);
+    std::atomic<bool> fits{true};
+    host_parallel_for(ntiles, [&](long long t) {
+      if (!fits) return;
+      const int r0 = (int)t * 64, r1 = std::min(nrow, r0 + 64);
       const int base_lo = (split && r0 >= split) ? r0 - split : r0;
-      if (split && r0 < split && r1 > split) return;   // a tile across the block boundary (N not a multiple of 64)
+      if (split && r0 < split && r1 > split) { fits = false; return; }   // a tile across the block boundary (N not a multiple of 64)
       tp[t] = h_rowptr[r0];
       for (int r = r0; r < r1; ++r) {
         ro[r] = (unsigned short)(h_rowptr[r] - h_rowptr[r0]);
         for (int k = h_rowptr[r]; k < h_rowptr[r + 1]; ++k) {
           if (!split) {
             const int d = h_col[k] - r0;
-            if (d < -32768 || d > 32767) return;
+            if (d < -32768 || d > 32767) { fits = false; return; }
             dc[k] = (short)d;
           } else {
             const int blk = h_col[k] >= split ? 1 : 0;
             const int d = h_col[k] - (base_lo + blk * split);
-            if (d < -16384 || d > 16383) return;
+            if (d < -16384 || d > 16383) { fits = false; return; }
             dc[k] = (short)(d * 2 + blk);     // arithmetic shift in the kernel recovers d, bit 0 the block
           }
         }
       }
-    }
+    });
+    if (!fits) return;
     tp[ntiles] = nnz; tp[ntiles + 1] = nnz;
     d_tileptr.upload(tp, stream); d_roff.upload(ro.data(), ro.size(), stream); d_dcol.upload(dc.data(), dc.size(), stream);
     compact_index = true;
@@ -1252,30 +1258,36 @@ struct Solver {
     const bool asked = opt.spmv_variant == 22 || opt.spmv_variant == 23;   // (also on request, next to the single-base index)
     if ((compact_index && !asked) || th || max_row_nnz > 8 || nghost > 0) return;
     const int ntiles = (nrow + 63) / 64;
-    std::vector<int> tp((size_t)ntiles + 2, 0), tb((size_t)ntiles * 8, 0), cols;
+    std::vector<int> tp((size_t)ntiles + 2, 0), tb((size_t)ntiles * 8, 0);
     std::vector<unsigned short> ro(nrow), mc(nnz);
-    for (int t = 0; t < ntiles; ++t) {
-      const int r0 = t * 64, r1 = std::min(nrow, r0 + 64);
-      tp[t] = h_rowptr[r0];
-      cols.assign(h_col.begin() + h_rowptr[r0], h_col.begin() + h_rowptr[r1]);
-      std::sort(cols.begin(), cols.end());
-      int nb = 0;
-      int *b = &tb[(size_t)t * 8];
-      for (int c : cols)
-        if (nb == 0 || c >= b[nb - 1] + 8192) {
-          if (nb == 8) return;
-          b[nb++] = c;
-        }
-      for (int k = nb; k < 8; ++k) b[k] = nb ? b[nb - 1] : 0;
-      for (int r = r0; r < r1; ++r) {
-        ro[r] = (unsigned short)(h_rowptr[r] - h_rowptr[r0]);
-        for (int k = h_rowptr[r]; k < h_rowptr[r + 1]; ++k) {
-          int wdw = nb - 1;
-          while (wdw > 0 && h_col[k] < b[wdw]) --wdw;
-          mc[k] = (unsigned short)((wdw << 13) | (h_col[k] - b[wdw]));
+    std::atomic<bool> fits{true};
+    host_parallel_ranges(ntiles, [&](long long t0, long long t1) {
+      std::vector<int> cols;
+      for (long long t = t0; t < t1 && fits; ++t) {
+        const int r0 = (int)t * 64, r1 = std::min(nrow, r0 + 64);
+        tp[t] = h_rowptr[r0];
+        cols.assign(h_col.begin() + h_rowptr[r0], h_col.begin() + h_rowptr[r1]);
+        std::sort(cols.begin(), cols.end());
+        int nb = 0;
+        int *b = &tb[(size_t)t * 8];
+        for (int c : cols)
+          if (nb == 0 || c >= b[nb - 1] + 8192) {
+            if (nb == 8) { fits = false; break; }
+            b[nb++] = c;
+          }
+        if (!fits) break;
+        for (int k = nb; k < 8; ++k) b[k] = nb ? b[nb - 1] : 0;
+        for (int r = r0; r < r1; ++r) {
+          ro[r] = (unsigned short)(h_rowptr[r] - h_rowptr[r0]);
+          for (int k = h_rowptr[r]; k < h_rowptr[r + 1]; ++k) {
+            int wdw = nb - 1;
+            while (wdw > 0 && h_col[k] < b[wdw]) --wdw;
+            mc[k] = (unsigned short)((wdw << 13) | (h_col[k] - b[wdw]));
+          }
         }
       }
-    }
+    });
+    if (!fits) return;
     tp[ntiles] = nnz; tp[ntiles + 1] = nnz;
     d_tileptr.upload(tp, stream); d_roff.upload(ro.data(), ro.size(), stream); d_mcol.upload(mc.data(), mc.size(), stream);
     d_tbase.upload(tb, stream);
@@ -2487,6 +2499,7 @@ struct Solver {
 
   void ilu_analyse() {
     if (d_ord.p) return;
+    PhaseTimer pt("ILU(0): level analysis");
     const int N = nrow;
     std::vector<int> lvl(N, 0), ulvl(N, 0);
     int nl = 0, nul = 0;
@@ -2615,6 +2628,7 @@ struct Solver {
     if (box_tried) return;
     box_tried = true; box_ok = false;
     if (opt.ilu_box == 0 || th || nghost > 0 || nrow != n || n < 2) return;
+    PhaseTimer pt("ILU(0): structured-grid test");
     const int N = n;
     int offs[3], no = 0;
     for (int r = 0; r < N; ++r) {
@@ -2634,7 +2648,9 @@ struct Solver {
     const long long n1 = no >= 2 ? offs[1] : N, s3 = no == 3 ? offs[2] : N;
     if (N % n1 || s3 % n1 || N % s3) return;
     const int n2 = (int)(s3 / n1), n3 = (int)(N / s3);
-    for (int r = 0; r < N; ++r) {   // the diagonal and exactly the grid neighbours in every row
+    std::atomic<bool> grid{true};
+    host_parallel_for(N, [&](long long r) {   // the diagonal and exactly the grid neighbours in every row
+      if (!grid) return;
       const int e = int2ext[r], ci = (int)(e % n1), cj = (int)((e / n1) % n2), ck = (int)(e / s3);
       const int expect = (ci > 0) + (ci < n1 - 1) + (cj > 0) + (cj < n2 - 1) + (ck > 0) + (ck < n3 - 1);
       int cnt = 0;
@@ -2644,10 +2660,11 @@ struct Solver {
         if (d == 0) diag = true;
         else if ((d == -1 && ci > 0) || (d == 1 && ci < n1 - 1) || (n2 > 1 && ((d == -n1 && cj > 0) || (d == n1 && cj < n2 - 1))) ||
                  (n3 > 1 && ((d == -s3 && ck > 0) || (d == s3 && ck < n3 - 1)))) ++cnt;
-        else return;
+        else { grid = false; return; }
       }
-      if (!diag || cnt != expect) return;
-    }
+      if (!diag || cnt != expect) grid = false;
+    });
+    if (!grid) return;
     BoxGrid g{};
     g.n1 = (int)n1; g.n2 = n2; g.n3 = n3;
     g.B3 = 1;
@@ -2662,14 +2679,14 @@ struct Solver {
     const long long nboxes = (long long)g.NB1 * g.NB2 * g.NB3, slots = nboxes * g.S * 64;
     if (slots >= (1ll << 31)) return;
     std::vector<int> cellmap((size_t)slots, -1), cellpos(N), order((size_t)nboxes);
-    for (int e = 0; e < N; ++e) {
+    host_parallel_for(N, [&](long long e) {
       const int i = (int)(e % n1), j = (int)((e / n1) % n2), k = (int)(e / s3);
       const int I = i / g.B1, J = j / g.B2, K = k / g.B3, ip = i % g.B1, jp = j % g.B2, kp = k % g.B3;
       const long long b = I + (long long)g.NB1 * (J + (long long)g.NB2 * K);
       const long long t = (long long)box_slot(g, b, ip + jp + kp, jp + g.B2 * kp);
       cellmap[(size_t)t] = ext2int[e];
       cellpos[ext2int[e]] = (int)t;
-    }
+    });
     const int nl = g.NB1 + g.NB2 + g.NB3 - 2;
     box_lptr.assign(nl + 1, 0);
     for (int K = 0; K < g.NB3; ++K) for (int J = 0; J < g.NB2; ++J) for (int I = 0; I < g.NB1; ++I) box_lptr[I + J + K + 1]++;
