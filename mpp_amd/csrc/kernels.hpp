@@ -329,6 +329,9 @@ struct ThTriArgs {
 };
 void launch_th_tri_factor(const ThTriArgs &a, hipStream_t stream);
 void launch_th_tri_solve(const ThTriArgs &a, const double *r, double *z, hipStream_t stream);   // r, z: [P; T]
+// ... with the partial sums of z.z (w == nullptr) or of z.w and z.z over both fields, one per block of 256 columns (returns the
+// number of blocks; layout partials[j * blocks + block]); finish with launch_finalize
+int launch_th_tri_solve_dots(const ThTriArgs &a, const double *r, double *z, const double *w, double *partials, hipStream_t stream);
 
 // ---- vectors (device scalars in `sc`) ----
 void launch_copy(int n, const double *x, double *y, hipStream_t stream);

@@ -183,6 +183,7 @@ struct Options {
   bool ell_assembly = true;    // general assembly on the ELL copy of the incidence lists (k_flux_rows_ell)
   int ilu_chain = 1;           // ILU(0) solves: one launch per triangle, tiles chained by flags (1: where it pays, 2: always;
                                // 0: one launch per level)
+  bool th_fused_dots = true;   // coupled TH, bjacobi: the Krylov dot products of M^{-1} r come out of the block column solve
   int ilu_box = 1;             // ILU(0) solves box by box when the pattern is a structured grid in natural ordering (BoxGrid); 0: never, 2: or fail
   bool ilu_box_factor = true;  // ... and the numeric factorisation too (extents other than 2); false: by the elimination program of the general path
   int ilu_box_len = 0;         // box extent along the fastest direction (0: 64 from 2^25 rows, else 32)

@@ -1417,7 +1417,7 @@ struct Solver {
   // z = M^{-1} r together with the dot products (z.z) or (z.w, z.z) of the result, left in sc[S_SUM0..]: one pass less
   // over z (and w) when the preconditioner is the column solver; otherwise the apply followed by the reduction kernels
   bool fused_pc_dots() const {
-    return opt.pc_type == 2 && !th && nghost == 0;
+    return opt.pc_type == 2 && nghost == 0 && (!th || opt.th_fused_dots);
   }
   // the column solve that parks L^{-1} r in LDS between its sweeps (k_tri_solve_lds) instead of going through z
   bool tri_lds() const {
@@ -1440,7 +1440,8 @@ struct Solver {
     {
       ProfScope ps(prof, KC_PC_APPLY);
       int nbk;
-      if (!w && r == fwd_rhs && pc_ready)
+      if (th) nbk = launch_th_tri_solve_dots(th_tri_args(), r, z, w, col_partials.p, stream);
+      else if (!w && r == fwd_rhs && pc_ready)
         nbk = launch_tri_back_dots(tri_args(), fwd_elim.p, z, col_partials.p, stream);
       else if (tri_lds()) nbk = launch_tri_solve_lds(tri_args(), r, z, w, col_partials.p, tri_scratch.p, opt.tri_group, stream);
       else nbk = launch_tri_solve_dots(tri_args(), r, z, w, col_partials.p, stream);
@@ -2767,6 +2768,7 @@ struct Solver {
     } else if (key == "nseg") opt.nseg = (int)num();
     else if (key == "fused_assembly") opt.fused_assembly = num() != 0;
     else if (key == "ilu_graph") opt.ilu_graph = num() != 0;
+    else if (key == "th_fused_dots") opt.th_fused_dots = num() != 0;
     else if (key == "ilu_box") { opt.ilu_box = (int)num(); pc_ready = false; }   // the factors are repacked for the other solve path
     else if (key == "ilu_box_factor") { opt.ilu_box_factor = num() != 0; pc_ready = false; }
     else if (key == "ilu_box_len") {

@@ -395,6 +395,58 @@ __global__ __launch_bounds__(kBlock) void k_th_tri_solve(ThTriArgs a, const doub
   }
 }
 
+// the same solve with the Krylov dot products of its result fused in (the back substitution holds z in registers when it
+// writes it): ND = 1 leaves the partial sums of z.z, ND = 2 those of z.w and z.z (in that order) over both fields, one per
+// block, layout partials[j * gridDim.x + block]
+template <int ND>
+__global__ __launch_bounds__(kBlock) void k_th_tri_solve_dots(ThTriArgs a, const double *__restrict__ r, double *__restrict__ z,
+                                                              const double *__restrict__ w, double *__restrict__ partials) {
+  __shared__ double lds[kBlock / 64];
+  const int c = blockIdx.x * kBlock + threadIdx.x;
+  double acc0 = 0.0, acc1 = 0.0;
+  if (c < a.ncols) {
+    const int tile = c >> 6, tw = min(64, a.ncols - (tile << 6));
+    const size_t cbase = (size_t)tile * 64 * a.nz + (c & 63), n = (size_t)a.n;
+    double dp = 0.0, dt = 0.0;
+    for (int k = 0; k < a.nz; ++k) {
+      const size_t i = cbase + (size_t)k * tw;
+      const B2 l = b2_load(a.L, n, i);
+      const double np = r[i] - (l.pp * dp + l.pt * dt);
+      const double nt = r[n + i] - (l.tp * dp + l.tt * dt);
+      z[i] = np; z[n + i] = nt;
+      dp = np; dt = nt;
+    }
+    double xp = 0.0, xt = 0.0;
+    for (int k = a.nz - 1; k >= 0; --k) {
+      const size_t i = cbase + (size_t)k * tw;
+      const B2 cc = b2_load(a.C, n, i), inv = b2_load(a.inv, n, i);
+      const double bp = z[i] - (cc.pp * xp + cc.pt * xt);
+      const double bt = z[n + i] - (cc.tp * xp + cc.tt * xt);
+      const double yp = inv.pp * bp + inv.pt * bt, yt = inv.tp * bp + inv.tt * bt;
+      z[i] = yp; z[n + i] = yt;
+      xp = yp; xt = yt;
+      if (ND == 2) { acc0 += yp * w[i]; acc0 += yt * w[n + i]; acc1 += yp * yp; acc1 += yt * yt; }
+      else { acc0 += yp * yp; acc0 += yt * yt; }
+    }
+  }
+  // block-wide sums in a fixed order (lanes -> wave leaders -> thread 0)
+  auto block_total = [&](double v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+    if (threadIdx.x == 0) for (int q = 0; q < kBlock / 64; ++q) t += lds[q];
+    return t;
+  };
+  const double t0 = block_total(acc0);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t0;
+  if (ND == 2) {
+    const double t1 = block_total(acc1);
+    if (threadIdx.x == 0) partials[(size_t)gridDim.x + blockIdx.x] = t1;
+  }
+}
+
 inline dim3 nblk(long long n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
 
 }  // namespace
@@ -406,6 +458,13 @@ void launch_th_tri_factor(const ThTriArgs &a, hipStream_t stream) {
 }
 void launch_th_tri_solve(const ThTriArgs &a, const double *r, double *z, hipStream_t stream) {
   if (a.ncols > 0) TH_LAUNCH(k_th_tri_solve, nblk(a.ncols), a, r, z);
+}
+int launch_th_tri_solve_dots(const ThTriArgs &a, const double *r, double *z, const double *w, double *partials, hipStream_t stream) {
+  if (a.ncols <= 0) return 0;
+  const dim3 grid = nblk(a.ncols);
+  if (w) TH_LAUNCH(k_th_tri_solve_dots<2>, grid, a, r, z, w, partials);
+  else TH_LAUNCH(k_th_tri_solve_dots<1>, grid, a, r, z, w, partials);
+  return (int)grid.x;
 }
 
 // mode 0 residual, 2 residual + Jacobian, 3 PreSolve (accumulation terms of both equations into F)
