@@ -1226,7 +1226,7 @@ __global__ __launch_bounds__(kBlock) void k_set(int n, double v, double *__restr
 // Factor values and the diagonal's reciprocals into the box layout: slot t holds internal cell cellmap[t] (-1: padding, all zero).
 // An entry is told apart by the distance of its column from the row in the caller's numbering.
 __global__ __launch_bounds__(kBlock) void k_box_fill(long long nslots, BoxGrid g, const int *__restrict__ cellmap, const int *__restrict__ int2ext,
-                                                     const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ lu,
+                                                     const int *__restrict__ rowptr, const int *__restrict__ col, int nown, const double *__restrict__ lu,
                                                      const double *__restrict__ idiag, double *Ld, double *Ls, double *Lw, double *Ue, double *Un,
                                                      double *Uu, double *Di) {
   const long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
@@ -1237,6 +1237,7 @@ __global__ __launch_bounds__(kBlock) void k_box_fill(long long nslots, BoxGrid g
     const int e = int2ext[r], s3 = g.n1 * g.n2;
     di = idiag[r];
     for (int q = rowptr[r]; q < rowptr[r + 1]; ++q) {
+      if (col[q] >= nown) continue;   // a ghost column: multiplies a zero in the solves
       const int d = int2ext[col[q]] - e;
       const double v = lu[q];
       if (d == -1) lw = v;
@@ -1253,7 +1254,7 @@ __global__ __launch_bounds__(kBlock) void k_box_fill(long long nslots, BoxGrid g
 // upper entries, and -- transposed -- the upper entries of its three lower neighbours that point back at it (T: a(c-1, c) etc.).
 // Padding slots: zeros and a unit diagonal (the factorisation divides by it).
 __global__ __launch_bounds__(kBlock) void k_box_load(long long nslots, BoxGrid g, const int *__restrict__ cellmap, const int *__restrict__ int2ext,
-                                                     const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val,
+                                                     const int *__restrict__ rowptr, const int *__restrict__ col, int nown, const double *__restrict__ val,
                                                      double *Ld, double *Ls, double *Lw, double *Ue, double *Un, double *Uu, double *Di,
                                                      double *Td, double *Ts, double *Tw) {
   const long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
@@ -1267,7 +1268,9 @@ __global__ __launch_bounds__(kBlock) void k_box_load(long long nslots, BoxGrid g
       return 0.0;
     };
     for (int q = rowptr[r]; q < rowptr[r + 1]; ++q) {
-      const int c = col[q], d = int2ext[c] - e;
+      const int c = col[q];
+      if (c >= nown) continue;        // a ghost column
+      const int d = int2ext[c] - e;
       const double v = val[q];
       if (d == 0) di = v;
       else if (d == -1) { lw = v; tw = back(c); }
@@ -2236,13 +2239,13 @@ void launch_copy(int n, const double *x, double *y, hipStream_t stream) {
 void launch_set(int n, double v, double *y, hipStream_t stream) {
   if (n > 0) LAUNCH(k_set, dim3(vec_grid(n)), n, v, y);
 }
-void launch_box_fill(long long nslots, const BoxGrid &g, const int *cellmap, const int *int2ext, const int *rowptr, const int *col,
+void launch_box_fill(long long nslots, const BoxGrid &g, const int *cellmap, const int *int2ext, const int *rowptr, const int *col, int nown,
                      const double *lu, const double *idiag, double *const L[3], double *const U[3], double *Di, hipStream_t stream) {
-  if (nslots > 0) LAUNCH(k_box_fill, dim3(nblk(nslots)), nslots, g, cellmap, int2ext, rowptr, col, lu, idiag, L[0], L[1], L[2], U[0], U[1], U[2], Di);
+  if (nslots > 0) LAUNCH(k_box_fill, dim3(nblk(nslots)), nslots, g, cellmap, int2ext, rowptr, col, nown, lu, idiag, L[0], L[1], L[2], U[0], U[1], U[2], Di);
 }
-void launch_box_load(long long nslots, const BoxGrid &g, const int *cellmap, const int *int2ext, const int *rowptr, const int *col,
+void launch_box_load(long long nslots, const BoxGrid &g, const int *cellmap, const int *int2ext, const int *rowptr, const int *col, int nown,
                      const double *val, double *const L[3], double *const U[3], double *Di, double *const T[3], hipStream_t stream) {
-  if (nslots > 0) LAUNCH(k_box_load, dim3(nblk(nslots)), nslots, g, cellmap, int2ext, rowptr, col, val, L[0], L[1], L[2], U[0], U[1], U[2], Di,
+  if (nslots > 0) LAUNCH(k_box_load, dim3(nblk(nslots)), nslots, g, cellmap, int2ext, rowptr, col, nown, val, L[0], L[1], L[2], U[0], U[1], U[2], Di,
                          T[0], T[1], T[2]);
 }
 void launch_box_factor(const BoxGrid &g, const int *boxes, int nboxes, double *const L[3], const double *const T[3], double *Di, double *scratch,

@@ -239,7 +239,8 @@ __host__ __device__ inline size_t box_slot(const BoxGrid &g, long long box, int 
   return ((size_t)box * g.S + (size_t)(row & ~1)) * 64 + 2 * lane + (row & 1);
 }
 // L = {down, south, west}, U = {east, north, up} entries (ascending column order within a row), Di = 1 / u_ii
-void launch_box_fill(long long nslots, const BoxGrid &g, const int *cellmap, const int *int2ext, const int *rowptr, const int *col,
+// (nown: the cells this rank owns come first; columns from nown on are ghost cells and are skipped)
+void launch_box_fill(long long nslots, const BoxGrid &g, const int *cellmap, const int *int2ext, const int *rowptr, const int *col, int nown,
                      const double *lu, const double *idiag, double *const L[3], double *const U[3], double *Di, hipStream_t stream);
 // The numeric factorisation by boxes, when every extent of the grid differs from 2 (box_factor_applies): launch_box_load puts the
 // matrix into the box layout (L, U, Di = the diagonal, T = the upper entries of the lower neighbours that point back at a cell),
@@ -247,7 +248,7 @@ void launch_box_fill(long long nslots, const BoxGrid &g, const int *cellmap, con
 // order -- the arithmetic and order of the elimination program of the general kernel.
 constexpr int kBoxRingFactor = 5;   // row pairs in flight there (11 memory instructions each)
 inline bool box_factor_applies(const BoxGrid &g) { return g.n1 != 2 && g.n2 != 2 && g.n3 != 2; }
-void launch_box_load(long long nslots, const BoxGrid &g, const int *cellmap, const int *int2ext, const int *rowptr, const int *col,
+void launch_box_load(long long nslots, const BoxGrid &g, const int *cellmap, const int *int2ext, const int *rowptr, const int *col, int nown,
                      const double *val, double *const L[3], double *const U[3], double *Di, double *const T[3], hipStream_t stream);
 void launch_box_factor(const BoxGrid &g, const int *boxes, int nboxes, double *const L[3], const double *const T[3], double *Di, double *scratch,
                        hipStream_t stream);

@@ -1323,7 +1323,7 @@ struct Solver {
       if (box_factored()) {   // structured grid: the factorisation itself runs box by box, no level analysis of the rows at all
         if (!box_T[0].p) for (auto &t : box_T) t.alloc((size_t)box_slots);
         double *const T[3] = {box_T[0].p, box_T[1].p, box_T[2].p};
-        launch_box_load(box_slots, box, box_cellmap.p, d_int2ext.p, d_rowptr.p, d_col.p, d_val.p, L, U, box_Di.p, T, stream);
+        launch_box_load(box_slots, box, box_cellmap.p, d_int2ext.p, d_rowptr.p, d_col.p, nred, d_val.p, L, U, box_Di.p, T, stream);
         run_graph(box_fgraph, box_fgraph_exec, [&] {
           for (size_t l = 0; l + 1 < box_lptr.size(); ++l)
             launch_box_factor(box, box_order.p + box_lptr[l], box_lptr[l + 1] - box_lptr[l], L, T, box_Di.p, box_scratch.p, stream);
@@ -1336,7 +1336,7 @@ struct Solver {
       for (size_t l = 0; l + 1 < h_lptr.size(); ++l)
         launch_ilu_factor_program(d_fptr.p, d_fprog.p, d_lrows.p, d_diag.p, h_lptr[l], h_lptr[l + 1], d_lu.p, d_idiag.p, stream);
       if (box_active()) {   // into the box layout of the structured-grid solves
-        launch_box_fill(box_slots, box, box_cellmap.p, d_int2ext.p, d_rowptr.p, d_col.p, d_lu.p, d_idiag.p, L, U, box_Di.p, stream);
+        launch_box_fill(box_slots, box, box_cellmap.p, d_int2ext.p, d_rowptr.p, d_col.p, nred, d_lu.p, d_idiag.p, L, U, box_Di.p, stream);
       } else {              // into the level-ordered ELL blocks the general solves stream through
         ilu_build_ell();
         launch_ilu_repack((long long)ell_KL * nrow, d_Lslot.p, d_lu.p, d_Lval.p, stream);
@@ -1384,7 +1384,8 @@ struct Solver {
     else if (opt.pc_type == 1 && box_active()) {
       launch_gather_or_zero(box_slots, box_cellmap.p, r, box_v.p, stream);   // r into the box layout, padding zero
       run_graph(box_graph, box_graph_exec, [&] { box_solve_levels(); });
-      launch_gather(nrow, box_cellpos.p, box_v.p, z, stream);                // back to the internal row order
+      launch_gather(nred, box_cellpos.p, box_v.p, z, stream);                // back to the internal row order
+      if (nghost > 0) launch_set(nghost, 0.0, z + nred, stream);             // (identity rows, zero right-hand side)
     } else if (opt.pc_type == 1) {
       launch_gather(nrow, d_lrows.p, r, ilu_y.p, stream);            // r into the L level order
       bool solved = false;
@@ -2628,13 +2629,16 @@ struct Solver {
   void ilu_box_analyse() {
     if (box_tried) return;
     box_tried = true; box_ok = false;
-    if (opt.ilu_box == 0 || th || nghost > 0 || nrow != n || n < 2) return;
+    if (opt.ilu_box == 0 || th || nrow != n || nred < 2) return;
     PhaseTimer pt("ILU(0): structured-grid test");
-    const int N = n;
+    // With ghost cells (last in the numbering, identity layout, identity rows, zero right-hand side in the preconditioner) the
+    // local ILU(0) is the ILU(0) of the block of the owned cells: the test and the boxes cover that block, ghost columns are skipped.
+    const int N = nred;
     int offs[3], no = 0;
     for (int r = 0; r < N; ++r) {
       const int e = int2ext[r];
       for (int q = h_rowptr[r]; q < h_rowptr[r + 1]; ++q) {
+        if (h_col[q] >= N) continue;
         const int d = int2ext[h_col[q]] - e;
         if (d <= 0) continue;
         bool seen = false;
@@ -2657,6 +2661,7 @@ struct Solver {
       int cnt = 0;
       bool diag = false;
       for (int q = h_rowptr[r]; q < h_rowptr[r + 1]; ++q) {
+        if (h_col[q] >= N) continue;
         const long long d = (long long)int2ext[h_col[q]] - e;
         if (d == 0) diag = true;
         else if ((d == -1 && ci > 0) || (d == 1 && ci < n1 - 1) || (n2 > 1 && ((d == -n1 && cj > 0) || (d == n1 && cj < n2 - 1))) ||

@@ -404,3 +404,38 @@ def test_box_ilu_is_refused_by_name_on_a_pattern_that_is_not_a_grid():
         g.soe.SetDtime(prob.dt); g.soe.PreSolve(); g.soe.ComputeJacobian(x)
     v = np.random.default_rng(5).standard_normal(x.size)
     assert np.array_equal(dflt.soe.PCApply(v), lev.soe.PCApply(v))
+
+
+@pytest.mark.parametrize("nranks,nz,boxed", [(2, 12, True), (3, 12, True), (3, 14, False)])
+def test_box_ilu_on_ranks_with_ghost_planes(nranks, nz, boxed):
+    """a 3-D grid split into contiguous id ranges with ghost cells: ghost rows are identity rows with a zero right-hand side in
+    the preconditioner, so a rank's ILU(0) is that of its block of owned cells.  Whole z-slabs (12 planes over 2 or 3 ranks) are
+    structured grids again and are factorised and solved by boxes; 14 planes over 3 ranks cut through planes and every rank falls
+    back to the general route by itself.  Same bits as the general route on the same partition either way, and the
+    single-handle answer to the linear tolerance"""
+    from mpp_amd import vsfm as V
+    from test_gpu_more import _run_ranks
+    tp = P.thermal_mms(3, 11, 9, nz, replicate_reference_soil_indexing=False)
+    ref = P.to_thermal_gpu(tp, {"ksp_type": "gmres", "pc_type": "ilu", "ksp_rtol": 1e-12})
+    ref.soe.PreStepDT()
+    assert ref.soe.StepDT(tp.dt)[0]
+    t_ref = ref.soe.GetSoln()
+    answers = {}
+    for box in (2 if boxed else 1, 0):
+        opts = {"ksp_type": "gmres", "pc_type": "ilu", "ksp_rtol": 1e-12, "ilu_box": box, "ilu_chain": 0}
+        parts = P.split_thermal_problem(tp, nranks)
+        gs = [P.to_thermal_gpu(lp, opts) for _, lp in parts]
+        V.comm_init_local([g.soe for g in gs])
+
+        def step(g):
+            g.soe.PreStepDT()
+            return g.soe.StepDT(tp.dt)
+
+        res = _run_ranks([lambda g=g: step(g) for g in gs])
+        assert all(r[0] for r in res)
+        assert all(g.soe.pc_info()["path"] == ("boxes" if box and boxed else "levels") for g in gs)
+        answers[box] = [(part, g.soe.GetSoln(), g.soe.last_linear_iterations) for (part, _), g in zip(parts, gs)]
+    for (part, tb, ib), (_, tl, il) in zip(answers[2 if boxed else 1], answers[0]):
+        assert ib == il
+        assert np.array_equal(tb[:part.nowned], tl[:part.nowned])
+        assert np.abs(tb[:part.nowned] - t_ref[part.l2g[:part.nowned]]).max() <= 1e-8
