@@ -1283,6 +1283,29 @@ __global__ __launch_bounds__(kBlock) void k_box_load(long long nslots, BoxGrid g
   }
   Ld[t] = ld; Ls[t] = ls; Lw[t] = lw; Ue[t] = ue; Un[t] = un; Uu[t] = uu; Di[t] = di; Td[t] = td; Ts[t] = ts; Tw[t] = tw;
 }
+// The right-hand side into the box layout, one workgroup per box: a box's cells are read line by line along the fastest
+// direction (consecutive cells of the caller's numbering: coalesced reads of ext2int and, in the layouts the library uses, of r),
+// placed in an LDS image of the box (padding zero) and written out row by row -- k_gather_or_zero reads r through the slot
+// order, two cells per 64-byte sector (PMC: 55 bytes per cell at 256^3)
+__global__ __launch_bounds__(kBlock) void k_box_gather_in(BoxGrid g, const int *__restrict__ ext2int, const double *__restrict__ r,
+                                                          double *__restrict__ v) {
+  extern __shared__ double img[];   // S * 64 doubles
+  const int b = blockIdx.x, nslot = g.S * 64;
+  const int I = b % g.NB1, J = (b / g.NB1) % g.NB2, K = b / (g.NB1 * g.NB2);
+  for (int t = threadIdx.x; t < nslot; t += kBlock) img[t] = 0.0;
+  __syncthreads();
+  for (int q = threadIdx.x; q < 64 * g.B1; q += kBlock) {
+    const int line = q / g.B1, ip = q - line * g.B1, jp = line & (g.B2 - 1), kp = line >> g.lg2;
+    const int i = I * g.B1 + ip, j = J * g.B2 + jp, k = K * g.B3 + kp;
+    if (i < g.n1 && j < g.n2 && k < g.n3) {
+      const int row = ip + jp + kp;
+      img[(row & ~1) * 64 + 2 * line + (row & 1)] = r[ext2int[i + g.n1 * (j + g.n2 * k)]];
+    }
+  }
+  __syncthreads();
+  double *out = v + (size_t)b * nslot;
+  for (int t = threadIdx.x; t < nslot; t += kBlock) out[t] = img[t];
+}
 __global__ __launch_bounds__(kBlock) void k_gather_or_zero(long long n, const int *idx, const double *in, double *out) {
   const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
   if (i < n) { const int j = idx[i]; out[i] = j >= 0 ? in[j] : 0.0; }
@@ -2253,6 +2276,11 @@ void launch_box_factor(const BoxGrid &g, const int *boxes, int nboxes, double *c
   const size_t lds = (size_t)box_face_doubles(g) * sizeof(double);
   if (nboxes > 0) hipLaunchKernelGGL((k_box_factor<kBoxRingFactor>), dim3(nboxes), dim3(64), lds, stream, g, boxes, L[0], L[1], L[2], T[0], T[1], T[2],
                                      Di, scratch);
+}
+bool box_gather_in_fits(const BoxGrid &g) { return (size_t)g.S * 64 * sizeof(double) <= 48 * 1024; }
+void launch_box_gather_in(const BoxGrid &g, const int *ext2int, const double *r, double *v, hipStream_t stream) {
+  const long long nboxes = (long long)g.NB1 * g.NB2 * g.NB3;
+  if (nboxes > 0) hipLaunchKernelGGL(k_box_gather_in, dim3((unsigned)nboxes), dim3(kBlock), (size_t)g.S * 64 * sizeof(double), stream, g, ext2int, r, v);
 }
 void launch_gather_or_zero(long long n, const int *idx, const double *in, double *out, hipStream_t stream) {
   if (n > 0) LAUNCH(k_gather_or_zero, dim3(nblk(n)), n, idx, in, out);

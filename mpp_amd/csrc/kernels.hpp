@@ -253,6 +253,10 @@ void launch_box_load(long long nslots, const BoxGrid &g, const int *cellmap, con
 void launch_box_factor(const BoxGrid &g, const int *boxes, int nboxes, double *const L[3], const double *const T[3], double *Di, double *scratch,
                        hipStream_t stream);
 void launch_gather_or_zero(long long n, const int *idx, const double *in, double *out, hipStream_t stream);   // out[i] = idx[i] >= 0 ? in[idx[i]] : 0
+// r (internal row order, ext2int: the caller's id -> internal row) into the box layout v, padding zero; one workgroup per box with an
+// LDS image of the box (box_gather_in_fits: S * 64 doubles within 48 KB; otherwise launch_gather_or_zero through the slot map)
+bool box_gather_in_fits(const BoxGrid &g);
+void launch_box_gather_in(const BoxGrid &g, const int *ext2int, const double *r, double *v, hipStream_t stream);
 // the boxes of one box level (ids in boxes[0 .. nboxes)), in place on the vector in box layout
 // scratch: 128 doubles anybody may overwrite
 void launch_box_lower(const BoxGrid &g, const int *boxes, int nboxes, const double *const L[3], double *y, double *scratch, hipStream_t stream);

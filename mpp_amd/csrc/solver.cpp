@@ -1382,7 +1382,8 @@ struct Solver {
     else if (opt.pc_type == 2) launch_tri_solve(tri_args(), r, z, stream);
     else if (opt.pc_type == 3) launch_pointwise_mult(nred, jac_invd.p, r, z, stream);
     else if (opt.pc_type == 1 && box_active()) {
-      launch_gather_or_zero(box_slots, box_cellmap.p, r, box_v.p, stream);   // r into the box layout, padding zero
+      if (box_gather_in_fits(box)) launch_box_gather_in(box, d_ext2int.p, r, box_v.p, stream);   // r into the box layout, padding zero
+      else launch_gather_or_zero(box_slots, box_cellmap.p, r, box_v.p, stream);
       run_graph(box_graph, box_graph_exec, [&] { box_solve_levels(); });
       launch_gather(nred, box_cellpos.p, box_v.p, z, stream);                // back to the internal row order
       if (nghost > 0) launch_set(nghost, 0.0, z + nred, stream);             // (identity rows, zero right-hand side)
