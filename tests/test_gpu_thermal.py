@@ -58,6 +58,23 @@ def test_thermal_solve_matches_tight_oracle_solution(ksp, pc):
     assert np.abs(g.soe.GetSoln() - tp.exact).max() < 1.0   # 0.75 K on this grid, 0.19 K at twice the resolution
 
 
+def test_thermal_mms_second_order_at_128_and_256_cubed_with_petsc_defaults():
+    """an eighth of BASELINE config 4 (512^3) on one GPU with the reference's solver choice, GMRES(30) + ILU(0), solved box by
+    box: the size-independent property of the manufactured-solution problem is second-order convergence, so at a tolerance that
+    resolves the discretisation error (PETSc's default 1e-5 on the preconditioned residual does not) the error
+    against the manufactured solution must drop fourfold from 128^3 to 256^3 (16.7 M cells, 766 dependency levels)"""
+    err = {}
+    for n in (128, 256):
+        tp = P.thermal_mms(3, n, n, n, replicate_reference_soil_indexing=False)
+        g = P.to_thermal_gpu(tp, {"ksp_type": "gmres", "pc_type": "ilu", "ksp_rtol": 1e-9, "ksp_max_it": 5000})
+        conv, _ = g.soe.StepDT(tp.dt, 1)
+        assert conv
+        assert g.soe.pc_info()["path"] == "boxes"
+        err[n] = np.abs(g.soe.GetSoln() - tp.exact).max()
+        del g, tp
+    assert err[256] < 2e-3 and 3.6 <= err[128] / err[256] <= 4.4, err
+
+
 def test_ilu0_apply_matches_the_oracle_on_the_vchannel_jacobian():
     """level-scheduled ILU(0) in the caller's natural ordering == sequential ILU(0) of the oracle / PETSc"""
     prob = P.vchannel(nx=9, ny=7, nz=8)
