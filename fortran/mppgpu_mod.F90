@@ -312,11 +312,11 @@ module mppgpu_mod
        real(c_double) :: dt_sub(*)
        integer(c_int) :: n
      end function
-     integer(c_int) function mppgpu_get_comm_stats(h, allreduces, halo_exchanges, chain_fallbacks) &
+     integer(c_int) function mppgpu_get_comm_stats(h, allreduces, halo_exchanges, chain_fallbacks, host_readbacks) &
           bind(C, name='mppgpu_get_comm_stats')
        import :: c_int, c_ptr, c_long_long
        type(c_ptr), value :: h
-       integer(c_long_long) :: allreduces, halo_exchanges, chain_fallbacks
+       integer(c_long_long) :: allreduces, halo_exchanges, chain_fallbacks, host_readbacks
      end function
      integer(c_int) function mppgpu_get_pc_info(h, path, launches, box_extents) bind(C, name='mppgpu_get_pc_info')
        import :: c_int, c_ptr

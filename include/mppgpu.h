@@ -299,9 +299,12 @@ int mppgpu_kernel_stats(mppgpu_handle h, const char *name, long long *launches, 
                         double *algorithmic_bytes_per_launch);
 int mppgpu_reset_stats(mppgpu_handle h);
 /* collectives this handle issued since the last mppgpu_reset_stats: all-reduces (RCCL ncclAllReduce or the in-process
- * group) and halo exchanges; and how many chained ILU(0) applications had to be redone with per-level launches because a
- * dependency wait exhausted its spin budget (since mppgpu_setup).  No counterpart in the reference (PETSC_COMM_SELF). */
-int mppgpu_get_comm_stats(mppgpu_handle h, long long *allreduces, long long *halo_exchanges, long long *chain_fallbacks);
+ * group) and halo exchanges; how many chained ILU(0) applications had to be redone with per-level launches because a
+ * dependency wait exhausted its spin budget (since mppgpu_setup); and how many times the host waited for device scalars
+ * (norms, dot products, Krylov recurrences) since the last mppgpu_reset_stats.  No counterpart in the reference
+ * (PETSC_COMM_SELF, host-resident Vec). */
+int mppgpu_get_comm_stats(mppgpu_handle h, long long *allreduces, long long *halo_exchanges, long long *chain_fallbacks,
+                          long long *host_readbacks);
 /* how the ILU(0) preconditioner (PETSc PCILU, MatSolve_SeqAIJ) applies its triangular solves on this handle, known once the
  * preconditioner has been set up: path = 0 no ILU(0) in use (or not set up yet), 1 one launch per dependency level,
  * 2 one launch per triangle with the tiles of a level chained by flags, 3 one launch per box level of a structured grid;

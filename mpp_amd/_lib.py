@@ -67,7 +67,7 @@ SIGNATURES = {
     "mppgpu_th_set_soils": (ct.c_int, [_h, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
     "mppgpu_kernel_stats": (ct.c_int, [_h, ct.c_char_p, _llp, _dp, _dp]),
     "mppgpu_reset_stats": (ct.c_int, [_h]),
-    "mppgpu_get_comm_stats": (ct.c_int, [_h, _llp, _llp, _llp]),
+    "mppgpu_get_comm_stats": (ct.c_int, [_h, _llp, _llp, _llp, _llp]),
     "mppgpu_get_pc_info": (ct.c_int, [_h, _ip, _ip, _ip]),
     "mppgpu_bench_kernel": (ct.c_int, [_h, ct.c_char_p, ct.c_int, ct.c_int, _dp, _dp]),
     "mppgpu_comm_get_unique_id": (ct.c_int, [ct.c_void_p]),

@@ -1611,6 +1611,10 @@ __global__ __launch_bounds__(kBlock) void k_gather(int n, const int *idx, const 
   const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (i < (size_t)n) out[i] = in[idx[i]];
 }
+__global__ __launch_bounds__(kBlock) void k_scatter(int n, const int *idx, const double *in, double *out) {
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < (size_t)n) out[idx[i]] = in[i];
+}
 __global__ __launch_bounds__(kBlock) void k_pmult(int n, const double *a, const double *x, double *y) {
   vec2_loop(n, [&](size_t q) { const double2 u = CD2(a)[q], v = CD2(x)[q]; D2(y)[q] = make_double2(u.x * v.x, u.y * v.y); }, [&](size_t i) { y[i] = a[i] * x[i]; });
 }
@@ -1951,18 +1955,35 @@ __device__ void bcgs_scalar_step(int step, double *sc) {
     sc[S_BETA] = (rho / sc[S_RHOOLD]) * (sc[S_ALPHA] / sc[S_OMEGAOLD]);
   }
 }
-__global__ void k_bcgs_scalars(int step, double *sc) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  bcgs_scalar_step(step, sc);
+// The scalar block straight into pinned host memory, then a sequence word: the host polls that word instead of queueing a
+// device-to-host copy behind the kernel and waiting for the stream (Solver::fetch_scalars).  Called by every thread of the
+// block that holds the final values, after the thread that wrote them has passed a workgroup barrier (`sync_first`: this call
+// places it).  System-scope stores; the sequence word follows the data (release) once every lane's stores are acknowledged.
+struct Publish { double *host; unsigned long long *seq; unsigned long long value; };
+__device__ __forceinline__ void publish_scalars(const Publish &p, const double *sc) {
+  if (!p.host) return;
+  __syncthreads();
+  for (int q = threadIdx.x; q < S_COUNT; q += blockDim.x)
+    __hip_atomic_store(p.host + q, __hip_atomic_load(sc + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this lane's stores have left
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(p.seq, p.value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void k_bcgs_scalars(int step, double *sc, Publish pub) {
+  if (blockIdx.x != 0) return;
+  if (threadIdx.x == 0 && step >= 0) bcgs_scalar_step(step, sc);
+  publish_scalars(pub, sc);
 }
 
 // Second stage of every reduction, in one launch: block (c, j) sums chunk c of vector j's partials in a fixed order into
 // stage[j*nchunk + c]; the block whose ticket comes last sums the chunk sums (again in a fixed order, so the result does not
-// depend on which block that is) into sums[S_SUM0 + j] and, step >= 0, runs the BiCGStab scalar recurrence that consumes them.
+// depend on which block that is) into sums[S_SUM0 + j] and, step >= 0, runs the BiCGStab scalar recurrence that consumes them;
+// pub.host != nullptr: it then publishes the scalar block to the host.
 // Hand-off: chunk sums are agent-scope stores, acknowledged (vmcnt(0)) before the storing wave takes its ticket; the last
 // block reads them with agent-scope loads after a workgroup barrier behind the returned ticket.  It leaves the counter at 0.
 __global__ __launch_bounds__(kBlock) void k_finalize(int nb, int chunk, const double *partials, double *stage, double *sums,
-                                                     unsigned *counter, double *sc, int step) {
+                                                     unsigned *counter, double *sc, int step, Publish pub) {
   __shared__ double lds[kBlock / 64];
   __shared__ int last;
   const int c = blockIdx.x, j = blockIdx.y, nchunk = gridDim.x, nvec = gridDim.y;
@@ -1971,7 +1992,11 @@ __global__ __launch_bounds__(kBlock) void k_finalize(int nb, int chunk, const do
   for (int b = b0 + threadIdx.x; b < b1; b += kBlock) acc += partials[(size_t)j * nb + b];
   const double t = block_sum(acc, lds);
   if (nchunk * nvec == 1) {   // nothing to wait for
-    if (threadIdx.x == 0) { sums[S_SUM0] = t; if (step >= 0) bcgs_scalar_step(step, sc); }
+    if (threadIdx.x == 0) {
+      __hip_atomic_store(sums + S_SUM0, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (step >= 0) bcgs_scalar_step(step, sc);
+    }
+    publish_scalars(pub, sc);
     return;
   }
   if (threadIdx.x == 0) {
@@ -1987,12 +2012,13 @@ __global__ __launch_bounds__(kBlock) void k_finalize(int nb, int chunk, const do
     for (int b = threadIdx.x; b < nchunk; b += kBlock)
       a2 += __hip_atomic_load(stage + (size_t)jj * nchunk + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const double tt = nchunk == 1 ? a2 : block_sum(a2, lds);   // one chunk: thread 0 holds it (the sum of the first stage, as is)
-    if (threadIdx.x == 0) sums[S_SUM0 + jj] = tt;
+    if (threadIdx.x == 0) __hip_atomic_store(sums + S_SUM0 + jj, tt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (threadIdx.x == 0) {
     __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (step >= 0) bcgs_scalar_step(step, sc);
   }
+  publish_scalars(pub, sc);
 }
 
 // partials != nullptr: also the partial sums of y.y of the result (the norm GMRES takes next), one per block
@@ -2297,6 +2323,9 @@ void launch_box_upper(const BoxGrid &g, const int *boxes, int nboxes, const doub
 void launch_gather(int n, const int *idx, const double *in, double *out, hipStream_t stream) {
   if (n > 0) LAUNCH(k_gather, dim3(nblk(n)), n, idx, in, out);
 }
+void launch_scatter(int n, const int *idx, const double *in, double *out, hipStream_t stream) {
+  if (n > 0) LAUNCH(k_scatter, dim3(nblk(n)), n, idx, in, out);
+}
 void launch_pointwise_mult(int n, const double *a, const double *x, double *y, hipStream_t stream) {
   if (n > 0) LAUNCH(k_pmult, dim3(vec_grid(n)), n, a, x, y);
 }
@@ -2347,7 +2376,8 @@ int finalize_chunks(int nblocks) { return nblocks <= 2 * kFinalizeChunk ? 1 : (n
 void launch_finalize(int nblocks, int nvec, const double *partials, double *sums, const Finalize &f, hipStream_t stream) {
   if (nvec <= 0) return;
   const int nchunk = finalize_chunks(nblocks);
-  LAUNCH(k_finalize, dim3(nchunk, nvec), nblocks, nchunk == 1 ? nblocks : kFinalizeChunk, partials, f.stage, sums, f.counter, f.sc, f.step);
+  LAUNCH(k_finalize, dim3(nchunk, nvec), nblocks, nchunk == 1 ? nblocks : kFinalizeChunk, partials, f.stage, sums, f.counter, f.sc, f.step,
+         Publish{f.pub_host, f.pub_seq, f.pub_value});
 }
 int maxpy_blocks(int n) { return nblk(n); }
 int launch_maxpy_neg(const MaxpyArgs &a, const double *sc, double *y, double *partials, hipStream_t stream) {
@@ -2363,7 +2393,10 @@ void launch_scale(int n, double *x, const double *sc, int slot_inv_of, hipStream
   if (n > 0) LAUNCH(k_scale_inv, dim3(nblk(n)), n, x, sc, slot_inv_of);
 }
 void launch_bcgs_scalars(int step, double *sc, hipStream_t stream) {
-  hipLaunchKernelGGL(k_bcgs_scalars, dim3(1), dim3(64), 0, stream, step, sc);
+  hipLaunchKernelGGL(k_bcgs_scalars, dim3(1), dim3(64), 0, stream, step, sc, Publish{nullptr, nullptr, 0ull});
+}
+void launch_publish(int step, double *sc, double *host, unsigned long long *seq, unsigned long long value, hipStream_t stream) {
+  hipLaunchKernelGGL(k_bcgs_scalars, dim3(1), dim3(128), 0, stream, step, sc, Publish{host, seq, value});
 }
 
 }  // namespace mpp

@@ -342,6 +342,7 @@ int launch_th_tri_solve_dots(const ThTriArgs &a, const double *r, double *z, con
 void launch_copy(int n, const double *x, double *y, hipStream_t stream);
 void launch_set(int n, double v, double *y, hipStream_t stream);
 void launch_gather(int n, const int *idx, const double *in, double *out, hipStream_t stream);   // out[i] = in[idx[i]]
+void launch_scatter(int n, const int *idx, const double *in, double *out, hipStream_t stream);  // out[idx[i]] = in[i] (idx without repeats)
 void launch_pointwise_mult(int n, const double *a, const double *x, double *y, hipStream_t stream);
 // w = y + a*x with a = sign * sc[slot] (or the literal `aval` when slot < 0)
 void launch_waxpy(int n, double *w, const double *sc, int slot, double sign, double aval, const double *x,
@@ -366,7 +367,10 @@ int launch_dots(const DotArgs &a, double *partials, hipStream_t stream);
 // `stage` (kFinalizeStage doubles) and the block that takes the last ticket of `counter` (one word, zero between launches) adds
 // them up; step >= 0: that block then runs BiCGStab's scalar recurrence `step` (launch_bcgs_scalars' codes) on `sc`.
 constexpr int kFinalizeStage = 8192;
-struct Finalize { double *stage; unsigned *counter; double *sc; int step; };
+// pub_host != nullptr: the block that finishes also copies the scalar block sc[0 .. S_COUNT) into pinned host memory (device
+// pointer pub_host) and then stores pub_value at pub_seq: the host polls that word instead of waiting for the stream.
+struct Finalize { double *stage; unsigned *counter; double *sc; int step; double *pub_host = nullptr; unsigned long long *pub_seq = nullptr;
+                  unsigned long long pub_value = 0; };
 int finalize_chunks(int nblocks);   // per vector; nvec * finalize_chunks(nblocks) <= kFinalizeStage is the caller's responsibility
 void launch_finalize(int nblocks, int nvec, const double *partials, double *sums, const Finalize &f, hipStream_t stream);
 // y -= sum_j h[j] * v_j  (h on device at sc[S_SUM0+j]); GMRES classical Gram-Schmidt update
@@ -381,5 +385,7 @@ struct MaxpyValArgs { int n, nvec; const double *v[kMaxMultiDot]; double c[kMaxM
 void launch_maxpy_val(const MaxpyValArgs &a, double *x, hipStream_t stream);
 // single-thread scalar updates of the BiCGStab recurrence; step = 0 init, 1 rho/beta, 2 alpha, 3 omega
 void launch_bcgs_scalars(int step, double *sc, hipStream_t stream);
+// the scalar step `step` (< 0: none) followed by the publication of the scalar block to the host (see Finalize)
+void launch_publish(int step, double *sc, double *host, unsigned long long *seq, unsigned long long value, hipStream_t stream);
 
 }  // namespace mpp

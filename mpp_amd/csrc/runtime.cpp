@@ -25,6 +25,8 @@ const char *kclass_name(int k) {
 void Profiler::begin(int cls) {
   open = enabled && ((mask >> cls) & 1u);
   if (!open) return;
+  open = (calls[cls]++ % stride) == 0;
+  if (!open) return;
   if (used == pool.size()) {
     if (pool.size() >= 8192) flush();
     else {
@@ -57,7 +59,7 @@ void Profiler::flush() {
 }
 void Profiler::reset() {
   flush();
-  for (int k = 0; k < KC_COUNT; ++k) { launches[k] = 0; total_ms[k] = 0.0; }
+  for (int k = 0; k < KC_COUNT; ++k) { launches[k] = 0; total_ms[k] = 0.0; calls[k] = 0; }
 }
 Profiler::~Profiler() {
   for (auto &pr : pool) { (void)hipEventDestroy(pr.a); (void)hipEventDestroy(pr.b); }

@@ -85,6 +85,9 @@ struct Profiler {
   bool enabled = false;
   unsigned mask = ~0u;     // kernel classes that are timed (bit k = class k); the others cost nothing
   bool open = false;       // begin() recorded an event that end() has to close
+  int stride = 1;          // every stride-th launch of a class is timed (an event pair costs ~10 us of queue time: it matters
+                           // where kernels last tens of microseconds); calls[] counts them all
+  long long calls[KC_COUNT] = {0};
   hipStream_t stream = nullptr;
   struct Pair { hipEvent_t a, b; int cls; };
   std::vector<Pair> pool;
@@ -190,7 +193,10 @@ struct Options {
   bool ilu_chain_tickets = false;  // chained ILU(0): tiles handed out by an atomic ticket instead of in dispatch order (kernels.hpp)
   unsigned ilu_chain_spins = 1u << 22;   // polls (~0.4 us apart) before a chained wait gives up and the apply is redone per level
   bool ls_ahead = true;        // the line search's first reductions ride behind the Krylov solver's last update
+  bool ls_spec = true;         // ... and the search's first trial point (the full step) is evaluated there too (LsAhead::spec)
   bool wide_xr = true;         // BiCGStab update kernel on a one-pair-per-lane grid (large vectors)
+  bool host_poll = true;       // scalar read-backs: the reducing kernel publishes into pinned host memory and the host polls a
+                               // sequence word (Solver::fetch_scalars); false: hipMemcpyAsync + hipStreamSynchronize
   bool soil_classes = true;    // column march: one byte per cell + a class table when the mesh has <= 256 distinct soil tuples
   bool level_geometry = true;  // column march: per-level upwind weight / gravity distance when they are the same in every column
   int tri_lds = -1;            // column solve with L^{-1} r parked in LDS between the sweeps: 0 off, 1 on, -1 auto (Solver::tri_lds)

@@ -165,7 +165,22 @@ struct Solver {
   // The line search's first reductions (||Y||, F.(J Y), ||X||) issued by the Krylov solver itself, behind the update of what
   // is expected to be its last iteration: one read-back and one all-reduce serve both.  Armed when the previous solve of
   // this handle converged in one iteration (the column-structured problems); a solve that goes on discards them.
-  struct LsAhead { bool armed = false, done = false; const double *F = nullptr, *X = nullptr; double r3[3] = {0, 0, 0}; } ls_ahead;
+  // spec: the line search's first trial point (the full step W = X - Y) is evaluated there as well -- boundary kernel, column
+  // march (with the Jacobian when the search would have asked for it), ||F(W)||^2 and ||W||^2 in the same read-back and the
+  // same all-reduce: a Newton iteration whose Krylov solve takes one iteration and whose full step is accepted costs the host
+  // ONE wait.  A solve that goes on finds its matrix overwritten by the trial point's: it is assembled again (spec_void; as
+  // rare as a second Krylov iteration on a column-structured problem, counted in spec_misses).
+  struct LsAhead {
+    bool armed = false, done = false;
+    const double *F = nullptr, *X = nullptr;
+    double r3[3] = {0, 0, 0};
+    bool spec = false, spec_issued = false, spec_done = false, spec_fused = false;
+    double *Xv = nullptr, *Wv = nullptr, *Gv = nullptr;
+    double g2 = 0.0, w2 = 0.0;
+  } ls_ahead;
+  long long spec_misses = 0;
+  int asm_slot = 0;          // complete-row march: where its two sums go (sc[S_SUM0 + asm_slot ..]) ...
+  bool asm_defer = false;    // ... and whether the caller all-reduces and reads them itself
   bool ksp_one_shot = false;   // pending X + a Y of the line search
   int debug_fail_at_fetch = 0; // test hook: the n-th scalar read-back from now throws (multi-rank failure handling)
   long long chain_fallbacks = 0;   // chained ILU(0) applications redone with per-level launches after a dependency timeout
@@ -174,6 +189,14 @@ struct Solver {
   const double *fwd_rhs = nullptr;   // the residual vector whose forward elimination fwd_elim holds (for the current factors)
   std::vector<int> h_cc_cell;
   double *h_sc = nullptr;  // pinned mirror of sc
+  // Scalar read-backs without a copy in the queue: the kernel that finishes a reduction writes the scalar block into h_sc
+  // itself (h_sc_dev: its device address) and then a sequence number into h_seq, which the host polls (fetch_scalars).
+  double *h_sc_dev = nullptr;
+  unsigned long long *h_seq = nullptr, *h_seq_dev = nullptr;
+  unsigned long long pub_issued = 0;   // sequence number of the most recent publication in the queue
+  bool pub_arm = false;                // the next finalize() is the last writer of sc before a read-back: it publishes
+  bool pub_valid = false;              // ... and nothing has written sc since
+  long long n_fetch = 0;               // scalar read-backs since the last mppgpu_reset_stats
   std::vector<DevBuf<double>> vv;
 
   // ---------------- thermal KSP path ----------------
@@ -241,6 +264,11 @@ struct Solver {
   std::vector<double> last_substeps;   // sub-steps the most recent StepDT accepted (dt, dt/2 ... after time-step cuts)
   bool pc_ready = false;
   std::vector<double> h_bc_value, h_ss_value;
+  double *h_bc_stage = nullptr;          // pinned staging of boundary values on their way to the device (set_data)
+  DevBuf<double> d_bc_stage;
+  DevBuf<int> d_bc_pos;                  // bc_pos_of_g on the device
+  hipEvent_t bc_stage_ev = nullptr;
+  std::vector<char> bc_stage_pending;
 
   ~Solver() {
     if (ilu_graph_exec) (void)hipGraphExecDestroy(ilu_graph_exec);
@@ -250,6 +278,9 @@ struct Solver {
     if (box_fgraph_exec) (void)hipGraphExecDestroy(box_fgraph_exec);
     if (box_fgraph) (void)hipGraphDestroy(box_fgraph);
     if (h_sc) (void)hipHostFree(h_sc);
+    if (h_seq) (void)hipHostFree(h_seq);
+    if (h_bc_stage) (void)hipHostFree(h_bc_stage);
+    if (bc_stage_ev) (void)hipEventDestroy(bc_stage_ev);
     if (stream) (void)hipStreamDestroy(stream);
   }
 
@@ -684,7 +715,11 @@ struct Solver {
     }
     sc.alloc(S_COUNT); sc.zero(stream);
     fin_stage.alloc(kFinalizeStage); fin_counter.alloc(1); fin_counter.zero(stream);
-    HIP_CHECK(hipHostMalloc(&h_sc, S_COUNT * sizeof(double), hipHostMallocDefault));
+    HIP_CHECK(hipHostMalloc(&h_sc, S_COUNT * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+    HIP_CHECK(hipHostMalloc(&h_seq, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    *h_seq = 0;
+    HIP_CHECK(hipHostGetDevicePointer((void **)&h_sc_dev, h_sc, 0));
+    HIP_CHECK(hipHostGetDevicePointer((void **)&h_seq_dev, h_seq, 0));
     d_Dq.alloc(nc_int); d_upw.alloc(nc_int); d_dgrav.alloc(nc_int); d_area.alloc(nc_int);
     if (thermal || th) {
       std::vector<double> du(nc_int, 0.0), dd(nc_int, 0.0), ar(nc_int, 0.0);
@@ -1034,6 +1069,10 @@ struct Solver {
   bool use_cols() const { return vertical_only && opt.assembly != 0 && !th; }
   int pick_nseg() const {
     if (opt.nseg > 0) return std::min(opt.nseg, nz);
+    // The complete-row march (one thread per column: rows_complete) folds the column LU, the forward elimination, the trial
+    // point and the norms into the assembly pass; from 32 768 columns that outweighs the occupancy of a split march
+    // (65 536 x 50: 2283 against 1963 Newton it/s; 16 384 x 50: 2783 against 2855 -- profiles/r03_nseg_small_grids.json)
+    if (rows_plan && opt.fused_rows && ncols >= (1 << 15)) return 1;
     // enough threads for >= 8 waves on each of the 256 CUs; one halo level per segment end is the price
     const long long want = 256LL * 8 * 64;
     int s = (int)std::min<long long>((want + ncols - 1) / std::max(ncols, 1), std::max(nz / 8, 1));
@@ -1124,9 +1163,12 @@ struct Solver {
     launch_assemble_cols(mode, a, stream);
     if (a.fwd) fwd_rhs = Fout;
     if (mode != 1) {
-      finalize((ncols + 255) / 256, 2, col_partials.p);
-      if (comm.active()) comm.allreduce_sum(sc.p + S_SUM0, 2, stream);
-      asm_sums = true;
+      pub_arm = true;   // the caller reads the two sums next (residual_sums, or the Krylov solver for a speculative trial point)
+      finalize((ncols + 255) / 256, 2, col_partials.p, asm_slot);
+      if (!asm_defer) {
+        if (comm.active()) comm.allreduce_sum(sc.p + S_SUM0, 2, stream);
+        asm_sums = true;
+      }
     }
     if (mode != 0) pc_ready = factor;
   }
@@ -1208,6 +1250,7 @@ struct Solver {
     return nv;
   }
   void op_spmv_dots(const double *y, const double *f, const double *x, double *out) {
+    pub_arm = true;
     const int nv = op_spmv_dots_launch(y, f, x, 0, x ? 3 : 2);
     fetch_scalars();
     for (int j = 0; j < nv; ++j) out[j] = h_sc[S_SUM0 + j];
@@ -1461,10 +1504,22 @@ struct Solver {
   void finalize(int nbk, int nvec, const double *partials_, int slot = 0, int step = -1) {
     if ((size_t)nvec * finalize_chunks(nbk) > (size_t)kFinalizeStage)
       throw Error(std::to_string(nvec) + " sums of " + std::to_string(nbk) + " partial sums exceed the reductions' staging buffer");
-    launch_finalize(nbk, nvec, partials_, sc.p + slot, Finalize{fin_stage.p, fin_counter.p, sc.p, comm.active() ? -1 : step}, stream);
+    Finalize f{fin_stage.p, fin_counter.p, sc.p, comm.active() ? -1 : step};
+    pub_valid = false;
+    if (pub_arm && !comm.active() && opt.host_poll) {   // (across ranks the all-reduce follows: see bcgs_step / fetch_scalars)
+      f.pub_host = h_sc_dev; f.pub_seq = h_seq_dev; f.pub_value = ++pub_issued;
+      pub_valid = true;
+      pub_arm = false;
+    }
+    launch_finalize(nbk, nvec, partials_, sc.p + slot, f, stream);
   }
   void bcgs_step(int step) {
-    if (step >= 0 && comm.active()) launch_bcgs_scalars(step, sc.p, stream);
+    if (step < 0 || !comm.active()) return;
+    if (pub_arm && opt.host_poll) {
+      launch_publish(step, sc.p, h_sc_dev, h_seq_dev, ++pub_issued, stream);
+      pub_valid = true;
+      pub_arm = false;
+    } else { launch_bcgs_scalars(step, sc.p, stream); pub_valid = false; }
   }
   void dots_dev(std::initializer_list<std::pair<const double *, const double *>> pairs, int step = -1) {
     ProfScope ps(prof, KC_REDUCE);
@@ -1476,12 +1531,41 @@ struct Solver {
     if (comm.active()) comm.allreduce_sum(sc.p + S_SUM0, a.nvec, stream);
     bcgs_step(step);
   }
+  // The device scalars on the host.  Default: the kernel that wrote them last has already published them (pub_valid), or a
+  // one-block kernel does now; the host polls the sequence word in pinned memory -- no copy command in the queue, no wait for
+  // the stream's completion signal.  host_poll = 0: hipMemcpyAsync + hipStreamSynchronize.
   void fetch_scalars() {
-    HIP_CHECK(hipMemcpyAsync(h_sc, sc.p, S_COUNT * sizeof(double), hipMemcpyDeviceToHost, stream));
-    HIP_CHECK(hipStreamSynchronize(stream));
+    ++n_fetch;
+    pub_arm = false;
+    if (!opt.host_poll) {
+      HIP_CHECK(hipMemcpyAsync(h_sc, sc.p, S_COUNT * sizeof(double), hipMemcpyDeviceToHost, stream));
+      HIP_CHECK(hipStreamSynchronize(stream));
+    } else {
+      if (!pub_valid) launch_publish(-1, sc.p, h_sc_dev, h_seq_dev, ++pub_issued, stream);
+      pub_valid = false;
+      wait_published(pub_issued);
+    }
     if (debug_fail_at_fetch > 0 && --debug_fail_at_fetch == 0) throw Error("injected failure (option debug_fail_at_fetch)");
   }
+  void wait_published(unsigned long long want) {
+    volatile unsigned long long *seq = h_seq;
+    unsigned spins = 0;
+    int idle_checks = 0;
+    while (*seq < want) {
+      __builtin_ia32_pause();
+      if ((++spins & 0x3FFF) != 0) continue;
+      // now and then: is the stream still alive?  An error ends the wait; a stream that has drained without the word
+      // arriving (it cannot, short of a lost store) ends it after a bounded number of looks
+      const hipError_t e = hipStreamQuery(stream);
+      if (e == hipErrorNotReady) continue;
+      if (e != hipSuccess) throw Error(std::string("stream failed while waiting for published scalars: ") + hipGetErrorString(e));
+      if (*seq >= want) break;
+      if (++idle_checks > 2000) throw Error("published scalars never arrived (sequence word not updated)");
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+  }
   void dots_host(std::initializer_list<std::pair<const double *, const double *>> pairs, double *out) {
+    pub_arm = true;
     dots_dev(pairs);
     fetch_scalars();
     int j = 0;
@@ -1620,6 +1704,7 @@ struct Solver {
         op_pc_apply_dots(Wk.p, V.p, RP.p, 0, 3);   // (v,rp), (v,v) and the parked (rp,rp) in one all-reduce
         launch_bcgs_scalars(6, sc.p, stream);
         launch_bcgs_scalars(2, sc.p, stream);
+        pub_valid = false;
       } else op_pc_apply_dots(Wk.p, V.p, RP.p, 0, -1, 2);   // (v,rp) in sc[S_SUM0]  [(v,v) in S_SUM0+1 is not used]; alpha
       { ProfScope ps(prof, KC_VEC); launch_waxpy(nred, S.p, sc.p, S_ALPHA, -1.0, 0.0, V.p, Rcur, stream); }
       op_spmv(S.p, Wk.p);
@@ -1638,26 +1723,43 @@ struct Solver {
         // end of the iteration: dp, rhoold, omegaold (step 4) and, from the second iteration on, the next one's rho = (r,rp)
         // and beta (step 5) -- harmless when the test below ends the solve
         end_step = i == 0 ? 4 : 45;
+        pub_arm = !(ls_ahead.armed && i == 0);   // the last writer of the scalars before the read-back publishes them
         finalize(nbk, i == 0 ? 1 : 2, pbuf, 0, end_step);
         if (!(ls_ahead.armed && i == 0) && comm.active()) comm.allreduce_sum(sc.p + S_SUM0, i == 0 ? 1 : 2, stream);
       }
       const bool ahead = ls_ahead.armed && i == 0;
       int ahead_nv = 0;
-      if (ahead) ahead_nv = op_spmv_dots_launch(x, ls_ahead.F, ls_ahead.X, 1, 1 + (ls_ahead.X ? 3 : 2));   // x is final if we stop here
+      const bool spec = ahead && ls_ahead.spec;
+      if (ahead) {   // x is final if we stop here
+        const int nv = ls_ahead.X ? 3 : 2;
+        pub_arm = !spec;
+        ahead_nv = op_spmv_dots_launch(x, ls_ahead.F, ls_ahead.X, 1, spec ? 0 : 1 + nv);
+      }
+      if (spec) {    // ... and so is the line search's first trial point X - x
+        ls_point = Trial{ls_ahead.Xv, x, -1.0};
+        ls_ahead.spec_fused = opt.fused_assembly && opt.fused_trials > 0 && !(opt.fused_predict && ls_backtracked_last);
+        asm_slot = 1 + ahead_nv; asm_defer = true;
+        if (ls_ahead.spec_fused) op_residual_jacobian(ls_ahead.Wv, ls_ahead.Gv); else op_residual(ls_ahead.Wv, ls_ahead.Gv);
+        asm_slot = 0; asm_defer = false;
+        ls_ahead.spec_issued = true;
+        if (comm.active()) comm.allreduce_sum(sc.p + S_SUM0, 1 + ahead_nv + 2, stream);   // ||r||^2, the search's sums, the trial point's
+      }
       Rcur = R.p;
+      if (comm.active()) pub_arm = true;
       bcgs_step(end_step);
       fetch_scalars();
+      auto leave = [&](int r) { spec_void(); return r; };   // every exit but the one that hands the trial point to the line search
       if (test0_pending) {
         test0_pending = false;
         reason = ksp_converged(cv, 0, h_sc[S_DP0]);
-        if (reason) { vec_set(0.0, x); return reason; }
+        if (reason) { vec_set(0.0, x); return leave(reason); }
       }
       const double rho = h_sc[S_RHOOLD], d1 = h_sc[S_D1];   // this iteration's rho (step 4 has just moved it there)
-      if (d1 == 0.0) return -5;
+      if (d1 == 0.0) return leave(-5);
       if (h_sc[S_FLAG] != 0.0) {  // t == 0: x += alpha p was applied (omega forced to 0)
         const double ss = std::sqrt(h_sc[S_SUM0]);  // r == s here
         ++*its;
-        return ss != 0.0 ? -5 : 2;
+        return leave(ss != 0.0 ? -5 : 2);
       }
       dp = h_sc[S_DP];
       ++*its;
@@ -1665,12 +1767,29 @@ struct Solver {
       if (reason > 0 && ahead) {
         ls_ahead.done = true;
         for (int j = 0; j < ahead_nv; ++j) ls_ahead.r3[j] = h_sc[S_SUM0 + 1 + j];
+        if (ls_ahead.spec_issued) {
+          ls_ahead.spec_issued = false;
+          ls_ahead.spec_done = true;
+          ls_ahead.g2 = h_sc[S_SUM0 + 1 + ahead_nv]; ls_ahead.w2 = h_sc[S_SUM0 + 2 + ahead_nv];
+        }
+        return reason;
       }
+      spec_void();   // the solve goes on (or has failed): the trial point is void and the matrix is needed again
       if (reason) return reason;
       if (rho == 0.0) return -5;
       ++i;
     } while (i < opt.ksp_max_it);
     return -3;
+  }
+
+  // a speculative trial point that is not going to be used: its function evaluation does not count, and the Jacobian, the
+  // column factors and L^{-1} F it replaced are assembled again at X
+  void spec_void() {
+    if (!ls_ahead.spec_issued) return;
+    ls_ahead.spec_issued = false;
+    --nfuncs; --cum_funcs; ++spec_misses;
+    asm_sums = false;
+    if (ls_ahead.spec_fused) op_jacobian(ls_ahead.Xv, const_cast<double *>(ls_ahead.F));
   }
 
   static constexpr int kNormSlot = 44;   // sc[S_SUM0 + 44]: beyond the <= 31 Gram-Schmidt coefficients
@@ -1689,6 +1808,7 @@ struct Solver {
     while (!reason) {
       // r0 = M^{-1}(b - A x) and its norm; with the column solver the norm comes out of the solve (and the first solve of
       // a Newton iteration starts from the right-hand side the assembly pass already forward-eliminated)
+      pub_arm = true;
       if (first) op_pc_apply_dots(b, vv[0].p, nullptr);
       else {
         op_spmv(x, Wk.p);
@@ -1729,6 +1849,7 @@ struct Solver {
           const size_t nb = (size_t)maxpy_blocks(nred), need = nb + nb / 2048 + 1;
           if (xr_partials.n < need) xr_partials.alloc(need);
           const int nbk = launch_maxpy_neg(ma, sc.p, vnew, xr_partials.p, stream);
+          pub_arm = true;
           finalize(nbk, 1, xr_partials.p, kNormSlot);
           if (comm.active()) comm.allreduce_sum(sc.p + S_SUM0 + kNormSlot, 1, stream);
         }
@@ -1779,6 +1900,7 @@ struct Solver {
   void scale_host(double *x, double divisor) {  // x <- x / divisor
     ProfScope ps(prof, KC_VEC);
     HIP_CHECK(hipMemcpyAsync(sc.p + S_D2, &divisor, sizeof(double), hipMemcpyHostToDevice, stream));
+    pub_valid = false;
     launch_scale(nred, x, sc.p, S_D2, stream);
   }
 
@@ -1828,6 +1950,11 @@ struct Solver {
     if (!xnorm_known) xnorm = std::sqrt(r3[2]);
     ynorm = std::sqrt(r3[0]);
     double initslope = r3[1];
+    // the full step's trial point was evaluated behind the Krylov solve (LsAhead::spec); it is void where PETSc would not
+    // have evaluated it, or not there (the evaluation is then not counted; J(X) is dead by now either way)
+    bool spec = ls_ahead.spec_done;
+    ls_ahead.spec_done = false;
+    if (spec && (ynorm == 0.0 || ynorm > maxstep || nfuncs - 1 >= opt.snes_max_funcs)) { spec = false; --nfuncs; --cum_funcs; }
     if (ynorm == 0.0) return 1;
     if (ynorm > maxstep) {
       vec_waxpy(Yv, maxstep / ynorm - 1.0, Yv, Yv);  // Y *= maxstep/ynorm
@@ -1843,6 +1970,13 @@ struct Solver {
     bool last_fused = false;
     jac_valid = false;
     auto eval = [&](double lam) {
+      if (spec) {   // trial 0, lambda = 1: already evaluated (into Wv, Gv), its sums came with the Krylov solver's read-back
+        spec = false;
+        last_fused = ls_ahead.spec_fused;
+        ++trial;
+        gnorm = std::sqrt(ls_ahead.g2); wnorm2 = ls_ahead.w2;
+        return gnorm * gnorm;
+      }
       // W = X - lam Y: formed inside the assembly pass when the column march finishes the rows itself
       if (rows_complete()) ls_point = Trial{X, Yv, -lam}; else vec_waxpy(Wv, -lam, Yv, X);
       // a trial point's Jacobian is assembled together with its residual when the point is likely to be accepted:
@@ -1856,7 +1990,7 @@ struct Solver {
       return gnorm * gnorm;
     };
     for (;;) {
-      if (nfuncs >= opt.snes_max_funcs) return 1;
+      if (!spec && nfuncs >= opt.snes_max_funcs) return 1;
       g = eval(lambda);
       if (std::isfinite(g)) break;
       if (lambda <= minlambda) return 1;
@@ -2036,8 +2170,10 @@ struct Solver {
       if (!jac_valid) op_jacobian(X, Fv);
       int its = 0;
       ls_ahead.armed = opt.ls_ahead && ksp_one_shot && opt.ksp_type == 2 && spmv_dots_fused() && opt.linesearch_type == 2;
-      ls_ahead.done = false;
+      ls_ahead.done = false; ls_ahead.spec_done = false; ls_ahead.spec_issued = false;
       ls_ahead.F = Fv; ls_ahead.X = i > 0 ? nullptr : X;
+      ls_ahead.spec = ls_ahead.armed && opt.ls_spec && rows_complete();
+      ls_ahead.Xv = X; ls_ahead.Wv = Wv; ls_ahead.Gv = Gv;
       const int kreason = ksp_solve(Fv, Yv, &its);
       ls_ahead.armed = false;
       ksp_one_shot = kreason > 0 && its == 1;
@@ -2139,6 +2275,7 @@ struct Solver {
       if (comm.active()) {  // every rank must take the same branch: worst reason wins
         double r = -(double)reason;
         HIP_CHECK(hipMemcpyAsync(sc.p + S_D2, &r, sizeof(double), hipMemcpyHostToDevice, stream));
+        pub_valid = false;
         comm.allreduce_max(sc.p + S_D2, 1, stream);
         HIP_CHECK(hipMemcpyAsync(&r, sc.p + S_D2, sizeof(double), hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
@@ -2274,9 +2411,26 @@ struct Solver {
       if (cond_id < 1 || cond_id > (int)bcs.size()) throw Error("set_data: bad boundary condition id");
       Condition &c = bcs[cond_id - 1];
       if (cnt > c.n) throw Error("set_data: size(data_1d) > nauxvar");
-      for (int i = 0; i < cnt; ++i) { c.value[i] = data[i]; h_bc_value[bc_pos_of_g[c.offset + i]] = data[i]; }
-      d_bc_value.upload(h_bc_value, stream);
-      HIP_CHECK(hipStreamSynchronize(stream));
+      std::memcpy(c.value.data(), data, (size_t)cnt * sizeof(double));
+      // The values go to the device through a pinned staging area (one region per condition) and are scattered there into the
+      // cell-grouped order the boundary kernel reads: no host loop over the entries, no wait for the stream (a time step's
+      // boundary values are typically set right before StepDT, which follows on the same stream).
+      if (!h_bc_stage) {
+        HIP_CHECK(hipHostMalloc(&h_bc_stage, std::max<size_t>(nb, 1) * sizeof(double), hipHostMallocDefault));
+        d_bc_stage.alloc(std::max(nb, 1));
+        d_bc_pos.upload(bc_pos_of_g, stream);
+        HIP_CHECK(hipEventCreateWithFlags(&bc_stage_ev, hipEventDisableTiming));
+        bc_stage_pending.assign(bcs.size(), 0);
+      }
+      if (bc_stage_pending[cond_id - 1]) {   // this region's previous copy may still be reading it
+        HIP_CHECK(hipEventSynchronize(bc_stage_ev));
+        std::fill(bc_stage_pending.begin(), bc_stage_pending.end(), 0);
+      }
+      std::memcpy(h_bc_stage + c.offset, data, (size_t)cnt * sizeof(double));
+      HIP_CHECK(hipMemcpyAsync(d_bc_stage.p + c.offset, h_bc_stage + c.offset, (size_t)cnt * sizeof(double), hipMemcpyHostToDevice, stream));
+      HIP_CHECK(hipEventRecord(bc_stage_ev, stream));
+      bc_stage_pending[cond_id - 1] = 1;
+      launch_scatter(cnt, d_bc_pos.p + c.offset, d_bc_stage.p + c.offset, d_bc_value.p, stream);
     } else if (auxvar_type == MPPGPU_AUXVAR_SS) {
       if (cond_id < 1 || cond_id > (int)sss.size()) throw Error("set_data: bad source-sink id");
       Condition &c = sss[cond_id - 1];
@@ -2792,6 +2946,8 @@ struct Solver {
     else if (key == "ell_assembly") opt.ell_assembly = num() != 0;
     else if (key == "ls_ahead") opt.ls_ahead = num() != 0;
     else if (key == "wide_xr") opt.wide_xr = num() != 0;
+    else if (key == "host_poll") opt.host_poll = num() != 0;
+    else if (key == "ls_spec") opt.ls_spec = num() != 0;
     else if (key == "spmv_tpw") opt.spmv_tpw = (int)num();
     else if (key == "soil_classes") { opt.soil_classes = num() != 0; soil_dirty = true; }
     else if (key == "level_geometry") { opt.level_geometry = num() != 0; soil_dirty = true; }
@@ -2818,6 +2974,7 @@ struct Solver {
       prof.enabled = m != 0;
       prof.mask = m == 2 ? (1u << KC_SPMV) : ~0u;
     }
+    else if (key == "profile_stride") { prof.flush(); prof.stride = std::max(1, (int)num()); }
     else throw Error("unknown option '" + key + "'");
   }
 
@@ -3222,10 +3379,13 @@ int mppgpu_reset_stats(mppgpu_handle h) {
   API_BEGIN(h)
   S.prof.reset();
   S.comm.n_allreduce = 0; S.comm.n_exchange = 0;
+  S.n_fetch = 0;
   API_END()
 }
-int mppgpu_get_comm_stats(mppgpu_handle h, long long *allreduces, long long *halo_exchanges, long long *chain_fallbacks) {
+int mppgpu_get_comm_stats(mppgpu_handle h, long long *allreduces, long long *halo_exchanges, long long *chain_fallbacks,
+                          long long *host_readbacks) {
   API_BEGIN(h)
+  if (host_readbacks) *host_readbacks = S.n_fetch;
   if (allreduces) *allreduces = S.comm.n_allreduce;
   if (halo_exchanges) *halo_exchanges = S.comm.n_exchange;
   if (chain_fallbacks) *chain_fallbacks = S.chain_fallbacks;

@@ -231,9 +231,9 @@ class SystemOfEquationsVSFM:
         self._chk(self.L.mppgpu_reset_stats(self.h))
 
     def comm_stats(self):
-        a, b, c = ct.c_longlong(), ct.c_longlong(), ct.c_longlong()
-        self._chk(self.L.mppgpu_get_comm_stats(self.h, ct.byref(a), ct.byref(b), ct.byref(c)))
-        return dict(allreduces=a.value, halo_exchanges=b.value, chain_fallbacks=c.value)
+        a, b, c, d = ct.c_longlong(), ct.c_longlong(), ct.c_longlong(), ct.c_longlong()
+        self._chk(self.L.mppgpu_get_comm_stats(self.h, ct.byref(a), ct.byref(b), ct.byref(c), ct.byref(d)))
+        return dict(allreduces=a.value, halo_exchanges=b.value, chain_fallbacks=c.value, host_readbacks=d.value)
 
     def pc_info(self):
         """how the ILU(0) triangular solves are applied (mppgpu_get_pc_info): path name, launches per application, box extents"""

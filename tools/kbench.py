@@ -27,9 +27,41 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--only", nargs="*", default=None, help="entries NAME[:VARIANT[:KEY=VAL,...]] instead of the default plan")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="mppgpu_set_option pairs before setup")
+    ap.add_argument("--satfunc", choices=["vg", "vg_m", "bc", "sbc_bz2", "sbc_bz3", "mixed"], default="vg",
+                    help="saturation function of every cell: van Genuchten m = 1/2 (the celia soil), van Genuchten m = 0.4 (general "
+                         "powers), Brooks-Corey, smoothed Brooks-Corey bz2 / bz3 (ELM's default), or vg / bc / sbc_bz3 mixed per column")
+    ap.add_argument("--density", choices=["constant", "tgdpb01", "ifc67"], default="tgdpb01")
+    ap.add_argument("--per-cell-soils", action="store_true",
+                    help="every cell its own (alpha, lambda, residual saturation): no soil classes, ELM-style soil maps")
+    ap.add_argument("--soil-classes", type=int, default=0, help="this many distinct soil tuples, assigned per cell at random")
     args = ap.parse_args()
     ncols = args.nx * args.ny
     prob = bench.build_problem(ncols, args.nz, 0, ncols)
+    import numpy as np
+    from mpp_amd import constants as C
+    n = prob.alpha.size
+    sf = {"vg": C.SAT_FUNC_VAN_GENUCHTEN, "vg_m": C.SAT_FUNC_VAN_GENUCHTEN, "bc": C.SAT_FUNC_BROOKS_COREY,
+          "sbc_bz2": C.SAT_FUNC_SMOOTHED_BROOKS_COREY_BZ2, "sbc_bz3": C.SAT_FUNC_SMOOTHED_BROOKS_COREY_BZ3}
+    if args.satfunc == "mixed":
+        kinds = np.array([C.SAT_FUNC_VAN_GENUCHTEN, C.SAT_FUNC_BROOKS_COREY, C.SAT_FUNC_SMOOTHED_BROOKS_COREY_BZ3], dtype=np.int32)
+        prob.satfunc_type = np.repeat(kinds[np.arange(ncols) % 3], args.nz).astype(np.int32)
+    else:
+        prob.satfunc_type = np.full(n, sf[args.satfunc], dtype=np.int32)
+    if args.satfunc == "vg_m":
+        prob.lam = np.full(n, 0.4)
+    prob.density_type = {"constant": C.DENSITY_CONSTANT, "tgdpb01": C.DENSITY_TGDPB01, "ifc67": C.DENSITY_IFC67}[args.density]
+    rng = np.random.default_rng(2024)
+    if args.per_cell_soils:
+        prob.alpha = prob.alpha * (1.0 + 0.05 * rng.random(n))
+        prob.sat_res = prob.sat_res * (1.0 + 0.05 * rng.random(n))
+        if args.satfunc != "vg":
+            prob.lam = prob.lam * (1.0 + 0.05 * rng.random(n))
+    elif args.soil_classes > 1:
+        k = args.soil_classes
+        ta, tr = 1.0 + 0.05 * rng.random(k), 1.0 + 0.05 * rng.random(k)
+        cls = rng.integers(0, k, n)
+        prob.alpha = prob.alpha * ta[cls]
+        prob.sat_res = prob.sat_res * tr[cls]
     opts = {"ksp_type": "bcgs", "pc_type": "bjacobi"}
     opts.update(kv.split("=", 1) for kv in args.opt)
     mpp = P.to_gpu(prob, opts)
@@ -49,7 +81,9 @@ def main():
         print("%-14s v%-2d %-18s %9.4f ms  %9.1f GB/s  %5.1f%%" % (name, var, ",".join("%s=%s" % i for i in kv.items()), ms, gbs, gbs / 80.0),
               flush=True)
     if args.out:
-        json.dump({"grid": [args.nx, args.ny, args.nz], "rows": rows}, open(args.out, "w"), indent=1)
+        json.dump({"grid": [args.nx, args.ny, args.nz], "satfunc": args.satfunc, "density": args.density,
+                   "per_cell_soils": args.per_cell_soils, "soil_classes": args.soil_classes, "converged_first_step": bool(conv),
+                   "rows": rows}, open(args.out, "w"), indent=1)
 
 
 if __name__ == "__main__":
