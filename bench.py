@@ -37,6 +37,20 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+EVENT_STRIDE = 4       # every 4th launch of a kernel class is bracketed by HIP events (a pair costs ~10 us of queue time)
+
+
+def kernel_source_hash():
+    """sha256 (16 hex digits) of the kernel sources this run was built from: profiles/kernel_traffic.json is quoted only when
+    its PMC passes were made with the same sources (tools/make_traffic.py)"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "mpp_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def perm_multipliers(ncols_global):
@@ -401,6 +415,7 @@ def main():
     if dog and args.warmup > 0:
         dog.done()
         dog = None
+    soe.SetOption("profile_stride", EVENT_STRIDE)
     soe.SetOption("profile", 1 if (args.profile == "all" or (args.profile == "auto" and world == 1)) else 2)
     soe.reset_stats()
     c0 = soe.counters()
@@ -419,6 +434,7 @@ def main():
     newton = c1["newton"] - c0["newton"]
     linear = c1["linear"] - c0["linear"]
     comm = soe.comm_stats()
+    layout = soe.assembly_info()
 
     stats = {k: soe.kernel_stats(k) for k in ("spmv", "pc_apply", "pc_setup", "residual", "jacobian", "vec", "reduce")}
     soe.SetOption("profile", 0)
@@ -434,32 +450,53 @@ def main():
         n_local = ncols_local * args.nz
         achieved = sp["bytes_per_launch"] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         compact = n_local >= (1 << 21) and args.spmv_variant < 0
-        traffic, traffic_src = None, None
-        tfile = os.path.join(ROOT, "profiles", "spmv_traffic.json")
+        # HBM bytes the kernels really move: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, kept in
+        # profiles/kernel_traffic.json with the hash of the kernel sources they were made with -- quoted only for the same
+        # sources at the same size, never replayed for other code
+        traffic, traffic_src, moved, stale = None, None, {}, None
+        tfile = os.path.join(ROOT, "profiles", "kernel_traffic.json")
         if os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile))
-                if tj.get("cells_per_gpu") == n_local:
-                    traffic = tj.get("hbm_bytes_per_launch")
-                    traffic_src = "profiles/spmv_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel at this size)"
-            except Exception:
-                traffic = None
+                if tj.get("cells_per_gpu") != n_local:
+                    stale = "measured at %s cells per GPU, this run has %d" % (tj.get("cells_per_gpu"), n_local)
+                elif tj.get("kernel_source_sha16") != kernel_source_hash():
+                    stale = "kernel sources changed since the PMC passes (%s then, %s now)" % (tj.get("kernel_source_sha16"), kernel_source_hash())
+                else:
+                    moved = tj.get("classes", {})
+                    traffic = moved.get("spmv", {}).get("hbm_bytes_per_launch")
+                    traffic_src = "profiles/kernel_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, %s; kernel sources %s)" % (
+                        tj.get("run"), tj.get("kernel_source_sha16"))
+            except Exception as e:
+                stale = "unreadable: %r" % (e,)
         kernels = {}
         for k, s in stats.items():
             if s["launches"]:
                 ms = s["total_ms"] / s["launches"]
-                kernels[k] = {"launches": s["launches"], "avg_ms": round(ms, 5),
-                              "share_of_step_time": round(s["total_ms"] * 1e-3 / elapsed, 4)}
+                kernels[k] = {"launches_timed": s["launches"], "avg_ms": round(ms, 5),
+                              "share_of_step_time": round(s["total_ms"] * EVENT_STRIDE * 1e-3 / elapsed, 4)}
                 if s["bytes_per_launch"] > 0:
-                    # SURVEY 8(d)'s algorithmic byte counts / time: the assembly passes move fewer bytes than that (soil
-                    # classes, per-level geometry: DESIGN.md section 4), so this figure may exceed the HBM peak for them
-                    kernels[k]["GBps_algorithmic"] = round(s["bytes_per_launch"] / (ms * 1e-3) / 1e9, 1)
+                    # SURVEY 8(d)'s algorithmic byte count / time.  The assembly passes move fewer bytes than SURVEY counts
+                    # (soil classes, per-level geometry, computed row slots: DESIGN.md section 3), so this rate can exceed
+                    # the HBM peak for them: structure_exploited says so, GBps_moved is the physical rate
+                    alg = s["bytes_per_launch"] / (ms * 1e-3) / 1e9
+                    kernels[k]["GBps_algorithmic"] = round(alg, 1)
+                    mv = moved.get(k)
+                    if mv:
+                        kernels[k]["bytes_moved"] = round(mv["hbm_bytes_per_launch"])
+                        kernels[k]["bytes_algorithmic"] = round(s["bytes_per_launch"])
+                        kernels[k]["GBps_moved"] = round(mv["hbm_bytes_per_launch"] / (ms * 1e-3) / 1e9, 1)
+                        kernels[k]["moved_kernels"] = sorted(mv["kernels"])
+                    if alg > HBM_PEAK_GBS or (mv and mv["hbm_bytes_per_launch"] < 0.9 * s["bytes_per_launch"]):
+                        kernels[k]["structure_exploited"] = True
         roof = {"kernel": "csr_spmv_fp64 (k_spmv_c: CSR values + compact 16-bit index, see DESIGN.md section 4)"
                           if compact else "csr_spmv_fp64",
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "achieved_is": "algorithmic CSR bytes (12 nnz + 20 N + 4, SURVEY 8d) / HIP-event average launch time",
-                "bytes_per_launch": sp["bytes_per_launch"], "avg_launch_ms": round(avg_ms, 5), "launches": sp["launches"]}
+                "bytes_per_launch": sp["bytes_per_launch"], "avg_launch_ms": round(avg_ms, 5), "launches_timed": sp["launches"]}
+        if stale:
+            roof["traffic_refused"] = stale
         if traffic:
             phys = traffic / (avg_ms * 1e-3) / 1e9
             roof["achieved_physical"] = round(phys, 1)        # bytes the kernel really moves (16-bit index) / the same time
@@ -478,11 +515,17 @@ def main():
             "config": {"workload": "VSFM celia-extruded %dx%d columns x %d layers, %s+%s, per-column perm multiplier"
                                    % (args.nx, args.ny, args.nz, args.ksp, args.pc),
                        "cells": n_global, "cells_per_gpu": n_local, "dt_s": prob.dt,
+                       "soil_classes": layout["soil_classes"], "level_geometry": bool(layout["level_geometry"]),
+                       "level_porosity_volume": bool(layout["level_porosity_volume"]),
+                       "complete_row_march": bool(layout["complete_rows"]),
                        "parallelism": "columns sharded over %d GPU(s), RCCL all-reduce of Krylov/Newton scalars" % world},
             "newton_iterations": newton, "linear_iterations": linear, "setup_s": round(t_setup, 2),
             "time_step_cuts": c1["time_cuts"] - c0["time_cuts"],
             "accepted_substeps_s": substeps[args.warmup:],
             "allreduces_per_newton_iteration": round(comm["allreduces"] / max(newton, 1), 2) if world > 1 else 0.0,
+            "host_readbacks_per_newton_iteration": round(comm["host_readbacks"] / max(newton, 1), 2),
+            "speculative_trial_points_discarded": layout["speculative_trials_discarded"],
+            "event_sampling": "every %d-th launch of a kernel class is timed with HIP events on the solver's stream" % EVENT_STRIDE,
             "roofline": roof,
             "kernels": kernels,
         }

@@ -32,10 +32,11 @@ module mppgpu_mod
         mppgpu_set_source_sink_auxvar, mppgpu_thermal_set_soils, mppgpu_thermal_set_soln_prev_clm, &
         mppgpu_thermal_pre_step_dt, mppgpu_thermal_step_dt, mppgpu_thermal_get_soln, mppgpu_thermal_compute_rhs, &
         mppgpu_thermal_compute_operators, mppgpu_th_add_condition, mppgpu_th_set_soils, mppgpu_kernel_stats, &
-        mppgpu_reset_stats, mppgpu_get_comm_stats, mppgpu_get_pc_info, mppgpu_bench_kernel, &
+        mppgpu_reset_stats, mppgpu_get_comm_stats, mppgpu_get_pc_info, mppgpu_get_assembly_info, mppgpu_bench_kernel, &
         mppgpu_comm_get_unique_id, mppgpu_comm_init, &
         mppgpu_comm_init_local, mppgpu_set_ghost_cells, mppgpu_set_halo, &
-        mppgpu_pre_step_dt, mppgpu_post_step_dt
+        mppgpu_pre_step_dt, mppgpu_post_step_dt, &
+        mppgpu_host_density, mppgpu_host_internal_energy_enthalpy, mppgpu_host_sat_relperm
 
   interface
      integer(c_int) function mppgpu_create(device_id, h) bind(C, name='mppgpu_create')
@@ -318,6 +319,12 @@ module mppgpu_mod
        type(c_ptr), value :: h
        integer(c_long_long) :: allreduces, halo_exchanges, chain_fallbacks, host_readbacks
      end function
+     integer(c_int) function mppgpu_get_assembly_info(h, n, info) bind(C, name='mppgpu_get_assembly_info')
+       import :: c_int, c_ptr
+       type(c_ptr), value :: h
+       integer(c_int), value :: n
+       integer(c_int) :: info(*)
+     end function
      integer(c_int) function mppgpu_get_pc_info(h, path, launches, box_extents) bind(C, name='mppgpu_get_pc_info')
        import :: c_int, c_ptr
        type(c_ptr), value :: h
@@ -329,6 +336,26 @@ module mppgpu_mod
        character(kind=c_char) :: kernel(*)
        integer(c_int), value :: variant, reps
        real(c_double) :: avg_ms, bytes
+     end function
+     ! the constitutive laws on the host (what a driver calls where the reference's drivers call Density,
+     ! InternalEnergyAndEnthalpy, SatFunc_PressToSat / _PressToRelPerm directly, e.g. th_mms_problem.F90:1262-1452)
+     integer(c_int) function mppgpu_host_density(density_type, n, p, t_K, den, dden_dp, dden_dt) bind(C, name='mppgpu_host_density')
+       import :: c_int, c_double
+       integer(c_int), value :: density_type, n
+       real(c_double) :: p(*), t_K(*), den(*), dden_dp(*), dden_dt(*)
+     end function
+     integer(c_int) function mppgpu_host_internal_energy_enthalpy(ie_type, n, p, t_K, den, dden_dt, dden_dp, u, h, du_dt, dh_dt, &
+          du_dp, dh_dp) bind(C, name='mppgpu_host_internal_energy_enthalpy')
+       import :: c_int, c_double
+       integer(c_int), value :: ie_type, n
+       real(c_double) :: p(*), t_K(*), den(*), dden_dt(*), dden_dp(*), u(*), h(*), du_dt(*), dh_dt(*), du_dp(*), dh_dp(*)
+     end function
+     integer(c_int) function mppgpu_host_sat_relperm(n, satfunc_type, p, sat_res, alpha, lambda, sat, dsat_dp, kr, dkr_dp) &
+          bind(C, name='mppgpu_host_sat_relperm')
+       import :: c_int, c_double
+       integer(c_int), value :: n
+       integer(c_int) :: satfunc_type(*)
+       real(c_double) :: p(*), sat_res(*), alpha(*), lambda(*), sat(*), dsat_dp(*), kr(*), dkr_dp(*)
      end function
      integer(c_int) function mppgpu_comm_get_unique_id(id128) bind(C, name='mppgpu_comm_get_unique_id')
        import :: c_int, c_char

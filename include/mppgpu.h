@@ -311,9 +311,33 @@ int mppgpu_get_comm_stats(mppgpu_handle h, long long *allreduces, long long *hal
  * launches = kernel launches per application of the preconditioner; box_extents[0..2] = cells per box in the caller's
  * fastest, second and third direction (path 3; zeros otherwise).  Any output pointer may be NULL. */
 int mppgpu_get_pc_info(mppgpu_handle h, int *path, int *launches, int *box_extents);
+/* which data layout and kernels the assembly and Krylov passes of this handle use (known after the first time step; no
+ * counterpart in the reference): info[0] soil classes in use by the column march (0: per-cell soil arrays are streamed),
+ * [1] per-level connection geometry (1 / 0), [2] per-level porosity x volume, [3] complete-row column march (boundary fluxes,
+ * norms, column LU and forward elimination inside the assembly pass), [4] column segments per thread-block row, [5] SpMV
+ * variant, [6] column solve through LDS, [7] speculative line-search trial points that had to be discarded since
+ * mppgpu_setup.  n = entries of info the caller provides (at most 8 are written). */
+int mppgpu_get_assembly_info(mppgpu_handle h, int n, int *info);
 /* device-resident micro-benchmark of one kernel class on the current state: `reps` launches, average ms */
 int mppgpu_bench_kernel(mppgpu_handle h, const char *name, int variant, int reps, double *avg_ms,
                         double *algorithmic_bytes);
+
+/* ------------------------------------------------------------------------------------------------
+ * The constitutive laws evaluated on the HOST, array by array -- for drivers that need them to build their inputs, as the
+ * reference's drivers do when they call the EOS and saturation-function modules directly: th_mms_problem.F90:1262-1452
+ * forms its manufactured mass and heat sources from Density (src/mpp/util/EOSWaterMod.F90:38-77), InternalEnergyAndEnthalpy
+ * (:589-707), SatFunc_PressToSat / SatFunc_PressToRelPerm (src/mpp/util/SaturationFunction.F90:564-650).  No handle, no GPU,
+ * not part of any solve; same arithmetic as the device kernels (mpp_amd/csrc/physics.hpp, th_physics.hpp).  Outputs may be
+ * NULL.  Units as in the reference: density kmol/m^3, energies J/kmol, temperatures K.  Errors: mppgpu_last_error(NULL).
+ * ---------------------------------------------------------------------------------------------- */
+int mppgpu_host_density(int density_type, int n, const double *p, const double *t_K, double *den, double *dden_dp, double *dden_dt);
+/* den, dden_dt, dden_dp in kg/m^3 (the reference passes den * FMWH2O: ThermalEnthalpySoilAuxType.F90:262-266) */
+int mppgpu_host_internal_energy_enthalpy(int ie_type, int n, const double *p, const double *t_K, const double *den,
+                                         const double *dden_dt, const double *dden_dp, double *u, double *h, double *du_dt,
+                                         double *dh_dt, double *du_dp, double *dh_dp);
+/* satfunc_type: MPPGPU_SAT_FUNC_* per entry; lambda = vg_m or bc_lambda */
+int mppgpu_host_sat_relperm(int n, const int *satfunc_type, const double *p, const double *sat_res, const double *alpha,
+                            const double *lambda, double *sat, double *dsat_dp, double *kr, double *dkr_dp);
 
 /* ------------------------------------------------------------------------------------------------
  * multi-GPU: one handle per rank, columns sharded across ranks, RCCL all-reduce for the global

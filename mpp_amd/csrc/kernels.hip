@@ -999,10 +999,13 @@ __global__ __launch_bounds__(kBlock) void k_ell_upper(int n, int Kdyn, const int
 
 // chained triangular solve (see ChainArgs): flags instead of kernel boundaries.  Values other workgroups wrote during this
 // launch are read and written with agent-scope atomics (they bypass the non-coherent caches).
-// Liveness does not rest on the order in which the hardware dispatches workgroups: a workgroup takes a TICKET when it starts
-// running (one returning atomic add) and owns the tiles [ticket * tpb, (ticket + 1) * tpb), in ascending order.  A tile
-// depends on lower-numbered tiles only, tickets are handed out in ascending order to workgroups that are already running,
-// so the workgroup that owns the lowest unfinished tile is always resident and never waits for a tile that nobody runs.
+// Two ways of handing out tiles.  a.ticket != nullptr: a workgroup takes a TICKET when it starts running (one returning
+// atomic add) and owns the tiles [ticket * tpb, (ticket + 1) * tpb), in ascending order; a tile depends on lower-numbered
+// tiles only and tickets go in ascending order to workgroups that are already running, so the workgroup that owns the lowest
+// unfinished tile is always resident: liveness does not rest on the dispatch order.  a.ticket == nullptr: tile = blockIdx.x;
+// the lowest unfinished tile is resident only as long as the hardware dispatches workgroups in index order, which it does on
+// this chip but HIP does not promise -- this mode is faster (no atomic in front of a tile's loads) and is what option
+// ilu_chain selects unless ilu_chain_tickets is set; the spin budget and the host's per-level redo are its safety net.
 // The counter is never reset: launch number L of a chain hands out [L * nblocks, (L + 1) * nblocks), ticket_base = L * nblocks
 // (unsigned arithmetic, wrap-around included).  A wait still has a spin budget; exhausting it flags the application,
 // which the host then redoes with per-level launches (Solver::op_pc_apply).

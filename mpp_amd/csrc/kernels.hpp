@@ -191,9 +191,11 @@ void launch_ilu_factor_program(const long long *ptr, const int *prog, const int 
 void launch_ilu_repack(long long total, const int *slot, const double *lu, double *out, hipStream_t stream);  // out[e] = slot[e] >= 0 ? lu[slot[e]] : 0
 // The same solves as ONE launch per triangle: a tile is <= 256 consecutive rows of one level; its workgroup waits (spinning
 // on per-tile flags) only for the tiles that hold its rows' dependencies, so the tail of a level overlaps the head of the
-// next and no per-level launch gap is paid.  Workgroups take their tiles by ticket (see k_ell_chain), so the lowest
-// unfinished tile always belongs to a running workgroup whatever the dispatch order.  A wait that exceeds its spin
-// budget sets sc[S_ERR]; the host checks it behind every chained application and redoes that application per level.
+// next and no per-level launch gap is paid.  With `ticket` set, workgroups take their tiles by ticket (see k_ell_chain), so
+// the lowest unfinished tile always belongs to a running workgroup whatever the dispatch order; with ticket == nullptr
+// (option ilu_chain_tickets = 0) tile = blockIdx.x and progress relies on the hardware dispatching workgroups in index
+// order -- observed, not promised by HIP; the whole mode is therefore opt-in (option ilu_chain).  A wait that exceeds its
+// spin budget sets sc[S_ERR]; the host checks it behind every chained application and redoes that application per level.
 struct ChainArgs {
   int n, K;                        // rows; ELL width
   const int *col;                  // [K][n] positions (in this triangle's level order) of the dependencies; self = padding

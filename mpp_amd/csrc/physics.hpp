@@ -30,12 +30,22 @@ enum SatFunc : int { kSatVG = 0, kSatBC = 1, kSatSBC = 2,
 enum DenType : int { kDenConstant = 1, kDenTGDPB01 = 2, kDenIFC67 = 3 };
 enum CondType : int { kCondMassFlux = 504, kCondDirichlet = 505, kCondSeepage = 509 };
 
+// IFC-67 density: everything that depends on the temperature alone.  In the VSFM the temperature is one number per problem
+// (298.15 K unless set; RichardsODEPressureAuxType.F90:92), so five of the formulation's six real powers -- theta^18, theta^-6,
+// theta^11, theta^19, (a6 - theta)^9 -- and the terms built from them are constants of the run: evaluated once on the host
+// (make_eos), which leaves the march one real power per cell (zz^(-5/17)) instead of six.
+struct Ifc67T {
+  double theta, theta20, yy, x_t /* a3 yy^2 */, a4theta, u2, u7, t_poly /* theta (aa13 + aa14 theta) */, t_u8 /* u8 (a6 - theta) */,
+         t_u4 /* aa16 u4 */, c21 /* 3 aa21 (a12 - theta) */, c21d /* 6 aa21 (a12 - theta) */;
+};
+
 // Problem-wide constants of the equation of state (temperature is uniform, 298.15 K unless set).
 struct EosParams {
   int density_type;
   double dent;    // TGDPB01: a5*(1 - (t+a1)^2 (t+a2)/a3/(t+a4))
   double kcoef;   // TGDPB01: k0 + k1 t + k2 t^2
   double t_C;     // temperature in degC (IFC67)
+  Ifc67T ifc;     // IFC67: the temperature-only part
 };
 
 // per-cell soil parameters as the kernels hold them in registers
@@ -67,46 +77,59 @@ __host__ __device__ inline EosParams make_eos(int density_type, double t_K) {
   e.dent = a5 * (1.0 - sq * (t_c + a2) / a3 / (t_c + a4));
   e.kcoef = k0 + k1 * t_c + k2 * (t_c * t_c);
   e.t_C = t_c;
+  {  // IFC-67, temperature-only terms (EOSWaterMod.F90:228-275; same names)
+    const double aa13 = 1.522411790e-3, aa14 = 2.284279054e-2, aa15 = 2.421647003e02, aa16 = 1.269716088e-10, aa20 = 1.293441934e01,
+                 aa21 = 1.308119072e-5;
+    const double ia1 = 8.438375405e-1, ia2 = 5.362162162e-4, ia3 = 1.720000000e00, ia4 = 7.342278489e-2, ia6 = 6.537154300e-1,
+                 ia7 = 1.150000000e-6, ia8 = 1.510800000e-5, ia9 = 1.418800000e-1, ia12 = 2.040000000e-1;
+    const double tc1 = 647.3;
+    Ifc67T &f = e.ifc;
+    f.theta = (t_c + 273.15) * (1.0 / tc1);
+    const double theta2x = f.theta * f.theta;
+    const double theta18 = pow(f.theta, 18.0);
+    f.theta20 = theta18 * theta2x;
+    f.yy = 1.0 - ia1 * theta2x - ia2 * pow(f.theta, -6.0);
+    f.x_t = ia3 * f.yy * f.yy;
+    f.a4theta = ia4 * f.theta;
+    f.u2 = 1.0 / (ia8 + pow(f.theta, 11.0));
+    const double u4 = 1.0 / (ia7 + theta18 * f.theta);
+    f.u7 = aa20 * theta18 * (ia9 + theta2x);
+    const double u8 = aa15 * pow(ia6 - f.theta, 9.0);
+    f.t_poly = f.theta * (aa13 + aa14 * f.theta);
+    f.t_u8 = u8 * (ia6 - f.theta);
+    f.t_u4 = aa16 * u4;
+    f.c21 = 3.0 * aa21 * (ia12 - f.theta);
+    f.c21d = 6.0 * aa21 * (ia12 - f.theta);
+  }
   return e;
 }
 
-// IFC-67 liquid water density [kmol/m3] and d/dp (EOSWaterMod.F90:181-344)
-__host__ __device__ inline void density_ifc67(double t, double p, double &dwmol, double &dwp) {
-  const double aa11 = 7.982692717e00, aa12 = -2.616571843e-2, aa13 = 1.522411790e-3, aa14 = 2.284279054e-2,
-               aa15 = 2.421647003e02, aa16 = 1.269716088e-10, aa17 = 2.074838328e-7, aa18 = 2.174020350e-8,
-               aa19 = 1.105710498e-9, aa20 = 1.293441934e01, aa21 = 1.308119072e-5, aa22 = 6.047626338e-14;
-  const double a1 = 8.438375405e-1, a2 = 5.362162162e-4, a3 = 1.720000000e00, a4 = 7.342278489e-2;
-  const double a5 = 4.975858870e-2, a6 = 6.537154300e-1, a7 = 1.150000000e-6, a8 = 1.510800000e-5;
-  const double a9 = 1.418800000e-1, a10 = 7.002753165e00, a11 = 2.995284926e-4, a12 = 2.040000000e-1;
-  const double tc1 = 647.3, pc1 = 22.064e6, vc1 = 0.00317;
-  double utc1 = 1.0 / tc1, upc1 = 1.0 / pc1, vc1mol = vc1 * kFMWH2O;
-  double theta = (t + 273.15) * utc1;
-  double theta2x = theta * theta;
-  double theta18 = pow(theta, 18.0);
-  double theta20 = theta18 * theta2x;
-  double beta = p * upc1;
-  double beta2x = beta * beta;
-  double yy = 1.0 - a1 * theta2x - a2 * pow(theta, -6.0);
-  double xx = a3 * yy * yy - 2.0 * (a4 * theta - a5 * beta);
-  xx = sqrt(xx);  // xx <= 0 only near the critical point; NaN propagates to the norm and the step fails
-  double zz = yy + xx;
-  double u0 = -5.0 / 17.0;
-  double u1 = aa11 * a5 * pow(zz, u0);
-  double u2 = 1.0 / (a8 + pow(theta, 11.0));
-  double u3 = aa17 + (2.0 * aa18 + 3.0 * aa19 * beta) * beta;
-  double u4 = 1.0 / (a7 + theta18 * theta);
-  double u5 = pow(a10 + beta, -4.0);
-  double u6 = a11 - 3.0 * u5;
-  double u7 = aa20 * theta18 * (a9 + theta2x);
-  double u8 = aa15 * pow(a6 - theta, 9.0);
-  double vr = u1 + aa12 + theta * (aa13 + aa14 * theta) + u8 * (a6 - theta) + aa16 * u4 - u2 * u3 - u6 * u7 +
-              (3.0 * aa21 * (a12 - theta) + 4.0 * aa22 * beta / theta20) * beta2x;
+// IFC-67 liquid water density [kmol/m3] and d/dp at the problem's temperature (EOSWaterMod.F90:181-344 with the
+// temperature-only terms taken from Ifc67T; same summation order as the formulation)
+__host__ __device__ inline void density_ifc67_at(const Ifc67T &f, double p, double &dwmol, double &dwp) {
+  const double aa11 = 7.982692717e00, aa12 = -2.616571843e-2, aa17 = 2.074838328e-7, aa18 = 2.174020350e-8,
+               aa19 = 1.105710498e-9, aa22 = 6.047626338e-14;
+  const double a5 = 4.975858870e-2, a10 = 7.002753165e00, a11 = 2.995284926e-4;
+  const double pc1 = 22.064e6, vc1 = 0.00317;
+  const double upc1 = 1.0 / pc1, vc1mol = vc1 * kFMWH2O;
+  const double beta = p * upc1;
+  const double beta2x = beta * beta;
+  double xx = f.x_t - 2.0 * (f.a4theta - a5 * beta);
+  xx = sqrt(xx);
+  const double zz = f.yy + xx;
+  const double u0 = -5.0 / 17.0;
+  const double u1 = aa11 * a5 * pow(zz, u0);
+  const double u3 = aa17 + (2.0 * aa18 + 3.0 * aa19 * beta) * beta;
+  const double ab = a10 + beta, ab2 = ab * ab;
+  const double u5 = 1.0 / (ab2 * ab2);           // (a10 + beta)^(-4)
+  const double u6 = a11 - 3.0 * u5;
+  const double vr = u1 + aa12 + f.t_poly + f.t_u8 + f.t_u4 - f.u2 * u3 - u6 * f.u7 + (f.c21 + 4.0 * aa22 * beta / f.theta20) * beta2x;
   dwmol = 1.0 / (vr * vc1mol);
-  double zpp = a5 / xx;
-  double u9 = u0 * u1 / zz;
-  double vrpp = u9 * zpp - u2 * (2.0 * aa18 + 6.0 * aa19 * beta) - 12.0 * u7 * u5 / (a10 + beta) +
-                (6.0 * aa21 * (a12 - theta) + 12.0 * aa22 * beta / theta20) * beta;
-  double cnv = -1.0 / (vc1mol * vr * vr);
+  const double zpp = a5 / xx;
+  const double u9 = u0 * u1 / zz;
+  const double vrpp = u9 * zpp - f.u2 * (2.0 * aa18 + 6.0 * aa19 * beta) - 12.0 * f.u7 * u5 / ab +
+                      (f.c21d + 12.0 * aa22 * beta / f.theta20) * beta;
+  const double cnv = -1.0 / (vc1mol * vr * vr);
   dwp = cnv * vrpp * upc1;
 }
 
@@ -115,7 +138,7 @@ __host__ __device__ inline void density_ifc67(double t, double p, double &dwmol,
 template <int DEN_T = -1>
 __host__ __device__ inline void density(const EosParams &e, double p, double &den, double &dden) {
   if (DEN_T == 1) {
-    density_ifc67(e.t_C, p, den, dden);
+    density_ifc67_at(e.ifc, p, den, dden);
     return;
   }
   if (e.density_type == kDenTGDPB01) {
@@ -134,10 +157,18 @@ __host__ __device__ inline void density(const EosParams &e, double p, double &de
     den = kDenH2O * kInvFMWH2O;
     dden = 0.0;
   } else if (DEN_T == -1) {
-    density_ifc67(e.t_C, p, den, dden);
+    density_ifc67_at(e.ifc, p, den, dden);
   } else {
     den = dden = 0.0;  // unreachable: DEN_T == 0 promises constant or TGDPB01
   }
+}
+
+// Brooks-Corey relative permeability kr = Se^(2.5 + 2/lambda) on the branch where Se = (alpha pc)^(-lambda)
+// (SaturationFunction.F90:960-975, 1100-1112): there Se^(2/lambda) = (alpha pc)^(-2), so the second real power of the
+// reference is two squares, a square root and a division -- ~60 instructions instead of the ~250 of a pow(), within a
+// few ulp of pow(Se, 2.5 + 2/lambda) (Se itself carries the rounding of the first power either way).
+__host__ __device__ inline double bc_relperm(double Se, double pc_alpha) {
+  return (Se * Se) * sqrt(Se) / (pc_alpha * pc_alpha);
 }
 
 // SatFunc_PressToSat + SatFunc_PressToRelPerm (Mualem) for one pressure; shares the common powers.
@@ -184,12 +215,16 @@ __host__ __device__ inline void sat_relperm(int sat_func_rt, const Soil &s, doub
         const double AA = pc_alpha_n / one_plus;
         const double AAm = pow(AA, mm);
         const double BB = 1.0 - AAm;
-        kr = sqrt(Se) * BB * BB;
+        const double q = sqrt(Se);
+        kr = q * BB * BB;
         if (DERIV) {
           const double dSe_dpc = -mm * nn * Se * AA / pc;
           dsat = (1.0 - sat_res) * dSe_dpc;
-          const double p1 = pow(Se, 1.0 / mm - 0.5);
-          const double p2 = pow(AA, mm - 1.0);
+          // Two of the reference's five real powers are quotients of values already at hand (a pow() is ~250 instructions
+          // here, a division 19): Se^(1/m - 1/2) = Se^(1/m) / sqrt(Se) with Se^(1/m) = 1 / (1 + (alpha pc)^n), and
+          // AA^(m - 1) = AA^m / AA.  Within a few ulp of the pow() results (SaturationFunction.F90:836-846 as written).
+          const double p1 = 1.0 / (one_plus * q);
+          const double p2 = AAm / AA;
           const double dkr_dSe = 0.5 * kr / Se + 2.0 * p1 * p2 * BB;
           dkr = dkr_dSe * dSe_dpc;
         }
@@ -205,7 +240,7 @@ __host__ __device__ inline void sat_relperm(int sat_func_rt, const Soil &s, doub
       const double Se = pow(pc_alpha, -lambda);
       sat = sat_res + (1.0 - sat_res) * Se;
       const double ex = 2.5 + 2.0 / lambda;
-      kr = pow(Se, ex);
+      kr = bc_relperm(Se, pc_alpha);
       if (DERIV) {
         const double dSe_dpc = -lambda * Se / pc;
         dsat = (1.0 - sat_res) * dSe_dpc;
@@ -221,9 +256,10 @@ __host__ __device__ inline void sat_relperm(int sat_func_rt, const Soil &s, doub
     const double lambda = s.m;
     const double ex = 2.5 + 2.0 / lambda;
     if (pc <= s.pu) {
-      const double Se = pow(-alpha * pc, -lambda);
+      const double pc_alpha = -alpha * pc;
+      const double Se = pow(pc_alpha, -lambda);
       sat = sat_res + (1.0 - sat_res) * Se;
-      kr = pow(Se, ex);
+      kr = bc_relperm(Se, pc_alpha);
       if (DERIV) {
         const double dSe_dpc = -lambda * Se / pc;
         dsat = (1.0 - sat_res) * dSe_dpc;

@@ -178,20 +178,23 @@ struct Options {
   int nseg = 0;            // column segments per thread block row (0 = auto)
   bool fused_assembly = true;  // F and J of a line-search trial point in one kernel ...
   bool track_mass_exchange = false;  // accumulate VAR_LATERAL_MASS_EXCHANGED / VAR_BC_MASS_EXCHANGED after every sub-step
-  bool ilu_graph = true;       // replay the level launches of the ILU(0) triangular solves from a hipGraph
+  bool ilu_graph = true;       // replay the level launches of the ILU(0) triangular solves from hipGraphs ...
+  int ilu_graph_nodes = 128;   // ... of at most this many kernel nodes each (Solver::run_graph)
   bool fused_ls_dots = true;   // line search: ||Y||, F.(J Y), ||X|| reduced inside the SpMV (compact-index kernels)
   bool fused_rows = true;      // column march with the boundary fluxes folded in: complete rows -> ||F||, ||X|| and the
                                // column LU come out of the assembly pass (see Solver::rows_complete)
   bool defer_test0 = true;     // bcgs: iteration 0's convergence test is made when the first iteration's scalars come back
   bool ell_assembly = true;    // general assembly on the ELL copy of the incidence lists (k_flux_rows_ell)
-  int ilu_chain = 1;           // ILU(0) solves: one launch per triangle, tiles chained by flags (1: where it pays, 2: always;
-                               // 0: one launch per level)
+  int ilu_chain = 0;           // ILU(0) solves: 0 one launch per level (graph replay; the default), 1 / 2 one launch per triangle with
+                               // tiles chained by flags (1: where it pays, 2: always).  Opt-in: without ilu_chain_tickets the chain's
+                               // progress relies on workgroups being dispatched in index order, which HIP does not promise
   bool th_fused_dots = true;   // coupled TH, bjacobi: the Krylov dot products of M^{-1} r come out of the block column solve
   int ilu_box = 1;             // ILU(0) solves box by box when the pattern is a structured grid in natural ordering (BoxGrid); 0: never, 2: or fail
   bool ilu_box_factor = true;  // ... and the numeric factorisation too (extents other than 2); false: by the elimination program of the general path
   int ilu_box_len = 0;         // box extent along the fastest direction (0: 64 from 2^25 rows, else 32)
-  bool ilu_chain_tickets = false;  // chained ILU(0): tiles handed out by an atomic ticket instead of in dispatch order (kernels.hpp)
-  unsigned ilu_chain_spins = 1u << 22;   // polls (~0.4 us apart) before a chained wait gives up and the apply is redone per level
+  bool ilu_chain_tickets = false;  // chained ILU(0): tiles handed out by an atomic ticket instead of in dispatch order (kernels.hpp):
+                                   // liveness then does not depend on the dispatch order, at +50-75 % per application
+  unsigned ilu_chain_spins = 1u << 16;   // polls (~0.4 us apart: ~26 ms) before a chained wait gives up and the apply is redone per level
   bool ls_ahead = true;        // the line search's first reductions ride behind the Krylov solver's last update
   bool ls_spec = true;         // ... and the search's first trial point (the full step) is evaluated there too (LsAhead::spec)
   bool wide_xr = true;         // BiCGStab update kernel on a one-pair-per-lane grid (large vectors)

@@ -19,6 +19,7 @@
 
 #include "../../include/mppgpu.h"
 #include "runtime.hpp"
+#include "th_physics.hpp"
 
 namespace mpp {
 
@@ -243,8 +244,19 @@ struct Solver {
   } chainL, chainU;
   static constexpr int kChainDeps = 8;
   unsigned chain_epoch = 0;
-  hipGraph_t ilu_graph = nullptr;
-  hipGraphExec_t ilu_graph_exec = nullptr;
+  // A fixed sequence of launches replayed from hipGraphs of at most opt.ilu_graph_nodes kernel nodes each (run_graph)
+  struct GraphSeq {
+    std::vector<hipGraph_t> graphs;
+    std::vector<hipGraphExec_t> execs;
+    void destroy() {
+      for (auto e : execs) (void)hipGraphExecDestroy(e);
+      for (auto g : graphs) (void)hipGraphDestroy(g);
+      execs.clear(); graphs.clear();
+    }
+  };
+  GraphSeq ilu_graph;
+  GraphSeq *capturing = nullptr;   // the sequence being captured (graph_tick cuts it into chunks)
+  int cap_nodes = 0;
   // box wavefront solves on a structured grid (BoxGrid, kernels.hpp)
   BoxGrid box{};
   bool box_ok = false, box_tried = false, ell_built = false;
@@ -252,8 +264,7 @@ struct Solver {
   DevBuf<int> box_cellmap, box_cellpos, box_order;
   std::vector<int> box_lptr;                 // boxes of box level l: box_order[box_lptr[l] .. box_lptr[l+1])
   DevBuf<double> box_L[3], box_U[3], box_Di, box_v, box_scratch, box_T[3];
-  hipGraph_t box_graph = nullptr, box_fgraph = nullptr;
-  hipGraphExec_t box_graph_exec = nullptr, box_fgraph_exec = nullptr;
+  GraphSeq box_graph, box_fgraph;
 
   double dtime = 0.0, time = 0.0;
   long long cum_newton = 0, cum_linear = 0, cum_cuts = 0, cum_funcs = 0;
@@ -271,12 +282,7 @@ struct Solver {
   std::vector<char> bc_stage_pending;
 
   ~Solver() {
-    if (ilu_graph_exec) (void)hipGraphExecDestroy(ilu_graph_exec);
-    if (ilu_graph) (void)hipGraphDestroy(ilu_graph);
-    if (box_graph_exec) (void)hipGraphExecDestroy(box_graph_exec);
-    if (box_graph) (void)hipGraphDestroy(box_graph);
-    if (box_fgraph_exec) (void)hipGraphExecDestroy(box_fgraph_exec);
-    if (box_fgraph) (void)hipGraphDestroy(box_fgraph);
+    ilu_graph.destroy(); box_graph.destroy(); box_fgraph.destroy();
     if (h_sc) (void)hipHostFree(h_sc);
     if (h_seq) (void)hipHostFree(h_seq);
     if (h_bc_stage) (void)hipHostFree(h_bc_stage);
@@ -1367,9 +1373,9 @@ struct Solver {
         if (!box_T[0].p) for (auto &t : box_T) t.alloc((size_t)box_slots);
         double *const T[3] = {box_T[0].p, box_T[1].p, box_T[2].p};
         launch_box_load(box_slots, box, box_cellmap.p, d_int2ext.p, d_rowptr.p, d_col.p, nred, d_val.p, L, U, box_Di.p, T, stream);
-        run_graph(box_fgraph, box_fgraph_exec, [&] {
+        run_graph(box_fgraph, [&] {
           for (size_t l = 0; l + 1 < box_lptr.size(); ++l)
-            launch_box_factor(box, box_order.p + box_lptr[l], box_lptr[l + 1] - box_lptr[l], L, T, box_Di.p, box_scratch.p, stream);
+            graph_tick(), launch_box_factor(box, box_order.p + box_lptr[l], box_lptr[l + 1] - box_lptr[l], L, T, box_Di.p, box_scratch.p, stream);
         });
         pc_ready = true;
         return;
@@ -1392,31 +1398,63 @@ struct Solver {
   // every level of both triangular solves, on the fixed buffers ilu_y / ilu_x (captured once into a hipGraph)
   void ilu_solve_levels() {
     for (size_t l = 1; l + 1 < h_lptr.size(); ++l)   // level 0 of L has no dependencies: y = r already
-      launch_ell_lower_level(nrow, ell_KL, d_Lcol.p, d_Lval.p, h_lptr[l], h_lptr[l + 1], ilu_y.p, stream);
+      graph_tick(), launch_ell_lower_level(nrow, ell_KL, d_Lcol.p, d_Lval.p, h_lptr[l], h_lptr[l + 1], ilu_y.p, stream);
+    graph_tick();
     launch_gather(nrow, d_l2u.p, ilu_y.p, ilu_x.p, stream);
     for (size_t l = 0; l + 1 < h_uptr.size(); ++l)
-      launch_ell_upper_level(nrow, ell_KU, d_Ucol.p, d_Uval.p, d_Uidiag.p, h_uptr[l], h_uptr[l + 1], ilu_x.p, stream);
+      graph_tick(), launch_ell_upper_level(nrow, ell_KU, d_Ucol.p, d_Uval.p, d_Uidiag.p, h_uptr[l], h_uptr[l + 1], ilu_x.p, stream);
   }
   // the box levels of both solves on the fixed buffer box_v
   void box_solve_levels() {
     const double *const L[3] = {box_L[0].p, box_L[1].p, box_L[2].p}, *const U[3] = {box_U[0].p, box_U[1].p, box_U[2].p};
     const int nl = (int)box_lptr.size() - 1;
-    for (int l = 0; l < nl; ++l) launch_box_lower(box, box_order.p + box_lptr[l], box_lptr[l + 1] - box_lptr[l], L, box_v.p, box_scratch.p, stream);
-    for (int l = nl - 1; l >= 0; --l) launch_box_upper(box, box_order.p + box_lptr[l], box_lptr[l + 1] - box_lptr[l], U, box_Di.p, box_v.p, box_scratch.p, stream);
+    for (int l = 0; l < nl; ++l) graph_tick(), launch_box_lower(box, box_order.p + box_lptr[l], box_lptr[l + 1] - box_lptr[l], L, box_v.p, box_scratch.p, stream);
+    for (int l = nl - 1; l >= 0; --l) graph_tick(), launch_box_upper(box, box_order.p + box_lptr[l], box_lptr[l + 1] - box_lptr[l], U, box_Di.p, box_v.p, box_scratch.p, stream);
   }
   bool box_active() const { return box_ok && opt.ilu_box != 0; }
   bool box_factored() const { return box_active() && opt.ilu_box_factor && box_factor_applies(box); }
-  // a fixed sequence of launches, captured into a hipGraph the first time and replayed afterwards (one by one under rocprofv3)
+  // A fixed sequence of launches, captured the first time and replayed afterwards -- as SEVERAL hipGraphs of at most
+  // opt.ilu_graph_nodes kernel nodes each (graph_tick, called in front of every launch of such a sequence, cuts the capture).
+  // One graph of several hundred nodes is what rocprofv3's kernel tracing (rocprofiler-sdk, ROCm 7.2) could not take: SIGSEGV
+  // inside the graph launch at 764 nodes, clean at 141 (profiles/r02_rocprofv3_graph_replay_{128,24}.log).  With the chunks
+  // profiled and unprofiled runs take the same path; no environment sniffing.
+  void graph_chunk_begin() {
+    HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+    cap_nodes = 0;
+  }
+  void graph_chunk_end() {
+    hipGraph_t g = nullptr;
+    hipGraphExec_t e = nullptr;
+    HIP_CHECK(hipStreamEndCapture(stream, &g));
+    capturing->graphs.push_back(g);
+    HIP_CHECK(hipGraphInstantiate(&e, g, nullptr, nullptr, 0));
+    capturing->execs.push_back(e);
+  }
+  void graph_tick() {
+    if (!capturing) return;
+    if (cap_nodes >= std::max(1, opt.ilu_graph_nodes)) { graph_chunk_end(); graph_chunk_begin(); }
+    ++cap_nodes;
+  }
   template <class F>
-  void run_graph(hipGraph_t &graph, hipGraphExec_t &exec, F &&launches) {
-    if (!opt.ilu_graph || under_rocprofiler()) { launches(); return; }
-    if (!exec) {
-      HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-      launches();
-      HIP_CHECK(hipStreamEndCapture(stream, &graph));
-      HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+  void run_graph(GraphSeq &gs, F &&launches) {
+    if (!opt.ilu_graph) { launches(); return; }
+    if (gs.execs.empty()) {
+      capturing = &gs;
+      try {
+        graph_chunk_begin();
+        launches();
+        graph_chunk_end();
+      } catch (...) {
+        hipGraph_t g = nullptr;
+        (void)hipStreamEndCapture(stream, &g);
+        if (g) (void)hipGraphDestroy(g);
+        capturing = nullptr;
+        gs.destroy();
+        throw;
+      }
+      capturing = nullptr;
     }
-    HIP_CHECK(hipGraphLaunch(exec, stream));
+    for (auto e : gs.execs) HIP_CHECK(hipGraphLaunch(e, stream));
   }
   void op_pc_apply(const double *r, double *z) {
     ProfScope ps(prof, KC_PC_APPLY);
@@ -1427,7 +1465,7 @@ struct Solver {
     else if (opt.pc_type == 1 && box_active()) {
       if (box_gather_in_fits(box)) launch_box_gather_in(box, d_ext2int.p, r, box_v.p, stream);   // r into the box layout, padding zero
       else launch_gather_or_zero(box_slots, box_cellmap.p, r, box_v.p, stream);
-      run_graph(box_graph, box_graph_exec, [&] { box_solve_levels(); });
+      run_graph(box_graph, [&] { box_solve_levels(); });
       launch_gather(nred, box_cellpos.p, box_v.p, z, stream);                // back to the internal row order
       if (nghost > 0) launch_set(nghost, 0.0, z + nred, stream);             // (identity rows, zero right-hand side)
     } else if (opt.pc_type == 1) {
@@ -1441,19 +1479,9 @@ struct Solver {
         solved = !chain_timed_out();
         if (!solved) launch_gather(nrow, d_lrows.p, r, ilu_y.p, stream);
       }
-      if (!solved) run_graph(ilu_graph, ilu_graph_exec, [&] { ilu_solve_levels(); });
+      if (!solved) run_graph(ilu_graph, [&] { ilu_solve_levels(); });
       launch_gather(nrow, d_posU.p, ilu_x.p, z, stream);             // back to the internal row order
     } else launch_copy(nred, r, z, stream);
-  }
-  // rocprofv3's kernel tracing (rocprofiler-sdk of ROCm 7.2) segfaults inside its interception of a hipGraph launch with
-  // several hundred kernel nodes (764 at 128^3; 141 nodes at 24^3 are fine): profiles/r02_rocprofv3_graph_replay_128.log.
-  // Under the profiler the level solves are therefore launched one by one -- the same kernels, visible in the trace.
-  static bool under_rocprofiler() {
-    static const bool yes = [] {
-      const char *pre = std::getenv("LD_PRELOAD"), *tool = std::getenv("ROCP_TOOL_LIBRARIES");
-      return (pre && std::strstr(pre, "rocprofiler")) || (tool && *tool);
-    }();
-    return yes;
   }
   void op_BA(const double *v, double *t) {  // t = M^{-1} A v  (left preconditioning)
     op_spmv(v, Wk.p);
@@ -2624,7 +2652,9 @@ struct Solver {
     HIP_CHECK(hipStreamSynchronize(stream));
     if (e == 0.0) return false;
     opt.ilu_chain = 0;
-    ++chain_fallbacks;
+    if (chain_fallbacks++ == 0)
+      std::fprintf(stderr, "mppgpu: a chained ILU(0) solve timed out waiting for a tile (spin budget %u); redone with one launch per "
+                           "level, the chain is off for this handle from now on\n", opt.ilu_chain_spins);
     launch_set(1, 0.0, sc.p + S_ERR, stream);
     return true;
   }
@@ -2782,9 +2812,9 @@ struct Solver {
   // Is the pattern a structured 7-point (5-, 3-point) grid in the caller's numbering?  Then the triangular solves run box by box
   // (BoxGrid): extents from the distinct positive column distances {1, n1, n1*n2}, every row checked against the grid.
   void ilu_box_analyse() {
-    if (box_tried) return;
+    if (box_tried || opt.ilu_box == 0) return;   // (ilu_box = 0 leaves the test for a later set_option("ilu_box", ...))
     box_tried = true; box_ok = false;
-    if (opt.ilu_box == 0 || th || nrow != n || nred < 2) return;
+    if (th || nrow != n || nred < 2) return;
     PhaseTimer pt("ILU(0): structured-grid test");
     // With ghost cells (last in the numbering, identity layout, identity rows, zero right-hand side in the preconditioner) the
     // local ILU(0) is the ILU(0) of the block of the owned cells: the test and the boxes cover that block, ghost columns are skipped.
@@ -2928,6 +2958,10 @@ struct Solver {
     } else if (key == "nseg") opt.nseg = (int)num();
     else if (key == "fused_assembly") opt.fused_assembly = num() != 0;
     else if (key == "ilu_graph") opt.ilu_graph = num() != 0;
+    else if (key == "ilu_graph_nodes") {   // kernel nodes per replayed graph (the sequences are cut into chunks of this size)
+      opt.ilu_graph_nodes = std::max(1, (int)num());
+      ilu_graph.destroy(); box_graph.destroy(); box_fgraph.destroy();
+    }
     else if (key == "th_fused_dots") opt.th_fused_dots = num() != 0;
     else if (key == "ilu_box") { opt.ilu_box = (int)num(); pc_ready = false; }   // the factors are repacked for the other solve path
     else if (key == "ilu_box_factor") { opt.ilu_box_factor = num() != 0; pc_ready = false; }
@@ -3392,6 +3426,16 @@ int mppgpu_get_comm_stats(mppgpu_handle h, long long *allreduces, long long *hal
   API_END()
 }
 
+int mppgpu_get_assembly_info(mppgpu_handle h, int n, int *info) {
+  API_BEGIN(h)
+  S.ensure_ready();
+  const bool cols = S.use_cols() && !S.th && !S.thermal;
+  const int v[8] = {cols ? S.ncls : 0, cols && S.lev_geo ? 1 : 0, cols && S.lev_pv ? 1 : 0, cols && S.rows_complete() ? 1 : 0,
+                    cols ? S.pick_nseg() : 0, S.spmv_variant(), (S.opt.pc_type == 2 && !S.th && S.tri_lds()) ? 1 : 0,
+                    (int)std::min<long long>(S.spec_misses, 2147483647LL)};
+  for (int i = 0; i < n && i < 8; ++i) info[i] = v[i];
+  API_END()
+}
 int mppgpu_get_pc_info(mppgpu_handle h, int *path, int *launches, int *box_extents) {
   API_BEGIN(h)
   int p = 0, n = 0, ext[3] = {0, 0, 0};
@@ -3484,6 +3528,61 @@ int mppgpu_bench_kernel(mppgpu_handle h, const char *name, int variant, int reps
                          : (k == "dots3") ? 32.0 * N : (k == "pc_apply_dots") ? 48.0 * N : (k == "tri_back") ? 32.0 * N : (k == "spmv_dots") ? 12.0 * S.nnz + 28.0 * N : (k == "assemble_both") ? 92.0 * N + 8.0 * S.nnz : S.algorithmic_bytes(cls);
   }
   API_END()
+}
+
+// ---- the constitutive laws on the host, for drivers that need them to build their inputs ----
+#define HOST_LAW_BEGIN try {
+#define HOST_LAW_END                    \
+    return 0;                           \
+  } catch (const std::exception &e) {   \
+    g_create_error = e.what();          \
+    return 1;                           \
+  }
+int mppgpu_host_density(int density_type, int n, const double *p, const double *t_K, double *den, double *dden_dp, double *dden_dt) {
+  HOST_LAW_BEGIN
+  if (density_type < mpp::kDenConstant || density_type > mpp::kDenIFC67) throw mpp::Error("unknown density type " + std::to_string(density_type));
+  for (int i = 0; i < n; ++i) {
+    double d, dp, dt;
+    mpp::density_pt<true>(density_type, p[i], t_K[i], d, dp, dt);
+    if (den) den[i] = d;
+    if (dden_dp) dden_dp[i] = dp;
+    if (dden_dt) dden_dt[i] = dt;
+  }
+  HOST_LAW_END
+}
+int mppgpu_host_internal_energy_enthalpy(int ie_type, int n, const double *p, const double *t_K, const double *den,
+                                         const double *dden_dt, const double *dden_dp, double *u, double *h, double *du_dt,
+                                         double *dh_dt, double *du_dp, double *dh_dp) {
+  HOST_LAW_BEGIN
+  if (ie_type != mpp::kIEConstant && ie_type != mpp::kIEIFC67) throw mpp::Error("unknown internal-energy type " + std::to_string(ie_type));
+  for (int i = 0; i < n; ++i) {
+    const mpp::IEOut o = mpp::internal_energy_enthalpy<true>(ie_type, p[i], t_K[i], den[i], dden_dt[i], dden_dp[i]);
+    if (u) u[i] = o.U;
+    if (h) h[i] = o.H;
+    if (du_dt) du_dt[i] = o.dU_dT;
+    if (dh_dt) dh_dt[i] = o.dH_dT;
+    if (du_dp) du_dp[i] = o.dU_dP;
+    if (dh_dp) dh_dp[i] = o.dH_dP;
+  }
+  HOST_LAW_END
+}
+int mppgpu_host_sat_relperm(int n, const int *satfunc_type, const double *p, const double *sat_res, const double *alpha,
+                            const double *lambda, double *sat, double *dsat_dp, double *kr, double *dkr_dp) {
+  HOST_LAW_BEGIN
+  for (int i = 0; i < n; ++i) {
+    const int sf = mpp::map_sat_func(satfunc_type[i]);
+    if (sf < 0) throw mpp::Error("unsupported saturation function " + std::to_string(satfunc_type[i]));
+    mpp::Soil s{};
+    s.sat_res = sat_res[i]; s.alpha = alpha[i]; s.m = lambda[i]; s.sf = sf;
+    if (sf == mpp::kSatSBC) mpp::Solver::sbc_coefficients(satfunc_type[i], alpha[i], lambda[i], s.pu, s.ps, s.b2, s.b3);
+    double a, da, k, dk;
+    mpp::sat_relperm<true>(sf, s, p[i], 1.0, a, da, k, dk);
+    if (sat) sat[i] = a;
+    if (dsat_dp) dsat_dp[i] = da;
+    if (kr) kr[i] = k;
+    if (dkr_dp) dkr_dp[i] = dk;
+  }
+  HOST_LAW_END
 }
 
 int mppgpu_comm_get_unique_id(void *id128) {

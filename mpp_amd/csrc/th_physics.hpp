@@ -27,9 +27,18 @@ __host__ __device__ inline double powi(double x, int m) {
   return y;
 }
 
-// Real powers with integer-valued exponents (theta**18.d0, theta**(-6.d0), ...) are evaluated with powi below: a handful of
-// multiplications instead of ~150 instructions of pow() each, within a few ulp of it (29 -> 5 pow calls per cell).
+// Real powers with integer-valued exponents (theta**18.d0, theta**(-6.d0), ...): the kernels evaluate them as multiplication
+// chains (LIB = false: a handful of multiplications instead of ~250 instructions of pow() each, within a few ulp of it; 29 -> 5
+// pow calls per cell); LIB = true goes through the math library, as the reference's compiled code does -- what the host entry
+// points for drivers use (mppgpu_host_*), whose callers may difference these functions numerically (th_mms: a 1e-6 central
+// difference of the enthalpy turns a last-bit difference into 1e-9 of the manufactured heat source).
+template <bool LIB>
+__host__ __device__ inline double rpow(double x, int n) {
+  if (LIB) return pow(x, (double)n);
+  return n >= 0 ? powi(x, n) : 1.0 / powi(x, -n);
+}
 // IFC-67 density [kmol/m3] with both derivatives (EOSWaterMod.F90:181-344); t in degC
+template <bool LIB = false>
 __host__ __device__ inline void density_ifc67_pt(double t, double p, double &dwmol, double &dwp, double &dwt) {
   const double aa11 = 7.982692717e00, aa12 = -2.616571843e-2, aa13 = 1.522411790e-3, aa14 = 2.284279054e-2,
                aa15 = 2.421647003e02, aa16 = 1.269716088e-10, aa17 = 2.074838328e-7, aa18 = 2.174020350e-8,
@@ -41,32 +50,32 @@ __host__ __device__ inline void density_ifc67_pt(double t, double p, double &dwm
   const double utc1 = 1.0 / tc1, upc1 = 1.0 / pc1, vc1mol = vc1 * kFMWH2O;
   const double theta = (t + 273.15) * utc1;
   const double theta2x = theta * theta;
-  const double theta18 = powi(theta, 18);
+  const double theta18 = rpow<LIB>(theta, 18);
   const double theta20 = theta18 * theta2x;
   const double beta = p * upc1;
   const double beta2x = beta * beta;
-  const double yy = 1.0 - a1 * theta2x - a2 * (1.0 / powi(theta, 6));
+  const double yy = 1.0 - a1 * theta2x - a2 * rpow<LIB>(theta, -6);
   double xx = a3 * yy * yy - 2.0 * (a4 * theta - a5 * beta);
   xx = sqrt(xx);
   const double zz = yy + xx;
   const double u0 = -5.0 / 17.0;
   const double u1 = aa11 * a5 * pow(zz, u0);
-  const double u2 = 1.0 / (a8 + powi(theta, 11));
+  const double u2 = 1.0 / (a8 + rpow<LIB>(theta, 11));
   const double u3 = aa17 + (2.0 * aa18 + 3.0 * aa19 * beta) * beta;
   const double u4 = 1.0 / (a7 + theta18 * theta);
-  const double u5 = (1.0 / powi(a10 + beta, 4));
+  const double u5 = rpow<LIB>(a10 + beta, -4);
   const double u6 = a11 - 3.0 * u5;
   const double u7 = aa20 * theta18 * (a9 + theta2x);
-  const double u8 = aa15 * powi(a6 - theta, 9);
+  const double u8 = aa15 * rpow<LIB>(a6 - theta, 9);
   const double vr = u1 + aa12 + theta * (aa13 + aa14 * theta) + u8 * (a6 - theta) + aa16 * u4 - u2 * u3 - u6 * u7 +
                     (3.0 * aa21 * (a12 - theta) + 4.0 * aa22 * beta / theta20) * beta2x;
   dwmol = 1.0 / (vr * vc1mol);
-  const double ypt = 6.0 * a2 * (1.0 / powi(theta, 7)) - 2.0 * a1 * theta;
+  const double ypt = 6.0 * a2 * rpow<LIB>(theta, -7) - 2.0 * a1 * theta;
   const double zpt = ypt + (a3 * yy * ypt - a4) / xx;
   const double zpp = a5 / xx;
   const double u9 = u0 * u1 / zz;
   const double vrpt = u9 * zpt + aa13 + 2.0 * aa14 * theta - 10.0 * u8 - 19.0 * aa16 * u4 * u4 * theta18 +
-                      11.0 * u2 * u2 * u3 * powi(theta, 10) - aa20 * u6 * (18.0 * a9 * theta18 + 20.0 * theta20) / theta -
+                      11.0 * u2 * u2 * u3 * rpow<LIB>(theta, 10) - aa20 * u6 * (18.0 * a9 * theta18 + 20.0 * theta20) / theta -
                       (3.0 * aa21 + 80.0 * aa22 * beta / (theta20 * theta)) * beta2x;
   const double vrpp = u9 * zpp - u2 * (2.0 * aa18 + 6.0 * aa19 * beta) - 12.0 * u7 * u5 / (a10 + beta) +
                       (6.0 * aa21 * (a12 - theta) + 12.0 * aa22 * beta / theta20) * beta;
@@ -76,6 +85,7 @@ __host__ __device__ inline void density_ifc67_pt(double t, double p, double &dwm
 }
 
 // Density(p, t_K, type) -> den [kmol/m3], dden_dp, dden_dT (EOSWaterMod.F90:38-178)
+template <bool LIB = false>
 __host__ __device__ inline void density_pt(int density_type, double p, double t_K, double &den, double &dden_dp, double &dden_dT) {
   if (density_type == kDenConstant) {
     den = kDenH2O / kFMWH2O; dden_dp = 0.0; dden_dT = 0.0;
@@ -99,11 +109,12 @@ __host__ __device__ inline void density_pt(int density_type, double p, double t_
     dden_dT = (ddent_dt * kappa + dent * dkappa_dt) / kFMWH2O;
     dden_dp = (0.0 * kappa + dent * dkappa_dp) / kFMWH2O;
   } else {
-    density_ifc67_pt(t_K - 273.15, p, den, dden_dp, dden_dT);
+    density_ifc67_pt<LIB>(t_K - 273.15, p, den, dden_dp, dden_dT);
   }
 }
 
 // EnthalpyIFC67 (EOSWaterMod.F90:346-566): hw [J/kmol], d/dp, d/dT; t in degC
+template <bool LIB = false>
 __host__ __device__ inline void enthalpy_ifc67(double t, double p, double &hw, double &hwp, double &hwt) {
   const double aa[23] = {
       6.824687741e03, -5.422063673e02, -2.096666205e04, 3.941286787e04, -6.733277739e04, 9.902381028e04,
@@ -117,18 +128,18 @@ __host__ __device__ inline void enthalpy_ifc67(double t, double p, double &hw, d
   const double utc1 = 1.0 / tc1, upc1 = 1.0 / pc1, vc1mol = vc1 * kFMWH2O;
   const double theta = (t + 273.15) * utc1;
   const double theta2x = theta * theta;
-  const double theta18 = powi(theta, 18);
+  const double theta18 = rpow<LIB>(theta, 18);
   const double theta20 = theta18 * theta2x;
   const double beta = p * upc1;
   const double beta2x = beta * beta;
   const double beta4 = beta2x * beta2x;
-  const double yy = 1.0 - a1 * theta2x - a2 * (1.0 / powi(theta, 6));
+  const double yy = 1.0 - a1 * theta2x - a2 * rpow<LIB>(theta, -6);
   double xx = a3 * yy * yy - 2.0 * (a4 * theta - a5 * beta);
   xx = sqrt(xx);
   const double zz = yy + xx;
   const double u0 = -5.0 / 17.0;
   const double u1 = aa[11] * a5 * pow(zz, u0);
-  const double ypt = 6.0 * a2 * (1.0 / powi(theta, 7)) - 2.0 * a1 * theta;
+  const double ypt = 6.0 * a2 * rpow<LIB>(theta, -7) - 2.0 * a1 * theta;
   const double utheta = 1.0 / theta;
   const double term1 = aa[0] * theta;
   double term2 = -aa[1];
@@ -146,20 +157,20 @@ __host__ __device__ inline void enthalpy_ifc67(double t, double p, double &hw, d
   const double term3 = v0_1 * v1_1;
   const double v1_2 = 9.0 * theta + a6;
   const double v20_2 = (a6 - theta);
-  const double v2_2 = powi(v20_2, 9);
-  const double theta19 = powi(theta, 19);
+  const double v2_2 = rpow<LIB>(v20_2, 9);
+  const double theta19 = rpow<LIB>(theta, 19);
   const double v3_2 = a7 + 20.0 * theta19;
   const double v40_2 = a7 + theta19;
   const double v4_2 = 1.0 / (v40_2 * v40_2);
   const double term4p = aa[12] - aa[14] * theta2x + aa[15] * v1_2 * v2_2 + aa[16] * v3_2 * v4_2;
   const double term4 = term4p * beta;
   const double v1_3 = beta * (aa[17] + aa[18] * beta + aa[19] * beta2x);
-  const double theta11 = powi(theta, 11);
+  const double theta11 = rpow<LIB>(theta, 11);
   const double v2_3 = 12.0 * theta11 + a8;
   const double v4_3 = 1.0 / (a8 + theta11);
   const double v3_3 = v4_3 * v4_3;
   const double term5 = v1_3 * v2_3 * v3_3;
-  const double v1_4 = (1.0 / powi(a10 + beta, 3)) + a11 * beta;
+  const double v1_4 = rpow<LIB>(a10 + beta, -3) + a11 * beta;
   const double v3_4 = (17.0 * a9 + 19.0 * theta2x);
   const double v2_4 = aa[20] * theta18 * v3_4;
   const double term6 = v1_4 * v2_4;
@@ -170,7 +181,7 @@ __host__ __device__ inline void enthalpy_ifc67(double t, double p, double &hw, d
   hw = (term1 - term2 + term3 + term4 - term5 + term6 + term7) * v1_6;
   const double zpt = ypt + (a3 * yy * ypt - a4) / xx;
   const double zpp = a5 / xx;
-  const double yptt = -2.0 * a1 - 42.0 * a2 / powi(theta, 8);
+  const double yptt = -2.0 * a1 - 42.0 * a2 / rpow<LIB>(theta, 8);
   const double dv2t = 17.0 * (zpt / 29.0 - ypt / 12.0) + 5.0 / 12.0 * (ypt + theta * yptt);
   const double dv3t = a4 - (a3 - 1.0) * (theta * yy * yptt + yy * ypt + theta * ypt * ypt);
   const double dv2p = 17.0 * zpp / 29.0;
@@ -180,9 +191,9 @@ __host__ __device__ inline void enthalpy_ifc67(double t, double p, double &hw, d
   const double term4t = (-2.0 * aa[14] * theta + 9.0 * aa[15] * (v2_2 - v1_2 * v2_2 / v20_2) +
                          38.0 * theta18 * aa[16] * (10.0 * v4_2 - v3_2 * v4_2 / v40_2)) * beta;
   const double term5p = v3_3 * v2_3 * (aa[17] + 2.0 * aa[18] * beta + 3.0 * aa[19] * beta2x);
-  const double theta10 = powi(theta, 10);
+  const double theta10 = rpow<LIB>(theta, 10);
   const double term5t = v1_3 * (132.0 * v3_3 * theta10 - 22.0 * v2_3 * v3_3 * v4_3 * theta10);
-  const double term6p = v2_4 * (a11 - 3.0 * (1.0 / powi(a10 + beta, 4)));
+  const double term6p = v2_4 * (a11 - 3.0 * rpow<LIB>(a10 + beta, -4));
   const double term6t = v1_4 * aa[20] * theta18 * (18.0 * v3_4 * utheta + 38.0 * theta);
   const double term7p = beta2x * (3.0 * aa[21] * a12 + 84.0 * aa[22] * beta / theta20);
   const double term7t = -420.0 * aa[22] * beta4 / (theta20 * theta);
@@ -193,6 +204,7 @@ __host__ __device__ inline void enthalpy_ifc67(double t, double p, double &hw, d
 struct IEOut { double U, H, dU_dT, dH_dT, dU_dP, dH_dP; };
 
 // InternalEnergyAndEnthalpy (EOSWaterMod.F90:589-707); den and its derivatives in kg m^-3
+template <bool LIB = false>
 __host__ __device__ inline IEOut internal_energy_enthalpy(int itype, double P, double t_K, double den, double dden_dT, double dden_dP) {
   IEOut o;
   if (itype == kIEConstant) {
@@ -206,7 +218,7 @@ __host__ __device__ inline IEOut internal_energy_enthalpy(int itype, double P, d
     o.dU_dP = dU_dP; o.dH_dP = dH_dP * kFMWH2O;
   } else {
     double H, dH_dP, dH_dT;
-    enthalpy_ifc67(t_K - 273.15, P, H, dH_dP, dH_dT);
+    enthalpy_ifc67<LIB>(t_K - 273.15, P, H, dH_dP, dH_dT);
     const double dm = den / kFMWH2O;
     o.H = H; o.dH_dP = dH_dP; o.dH_dT = dH_dT;
     o.U = H - P / dm;

@@ -11,8 +11,9 @@ categories of the regression file are those of the drivers' `output_regression_*
 mass_and_heat_model_problem.F90:682-694).  Solver options not given are PETSc's defaults, as in the reference runs
 (GMRES(30) + ILU(0)); `-name value` pairs on the command line play the role of the PETSc options database.
 
-Problems of the reference that are outside this path (SURVEY 2 OUT OF SCOPE: vsfm_spac*, the canopy models) or that need
-inputs this package does not build (th_mms: its manufactured sources) are refused by name.
+th_mms forms its manufactured mass and heat sources on the host from the constitutive laws, as the reference driver does
+(th_mms_problem.F90:901-934, 1262-1452; mpp_amd.workloads.th_mms with mpp_amd.laws).  Problems of the reference that are
+outside this path (SURVEY 2 OUT OF SCOPE: vsfm_spac*, the canopy models) are refused by name.
 """
 from __future__ import annotations
 
@@ -76,18 +77,16 @@ def run_problem(problem_type, groups, options=None, device_id=0):
         if not conv:
             raise DriverError("thermal_mms: the linear solve did not converge")
         return [("temperature", "general", mpp.soe.GetSoln())]
-    if problem_type == "mass_and_heat":
-        tp = P.mass_and_heat()
+    if problem_type in ("mass_and_heat", "th_mms"):
+        tp = P.mass_and_heat() if problem_type == "mass_and_heat" else P.th_mms()   # (th_mms: nx = 20, th_mms_problem.F90:943)
         mpp = P.to_th_gpu(tp, opts, device_id)
         for s in range(tp.nstep):
             P.th_gpu_set_conditions(tp, mpp)
             conv, reason = mpp.soe.StepDT(tp.dt, s + 1)
             if not conv:
-                raise DriverError("mass_and_heat: StepDT did not converge (reason %d)" % reason)
+                raise DriverError("%s: StepDT did not converge (reason %d)" % (problem_type, reason))
         return [("liquid_pressure", "pressure", mpp.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE)),
                 ("temperature", "temperature", mpp.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_TEMPERATURE))]
-    if problem_type == "th_mms":
-        raise DriverError("problem_type 'th_mms': its manufactured mass and heat sources are not built by this package")
     if problem_type in OUT_OF_SCOPE:
         raise DriverError("problem_type '%s' is outside the GPU solve path (plant hydraulics / canopy models)" % problem_type)
     raise DriverError("Unknown problem_type '%s'" % problem_type)   # standalone_mpp.F90:196-199

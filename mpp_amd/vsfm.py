@@ -235,6 +235,14 @@ class SystemOfEquationsVSFM:
         self._chk(self.L.mppgpu_get_comm_stats(self.h, ct.byref(a), ct.byref(b), ct.byref(c), ct.byref(d)))
         return dict(allreduces=a.value, halo_exchanges=b.value, chain_fallbacks=c.value, host_readbacks=d.value)
 
+    def assembly_info(self):
+        """layout and kernel selection of this handle (mppgpu_get_assembly_info)"""
+        v = (ct.c_int * 8)()
+        self._chk(self.L.mppgpu_get_assembly_info(self.h, 8, v))
+        keys = ("soil_classes", "level_geometry", "level_porosity_volume", "complete_rows", "column_segments", "spmv_variant",
+                "column_solve_in_lds", "speculative_trials_discarded")
+        return dict(zip(keys, (int(x) for x in v)))
+
     def pc_info(self):
         """how the ILU(0) triangular solves are applied (mppgpu_get_pc_info): path name, launches per application, box extents"""
         path, n = ct.c_int(), ct.c_int()

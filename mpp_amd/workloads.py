@@ -393,6 +393,96 @@ def mass_and_heat(nx=100) -> THProblem:
         dt=3600.0, nstep=1)
 
 
+def th_mms(nx=20) -> THProblem:
+    """src/driver/standalone/thermal-e/th_mms_problem.F90 (STEADY_STATE_SOIL_ONLY_1D): manufactured steady pressure and
+    temperature on x in [0,10], zero porosity and heat capacity (no storage), constant density + IFC67 enthalpy, Dirichlet
+    P and T at both ends of both equations, manufactured mass and heat sources in every cell
+    (set_source_sink_conditions :901-934; DATA_MASS_SOURCE :1262-1316, DATA_HEAT_SOURCE :1365-1452, with the driver's 1e-6
+    central differences of density, enthalpy and the Kersten number), one step.  The driver evaluates the constitutive laws
+    on the host to form those sources; so does this builder (mpp_amd.laws: the library's own functions)."""
+    from . import laws as L
+    x_min, x_max = 0.0, 10.0
+    xlim = x_max - x_min
+    dx = (x_max - x_min) / nx
+    m = M.mesh_create("Soil mesh", x_max, 1.0, 1.0, nx, 1, 1, C.CONN_IN_XYZ_DIR, x_min=x_min)
+    n = m.ncells_local
+    xc = np.asarray(m.x, dtype=np.float64)
+    pi = 4 * np.arctan(1.0)
+    FMW = C.FMWH2O
+    density_type, ie_type = C.DENSITY_CONSTANT, 2     # set_problem :960-962 (the second assignment wins)
+
+    def pres(x):      # compute_pressure_or_deriv :991-1021
+        a0, a1 = 15000.0, -20000.0
+        sn, cs = np.sin((x - x_min) / xlim * pi), np.cos((x - x_min) / xlim * pi)
+        return a0 * sn + a1 + 101325.0, a0 * pi / xlim * cs, -a0 * pi * pi / xlim / xlim * sn
+
+    def temp(x):      # compute_temperature_or_deriv :1023-1044 (the second set of assignments wins)
+        a0, a1 = 5.0, 290.0
+        sn, cs = np.sin((x - x_min) / xlim * pi), np.cos((x - x_min) / xlim * pi)
+        return a0 * sn * 1.0 + a1, a0 * pi / xlim * cs * 1.0, -a0 * pi * pi / xlim / xlim * sn * 1.0
+
+    def permf(x):     # compute_permeability_or_deriv :1046-1060
+        p0 = 1e-11
+        return p0 * (2.0 - np.cos((x - x_min) / xlim * pi)), p0 * pi / xlim * np.sin((x - x_min) / xlim * pi)
+
+    alpha0, lam0, sr0, kdry0, kwet0, talpha0 = 1.0 / 4000.0, 0.5, 0.0, 0.25, 1.3, 0.45
+    pert = 1e-6
+    mu = 8.904156e-4
+
+    def rho_of(P, T):   # Density in kmol/m^3 -> kg/m^3, with both derivatives
+        den, ddp, ddt = L.density(P, T, density_type)
+        return den * FMW, ddp * FMW, ddt * FMW
+
+    def sat_of(P):
+        return L.sat_relperm(P, C.SAT_FUNC_VAN_GENUCHTEN, sr0, alpha0, lam0)   # sat, dsat_dP, kr, dkr_dP
+
+    def enth(P, T, rho, drho_dT, drho_dP):
+        return L.internal_energy_enthalpy(P, T, ie_type, rho, drho_dT, drho_dP)[1]
+
+    k, dk_dx = permf(xc)
+    P, dP_dx, d2P_dx2 = pres(xc)
+    T, dT_dx, d2T_dx2 = temp(xc)
+    rho, drho_dP, drho_dT = rho_of(P, T)
+    se, _dse_dP, kr, dkr_dP = sat_of(P)
+    dkr_dx = dkr_dP * dP_dx
+    Pp, Tp = pres(xc + pert)[0], temp(xc + pert)[0]
+    Pn, Tn = pres(xc - pert)[0], temp(xc - pert)[0]
+    rho_p, drho_p_dP, drho_p_dT = rho_of(Pp, Tp)
+    rho_n, drho_n_dP, drho_n_dT = rho_of(Pn, Tn)
+    drho_dx = (rho_p - rho_n) / pert / 2.0
+    drhoq_dx = -((k * kr / mu) * drho_dx + (rho * kr / mu) * dk_dx + (rho * k / mu) * dkr_dx) * dP_dx - (rho * k * kr / mu) * d2P_dx2
+    mass_src = drhoq_dx * dx                                               # DATA_MASS_SOURCE :1262-1316
+    H = enth(P, T, rho, drho_dT, drho_dP)
+    rhoq = -rho * (k * kr / mu * dP_dx)
+    se_p, se_n = sat_of(Pp)[0], sat_of(Pn)[0]
+    Ke = (se + 1e-6) ** talpha0
+    dKe_dx = ((se_p + 1e-6) ** talpha0 - (se_n + 1e-6) ** talpha0) / pert / 2.0
+    kappa = kwet0 * Ke + kdry0 * (1.0 - Ke)
+    dkappa_dx = 0.0 * Ke + 0.0 * (1.0 - Ke) + (kwet0 - kdry0) * dKe_dx
+    dH_dx = (enth(Pp, Tp, rho_p, drho_p_dT, drho_p_dP) - enth(Pn, Tn, rho_n, drho_n_dT, drho_n_dP)) / pert / 2.0
+    heat_src = -(drhoq_dx * H / FMW + rhoq * dH_dx / FMW - dkappa_dx * dT_dx - kappa * d2T_dx2) * dx   # :1365-1452
+
+    P0 = 0.0; T0 = 0.0
+    for i in range(n):      # DATA_INITIAL_PRESSURE / _TEMPERATURE: running mean, same summation order
+        P0 = P0 + 1.0 / nx * P[i]; T0 = T0 + 1.0 / nx * T[i]
+    pres_bc = np.array([pres(xc[0] - dx / 2.0)[0], pres(xc[-1] + dx / 2.0)[0]])
+    temp_bc = np.array([temp(xc[0] - dx / 2.0)[0], temp(xc[-1] + dx / 2.0)[0]])
+    ends = M.ConnectionSet(np.array([0, 0]), np.array([1, nx]), np.zeros(2), np.full(2, dx / 2.0), np.full(2, 1.0 * 1.0),
+                           np.array([[1.0, 0.0, 0.0], [-1.0, 0.0, 0.0]]))      # ComputeBoundaryDomainConnection, ny = nz = 1
+    ids = np.arange(1, n + 1)
+    z = np.zeros(n)
+    allcells = M.ConnectionSet(np.zeros(n, dtype=np.int64), ids, z, z, np.ones(n), np.zeros((n, 3)))
+    return THProblem(
+        name="th_mms", mesh=m, perm=np.stack([k] * 3, axis=1), por=np.zeros(n),
+        satfunc_type=np.full(n, C.SAT_FUNC_VAN_GENUCHTEN, dtype=np.int32), alpha=np.full(n, alpha0), lam=np.full(n, lam0),
+        sat_res=np.full(n, sr0), density_type=density_type, ie_type=ie_type, heat_cap=np.zeros(n),
+        tcond_wet=np.full(n, kwet0), tcond_dry=np.full(n, kdry0), talpha=np.full(n, talpha0), den_soil=np.zeros(n),
+        energy_perm=(k, k, k), press_ic=np.full(n, P0), temp_ic=np.full(n, T0),
+        mass_bcs=[(C.COND_DIRICHLET, ends, pres_bc, temp_bc)], mass_sss=[(C.COND_MASS_RATE, allcells, mass_src)],
+        energy_bcs=[(C.COND_DIRICHLET, ends, temp_bc, pres_bc)], energy_sss=[(C.COND_HEAT_RATE, allcells, heat_src)],
+        dt=1.0, nstep=1)
+
+
 def to_th_gpu(tp: THProblem, options=None, device_id=0):
     """the reference drivers' call sequence (mass_and_heat_model_problem.F90:112-139) through the Python mirror"""
     from mpp_amd import th as TH

@@ -223,6 +223,7 @@ def test_dynamic_linesearch_sequence_before_a_time_step_cut(ls):
     ("thermal_mms_2d", "thermal.cfg", {"general": "1.0e-9 relative"}),
     ("thermal_mms_3d", "thermal.cfg", {"general": "1.0e-9 relative"}),
     ("mass_and_heat", "th.cfg", {"pressure": "1.0e-9 relative"}),
+    ("th_mms", "th.cfg", {"pressure": "1.0e-9 relative"}),   # manufactured sources built by the product (mpp_amd.workloads.th_mms)
 ])
 def test_standalone_driver_from_namelist_to_regression_file(golden_dir, tmp_path, name, cfg, loosen):
     """f-3 end to end on the GPU: the reference's own .namelist -> mpp_amd.standalone (problem on the GPU, PETSc's default
@@ -320,7 +321,10 @@ def test_fortran_hosted_thermal_mms(golden_dir, name, ptype, dims, ncell):
 
 
 @pytest.mark.parametrize("dims,box_len", [((37, 19, 11), 0), ((37, 19, 11), 5), ((70, 9, 3), 16), ((23, 17, 1), 0), ((20, 1, 1), 0),
-                                          ((64, 16, 8), 64), ((33, 40, 21), 32)])
+                                          ((64, 16, 8), 64), ((33, 40, 21), 32)]
+                         # odd and user-chosen box lengths, the tail where the row pairs do not divide the steps, boxes longer than
+                         # 64 (faces beyond one LDS batch, the gather through the slot map instead of the LDS image), 2-D grids
+                         + [(d, bl) for d in ((5, 3, 1), (33, 7, 9), (130, 9, 17)) for bl in (5, 32, 128)])
 def test_box_ilu_solves_reproduce_the_level_scheduled_ones_bit_for_bit(dims, box_len):
     """ILU(0) triangular solves of a structured grid box by box (one wave per box, dependencies through registers and cross-lane
     moves) against one launch per dependency level: per row the entries are eliminated in the same order, so the Krylov
@@ -378,6 +382,24 @@ def test_box_ilu_applications_on_the_3d_vsfm_jacobian():
     assert box.soe.counters() == lev.soe.counters()
     assert np.array_equal(box.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1),
                           lev.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1))
+
+
+def test_ilu_box_option_can_be_switched_on_after_a_first_setup_without_it():
+    """a handle whose first preconditioner set-up ran with ilu_box = 0 has not been tested for a structured grid yet: switching the
+    option on later must run the test then (1: boxes are used; 2: no 'not a structured grid' error for a grid that is one)"""
+    tp = P.thermal_mms(3, 13, 9, 7, replicate_reference_soil_indexing=False)
+    g = P.to_thermal_gpu(tp, {"ksp_type": "gmres", "pc_type": "ilu", "ilu_box": 0})
+    ref = P.to_thermal_gpu(tp, {"ksp_type": "gmres", "pc_type": "ilu", "ilu_box": 2})
+    assert g.soe.StepDT(tp.dt, 1)[0] and ref.soe.StepDT(tp.dt, 1)[0]
+    assert g.soe.pc_info()["path"] == "levels" and ref.soe.pc_info()["path"] == "boxes"
+    t1 = g.soe.GetSoln()
+    assert np.array_equal(t1, ref.soe.GetSoln())
+    for mode in (1, 2):
+        g.soe.SetOption("ilu_box", mode)
+        assert g.soe.StepDT(tp.dt, 2)[0]
+        assert g.soe.pc_info()["path"] == "boxes"
+    ref.soe.StepDT(tp.dt, 2); ref.soe.StepDT(tp.dt, 3)
+    assert np.array_equal(g.soe.GetSoln(), ref.soe.GetSoln())
 
 
 def test_box_ilu_is_refused_by_name_on_a_pattern_that_is_not_a_grid():

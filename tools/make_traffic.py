@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""profiles/kernel_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of `bench.py` at one grid size.
+
+    python3 tools/make_traffic.py <pmc summary json of tools/pmc_summary.py> <cells_per_gpu> <run label> > profiles/kernel_traffic.json
+
+The file carries the sha256 of the kernel sources the passes were made with (mpp_amd/csrc/*): bench.py quotes the moved
+bytes of a kernel class only when that hash equals the one of the sources it runs (a stale file is refused, not replayed)."""
+from __future__ import annotations
+
+import hashlib
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# kernel class of bench.py's `kernels` object -> the kernels that make up a launch of that class (substring of the demangled name)
+CLASSES = {
+    "spmv": ["k_spmv_c<3, false, false>"],
+    "residual": ["k_assemble_cols<0,", "k_bc<0>"],
+    "jacobian": ["k_assemble_cols<2,", "k_bc<2>"],
+    "pc_apply": ["k_tri_solve_lds<2,"],
+    "pc_apply_first": ["k_tri_back_dots"],
+    "spmv_with_line_search_sums": ["k_spmv_c<3, false, true>"],
+    "krylov_update": ["k_bcgs_xr<true>"],
+    "vec": ["k_waxpy"],
+}
+
+
+def source_hash():
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "mpp_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def main():
+    pmc = json.load(open(sys.argv[1]))
+    cells = int(sys.argv[2])
+    label = sys.argv[3] if len(sys.argv) > 3 else ""
+    out = {"cells_per_gpu": cells, "kernel_source_sha16": source_hash(), "run": label,
+           "correction": "reads = %.5f x FETCH_SIZE (gfx950: 128-byte requests tallied at 64 B), calibrated on k_copy of the same run"
+                         % pmc["read_factor"],
+           "classes": {}}
+    for cls, subs in CLASSES.items():
+        ks = {}
+        for sub in subs:
+            for name, v in pmc["kernels"].items():
+                short = re.sub(r"\(.*$", "", name.replace("mpp::(anonymous namespace)::", "").replace("void ", ""))
+                if sub in short:
+                    ks[short] = v["hbm_bytes_per_launch"]
+        if ks:
+            out["classes"][cls] = {"kernels": ks, "hbm_bytes_per_launch": sum(ks.values())}
+    json.dump(out, sys.stdout, indent=1)
+    print()
+
+
+if __name__ == "__main__":
+    main()
