@@ -216,6 +216,8 @@ def launch_ranks(nranks, argv, timeout_s):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nranks), LOCAL_WORLD_SIZE=str(nranks),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MPPGPU_BENCH_RANK_PROCESS="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if env.get("NCCL_DEBUG") and not env.get("NCCL_DEBUG_FILE"):
+            env["NCCL_DEBUG_FILE"] = "/dev/stderr"   # RCCL logs to stdout by default: keep rank 0's stdout for the ONE JSON line
         err = tempfile.TemporaryFile(mode="w+")
         logs.append(err)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
@@ -575,4 +577,19 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if os.environ.get("MPPGPU_BENCH_RANK_PROCESS") or ("RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1):
+        # a rank of a multi-GPU run: an error ends THIS process at once, with its message on stderr and a non-zero code -- no
+        # interpreter teardown (a communicator with an unfinished collective would be waited for), never a re-exec; the
+        # launcher (or torch.distributed.run) then stops the other ranks
+        try:
+            main()
+        except SystemExit:
+            raise
+        except BaseException:
+            import traceback
+            traceback.print_exc()
+            sys.stderr.flush()
+            sys.stdout.flush()
+            os._exit(1)
+    else:
+        main()

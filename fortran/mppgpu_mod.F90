@@ -33,7 +33,7 @@ module mppgpu_mod
         mppgpu_thermal_pre_step_dt, mppgpu_thermal_step_dt, mppgpu_thermal_get_soln, mppgpu_thermal_compute_rhs, &
         mppgpu_thermal_compute_operators, mppgpu_th_add_condition, mppgpu_th_set_soils, mppgpu_kernel_stats, &
         mppgpu_reset_stats, mppgpu_get_comm_stats, mppgpu_get_pc_info, mppgpu_get_assembly_info, mppgpu_bench_kernel, &
-        mppgpu_comm_get_unique_id, mppgpu_comm_init, &
+        mppgpu_comm_get_unique_id, mppgpu_comm_runtime_version, mppgpu_comm_init, &
         mppgpu_comm_init_local, mppgpu_set_ghost_cells, mppgpu_set_halo, &
         mppgpu_pre_step_dt, mppgpu_post_step_dt, &
         mppgpu_host_density, mppgpu_host_internal_energy_enthalpy, mppgpu_host_sat_relperm
@@ -356,6 +356,10 @@ module mppgpu_mod
        integer(c_int), value :: n
        integer(c_int) :: satfunc_type(*)
        real(c_double) :: p(*), sat_res(*), alpha(*), lambda(*), sat(*), dsat_dp(*), kr(*), dkr_dp(*)
+     end function
+     integer(c_int) function mppgpu_comm_runtime_version(version) bind(C, name='mppgpu_comm_runtime_version')
+       import :: c_int
+       integer(c_int) :: version
      end function
      integer(c_int) function mppgpu_comm_get_unique_id(id128) bind(C, name='mppgpu_comm_get_unique_id')
        import :: c_int, c_char

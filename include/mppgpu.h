@@ -316,7 +316,8 @@ int mppgpu_get_pc_info(mppgpu_handle h, int *path, int *launches, int *box_exten
  * [1] per-level connection geometry (1 / 0), [2] per-level porosity x volume, [3] complete-row column march (boundary fluxes,
  * norms, column LU and forward elimination inside the assembly pass), [4] column segments per thread-block row, [5] SpMV
  * variant, [6] column solve through LDS, [7] speculative line-search trial points that had to be discarded since
- * mppgpu_setup.  n = entries of info the caller provides (at most 8 are written). */
+ * mppgpu_setup, [8] the level / box launches of the ILU(0) solves are replayed from hipGraphs (option ilu_graph), [9] graphs
+ * instantiated for them so far.  n = entries of info the caller provides (at most 10 are written). */
 int mppgpu_get_assembly_info(mppgpu_handle h, int n, int *info);
 /* device-resident micro-benchmark of one kernel class on the current state: `reps` launches, average ms */
 int mppgpu_bench_kernel(mppgpu_handle h, const char *name, int variant, int reps, double *avg_ms,
@@ -345,6 +346,10 @@ int mppgpu_host_sat_relperm(int n, const int *satfunc_type, const double *p, con
  * all PETSC_COMM_SELF: src/mpp/mpp/MultiPhysicsProbBaseType.F90:1132,1154,1193).
  * The 128-byte unique id is produced on rank 0 and broadcast by the host (MPI_Bcast / torch.distributed).
  * ---------------------------------------------------------------------------------------------- */
+/* Loads RCCL and runs the guard every communicator creation runs: the library's ncclGetVersion must be 2.x and of the same
+ * major version as the rccl.h the hand-written prototypes and enumerator values were checked against at build time
+ * (static_asserts in mpp_amd/csrc/runtime.cpp).  version = major * 10000 + minor * 100 + patch.  Needs no GPU. */
+int mppgpu_comm_runtime_version(int *version);
 int mppgpu_comm_get_unique_id(void *id128);
 int mppgpu_comm_init(mppgpu_handle h, int nranks, int rank, const void *id128);
 /* The same global solve across several handles of ONE process: rank r = handles[r], every handle driven by its own host

@@ -70,6 +70,7 @@ SIGNATURES = {
     "mppgpu_get_comm_stats": (ct.c_int, [_h, _llp, _llp, _llp, _llp]),
     "mppgpu_get_pc_info": (ct.c_int, [_h, _ip, _ip, _ip]),
     "mppgpu_get_assembly_info": (ct.c_int, [_h, ct.c_int, _ip]),
+    "mppgpu_comm_runtime_version": (ct.c_int, [_ip]),
     "mppgpu_host_density": (ct.c_int, [ct.c_int, ct.c_int, _dp, _dp, _dp, _dp, _dp]),
     "mppgpu_host_internal_energy_enthalpy": (ct.c_int, [ct.c_int, ct.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
     "mppgpu_host_sat_relperm": (ct.c_int, [ct.c_int, _ip, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),

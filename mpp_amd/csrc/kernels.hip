@@ -83,12 +83,13 @@ __device__ __forceinline__ bool owns_row(const CellArrays &ca, size_t i) {
 // accumulation term only (RichardsODEPressureAccum, GoveqnRichardsODEPressureType.F90:1603-1634) -- PreSolve
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_accum(CellArrays ca, int n, double dtInv, double *out) {
+  MPP_STAGE_POW(ca.powtab);
   const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= (size_t)n) return;
   double acc = 0.0;
   if (owns_row(ca, i)) {
     Soil s = load_soil(ca, i);
-    Aux a = auxvar_compute<false>(s.sf, ca.eos, s, ca.P[i], frac_of(ca, i));
+    Aux a = auxvar_compute<false>(s.sf, ca.eos, s, ca.P[i], frac_of(ca, i), pt);
     double por, dpor;
     porosity(s, ca.por_slope != nullptr, ca.P[i], por, dpor);
     acc = por * a.den * a.sat * ca.vol[i] * dtInv;
@@ -119,6 +120,10 @@ __global__ __launch_bounds__(kBlock) void k_assemble_cols(ColsArgs a) {
   extern __shared__ __attribute__((aligned(16))) double cls_lds[];   // [7][ncls] when soil classes are in use
   constexpr bool RES = (MODE == 0 || MODE == 2), JAC = (MODE == 1 || MODE == 2);
   constexpr bool GEN = SAT_T < 0;   // general soil: per-cell saturation functions and / or the linear porosity model
+  constexpr bool NEEDS_POW = !(SAT_T == kSatVGHalf && DEN_T == 0);   // (van Genuchten m = 1/2 with TGDPB01: no real power at all)
+  __shared__ double pow_lds_[NEEDS_POW ? kPowTableDoubles : 1];
+  PowTab pt{nullptr, nullptr};
+  if (NEEDS_POW) pt = stage_pow_tables(a.cell.powtab, pow_lds_);
   const int c = blockIdx.x * kBlock + threadIdx.x;
   const bool valid = c < a.ncols;
   const bool classes = !GEN && a.soil_cls != nullptr;
@@ -220,7 +225,9 @@ __global__ __launch_bounds__(kBlock) void k_assemble_cols(ColsArgs a) {
         L.vol = 1.0;
         L.pref = L.slope = 0.0; L.sf = SAT_T;
       }
-      if (L.sf == kSatSBC && !classes) { L.pu = ca.sbc_pu[i]; L.ps = ca.sbc_ps[i]; L.b2 = ca.sbc_b2[i]; L.b3 = ca.sbc_b3[i]; }
+      if (SAT_T == kSatSBC && !classes && a.sbc_b) {   // one smoothing kind in the mesh: p_u and the one non-zero coefficient
+        L.pu = ldnt(ca.sbc_pu + i); L.b2 = ldnt(a.sbc_b + i); L.ps = L.b3 = 0.0;   // (p_s and the other one: formed at use)
+      } else if (L.sf == kSatSBC && !classes) { L.pu = ca.sbc_pu[i]; L.ps = ca.sbc_ps[i]; L.b2 = ca.sbc_b2[i]; L.b3 = ca.sbc_b3[i]; }
       else L.pu = L.ps = L.b2 = L.b3 = 0.0;
       L.accp = RES ? ldnt(a.accum_prev + i) : 0.0;
       L.act = ca.active ? ca.active[i] : (signed char)1;
@@ -254,6 +261,10 @@ __global__ __launch_bounds__(kBlock) void k_assemble_cols(ColsArgs a) {
         s.sat_res = L.sat_res; s.alpha = L.alpha; s.m = L.m; s.por = L.por;
         s.por_pref = L.pref; s.por_slope = L.slope; s.sf = L.sf;
         s.pu = L.pu; s.ps = L.ps; s.b2 = L.b2; s.b3 = L.b3;
+        if (SAT_T == kSatSBC && !classes && a.sbc_b) {
+          s.ps = -0.9 / s.alpha;                       // SatFunc_Set_SBC_*: ps = -0.9/alpha, the same IEEE quotient as on the host
+          if (a.sbc_b_is_b3) { s.b3 = L.b2; s.b2 = 0.0; }
+        }
         if (classes) {
           const double *t = cls_lds + L.cls;
           const int nc = a.ncls;
@@ -261,7 +272,7 @@ __global__ __launch_bounds__(kBlock) void k_assemble_cols(ColsArgs a) {
           s.m = (SAT_T == kSatVGHalf) ? 0.5 : t[2 * nc];
           if (SAT_T == kSatSBC) { s.pu = t[3 * nc]; s.ps = t[4 * nc]; s.b2 = t[5 * nc]; s.b3 = t[6 * nc]; }
         }
-        cur = auxvar_compute<JAC, SAT_T, DEN_T>(L.sf, ca.eos, s, Pi, L.frac);
+        cur = auxvar_compute<JAC, SAT_T, DEN_T>(L.sf, ca.eos, s, Pi, L.frac, pt);
         if (owned) {
           const double vol = L.vol;
           if (lin_por) {
@@ -326,6 +337,7 @@ __global__ __launch_bounds__(kBlock) void k_assemble_cols(ColsArgs a) {
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void k_auxvars(GenArgs a) {
   constexpr bool RES = (MODE == 0 || MODE == 2), JAC = (MODE == 1 || MODE == 2);
+  MPP_STAGE_POW(a.cell.powtab);
   const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= (size_t)a.n) return;
   const CellArrays &ca = a.cell;
@@ -333,7 +345,7 @@ __global__ __launch_bounds__(kBlock) void k_auxvars(GenArgs a) {
   Aux x = {};
   if (is_active(ca, i)) {
     Soil s = load_soil(ca, i);
-    x = auxvar_compute<JAC>(s.sf, ca.eos, s, ca.P[i], frac_of(ca, i));
+    x = auxvar_compute<JAC>(s.sf, ca.eos, s, ca.P[i], frac_of(ca, i), pt);
     if (owns_row(ca, i)) {
       const double vol = ca.vol[i];
       if (ca.por_slope) {   // linear porosity model: all three terms of RichardsODEPressureAccumDeriv (GE:1675-1677)
@@ -472,6 +484,7 @@ __global__ __launch_bounds__(kBlock) void k_flux_rows_ell(GenArgs a) {
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void k_bc(BcArgs a) {
   constexpr bool RES = (MODE == 0 || MODE == 2), JAC = (MODE == 1 || MODE == 2), OUT = (MODE == 4);
+  MPP_STAGE_POW(a.cell.powtab);
   const int j = blockIdx.x * kBlock + threadIdx.x;
   if (j >= a.ncond_cells) return;
   const CellArrays &ca = a.cell;
@@ -482,7 +495,7 @@ __global__ __launch_bounds__(kBlock) void k_bc(BcArgs a) {
   }
   Soil s = load_soil(ca, cell);
   const double Pc = a.trial_x ? fma(a.trial_a, a.trial_y[cell], a.trial_x[cell]) : ca.P[cell];
-  const Aux in = auxvar_compute<JAC>(s.sf, ca.eos, s, Pc, frac_of(ca, cell));
+  const Aux in = auxvar_compute<JAC>(s.sf, ca.eos, s, Pc, frac_of(ca, cell), pt);
   const bool side = a.side_f != nullptr;   // fluxes into per-condition-cell side arrays (complete-row column march)
   double f = (RES && !side) ? a.F[cell] : 0.0;
   double d = 0.0;
@@ -490,7 +503,7 @@ __global__ __launch_bounds__(kBlock) void k_bc(BcArgs a) {
     const int t = a.type[e];
     const int ctype = t & 0xffff, swap = t >> 16;
     const double pb = (ctype == kCondMassFlux) ? in.P : a.value[e];
-    const Aux bc = auxvar_compute<JAC>(s.sf, ca.eos, s, pb, ca.frac_liq);
+    const Aux bc = auxvar_compute<JAC>(s.sf, ca.eos, s, pb, ca.frac_liq, pt);
     ConnGeom g;
     g.Dq = a.Dq[e]; g.upweight = 0.0; g.dist_gravity = a.dgrav[e]; g.area = a.area[e];
     double Jup = 0.0, Jdn = 0.0, flux, jdn_outer;
@@ -547,14 +560,15 @@ __global__ __launch_bounds__(kBlock) void k_sinks(SinkArgs a) {
 
 __global__ __launch_bounds__(kBlock) void k_conn_flux(CellArrays ca, ConnArrays cn, const int *cup, const int *cdn,
                                                       int nc, double *out) {
+  MPP_STAGE_POW(ca.powtab);
   const int ic = blockIdx.x * kBlock + threadIdx.x;
   if (ic >= nc) return;
   const size_t u = cup[ic], d = cdn[ic];
   double flux = 0.0;
   if (is_active(ca, u) && is_active(ca, d)) {
     Soil su = load_soil(ca, u), sd = load_soil(ca, d);
-    Aux au = auxvar_compute<false>(su.sf, ca.eos, su, ca.P[u], frac_of(ca, u));
-    Aux ad = auxvar_compute<false>(sd.sf, ca.eos, sd, ca.P[d], frac_of(ca, d));
+    Aux au = auxvar_compute<false>(su.sf, ca.eos, su, ca.P[u], frac_of(ca, u), pt);
+    Aux ad = auxvar_compute<false>(sd.sf, ca.eos, sd, ca.P[d], frac_of(ca, d), pt);
     ConnGeom g;
     g.Dq = cn.Dq[ic]; g.upweight = cn.upw[ic]; g.dist_gravity = cn.dgrav[ic]; g.area = cn.area[ic];
     double j1, j2;
@@ -565,11 +579,12 @@ __global__ __launch_bounds__(kBlock) void k_conn_flux(CellArrays ca, ConnArrays 
 
 // soe auxvar fields filled by RichardsODEPressureSetDataInSOEAuxVar (GE:1170-1195)
 __global__ __launch_bounds__(kBlock) void k_cell_var(CellArrays ca, int n, int var_type, double *out) {
+  MPP_STAGE_POW(ca.powtab);
   const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= (size_t)n) return;
   Soil s = load_soil(ca, i);
   const double P = ca.P[i];
-  Aux a = auxvar_compute<false>(s.sf, ca.eos, s, P, frac_of(ca, i));
+  Aux a = auxvar_compute<false>(s.sf, ca.eos, s, P, frac_of(ca, i), pt);
   double v, por, dpor;
   porosity(s, ca.por_slope != nullptr, P, por, dpor);
   if (var_type == 608) v = a.sat;
@@ -2067,7 +2082,7 @@ void launch_accum(const CellArrays &cell, int n, double dtInv, double *out, hipS
 
 template <int SAT_T, int DEN_T>
 static void launch_cols_mode(int mode, const ColsArgs &a, dim3 grid, hipStream_t stream) {
-  const size_t lds = (SAT_T >= 0 && a.soil_cls) ? (size_t)7 * a.ncls * sizeof(double) : 0;   // the class table, staged per block
+  const size_t lds = (SAT_T >= 0 && a.soil_cls) ? (size_t)7 * a.ncls * sizeof(double) : 0;   // the class table, staged per block (<= 256 classes)
 #define COLS(M, F) hipLaunchKernelGGL((k_assemble_cols<M, SAT_T, DEN_T, F>), grid, dim3(kBlock), lds, stream, a)
   if (a.col_bc) {   // complete-row variant (grid.y == 1)
     if (mode == 0) COLS(0, true); else if (mode == 1) COLS(1, true); else COLS(2, true);

@@ -32,6 +32,7 @@ struct CellArrays {
   double frac_liq;                                   // frac_liq_sat of boundary auxvars (1.0) and of every cell when ...
   const double *frac_cell;                           // ... no per-cell values were set (VAR_FRAC_LIQ_SAT), else per cell
   EosParams eos;
+  const double *powtab;                              // the tables of fpow (fastpow.hpp) in device memory
 };
 
 struct ConnArrays {   // internal connections, precomputed geometry
@@ -53,6 +54,10 @@ struct ColsArgs {
   int ncls = 0;
   const double *lev_upw = nullptr, *lev_dgrav = nullptr;
   const double *lev_porvol = nullptr;   // likewise porosity x volume per level when every column agrees (constant-porosity soils)
+  // smoothed Brooks-Corey with per-cell soils, one smoothing kind in the whole mesh (bz2: b2 = 0, bz3: b3 = 0): the march streams
+  // p_u and the one non-zero coefficient (sbc_b) and forms p_s = -0.9 / alpha itself: 16 instead of 32 bytes per cell
+  const double *sbc_b = nullptr;
+  int sbc_b_is_b3 = 0;
   const double *accum_prev, *src;   // src: dense mass-rate source [kmol/s], nullptr if none
   double *F;             // residual out (MODE 0,2)
   double *val;           // CSR values out (MODE 1,2), level-major analytic layout
@@ -313,6 +318,7 @@ struct ThArgs {
   int nnzc;                                // entries of the cell pattern
   double dtInv;
   int ncols, nz, use_cols;                 // vertical-only grids: fused column march instead of passes 1 + 2
+  const double *powtab;                    // the tables of fpow (fastpow.hpp) in device memory
 };
 struct ThBcArgs {
   ThArgs t;

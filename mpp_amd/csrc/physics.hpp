@@ -13,7 +13,20 @@
 
 #include <cmath>
 
+#include "fastpow.hpp"
+
 namespace mpp {
+
+// x^y with a real exponent, x > 0, as the laws below need it: the table-driven fpow in device code (fastpow.hpp: ~100 instructions
+// against the ~270 of the library pow, < 1 ulp), the math library on the host (set-up code and the host entry points for drivers)
+__host__ __device__ inline double rpw(double x, double y, const PowTab &pt) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return fpow(x, y, pt);
+#else
+  (void)pt;
+  return pow(x, y);
+#endif
+}
 
 constexpr double kPressureRef = 101325.0;     // MultiPhysicsProbConstants.F90:199
 constexpr double kGravity = 9.80665;          // :201
@@ -106,7 +119,7 @@ __host__ __device__ inline EosParams make_eos(int density_type, double t_K) {
 
 // IFC-67 liquid water density [kmol/m3] and d/dp at the problem's temperature (EOSWaterMod.F90:181-344 with the
 // temperature-only terms taken from Ifc67T; same summation order as the formulation)
-__host__ __device__ inline void density_ifc67_at(const Ifc67T &f, double p, double &dwmol, double &dwp) {
+__host__ __device__ inline void density_ifc67_at(const Ifc67T &f, double p, double &dwmol, double &dwp, const PowTab &pt) {
   const double aa11 = 7.982692717e00, aa12 = -2.616571843e-2, aa17 = 2.074838328e-7, aa18 = 2.174020350e-8,
                aa19 = 1.105710498e-9, aa22 = 6.047626338e-14;
   const double a5 = 4.975858870e-2, a10 = 7.002753165e00, a11 = 2.995284926e-4;
@@ -118,7 +131,7 @@ __host__ __device__ inline void density_ifc67_at(const Ifc67T &f, double p, doub
   xx = sqrt(xx);
   const double zz = f.yy + xx;
   const double u0 = -5.0 / 17.0;
-  const double u1 = aa11 * a5 * pow(zz, u0);
+  const double u1 = aa11 * a5 * rpw(zz, u0, pt);
   const double u3 = aa17 + (2.0 * aa18 + 3.0 * aa19 * beta) * beta;
   const double ab = a10 + beta, ab2 = ab * ab;
   const double u5 = 1.0 / (ab2 * ab2);           // (a10 + beta)^(-4)
@@ -136,9 +149,9 @@ __host__ __device__ inline void density_ifc67_at(const Ifc67T &f, double p, doub
 // DEN_T: -1 decide at run time; 0 the density type is not IFC-67 (constant / TGDPB01); 1 it is IFC-67.
 // Compile-time pruning keeps the 60-register IFC-67 polynomial out of kernels that never need it.
 template <int DEN_T = -1>
-__host__ __device__ inline void density(const EosParams &e, double p, double &den, double &dden) {
+__host__ __device__ inline void density(const EosParams &e, double p, double &den, double &dden, const PowTab &pt) {
   if (DEN_T == 1) {
-    density_ifc67_at(e.ifc, p, den, dden);
+    density_ifc67_at(e.ifc, p, den, dden, pt);
     return;
   }
   if (e.density_type == kDenTGDPB01) {
@@ -157,7 +170,7 @@ __host__ __device__ inline void density(const EosParams &e, double p, double &de
     den = kDenH2O * kInvFMWH2O;
     dden = 0.0;
   } else if (DEN_T == -1) {
-    density_ifc67_at(e.ifc, p, den, dden);
+    density_ifc67_at(e.ifc, p, den, dden, pt);
   } else {
     den = dden = 0.0;  // unreachable: DEN_T == 0 promises constant or TGDPB01
   }
@@ -175,7 +188,7 @@ __host__ __device__ inline double bc_relperm(double Se, double pc_alpha) {
 // SAT_T >= 0 fixes the saturation function at compile time (the run-time `sat_func_rt` is then ignored)
 template <bool DERIV, int SAT_T = -1>
 __host__ __device__ inline void sat_relperm(int sat_func_rt, const Soil &s, double press, double frac_liq, double &sat,
-                                            double &dsat, double &kr, double &dkr) {
+                                            double &dsat, double &kr, double &dkr, const PowTab &pt) {
   const int sat_func = SAT_T == kSatVGHalf ? (int)kSatVG : (SAT_T >= 0 ? SAT_T : sat_func_rt);
   const double pc = press - kPressureRef;
   const double sat_res = s.sat_res, alpha = s.alpha;
@@ -208,12 +221,12 @@ __host__ __device__ inline void sat_relperm(int sat_func_rt, const Soil &s, doub
       } else {
         const double mm = s.m;
         const double nn = 1.0 / (1.0 - mm);  // SatFunc_Set_VG, SaturationFunction.F90:157
-        const double pc_alpha_n = pow(t, nn);
+        const double pc_alpha_n = rpw(t, nn, pt);
         const double one_plus = 1.0 + pc_alpha_n;
-        const double Se = pow(one_plus, -mm);
+        const double Se = rpw(one_plus, -mm, pt);
         sat = sat_res + (1.0 - sat_res) * Se;
         const double AA = pc_alpha_n / one_plus;
-        const double AAm = pow(AA, mm);
+        const double AAm = rpw(AA, mm, pt);
         const double BB = 1.0 - AAm;
         const double q = sqrt(Se);
         kr = q * BB * BB;
@@ -237,7 +250,7 @@ __host__ __device__ inline void sat_relperm(int sat_func_rt, const Soil &s, doub
     const double lambda = s.m;
     const double pc_alpha = -alpha * pc;
     if (pc_alpha > 1.0) {
-      const double Se = pow(pc_alpha, -lambda);
+      const double Se = rpw(pc_alpha, -lambda, pt);
       sat = sat_res + (1.0 - sat_res) * Se;
       const double ex = 2.5 + 2.0 / lambda;
       kr = bc_relperm(Se, pc_alpha);
@@ -257,7 +270,7 @@ __host__ __device__ inline void sat_relperm(int sat_func_rt, const Soil &s, doub
     const double ex = 2.5 + 2.0 / lambda;
     if (pc <= s.pu) {
       const double pc_alpha = -alpha * pc;
-      const double Se = pow(pc_alpha, -lambda);
+      const double Se = rpw(pc_alpha, -lambda, pt);
       sat = sat_res + (1.0 - sat_res) * Se;
       kr = bc_relperm(Se, pc_alpha);
       if (DERIV) {
@@ -269,7 +282,7 @@ __host__ __device__ inline void sat_relperm(int sat_func_rt, const Soil &s, doub
       const double deltaPc = pc - s.ps;
       const double Se = 1.0 + deltaPc * deltaPc * (s.b2 + deltaPc * s.b3);
       sat = sat_res + (1.0 - sat_res) * Se;
-      kr = pow(Se, ex);
+      kr = rpw(Se, ex, pt);
       if (DERIV) {
         const double dSe_dpc = deltaPc * (2 * s.b2 + 3 * deltaPc * s.b3);
         dsat = (1.0 - sat_res) * dSe_dpc;
@@ -285,12 +298,12 @@ __host__ __device__ inline void sat_relperm(int sat_func_rt, const Soil &s, doub
 // RichODEPressureAuxVarCompute (RichardsODEPressureAuxType.F90:237-294)
 template <bool DERIV, int SAT_T = -1, int DEN_T = -1>
 __host__ __device__ inline Aux auxvar_compute(int sat_func, const EosParams &e, const Soil &s, double press,
-                                              double frac_liq) {
+                                              double frac_liq, const PowTab &pt) {
   Aux a;
   a.P = press;
   a.dsat = 0.0; a.dkr = 0.0;
-  sat_relperm<DERIV, SAT_T>(sat_func, s, press, frac_liq, a.sat, a.dsat, a.kr, a.dkr);
-  density<DEN_T>(e, press, a.den, a.dden);
+  sat_relperm<DERIV, SAT_T>(sat_func, s, press, frac_liq, a.sat, a.dsat, a.kr, a.dkr, pt);
+  density<DEN_T>(e, press, a.den, a.dden, pt);
   return a;
 }
 

@@ -13,6 +13,17 @@
 #include <dlfcn.h>
 
 #include <cstring>
+#include <type_traits>
+
+// RCCL is bound at run time (dlopen: single-GPU use never needs the library), through hand-written prototypes.  When the
+// header is there at build time, the prototypes and the three enumerators this file passes as plain ints are checked against it
+// -- a 1-rank all-reduce is the identity for any datatype / operation, so no single-GPU test could catch a wrong constant.
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#define MPPGPU_RCCL_HEADER_VERSION NCCL_VERSION_CODE
+#else
+#define MPPGPU_RCCL_HEADER_VERSION 0
+#endif
 
 namespace mpp {
 
@@ -78,6 +89,24 @@ using fn_errstr = const char *(*)(int);
 constexpr int kNcclFloat64 = 8;  // ncclDataType_t ncclDouble (rccl.h)
 constexpr int kNcclSum = 0;      // ncclRedOp_t ncclSum
 constexpr int kNcclMax = 2;      // ncclRedOp_t ncclMax
+using fn_version = int (*)(int *);
+#if MPPGPU_RCCL_HEADER_VERSION
+static_assert((int)ncclDouble == kNcclFloat64 && (int)ncclFloat64 == kNcclFloat64, "ncclDouble");
+static_assert((int)ncclSum == kNcclSum && (int)ncclMax == kNcclMax, "ncclSum / ncclMax");
+static_assert(sizeof(ncclUniqueId) == sizeof(NcclUniqueId) && alignof(ncclUniqueId) == alignof(NcclUniqueId), "ncclUniqueId");
+static_assert(std::is_pointer<ncclComm_t>::value && sizeof(ncclResult_t) == sizeof(int) && sizeof(ncclDataType_t) == sizeof(int) &&
+                  sizeof(ncclRedOp_t) == sizeof(int), "handle and enum widths");
+static_assert(std::is_same<decltype(&ncclGetUniqueId), ncclResult_t (*)(ncclUniqueId *)>::value, "ncclGetUniqueId");
+static_assert(std::is_same<decltype(&ncclCommInitRank), ncclResult_t (*)(ncclComm_t *, int, ncclUniqueId, int)>::value, "ncclCommInitRank");
+static_assert(std::is_same<decltype(&ncclAllReduce),
+                           ncclResult_t (*)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t)>::value,
+              "ncclAllReduce");
+static_assert(std::is_same<decltype(&ncclSend), ncclResult_t (*)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t)>::value, "ncclSend");
+static_assert(std::is_same<decltype(&ncclRecv), ncclResult_t (*)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t)>::value, "ncclRecv");
+static_assert(std::is_same<decltype(&ncclCommDestroy), ncclResult_t (*)(ncclComm_t)>::value, "ncclCommDestroy");
+static_assert(std::is_same<decltype(&ncclCommAbort), ncclResult_t (*)(ncclComm_t)>::value, "ncclCommAbort");
+static_assert(std::is_same<decltype(&ncclGetVersion), ncclResult_t (*)(int *)>::value, "ncclGetVersion");
+#endif
 
 void *open_rccl() {
   const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
@@ -93,6 +122,18 @@ F sym(void *lib, const char *name) {
   if (!p) throw Error(std::string("RCCL symbol missing: ") + name);
   return reinterpret_cast<F>(p);
 }
+// the library that was loaded must be the generation the prototypes above were checked against: same major version as the
+// header (NCCL_VERSION_CODE = major * 10000 + minor * 100 + patch from 2.9 on), and 2.x at all
+int checked_version(void *lib) {
+  int v = 0;
+  const int rc = sym<fn_version>(lib, "ncclGetVersion")(&v);
+  if (rc != 0) throw Error("ncclGetVersion failed");
+  const int hdr = MPPGPU_RCCL_HEADER_VERSION;
+  if (v < 20000 || (hdr && v / 10000 != hdr / 10000))
+    throw Error("RCCL " + std::to_string(v) + " was loaded at run time, but the bindings were checked against rccl.h " + std::to_string(hdr) +
+                ": datatype / reduction enumerators and prototypes may differ");
+  return v;
+}
 void nccl_check(void *lib, int rc, const char *what) {
   if (rc == 0) return;
   const char *msg = "?";
@@ -101,8 +142,13 @@ void nccl_check(void *lib, int rc, const char *what) {
 }
 }  // namespace
 
+int Comm::runtime_version() {
+  void *l = open_rccl();
+  return checked_version(l);
+}
 void Comm::get_unique_id(void *id128) {
   void *l = open_rccl();
+  (void)checked_version(l);
   NcclUniqueId id;
   nccl_check(l, sym<fn_get_id>(l, "ncclGetUniqueId")(&id), "ncclGetUniqueId");
   std::memcpy(id128, id.internal, 128);
@@ -110,11 +156,13 @@ void Comm::get_unique_id(void *id128) {
 void Comm::init(int nr, int r, const void *id128) {
   if (comm) throw Error("communicator already initialised");
   lib = open_rccl();
+  version = checked_version(lib);
   NcclUniqueId id;
   std::memcpy(id.internal, id128, 128);
   nccl_check(lib, sym<fn_init_rank>(lib, "ncclCommInitRank")(&comm, nr, id, r), "ncclCommInitRank");
   nranks = nr;
   rank = r;
+  std::fprintf(stderr, "mppgpu: rank %d of %d: RCCL %d.%d.%d communicator ready\n", r, nr, version / 10000, (version / 100) % 100, version % 100);
 }
 void LocalGroup::abort() {
   std::lock_guard<std::mutex> lk(m);
@@ -221,7 +269,9 @@ void Comm::allreduce_max(double *dev, int count, hipStream_t s) {
 Comm::~Comm() {
   if (h_buf) (void)hipHostFree(h_buf);
   if (comm && lib) {
-    if (void *p = dlsym(lib, "ncclCommDestroy")) (void)reinterpret_cast<fn_destroy>(p)(comm);
+    // a communicator with a collective that never completed (a peer is gone) is aborted, not destroyed: ncclCommDestroy
+    // would wait for the queue to drain
+    if (void *p = dlsym(lib, poisoned ? "ncclCommAbort" : "ncclCommDestroy")) (void)reinterpret_cast<fn_destroy>(p)(comm);
   }
 }
 

@@ -135,6 +135,9 @@ struct Comm {
   double *h_buf = nullptr;     // pinned staging of the in-process path
   int nranks = 1, rank = 0;
   long long n_allreduce = 0, n_exchange = 0;   // collectives issued since the last mppgpu_reset_stats
+  int version = 0;             // RCCL's ncclGetVersion (checked against the header the bindings were verified with: runtime.cpp)
+  bool poisoned = false;       // a wait for this communicator's work timed out: abort it at destruction instead of draining it
+  static int runtime_version();   // loads RCCL, runs the version guard, returns ncclGetVersion
   bool active() const { return comm != nullptr || local != nullptr; }
   void init_local(std::shared_ptr<LocalGroup> g, int rank);
   static void get_unique_id(void *id128);
@@ -198,6 +201,8 @@ struct Options {
   bool ls_ahead = true;        // the line search's first reductions ride behind the Krylov solver's last update
   bool ls_spec = true;         // ... and the search's first trial point (the full step) is evaluated there too (LsAhead::spec)
   bool wide_xr = true;         // BiCGStab update kernel on a one-pair-per-lane grid (large vectors)
+  double collective_timeout = 900.0;   // seconds a rank waits for device scalars that depend on the other ranks (an all-reduce) before it
+                               // gives up with an error -- a peer that failed or never arrived must not leave this rank waiting forever
   bool host_poll = true;       // scalar read-backs: the reducing kernel publishes into pinned host memory and the host polls a
                                // sequence word (Solver::fetch_scalars); false: hipMemcpyAsync + hipStreamSynchronize
   bool soil_classes = true;    // column march: one byte per cell + a class table when the mesh has <= 256 distinct soil tuples

@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <numeric>
 #include <tuple>
@@ -97,12 +98,14 @@ struct Solver {
   std::vector<double> permx, permy, permz, por, alpha, lam, sat_res;
   std::vector<int> satf;
   int sat_func = -1;
+  int sbc_kind = 0;   // smoothed Brooks-Corey cells of the mesh: 2 all bz2, 3 all bz3, 0 none or both kinds
   bool mixed_satf = false;     // cells of one mesh use different saturation functions (satParams are per cell in the reference)
   bool all_vg_half = false;
   std::vector<double> por_pref, por_slope;   // POROSITY_LINEAR (PorosityFunctionMod.F90:75-96); empty = constant model
   DevBuf<signed char> d_satf;
   // byte savers of the column march (ColsArgs): soil classes and per-level connection geometry
   DevBuf<unsigned char> d_soil_cls;
+  DevBuf<double> d_powtab;
   DevBuf<double> d_cls_table, d_lev_upw, d_lev_dgrav, d_lev_porvol;
   int ncls = 0;
   bool lev_geo = false, lev_pv = false;
@@ -720,6 +723,7 @@ struct Solver {
       tri_scratch.alloc(64);
     }
     sc.alloc(S_COUNT); sc.zero(stream);
+    d_powtab.upload(host_pow_tables(), kPowTableDoubles, stream);   // fpow's tables (fastpow.hpp)
     fin_stage.alloc(kFinalizeStage); fin_counter.alloc(1); fin_counter.zero(stream);
     HIP_CHECK(hipHostMalloc(&h_sc, S_COUNT * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
     HIP_CHECK(hipHostMalloc(&h_seq, 64, hipHostMallocMapped | hipHostMallocCoherent));
@@ -852,18 +856,25 @@ struct Solver {
     if (!soil_dirty) return;
     if ((int)permx.size() != n || (int)por.size() != n || (int)alpha.size() != n)
       throw Error("soil properties are incomplete: set permeability, porosity and saturation function");
+    // (the per-cell passes of this function run on the host's cores: they were 4.5 of the 9 s the 105 M-cell grid took to set up)
     std::vector<double> a(n), b(n), c(n), d(n);
-    for (int i = 0; i < n; ++i) { const int e = int2ext[i]; a[i] = por[e]; b[i] = sat_res[e]; c[i] = alpha[e]; d[i] = lam[e]; }
+    host_parallel_for(n, [&](long long i) { const int e = int2ext[i]; a[i] = por[e]; b[i] = sat_res[e]; c[i] = alpha[e]; d[i] = lam[e]; });
     d_por.upload(a, stream); d_sat_res.upload(b, stream); d_alpha.upload(c, stream); d_m.upload(d, stream);
     if (vertical_only && columns && !th) {   // the column march streams porosity x volume as one operand
-      for (int i = 0; i < n; ++i) a[i] = a[i] * vol[int2ext[i]];
+      HIP_CHECK(hipStreamSynchronize(stream));   // (a is about to be reused)
+      host_parallel_for(n, [&](long long i) { a[i] = a[i] * vol[int2ext[i]]; });
       d_porvol.upload(a, stream);
       lev_pv = opt.level_geometry && por_slope.empty();   // ... or reads it per level when every column agrees
       std::vector<double> lp(nz, 0.0);
-      for (int k = 0; k < nz && lev_pv; ++k) {
-        lp[k] = a[cell_index(k, 0)];
-        for (int col = 1; col < ncols; ++col)
-          if (a[cell_index(k, col)] != lp[k]) { lev_pv = false; break; }
+      if (lev_pv) {
+        for (int k = 0; k < nz; ++k) lp[k] = a[cell_index(k, 0)];
+        std::atomic<bool> same{true};
+        host_parallel_for(ncols, [&](long long col) {
+          if (!same.load(std::memory_order_relaxed)) return;
+          for (int k = 0; k < nz; ++k)
+            if (a[cell_index(k, (int)col)] != lp[k]) { same = false; return; }
+        });
+        lev_pv = same;
       }
       if (lev_pv) d_lev_porvol.upload(lp, stream);
     }
@@ -878,7 +889,16 @@ struct Solver {
       d_por_pref.upload(a, stream); d_por_slope.upload(b, stream);
     } else { d_por_pref.release(); d_por_slope.release(); }
     bool any_sbc = false;
-    for (int i = 0; i < n && !any_sbc; ++i) any_sbc = map_sat_func(satf[i]) == kSatSBC;
+    sbc_kind = 0;
+    {   // which smoothing kinds occur: 2 = bz2 only, 3 = bz3 only, 0 = none or both
+      bool bz2 = false, bz3 = false;
+      for (int i = 0; i < n; ++i) {
+        bz2 |= satf[i] == MPPGPU_SAT_FUNC_SMOOTHED_BROOKS_COREY_BZ2;
+        bz3 |= satf[i] == MPPGPU_SAT_FUNC_SMOOTHED_BROOKS_COREY_BZ3;
+      }
+      any_sbc = bz2 || bz3;
+      if (bz2 != bz3) sbc_kind = bz2 ? 2 : 3;
+    }
     if (any_sbc) {
       // SatFunc_Set_SBC_bz2 / _bz3 (SaturationFunction.F90:260-372), ps = -0.9/alpha (:1409,1412)
       std::vector<double> pu(n, 0.0), ps(n, 0.0), b2(n, 0.0), b3(n, 0.0);
@@ -892,27 +912,32 @@ struct Solver {
     // internal connection geometry (RichardsMod.F90:236-272)
     {
       std::vector<double> Dq(nc_int, 0.0), upw(nc_int, 0.0), dg(nc_int, 0.0), ar(nc_int, 0.0);
-      for (int cidx = 0; cidx < nc; ++cidx) {
+      host_parallel_for(nc, [&](long long cidx) {   // (cext2int is one-to-one: no two connections write the same entry)
         const int u = cup_e[cidx], dn = cdn_e[cidx];
         const double pu[3] = {permx[u], permy[u], permz[u]}, pd[3] = {permx[dn], permy[dn], permz[dn]};
         ConnGeom g = make_conn_geom(true, carea[cidx], cdu[cidx], cdd[cidx], &cuv[3 * (size_t)cidx], pu, pd);
         const int ic = cext2int[cidx];
         Dq[ic] = g.Dq; upw[ic] = g.upweight; dg[ic] = g.dist_gravity; ar[ic] = g.area;
-      }
+      });
       d_Dq.upload(Dq, stream); d_upw.upload(upw, stream); d_dgrav.upload(dg, stream); d_area.upload(ar, stream);
       if (vertical_only && columns && !th) {   // ... and conductance x face area
-        for (int ic = 0; ic < nc_int; ++ic) Dq[ic] = Dq[ic] * ar[ic];
+        HIP_CHECK(hipStreamSynchronize(stream));   // (Dq is about to be reused)
+        host_parallel_for(nc_int, [&](long long ic) { Dq[ic] = Dq[ic] * ar[ic]; });
         d_DqA.upload(Dq, stream);
         // extruded grids: the connection below level k has the same upwind weight and gravity distance in every column
         lev_geo = opt.level_geometry && nz >= 2;
         std::vector<double> lu(nz, 0.0), lg(nz, 0.0);
-        for (int k = 1; k < nz && lev_geo; ++k) {
-          const int i0 = cell_index(k - 1, 0);
-          lu[k] = upw[i0]; lg[k] = dg[i0];
-          for (int col = 1; col < ncols; ++col) {
-            const int ic = cell_index(k - 1, col);
-            if (upw[ic] != lu[k] || dg[ic] != lg[k]) { lev_geo = false; break; }
-          }
+        if (lev_geo) {
+          for (int k = 1; k < nz; ++k) { const int i0 = cell_index(k - 1, 0); lu[k] = upw[i0]; lg[k] = dg[i0]; }
+          std::atomic<bool> same{true};
+          host_parallel_for(ncols, [&](long long col) {
+            if (!same.load(std::memory_order_relaxed)) return;
+            for (int k = 1; k < nz; ++k) {
+              const int ic = cell_index(k - 1, (int)col);
+              if (upw[ic] != lu[k] || dg[ic] != lg[k]) { same = false; return; }
+            }
+          });
+          lev_geo = same;
         }
         if (lev_geo) { d_lev_upw.upload(lu, stream); d_lev_dgrav.upload(lg, stream); }
       }
@@ -977,7 +1002,10 @@ struct Solver {
     soil_dirty = false;
   }
   // soil classes of the column march: at most 256 distinct (saturation function, sat_res, alpha, m) tuples in the mesh ->
-  // one byte per cell + a table (the smoothed Brooks-Corey coefficients are functions of the tuple)
+  // one byte per cell + a table (the smoothed Brooks-Corey coefficients are functions of the tuple), staged in LDS by every block.
+  // (Wider ids with the table read through the caches were built and measured in round 3: a wave then gathers up to 64
+  // different cache lines per parameter and level, 4.9 ms against the 2.7 ms of streaming the per-cell arrays at 4096 random
+  // classes, and the second code path cost the one-byte kernels registers: profiles/r03_kbench_laws.json, not kept.)
   void build_soil_classes() {
     ncls = 0;
     d_soil_cls.release();
@@ -997,11 +1025,11 @@ struct Solver {
       }
       last = (int)(it - keys.begin());
     }
-    for (int i = 0; i < n; ++i) {
+    host_parallel_for(n, [&](long long i) {
       const int e = int2ext[i];
       const Key k{satf[e], sat_res[e], alpha[e], lam[e]};
       cls[i] = (unsigned char)(std::lower_bound(keys.begin(), keys.end(), k) - keys.begin());
-    }
+    });
     ncls = (int)keys.size();
     std::vector<double> tab(7 * (size_t)ncls, 0.0);
     for (int q = 0; q < ncls; ++q) {
@@ -1048,6 +1076,7 @@ struct Solver {
     a.accum_prev = accum_prev.p; a.src = has_src ? d_src.p : nullptr;
     a.F = Fout; a.val = d_val.p; a.nnzc = nnzc; a.dtInv = 1.0 / dtime;
     a.ncols = ncols; a.nz = nz;
+    a.powtab = d_powtab.p;
     // the column march needs enough columns to fill the chip (one lane per column); otherwise the 3-pass kernels
     a.use_cols = (vertical_only && columns && opt.assembly != 0 && (opt.assembly == 1 || ncols >= 16384)) ? 1 : 0;
     b.ncond_cells = ncond_cells; b.cc_cell = d_cc_cell.p; b.cc_ptr = d_cc_ptr.p; b.type = d_bc_type.p;
@@ -1069,6 +1098,7 @@ struct Solver {
     ca.sat_func = sat_func; ca.all_vg_half = all_vg_half ? 1 : 0; ca.frac_liq = frac_liq;
     ca.frac_cell = d_frac.p;   // nullptr until VAR_FRAC_LIQ_SAT is set
     ca.eos = make_eos(density_type, temperature);
+    ca.powtab = d_powtab.p;
     return ca;
   }
   ConnArrays conns() const { return ConnArrays{d_Dq.p, d_upw.p, d_dgrav.p, d_area.p}; }
@@ -1094,6 +1124,7 @@ struct Solver {
     if (ncls > 0) { a.soil_cls = d_soil_cls.p; a.cls_table = d_cls_table.p; a.ncls = ncls; }
     if (lev_geo) { a.lev_upw = d_lev_upw.p; a.lev_dgrav = d_lev_dgrav.p; }
     if (lev_pv) a.lev_porvol = d_lev_porvol.p;
+    if (sbc_kind == 2) { a.sbc_b = d_b3.p; a.sbc_b_is_b3 = 1; } else if (sbc_kind == 3) a.sbc_b = d_b2.p;
     return a;
   }
   GenArgs gen_args(const double *P, double *Fout) const {
@@ -1565,10 +1596,10 @@ struct Solver {
   void fetch_scalars() {
     ++n_fetch;
     pub_arm = false;
-    if (!opt.host_poll) {
+    if (!opt.host_poll && !comm.comm) {
       HIP_CHECK(hipMemcpyAsync(h_sc, sc.p, S_COUNT * sizeof(double), hipMemcpyDeviceToHost, stream));
       HIP_CHECK(hipStreamSynchronize(stream));
-    } else {
+    } else {   // (with an RCCL communicator always: the wait is bounded, see wait_published)
       if (!pub_valid) launch_publish(-1, sc.p, h_sc_dev, h_seq_dev, ++pub_issued, stream);
       pub_valid = false;
       wait_published(pub_issued);
@@ -1579,9 +1610,18 @@ struct Solver {
     volatile unsigned long long *seq = h_seq;
     unsigned spins = 0;
     int idle_checks = 0;
+    const bool bounded = comm.comm != nullptr && opt.collective_timeout > 0.0;
+    const auto t0 = std::chrono::steady_clock::now();
     while (*seq < want) {
       __builtin_ia32_pause();
       if ((++spins & 0x3FFF) != 0) continue;
+      // Across ranks the scalars sit behind an all-reduce: when a peer has failed or never arrived it never completes.  The wait
+      // is bounded; the error ends this rank's call (and, in bench.py, the rank process: the launcher then stops the others)
+      if (bounded && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > opt.collective_timeout) {
+        comm.poisoned = true;
+        throw Error("rank " + std::to_string(comm.rank) + " of " + std::to_string(comm.nranks) + ": no result of a collective within " +
+                    std::to_string((int)opt.collective_timeout) + " s (option collective_timeout): a peer rank has failed or never arrived");
+      }
       // now and then: is the stream still alive?  An error ends the wait; a stream that has drained without the word
       // arriving (it cannot, short of a lost store) ends it after a bounded number of looks
       const hipError_t e = hipStreamQuery(stream);
@@ -2305,8 +2345,8 @@ struct Solver {
         HIP_CHECK(hipMemcpyAsync(sc.p + S_D2, &r, sizeof(double), hipMemcpyHostToDevice, stream));
         pub_valid = false;
         comm.allreduce_max(sc.p + S_D2, 1, stream);
-        HIP_CHECK(hipMemcpyAsync(&r, sc.p + S_D2, sizeof(double), hipMemcpyDeviceToHost, stream));
-        HIP_CHECK(hipStreamSynchronize(stream));
+        fetch_scalars();   // (a bounded wait when the communicator is RCCL)
+        r = h_sc[S_D2];
         if (reason > 0 && r > 0) reason = -(int)r;
       }
       *converged_reason = reason;
@@ -2981,6 +3021,7 @@ struct Solver {
     else if (key == "ls_ahead") opt.ls_ahead = num() != 0;
     else if (key == "wide_xr") opt.wide_xr = num() != 0;
     else if (key == "host_poll") opt.host_poll = num() != 0;
+    else if (key == "collective_timeout") opt.collective_timeout = num();
     else if (key == "ls_spec") opt.ls_spec = num() != 0;
     else if (key == "spmv_tpw") opt.spmv_tpw = (int)num();
     else if (key == "soil_classes") { opt.soil_classes = num() != 0; soil_dirty = true; }
@@ -3430,10 +3471,11 @@ int mppgpu_get_assembly_info(mppgpu_handle h, int n, int *info) {
   API_BEGIN(h)
   S.ensure_ready();
   const bool cols = S.use_cols() && !S.th && !S.thermal;
-  const int v[8] = {cols ? S.ncls : 0, cols && S.lev_geo ? 1 : 0, cols && S.lev_pv ? 1 : 0, cols && S.rows_complete() ? 1 : 0,
-                    cols ? S.pick_nseg() : 0, S.spmv_variant(), (S.opt.pc_type == 2 && !S.th && S.tri_lds()) ? 1 : 0,
-                    (int)std::min<long long>(S.spec_misses, 2147483647LL)};
-  for (int i = 0; i < n && i < 8; ++i) info[i] = v[i];
+  const int v[10] = {cols ? S.ncls : 0, cols && S.lev_geo ? 1 : 0, cols && S.lev_pv ? 1 : 0, cols && S.rows_complete() ? 1 : 0,
+                     cols ? S.pick_nseg() : 0, S.spmv_variant(), (S.opt.pc_type == 2 && !S.th && S.tri_lds()) ? 1 : 0,
+                     (int)std::min<long long>(S.spec_misses, 2147483647LL), S.opt.ilu_graph ? 1 : 0,
+                     (int)(S.box_graph.execs.size() + S.ilu_graph.execs.size())};
+  for (int i = 0; i < n && i < 10; ++i) info[i] = v[i];
   API_END()
 }
 int mppgpu_get_pc_info(mppgpu_handle h, int *path, int *launches, int *box_extents) {
@@ -3543,7 +3585,7 @@ int mppgpu_host_density(int density_type, int n, const double *p, const double *
   if (density_type < mpp::kDenConstant || density_type > mpp::kDenIFC67) throw mpp::Error("unknown density type " + std::to_string(density_type));
   for (int i = 0; i < n; ++i) {
     double d, dp, dt;
-    mpp::density_pt<true>(density_type, p[i], t_K[i], d, dp, dt);
+    mpp::density_pt<true>(density_type, p[i], t_K[i], d, dp, dt, mpp::PowTab{nullptr, nullptr});
     if (den) den[i] = d;
     if (dden_dp) dden_dp[i] = dp;
     if (dden_dt) dden_dt[i] = dt;
@@ -3556,7 +3598,7 @@ int mppgpu_host_internal_energy_enthalpy(int ie_type, int n, const double *p, co
   HOST_LAW_BEGIN
   if (ie_type != mpp::kIEConstant && ie_type != mpp::kIEIFC67) throw mpp::Error("unknown internal-energy type " + std::to_string(ie_type));
   for (int i = 0; i < n; ++i) {
-    const mpp::IEOut o = mpp::internal_energy_enthalpy<true>(ie_type, p[i], t_K[i], den[i], dden_dt[i], dden_dp[i]);
+    const mpp::IEOut o = mpp::internal_energy_enthalpy<true>(ie_type, p[i], t_K[i], den[i], dden_dt[i], dden_dp[i], mpp::PowTab{nullptr, nullptr});
     if (u) u[i] = o.U;
     if (h) h[i] = o.H;
     if (du_dt) du_dt[i] = o.dU_dT;
@@ -3576,7 +3618,7 @@ int mppgpu_host_sat_relperm(int n, const int *satfunc_type, const double *p, con
     s.sat_res = sat_res[i]; s.alpha = alpha[i]; s.m = lambda[i]; s.sf = sf;
     if (sf == mpp::kSatSBC) mpp::Solver::sbc_coefficients(satfunc_type[i], alpha[i], lambda[i], s.pu, s.ps, s.b2, s.b3);
     double a, da, k, dk;
-    mpp::sat_relperm<true>(sf, s, p[i], 1.0, a, da, k, dk);
+    mpp::sat_relperm<true>(sf, s, p[i], 1.0, a, da, k, dk, mpp::PowTab{nullptr, nullptr});
     if (sat) sat[i] = a;
     if (dsat_dp) dsat_dp[i] = da;
     if (kr) kr[i] = k;
@@ -3585,6 +3627,16 @@ int mppgpu_host_sat_relperm(int n, const int *satfunc_type, const double *p, con
   HOST_LAW_END
 }
 
+int mppgpu_comm_runtime_version(int *version) {
+  try {
+    const int v = mpp::Comm::runtime_version();
+    if (version) *version = v;
+    return 0;
+  } catch (const std::exception &e) {
+    g_create_error = e.what();
+    return 1;
+  }
+}
 int mppgpu_comm_get_unique_id(void *id128) {
   try {
     mpp::Comm::get_unique_id(id128);

@@ -54,6 +54,7 @@ __device__ __forceinline__ Aux heat_view(const ThAux &x) { return Aux{x.P, x.kr,
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void k_th_aux(ThArgs a) {
   constexpr bool JAC = (MODE == 2), PRE = (MODE == 3);
+  MPP_STAGE_POW(a.powtab);
   const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
   const size_t n = (size_t)a.n;
   if (i >= n) return;
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(kBlock) void k_th_aux(ThArgs a) {
   const Soil s = th_load_soil(a, i);
   const ThSoil ts{a.tc_wet[i], a.tc_dry[i], a.talpha[i]};
   const double P = a.x[i], T = a.x[n + i];
-  const ThAux x = th_auxvar_compute<true>(a.sat_func, a.density_type, a.ie_type, s, ts, P, T, true);  // every cell (GE:942-961)
+  const ThAux x = th_auxvar_compute<true>(a.sat_func, a.density_type, a.ie_type, s, ts, P, T, true, pt);  // every cell (GE:942-961)
   if (!PRE) {
     a.kr[i] = x.kr; a.dkr[i] = x.dkr;
     a.den_m[i] = x.den_m; a.ddenP_m[i] = x.ddenP_m; a.ddenT_m[i] = x.ddenT_m;
@@ -183,6 +184,7 @@ struct ThRowAcc {      // what a row accumulates before it is written
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void k_th_cols(ThArgs a) {
   constexpr bool JAC = (MODE == 2);
+  MPP_STAGE_POW(a.powtab);
   const int c = blockIdx.x * kBlock + threadIdx.x;
   if (c >= a.ncols) return;
   const int nz = a.nz;
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(kBlock) void k_th_cols(ThArgs a) {
       const Soil s = th_load_soil(a, i);
       const ThSoil ts{a.tc_wet[i], a.tc_dry[i], a.talpha[i]};
       const double P = a.x[i], T = a.x[n + i];
-      cur = th_auxvar_compute<true>(a.sat_func, a.density_type, a.ie_type, s, ts, P, T, true);
+      cur = th_auxvar_compute<true>(a.sat_func, a.density_type, a.ie_type, s, ts, P, T, true, pt);
       const double vol = a.vol[i], dsoil = a.den_soil[i], csoil = a.heat_cap[i];
       double fm = 0.0, fe = 0.0;
       rc.aPP = rc.aPT = rc.aTP = rc.aTT = 1.0;
@@ -274,6 +276,7 @@ template <int MODE>
 __global__ __launch_bounds__(kBlock) void k_th_bc(ThBcArgs b) {
   constexpr bool JAC = (MODE == 2);
   const ThArgs &a = b.t;
+  MPP_STAGE_POW(a.powtab);
   const int j = blockIdx.x * kBlock + threadIdx.x;
   if (j >= b.ncond_cells) return;
   const size_t cell = b.cc_cell[j];
@@ -281,7 +284,7 @@ __global__ __launch_bounds__(kBlock) void k_th_bc(ThBcArgs b) {
   if (!th_active(a, cell)) return;
   const Soil s = th_load_soil(a, cell);
   const ThSoil ts{a.tc_wet[cell], a.tc_dry[cell], a.talpha[cell]};
-  const ThAux in = th_auxvar_compute<true>(a.sat_func, a.density_type, a.ie_type, s, ts, a.x[cell], a.x[n + cell], true);
+  const ThAux in = th_auxvar_compute<true>(a.sat_func, a.density_type, a.ie_type, s, ts, a.x[cell], a.x[n + cell], true, pt);
   double fm = a.F[cell], fe = a.F[n + cell];
   double dPP = 0.0, dTP = 0.0, dTT = 0.0;
   for (int e = b.cc_ptr[j]; e < b.cc_ptr[j + 1]; ++e) {
@@ -291,14 +294,14 @@ __global__ __launch_bounds__(kBlock) void k_th_bc(ThBcArgs b) {
     g.Dq = b.Dq[e]; g.upweight = 0.0; g.dist_gravity = b.dgrav[e]; g.area = b.area[e];
     if (!heat) {
       const double pb = (ctype == kCondMassFlux) ? in.P : b.value[e];
-      const ThAux bc = th_auxvar_compute<true>(a.sat_func, a.density_type, a.ie_type, s, ts, pb, b.other[e], true);
+      const ThAux bc = th_auxvar_compute<true>(a.sat_func, a.density_type, a.ie_type, s, ts, pb, b.other[e], true, pt);
       double Jup = 0.0, Jdn = 0.0, flux, jdn_outer;
       if (!swap) { flux = richards_flux<JAC>(mass_view(bc), mass_view(in), g, ctype, Jup, Jdn); jdn_outer = Jdn; }
       else { flux = -richards_flux<JAC>(mass_view(in), mass_view(bc), g, ctype, Jup, Jdn); jdn_outer = -Jup; }
       fm += flux;
       if (JAC) dPP += -jdn_outer;
     } else {
-      const ThAux bc = th_auxvar_compute<true>(a.sat_func, a.density_type, a.ie_type, s, ts, b.other[e], b.value[e], false);
+      const ThAux bc = th_auxvar_compute<true>(a.sat_func, a.density_type, a.ie_type, s, ts, b.other[e], b.value[e], false, pt);
       double Eup = 0.0, Edn = 0.0, t1, t2;
       const double mflux = richards_flux<JAC>(heat_view(bc), heat_view(in), g, ctype, Eup, Edn);
       const double du = b.du[e], dd = b.dd[e];

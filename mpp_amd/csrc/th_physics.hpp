@@ -39,7 +39,7 @@ __host__ __device__ inline double rpow(double x, int n) {
 }
 // IFC-67 density [kmol/m3] with both derivatives (EOSWaterMod.F90:181-344); t in degC
 template <bool LIB = false>
-__host__ __device__ inline void density_ifc67_pt(double t, double p, double &dwmol, double &dwp, double &dwt) {
+__host__ __device__ inline void density_ifc67_pt(double t, double p, double &dwmol, double &dwp, double &dwt, const PowTab &pt) {
   const double aa11 = 7.982692717e00, aa12 = -2.616571843e-2, aa13 = 1.522411790e-3, aa14 = 2.284279054e-2,
                aa15 = 2.421647003e02, aa16 = 1.269716088e-10, aa17 = 2.074838328e-7, aa18 = 2.174020350e-8,
                aa19 = 1.105710498e-9, aa20 = 1.293441934e01, aa21 = 1.308119072e-5, aa22 = 6.047626338e-14;
@@ -59,7 +59,7 @@ __host__ __device__ inline void density_ifc67_pt(double t, double p, double &dwm
   xx = sqrt(xx);
   const double zz = yy + xx;
   const double u0 = -5.0 / 17.0;
-  const double u1 = aa11 * a5 * pow(zz, u0);
+  const double u1 = aa11 * a5 * (LIB ? pow(zz, u0) : rpw(zz, u0, pt));
   const double u2 = 1.0 / (a8 + rpow<LIB>(theta, 11));
   const double u3 = aa17 + (2.0 * aa18 + 3.0 * aa19 * beta) * beta;
   const double u4 = 1.0 / (a7 + theta18 * theta);
@@ -86,7 +86,8 @@ __host__ __device__ inline void density_ifc67_pt(double t, double p, double &dwm
 
 // Density(p, t_K, type) -> den [kmol/m3], dden_dp, dden_dT (EOSWaterMod.F90:38-178)
 template <bool LIB = false>
-__host__ __device__ inline void density_pt(int density_type, double p, double t_K, double &den, double &dden_dp, double &dden_dT) {
+__host__ __device__ inline void density_pt(int density_type, double p, double t_K, double &den, double &dden_dp, double &dden_dT,
+                                           const PowTab &pt) {
   if (density_type == kDenConstant) {
     den = kDenH2O / kFMWH2O; dden_dp = 0.0; dden_dT = 0.0;
   } else if (density_type == kDenTGDPB01) {
@@ -109,13 +110,13 @@ __host__ __device__ inline void density_pt(int density_type, double p, double t_
     dden_dT = (ddent_dt * kappa + dent * dkappa_dt) / kFMWH2O;
     dden_dp = (0.0 * kappa + dent * dkappa_dp) / kFMWH2O;
   } else {
-    density_ifc67_pt<LIB>(t_K - 273.15, p, den, dden_dp, dden_dT);
+    density_ifc67_pt<LIB>(t_K - 273.15, p, den, dden_dp, dden_dT, pt);
   }
 }
 
 // EnthalpyIFC67 (EOSWaterMod.F90:346-566): hw [J/kmol], d/dp, d/dT; t in degC
 template <bool LIB = false>
-__host__ __device__ inline void enthalpy_ifc67(double t, double p, double &hw, double &hwp, double &hwt) {
+__host__ __device__ inline void enthalpy_ifc67(double t, double p, double &hw, double &hwp, double &hwt, const PowTab &pt) {
   const double aa[23] = {
       6.824687741e03, -5.422063673e02, -2.096666205e04, 3.941286787e04, -6.733277739e04, 9.902381028e04,
       -1.093911774e05, 8.590841667e04, -4.511168742e04, 1.418138926e04, -2.017271113e03, 7.982692717e00,
@@ -138,7 +139,7 @@ __host__ __device__ inline void enthalpy_ifc67(double t, double p, double &hw, d
   xx = sqrt(xx);
   const double zz = yy + xx;
   const double u0 = -5.0 / 17.0;
-  const double u1 = aa[11] * a5 * pow(zz, u0);
+  const double u1 = aa[11] * a5 * (LIB ? pow(zz, u0) : rpw(zz, u0, pt));
   const double ypt = 6.0 * a2 * rpow<LIB>(theta, -7) - 2.0 * a1 * theta;
   const double utheta = 1.0 / theta;
   const double term1 = aa[0] * theta;
@@ -205,7 +206,8 @@ struct IEOut { double U, H, dU_dT, dH_dT, dU_dP, dH_dP; };
 
 // InternalEnergyAndEnthalpy (EOSWaterMod.F90:589-707); den and its derivatives in kg m^-3
 template <bool LIB = false>
-__host__ __device__ inline IEOut internal_energy_enthalpy(int itype, double P, double t_K, double den, double dden_dT, double dden_dP) {
+__host__ __device__ inline IEOut internal_energy_enthalpy(int itype, double P, double t_K, double den, double dden_dT, double dden_dP,
+                                                          const PowTab &pt) {
   IEOut o;
   if (itype == kIEConstant) {
     const double u0 = (double)4.217f * 1.e3;   // `4.217 * 1.d3` in the reference: a single-precision literal
@@ -218,7 +220,7 @@ __host__ __device__ inline IEOut internal_energy_enthalpy(int itype, double P, d
     o.dU_dP = dU_dP; o.dH_dP = dH_dP * kFMWH2O;
   } else {
     double H, dH_dP, dH_dT;
-    enthalpy_ifc67<LIB>(t_K - 273.15, P, H, dH_dP, dH_dT);
+    enthalpy_ifc67<LIB>(t_K - 273.15, P, H, dH_dP, dH_dT, pt);
     const double dm = den / kFMWH2O;
     o.H = H; o.dH_dP = dH_dP; o.dH_dT = dH_dT;
     o.U = H - P / dm;
@@ -243,22 +245,25 @@ struct ThSoil { double tc_wet, tc_dry, talpha; };
 // RichODEPressureAuxVarCompute with the cell temperature + ThermEnthalpyAuxVarCompute
 template <bool DERIV>
 __host__ __device__ inline ThAux th_auxvar_compute(int sat_func, int density_type, int ie_type, const Soil &s, const ThSoil &ts,
-                                                   double P, double T, bool mass_view) {
+                                                   double P, double T, bool mass_view, const PowTab &pt) {
   ThAux a;
   a.P = P; a.T = T;
   a.dsat = 0.0; a.dkr = 0.0;
-  sat_relperm<true>(sat_func, s, P, 1.0, a.sat, a.dsat, a.kr, a.dkr);
+  sat_relperm<true>(sat_func, s, P, 1.0, a.sat, a.dsat, a.kr, a.dkr, pt);
   const double Pc = (P < kPressureRef) ? kPressureRef : P;
-  density_pt(density_type, Pc, T, a.den_e, a.ddenP_e, a.ddenT_e);
+  density_pt(density_type, Pc, T, a.den_e, a.ddenP_e, a.ddenT_e, pt);
   a.den_m = a.ddenP_m = a.ddenT_m = 0.0;
   if (mass_view) {
     if (Pc == P) { a.den_m = a.den_e; a.ddenP_m = a.ddenP_e; a.ddenT_m = a.ddenT_e; }   // same arguments, same value
-    else density_pt(density_type, P, T, a.den_m, a.ddenP_m, a.ddenT_m);
+    else density_pt(density_type, P, T, a.den_m, a.ddenP_m, a.ddenT_m, pt);
   }
-  const IEOut ie = internal_energy_enthalpy(ie_type, Pc, T, a.den_e * kFMWH2O, a.ddenT_e * kFMWH2O, a.ddenP_e * kFMWH2O);
+  const IEOut ie = internal_energy_enthalpy(ie_type, Pc, T, a.den_e * kFMWH2O, a.ddenT_e * kFMWH2O, a.ddenP_e * kFMWH2O, pt);
   a.ul = ie.U; a.hl = ie.H; a.dul_dT = ie.dU_dT; a.dhl_dT = ie.dH_dT; a.dul_dP = ie.dU_dP; a.dhl_dP = ie.dH_dP;
-  const double Kel = pow(a.sat + 1.e-6, ts.talpha);
-  const double dKel_dp = ts.talpha * pow(a.sat + 1.e-6, ts.talpha - 1.0) * a.dsat;
+  // Kersten number (sat + 1e-6)^alpha and its derivative alpha (sat + 1e-6)^(alpha - 1) dsat/dP: the second real power of the
+  // reference (ThermalEnthalpySoilAuxType.F90:268-272) is the first one divided by its base
+  const double kbase = a.sat + 1.e-6;
+  const double Kel = rpw(kbase, ts.talpha, pt);
+  const double dKel_dp = ts.talpha * (Kel / kbase) * a.dsat;
   a.tc = ts.tc_wet * Kel + ts.tc_dry * (1.0 - Kel);
   a.dtc_dP = (ts.tc_wet - ts.tc_dry) * dKel_dp;
   (void)DERIV;

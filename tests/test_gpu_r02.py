@@ -279,6 +279,33 @@ def test_soil_classes_and_level_geometry_change_no_bit(sf, lam, nseg):
         assert np.array_equal(out[key][0], out[0, 0][0]) and np.array_equal(out[key][1], out[0, 0][1]), key
 
 
+@pytest.mark.parametrize("sf", [C.SAT_FUNC_VAN_GENUCHTEN, C.SAT_FUNC_SMOOTHED_BROOKS_COREY_BZ3, C.SAT_FUNC_SMOOTHED_BROOKS_COREY_BZ2],
+                         ids=["vg", "sbc_bz3", "sbc_bz2"])
+@pytest.mark.parametrize("nclasses", [700, 5000])
+def test_more_than_256_soil_tuples_stream_the_per_cell_arrays(sf, nclasses):
+    """soil maps with more than 256 distinct parameter tuples get no class table: the per-cell parameter streams are used (for
+    smoothed Brooks-Corey they carry p_u and the one non-zero smoothing coefficient, and p_s = -0.9 / alpha is formed on the
+    device) -- the oracle's residual and Jacobian, and the same bits whether classes are asked for or not"""
+    rng = np.random.default_rng(33)
+    ncols, nz = 200, 31
+    prob = P.celia1990(ncols=ncols, nz=nz, perm_mult=np.exp(0.5 * rng.standard_normal(ncols)))
+    n = prob.mesh.ncells_local
+    ta, tl, ts = 1.0 + 0.2 * rng.random(nclasses), 0.4 + 0.3 * rng.random(nclasses), 0.2 + 0.1 * rng.random(nclasses)
+    pick = rng.integers(0, nclasses, n)
+    prob.satfunc_type = np.full(n, sf, dtype=np.int32)
+    prob.alpha = prob.alpha * ta[pick]; prob.lam = tl[pick]; prob.sat_res = ts[pick]
+    x = prob.press_ic + rng.uniform(0, 1.2e5, n)
+    base = {"assembly": "columns", "nseg": 1, "ksp_type": "bcgs", "pc_type": "bjacobi"}
+    _operator_parity(prob, x, base)
+    out = {}
+    for cls in (0, 1):
+        g = P.to_gpu(prob, dict(base, soil_classes=cls))
+        g.soe.SetDtime(prob.dt); g.soe.PreSolve()
+        out[cls] = (g.soe.ComputeResidual(x), g.soe.ComputeJacobian(x)[2])
+        assert g.soe.assembly_info()["soil_classes"] == 0
+    assert np.array_equal(out[1][0], out[0][0]) and np.array_equal(out[1][1], out[0][1])
+
+
 def test_level_geometry_falls_back_when_columns_differ():
     """one column with a different layer spacing: the per-connection streams are used (and the answer is the oracle's)"""
     prob, x = _hetero(ncols=70, nz=19, seed=12)

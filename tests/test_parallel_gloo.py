@@ -193,3 +193,23 @@ def test_bench_launcher_time_limit():
     r = _run_bench("--gpus", "2", "--dry-run-ranks", "--nx", "4", "--ny", "4", "--fail-rank", "-2", "--launch-timeout", "3")
     assert time.time() - t0 < 60
     assert r.returncode == 124 and "launcher time limit" in r.stderr
+
+
+def test_rccl_binding_guard_runs_without_a_gpu():
+    """the run-time half of the RCCL binding guard (the build-time half are the static_asserts of mpp_amd/csrc/runtime.cpp against
+    <rccl/rccl.h>: enumerator values and prototypes): the library that dlopen finds must report a 2.x version of the same major
+    as that header.  A one-rank all-reduce is the identity for every datatype and operation, so this -- not a single-GPU solve --
+    is what catches a wrong constant"""
+    import ctypes as ct
+    from mpp_amd import _lib
+    L = _lib.lib()
+    v = ct.c_int(0)
+    rc = L.mppgpu_comm_runtime_version(ct.byref(v))
+    if rc != 0 and b"cannot load RCCL" in L.mppgpu_last_error(None):
+        pytest.skip("no RCCL on this machine")
+    assert rc == 0, L.mppgpu_last_error(None)
+    assert 20000 <= v.value < 30000
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mpp_amd", "csrc", "runtime.cpp")).read()
+    for what in ("ncclDouble == kNcclFloat64", "ncclSum == kNcclSum", "ncclMax == kNcclMax", "decltype(&ncclCommInitRank)",
+                 "decltype(&ncclAllReduce)"):
+        assert what in src

@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="extra mppgpu_set_option pairs")
     ap.add_argument("--rtol-sweep", default="", help="comma-separated ksp_rtol values solved one after the other on the same problem "
                                                      "(time, iterations and error against the manufactured solution for each)")
+    ap.add_argument("--no-events", action="store_true", help="no HIP-event timing of the kernel classes")
+    ap.add_argument("--dump-maps", default="", help="write /proc/self/maps there before the timed step (to attribute stack frames)")
     a = ap.parse_args()
     t0 = time.perf_counter()
     tp = P.thermal_mms(3, a.n, a.n, a.n, replicate_reference_soil_indexing=False)
@@ -49,8 +51,10 @@ def main():
     t_setup = time.perf_counter() - t0
     g.soe.StepDT(tp.dt, 1)          # warm-up (ILU analysis, allocations)
     g.soe.PreStepDT()
-    g.soe.SetOption("profile", 1)
+    g.soe.SetOption("profile", 0 if a.no_events else 1)
     g.soe.reset_stats()
+    if a.dump_maps:
+        open(a.dump_maps, "w").write(open("/proc/self/maps").read())
     g.soe.synchronize()
     t0 = time.perf_counter()
     conv, _ = g.soe.StepDT(tp.dt, 1)
