@@ -265,7 +265,9 @@ __host__ __device__ inline void sat_relperm(int sat_func_rt, const Soil &s, doub
     }
     kr = frac_liq * kr;  // SaturationFunction.F90:987-988 (Brooks-Corey only)
     if (DERIV) dkr = frac_liq * dkr;
-  } else {  // smoothed Brooks-Corey
+  } else {  // smoothed Brooks-Corey (SaturationFunction.F90:1027-1140): Brooks-Corey below p_u, a cubic in (pc - p_s) up to p_s
+    // (one call site for the two branches' real powers, selected per lane, was measured: 2.29 / 2.58 ms against 2.21 / 2.34 ms
+    // for the residual + Jacobian march with class-table / per-cell soils -- most waves sit on one branch; not kept)
     const double lambda = s.m;
     const double ex = 2.5 + 2.0 / lambda;
     if (pc <= s.pu) {

@@ -283,6 +283,20 @@ int host_threads() {
     int cores = (int)std::thread::hardware_concurrency();
     cpu_set_t set;
     if (sched_getaffinity(0, sizeof(set), &set) == 0) cores = CPU_COUNT(&set);
+    // a container's CPU quota (cgroup v2 cpu.max / v1 cfs quota): more runnable threads than the quota get throttled in whole
+    // scheduler periods, which costs more than the extra threads bring
+    if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+      char q[32] = {0};
+      long long period = 0;
+      if (std::fscanf(f, "%31s %lld", q, &period) == 2 && std::strcmp(q, "max") != 0 && period > 0)
+        cores = std::min(cores, (int)std::max(1LL, std::atoll(q) / period));
+      std::fclose(f);
+    } else {
+      long long quota = -1, period = 0;
+      if (FILE *g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (std::fscanf(g, "%lld", &quota) != 1) quota = -1; std::fclose(g); }
+      if (FILE *g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (std::fscanf(g, "%lld", &period) != 1) period = 0; std::fclose(g); }
+      if (quota > 0 && period > 0) cores = std::min(cores, (int)std::max(1LL, quota / period));
+    }
     return std::max(1, std::min(cores, 32));
   }();
   return n;

@@ -459,20 +459,33 @@ struct Solver {
     return t * 64 * nz + lev * tw + (col & 63);
   }
 
+  // The set-up passes over the caller's cells and connections run on the host's cores (host_parallel_for): where the serial
+  // code relied on the order of its loop, the parallel one fills with relaxed atomics in any order and then sorts each cell's short
+  // list by connection number, so the results are the same for any number of threads.
+  static int fetch_inc(int *p) { return __atomic_fetch_add(p, 1, __ATOMIC_RELAXED); }
+  static void put(int *p, int v) { __atomic_store_n(p, v, __ATOMIC_RELAXED); }
+
   void detect_columns() {
     // vertical chains of the internal connection set (any cell numbering)
     std::vector<int> nxt(n, -1), below(n, -1);
     std::vector<char> is_vert(nc, 0);
-    bool ok = true;
-    for (int c = 0; c < nc && ok; ++c) {
-      const double ux = cuv[3 * (size_t)c], uy = cuv[3 * (size_t)c + 1], uz = cuv[3 * (size_t)c + 2];
-      if (std::fabs(uz) > 0.5 * std::sqrt(ux * ux + uy * uy + uz * uz)) {
-        is_vert[c] = 1;
-        if (nxt[cup_e[c]] != -1 || below[cdn_e[c]] != -1) ok = false;
-        nxt[cup_e[c]] = cdn_e[c];
-        below[cdn_e[c]] = cup_e[c];
+    std::atomic<bool> ok{true};
+    std::atomic<long long> nvert{0};
+    host_parallel_ranges(nc, [&](long long c0, long long c1) {
+      long long mine = 0;
+      for (long long c = c0; c < c1; ++c) {
+        const double ux = cuv[3 * (size_t)c], uy = cuv[3 * (size_t)c + 1], uz = cuv[3 * (size_t)c + 2];
+        if (std::fabs(uz) > 0.5 * std::sqrt(ux * ux + uy * uy + uz * uz)) {
+          is_vert[c] = 1;
+          ++mine;
+          put(&nxt[cup_e[c]], cdn_e[c]); put(&below[cdn_e[c]], cup_e[c]);   // (plain stores; a cell with two links is found below)
+        }
       }
-    }
+      nvert += mine;
+    });
+    host_parallel_for(nc, [&](long long c) {   // two vertical links at one cell: one of them lost its store
+      if (is_vert[c] && (nxt[cup_e[c]] != cdn_e[c] || below[cdn_e[c]] != cup_e[c])) ok = false;
+    });
     ext2int.assign(n, -1);
     int2ext.assign(n, -1);
     columns = false;
@@ -483,50 +496,65 @@ struct Solver {
       const int nchains = (int)starts.size();
       if (nchains > 0 && n % nchains == 0) {
         const int len = n / nchains;
-        bool equal = true;
+        std::atomic<bool> equal{true};
         std::vector<int> lev(n, -1), colof(n, -1);
-        for (int ch = 0; ch < nchains && equal; ++ch) {
+        host_parallel_for(nchains, [&](long long ch) {
+          if (!equal.load(std::memory_order_relaxed)) return;
           int cur = starts[ch], k = 0;
-          while (cur != -1 && k <= len) { lev[cur] = k; colof[cur] = ch; cur = nxt[cur]; ++k; }
+          while (cur != -1 && k <= len) { lev[cur] = k; colof[cur] = (int)ch; cur = nxt[cur]; ++k; }
           if (k != len) equal = false;
-        }
+        });
         if (equal) {
-          columns = true; ncols = nchains; nz = len;
-          for (int i = 0; i < n; ++i) {
-            if (lev[i] < 0) { columns = false; break; }
+          ncols = nchains; nz = len;
+          std::atomic<bool> all{true};
+          host_parallel_for(n, [&](long long i) {
+            if (lev[i] < 0) { all = false; return; }
             ext2int[i] = cell_index(lev[i], colof[i]);
-          }
+          });
+          columns = all;
         }
       }
     }
     if (!columns) {  // every cell its own block: identity layout
       ncols = n; nz = 1;
-      for (int i = 0; i < n; ++i) ext2int[i] = i;
+      host_parallel_for(n, [&](long long i) { ext2int[i] = (int)i; });
     }
-    identity_perm = true;
-    for (int i = 0; i < n; ++i) { int2ext[ext2int[i]] = i; identity_perm &= (ext2int[i] == i); }
+    {
+      std::atomic<bool> ident{true};
+      host_parallel_for(n, [&](long long i) { int2ext[ext2int[i]] = (int)i; if (ext2int[i] != i) ident = false; });
+      identity_perm = ident;
+    }
     // internal connection numbering: chain links at the index of their lower cell, the rest appended
     cext2int.assign(nc, -1);
-    int nlat = 0;
-    if (columns) {
-      // lateral connections: the j-th one whose upwind cell is u sits at n + j*n + u, so that the rows of a column tile
-      // (consecutive u) read consecutive geometry entries whichever end of the connection they are (holes carry zeros)
-      std::vector<int> seen(n, 0);
-      int jmax = 0;
-      for (int c = 0; c < nc; ++c) {
+    if (columns && nvert == nc) {   // nothing but chain links (the soil-column grids)
+      host_parallel_for(nc, [&](long long c) { cext2int[c] = ext2int[cup_e[c]]; });
+      nc_int = n;
+      vertical_only = true;
+    } else if (columns) {
+      // lateral connections: the j-th one (in the caller's order) whose upwind cell is u sits at n + j*n + u, so that the rows
+      // of a column tile (consecutive u) read consecutive geometry entries whichever end of the connection they are (holes
+      // carry zeros).  j = the rank of the connection in its upwind cell's list: lists filled in any order, then sorted.
+      std::vector<int> ptr((size_t)n + 1, 0);
+      host_parallel_for(nc, [&](long long c) {
         if (is_vert[c]) cext2int[c] = ext2int[cup_e[c]];
-        else {
-          const int u = ext2int[cup_e[c]], j = seen[u]++;
-          if ((long long)n * (j + 2) > 0x3fffffffLL) throw Error("too many lateral connections per cell for 32-bit connection ids");
-          cext2int[c] = n + j * n + u;
-          jmax = std::max(jmax, j + 1);
-          ++nlat;
-        }
+        else fetch_inc(&ptr[(size_t)ext2int[cup_e[c]] + 1]);
+      });
+      int jmax = 0;
+      for (int i = 0; i < n; ++i) { jmax = std::max(jmax, ptr[i + 1]); ptr[i + 1] += ptr[i]; }
+      const int nlat = ptr[n];
+      if (nlat > 0) {
+        if ((long long)n * (jmax + 1) > 0x3fffffffLL) throw Error("too many lateral connections per cell for 32-bit connection ids");
+        std::vector<int> fill(ptr.begin(), ptr.end() - 1), list(nlat);
+        host_parallel_for(nc, [&](long long c) { if (!is_vert[c]) list[fetch_inc(&fill[ext2int[cup_e[c]]])] = (int)c; });
+        host_parallel_for(n, [&](long long u) {
+          std::sort(list.begin() + ptr[u], list.begin() + ptr[u + 1]);
+          for (int e = ptr[u], j = 0; e < ptr[u + 1]; ++e, ++j) cext2int[list[e]] = n + j * n + (int)u;
+        });
       }
       nc_int = n + jmax * n;
       vertical_only = (nlat == 0);
     } else {
-      for (int c = 0; c < nc; ++c) cext2int[c] = c;
+      host_parallel_for(nc, [&](long long c) { cext2int[c] = (int)c; });
       nc_int = nc;
       vertical_only = false;
     }
@@ -543,25 +571,26 @@ struct Solver {
     // CSR pattern = diagonal + both directions of every internal connection: exactly the entries the reference
     // creates with MatSetValuesLocal (GoveqnRichardsODEPressureType.F90:1689, 2051-2069), rows in internal order
     std::vector<int> cnt((size_t)n + 1, 0);
-    for (int i = 0; i < n; ++i) cnt[i + 1] = 1;
-    for (int c = 0; c < nc; ++c) { cnt[ext2int[cup_e[c]] + 1]++; cnt[ext2int[cdn_e[c]] + 1]++; }
+    host_parallel_for(n, [&](long long i) { cnt[i + 1] = 1; });
+    host_parallel_for(nc, [&](long long c) { fetch_inc(&cnt[(size_t)ext2int[cup_e[c]] + 1]); fetch_inc(&cnt[(size_t)ext2int[cdn_e[c]] + 1]); });
     for (int i = 0; i < n; ++i) cnt[i + 1] += cnt[i];
     std::vector<int> col(cnt[n]), fill(cnt.begin(), cnt.end() - 1);
-    for (int i = 0; i < n; ++i) col[fill[i]++] = i;
-    for (int c = 0; c < nc; ++c) {
+    host_parallel_for(n, [&](long long i) { col[fill[i]++] = (int)i; });   // (each row's first entry: no other writer yet)
+    host_parallel_for(nc, [&](long long c) {
       const int u = ext2int[cup_e[c]], d = ext2int[cdn_e[c]];
-      col[fill[u]++] = d; col[fill[d]++] = u;
-    }
-    host_parallel_for(n, [&](long long i) { std::sort(col.begin() + cnt[i], col.begin() + cnt[i + 1]); });
+      col[fetch_inc(&fill[u])] = d; col[fetch_inc(&fill[d])] = u;
+    });
+    // sort every row, drop repeated columns (two connections between the same pair of cells), compact
     h_rowptr.assign((size_t)n + 1, 0);
-    h_col.clear(); h_col.reserve(col.size());
-    for (int i = 0; i < n; ++i) {
-      h_rowptr[i] = (int)h_col.size();
-      for (int k = cnt[i]; k < cnt[i + 1]; ++k)
-        if (k == cnt[i] || col[k] != col[k - 1]) h_col.push_back(col[k]);
-    }
-    nnz = (int)h_col.size();
-    h_rowptr[n] = nnz;
+    host_parallel_for(n, [&](long long i) {
+      int *b = col.data() + cnt[i], *e = col.data() + cnt[i + 1];
+      std::sort(b, e);
+      h_rowptr[i + 1] = (int)(std::unique(b, e) - b);
+    });
+    for (int i = 0; i < n; ++i) h_rowptr[i + 1] += h_rowptr[i];
+    nnz = h_rowptr[n];
+    h_col.resize(nnz);
+    host_parallel_for(n, [&](long long i) { std::copy(col.begin() + cnt[i], col.begin() + cnt[i] + (h_rowptr[i + 1] - h_rowptr[i]), h_col.begin() + h_rowptr[i]); });
     h_diag.resize(n);
     host_parallel_for(n, [&](long long i) { h_diag[i] = find_slot((int)i, (int)i); });
     max_row_nnz = 0;
@@ -586,32 +615,41 @@ struct Solver {
 
     // mesh arrays in internal order
     std::vector<double> v(n);
-    for (int i = 0; i < n; ++i) v[i] = vol[int2ext[i]];
+    host_parallel_for(n, [&](long long i) { v[i] = vol[int2ext[i]]; });
     d_vol.upload(v, stream);
     if (any_inactive) {
       std::vector<signed char> a(n);
-      for (int i = 0; i < n; ++i) a[i] = (signed char)active[int2ext[i]];
+      host_parallel_for(n, [&](long long i) { a[i] = (signed char)active[int2ext[i]]; });
       d_active.upload(a.data(), a.size(), stream);
     }
     // connection end cells (internal numbering both ways)
     {
       std::vector<int> up(nc_int, 0), dn(nc_int, 0);
-      for (int c = 0; c < nc; ++c) { up[cext2int[c]] = ext2int[cup_e[c]]; dn[cext2int[c]] = ext2int[cdn_e[c]]; }
+      host_parallel_for(nc, [&](long long c) { up[cext2int[c]] = ext2int[cup_e[c]]; dn[cext2int[c]] = ext2int[cdn_e[c]]; });
       d_cup.upload(up, stream); d_cdn.upload(dn, stream);
     }
     // per-row incident connection lists, in the caller's connection order (general kernels only)
     if (!vertical_only || opt.assembly == 0 || thermal || th) {
-      std::vector<int> ptr((size_t)n + 1, 0);
-      for (int c = 0; c < nc; ++c) { ptr[ext2int[cup_e[c]] + 1]++; ptr[ext2int[cdn_e[c]] + 1]++; }
-      for (int i = 0; i < n; ++i) ptr[i + 1] += ptr[i];
       PhaseTimer pt("setup: incidence lists");
+      std::vector<int> ptr((size_t)n + 1, 0);
+      host_parallel_for(nc, [&](long long c) { fetch_inc(&ptr[(size_t)ext2int[cup_e[c]] + 1]); fetch_inc(&ptr[(size_t)ext2int[cdn_e[c]] + 1]); });
+      for (int i = 0; i < n; ++i) ptr[i + 1] += ptr[i];
       std::vector<int> fill(ptr.begin(), ptr.end() - 1), rconn(ptr[n]), rslot(ptr[n]), roth(ptr[n]);
-      for (int c = 0; c < nc; ++c) {   // (serial: a row's list keeps the caller's connection order)
-        const int u = ext2int[cup_e[c]], d = ext2int[cdn_e[c]], ic = cext2int[c];
-        rconn[fill[u]] = (ic << 1) | 0; roth[fill[u]++] = d;
-        rconn[fill[d]] = (ic << 1) | 1; roth[fill[d]++] = u;
-      }
-      host_parallel_for(n, [&](long long i) { for (int e = ptr[i]; e < ptr[i + 1]; ++e) rslot[e] = find_slot((int)i, roth[e]); });
+      // a row's list keeps the caller's connection order: filled in any order as (connection << 1 | side), sorted per row
+      if ((long long)nc * 2 > 0x7fffffffLL) throw Error("too many connections for the 32-bit incidence keys");
+      host_parallel_for(nc, [&](long long c) {
+        rconn[fetch_inc(&fill[ext2int[cup_e[c]]])] = (int)(c << 1);
+        rconn[fetch_inc(&fill[ext2int[cdn_e[c]]])] = (int)(c << 1) | 1;
+      });
+      host_parallel_for(n, [&](long long i) {
+        std::sort(rconn.begin() + ptr[i], rconn.begin() + ptr[i + 1]);
+        for (int e = ptr[i]; e < ptr[i + 1]; ++e) {
+          const int c = rconn[e] >> 1, side = rconn[e] & 1;
+          roth[e] = side ? ext2int[cup_e[c]] : ext2int[cdn_e[c]];
+          rconn[e] = (cext2int[c] << 1) | side;
+          rslot[e] = find_slot((int)i, roth[e]);
+        }
+      });
       d_rc_ptr.upload(ptr, stream); d_rc_conn.upload(rconn, stream); d_rc_slot.upload(rslot, stream);
       aux_kr.alloc(n); aux_dkr.alloc(n); aux_den.alloc(n); aux_dden.alloc(n);
       // ELL copy for k_flux_rows_ell (rows of <= 8 incident connections, one connection per matrix entry)

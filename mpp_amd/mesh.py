@@ -117,7 +117,17 @@ def mesh_create(name, x_max, y_max, z_max, nx, ny, nz, internal_conn_dir,
     m.compute_volume()
     up, dn, du, dd, area, itype = compute_internal_connections(nx, ny, nz, dx, dy, dz, internal_conn_dir)
     cs = ConnectionSet(up, dn, du, dd, area, None, itype)
-    cs.unit_vec = unit_vec_from_centroids(m, up, dn)
+    # unit vectors (x_dn - x_up) / |.| (MeshType.F90:932-938): on this grid the two cells of a connection differ in one coordinate
+    # only, so the quotient is exactly +1 along that axis and 0 elsewhere -- written down per direction block instead of gathered
+    # from the centroids (identical values; the gathers took longer than everything else in here)
+    dirs = {C.CONN_IN_X_DIR: [0], C.CONN_IN_Y_DIR: [1], C.CONN_IN_Z_DIR: [2], C.CONN_IN_XYZ_DIR: [0, 1, 2]}[internal_conn_dir]
+    counts = {0: (nx - 1) * ny * nz, 1: nx * (ny - 1) * nz, 2: nx * ny * (nz - 1)}
+    uv = np.zeros((up.size, 3))
+    at = 0
+    for d in dirs:
+        uv[at:at + counts[d], d] = 1.0
+        at += counts[d]
+    cs.unit_vec = uv
     m.intrn_conn_sets.append(cs)
     m.ncols, m.ordering = nx * ny, "x-fastest"
     return m

@@ -281,27 +281,30 @@ def thermal_mms(ptype=3, nx=3, ny=3, nz=3, replicate_reference_soil_indexing=Tru
             tk[(c * nz + kk).ravel()] = lam_pos[kk].ravel()                  # cell (c-1)*nz + kk (0-based)
     else:
         tk = lam_pos.ravel().copy()
-    # boundary connections in the driver's order (thermal_mms_problem.F90:365-452)
-    idd, du, dd, ar, tb = [], [], [], [], []
+    # boundary connections in the driver's order (thermal_mms_problem.F90:365-452): x faces per (kk, jj) low then high, y faces
+    # per (kk, ii), z faces per (jj, ii) -- built as arrays (a Python loop over the 6 n^2 faces took a minute at 512^3)
+    parts = []
 
-    def face(cell, x, y, z, dist, area):
-        idd.append(cell); du.append(0.0); dd.append(dist); ar.append(area); tb.append(T(x, y, z))
+    def faces(lo, hi, axis, d, area):
+        """cells of the low / high plane (same shape), the face centre offset by -+ d/2 along `axis`"""
+        cell = np.stack([ids[lo], ids[hi]], axis=-1).ravel()
+        xyz = []
+        for a, A in enumerate((X, Y, Z)):
+            off = (-d / 2, d / 2) if a == axis else (0.0, 0.0)
+            xyz.append(np.stack([A[lo] + off[0], A[hi] + off[1]], axis=-1).ravel())
+        parts.append((cell, np.full(cell.size, d / 2), np.full(cell.size, area), T(*xyz)))
 
     if nx > 1:
-        for kk in range(nz):
-            for jj in range(ny):
-                face(ids[kk, jj, 0], X[kk, jj, 0] - dx / 2, Y[kk, jj, 0], Z[kk, jj, 0], dx / 2, dy * dz)
-                face(ids[kk, jj, nx - 1], X[kk, jj, nx - 1] + dx / 2, Y[kk, jj, nx - 1], Z[kk, jj, nx - 1], dx / 2, dy * dz)
+        faces((slice(None), slice(None), 0), (slice(None), slice(None), nx - 1), 0, dx, dy * dz)       # [kk, jj]
     if ny > 1:
-        for kk in range(nz):
-            for ii in range(nx):
-                face(ids[kk, 0, ii], X[kk, 0, ii], Y[kk, 0, ii] - dy / 2, Z[kk, 0, ii], dy / 2, dx * dz)
-                face(ids[kk, ny - 1, ii], X[kk, ny - 1, ii], Y[kk, ny - 1, ii] + dy / 2, Z[kk, ny - 1, ii], dy / 2, dx * dz)
+        faces((slice(None), 0, slice(None)), (slice(None), ny - 1, slice(None)), 1, dy, dx * dz)       # [kk, ii]
     if nz > 1:
-        for jj in range(ny):
-            for ii in range(nx):
-                face(ids[0, jj, ii], X[0, jj, ii], Y[0, jj, ii], Z[0, jj, ii] - dz / 2, dz / 2, dx * dy)
-                face(ids[nz - 1, jj, ii], X[nz - 1, jj, ii], Y[nz - 1, jj, ii], Z[nz - 1, jj, ii] + dz / 2, dz / 2, dx * dy)
+        faces((0, slice(None), slice(None)), (nz - 1, slice(None), slice(None)), 2, dz, dx * dy)       # [jj, ii]
+    idd = np.concatenate([q[0] for q in parts]) if parts else np.zeros(0, dtype=np.int64)
+    dd = np.concatenate([q[1] for q in parts]) if parts else np.zeros(0)
+    ar = np.concatenate([q[2] for q in parts]) if parts else np.zeros(0)
+    tb = np.concatenate([q[3] for q in parts]) if parts else np.zeros(0)
+    du = np.zeros(idd.size)
     nb = len(idd)
     uv = np.zeros((nb, 3)); uv[:, 0] = 1.0
     bc = M.ConnectionSet(np.zeros(nb, dtype=np.int64), np.asarray(idd, dtype=np.int64), np.asarray(du), np.asarray(dd),
