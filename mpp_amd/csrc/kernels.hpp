@@ -303,6 +303,8 @@ struct ThArgs {
   const double *por, *sat_res, *alpha, *m, *vol;           // soil shared by both equations
   const double *sbc_pu, *sbc_ps, *sbc_b2, *sbc_b3;         // smoothed Brooks-Corey only
   const signed char *active;                                // nullptr = every cell active
+  const signed char *satf;                                  // per-cell saturation function (SatFunc ids) when the mesh mixes them, else nullptr
+  const double *por_pref, *por_slope;                       // POROSITY_LINEAR in both equations; nullptr = constant model
   const double *tc_wet, *tc_dry, *talpha, *heat_cap, *den_soil;
   int sat_func, density_type, ie_type;
   // auxvars stored by pass 1 for passes 2 and 3

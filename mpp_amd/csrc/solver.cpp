@@ -342,15 +342,18 @@ struct Solver {
                        const double *uv) {
     need_setup(false);
     if (n == 0) throw Error("mppgpu_set_mesh must precede mppgpu_set_connections");
+    PhaseTimer pt("set_connections");
     nc = nconn;
     cup_e.resize(nc); cdn_e.resize(nc);
-    for (int c = 0; c < nc; ++c) {
+    cdu.resize(nc); cdd.resize(nc); carea.resize(nc); cuv.resize(3 * (size_t)nc);
+    host_parallel_for(nc, [&](long long c) {   // (the first exception any thread throws reaches the caller)
       if (up[c] < 1 || up[c] > n || dn[c] < 1 || dn[c] > n)
         throw Error("connection " + std::to_string(c + 1) + ": cell id out of range");
       if (up[c] == dn[c]) throw Error("connection " + std::to_string(c + 1) + ": id_up == id_dn");
       cup_e[c] = up[c] - 1; cdn_e[c] = dn[c] - 1;
-    }
-    cdu.assign(du, du + nc); cdd.assign(dd, dd + nc); carea.assign(ar, ar + nc); cuv.assign(uv, uv + 3 * (size_t)nc);
+      cdu[c] = du[c]; cdd[c] = dd[c]; carea[c] = ar[c];
+      cuv[3 * (size_t)c] = uv[3 * (size_t)c]; cuv[3 * (size_t)c + 1] = uv[3 * (size_t)c + 1]; cuv[3 * (size_t)c + 2] = uv[3 * (size_t)c + 2];
+    });
   }
 
   void set_lateral_connections(int nconn, const int *up, const int *dn, const double *du, const double *dd, const double *ar,
@@ -426,7 +429,7 @@ struct Solver {
   }
   void set_por_linear(const double *base, const double *pref, const double *slope) {   // PorosityFunctionSetLinearModel
     if (!n) throw Error("mesh not set");
-    if (th || thermal) throw Error("the linear porosity model is available for the VSFM only");
+    if (thermal) throw Error("the linear porosity model belongs to the VSFM and the coupled thermal-hydrology system");
     por.assign(base, base + n); por_pref.assign(pref, pref + n); por_slope.assign(slope, slope + n);
     soil_dirty = true;
   }
@@ -441,7 +444,6 @@ struct Solver {
       if (type[i] == MPPGPU_SAT_FUNC_VAN_GENUCHTEN) bad |= lam_i >= 1.0; else bad |= lam_i >= 2.0;
       if (bad) throw Error("bad saturation parameters at cell " + std::to_string(i + 1));  // SatFunc_Set_* argument checks
     }
-    if (mixed && th) throw Error("mixed saturation-function types are available for the VSFM only");
     satf.assign(type, type + n); alpha.assign(a, a + n); lam.assign(l, l + n); sat_res.assign(sr, sr + n);
     mixed_satf = mixed;
     sat_func = map_sat_func(type[0]);   // the mesh's function when !mixed_satf
@@ -462,13 +464,34 @@ struct Solver {
   // The set-up passes over the caller's cells and connections run on the host's cores (host_parallel_for): where the serial
   // code relied on the order of its loop, the parallel one fills with relaxed atomics in any order and then sorts each cell's short
   // list by connection number, so the results are the same for any number of threads.
+  // a scratch array of the set-up passes whose pages are first touched -- and whose initial value is written -- by all host
+  // threads (a std::vector of 10^8 ints is value-initialised by one: 0.15 s each, and these passes use a dozen)
+  template <class T>
+  struct Scratch {
+    T *p = nullptr;
+    size_t n = 0;
+    Scratch(size_t count, T init) : p(static_cast<T *>(std::malloc(std::max<size_t>(count, 1) * sizeof(T)))), n(count) {
+      if (!p) throw Error("out of host memory in set-up");
+      T *q = p;
+      host_parallel_for((long long)count, [q, init](long long i) { q[i] = init; });
+    }
+    explicit Scratch(size_t count) : p(static_cast<T *>(std::malloc(std::max<size_t>(count, 1) * sizeof(T)))), n(count) {
+      if (!p) throw Error("out of host memory in set-up");
+    }
+    Scratch(const Scratch &) = delete;
+    Scratch &operator=(const Scratch &) = delete;
+    ~Scratch() { std::free(p); }
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+    T *begin() { return p; }
+  };
   static int fetch_inc(int *p) { return __atomic_fetch_add(p, 1, __ATOMIC_RELAXED); }
   static void put(int *p, int v) { __atomic_store_n(p, v, __ATOMIC_RELAXED); }
 
   void detect_columns() {
     // vertical chains of the internal connection set (any cell numbering)
-    std::vector<int> nxt(n, -1), below(n, -1);
-    std::vector<char> is_vert(nc, 0);
+    Scratch<int> nxt(n, -1), below(n, -1);
+    Scratch<char> is_vert(nc, 0);
     std::atomic<bool> ok{true};
     std::atomic<long long> nvert{0};
     host_parallel_ranges(nc, [&](long long c0, long long c1) {
@@ -486,8 +509,8 @@ struct Solver {
     host_parallel_for(nc, [&](long long c) {   // two vertical links at one cell: one of them lost its store
       if (is_vert[c] && (nxt[cup_e[c]] != cdn_e[c] || below[cdn_e[c]] != cup_e[c])) ok = false;
     });
-    ext2int.assign(n, -1);
-    int2ext.assign(n, -1);
+    PhaseTimer pt2("  columns: chains and numbering");
+    ext2int.resize(n); int2ext.resize(n);   // (every entry is written below)
     columns = false;
     if (nghost > 0) ok = false;   // ghost cells stay last: identity layout
     if (ok) {
@@ -497,7 +520,7 @@ struct Solver {
       if (nchains > 0 && n % nchains == 0) {
         const int len = n / nchains;
         std::atomic<bool> equal{true};
-        std::vector<int> lev(n, -1), colof(n, -1);
+        Scratch<int> lev(n, -1), colof(n, -1);
         host_parallel_for(nchains, [&](long long ch) {
           if (!equal.load(std::memory_order_relaxed)) return;
           int cur = starts[ch], k = 0;
@@ -525,7 +548,7 @@ struct Solver {
       identity_perm = ident;
     }
     // internal connection numbering: chain links at the index of their lower cell, the rest appended
-    cext2int.assign(nc, -1);
+    cext2int.resize(nc);   // (every entry is written below)
     if (columns && nvert == nc) {   // nothing but chain links (the soil-column grids)
       host_parallel_for(nc, [&](long long c) { cext2int[c] = ext2int[cup_e[c]]; });
       nc_int = n;
@@ -570,12 +593,12 @@ struct Solver {
     PhaseTimer pt("setup: CSR pattern");
     // CSR pattern = diagonal + both directions of every internal connection: exactly the entries the reference
     // creates with MatSetValuesLocal (GoveqnRichardsODEPressureType.F90:1689, 2051-2069), rows in internal order
-    std::vector<int> cnt((size_t)n + 1, 0);
-    host_parallel_for(n, [&](long long i) { cnt[i + 1] = 1; });
+    Scratch<int> cnt((size_t)n + 1, 1);   // (the diagonal)
+    cnt[0] = 0;
     host_parallel_for(nc, [&](long long c) { fetch_inc(&cnt[(size_t)ext2int[cup_e[c]] + 1]); fetch_inc(&cnt[(size_t)ext2int[cdn_e[c]] + 1]); });
     for (int i = 0; i < n; ++i) cnt[i + 1] += cnt[i];
-    std::vector<int> col(cnt[n]), fill(cnt.begin(), cnt.end() - 1);
-    host_parallel_for(n, [&](long long i) { col[fill[i]++] = (int)i; });   // (each row's first entry: no other writer yet)
+    Scratch<int> col((size_t)cnt[n]), fill((size_t)n);
+    host_parallel_for(n, [&](long long i) { fill[i] = cnt[i]; col[fill[i]++] = (int)i; });   // (each row's first entry: no other writer yet)
     host_parallel_for(nc, [&](long long c) {
       const int u = ext2int[cup_e[c]], d = ext2int[cdn_e[c]];
       col[fetch_inc(&fill[u])] = d; col[fetch_inc(&fill[d])] = u;
@@ -583,14 +606,14 @@ struct Solver {
     // sort every row, drop repeated columns (two connections between the same pair of cells), compact
     h_rowptr.assign((size_t)n + 1, 0);
     host_parallel_for(n, [&](long long i) {
-      int *b = col.data() + cnt[i], *e = col.data() + cnt[i + 1];
+      int *b = col.p + cnt[i], *e = col.p + cnt[i + 1];
       std::sort(b, e);
       h_rowptr[i + 1] = (int)(std::unique(b, e) - b);
     });
     for (int i = 0; i < n; ++i) h_rowptr[i + 1] += h_rowptr[i];
     nnz = h_rowptr[n];
     h_col.resize(nnz);
-    host_parallel_for(n, [&](long long i) { std::copy(col.begin() + cnt[i], col.begin() + cnt[i] + (h_rowptr[i + 1] - h_rowptr[i]), h_col.begin() + h_rowptr[i]); });
+    host_parallel_for(n, [&](long long i) { std::copy(col.p + cnt[i], col.p + cnt[i] + (h_rowptr[i + 1] - h_rowptr[i]), h_col.begin() + h_rowptr[i]); });
     h_diag.resize(n);
     host_parallel_for(n, [&](long long i) { h_diag[i] = find_slot((int)i, (int)i); });
     max_row_nnz = 0;
@@ -598,6 +621,7 @@ struct Solver {
   }
 
   void setup() {
+    PhaseTimer pt_all("setup (all of mppgpu_setup)");
     need_setup(false);
     if (n == 0) throw Error("mppgpu_set_mesh has not been called");
     HIP_CHECK(hipSetDevice(device));
@@ -1103,6 +1127,8 @@ struct Solver {
     a.por = d_por.p; a.sat_res = d_sat_res.p; a.alpha = d_alpha.p; a.m = d_m.p; a.vol = d_vol.p;
     a.sbc_pu = d_pu.p; a.sbc_ps = d_ps.p; a.sbc_b2 = d_b2.p; a.sbc_b3 = d_b3.p;
     a.active = any_inactive ? d_active.p : nullptr;
+    a.satf = mixed_satf ? d_satf.p : nullptr;
+    a.por_pref = d_por_pref.p; a.por_slope = d_por_slope.p;
     a.tc_wet = d_tcw.p; a.tc_dry = d_tcd.p; a.talpha = d_talpha.p; a.heat_cap = d_hcap.p; a.den_soil = d_dsoil.p;
     a.sat_func = sat_func; a.density_type = density_type; a.ie_type = ie_type;
     a.kr = tha[0].p; a.dkr = tha[1].p; a.den_m = tha[2].p; a.ddenP_m = tha[3].p; a.ddenT_m = tha[4].p;
@@ -1696,15 +1722,18 @@ struct Solver {
   void thermal_upload_cells() {
     if (!th_cell_dirty) return;
     if ((int)th_dz.size() != n) throw Error("thermal soils are not set (mppgpu_thermal_set_soils)");
+    PhaseTimer pt("thermal cell properties");
     auto perm_d = [&](const std::vector<double> &v, DevBuf<double> &d) {
       std::vector<double> t(n);
-      for (int i = 0; i < n; ++i) t[i] = v[int2ext[i]];
+      host_parallel_for(n, [&](long long i) { t[i] = v[int2ext[i]]; });
       d.upload(t, stream);
+      HIP_CHECK(hipStreamSynchronize(stream));   // (t goes out of scope)
     };
     auto perm_c = [&](const std::vector<int> &v, DevBuf<signed char> &d, bool zero_is_one) {
       std::vector<signed char> t(n);
-      for (int i = 0; i < n; ++i) t[i] = (signed char)(zero_is_one ? (v[int2ext[i]] == 0) : v[int2ext[i]]);
+      host_parallel_for(n, [&](long long i) { t[i] = (signed char)(zero_is_one ? (v[int2ext[i]] == 0) : v[int2ext[i]]); });
       d.upload(t.data(), t.size(), stream);
+      HIP_CHECK(hipStreamSynchronize(stream));
     };
     perm_d(th_dz, d_th_dz); perm_d(th_por, d_th_por); perm_d(th_tkmg, d_th_tkmg); perm_d(th_tkdry, d_th_tkdry);
     perm_d(th_csol, d_th_csol); perm_d(th_liq, d_th_liq); perm_d(th_ice, d_th_ice); perm_d(th_snow, d_th_snow);

@@ -27,8 +27,10 @@ __device__ __forceinline__ bool th_active(const ThArgs &a, size_t i) { return a.
 __device__ __forceinline__ Soil th_load_soil(const ThArgs &a, size_t i) {
   Soil s;
   s.sat_res = a.sat_res[i]; s.alpha = a.alpha[i]; s.m = a.m[i]; s.por = a.por[i];
-  if (a.sat_func == kSatSBC) { s.pu = a.sbc_pu[i]; s.ps = a.sbc_ps[i]; s.b2 = a.sbc_b2[i]; s.b3 = a.sbc_b3[i]; }
+  s.sf = a.satf ? (int)a.satf[i] : a.sat_func;   // satParams are per auxvar (ThermalEnthalpySoilAuxType.F90:156-157): per-cell dispatch
+  if (s.sf == kSatSBC) { s.pu = a.sbc_pu[i]; s.ps = a.sbc_ps[i]; s.b2 = a.sbc_b2[i]; s.b3 = a.sbc_b3[i]; }
   else { s.pu = s.ps = s.b2 = s.b3 = 0.0; }
+  if (a.por_slope) { s.por_pref = a.por_pref[i]; s.por_slope = a.por_slope[i]; } else { s.por_pref = s.por_slope = 0.0; }
   return s;
 }
 
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(kBlock) void k_th_aux(ThArgs a) {
   const Soil s = th_load_soil(a, i);
   const ThSoil ts{a.tc_wet[i], a.tc_dry[i], a.talpha[i]};
   const double P = a.x[i], T = a.x[n + i];
-  const ThAux x = th_auxvar_compute<true>(a.sat_func, a.density_type, a.ie_type, s, ts, P, T, true, pt);  // every cell (GE:942-961)
+  const ThAux x = th_auxvar_compute<true>(s.sf, a.density_type, a.ie_type, s, ts, P, T, true, pt);  // every cell (GE:942-961)
   if (!PRE) {
     a.kr[i] = x.kr; a.dkr[i] = x.dkr;
     a.den_m[i] = x.den_m; a.ddenP_m[i] = x.ddenP_m; a.ddenT_m[i] = x.ddenT_m;
@@ -73,9 +75,12 @@ __global__ __launch_bounds__(kBlock) void k_th_aux(ThArgs a) {
   const double vol = a.vol[i];
   const double dsoil = a.den_soil[i], csoil = a.heat_cap[i];
   double fm = 0.0, fe = 0.0;
+  const bool lin_por = a.por_slope != nullptr;   // POROSITY_LINEAR: por(P), dpor/dP enter both accumulation terms
+  double por = s.por, dpor = 0.0;
+  if (lin_por) porosity(s, true, P, por, dpor);
   if (act) {
-    fm = s.por * x.den_m * x.sat * vol * a.dtInv;                                                         // GE(Richards):1603-1634
-    fe = (s.por * x.den_e * x.sat * x.ul + (1.0 - s.por) * dsoil * csoil * (T - 273.15)) * vol * a.dtInv;  // GE(heat):1174-1219
+    fm = por * x.den_m * x.sat * vol * a.dtInv;                                                         // GE(Richards):1603-1634
+    fe = (por * x.den_e * x.sat * x.ul + (1.0 - por) * dsoil * csoil * (T - 273.15)) * vol * a.dtInv;  // GE(heat):1174-1219
   }
   if (PRE) { a.F[i] = fm; a.F[n + i] = fe; return; }
   a.F[i] = fm - a.accum_prev[i];
@@ -85,10 +90,16 @@ __global__ __launch_bounds__(kBlock) void k_th_aux(ThArgs a) {
     const int sPP = r0 + a.cdiag[i], sPT = sPP + len, sTP = 2 * a.nnzc + sPP, sTT = sTP + len;
     double dPP = 1.0, dPT = 1.0, dTP = 1.0, dTT = 1.0;  // inactive cell: 1 on all four diagonals (GE:1682; 2501; 2136; 1283)
     if (act) {
-      dPP = (s.por * x.ddenP_m * x.sat + s.por * x.den_m * x.dsat) * vol * a.dtInv;
-      dPT = (s.por * x.ddenT_m * x.sat) * vol * a.dtInv;
-      dTP = (s.por * x.ddenP_e * x.sat * x.ul + s.por * x.den_e * x.dsat * x.ul + s.por * x.den_e * x.sat * x.dul_dP) * vol * a.dtInv;
-      dTT = ((s.por * x.ddenT_e * x.sat * x.ul + s.por * x.den_e * x.sat * x.dul_dT) + (1.0 - s.por) * dsoil * csoil) * vol * a.dtInv;
+      dPT = (por * x.ddenT_m * x.sat) * vol * a.dtInv;
+      dTT = ((por * x.ddenT_e * x.sat * x.ul + por * x.den_e * x.sat * x.dul_dT) + (1.0 - por) * dsoil * csoil) * vol * a.dtInv;
+      if (lin_por) {   // GE(Richards):1675-1677; GE(heat):2178-2182
+        dPP = (dpor * x.den_m * x.sat + por * x.ddenP_m * x.sat + por * x.den_m * x.dsat) * vol * a.dtInv;
+        dTP = (dpor * x.den_e * x.sat * x.ul + por * x.ddenP_e * x.sat * x.ul + por * x.den_e * x.dsat * x.ul + por * x.den_e * x.sat * x.dul_dP +
+               (-dpor * dsoil * csoil * (T - 273.15))) * vol * a.dtInv;
+      } else {
+        dPP = (por * x.ddenP_m * x.sat + por * x.den_m * x.dsat) * vol * a.dtInv;
+        dTP = (por * x.ddenP_e * x.sat * x.ul + por * x.den_e * x.dsat * x.ul + por * x.den_e * x.sat * x.dul_dP) * vol * a.dtInv;
+      }
     }
     a.val[sPP] = dPP; a.val[sPT] = dPT; a.val[sTP] = dTP; a.val[sTT] = dTT;
   }
@@ -204,18 +215,27 @@ __global__ __launch_bounds__(kBlock) void k_th_cols(ThArgs a) {
       const Soil s = th_load_soil(a, i);
       const ThSoil ts{a.tc_wet[i], a.tc_dry[i], a.talpha[i]};
       const double P = a.x[i], T = a.x[n + i];
-      cur = th_auxvar_compute<true>(a.sat_func, a.density_type, a.ie_type, s, ts, P, T, true, pt);
+      cur = th_auxvar_compute<true>(s.sf, a.density_type, a.ie_type, s, ts, P, T, true, pt);
       const double vol = a.vol[i], dsoil = a.den_soil[i], csoil = a.heat_cap[i];
       double fm = 0.0, fe = 0.0;
       rc.aPP = rc.aPT = rc.aTP = rc.aTT = 1.0;
       if (act) {
-        fm = s.por * cur.den_m * cur.sat * vol * a.dtInv;
-        fe = (s.por * cur.den_e * cur.sat * cur.ul + (1.0 - s.por) * dsoil * csoil * (T - 273.15)) * vol * a.dtInv;
+        const bool lin_por = a.por_slope != nullptr;
+        double por = s.por, dpor = 0.0;
+        if (lin_por) porosity(s, true, P, por, dpor);
+        fm = por * cur.den_m * cur.sat * vol * a.dtInv;
+        fe = (por * cur.den_e * cur.sat * cur.ul + (1.0 - por) * dsoil * csoil * (T - 273.15)) * vol * a.dtInv;
         if (JAC) {
-          rc.aPP = (s.por * cur.ddenP_m * cur.sat + s.por * cur.den_m * cur.dsat) * vol * a.dtInv;
-          rc.aPT = (s.por * cur.ddenT_m * cur.sat) * vol * a.dtInv;
-          rc.aTP = (s.por * cur.ddenP_e * cur.sat * cur.ul + s.por * cur.den_e * cur.dsat * cur.ul + s.por * cur.den_e * cur.sat * cur.dul_dP) * vol * a.dtInv;
-          rc.aTT = ((s.por * cur.ddenT_e * cur.sat * cur.ul + s.por * cur.den_e * cur.sat * cur.dul_dT) + (1.0 - s.por) * dsoil * csoil) * vol * a.dtInv;
+          rc.aPT = (por * cur.ddenT_m * cur.sat) * vol * a.dtInv;
+          rc.aTT = ((por * cur.ddenT_e * cur.sat * cur.ul + por * cur.den_e * cur.sat * cur.dul_dT) + (1.0 - por) * dsoil * csoil) * vol * a.dtInv;
+          if (lin_por) {
+            rc.aPP = (dpor * cur.den_m * cur.sat + por * cur.ddenP_m * cur.sat + por * cur.den_m * cur.dsat) * vol * a.dtInv;
+            rc.aTP = (dpor * cur.den_e * cur.sat * cur.ul + por * cur.ddenP_e * cur.sat * cur.ul + por * cur.den_e * cur.dsat * cur.ul +
+                      por * cur.den_e * cur.sat * cur.dul_dP + (-dpor * dsoil * csoil * (T - 273.15))) * vol * a.dtInv;
+          } else {
+            rc.aPP = (por * cur.ddenP_m * cur.sat + por * cur.den_m * cur.dsat) * vol * a.dtInv;
+            rc.aTP = (por * cur.ddenP_e * cur.sat * cur.ul + por * cur.den_e * cur.dsat * cur.ul + por * cur.den_e * cur.sat * cur.dul_dP) * vol * a.dtInv;
+          }
         }
       }
       rc.fm = fm - a.accum_prev[i];
@@ -284,7 +304,7 @@ __global__ __launch_bounds__(kBlock) void k_th_bc(ThBcArgs b) {
   if (!th_active(a, cell)) return;
   const Soil s = th_load_soil(a, cell);
   const ThSoil ts{a.tc_wet[cell], a.tc_dry[cell], a.talpha[cell]};
-  const ThAux in = th_auxvar_compute<true>(a.sat_func, a.density_type, a.ie_type, s, ts, a.x[cell], a.x[n + cell], true, pt);
+  const ThAux in = th_auxvar_compute<true>(s.sf, a.density_type, a.ie_type, s, ts, a.x[cell], a.x[n + cell], true, pt);
   double fm = a.F[cell], fe = a.F[n + cell];
   double dPP = 0.0, dTP = 0.0, dTT = 0.0;
   for (int e = b.cc_ptr[j]; e < b.cc_ptr[j + 1]; ++e) {
@@ -294,14 +314,14 @@ __global__ __launch_bounds__(kBlock) void k_th_bc(ThBcArgs b) {
     g.Dq = b.Dq[e]; g.upweight = 0.0; g.dist_gravity = b.dgrav[e]; g.area = b.area[e];
     if (!heat) {
       const double pb = (ctype == kCondMassFlux) ? in.P : b.value[e];
-      const ThAux bc = th_auxvar_compute<true>(a.sat_func, a.density_type, a.ie_type, s, ts, pb, b.other[e], true, pt);
+      const ThAux bc = th_auxvar_compute<true>(s.sf, a.density_type, a.ie_type, s, ts, pb, b.other[e], true, pt);
       double Jup = 0.0, Jdn = 0.0, flux, jdn_outer;
       if (!swap) { flux = richards_flux<JAC>(mass_view(bc), mass_view(in), g, ctype, Jup, Jdn); jdn_outer = Jdn; }
       else { flux = -richards_flux<JAC>(mass_view(in), mass_view(bc), g, ctype, Jup, Jdn); jdn_outer = -Jup; }
       fm += flux;
       if (JAC) dPP += -jdn_outer;
     } else {
-      const ThAux bc = th_auxvar_compute<true>(a.sat_func, a.density_type, a.ie_type, s, ts, b.other[e], b.value[e], false, pt);
+      const ThAux bc = th_auxvar_compute<true>(s.sf, a.density_type, a.ie_type, s, ts, b.other[e], b.value[e], false, pt);
       double Eup = 0.0, Edn = 0.0, t1, t2;
       const double mflux = richards_flux<JAC>(heat_view(bc), heat_view(in), g, ctype, Eup, Edn);
       const double du = b.du[e], dd = b.dd[e];

@@ -363,6 +363,8 @@ class THProblem:
     talpha: np.ndarray
     den_soil: np.ndarray
     energy_perm: object = None          # None: the auxvar default 8.3913e-12 (MPPTHSetSoils never sets it)
+    por_pressure_reference: np.ndarray = None   # linear porosity model (PorosityFunctionMod.F90:75-96) in both equations:
+    por_slope: np.ndarray = None                # por is then porosity_base
     press_ic: np.ndarray = None
     temp_ic: np.ndarray = None
     mass_bcs: list = field(default_factory=list)     # [(cond_type, ConnectionSet, values, bc_temperature or None)]
@@ -512,6 +514,9 @@ def to_th_gpu(tp: THProblem, options=None, device_id=0):
     mpp.SetupProblem()
     TH.MPPTHSetSoilsSI(mpp, tp.perm, tp.por, tp.satfunc_type, tp.alpha, tp.lam, tp.sat_res, tp.density_type, tp.ie_type,
                        tp.heat_cap, tp.tcond_wet, tp.tcond_dry, tp.talpha, tp.den_soil, energy_perm=tp.energy_perm)
+    if tp.por_slope is not None:   # POROSITY_LINEAR in both equations (porParams are per auxvar; no MPP-level routine of the reference)
+        from mpp_amd import vsfm as V
+        V.VSFMMPPSetSoilPorosityLinearModel(mpp, 1, tp.por, tp.por_pressure_reference, tp.por_slope)
     mpp.Restart(tp.press_ic, tp.temp_ic)
     mpp.cond_ids = ids
     th_gpu_set_conditions(tp, mpp)

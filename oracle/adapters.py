@@ -77,11 +77,17 @@ def to_th_oracle(tp: THProblem, ksp_rtol=0.0):
     for ss in tp.energy_sss:
         o.energy_add_condition(C.COND_SS, ss[0], ss[1])
     ms.set_soil_permeability(tp.perm[:, 0], tp.perm[:, 1], tp.perm[:, 2])
-    ms.set_soil_porosity(tp.por)
+    linear = getattr(tp, "por_slope", None) is not None
+    if linear:
+        ms.set_soil_porosity_linear(tp.por, tp.por_pressure_reference, tp.por_slope)
+    else:
+        ms.set_soil_porosity(tp.por)
     ms.set_saturation_function(tp.satfunc_type, tp.alpha, tp.lam, tp.sat_res)
     o.set_eos(tp.density_type, tp.ie_type)
     o.energy_set_soils(tp.por, tp.satfunc_type, tp.alpha, tp.lam, tp.sat_res, tp.heat_cap, tp.tcond_wet, tp.tcond_dry,
                        tp.talpha, tp.den_soil, perm=tp.energy_perm)
+    if linear:
+        o.energy_set_porosity_linear(tp.por_pressure_reference, tp.por_slope)
     o.setup()
     o.restart(tp.press_ic, tp.temp_ic)
     if ksp_rtol:

@@ -178,7 +178,11 @@ static void thaux_compute(thaux *t, int density_type, int ie_type) {
   double dvis_dT, e[6];
   vo__press_to_sat(&a->sp, a->pressure, &a->sat, &a->dsat_dP);
   vo__press_to_relperm(&a->sp, a->pressure, 1.0, &a->kr, &a->dkr_dP);
-  a->por = a->por_base; a->dpor_dP = 0.0;
+  /* PorosityFunctionComputation (PorosityFunctionMod.F90:99-163) at the cell pressure, ThermalEnthalpySoilAuxType.F90:246-249 */
+  if (a->por_model == 2) {
+    a->por = a->por_base + (a->pressure - a->por_pressure_reference) * a->por_lin_mod_slope;
+    a->dpor_dP = a->por_lin_mod_slope;
+  } else { a->por = a->por_base; a->dpor_dP = 0.0; }
   double pressure = a->pressure;
   if (a->pressure < PRESSURE_REF) pressure = PRESSURE_REF;
   vo_density(pressure, a->temperature, density_type, &a->den, &a->dden_dP, &a->dden_dT);
@@ -389,6 +393,25 @@ int tho_energy_add_condition(tho_problem *t, int kind, int cond_type, int nconn,
   }
   ++*cnt;
   if (cond_id) *cond_id = *cnt;
+  return 0;
+}
+
+/* The linear porosity model (PorosityFunctionMod.F90:75-96) for the heat equation's auxvars: porParams are per auxvar
+ * (ThermalEnthalpySoilAuxType.F90:156-157); por given to tho_energy_set_soils is then porosity_base.  NULL, NULL: constant model.
+ * No MPP-level routine of the reference selects the model: parity unpinned by the reference. */
+int tho_energy_set_porosity_linear(tho_problem *t, const double *press_ref, const double *slope) {
+  for (int i = 0; i < t->n; i++) {
+    auxvar *a = &t->aux[i].a;
+    a->por_model = press_ref ? 2 : 1;
+    a->por_pressure_reference = press_ref ? press_ref[i] : 0.0;
+    a->por_lin_mod_slope = slope ? slope[i] : 0.0;
+  }
+  for (int b = 0; b < t->nbc; b++)
+    for (int i = 0; i < t->bc[b].n; i++) {
+      auxvar *x = &t->bc[b].aux[i].a;
+      const auxvar *s = &t->aux[t->bc[b].id_dn[i]].a;
+      x->por_model = s->por_model; x->por_pressure_reference = s->por_pressure_reference; x->por_lin_mod_slope = s->por_lin_mod_slope;
+    }
   return 0;
 }
 

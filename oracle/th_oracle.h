@@ -29,6 +29,7 @@ vo_problem *tho_global(tho_problem *t);
 int tho_set_eos(tho_problem *t, int density_type, int int_energy_enthalpy_type);
 int tho_energy_add_condition(tho_problem *t, int kind, int cond_type, int nconn, const int *id_dn, const double *dist_up,
                              const double *dist_dn, const double *area, const double *unit_vec, int *cond_id);
+int tho_energy_set_porosity_linear(tho_problem *t, const double *press_ref, const double *slope);
 int tho_energy_set_soils(tho_problem *t, const double *por, const int *satfunc_type, const double *alpha, const double *lambda,
                          const double *sat_res, const double *perm_x, const double *perm_y, const double *perm_z,
                          const double *heat_cap, const double *tcond_wet, const double *tcond_dry, const double *talpha,

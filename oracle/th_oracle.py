@@ -32,6 +32,7 @@ def lib():
         L.tho_set_eos.argtypes = [ct.c_void_p, ct.c_int, ct.c_int]
         L.tho_energy_add_condition.argtypes = [ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, _ip, _dp, _dp, _dp, _dp, _ip]
         L.tho_energy_set_soils.argtypes = [ct.c_void_p, _dp, _ip] + [_dp] * 11
+        L.tho_energy_set_porosity_linear.argtypes = [ct.c_void_p, _dp, _dp]
         L.tho_energy_set_condition_values.argtypes = [ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, _dp]
         L.tho_energy_set_bc_pressure.argtypes = [ct.c_void_p, ct.c_int, ct.c_int, _dp]
         L.tho_mass_set_bc_temperature.argtypes = [ct.c_void_p, ct.c_int, ct.c_int, _dp]
@@ -115,6 +116,11 @@ class THOracle:
         else:
             (ax, px), (ay, py), (az, pz) = b(perm[0]), b(perm[1]), b(perm[2])
         _chk(self.L.tho_energy_set_soils(self.h, p_por, pt, p_al, p_l, p_s, px, py, pz, p_hc, p_w, p_d, p_ta, p_ds))
+
+    def energy_set_porosity_linear(self, press_ref, slope):
+        """POROSITY_LINEAR for the heat equation's auxvars (por of energy_set_soils is then porosity_base)"""
+        (a, pa), (b, pb) = _d(press_ref), _d(slope)
+        _chk(self.L.tho_energy_set_porosity_linear(self.h, pa, pb))
 
     def energy_set_condition_values(self, kind, cond_id, values):
         v, pv = _d(values)

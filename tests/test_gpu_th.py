@@ -121,9 +121,40 @@ def test_th_error_paths():
 def test_th_columns_vs_oracle(ncols, nz, assembly):
     """soil columns with gravity, Dirichlet boundaries on both equations, permuted internal layout (column tiles):
     operators and two coupled time steps against the oracle"""
+    _th_columns_vs_oracle(ncols, nz, assembly, mixed=False)
+
+
+@pytest.mark.parametrize("assembly", ["general", "columns"])
+def test_th_columns_with_mixed_saturation_functions(assembly):
+    """satParams belong to the auxvar (ThermalEnthalpySoilAuxType.F90:156-157, 240-249), so the cells of one TH mesh may use
+    different retention curves: van Genuchten, Brooks-Corey and both smoothed Brooks-Corey kinds side by side, every cell its own
+    parameters -- operators and two coupled steps against the oracle (parity unpinned by the reference: no fixture mixes them)"""
+    _th_columns_vs_oracle(70, 9, assembly, mixed=True)
+
+
+@pytest.mark.parametrize("assembly", ["general", "columns"])
+def test_th_columns_with_the_linear_porosity_model(assembly):
+    """POROSITY_LINEAR in both equations (PorosityFunctionMod.F90:144-163 at the cell pressure, ThermalEnthalpySoilAuxType.F90:246-249):
+    porosity(P) in both accumulation terms, dpor_dP in the mass equation's diagonal (GE:1675-1677) and in d(energy)/dP
+    (GoveqnThermalEnthalpySoilType.F90:2178-2182); together with mixed saturation functions; against the oracle, whose
+    derivative is checked by finite differences (tests/test_oracle_operators.py).  Parity unpinned by the reference."""
+    _th_columns_vs_oracle(70, 9, assembly, mixed=True, linear_porosity=True)
+
+
+def _th_columns_vs_oracle(ncols, nz, assembly, mixed, linear_porosity=False):
     rng = np.random.default_rng(5)
     tp = P.th_columns(ncols=ncols, nz=nz, perm_mult=np.exp(0.3 * rng.standard_normal(ncols)))
     n = tp.mesh.ncells_local
+    if linear_porosity:
+        tp.por_pressure_reference = np.full(n, 101325.0) + rng.uniform(-2e4, 2e4, n)
+        tp.por_slope = rng.uniform(1e-7, 6e-7, n)
+    if mixed:
+        kinds = np.array([C.SAT_FUNC_VAN_GENUCHTEN, C.SAT_FUNC_BROOKS_COREY, C.SAT_FUNC_SMOOTHED_BROOKS_COREY_BZ2,
+                          C.SAT_FUNC_SMOOTHED_BROOKS_COREY_BZ3], dtype=np.int32)
+        tp.satfunc_type = kinds[rng.integers(0, 4, n)]
+        tp.alpha = tp.alpha * (1.0 + 0.2 * rng.random(n))
+        tp.lam = 0.4 + 0.3 * rng.random(n)
+        tp.sat_res = 0.2 + 0.1 * rng.random(n)
     o = P.to_th_oracle(tp)
     g = P.to_th_gpu(tp, {"ksp_type": "gmres", "pc_type": "ilu", "assembly": assembly})
     x = _state(tp, seed=2, dp=(0.0, 9e4), dt=(0.0, 15.0))

@@ -216,3 +216,41 @@ def test_linear_porosity_and_mixed_saturation_functions_jacobian_vs_finite_diffe
         assert not np.allclose(o2.get(C.AUXVAR_INTERNAL, C.VAR_MASS), mass)
     conv, reason = o.step_dt(prob.dt, 1)
     assert conv and reason > 0
+
+
+def test_th_linear_porosity_and_mixed_saturation_functions_jacobian_vs_finite_differences():
+    """the coupled thermal-hydrology restatement with POROSITY_LINEAR in both equations (ThermalEnthalpySoilAuxType.F90:246-249:
+    PorosityFunctionComputation at the cell pressure; accumulation terms GE(heat):1174-1219, their pressure derivative with the
+    dpor_dP terms :2178-2182, the mass equation's AccumDeriv GE:1675-1677) and per-cell saturation functions: no fixture of the
+    reference exercises either, so all four Jacobian blocks are checked against central differences of the restated residual"""
+    rng = np.random.default_rng(8)
+    tp = P.th_columns(ncols=3, nz=6, perm_mult=np.exp(0.3 * rng.standard_normal(3)))
+    n = tp.mesh.ncells_local
+    kinds = np.array([C.SAT_FUNC_VAN_GENUCHTEN, C.SAT_FUNC_BROOKS_COREY, C.SAT_FUNC_SMOOTHED_BROOKS_COREY_BZ2,
+                      C.SAT_FUNC_SMOOTHED_BROOKS_COREY_BZ3], dtype=np.int32)
+    tp.satfunc_type = kinds[rng.integers(0, 4, n)]
+    tp.lam = 0.4 + 0.3 * rng.random(n)
+    tp.por_pressure_reference = np.full(n, 101325.0) + rng.uniform(-2e4, 2e4, n)
+    tp.por_slope = rng.uniform(1e-7, 6e-7, n)
+    o = P.to_th_oracle(tp)
+    o.set_dtime(tp.dt); o.pre_solve()
+    x = np.concatenate([tp.press_ic + rng.uniform(0.0, 9e4, n), tp.temp_ic + rng.uniform(0.0, 15.0, n)])
+    rp, cj, val = o.jacobian(x)
+    J = _dense(rp, cj, val, 2 * n)
+    for j in range(2 * n):
+        h = 1e-2 if j < n else 1e-4
+        xp = x.copy(); xp[j] += h
+        xm = x.copy(); xm[j] -= h
+        col = (o.residual(xp) - o.residual(xm)) / (2 * h)
+        for blk in (slice(0, n), slice(n, 2 * n)):
+            if j >= n and blk.start == 0 and (j - n) % 6 in (0, 5):
+                continue   # d(mass)/dT of a cell that carries a boundary condition: the reference's off-diagonal Jacobian has no
+                           # boundary term there (GE:2203-2612 loops internal connections only); the same with constant porosity
+            scale = np.abs(J[blk, j]).max() + 1e-30
+            assert np.abs(col[blk] - J[blk, j]).max() / scale < 1e-3, (j, blk)
+    # the model really is in: with the slope switched off the accumulation terms differ
+    tp2 = P.th_columns(ncols=3, nz=6, perm_mult=np.exp(0.3 * np.random.default_rng(8).standard_normal(3)))
+    tp2.satfunc_type, tp2.lam = tp.satfunc_type, tp.lam
+    o2 = P.to_th_oracle(tp2)
+    o2.set_dtime(tp.dt); o2.pre_solve()
+    assert not np.allclose(o2.residual(x), o.residual(x))
