@@ -438,8 +438,19 @@ def main():
     comm = soe.comm_stats()
     layout = soe.assembly_info()
 
-    stats = {k: soe.kernel_stats(k) for k in ("spmv", "pc_apply", "pc_setup", "residual", "jacobian", "vec", "reduce")}
+    stats = {k: soe.kernel_stats(k) for k in ("spmv", "spmv_pc", "pc_apply", "pc_setup", "residual", "jacobian", "vec", "reduce")}
     soe.SetOption("profile", 0)
+    # the plain CSR SpMV kernel (y = A x) by itself, right behind the timed region: where M^{-1} A v runs as one kernel (vertical-only
+    # grids) the only CSR SpMV launches left inside a Newton iteration are the line search's (same matrix pass, f in instead of y
+    # out, three reductions): the roofline object is measured on those, live; this is the reference point next to it
+    plain_spmv = None
+    if layout["spmv_variant"] in (20, 21) and world == 1:
+        try:
+            ms, by = soe.bench_kernel("spmv", layout["spmv_variant"], 20)
+            plain_spmv = {"kernel": "k_spmv_c (y = A x), 20 launches behind the timed region", "avg_launch_ms": round(ms, 5),
+                          "achieved": round(by / (ms * 1e-3) / 1e9, 1), "frac": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        except Exception as e:
+            plain_spmv = {"error": repr(e)}
 
     # rank-local SpMV of every rank (the roofline kernel): average launch time, gathered on the host
     sp = stats["spmv"]
@@ -491,12 +502,18 @@ def main():
                         kernels[k]["moved_kernels"] = sorted(mv["kernels"])
                     if alg > HBM_PEAK_GBS or (mv and mv["hbm_bytes_per_launch"] < 0.9 * s["bytes_per_launch"]):
                         kernels[k]["structure_exploited"] = True
-        roof = {"kernel": "csr_spmv_fp64 (k_spmv_c: CSR values + compact 16-bit index, see DESIGN.md section 4)"
+        fused = stats["spmv_pc"]["launches"] > 0
+        roof = {"kernel": ("csr_spmv_fp64 (k_spmv_c: CSR values + compact 16-bit index; the launches timed are the line search's pass "
+                           "-- x.x, f.(A x), ||x|| reduced on the way, A x not written -- because the two products of a BiCGStab iteration "
+                           "run fused with the column solve: kernels.spmv_pc, DESIGN.md section 4)" if fused else
+                           "csr_spmv_fp64 (k_spmv_c: CSR values + compact 16-bit index, see DESIGN.md section 4)")
                           if compact else "csr_spmv_fp64",
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "achieved_is": "algorithmic CSR bytes (12 nnz + 20 N + 4, SURVEY 8d) / HIP-event average launch time",
                 "bytes_per_launch": sp["bytes_per_launch"], "avg_launch_ms": round(avg_ms, 5), "launches_timed": sp["launches"]}
+        if plain_spmv:
+            roof["plain_spmv_kernel"] = plain_spmv
         if stale:
             roof["traffic_refused"] = stale
         if traffic:

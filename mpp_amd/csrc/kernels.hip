@@ -1738,7 +1738,14 @@ __global__ __launch_bounds__(kBlock) void k_tri_solve_dots(TriArgs a, const doub
 // store to a scratch line) -- so that the compiler can count the outstanding operations instead of draining them.
 // Arithmetic per column is the one of k_tri_solve_dots (same order, same roundings); the dot products are summed per lane
 // over the column, then over the 64 lanes: one partial sum per tile, layout partials[j*nb + tile].
-template <int ND, int G, int RF, int RB>
+// SPMV (round 3): the right-hand side is not read but formed on the way, r = A x with A the column's tridiagonal taken from the
+// CSR values (`r` then points at x): z = M^{-1} (A x) in one pass -- what BiCGStab / GMRES ask for twice per iteration on a
+// vertical-only grid, where the CSR matrix IS the block diagonal of column tridiagonals.  A x is never written or read back
+// (98 -> 72 bytes per cell for the SpMV + column solve pair).  Row k is summed as the CSR SpMV kernels sum it -- products rounded
+// one by one, added in entry order (lower, diagonal, upper), no fused multiply-add -- so z equals the two-kernel result bit for
+// bit.  The slots of a row are computed (rows of a column tile are level-major, 2 entries in the end rows and 3 between: the
+// pattern of a vertical-only grid in the tiled layout); an entry a row does not have is read from a harmless slot and meets x = 0.
+template <int ND, int G, int RF, int RB, bool SPMV>
 __global__ __launch_bounds__(64) void k_tri_solve_lds(TriArgs a, const double *__restrict__ r, double *__restrict__ z,
                                                       const double *__restrict__ w, double *__restrict__ partials,
                                                       double *__restrict__ scratch64) {
@@ -1750,7 +1757,61 @@ __global__ __launch_bounds__(64) void k_tri_solve_lds(TriArgs a, const double *_
   const size_t cbase = (size_t)tile * 64 * nz + (valid ? lane : 0);   // idle lanes of the last tile shadow lane 0 ...
   double *zs = valid ? z + cbase : scratch64 + lane;                  // ... and store into a scratch line
   const size_t tws = valid ? (size_t)tw : 0;
-  {
+  if (SPMV) {
+#pragma clang fp contract(off)   // the row sums below must round like the CSR SpMV's; d = r - l prev is written as the fma it is elsewhere
+    const int vl = valid ? lane : 0;
+    const double *__restrict__ vt = a.val + (size_t)tile * 64 * (3 * nz - 2);   // this tile's CSR values
+    double xb[RF][G], lb[RF][G], v0[RF][G], v1[RF][G], v2[RF][G];
+    auto fetch = [&](int q, int kfirst) {   // levels kfirst .. kfirst+G-1 (clamped) into group q
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        const int k = min(kfirst + j, nz - 1);
+        const size_t i = cbase + (size_t)k * tw;
+        xb[q][j] = ldnt(r + i); lb[q][j] = ldnt(a.l + i);
+        // first slot of row k in the tile: [di up] at level 0, [lo di up] between, [lo di] at the top
+        const int s = (k == 0) ? 2 * vl : (k == nz - 1) ? 2 * tw + 3 * (nz - 2) * tw + 2 * vl : 2 * tw + 3 * ((k - 1) * tw + vl);
+        const int sd = (k == 0) ? s : s + 1;                         // the diagonal
+        const int su = (k == nz - 1) ? sd : sd + 1;                  // no upper entry in the top row: a harmless slot
+        v0[q][j] = ldnt(vt + s); v1[q][j] = ldnt(vt + sd); v2[q][j] = ldnt(vt + su);
+      }
+    };
+#pragma unroll
+    for (int q = 0; q < RF; ++q) { fetch(q, q * G); __builtin_amdgcn_sched_barrier(0); }
+    // level k arrives: row k-1 is complete (its upper neighbour is x_k).  Carried: x_{k-2}, x_{k-1}, row k-1's entries and factor
+    double xm2 = 0.0, xm1 = 0.0, plo = 0.0, pdi = 0.0, pup = 0.0, pl = 0.0, prev = 0.0;
+    auto finish = [&](int kr, double xnext) {   // row kr from the carried values and x_{kr+1}
+      const double p0 = plo * xm2, p1 = pdi * xm1, p2 = pup * xnext;
+      const double rk = (p0 + p1) + p2;
+      const double d = fma(-pl, prev, rk);
+      prev = d;
+      dsl[kr * 64 + lane] = d;
+    };
+    auto step = [&](int k, double xk, double lo, double di, double up, double lk) {
+      if (k > 0) finish(k - 1, xk);
+      xm2 = (k > 0) ? xm1 : 0.0;   // x_{-1} = 0 meets the lower entry row 0 does not have
+      xm1 = xk;
+      plo = lo; pdi = di; pup = up; pl = lk;
+    };
+    int k0 = 0;
+    for (; k0 + RF * G <= nz; k0 += RF * G) {
+#pragma unroll
+      for (int q = 0; q < RF; ++q) {
+#pragma unroll
+        for (int j = 0; j < G; ++j) step(k0 + q * G + j, xb[q][j], v0[q][j], v1[q][j], v2[q][j], lb[q][j]);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(q, k0 + (RF + q) * G);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < RF; ++q)
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        const int k = k0 + q * G + j;
+        if (k < nz) step(k, xb[q][j], v0[q][j], v1[q][j], v2[q][j], lb[q][j]);
+      }
+    finish(nz - 1, 0.0);   // the top row: no upper neighbour
+  } else {
     double rb[RF][G], lb[RF][G];
     auto fetch = [&](int q, int kfirst) {   // levels kfirst .. kfirst+G-1 (clamped) into group q
 #pragma unroll
@@ -2229,11 +2290,19 @@ int launch_tri_solve_lds(const TriArgs &a, const double *r, double *z, const dou
                          int group, hipStream_t stream) {
   const dim3 grid(tri_solve_lds_blocks(a.ncols));
   const size_t shmem = (size_t)a.nz * 64 * sizeof(double);
-#define TRI_LDS(ND, G, RF, RB) hipLaunchKernelGGL((k_tri_solve_lds<ND, G, RF, RB>), grid, dim3(64), shmem, stream, a, r, z, w, partials, scratch64)
+#define TRI_LDS(ND, G, RF, RB) hipLaunchKernelGGL((k_tri_solve_lds<ND, G, RF, RB, false>), grid, dim3(64), shmem, stream, a, r, z, w, partials, scratch64)
   // `group` = levels in flight per stream: rings of 4-level groups
   if (w) { if (group <= 8) TRI_LDS(2, 4, 2, 2); else if (group <= 16) TRI_LDS(2, 4, 4, 3); else TRI_LDS(2, 4, 6, 4); }
   else { if (group <= 8) TRI_LDS(1, 4, 2, 2); else if (group <= 16) TRI_LDS(1, 4, 4, 4); else TRI_LDS(1, 4, 6, 5); }
 #undef TRI_LDS
+  return (int)grid.x;
+}
+int launch_spmv_tri_lds(const TriArgs &a, const double *x, double *z, const double *w, double *partials, double *scratch64, hipStream_t stream) {
+  const dim3 grid(tri_solve_lds_blocks(a.ncols));
+  const size_t shmem = (size_t)a.nz * 64 * sizeof(double);
+  // forward: five streams (x, three matrix entries, l) in a ring of 3 groups of 4 levels = 60 loads in flight (the counter holds 63)
+  if (w) hipLaunchKernelGGL((k_tri_solve_lds<2, 4, 3, 4, true>), grid, dim3(64), shmem, stream, a, x, z, w, partials, scratch64);
+  else hipLaunchKernelGGL((k_tri_solve_lds<1, 4, 3, 5, true>), grid, dim3(64), shmem, stream, a, x, z, w, partials, scratch64);
   return (int)grid.x;
 }
 int launch_tri_back_dots(const TriArgs &a, const double *d, double *z, double *partials, hipStream_t stream) {

@@ -180,6 +180,10 @@ constexpr int kTriLdsMaxLevels = 120;   // 120 x 512 B = 60 KB of LDS per wave
 int tri_solve_lds_blocks(int ncols);
 int launch_tri_solve_lds(const TriArgs &a, const double *r, double *z, const double *w, double *partials, double *scratch64,
                          int group, hipStream_t stream);
+// z = M^{-1} (A x) in one pass on a vertical-only grid (A = the CSR values of the column tridiagonals at their computed slots, a.val;
+// row sums as the CSR SpMV kernels form them: same bits as launch_spmv_compact followed by launch_tri_solve_lds), with the same
+// partial sums; nz >= 2
+int launch_spmv_tri_lds(const TriArgs &a, const double *x, double *z, const double *w, double *partials, double *scratch64, hipStream_t stream);
 // z = U^{-1} d for a right-hand side the assembly pass already forward-eliminated, with the partial sums of z.z
 int launch_tri_back_dots(const TriArgs &a, const double *d, double *z, double *partials, hipStream_t stream);
 void launch_jacobi_setup(int n, const int *diag_slot, const double *val, double *invd, hipStream_t stream);

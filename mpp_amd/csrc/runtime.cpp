@@ -28,7 +28,7 @@
 namespace mpp {
 
 const char *kclass_name(int k) {
-  static const char *names[KC_COUNT] = {"spmv", "pc_apply", "pc_setup", "residual", "jacobian", "vec", "reduce"};
+  static const char *names[KC_COUNT] = {"spmv", "pc_apply", "pc_setup", "residual", "jacobian", "vec", "reduce", "spmv_pc"};
   return (k >= 0 && k < KC_COUNT) ? names[k] : "?";
 }
 

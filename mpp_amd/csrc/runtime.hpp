@@ -78,7 +78,7 @@ struct DevBuf {
 };
 
 // ---- kernel classes for the HIP-event profiler ----
-enum KClass : int { KC_SPMV = 0, KC_PC_APPLY, KC_PC_SETUP, KC_RESIDUAL, KC_JACOBIAN, KC_VEC, KC_REDUCE, KC_COUNT };
+enum KClass : int { KC_SPMV = 0, KC_PC_APPLY, KC_PC_SETUP, KC_RESIDUAL, KC_JACOBIAN, KC_VEC, KC_REDUCE, KC_SPMV_PC, KC_COUNT };
 const char *kclass_name(int k);
 
 struct Profiler {
@@ -199,6 +199,8 @@ struct Options {
                                    // liveness then does not depend on the dispatch order, at +50-75 % per application
   unsigned ilu_chain_spins = 1u << 16;   // polls (~0.4 us apart: ~26 ms) before a chained wait gives up and the apply is redone per level
   bool ls_ahead = true;        // the line search's first reductions ride behind the Krylov solver's last update
+  bool fused_spmv_pc = true;   // vertical-only grids, column preconditioner: M^{-1} A v as one kernel (k_tri_solve_lds<..., SPMV>) instead of
+                               // the CSR SpMV followed by the column solve -- A v is never written or read back
   bool ls_spec = true;         // ... and the search's first trial point (the full step) is evaluated there too (LsAhead::spec)
   bool wide_xr = true;         // BiCGStab update kernel on a one-pair-per-lane grid (large vectors)
   double collective_timeout = 900.0;   // seconds a rank waits for device scalars that depend on the other ranks (an all-reduce) before it

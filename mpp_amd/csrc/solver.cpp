@@ -1340,12 +1340,16 @@ struct Solver {
     // (with the reductions the kernel carries three more streams and one partial sum per block: 6 tiles per wave measured best,
     // 0.958 ms against 1.07 at 2 and 0.977 at 4: profiles/r02_kbench_spmv_dots_tpw.json)
     const int tpw = opt.spmv_tpw > 0 ? opt.spmv_tpw : 6, nv = x ? 3 : 2;
-    ProfScope ps(prof, KC_REDUCE);
     const size_t nbmax = (size_t)spmv_compact_dots_blocks(tpw, nred);
     const size_t need = 3 * (nbmax + nbmax / 2048 + 1);
     if (spmv_partials.n < need) spmv_partials.alloc(need);
-    const int nbk = launch_spmv_compact_dots(tpw, nred, max_row_nnz, compact_split, d_tileptr.p, d_roff.p, d_dcol.p, d_val.p, y, f, x,
-                                             spmv_partials.p, stream);
+    int nbk;
+    {   // a CSR SpMV pass like any other (values, index, x in; f in instead of y out): timed in the SpMV class
+      ProfScope ps(prof, KC_SPMV);
+      nbk = launch_spmv_compact_dots(tpw, nred, max_row_nnz, compact_split, d_tileptr.p, d_roff.p, d_dcol.p, d_val.p, y, f, x,
+                                     spmv_partials.p, stream);
+    }
+    ProfScope ps(prof, KC_REDUCE);
     finalize(nbk, nv, spmv_partials.p, slot);
     if (comm.active() && nreduce > 0) comm.allreduce_sum(sc.p + S_SUM0, nreduce, stream);
     return nv;
@@ -1577,6 +1581,26 @@ struct Solver {
       if (!solved) run_graph(ilu_graph, [&] { ilu_solve_levels(); });
       launch_gather(nrow, d_posU.p, ilu_x.p, z, stream);             // back to the internal row order
     } else launch_copy(nred, r, z, stream);
+  }
+  // t = M^{-1} A v with the Krylov dot products of t, in ONE kernel: vertical-only grids, column preconditioner, LDS column solve
+  bool fused_spmv_pc() const {
+    return opt.fused_spmv_pc && opt.pc_type == 2 && !th && !thermal && vertical_only && columns && nghost == 0 && nz >= 2 && tri_lds() &&
+           pc_ready && fused_pc_dots();
+  }
+  void op_BA_dots(const double *v, double *t, const double *w, int slot = 0, int nreduce = -1, int step = -1) {
+    if (!fused_spmv_pc()) {
+      op_spmv(v, Wk.p);
+      op_pc_apply_dots(Wk.p, t, w, slot, nreduce, step);
+      return;
+    }
+    {
+      ProfScope ps(prof, KC_SPMV_PC);
+      const int nbk = launch_spmv_tri_lds(tri_args(), v, t, w, col_partials.p, tri_scratch.p, stream);
+      finalize(nbk, w ? 2 : 1, col_partials.p, slot, step);
+    }
+    if (nreduce < 0) nreduce = w ? 2 : 1;
+    if (comm.active() && nreduce > 0) comm.allreduce_sum(sc.p + S_SUM0, nreduce, stream);
+    bcgs_step(step);
   }
   void op_BA(const double *v, double *t) {  // t = M^{-1} A v  (left preconditioning)
     op_spmv(v, Wk.p);
@@ -1834,17 +1858,16 @@ struct Solver {
         launch_bcgs_p(nred, Pv.p, Pcur, Rcur, V.p, sc.p, stream);
         Pcur = Pv.p;
       }
-      op_spmv(Pcur, Wk.p);
+      // v = M^{-1} A p and t = M^{-1} A s: SpMV + column solve, one kernel each where the grid allows it (op_BA_dots)
       if (merge0 && i == 0) {
-        op_pc_apply_dots(Wk.p, V.p, RP.p, 0, 3);   // (v,rp), (v,v) and the parked (rp,rp) in one all-reduce
+        op_BA_dots(Pcur, V.p, RP.p, 0, 3);   // (v,rp), (v,v) and the parked (rp,rp) in one all-reduce
         launch_bcgs_scalars(6, sc.p, stream);
         launch_bcgs_scalars(2, sc.p, stream);
         pub_valid = false;
-      } else op_pc_apply_dots(Wk.p, V.p, RP.p, 0, -1, 2);   // (v,rp) in sc[S_SUM0]  [(v,v) in S_SUM0+1 is not used]; alpha
+      } else op_BA_dots(Pcur, V.p, RP.p, 0, -1, 2);   // (v,rp) in sc[S_SUM0]  [(v,v) in S_SUM0+1 is not used]; alpha
       { ProfScope ps(prof, KC_VEC); launch_waxpy(nred, S.p, sc.p, S_ALPHA, -1.0, 0.0, V.p, Rcur, stream); }
-      op_spmv(S.p, Wk.p);
       int end_step = 4;
-      op_pc_apply_dots(Wk.p, T.p, S.p, 0, -1, 3);    // (t,s), (t,t) in sc[S_SUM0], sc[S_SUM0+1]; omega
+      op_BA_dots(S.p, T.p, S.p, 0, -1, 3);    // (t,s), (t,t) in sc[S_SUM0], sc[S_SUM0+1]; omega
       {
         ProfScope ps(prof, KC_REDUCE);
         const bool wide = opt.wide_xr && nred >= (1 << 22);
@@ -1962,10 +1985,8 @@ struct Solver {
       while (it < m && *its < opt.ksp_max_it) {
         double *vnew = vv[it + 1].p;
         const bool dots_in_solve = it == 0 && fused_pc_dots();   // (w, v0) reduced by the column solve that produces w
-        if (dots_in_solve) {
-          op_spmv(vv[0].p, Wk.p);
-          op_pc_apply_dots(Wk.p, vnew, vv[0].p);
-        } else op_BA(vv[it].p, vnew);
+        if (dots_in_solve) op_BA_dots(vv[0].p, vnew, vv[0].p);
+        else op_BA(vv[it].p, vnew);
         if (!dots_in_solve) {  // classical Gram-Schmidt: all dots, then one fused update
           ProfScope ps(prof, KC_REDUCE);
           DotArgs a;
@@ -3090,6 +3111,7 @@ struct Solver {
     else if (key == "host_poll") opt.host_poll = num() != 0;
     else if (key == "collective_timeout") opt.collective_timeout = num();
     else if (key == "ls_spec") opt.ls_spec = num() != 0;
+    else if (key == "fused_spmv_pc") opt.fused_spmv_pc = num() != 0;
     else if (key == "spmv_tpw") opt.spmv_tpw = (int)num();
     else if (key == "soil_classes") { opt.soil_classes = num() != 0; soil_dirty = true; }
     else if (key == "level_geometry") { opt.level_geometry = num() != 0; soil_dirty = true; }
@@ -3125,6 +3147,7 @@ struct Solver {
     switch (cls) {
       case KC_SPMV: return 12.0 * NNZ + 20.0 * N + 4.0;
       case KC_PC_APPLY: return 40.0 * N;                   // 3 diagonals + rhs in, x out
+      case KC_SPMV_PC: return 12.0 * NNZ + 20.0 * N + 4.0 + 40.0 * N;   // the two it replaces, as SURVEY counts them
       case KC_PC_SETUP: return 8.0 * NNZ + 24.0 * N;
       case KC_RESIDUAL: return 96.0 * N;                   // P, 5 soil arrays, accum_prev, 4 geometry arrays in; F out
       case KC_JACOBIAN: return 84.0 * N + 8.0 * NNZ;       // same reads + rowptr, CSR values out

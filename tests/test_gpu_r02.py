@@ -167,11 +167,13 @@ def test_linear_porosity_and_mixed_saturation_functions(route, linear_porosity, 
 
 
 def test_linear_porosity_is_refused_where_it_is_not_built():
+    """the model belongs to the flow equation (VSFM, and both equations of the coupled TH system: tests/test_gpu_th.py); the soil
+    heat-diffusion path has no pressure to evaluate it at"""
     from mpp_amd import vsfm as V
-    tp = P.th_columns(ncols=2, nz=6)
-    g = P.to_th_gpu(tp)
+    tp = P.thermal_mms(3, 3, 3, 3)
+    g = P.to_thermal_gpu(tp)
     n = tp.mesh.ncells_local
-    with pytest.raises(V.MPPError, match="VSFM only"):
+    with pytest.raises(V.MPPError, match="linear porosity"):
         V.VSFMMPPSetSoilPorosityLinearModel(g, 1, np.full(n, 0.4), np.full(n, 101325.0), np.full(n, 1e-7))
 
 

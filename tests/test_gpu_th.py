@@ -306,3 +306,29 @@ def test_th_compact_spmv_index_of_the_field_blocked_system():
     for var in (C.VAR_PRESSURE, 605):
         va, vb = a.soe.GetDataForCLM(C.AUXVAR_INTERNAL, var), b.soe.GetDataForCLM(C.AUXVAR_INTERNAL, var)
         assert np.abs(va - vb).max() <= 1e-10 * np.abs(vb).max()
+
+
+def test_th_at_config_5_size_every_column_gives_the_single_column_answer():
+    """BASELINE config 5's size on one GPU (512 x 512 columns x 80 layers, 21 M cells, 42 M unknowns, BiCGStab + per-column
+    block-Jacobi): identical columns are independent copies of one problem, so after two coupled time steps every column must
+    hold the answer of the CPU oracle solving ONE such column (the global Newton norm sees 262 144 copies, so the stopping
+    point can differ by an iteration: compared at the nonlinear tolerance), and all columns must agree with each other to
+    rounding -- a size-independent check of the layout, the fused column march and the 2 x 2 block column solve at full size"""
+    ncols, nz = 512 * 512, 80
+    tp = P.th_columns(ncols=ncols, nz=nz)
+    g = P.to_th_gpu(tp, {"ksp_type": "bcgs", "pc_type": "bjacobi"})
+    one = P.th_columns(ncols=1, nz=nz)
+    o = P.to_th_oracle(one)
+    for s in range(2):
+        P.th_gpu_set_conditions(tp, g); P.th_set_conditions(one, o)
+        conv, reason = g.soe.StepDT(tp.dt, s + 1)
+        assert conv and reason > 0
+        co, ro = o.step_dt(one.dt)
+        assert co
+    p_o, t_o = o.solution()
+    p = g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE).reshape(ncols, nz)
+    t = g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, 605).reshape(ncols, nz)
+    assert np.abs(p - p[0]).max() <= 1e-9 * np.abs(p[0]).max() and np.abs(t - t[0]).max() <= 1e-9
+    assert np.abs(p[0] - p_o).max() <= 1e-6 * np.abs(p_o).max()
+    assert np.abs(t[0] - t_o).max() <= 1e-6
+    assert g.soe.counters()["time_cuts"] == 0

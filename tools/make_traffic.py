@@ -17,12 +17,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # kernel class of bench.py's `kernels` object -> the kernels that make up a launch of that class (substring of the demangled name)
 CLASSES = {
-    "spmv": ["k_spmv_c<3, false, false>"],
+    "spmv": ["k_spmv_c<3, false, true>"],          # the launches bench.py times in the SpMV class (the line search's pass)
+    "spmv_plain": ["k_spmv_c<3, false, false>"],
+    "spmv_pc": ["k_tri_solve_lds<2, 4, 3, 4, true>"],
     "residual": ["k_assemble_cols<0,", "k_bc<0>"],
     "jacobian": ["k_assemble_cols<2,", "k_bc<2>"],
     "pc_apply": ["k_tri_solve_lds<2,"],
     "pc_apply_first": ["k_tri_back_dots"],
-    "spmv_with_line_search_sums": ["k_spmv_c<3, false, true>"],
     "krylov_update": ["k_bcgs_xr<true>"],
     "vec": ["k_waxpy"],
 }
