@@ -1761,6 +1761,11 @@ __global__ __launch_bounds__(64) void k_tri_solve_lds(TriArgs a, const double *_
 #pragma clang fp contract(off)   // the row sums below must round like the CSR SpMV's; d = r - l prev is written as the fma it is elsewhere
     const int vl = valid ? lane : 0;
     const double *__restrict__ vt = a.val + (size_t)tile * 64 * (3 * nz - 2);   // this tile's CSR values
+    // The 3 tw entries of a middle level are contiguous, row after row: the wave loads them as three fully coalesced segments
+    // (lane l: entries l, tw + l, 2 tw + l) and turns them into (lower, diagonal, upper) of its own row -- entries 3l, 3l + 1,
+    // 3l + 2 -- through a 1.5 KB LDS scratch when the level is used; three 8-byte loads at a 24-byte lane stride would touch every
+    // line of the segment three times.  The two end levels (2 entries per row) are read directly.
+    __shared__ double tr[3 * 64];
     double xb[RF][G], lb[RF][G], v0[RF][G], v1[RF][G], v2[RF][G];
     auto fetch = [&](int q, int kfirst) {   // levels kfirst .. kfirst+G-1 (clamped) into group q
 #pragma unroll
@@ -1768,11 +1773,15 @@ __global__ __launch_bounds__(64) void k_tri_solve_lds(TriArgs a, const double *_
         const int k = min(kfirst + j, nz - 1);
         const size_t i = cbase + (size_t)k * tw;
         xb[q][j] = ldnt(r + i); lb[q][j] = ldnt(a.l + i);
-        // first slot of row k in the tile: [di up] at level 0, [lo di up] between, [lo di] at the top
-        const int s = (k == 0) ? 2 * vl : (k == nz - 1) ? 2 * tw + 3 * (nz - 2) * tw + 2 * vl : 2 * tw + 3 * ((k - 1) * tw + vl);
-        const int sd = (k == 0) ? s : s + 1;                         // the diagonal
-        const int su = (k == nz - 1) ? sd : sd + 1;                  // no upper entry in the top row: a harmless slot
-        v0[q][j] = ldnt(vt + s); v1[q][j] = ldnt(vt + sd); v2[q][j] = ldnt(vt + su);
+        if (k == 0) {                 // [di up]: lower slot harmless (meets x = 0)
+          v0[q][j] = ldnt(vt + 2 * vl); v1[q][j] = v0[q][j]; v2[q][j] = ldnt(vt + 2 * vl + 1);
+        } else if (k == nz - 1) {     // [lo di]: upper slot harmless
+          const int s = 2 * tw + 3 * (nz - 2) * tw + 2 * vl;
+          v0[q][j] = ldnt(vt + s); v1[q][j] = ldnt(vt + s + 1); v2[q][j] = v1[q][j];
+        } else {                      // three coalesced segments of the level's 3 tw entries
+          const int b = 2 * tw + 3 * (k - 1) * tw + vl;
+          v0[q][j] = ldnt(vt + b); v1[q][j] = ldnt(vt + b + tw); v2[q][j] = ldnt(vt + b + 2 * tw);
+        }
       }
     };
 #pragma unroll
@@ -1787,6 +1796,12 @@ __global__ __launch_bounds__(64) void k_tri_solve_lds(TriArgs a, const double *_
       dsl[kr * 64 + lane] = d;
     };
     auto step = [&](int k, double xk, double lo, double di, double up, double lk) {
+      if (k > 0 && k < nz - 1) {   // a middle level: (lo, di, up) hold segment entries l, tw + l, 2 tw + l -> this lane's row
+        if (valid) { tr[lane] = lo; tr[tw + lane] = di; tr[2 * tw + lane] = up; }
+        __builtin_amdgcn_wave_barrier();
+        lo = tr[3 * vl]; di = tr[3 * vl + 1]; up = tr[3 * vl + 2];
+        __builtin_amdgcn_wave_barrier();
+      }
       if (k > 0) finish(k - 1, xk);
       xm2 = (k > 0) ? xm1 : 0.0;   // x_{-1} = 0 meets the lower entry row 0 does not have
       xm1 = xk;
