@@ -1745,10 +1745,13 @@ __global__ __launch_bounds__(kBlock) void k_tri_solve_dots(TriArgs a, const doub
 // one by one, added in entry order (lower, diagonal, upper), no fused multiply-add -- so z equals the two-kernel result bit for
 // bit.  The slots of a row are computed (rows of a column tile are level-major, 2 entries in the end rows and 3 between: the
 // pattern of a vertical-only grid in the tiled layout); an entry a row does not have is read from a harmless slot and meets x = 0.
-template <int ND, int G, int RF, int RB, bool SPMV>
+// SPMV == 2: x itself is produced first -- x = U^{-1} d, the back substitution of a right-hand side the assembly pass already
+// forward-eliminated (k_tri_back_dots' arithmetic), written to `xout` and parked in the slab -- then z = M^{-1} (A x) as above with
+// x taken from the slab: the start of a BiCGStab solve (rp = M^{-1} F, v = M^{-1} A rp) in one kernel, with (z,x), (z,z), (x,x).
+template <int ND, int G, int RF, int RB, int SPMV>
 __global__ __launch_bounds__(64) void k_tri_solve_lds(TriArgs a, const double *__restrict__ r, double *__restrict__ z,
                                                       const double *__restrict__ w, double *__restrict__ partials,
-                                                      double *__restrict__ scratch64) {
+                                                      double *__restrict__ scratch64, double *__restrict__ xout) {
   extern __shared__ __attribute__((aligned(16))) double dsl[];   // [nz][64]
   const int lane = threadIdx.x, tile = blockIdx.x;
   const int nz = a.nz;
@@ -1757,6 +1760,52 @@ __global__ __launch_bounds__(64) void k_tri_solve_lds(TriArgs a, const double *_
   const size_t cbase = (size_t)tile * 64 * nz + (valid ? lane : 0);   // idle lanes of the last tile shadow lane 0 ...
   double *zs = valid ? z + cbase : scratch64 + lane;                  // ... and store into a scratch line
   const size_t tws = valid ? (size_t)tw : 0;
+  double accx = 0.0;
+  if (SPMV == 2) {   // x = U^{-1} d, top down
+    double *xs = valid ? xout + cbase : scratch64 + lane;
+    double cb[RB][G], ib[RB][G], db[RB][G];
+    auto fetch = [&](int q, int ktop) {
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        const size_t i = cbase + (size_t)max(ktop - j, 0) * tw;
+        cb[q][j] = ldnt(a.c + i); ib[q][j] = ldnt(a.invb + i); db[q][j] = ldnt(r + i);
+      }
+    };
+#pragma unroll
+    for (int q = 0; q < RB; ++q) { fetch(q, nz - 1 - q * G); __builtin_amdgcn_sched_barrier(0); }
+    double next = 0.0;
+    int k0 = nz - 1;
+    for (; k0 - RB * G + 1 >= 0; k0 -= RB * G) {
+#pragma unroll
+      for (int q = 0; q < RB; ++q) {
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+          const int k = k0 - q * G - j;
+          const double xk = (db[q][j] - cb[q][j] * next) * ib[q][j];
+          next = xk;
+          stnt(xk, xs + (size_t)k * tws);
+          dsl[k * 64 + lane] = xk;
+          accx += xk * xk;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(q, k0 - (RB + q) * G);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < RB; ++q)
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        const int k = k0 - q * G - j;
+        if (k >= 0) {
+          const double xk = (db[q][j] - cb[q][j] * next) * ib[q][j];
+          next = xk;
+          stnt(xk, xs + (size_t)k * tws);
+          dsl[k * 64 + lane] = xk;
+          accx += xk * xk;
+        }
+      }
+  }
   if (SPMV) {
 #pragma clang fp contract(off)   // the row sums below must round like the CSR SpMV's; d = r - l prev is written as the fma it is elsewhere
     const int vl = valid ? lane : 0;
@@ -1772,7 +1821,8 @@ __global__ __launch_bounds__(64) void k_tri_solve_lds(TriArgs a, const double *_
       for (int j = 0; j < G; ++j) {
         const int k = min(kfirst + j, nz - 1);
         const size_t i = cbase + (size_t)k * tw;
-        xb[q][j] = ldnt(r + i); lb[q][j] = ldnt(a.l + i);
+        xb[q][j] = (SPMV == 1) ? ldnt(r + i) : 0.0;   // (SPMV == 2: x is in the slab)
+        lb[q][j] = ldnt(a.l + i);
         if (k == 0) {                 // [di up]: lower slot harmless (meets x = 0)
           v0[q][j] = ldnt(vt + 2 * vl); v1[q][j] = v0[q][j]; v2[q][j] = ldnt(vt + 2 * vl + 1);
         } else if (k == nz - 1) {     // [lo di]: upper slot harmless
@@ -1796,6 +1846,7 @@ __global__ __launch_bounds__(64) void k_tri_solve_lds(TriArgs a, const double *_
       dsl[kr * 64 + lane] = d;
     };
     auto step = [&](int k, double xk, double lo, double di, double up, double lk) {
+      if (SPMV == 2) xk = dsl[k * 64 + lane];   // (rows below k have been replaced by their eliminated sums already: not needed any more)
       if (k > 0 && k < nz - 1) {   // a middle level: (lo, di, up) hold segment entries l, tw + l, 2 tw + l -> this lane's row
         if (valid) { tr[lane] = lo; tr[tw + lane] = di; tr[2 * tw + lane] = up; }
         __builtin_amdgcn_wave_barrier();
@@ -1874,7 +1925,7 @@ __global__ __launch_bounds__(64) void k_tri_solve_lds(TriArgs a, const double *_
       for (int j = 0; j < G; ++j) {
         const size_t i = cbase + (size_t)max(ktop - j, 0) * tw;
         cb[q][j] = ldnt(a.c + i); ib[q][j] = ldnt(a.invb + i);
-        if (ND == 2) wb[q][j] = ldnt(w + i);
+        if (ND == 2) wb[q][j] = (SPMV == 2) ? ldnt(xout + i) : ldnt(w + i);   // (SPMV == 2: w is the x this kernel wrote -- same pointer)
       }
     };
 #pragma unroll
@@ -1910,12 +1961,16 @@ __global__ __launch_bounds__(64) void k_tri_solve_lds(TriArgs a, const double *_
         }
       }
   }
-  if (!valid) acc0 = acc1 = 0.0;
+  if (!valid) acc0 = acc1 = accx = 0.0;
   const double t0 = wave_sum(acc0);
   if (lane == 0) partials[tile] = t0;
   if (ND == 2) {
     const double t1 = wave_sum(acc1);
     if (lane == 0) partials[(size_t)gridDim.x + tile] = t1;
+  }
+  if (SPMV == 2) {
+    const double t2 = wave_sum(accx);
+    if (lane == 0) partials[2 * (size_t)gridDim.x + tile] = t2;
   }
 }
 
@@ -1923,7 +1978,6 @@ __global__ __launch_bounds__(64) void k_tri_solve_lds(TriArgs a, const double *_
 // the partial sums of z.z
 __global__ __launch_bounds__(kBlock) void k_tri_back_dots(TriArgs a, const double *__restrict__ d, double *__restrict__ z,
                                                           double *__restrict__ partials) {
-  __shared__ double lds[kBlock / 64];
   const int c = blockIdx.x * kBlock + threadIdx.x;
   double acc = 0.0;
   if (c < a.ncols) {
@@ -1939,8 +1993,10 @@ __global__ __launch_bounds__(kBlock) void k_tri_back_dots(TriArgs a, const doubl
       acc += xk * xk;
     }
   }
-  const double t = block_sum(acc, lds);
-  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+  // one partial sum per wave = per 64-column tile, as the LDS column kernels leave them: the same sum whichever kernel made z
+  const double t = wave_sum(acc);
+  const int tile = c >> 6;
+  if ((threadIdx.x & 63) == 0 && tile < (a.ncols + 63) / 64) partials[tile] = t;
 }
 
 // dot-product patterns the solvers use; every distinct vector is streamed once
@@ -2037,6 +2093,16 @@ __device__ void bcgs_scalar_step(int step, double *sc) {
     sc[S_DP0] = sqrt(rho);
     sc[S_RHO] = rho;
     sc[S_BETA] = (rho / sc[S_RHOOLD]) * (sc[S_ALPHA] / sc[S_OMEGAOLD]);
+  }
+  if (step == 62) {  // 6 then 2: the solve's first kernel left (v,rp), (v,v), (rp,rp) in S_SUM0 .. S_SUM0+2
+    sc[S_RHOOLD] = 1.0; sc[S_ALPHA] = 1.0; sc[S_OMEGAOLD] = 1.0; sc[S_FLAG] = 0.0;
+    const double rho = sc[S_SUM0 + 2];
+    sc[S_DP0] = sqrt(rho);
+    sc[S_RHO] = rho;
+    sc[S_BETA] = (rho / sc[S_RHOOLD]) * (sc[S_ALPHA] / sc[S_OMEGAOLD]);
+    const double d1 = sc[S_SUM0];
+    sc[S_D1] = d1;
+    sc[S_ALPHA] = sc[S_RHO] / d1;
   }
   if (step == 4 || step == 45) {  // end of iteration: dp^2 = (r,r); rhoold = rho; omegaold = omega; (r,rp) if it was reduced
     sc[S_DP] = sqrt(sc[S_SUM0]);
@@ -2305,7 +2371,7 @@ int launch_tri_solve_lds(const TriArgs &a, const double *r, double *z, const dou
                          int group, hipStream_t stream) {
   const dim3 grid(tri_solve_lds_blocks(a.ncols));
   const size_t shmem = (size_t)a.nz * 64 * sizeof(double);
-#define TRI_LDS(ND, G, RF, RB) hipLaunchKernelGGL((k_tri_solve_lds<ND, G, RF, RB, false>), grid, dim3(64), shmem, stream, a, r, z, w, partials, scratch64)
+#define TRI_LDS(ND, G, RF, RB) hipLaunchKernelGGL((k_tri_solve_lds<ND, G, RF, RB, 0>), grid, dim3(64), shmem, stream, a, r, z, w, partials, scratch64, (double *)nullptr)
   // `group` = levels in flight per stream: rings of 4-level groups
   if (w) { if (group <= 8) TRI_LDS(2, 4, 2, 2); else if (group <= 16) TRI_LDS(2, 4, 4, 3); else TRI_LDS(2, 4, 6, 4); }
   else { if (group <= 8) TRI_LDS(1, 4, 2, 2); else if (group <= 16) TRI_LDS(1, 4, 4, 4); else TRI_LDS(1, 4, 6, 5); }
@@ -2316,14 +2382,20 @@ int launch_spmv_tri_lds(const TriArgs &a, const double *x, double *z, const doub
   const dim3 grid(tri_solve_lds_blocks(a.ncols));
   const size_t shmem = (size_t)a.nz * 64 * sizeof(double);
   // forward: five streams (x, three matrix entries, l) in a ring of 3 groups of 4 levels = 60 loads in flight (the counter holds 63)
-  if (w) hipLaunchKernelGGL((k_tri_solve_lds<2, 4, 3, 4, true>), grid, dim3(64), shmem, stream, a, x, z, w, partials, scratch64);
-  else hipLaunchKernelGGL((k_tri_solve_lds<1, 4, 3, 5, true>), grid, dim3(64), shmem, stream, a, x, z, w, partials, scratch64);
+  if (w) hipLaunchKernelGGL((k_tri_solve_lds<2, 4, 3, 4, 1>), grid, dim3(64), shmem, stream, a, x, z, w, partials, scratch64, (double *)nullptr);
+  else hipLaunchKernelGGL((k_tri_solve_lds<1, 4, 3, 5, 1>), grid, dim3(64), shmem, stream, a, x, z, w, partials, scratch64, (double *)nullptr);
+  return (int)grid.x;
+}
+int launch_back_spmv_tri_lds(const TriArgs &a, const double *d, double *x, double *z, double *partials, double *scratch64, hipStream_t stream) {
+  const dim3 grid(tri_solve_lds_blocks(a.ncols));
+  const size_t shmem = (size_t)a.nz * 64 * sizeof(double);
+  hipLaunchKernelGGL((k_tri_solve_lds<2, 4, 3, 4, 2>), grid, dim3(64), shmem, stream, a, d, z, (const double *)x, partials, scratch64, x);
   return (int)grid.x;
 }
 int launch_tri_back_dots(const TriArgs &a, const double *d, double *z, double *partials, hipStream_t stream) {
   const dim3 grid(nblk(a.ncols));
   LAUNCH(k_tri_back_dots, grid, a, d, z, partials);
-  return (int)grid.x;
+  return (a.ncols + 63) / 64;
 }
 void launch_jacobi_setup(int n, const int *diag_slot, const double *val, double *invd, hipStream_t stream) {
   if (n > 0) LAUNCH(k_jacobi_setup, dim3(nblk(n)), n, diag_slot, val, invd);

@@ -184,6 +184,9 @@ int launch_tri_solve_lds(const TriArgs &a, const double *r, double *z, const dou
 // row sums as the CSR SpMV kernels form them: same bits as launch_spmv_compact followed by launch_tri_solve_lds), with the same
 // partial sums; nz >= 2
 int launch_spmv_tri_lds(const TriArgs &a, const double *x, double *z, const double *w, double *partials, double *scratch64, hipStream_t stream);
+// the same with x = U^{-1} d produced first (d: a right-hand side the assembly pass forward-eliminated; x is written): the start of
+// a BiCGStab solve in one kernel.  Partial sums, one per 64-column tile: (z,x), (z,z), (x,x) in rows 0, 1, 2 of `partials`.
+int launch_back_spmv_tri_lds(const TriArgs &a, const double *d, double *x, double *z, double *partials, double *scratch64, hipStream_t stream);
 // z = U^{-1} d for a right-hand side the assembly pass already forward-eliminated, with the partial sums of z.z
 int launch_tri_back_dots(const TriArgs &a, const double *d, double *z, double *partials, hipStream_t stream);
 void launch_jacobi_setup(int n, const int *diag_slot, const double *val, double *invd, hipStream_t stream);

@@ -201,6 +201,7 @@ struct Options {
   bool ls_ahead = true;        // the line search's first reductions ride behind the Krylov solver's last update
   bool fused_spmv_pc = true;   // vertical-only grids, column preconditioner: M^{-1} A v as one kernel (k_tri_solve_lds<..., SPMV>) instead of
                                // the CSR SpMV followed by the column solve -- A v is never written or read back
+  bool fused_first = true;     // ... and the start of a BiCGStab solve -- rp = U^{-1}(L^{-1} F) and v = M^{-1} A rp -- as one kernel too
   bool ls_spec = true;         // ... and the search's first trial point (the full step) is evaluated there too (LsAhead::spec)
   bool wide_xr = true;         // BiCGStab update kernel on a one-pair-per-lane grid (large vectors)
   double collective_timeout = 900.0;   // seconds a rank waits for device scalars that depend on the other ranks (an all-reduce) before it

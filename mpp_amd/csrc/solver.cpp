@@ -781,7 +781,7 @@ struct Solver {
     partials.alloc((size_t)kMaxPartialBlocks * kMaxMultiDot);
     {  // one partial sum per block of 256 columns (column solves, complete-row march): two vectors + the staging tail
       const size_t nbc = ((size_t)ncols + 63) / 64;   // (the LDS column solve leaves one per 64-column tile)
-      col_partials.alloc(2 * (nbc + nbc / 2048 + 1));
+      col_partials.alloc(3 * (nbc + nbc / 2048 + 1));
       tri_scratch.alloc(64);
     }
     sc.alloc(S_COUNT); sc.zero(stream);
@@ -1831,7 +1831,21 @@ struct Solver {
     // Across ranks the initial (rp,rp) is not needed (rho, the iteration-0 test) before the first (v,rp) is: both travel in
     // one all-reduce, (rp,rp) parked in sc[S_SUM0+2] meanwhile.
     const bool merge0 = comm.active() && fused_pc_dots() && opt.defer_test0;
-    if (merge0) op_pc_apply_dots(b, RP.p, nullptr, 2, 0);
+    // rp = M^{-1} b by back substitution of the right-hand side the assembly pass forward-eliminated AND v = M^{-1} A rp in one
+    // kernel (k_tri_solve_lds<..., 2>): (v,rp), (v,v), (rp,rp) come out together, one scalar step (62) runs both recurrences
+    const bool first_fused = opt.fused_first && fused_spmv_pc() && b == fwd_rhs && opt.defer_test0;
+    if (first_fused) {
+      {
+        ProfScope ps(prof, KC_SPMV_PC);
+        const int nbk = launch_back_spmv_tri_lds(tri_args(), fwd_elim.p, RP.p, V.p, col_partials.p, tri_scratch.p, stream);
+        finalize(nbk, 3, col_partials.p, 0, 62);
+      }
+      if (comm.active()) {
+        comm.allreduce_sum(sc.p + S_SUM0, 3, stream);
+        launch_bcgs_scalars(62, sc.p, stream);
+        pub_valid = false;
+      }
+    } else if (merge0) op_pc_apply_dots(b, RP.p, nullptr, 2, 0);
     else op_pc_apply_dots(b, RP.p, nullptr, 0, -1, 10);   // (rp,rp) in sc[S_SUM0]; scalar steps 0 and 1 (rho = (rp,rp), beta)
     *its = 0;
     // The convergence test of iteration 0 needs ||rp|| on the host.  Rather than stall the queue for it, the first
@@ -1859,7 +1873,9 @@ struct Solver {
         Pcur = Pv.p;
       }
       // v = M^{-1} A p and t = M^{-1} A s: SpMV + column solve, one kernel each where the grid allows it (op_BA_dots)
-      if (merge0 && i == 0) {
+      if (first_fused && i == 0) {
+        // v, alpha: done by the solve's first kernel
+      } else if (merge0 && i == 0) {
         op_BA_dots(Pcur, V.p, RP.p, 0, 3);   // (v,rp), (v,v) and the parked (rp,rp) in one all-reduce
         launch_bcgs_scalars(6, sc.p, stream);
         launch_bcgs_scalars(2, sc.p, stream);
@@ -3112,6 +3128,7 @@ struct Solver {
     else if (key == "collective_timeout") opt.collective_timeout = num();
     else if (key == "ls_spec") opt.ls_spec = num() != 0;
     else if (key == "fused_spmv_pc") opt.fused_spmv_pc = num() != 0;
+    else if (key == "fused_first") opt.fused_first = num() != 0;
     else if (key == "spmv_tpw") opt.spmv_tpw = (int)num();
     else if (key == "soil_classes") { opt.soil_classes = num() != 0; soil_dirty = true; }
     else if (key == "level_geometry") { opt.level_geometry = num() != 0; soil_dirty = true; }

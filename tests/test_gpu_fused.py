@@ -148,18 +148,21 @@ def test_spmv_fused_with_the_column_solve_changes_no_bit(ncols, nz, ksp):
         act[[1, nz, 2 * nz + 1]] = 0
         prob.mesh.is_active = act
     base = dict(ROWS, ksp_type=ksp, tri_lds=1)
-    gs = [P.to_gpu(prob, dict(base, fused_spmv_pc=f)) for f in (1, 0)]
+    # all three fused (the default: the solve's first kernel also does the back substitution of the forward-eliminated residual),
+    # the two products fused only, nothing fused
+    gs = [P.to_gpu(prob, dict(base, fused_spmv_pc=f, fused_first=ff)) for f, ff in ((1, 1), (1, 0), (0, 0))]
     for g in gs:
         g.soe.SetDtime(prob.dt); g.soe.PreSolve()
         g.soe.ComputeJacobian(x)
     b = np.random.default_rng(4).standard_normal(n)
     sols = [g.soe.KSPSolve(b) for g in gs]
-    assert sols[0][1:] == sols[1][1:] and sols[0][1] > 0           # iterations, reason
-    assert np.array_equal(sols[0][0], sols[1][0])
+    assert sols[0][1:] == sols[2][1:] and sols[0][1] > 0           # iterations, reason
+    assert np.array_equal(sols[0][0], sols[2][0]) and np.array_equal(sols[1][0], sols[2][0])
     for g in gs:
         for s in range(2):
             conv, reason = g.soe.StepDT(prob.dt, s + 1)
             assert conv
-    assert gs[0].soe.counters() == gs[1].soe.counters()
-    assert np.array_equal(gs[0].soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1),
-                          gs[1].soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1))
+    for g in gs[:2]:
+        assert g.soe.counters() == gs[2].soe.counters()
+        assert np.array_equal(g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1),
+                              gs[2].soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1))

@@ -16,16 +16,17 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # kernel class of bench.py's `kernels` object -> the kernels that make up a launch of that class (substring of the demangled name)
+# kernel class of bench.py's `kernels` object -> how a launch of that class is made up: ("sum", ...) = every launch of the class runs
+# all of these kernels (substrings of the demangled name); ("mean", ...) = launches of the class alternate between them
 CLASSES = {
-    "spmv": ["k_spmv_c<3, false, true>"],          # the launches bench.py times in the SpMV class (the line search's pass)
-    "spmv_plain": ["k_spmv_c<3, false, false>"],
-    "spmv_pc": ["k_tri_solve_lds<2, 4, 3, 4, true>"],
-    "residual": ["k_assemble_cols<0,", "k_bc<0>"],
-    "jacobian": ["k_assemble_cols<2,", "k_bc<2>"],
-    "pc_apply": ["k_tri_solve_lds<2,"],
-    "pc_apply_first": ["k_tri_back_dots"],
-    "krylov_update": ["k_bcgs_xr<true>"],
-    "vec": ["k_waxpy"],
+    "spmv": ("sum", ["k_spmv_c<3, false, true>"]),          # the launches bench.py times in the SpMV class (the line search's pass)
+    "spmv_plain": ("sum", ["k_spmv_c<3, false, false>"]),
+    "spmv_pc": ("mean", ["k_tri_solve_lds<2, 4, 3, 4, 1>", "k_tri_solve_lds<2, 4, 3, 4, 2>"]),
+    "residual": ("sum", ["k_assemble_cols<0,", "k_bc<0>"]),
+    "jacobian": ("sum", ["k_assemble_cols<2,", "k_bc<2>"]),
+    "pc_apply": ("sum", ["k_tri_back_dots"]),
+    "krylov_update": ("sum", ["k_bcgs_xr<true>"]),
+    "vec": ("sum", ["k_waxpy"]),
 }
 
 
@@ -47,7 +48,7 @@ def main():
            "correction": "reads = %.5f x FETCH_SIZE (gfx950: 128-byte requests tallied at 64 B), calibrated on k_copy of the same run"
                          % pmc["read_factor"],
            "classes": {}}
-    for cls, subs in CLASSES.items():
+    for cls, (mode, subs) in CLASSES.items():
         ks = {}
         for sub in subs:
             for name, v in pmc["kernels"].items():
@@ -55,7 +56,9 @@ def main():
                 if sub in short:
                     ks[short] = v["hbm_bytes_per_launch"]
         if ks:
-            out["classes"][cls] = {"kernels": ks, "hbm_bytes_per_launch": sum(ks.values())}
+            total = sum(ks.values())
+            out["classes"][cls] = {"kernels": ks, "hbm_bytes_per_launch": total if mode == "sum" else total / len(ks),
+                                   "launch_is": "all of these kernels" if mode == "sum" else "one of these kernels in turn (mean)"}
     json.dump(out, sys.stdout, indent=1)
     print()
 
