@@ -37,7 +37,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-EVENT_STRIDE = 4       # every 4th launch of a kernel class is bracketed by HIP events (a pair costs ~10 us of queue time)
+EVENT_STRIDE = 5       # every 5th launch of a kernel class is bracketed by HIP events (a pair costs ~10 us of queue time); 5 is
+                       # co-prime with the periods (2, 3, 4) at which different kernels alternate inside a class
 
 
 def kernel_source_hash():

@@ -1669,7 +1669,7 @@ __global__ __launch_bounds__(kBlock) void k_bcgs_xr(int n, double *X, double *R,
               const double2 s = CD2(S)[q], p = CD2(P)[q], t = CD2(T)[q], x = FIRST ? make_double2(0.0, 0.0) : CD2(X)[q];
               D2(X)[q] = make_double2(alpha * p.x + omega * s.x + x.x, alpha * p.y + omega * s.y + x.y);
               const double r0 = s.x - omega * t.x, r1 = s.y - omega * t.y;
-              D2(R)[q] = make_double2(r0, r1);
+              if (R) D2(R)[q] = make_double2(r0, r1);   // (R == nullptr: only ||r|| is wanted -- the solve is expected to end here)
               acc += r0 * r0;
               acc += r1 * r1;
               if (!FIRST) { const double2 rp = CD2(RP)[q]; acc2 += r0 * rp.x; acc2 += r1 * rp.y; }
@@ -1677,7 +1677,7 @@ __global__ __launch_bounds__(kBlock) void k_bcgs_xr(int n, double *X, double *R,
               const double s = S[i];
               X[i] = alpha * P[i] + omega * s + (FIRST ? 0.0 : X[i]);
               const double r = s - omega * T[i];
-              R[i] = r;
+              if (R) R[i] = r;
               acc += r * r;
               if (!FIRST) acc2 += r * RP[i];
             });

@@ -1862,6 +1862,7 @@ struct Solver {
     }
     const double *Rcur = RP.p, *Pcur = RP.p;
     int i = 0;
+    bool lazy_r = false;
     do {
       // rho = (r,rp): the initial (rp,rp) at i == 0; a separate reduction at i == 1 (the first update does not read rp:
       // most solves of the column-structured problems end there); afterwards the update kernel reduces it on the way
@@ -1893,7 +1894,10 @@ struct Solver {
           if (xr_partials.n < need) xr_partials.alloc(need);
           pbuf = xr_partials.p;
         }
-        const int nbk = launch_bcgs_xr(nred, i == 0, wide, x, R.p, Pcur, S.p, T.p, RP.p, sc.p, pbuf, stream);
+        // r = s - omega t is written only if somebody will read it: where the solve is expected to end with this iteration (the
+        // line search's reductions are already queued behind it) only its norm is formed; a solve that goes on forms r then
+        lazy_r = opt.lazy_r && ls_ahead.armed && i == 0;
+        const int nbk = launch_bcgs_xr(nred, i == 0, wide, x, lazy_r ? nullptr : R.p, Pcur, S.p, T.p, RP.p, sc.p, pbuf, stream);
         // end of the iteration: dp, rhoold, omegaold (step 4) and, from the second iteration on, the next one's rho = (r,rp)
         // and beta (step 5) -- harmless when the test below ends the solve
         end_step = i == 0 ? 4 : 45;
@@ -1951,6 +1955,7 @@ struct Solver {
       spec_void();   // the solve goes on (or has failed): the trial point is void and the matrix is needed again
       if (reason) return reason;
       if (rho == 0.0) return -5;
+      if (lazy_r) { ProfScope ps(prof, KC_VEC); launch_waxpy(nred, R.p, sc.p, S_OMEGA, -1.0, 0.0, T.p, S.p, stream); }   // r = s - omega t after all
       ++i;
     } while (i < opt.ksp_max_it);
     return -3;
@@ -3129,6 +3134,7 @@ struct Solver {
     else if (key == "ls_spec") opt.ls_spec = num() != 0;
     else if (key == "fused_spmv_pc") opt.fused_spmv_pc = num() != 0;
     else if (key == "fused_first") opt.fused_first = num() != 0;
+    else if (key == "lazy_r") opt.lazy_r = num() != 0;
     else if (key == "spmv_tpw") opt.spmv_tpw = (int)num();
     else if (key == "soil_classes") { opt.soil_classes = num() != 0; soil_dirty = true; }
     else if (key == "level_geometry") { opt.level_geometry = num() != 0; soil_dirty = true; }

@@ -166,3 +166,27 @@ def test_spmv_fused_with_the_column_solve_changes_no_bit(ncols, nz, ksp):
         assert g.soe.counters() == gs[2].soe.counters()
         assert np.array_equal(g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1),
                               gs[2].soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1))
+
+
+def test_a_krylov_solve_that_goes_on_discards_the_speculative_work():
+    """behind the first BiCGStab iteration the solver queues what follows a one-iteration solve: the line search's reductions, its
+    first trial point (which overwrites the Jacobian), and it skips writing r.  When the solve does go on -- forced here by a
+    ksp_rtol the first iteration cannot reach -- all of that is void: the matrix and factors are assembled again, r is formed, the
+    function evaluation is not counted.  Same decisions, counters and pressures as the plain sequence of operations"""
+    prob, x = _hetero(ncols=70, nz=19, seed=41)
+    big = dict(ROWS, spmv_variant=20, tri_lds=1)   # the kernels a large grid selects by itself (the look-ahead needs the compact-index SpMV)
+    gs = [P.to_gpu(prob, dict(big, **o)) for o in ({}, {"ls_spec": 0, "ls_ahead": 0, "lazy_r": 0, "fused_first": 0, "fused_spmv_pc": 0})]
+    out = []
+    for g in gs:
+        res = [g.soe.StepDT(prob.dt, 1)]           # a normal step: every solve takes one iteration, speculation gets armed
+        g.soe.SetOption("ksp_rtol", 1e-15)         # below what one iteration of an exact preconditioner leaves in fp64
+        g.soe.SetOption("ksp_max_it", 4)
+        res.append(g.soe.StepDT(prob.dt, 2))
+        g.soe.SetOption("ksp_rtol", 1e-5)
+        res.append(g.soe.StepDT(prob.dt, 3))
+        out.append((res, g.soe.counters(), g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1)))
+    assert out[0][0] == out[1][0]
+    assert out[0][1] == out[1][1]
+    assert np.array_equal(out[0][2], out[1][2])
+    assert gs[0].soe.assembly_info()["speculative_trials_discarded"] > 0
+    assert gs[1].soe.assembly_info()["speculative_trials_discarded"] == 0
