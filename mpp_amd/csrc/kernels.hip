@@ -1748,10 +1748,13 @@ __global__ __launch_bounds__(kBlock) void k_tri_solve_dots(TriArgs a, const doub
 // SPMV == 2: x itself is produced first -- x = U^{-1} d, the back substitution of a right-hand side the assembly pass already
 // forward-eliminated (k_tri_back_dots' arithmetic), written to `xout` and parked in the slab -- then z = M^{-1} (A x) as above with
 // x taken from the slab: the start of a BiCGStab solve (rp = M^{-1} F, v = M^{-1} A rp) in one kernel, with (z,x), (z,z), (x,x).
+// SPMV == 3: x = r + a v with a = -sc[S_ALPHA] (BiCGStab's s = r - alpha v, VecWAXPY) is formed on the way, written to `xout`, and is
+// also the w of the dot products: the second half of a BiCGStab iteration's products -- s, t = M^{-1} A s, (t,s), (t,t) -- in one kernel.
 template <int ND, int G, int RF, int RB, int SPMV>
 __global__ __launch_bounds__(64) void k_tri_solve_lds(TriArgs a, const double *__restrict__ r, double *__restrict__ z,
                                                       const double *__restrict__ w, double *__restrict__ partials,
-                                                      double *__restrict__ scratch64, double *__restrict__ xout) {
+                                                      double *__restrict__ scratch64, double *__restrict__ xout,
+                                                      const double *__restrict__ vsub, const double *__restrict__ sc) {
   extern __shared__ __attribute__((aligned(16))) double dsl[];   // [nz][64]
   const int lane = threadIdx.x, tile = blockIdx.x;
   const int nz = a.nz;
@@ -1815,13 +1818,16 @@ __global__ __launch_bounds__(64) void k_tri_solve_lds(TriArgs a, const double *_
     // 3l + 2 -- through a 1.5 KB LDS scratch when the level is used; three 8-byte loads at a 24-byte lane stride would touch every
     // line of the segment three times.  The two end levels (2 entries per row) are read directly.
     __shared__ double tr[3 * 64];
-    double xb[RF][G], lb[RF][G], v0[RF][G], v1[RF][G], v2[RF][G];
+    double xb[RF][G], lb[RF][G], v0[RF][G], v1[RF][G], v2[RF][G], sb[SPMV == 3 ? RF : 1][SPMV == 3 ? G : 1];
+    const double na = (SPMV == 3) ? -1.0 * sc[S_ALPHA] : 0.0;
+    double *ss = (SPMV == 3) ? (valid ? xout + cbase : scratch64 + lane) : nullptr;
     auto fetch = [&](int q, int kfirst) {   // levels kfirst .. kfirst+G-1 (clamped) into group q
 #pragma unroll
       for (int j = 0; j < G; ++j) {
         const int k = min(kfirst + j, nz - 1);
         const size_t i = cbase + (size_t)k * tw;
-        xb[q][j] = (SPMV == 1) ? ldnt(r + i) : 0.0;   // (SPMV == 2: x is in the slab)
+        xb[q][j] = (SPMV == 1 || SPMV == 3) ? ldnt(r + i) : 0.0;   // (SPMV == 2: x is in the slab)
+        if (SPMV == 3) sb[q][j] = ldnt(vsub + i);
         lb[q][j] = ldnt(a.l + i);
         if (k == 0) {                 // [di up]: lower slot harmless (meets x = 0)
           v0[q][j] = ldnt(vt + 2 * vl); v1[q][j] = v0[q][j]; v2[q][j] = ldnt(vt + 2 * vl + 1);
@@ -1845,8 +1851,9 @@ __global__ __launch_bounds__(64) void k_tri_solve_lds(TriArgs a, const double *_
       prev = d;
       dsl[kr * 64 + lane] = d;
     };
-    auto step = [&](int k, double xk, double lo, double di, double up, double lk) {
+    auto step = [&](int k, double xk, double lo, double di, double up, double lk, double vk) {
       if (SPMV == 2) xk = dsl[k * 64 + lane];   // (rows below k have been replaced by their eliminated sums already: not needed any more)
+      if (SPMV == 3) { xk = fma(na, vk, xk); stnt(xk, ss + (size_t)k * tws); }   // s = r - alpha v (k_waxpy's arithmetic), kept for the update kernel
       if (k > 0 && k < nz - 1) {   // a middle level: (lo, di, up) hold segment entries l, tw + l, 2 tw + l -> this lane's row
         if (valid) { tr[lane] = lo; tr[tw + lane] = di; tr[2 * tw + lane] = up; }
         __builtin_amdgcn_wave_barrier();
@@ -1863,7 +1870,7 @@ __global__ __launch_bounds__(64) void k_tri_solve_lds(TriArgs a, const double *_
 #pragma unroll
       for (int q = 0; q < RF; ++q) {
 #pragma unroll
-        for (int j = 0; j < G; ++j) step(k0 + q * G + j, xb[q][j], v0[q][j], v1[q][j], v2[q][j], lb[q][j]);
+        for (int j = 0; j < G; ++j) step(k0 + q * G + j, xb[q][j], v0[q][j], v1[q][j], v2[q][j], lb[q][j], SPMV == 3 ? sb[q][j] : 0.0);
         __builtin_amdgcn_sched_barrier(0);
         fetch(q, k0 + (RF + q) * G);
         __builtin_amdgcn_sched_barrier(0);
@@ -1874,7 +1881,7 @@ __global__ __launch_bounds__(64) void k_tri_solve_lds(TriArgs a, const double *_
 #pragma unroll
       for (int j = 0; j < G; ++j) {
         const int k = k0 + q * G + j;
-        if (k < nz) step(k, xb[q][j], v0[q][j], v1[q][j], v2[q][j], lb[q][j]);
+        if (k < nz) step(k, xb[q][j], v0[q][j], v1[q][j], v2[q][j], lb[q][j], SPMV == 3 ? sb[q][j] : 0.0);
       }
     finish(nz - 1, 0.0);   // the top row: no upper neighbour
   } else {
@@ -1925,7 +1932,7 @@ __global__ __launch_bounds__(64) void k_tri_solve_lds(TriArgs a, const double *_
       for (int j = 0; j < G; ++j) {
         const size_t i = cbase + (size_t)max(ktop - j, 0) * tw;
         cb[q][j] = ldnt(a.c + i); ib[q][j] = ldnt(a.invb + i);
-        if (ND == 2) wb[q][j] = (SPMV == 2) ? ldnt(xout + i) : ldnt(w + i);   // (SPMV == 2: w is the x this kernel wrote -- same pointer)
+        if (ND == 2) wb[q][j] = (SPMV >= 2) ? ldnt(xout + i) : ldnt(w + i);   // (SPMV >= 2: w is the x this kernel wrote -- same pointer)
       }
     };
 #pragma unroll
@@ -2371,7 +2378,7 @@ int launch_tri_solve_lds(const TriArgs &a, const double *r, double *z, const dou
                          int group, hipStream_t stream) {
   const dim3 grid(tri_solve_lds_blocks(a.ncols));
   const size_t shmem = (size_t)a.nz * 64 * sizeof(double);
-#define TRI_LDS(ND, G, RF, RB) hipLaunchKernelGGL((k_tri_solve_lds<ND, G, RF, RB, 0>), grid, dim3(64), shmem, stream, a, r, z, w, partials, scratch64, (double *)nullptr)
+#define TRI_LDS(ND, G, RF, RB) hipLaunchKernelGGL((k_tri_solve_lds<ND, G, RF, RB, 0>), grid, dim3(64), shmem, stream, a, r, z, w, partials, scratch64, (double *)nullptr, (const double *)nullptr, (const double *)nullptr)
   // `group` = levels in flight per stream: rings of 4-level groups
   if (w) { if (group <= 8) TRI_LDS(2, 4, 2, 2); else if (group <= 16) TRI_LDS(2, 4, 4, 3); else TRI_LDS(2, 4, 6, 4); }
   else { if (group <= 8) TRI_LDS(1, 4, 2, 2); else if (group <= 16) TRI_LDS(1, 4, 4, 4); else TRI_LDS(1, 4, 6, 5); }
@@ -2382,14 +2389,22 @@ int launch_spmv_tri_lds(const TriArgs &a, const double *x, double *z, const doub
   const dim3 grid(tri_solve_lds_blocks(a.ncols));
   const size_t shmem = (size_t)a.nz * 64 * sizeof(double);
   // forward: five streams (x, three matrix entries, l) in a ring of 3 groups of 4 levels = 60 loads in flight (the counter holds 63)
-  if (w) hipLaunchKernelGGL((k_tri_solve_lds<2, 4, 3, 4, 1>), grid, dim3(64), shmem, stream, a, x, z, w, partials, scratch64, (double *)nullptr);
-  else hipLaunchKernelGGL((k_tri_solve_lds<1, 4, 3, 5, 1>), grid, dim3(64), shmem, stream, a, x, z, w, partials, scratch64, (double *)nullptr);
+  if (w) hipLaunchKernelGGL((k_tri_solve_lds<2, 4, 3, 4, 1>), grid, dim3(64), shmem, stream, a, x, z, w, partials, scratch64, (double *)nullptr, (const double *)nullptr, (const double *)nullptr);
+  else hipLaunchKernelGGL((k_tri_solve_lds<1, 4, 3, 5, 1>), grid, dim3(64), shmem, stream, a, x, z, w, partials, scratch64, (double *)nullptr, (const double *)nullptr, (const double *)nullptr);
   return (int)grid.x;
 }
 int launch_back_spmv_tri_lds(const TriArgs &a, const double *d, double *x, double *z, double *partials, double *scratch64, hipStream_t stream) {
   const dim3 grid(tri_solve_lds_blocks(a.ncols));
   const size_t shmem = (size_t)a.nz * 64 * sizeof(double);
-  hipLaunchKernelGGL((k_tri_solve_lds<2, 4, 3, 4, 2>), grid, dim3(64), shmem, stream, a, d, z, (const double *)x, partials, scratch64, x);
+  hipLaunchKernelGGL((k_tri_solve_lds<2, 4, 3, 4, 2>), grid, dim3(64), shmem, stream, a, d, z, (const double *)x, partials, scratch64, x, (const double *)nullptr, (const double *)nullptr);
+  return (int)grid.x;
+}
+int launch_waxpy_spmv_tri_lds(const TriArgs &a, const double *r, const double *v, const double *sc, double *s, double *z, double *partials,
+                              double *scratch64, hipStream_t stream) {
+  const dim3 grid(tri_solve_lds_blocks(a.ncols));
+  const size_t shmem = (size_t)a.nz * 64 * sizeof(double);
+  // forward: six streams (r, v, three matrix entries, l) in a ring of 2 groups of 5 levels = 60 loads in flight
+  hipLaunchKernelGGL((k_tri_solve_lds<2, 5, 2, 4, 3>), grid, dim3(64), shmem, stream, a, r, z, (const double *)s, partials, scratch64, s, v, sc);
   return (int)grid.x;
 }
 int launch_tri_back_dots(const TriArgs &a, const double *d, double *z, double *partials, hipStream_t stream) {

@@ -187,6 +187,10 @@ int launch_spmv_tri_lds(const TriArgs &a, const double *x, double *z, const doub
 // the same with x = U^{-1} d produced first (d: a right-hand side the assembly pass forward-eliminated; x is written): the start of
 // a BiCGStab solve in one kernel.  Partial sums, one per 64-column tile: (z,x), (z,z), (x,x) in rows 0, 1, 2 of `partials`.
 int launch_back_spmv_tri_lds(const TriArgs &a, const double *d, double *x, double *z, double *partials, double *scratch64, hipStream_t stream);
+// ... and with s = r - sc[S_ALPHA] v formed on the way (written to `s`): z = M^{-1} A s with (z,s), (z,z) -- BiCGStab's VecWAXPY, second
+// product and omega's two dot products in one kernel
+int launch_waxpy_spmv_tri_lds(const TriArgs &a, const double *r, const double *v, const double *sc, double *s, double *z, double *partials,
+                              double *scratch64, hipStream_t stream);
 // z = U^{-1} d for a right-hand side the assembly pass already forward-eliminated, with the partial sums of z.z
 int launch_tri_back_dots(const TriArgs &a, const double *d, double *z, double *partials, hipStream_t stream);
 void launch_jacobi_setup(int n, const int *diag_slot, const double *val, double *invd, hipStream_t stream);

@@ -1882,9 +1882,19 @@ struct Solver {
         launch_bcgs_scalars(2, sc.p, stream);
         pub_valid = false;
       } else op_BA_dots(Pcur, V.p, RP.p, 0, -1, 2);   // (v,rp) in sc[S_SUM0]  [(v,v) in S_SUM0+1 is not used]; alpha
-      { ProfScope ps(prof, KC_VEC); launch_waxpy(nred, S.p, sc.p, S_ALPHA, -1.0, 0.0, V.p, Rcur, stream); }
       int end_step = 4;
-      op_BA_dots(S.p, T.p, S.p, 0, -1, 3);    // (t,s), (t,t) in sc[S_SUM0], sc[S_SUM0+1]; omega
+      if (opt.fused_waxpy && fused_spmv_pc()) {   // s = r - alpha v, t = M^{-1} A s, (t,s), (t,t): one kernel
+        {
+          ProfScope ps(prof, KC_SPMV_PC);
+          const int nbk = launch_waxpy_spmv_tri_lds(tri_args(), Rcur, V.p, sc.p, S.p, T.p, col_partials.p, tri_scratch.p, stream);
+          finalize(nbk, 2, col_partials.p, 0, 3);
+        }
+        if (comm.active()) comm.allreduce_sum(sc.p + S_SUM0, 2, stream);
+        bcgs_step(3);
+      } else {
+        { ProfScope ps(prof, KC_VEC); launch_waxpy(nred, S.p, sc.p, S_ALPHA, -1.0, 0.0, V.p, Rcur, stream); }
+        op_BA_dots(S.p, T.p, S.p, 0, -1, 3);    // (t,s), (t,t) in sc[S_SUM0], sc[S_SUM0+1]; omega
+      }
       {
         ProfScope ps(prof, KC_REDUCE);
         const bool wide = opt.wide_xr && nred >= (1 << 22);
@@ -3135,6 +3145,7 @@ struct Solver {
     else if (key == "fused_spmv_pc") opt.fused_spmv_pc = num() != 0;
     else if (key == "fused_first") opt.fused_first = num() != 0;
     else if (key == "lazy_r") opt.lazy_r = num() != 0;
+    else if (key == "fused_waxpy") opt.fused_waxpy = num() != 0;
     else if (key == "spmv_tpw") opt.spmv_tpw = (int)num();
     else if (key == "soil_classes") { opt.soil_classes = num() != 0; soil_dirty = true; }
     else if (key == "level_geometry") { opt.level_geometry = num() != 0; soil_dirty = true; }

@@ -150,19 +150,20 @@ def test_spmv_fused_with_the_column_solve_changes_no_bit(ncols, nz, ksp):
     base = dict(ROWS, ksp_type=ksp, tri_lds=1)
     # all three fused (the default: the solve's first kernel also does the back substitution of the forward-eliminated residual),
     # the two products fused only, nothing fused
-    gs = [P.to_gpu(prob, dict(base, fused_spmv_pc=f, fused_first=ff)) for f, ff in ((1, 1), (1, 0), (0, 0))]
+    # (also: s = r - alpha v formed inside the kernel of the second product, fused_waxpy)
+    gs = [P.to_gpu(prob, dict(base, fused_spmv_pc=f, fused_first=ff, fused_waxpy=fw)) for f, ff, fw in ((1, 1, 1), (1, 0, 0), (0, 0, 0), (1, 1, 0))]
     for g in gs:
         g.soe.SetDtime(prob.dt); g.soe.PreSolve()
         g.soe.ComputeJacobian(x)
     b = np.random.default_rng(4).standard_normal(n)
     sols = [g.soe.KSPSolve(b) for g in gs]
     assert sols[0][1:] == sols[2][1:] and sols[0][1] > 0           # iterations, reason
-    assert np.array_equal(sols[0][0], sols[2][0]) and np.array_equal(sols[1][0], sols[2][0])
+    assert all(np.array_equal(q[0], sols[2][0]) and q[1:] == sols[2][1:] for q in sols)
     for g in gs:
         for s in range(2):
             conv, reason = g.soe.StepDT(prob.dt, s + 1)
             assert conv
-    for g in gs[:2]:
+    for g in (gs[0], gs[1], gs[3]):
         assert g.soe.counters() == gs[2].soe.counters()
         assert np.array_equal(g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1),
                               gs[2].soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1))
