@@ -180,8 +180,8 @@ def test_a_krylov_solve_that_goes_on_discards_the_speculative_work():
     out = []
     for g in gs:
         res = [g.soe.StepDT(prob.dt, 1)]           # a normal step: every solve takes one iteration, speculation gets armed
-        g.soe.SetOption("ksp_rtol", 1e-15)         # below what one iteration of an exact preconditioner leaves in fp64
-        g.soe.SetOption("ksp_max_it", 4)
+        g.soe.SetOption("ksp_rtol", 1e-300)        # unreachable (the exact column solve leaves ~1e-17 after one iteration)
+        g.soe.SetOption("ksp_max_it", 3)           # ... so every linear solve of this step fails and the step is cut until it gives up
         res.append(g.soe.StepDT(prob.dt, 2))
         g.soe.SetOption("ksp_rtol", 1e-5)
         res.append(g.soe.StepDT(prob.dt, 3))
