@@ -161,6 +161,43 @@ __global__ __launch_bounds__(kBlock) void k_assemble_cols(ColsArgs a) {
     };
     double inv_pp = 0.0, c_pp = 0.0;   // 1/pivot and super-diagonal of the row before the one being completed
     double d_pp = 0.0;                 // ... and its forward-eliminated residual
+    // Boundary fluxes of this column's two end cells, evaluated here instead of by a separate k_bc launch (a.bc_ptr != nullptr): the
+    // same loop over the cell's boundary entries, the same functions (GE:1815-1877, 2076-2139).  Kept in four registers until the
+    // rows are finished.
+    double sF0 = 0.0, sF1 = 0.0, sD0 = 0.0, sD1 = 0.0;   // bottom / top
+    const bool bc_inline = FUSE && a.bc_ptr != nullptr;
+    if (bc_inline) {
+#pragma unroll
+      for (int end = 0; end < 2; ++end) {   // (unrolled: the four sums stay in registers)
+        const int j = end ? jt : jb;
+        if (j < 0) continue;
+        const size_t cell = cbase + (size_t)(end ? nz - 1 : 0) * tw;
+        if (!owns_row(ca, cell)) continue;   // inactive (or ghost) cell: no boundary flux
+        Soil s = load_soil(ca, cell);
+        const double Pc = trial ? fma(a.trial_a, a.trial_y[cell], a.trial_x[cell]) : ca.P[cell];
+        const Aux in = auxvar_compute<JAC, SAT_T, DEN_T>(s.sf, ca.eos, s, Pc, frac_of(ca, cell), pt);
+        double f = 0.0, d = 0.0;
+        for (int e = a.bc_ptr[j]; e < a.bc_ptr[j + 1]; ++e) {
+          const int t = a.bc_type[e];
+          const int ctype = t & 0xffff, swap = t >> 16;
+          const double pb = (ctype == kCondMassFlux) ? in.P : a.bc_value[e];
+          const Aux bc = auxvar_compute<JAC, SAT_T, DEN_T>(s.sf, ca.eos, s, pb, ca.frac_liq, pt);
+          ConnGeom g;
+          g.Dq = a.bc_Dq[e]; g.upweight = 0.0; g.dist_gravity = a.bc_dgrav[e]; g.area = a.bc_area[e];
+          double Jup = 0.0, Jdn = 0.0, flux, jdn_outer;
+          if (!swap) {
+            flux = richards_flux<JAC>(bc, in, g, ctype, Jup, Jdn);
+            jdn_outer = Jdn;
+          } else {  // RichardsFlux swap_order (RichardsMod.F90:96-112)
+            flux = -richards_flux<JAC>(in, bc, g, ctype, Jup, Jdn);
+            jdn_outer = -Jup;
+          }
+          if (RES) f += flux;
+          if (JAC) d += -jdn_outer;
+        }
+        if (end) { sF1 = f; sD1 = d; } else { sF0 = f; sD0 = d; }
+      }
+    }
 
     Aux prev = {};
     bool prev_act = false;
@@ -173,14 +210,14 @@ __global__ __launch_bounds__(kBlock) void k_assemble_cols(ColsArgs a) {
       if (RES) {
         double f = f_prev;
         if (a.src) f -= src_prev;
-        if (FUSE && js >= 0) f += a.side_f[js];
+        if (FUSE && js >= 0) f += bc_inline ? (kp == 0 ? sF0 : sF1) : a.side_f[js];
         stnt(f, a.F + ip);
         if (FUSE) accF += f * f;
         f_row = f;
       }
       if (JAC) {
         double di = dconn_prev + dacc_prev;
-        if (FUSE && js >= 0) di += a.side_d[js];
+        if (FUSE && js >= 0) di += bc_inline ? (kp == 0 ? sD0 : sD1) : a.side_d[js];
         int slot = row_slot(kp);
         if (kp > 0) a.val[slot++] = lo_prev;
         a.val[slot++] = di;

@@ -69,6 +69,10 @@ struct ColsArgs {
   // k_bc left there, the column LU factors to write (tl may be nullptr) and the partial sums of F.F, P.P (mode 0, 2)
   const int *col_bc = nullptr;
   const double *side_f = nullptr, *side_d = nullptr;
+  // ... or (bc_ptr != nullptr) the boundary entries themselves: the march evaluates the fluxes of its column's end cells in its
+  // prologue (k_bc's loop and arithmetic) and no k_bc launch precedes it.  Entry e of condition cell j: bc_ptr[j] <= e < bc_ptr[j+1]
+  const int *bc_ptr = nullptr, *bc_type = nullptr;
+  const double *bc_Dq = nullptr, *bc_dgrav = nullptr, *bc_area = nullptr, *bc_value = nullptr;
   double *tl = nullptr, *tinvb = nullptr, *tc = nullptr;
   double *fwd = nullptr;    // with tl: L^{-1} F as well (F = the residual of this pass, or the one in `F` in mode 1)
   double *partials = nullptr;

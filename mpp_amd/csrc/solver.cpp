@@ -1247,10 +1247,14 @@ struct Solver {
   // have_F (mode 1): Fout holds the residual of this very state, so its forward elimination can ride along
   void assemble_complete_rows(int mode, const double *P, double *Fout, bool have_F = true) {
     BcArgs b = bc_args(P, Fout);
-    b.side_f = bc_side_f.p; b.side_d = bc_side_d.p;
-    b.trial_x = ls_point.x; b.trial_y = ls_point.y; b.trial_a = ls_point.a;
-    launch_bc(mode, b, stream);
     ColsArgs a = cols_args(P, Fout);
+    if (opt.bc_inline) {   // the march evaluates the boundary fluxes of its column's end cells itself (no k_bc launch)
+      a.bc_ptr = b.cc_ptr; a.bc_type = b.type; a.bc_Dq = b.Dq; a.bc_dgrav = b.dgrav; a.bc_area = b.area; a.bc_value = b.value;
+    } else {
+      b.side_f = bc_side_f.p; b.side_d = bc_side_d.p;
+      b.trial_x = ls_point.x; b.trial_y = ls_point.y; b.trial_a = ls_point.a;
+      launch_bc(mode, b, stream);
+    }
     a.trial_x = ls_point.x; a.trial_y = ls_point.y; a.trial_a = ls_point.a; a.trial_w = const_cast<double *>(P);
     ls_point = Trial{};
     a.col_bc = d_col_bc.p; a.side_f = bc_side_f.p; a.side_d = bc_side_d.p; a.partials = col_partials.p;
@@ -3146,6 +3150,7 @@ struct Solver {
     else if (key == "fused_first") opt.fused_first = num() != 0;
     else if (key == "lazy_r") opt.lazy_r = num() != 0;
     else if (key == "fused_waxpy") opt.fused_waxpy = num() != 0;
+    else if (key == "bc_inline") opt.bc_inline = num() != 0;
     else if (key == "spmv_tpw") opt.spmv_tpw = (int)num();
     else if (key == "soil_classes") { opt.soil_classes = num() != 0; soil_dirty = true; }
     else if (key == "level_geometry") { opt.level_geometry = num() != 0; soil_dirty = true; }
