@@ -63,8 +63,6 @@ def main():
         row("k_assemble_cols<0, 3, 0, true>", "GE:388-421, 1603-1938 (residual), `VecWAXPY`, 2 `VecNorm`", 104.0),
         row("k_bcgs_xr<true>", "`VecAXPBYPCZ`, `VecWAXPY`, `VecNorm` (r not written when the solve is expected to end)", 40.0),
         row("k_bc<2>", "boundary fluxes + derivatives (GE:1815-1877, 2076-2139) into side arrays", 0.0),
-        row("k_tri_back_dots", "`PCApply` from a forward-eliminated right-hand side (when the first kernel is not fused)", 32.0),
-        row("k_waxpy", "`VecWAXPY`", 24.0),
     ):
         if r:
             rows.append(r)
@@ -104,7 +102,7 @@ def main():
     cb = bench.get("cpu_baseline", {})
     results.append("")
     results.append("Round 2's driver run: 105.7 Newton it/s (`BENCH_r02.json`); box-to-box spread of this pool ≈ ±4 %% (the column march "
-                   "follows the box's clocks: %.2f ms here, 1.92–2.30 ms over the round's boxes)." % bench["kernels"]["jacobian"]["avg_ms"])
+                   "follows the box's clocks: %.2f ms here, 1.83–2.30 ms over the round's boxes)." % bench["kernels"]["jacobian"]["avg_ms"])
     results.append("`roofline` of that line: %s → **%.0f GB/s of algorithmic CSR bytes = %.3f of peak** (%.5f ms per launch, HIP events); "
                    "%.0f GB/s = %.3f of peak on the bytes it moves (PMC %.3f GB per launch); the plain `y = A x` kernel timed behind the "
                    "region: %.5f ms = %.3f of peak." % (

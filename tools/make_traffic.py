@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLASSES = {
     "spmv": ("sum", ["k_spmv_c<3, false, true>"]),          # the launches bench.py times in the SpMV class (the line search's pass)
     "spmv_plain": ("sum", ["k_spmv_c<3, false, false>"]),
-    "spmv_pc": ("mean", ["k_tri_solve_lds<2, 4, 3, 4, 1>", "k_tri_solve_lds<2, 4, 3, 4, 2>"]),
+    "spmv_pc": ("mean", ["k_tri_solve_lds<2, 4, 3, 4, 2>", "k_tri_solve_lds<2, 5, 2, 4, 3>"]),   # first kernel of a solve / second product
     "residual": ("sum", ["k_assemble_cols<0,", "k_bc<0>"]),
     "jacobian": ("sum", ["k_assemble_cols<2,", "k_bc<2>"]),
     "pc_apply": ("sum", ["k_tri_back_dots"]),
