@@ -1230,11 +1230,13 @@ __global__ __launch_bounds__(kBlock) void k_thermal_bc(ThermalBcArgs a) {
                      t.tkdry[cell], t.csol[cell], t.dz[cell], kbc, cbc);
       const double du = a.du[e], dd = a.dd[e], dist = du + dd, kc = t.therm_cond[cell];
       const double kav = kbc * kc * dist / (kbc * dd + kc * du);
-      if (RHS) b = b + kav / dist * a.value[e] * a.area[e] * 1.0;
+      if (RHS) b = b + kav / dist * a.value[e] * (a.reference_defects ? a.area_dirichlet_rhs[e] : a.area[e]) * 1.0;
       if (OPR) d += a.frac[e] * (1.0 - t.cnfac) * kav / dist * a.area[e] * 1.0;
     } else if (ctype == 507) {
-      if (RHS) b = b + 1.0 * a.value[e] * a.frac[e] * a.area[e];
-      if (OPR) d += -a.frac[e] * a.dhsdT[e] * a.area[e] * 1.0;
+      // cur_cond%value = H - dH/dT * T of the cell (ThermKSPTempSoilGetFromSOEAuxVarsBC, GE :339-354; T = soln_prev)
+      if (RHS) b = b + 1.0 * (a.value[e] - a.dhsdT[e] * t.T[cell]) * a.frac[e] * a.area[e];
+      if (OPR) d += a.reference_defects ? -a.frac[e] * pow(a.dhsdT[e], a.area[e]) * 1.0   // `dhsdT**area` as written (GE :1215)
+                                        : -a.frac[e] * a.dhsdT[e] * a.area[e] * 1.0;
     }
   }
   if (RHS) t.rhs[cell] = b;

@@ -307,6 +307,8 @@ struct ThermalBcArgs {
   int ncond_cells;
   const int *cc_cell, *cc_ptr, *type;            // cond_type per entry
   const double *du, *dd, *area, *value, *frac, *dhsdT;
+  const double *area_dirichlet_rhs = nullptr;    // thermal_reference_defects: the reference's stale `area` per COND_DIRICHLET entry
+  bool reference_defects = false;
   const signed char *bc_active;
 };
 void launch_thermal_bc(int mode, const ThermalBcArgs &a, hipStream_t stream);

@@ -202,6 +202,7 @@ struct Options {
   bool fused_spmv_pc = true;   // vertical-only grids, column preconditioner: M^{-1} A v as one kernel (k_tri_solve_lds<..., SPMV>) instead of
                                // the CSR SpMV followed by the column solve -- A v is never written or read back
   bool fused_first = true;     // ... and the start of a BiCGStab solve -- rp = U^{-1}(L^{-1} F) and v = M^{-1} A rp -- as one kernel too
+  bool thermal_reference_defects = false;   // reproduce GoveqnThermalKSPTemperatureSoilType.F90:906-908 (stale area) and :1215 (dhsdT**area)
   bool bc_inline = true;       // complete-row march: boundary fluxes of a column's end cells evaluated in the march's prologue
   bool fused_waxpy = true;     // ... and s = r - alpha v inside the kernel of the second product
   bool lazy_r = true;          // BiCGStab: r = s - omega t is not written by an iteration that is expected to be the last (only its norm)

@@ -212,7 +212,7 @@ struct Solver {
   DevBuf<double> d_th_dz, d_th_por, d_th_tkmg, d_th_tkdry, d_th_csol, d_th_liq, d_th_ice, d_th_snow, d_th_tuning;
   DevBuf<signed char> d_th_itype, d_th_shallow, d_th_nsnow0;
   DevBuf<double> d_therm_cond, d_heat_cap, d_cdu, d_cdd, d_carea, soln_prev_clm;
-  DevBuf<double> d_bc_du, d_bc_dd, d_bc_rawarea, d_bc_frac, d_bc_dhsdT;
+  DevBuf<double> d_bc_du, d_bc_dd, d_bc_rawarea, d_bc_stalearea, d_bc_frac, d_bc_dhsdT;
   DevBuf<signed char> d_bc_act;
   std::vector<double> h_bc_frac, h_bc_dhsdT;
   std::vector<signed char> h_bc_act;
@@ -804,6 +804,21 @@ struct Solver {
           bdu[e] = cd.dist_up[i]; bdd[e] = cd.dist_dn[i]; bar[e] = cd.area[i];
         }
       d_bc_du.upload(bdu, stream); d_bc_dd.upload(bdd, stream); d_bc_rawarea.upload(bar, stream);
+      if (thermal) {
+        // option thermal_reference_defects: the value the reference routine's local `area` holds when it reaches a COND_DIRICHLET
+        // connection (GoveqnThermalKSPTemperatureSoilType.F90:787, 906-911): the last internal connection between two active cells,
+        // or the last COND_HEAT_FLUX connection of an active cell met before it; undefined in the reference without either (0 here)
+        double stale = 0.0;
+        for (int c = 0; c < nc; ++c) if (active[cup_e[c]] == 1 && active[cdn_e[c]] == 1) stale = carea[c];
+        std::vector<double> bst(nb, 0.0);
+        for (auto &cd : bcs)
+          for (int i = 0; i < cd.n; ++i) {
+            if (active[cd.cell[i]] != 1) continue;
+            if (cd.cond_type == MPPGPU_COND_HEAT_FLUX) stale = cd.area[i];
+            bst[bc_pos_of_g[cd.offset + i]] = stale;
+          }
+        d_bc_stalearea.upload(bst, stream);
+      }
     }
     if (th) th_setup();
     if (thermal) {
@@ -1799,6 +1814,8 @@ struct Solver {
     b.t = a; b.ncond_cells = ncond_cells; b.cc_cell = d_cc_cell.p; b.cc_ptr = d_cc_ptr.p; b.type = d_bc_type.p;
     b.du = d_bc_du.p; b.dd = d_bc_dd.p; b.area = d_bc_rawarea.p; b.value = d_bc_value.p; b.frac = d_bc_frac.p;
     b.dhsdT = d_bc_dhsdT.p; b.bc_active = d_bc_act.p;
+    b.reference_defects = opt.thermal_reference_defects;
+    if (b.reference_defects) b.area_dirichlet_rhs = d_bc_stalearea.p;
     launch_thermal_bc(mode, b, stream);
     if (mode != 0) pc_ready = false;
   }
@@ -3151,6 +3168,7 @@ struct Solver {
     else if (key == "lazy_r") opt.lazy_r = num() != 0;
     else if (key == "fused_waxpy") opt.fused_waxpy = num() != 0;
     else if (key == "bc_inline") opt.bc_inline = num() != 0;
+    else if (key == "thermal_reference_defects") opt.thermal_reference_defects = num() != 0;
     else if (key == "spmv_tpw") opt.spmv_tpw = (int)num();
     else if (key == "soil_classes") { opt.soil_classes = num() != 0; soil_dirty = true; }
     else if (key == "level_geometry") { opt.level_geometry = num() != 0; soil_dirty = true; }

@@ -9,10 +9,13 @@
  * The linear solve is PETSc's (GMRES(30)+ILU(0) by default): the restatement in vsfm_oracle.c is reused.
  * Pinned by the reference's regression baselines regression_tests/thermal/thermal_mms{,_2d,_3d}.regression.baseline.
  *
- * Reference defects deliberately NOT replicated (both are invisible on the reference's own test problems):
- *   - the COND_DIRICHLET branch of the RHS uses the stale `area`/`factor` of the last internal connection
- *     (GoveqnThermalKSPTemperatureSoilType.F90:906-908); here the boundary connection's own area is used;
- *   - the COND_HEAT_FLUX operator term is written `dhsdT**area` (:1215); here it is dhsdT*area.
+ * Two reference defects (both invisible on the reference's own test problems) are NOT replicated unless
+ * to_set_reference_defects(p, 1) asks for them:
+ *   - the COND_DIRICHLET branch of the RHS uses the stale local `area` (GoveqnThermalKSPTemperatureSoilType.F90:906-908):
+ *     the area of the last internal connection between two active cells (:787), or of the last COND_HEAT_FLUX boundary
+ *     connection met before it in the loop over conditions (:911); by default the boundary connection's own area is used
+ *     (a mesh without any such earlier connection reads an undefined variable in the reference: 0 here);
+ *   - the COND_HEAT_FLUX operator term is written `dhsdT**area` (:1215); by default it is dhsdT*area.
  */
 #include <math.h>
 #include <stdlib.h>
@@ -58,6 +61,7 @@ typedef struct to_problem {
   int *rowptr, *col, *diag;
   double *val, *rhs, *soln, *soln_prev, *soln_prev_clm;
   double dtime, cnfac;
+  int reference_defects;
   int ksp_type, pc_type;
   double ksp_rtol;
   long cum_linear;
@@ -250,6 +254,19 @@ int to_set_condition_values(to_problem *p, int kind, int id, int n, const double
   return 0;
 }
 
+/* sysofeqns_thermal_auxvar_type of a boundary condition: var 1 frac, 2 dhsdT, 3 is_active (SystemOfEquationsThermalAuxType.F90:23-32) */
+int to_set_condition_aux(to_problem *p, int id, int var, int n, const double *v) {
+  tcond *c = &p->bc[id - 1];
+  if (n > c->n) return -1;
+  for (int i = 0; i < n; i++) {
+    if (var == 1) c->aux[i].frac = v[i];
+    else if (var == 2) c->aux[i].dhsdT = v[i];
+    else if (var == 3) c->aux[i].is_active = v[i] != 0.0;
+    else return -1;
+  }
+  return 0;
+}
+
 int to_set_options(to_problem *p, double cnfac, int ksp_type, int pc_type, double ksp_rtol) {
   if (cnfac >= 0) p->cnfac = cnfac;
   p->ksp_type = ksp_type; p->pc_type = pc_type;
@@ -257,6 +274,7 @@ int to_set_options(to_problem *p, double cnfac, int ksp_type, int pc_type, doubl
   return 0;
 }
 
+int to_set_reference_defects(to_problem *p, int on) { p->reference_defects = on != 0; return 0; }
 int to_set_soln_prev_clm(to_problem *p, const double *T) { memcpy(p->soln_prev_clm, T, p->n * sizeof(double)); return 0; }
 /* ThermalSOEPreStepDT :391-409 */
 int to_pre_step_dt(to_problem *p) {
@@ -283,7 +301,7 @@ static double harmonic(double ku, double kd, double du, double dd) { return ku *
 
 /* ThermKSPTempSoilComputeRHS = Accum + Divergence (GE :646-972) */
 int to_compute_rhs(to_problem *p, double *b) {
-  double dt = p->dtime, cnfac = p->cnfac;
+  double dt = p->dtime, cnfac = p->cnfac, stale_area = 0.0;
   update_auxvars(p);
   memset(b, 0, p->n * sizeof(double));
   for (int i = 0; i < p->n; i++) {
@@ -297,6 +315,7 @@ int to_compute_rhs(to_problem *p, double *b) {
     double flux = -k * (p->aux[u].temperature - p->aux[d].temperature) / (p->dist_up[c] + p->dist_dn[c]); /* DiffHeatFlux :975-1003 */
     b[u] = b[u] + cnfac * flux * p->area[c] * 1.0;
     b[d] = b[d] - cnfac * flux * p->area[c] * 1.0;
+    stale_area = p->area[c]; /* the local `area` of the reference routine (:787) */
   }
   for (int bb = 0; bb < p->nbc; bb++) {
     tcond *cd = &p->bc[bb];
@@ -307,9 +326,12 @@ int to_compute_rhs(to_problem *p, double *b) {
         if (!cd->aux[i].is_active) continue;
         double du = cd->dist_up[i], dd = cd->dist_dn[i], dist = du + dd;
         double k = cd->aux[i].therm_cond * p->aux[cell].therm_cond * (du + dd) / (cd->aux[i].therm_cond * dd + p->aux[cell].therm_cond * du);
-        b[cell] = b[cell] + k / dist * cd->aux[i].temperature * cd->area[i] * 1.0;
+        b[cell] = b[cell] + k / dist * cd->aux[i].temperature * (p->reference_defects ? stale_area : cd->area[i]) * 1.0;
       } else if (cd->cond_type == TO_COND_HEAT_FLUX) {
-        b[cell] = b[cell] + 1.0 * cd->value[i] * cd->aux[i].frac * cd->area[i];
+        stale_area = cd->area[i]; /* :911 */
+        /* cur_cond%value = H - dH/dT * T of the cell (ThermKSPTempSoilGetFromSOEAuxVarsBC :339-354; T = soln_prev, :157-187) */
+        double value = cd->aux[i].condition_value - cd->aux[i].dhsdT * p->aux[cell].temperature;
+        b[cell] = b[cell] + 1.0 * value * cd->aux[i].frac * cd->area[i];
       }
     }
   }
@@ -356,7 +378,8 @@ int to_compute_operators(to_problem *p) {
         double value = cd->aux[i].frac * (1.0 - cnfac) * k / dist * cd->area[i] * 1.0;
         p->val[p->diag[cell]] += value;
       } else if (cd->cond_type == TO_COND_HEAT_FLUX) {
-        p->val[p->diag[cell]] += -cd->aux[i].frac * cd->aux[i].dhsdT * cd->area[i] * 1.0;
+        if (p->reference_defects) p->val[p->diag[cell]] += -cd->aux[i].frac * pow(cd->aux[i].dhsdT, cd->area[i]) * 1.0; /* :1215 as written */
+        else p->val[p->diag[cell]] += -cd->aux[i].frac * cd->aux[i].dhsdT * cd->area[i] * 1.0;
       }
     }
   }

@@ -85,6 +85,15 @@ class ThermalOracle:
     def set_options(self, cnfac=-1.0, ksp_type=VO.lib and 1, pc_type=1, ksp_rtol=0.0):
         self._chk(self.L.to_set_options(self.h, float(cnfac), int(ksp_type), int(pc_type), float(ksp_rtol)))
 
+    def set_condition_aux(self, cid, var, values):
+        """frac / dhsdT / is_active of a boundary condition's auxvars (var = 'frac' | 'dhsdT' | 'active')"""
+        v, pv = _d(values)
+        self._chk(self.L.to_set_condition_aux(self.h, cid, {"frac": 1, "dhsdT": 2, "active": 3}[var], v.size, pv))
+
+    def set_reference_defects(self, on=True):
+        """Reproduce GoveqnThermalKSPTemperatureSoilType.F90:906-908 (stale area) and :1215 (dhsdT**area) as written."""
+        self._chk(self.L.to_set_reference_defects(self.h, int(bool(on))))
+
     def set_soln_prev_clm(self, T):
         v, pv = _d(T)
         self._chk(self.L.to_set_soln_prev_clm(self.h, pv))

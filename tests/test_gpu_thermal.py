@@ -153,3 +153,30 @@ def test_multibase_spmv_index_on_a_grid_with_far_neighbours():
     bad.soe.SetDtime(prob.dt); bad.soe.PreSolve(); bad.soe.ComputeJacobian(x)
     with pytest.raises(Exception):
         bad.soe.MatMult(v)                               # no single-base index for this pattern
+
+
+@pytest.mark.parametrize("flux_first", [False, True])
+@pytest.mark.parametrize("defects", [False, True])
+def test_heat_flux_boundary_and_reference_defects_switch_match_the_oracle(flux_first, defects):
+    """COND_HEAT_FLUX with frac and dhsdT (GE :339-354, 909-924, 1199-1217) next to Dirichlet faces; with
+    `thermal_reference_defects` the stale-area right-hand side (:906-908) and `dhsdT**area` (:1215) as the reference has them"""
+    case = P.thermal_flux_case()
+    g = P.to_thermal_flux_gpu(case, flux_first, {"thermal_reference_defects": int(defects)})
+    o = P.to_thermal_flux_oracle(case, flux_first, defects=defects)
+    b_o = o.compute_rhs(1800.0)
+    rp, cj, val = o.compute_operators()
+    b_g = g.soe.ComputeRHS(1800.0)
+    rp_g, cj_g, val_g = g.soe.ComputeOperators(1800.0)
+    assert np.array_equal(rp, rp_g) and np.array_equal(cj, cj_g)
+    assert np.abs(val_g - val).max() <= 1e-13 * np.abs(val).max()
+    assert np.abs(b_g - b_o).max() <= 1e-12 * np.abs(b_o).max()
+    # the switch changes both on this mesh (so the comparison above is not vacuous)
+    o2 = P.to_thermal_flux_oracle(case, flux_first, defects=not defects)
+    assert np.abs(o2.compute_rhs(1800.0) - b_o).max() > 1e-3 * np.abs(b_o).max()
+    # and a step: GMRES(30) + ILU(0) to a tight tolerance on both sides
+    g2 = P.to_thermal_flux_gpu(case, flux_first, {"thermal_reference_defects": int(defects), "ksp_type": "gmres", "pc_type": "ilu", "ksp_rtol": 1e-12})
+    conv, _ = g2.soe.StepDT(1800.0, 1)
+    assert conv
+    o3 = P.to_thermal_flux_oracle(case, flux_first, defects=defects, ksp_rtol=1e-13)
+    assert o3.step_dt(1800.0)
+    assert np.abs(g2.soe.GetSoln() - o3.get_soln()).max() <= 1e-8

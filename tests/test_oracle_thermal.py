@@ -47,3 +47,59 @@ def test_thermal_mms_second_order_convergence():
         o.step_dt(tp.dt)
         errs.append(np.abs(o.get_soln() - tp.exact).max())
     assert 3.5 < errs[0] / errs[1] < 4.5 and 3.5 < errs[1] / errs[2] < 4.5
+
+
+def _flux_rhs_and_operator(case, flux_first, defects, H=None, dhsdT=None, tdir=None):
+    tp, diri, tdir0, flux, H0, frac, dhsdT0 = case
+    c = (tp, diri, tdir0 if tdir is None else tdir, flux, H0 if H is None else H, frac, dhsdT0 if dhsdT is None else dhsdT)
+    o = P.to_thermal_flux_oracle(c, flux_first, defects=defects)
+    b = o.compute_rhs(1800.0)
+    rp, cj, val = o.compute_operators()
+    diag = np.array([val[rp[i]:rp[i + 1]][cj[rp[i]:rp[i + 1]] == i][0] for i in range(len(b))])
+    return b, diag
+
+
+def test_heat_flux_boundary_is_the_linearised_surface_flux():
+    """COND_HEAT_FLUX: the right-hand side takes (H - dH/dT T_old) frac area (GetFromSOEAuxVarsBC :339-354, Divergence :909-924),
+    the operator's diagonal -frac dH/dT area (ComputeOperatorsDiag :1199-1217 as intended) -- CLM's H + dH/dT (T_new - T_old)."""
+    case = P.thermal_flux_case()
+    tp, diri, tdir, flux, H, frac, dhsdT = case
+    cells = np.asarray(flux.id_dn) - 1
+    b, d = _flux_rhs_and_operator(case, False, False)
+    b0, d0 = _flux_rhs_and_operator(case, False, False, H=0 * H, dhsdT=0 * dhsdT)
+    want_b = np.zeros_like(b); want_d = np.zeros_like(b)
+    np.add.at(want_b, cells, (H - dhsdT * tp.exact[cells]) * frac * flux.area)
+    np.add.at(want_d, cells, -frac * dhsdT * flux.area)
+    assert np.abs((b - b0) - want_b).max() <= 1e-12 * np.abs(b).max()
+    assert np.abs((d - d0) - want_d).max() <= 1e-12 * np.abs(d).max()
+    assert np.abs(want_b).max() > 0 and np.abs(want_d).max() > 0
+
+
+@pytest.mark.parametrize("flux_first", [False, True])
+def test_reference_defects_switch_of_the_thermal_operator(flux_first):
+    """With the switch the COND_DIRICHLET right-hand side takes the routine's stale `area` (:906-908) -- the last internal
+    connection's, or the last COND_HEAT_FLUX connection's when that condition comes first -- and the heat-flux operator term is
+    dhsdT**area (:1215).  Off (the default) neither happens."""
+    case = P.thermal_flux_case()
+    tp, diri, tdir, flux, H, frac, dhsdT = case
+    ic = tp.mesh.internal_connections()
+    stale = flux.area[-1] if flux_first else ic.area[-1]
+    assert not np.isclose(flux.area[-1], ic.area[-1])
+    b, d = _flux_rhs_and_operator(case, flux_first, False)
+    bd, dd = _flux_rhs_and_operator(case, flux_first, True)
+    # Dirichlet part of the right-hand side: linear in the boundary temperature (dry soil: no T in the conductivity)
+    D = b - _flux_rhs_and_operator(case, flux_first, False, tdir=0 * tdir)[0]
+    Dd = bd - _flux_rhs_and_operator(case, flux_first, True, tdir=0 * tdir)[0]
+    cells = np.asarray(diri.id_dn) - 1
+    once = np.bincount(cells, minlength=len(b)) == 1           # cells with exactly one Dirichlet face
+    area_of = np.zeros(len(b)); area_of[cells] = diri.area
+    sel = once & (D != 0)
+    assert sel.sum() > 50
+    np.testing.assert_allclose(Dd[sel] / D[sel], stale / area_of[sel], rtol=1e-11)
+    assert np.abs(Dd[sel] / D[sel] - 1.0).max() > 0.1                # ... and it matters on this mesh
+    # operator: -frac dhsdT**area instead of -frac dhsdT area on the diagonal of the heat-flux cells
+    fc = np.asarray(flux.id_dn) - 1
+    want = np.zeros_like(d)
+    np.add.at(want, fc, -frac * dhsdT ** flux.area + frac * dhsdT * flux.area)
+    assert np.abs((dd - d) - want).max() <= 1e-12 * np.abs(d).max()
+    assert np.abs(want).max() > 1e-3
