@@ -1225,8 +1225,10 @@ __global__ __launch_bounds__(kBlock) void k_thermal_bc(ThermalBcArgs a) {
     const int ctype = a.type[e];
     if (ctype == 505) {
       if (!a.bc_active[e]) continue;
-      double kbc, cbc;  // the BC auxvar: soil of its id_dn cell, no water, boundary temperature
-      thermal_auxvar(t.itype[cell], t.shallow[cell] != 0, a.value[e], 0.0, 0.0, 0.0, true, t.por[cell], t.tkmg[cell],
+      // the BC auxvar: land unit and soil constants of its id_dn cell, no water, boundary temperature -- and is_soil_shallow
+      // FALSE, which MPPThermalSetSoils never sets on boundary auxvars (MultiPhysicsProbThermal.F90:186-204; auxvar :65)
+      double kbc, cbc;
+      thermal_auxvar(t.itype[cell], false, a.value[e], 0.0, 0.0, 0.0, true, t.por[cell], t.tkmg[cell],
                      t.tkdry[cell], t.csol[cell], t.dz[cell], kbc, cbc);
       const double du = a.du[e], dd = a.dd[e], dist = du + dd, kc = t.therm_cond[cell];
       const double kav = kbc * kc * dist / (kbc * dd + kc * du);

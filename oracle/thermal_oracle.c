@@ -209,6 +209,10 @@ int to_add_condition(to_problem *p, int kind, int cond_type, int n, const int *i
     if (id_dn[i] < 1 || id_dn[i] > p->n) return -1;
     c->id_dn[i] = id_dn[i] - 1;
     taux_init(&c->aux[i]);
+    /* a boundary auxvar keeps the is_soil_shallow = FALSE of ThermKSPTempSoilAuxVarInit (auxvar :65): MPPThermalSetSoils copies
+       itype, por and the soil constants to it but not that flag (MultiPhysicsProbThermal.F90:186-204), so its conductivity is
+       thk_bedrock for soil and wetland cells -- visible only when the boundary connection has dist_up > 0 */
+    c->aux[i].is_soil_shallow = 0;
     if (kind == TO_COND_BC) { c->dist_up[i] = du[i]; c->dist_dn[i] = dd[i]; c->area[i] = area[i]; }
   }
   return ++(*cnt);
@@ -241,6 +245,7 @@ int to_set_cell_data(to_problem *p, int var, const double *v) {
       case 2: a->ice_areal_den = v[i]; break;
       case 3: a->tuning_factor = v[i]; break;
       case 4: a->snow_water = v[i]; break;
+      case 5: a->num_snow_layer = (int)v[i]; break;
       default: return -1;
     }
   }

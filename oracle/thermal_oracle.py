@@ -11,7 +11,7 @@ _dp = ct.POINTER(ct.c_double)
 _ip = ct.POINTER(ct.c_int)
 SOIL, WETLAND, ICE = 1, 2, 3
 COND_BC, COND_SS, COND_DIRICHLET, COND_HEAT_FLUX, COND_HEAT_RATE = 501, 502, 505, 507, 511
-VAR_LIQ_AREAL_DEN, VAR_ICE_AREAL_DEN, VAR_TUNING_FACTOR, VAR_SNOW_WATER = 1, 2, 3, 4
+VAR_LIQ_AREAL_DEN, VAR_ICE_AREAL_DEN, VAR_TUNING_FACTOR, VAR_SNOW_WATER, VAR_NUM_SNOW_LYR = 1, 2, 3, 4, 5
 
 
 def _d(a):

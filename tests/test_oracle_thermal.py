@@ -103,3 +103,20 @@ def test_reference_defects_switch_of_the_thermal_operator(flux_first):
     np.add.at(want, fc, -frac * dhsdT ** flux.area + frac * dhsdT * flux.area)
     assert np.abs((dd - d) - want).max() <= 1e-12 * np.abs(d).max()
     assert np.abs(want).max() > 1e-3
+
+
+def test_boundary_auxvars_are_never_shallow_soil():
+    """MPPThermalSetSoils copies itype, por and the soil constants to the boundary auxvars but not is_soil_shallow
+    (MultiPhysicsProbThermal.F90:186-204), which ThermKSPTempSoilAuxVarInit left FALSE: a soil cell's Dirichlet auxvar conducts
+    like bedrock (3 W/m/K).  With dist_up = 0 (the MMS baselines) the harmonic mean does not see it; with dist_up > 0 it does."""
+    case = P.thermal_flux_case(bc_dist_up=0.4)
+    tp, diri, tdir, flux, H, frac, dhsdT = case
+    b = _flux_rhs_and_operator(case, False, False)[0]
+    b0 = _flux_rhs_and_operator(case, False, False, tdir=0 * tdir)[0]
+    cells = np.asarray(diri.id_dn) - 1
+    kc = tp.tkdry[cells]                                      # dry shallow soil: the cell's conductivity
+    du, dd = np.asarray(diri.dist_up), np.asarray(diri.dist_dn)
+    kav = 3.0 * kc * (du + dd) / (3.0 * dd + kc * du)
+    want = np.zeros_like(b)
+    np.add.at(want, cells, kav / (du + dd) * tdir * diri.area)
+    assert np.abs((b - b0) - want).max() <= 1e-12 * np.abs(want).max()
