@@ -1613,7 +1613,16 @@ int vo_step_dt(vo_problem *p, double dt, int nstep, int *converged, int *converg
       for (int b = 0; b < p->nbc; b++)
         for (int i = 0; i < p->bc[b].n; i++) p->bc[b].mass_exc[i] = p->bc[b].mass_exc[i] + p->bc[b].flux[i] * p->dtime;
     }
-    if (num_time_cuts > max_num_time_cuts) { *converged = 0; p->linesearch_type = ls_default; return 0; }
+    if (num_time_cuts > max_num_time_cuts) {
+      /* The SoE auxvars GetDataForCLM reads are filled in PostSolve only (VSFMSOEPostSolve :566-660), so after a step that
+       * gave up they still hold the state of the last sub-step that converged = soln (restored above); the auxvars and
+       * fluxes of this restatement, left at the diverged iterate by the last residual, are brought back to that state */
+      double *scratch = (double *)malloc(p->n * sizeof(double));
+      vo_residual(p, p->soln, scratch);
+      p->nfuncs--; p->cum_funcs--;   /* (not one of SNES's function evaluations) */
+      free(scratch);
+      *converged = 0; p->linesearch_type = ls_default; return 0;
+    }
     if (p->time >= target_time) break;
   }
   p->linesearch_type = ls_default;   /* "Set the linsearch type to be the default setting" :539-550 */
