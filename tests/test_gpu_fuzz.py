@@ -107,3 +107,90 @@ def test_random_vsfm_problem_matches_the_oracle(seed):
     assert (cg["newton"], cg["time_cuts"]) == (co["newton"], co["time_cuts"]), what
     p_o, p_g = o.get(C.AUXVAR_INTERNAL, C.VAR_PRESSURE), g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1)
     assert np.abs(p_g - p_o).max() <= 1e-8 * np.abs(p_o).max(), what
+
+
+# ---- 3-D grids (the v-channel mesh family: 7-point stencil, sloping surface, gravity along every connection) ----
+ROUTES_3D = [{}, {"ilu_box": 0}, {"ilu_box": 0, "ilu_chain": 1}, {"ilu_graph": 0}, {"spmv_variant": 0}, {"spmv_variant": 1},
+             {"ilu_box": 1, "ilu_box_len": 4}, {"host_poll": 0}]
+SOLVERS_3D = [("gmres", "ilu", C.KSP_GMRES, C.PC_ILU0), ("bcgs", "ilu", C.KSP_BCGS, C.PC_ILU0), ("gmres", "jacobi", C.KSP_GMRES, C.PC_JACOBI)]
+
+
+def draw3d(seed):
+    rng = np.random.default_rng(5000 + seed)
+    nx, ny, nz = (int(v) for v in rng.integers(2, 9, 3))
+    prob = P.vchannel(nx, ny, nz)
+    n = prob.mesh.ncells_local
+    what = {"grid": (nx, ny, nz)}
+    f = (lambda lo, hi: rng.uniform(lo, hi, n)) if rng.random() < 0.7 else (lambda lo, hi: np.ones(n))
+    prob.perm = prob.perm * np.exp(0.4 * rng.standard_normal(n))[:, None] * rng.uniform(0.5, 2.0, 3)[None, :]   # anisotropic too
+    prob.por = prob.por * f(0.8, 1.2)
+    prob.alpha = prob.alpha * f(0.8, 1.2)
+    prob.sat_res = prob.sat_res * f(0.8, 1.2)
+    law = what["law"] = str(rng.choice(["vg_half", "vg", "sbc2", "sbc3", "mixed"]))
+    if law == "vg":
+        prob.lam = np.clip(prob.lam * f(0.7, 1.3), 0.05, 0.95)
+    elif law == "mixed":
+        prob.satfunc_type = np.asarray(SATF, dtype=np.int32)[rng.integers(0, 4, n)]
+        prob.lam = np.where(prob.satfunc_type == C.SAT_FUNC_VAN_GENUCHTEN, rng.uniform(0.3, 0.7, n), rng.uniform(0.4, 1.6, n))
+    elif law != "vg_half":
+        prob.satfunc_type = np.full(n, {"sbc2": SATF[2], "sbc3": SATF[3]}[law], dtype=np.int32)
+        prob.lam = rng.uniform(0.4, 1.6, n)
+    prob.density_type = what["density"] = int(rng.choice([C.DENSITY_CONSTANT, C.DENSITY_TGDPB01, C.DENSITY_IFC67]))
+    if rng.random() < 0.3:
+        what["linear_porosity"] = True
+        prob.por_pressure_reference = np.full(n, 101325.0) + rng.uniform(-2e4, 2e4, n)
+        prob.por_slope = rng.uniform(1e-8, 6e-8, n)
+    if rng.random() < 0.4:
+        what["sources"] = True
+        ids = np.arange(1, n + 1); z = np.zeros(n)
+        prob.sss = [(C.COND_MASS_RATE, M.ConnectionSet(np.full(n, -1), ids, z, z, np.ones(n), np.zeros((n, 3))), rng.uniform(-2e-4, 2e-4, n))]
+    if rng.random() < 0.3:
+        what["inactive"] = True
+        act = np.ones(n, dtype=np.int32)
+        act[rng.choice(n, max(1, n // 40), replace=False)] = 0
+        prob.mesh.is_active = act
+    if rng.random() < 0.5:    # a drier start: unsaturated cells above the water table
+        what["start"] = "dry_top"
+        prob.press_ic = prob.press_ic - rng.uniform(0.0, 1.5e5)
+    ksp, pc, oksp, opc = SOLVERS_3D[int(rng.integers(0, len(SOLVERS_3D)))]
+    opts = dict({"ksp_type": ksp, "pc_type": pc}, **ROUTES_3D[int(rng.integers(0, len(ROUTES_3D)))])
+    what["options"] = opts
+    x = prob.press_ic + rng.uniform(-1.0e5, 2.0e4, n)
+    prob.dt = float(rng.choice([600.0, 8640.0]))
+    return prob, x, opts, (oksp, opc), what
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_3d_vsfm_problem_matches_the_oracle(seed):
+    prob, x, opts, (oksp, opc), what = draw3d(seed)
+    o, g, _csr, _v = _operator_parity(prob, x, opts)
+    o.set_solver(oksp, opc)
+    res_g = [g.soe.StepDT(prob.dt, s + 1) for s in range(2)]
+    res_o = [tuple(o.step_dt(prob.dt, s + 1)) for s in range(2)]
+    cg, co = g.soe.counters(), o.counters()
+    p_o, p_g = o.get(C.AUXVAR_INTERNAL, C.VAR_PRESSURE), g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1)
+    if co["linear"] > 500 * max(1, co["newton"]):
+        # restarted GMRES behind a point-Jacobi preconditioner stagnating for thousands of iterations: whether a solve ends
+        # just before or just after ksp_max_it (a time-step cut) is decided by rounding; the answers still have to agree
+        assert [r[0] for r in res_g] == [r[0] for r in res_o], what
+        assert np.abs(p_g - p_o).max() <= 1e-4 * np.abs(p_o).max(), what     # (a cut step is two half steps: O(dt^2) apart)
+        return
+    assert res_g == res_o, what
+    assert (cg["newton"], cg["time_cuts"]) == (co["newton"], co["time_cuts"]), what
+    assert np.abs(p_g - p_o).max() <= 1e-8 * np.abs(p_o).max(), what
+
+
+# ---- coupled thermal-hydrology on soil columns ----
+@pytest.mark.parametrize("seed", range(24))
+def test_random_th_columns_problem_matches_the_oracle(seed):
+    """grid, permeabilities, retention curves (one kind or all four mixed), porosity model, density and internal-energy
+    formulations and the assembly route drawn at random: operators, ILU(0) application and two coupled steps (test_gpu_th.py's
+    comparison)"""
+    from test_gpu_th import _th_columns_vs_oracle
+    rng = np.random.default_rng(9000 + seed)
+    ncols, nz = int(rng.choice([1, 3, 70, 131])), int(rng.choice([2, 5, 9, 20]))
+    _th_columns_vs_oracle(ncols, nz, str(rng.choice(["general", "columns"])), mixed=bool(rng.random() < 0.5),
+                          linear_porosity=bool(rng.random() < 0.4), seed=100 + seed,
+                          density_type=int(rng.choice([C.DENSITY_CONSTANT, C.DENSITY_TGDPB01, C.DENSITY_IFC67])),
+                          ie_type=int(rng.choice([1, 2])),
+                          jtol=1e-8)   # d(energy)/dP on the diagonal is a difference of accumulation and flux terms 1e3 times its size
