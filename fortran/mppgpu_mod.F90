@@ -378,7 +378,7 @@ module mppgpu_mod
      end function
   end interface
 
-  integer(c_int), parameter, public :: VAR_LIQ_AREAL_DEN = 615, VAR_TUNING_FACTOR = 630
+  integer(c_int), parameter, public :: VAR_LIQ_AREAL_DEN = 615, VAR_TUNING_FACTOR = 630, VAR_FRAC = 618, VAR_ACTIVE = 624
 
   !> sysofeqns_vsfm_type stand-in: same method names as the reference's SoE and governing equation
   !! (SoE: SetDataFromCLM / GetDataForCLM / PreStepDT / StepDT / PostStepDT / ComputeLateralFlux,

@@ -10,7 +10,7 @@ program thermal_mms_gpu
   integer :: n, nlev, nconn, nbc, num_cells, ierr, i, bc_id, ss_id, its
   real(8) :: t_init, cnfac, dt
   integer, allocatable :: is_active(:), id_up(:), id_dn(:), bc_dn(:), all_cells(:), itype(:), shallow(:)
-  real(8), allocatable :: vol(:), dz(:), du(:), dd(:), area(:), uvec(:), bdu(:), bdd(:), barea(:), buvec(:), bval(:)
+  real(8), allocatable :: vol(:), dz(:), du(:), dd(:), area(:), uvec(:), bdu(:), bdd(:), barea(:), buvec(:), bval(:), bones(:)
   real(8), allocatable :: tkdry(:), src(:), zeros(:), ones(:), watsat(:), temp(:), uv0(:)
   logical :: converged
   character(len=32) :: val
@@ -18,7 +18,7 @@ program thermal_mms_gpu
   read(*,*) n, nlev, nconn, nbc, num_cells
   read(*,*) t_init, cnfac, dt
   allocate(is_active(n), vol(n), dz(n), id_up(nconn), id_dn(nconn), du(nconn), dd(nconn), area(nconn), uvec(3*nconn))
-  allocate(bc_dn(nbc), bdu(nbc), bdd(nbc), barea(nbc), buvec(3*nbc), bval(nbc), tkdry(n), src(n))
+  allocate(bc_dn(nbc), bdu(nbc), bdd(nbc), barea(nbc), buvec(3*nbc), bval(nbc), bones(nbc), tkdry(n), src(n))
   allocate(all_cells(n), itype(n), shallow(n), zeros(n), ones(n), watsat(n), temp(n), uv0(3*n))
   read(*,*) vol
   read(*,*) dz
@@ -34,6 +34,7 @@ program thermal_mms_gpu
   read(*,*) barea
   read(*,*) buvec
   read(*,*) bval
+  bones = 1.d0
   read(*,*) tkdry
   read(*,*) src
   is_active = 1; zeros = 0.d0; ones = 1.d0; uv0 = 0.d0
@@ -58,6 +59,8 @@ program thermal_mms_gpu
   call soe%SetDataFromCLM(AUXVAR_INTERNAL, VAR_TUNING_FACTOR, 1, ones, ierr);        call chk('tuning')
   call soe%SetDataFromCLM(AUXVAR_INTERNAL, VAR_LIQ_AREAL_DEN, 1, zeros, ierr);       call chk('liq')
   call soe%SetDataFromCLM(AUXVAR_BC, VAR_BC_SS_CONDITION, bc_id, bval, ierr);        call chk('bc values')
+  call soe%SetDataFromCLM(AUXVAR_BC, VAR_ACTIVE, bc_id, bones, ierr);                call chk('bc active')   ! thermal_mms_problem.F90:664-668
+  call soe%SetDataFromCLM(AUXVAR_BC, VAR_FRAC, bc_id, bones, ierr);                  call chk('bc frac')
   call soe%SetDataFromCLM(AUXVAR_SS, VAR_BC_SS_CONDITION, ss_id, src, ierr);         call chk('ss values')
   call soe%PreStepDT(ierr);                                                          call chk('PreStepDT')
   call soe%StepDTKSP(dt, converged, its, ierr);                                      call chk('StepDT')

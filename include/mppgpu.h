@@ -279,7 +279,12 @@ int mppgpu_thermal_set_soils(mppgpu_handle h, const int *itype, const int *is_so
 /* soe%SetSolnPrevCLM / PreStepDT / StepDT / GetSoln (src/mpp/soe/SystemOfEquationsThermalType.F90:171-230, 391-409;
  * src/mpp/soe/SystemOfEquationsBaseType.F90:555-647).  mppgpu_set_data carries SetRDataFromCLM:
  * AUXVAR_INTERNAL x {VAR_LIQ_AREAL_DEN, VAR_ICE_AREAL_DEN, VAR_SNOW_WATER, VAR_NUM_SNOW_LYR, VAR_TUNING_FACTOR},
- * AUXVAR_BC x {VAR_BC_SS_CONDITION, VAR_FRAC, VAR_DHS_DT, VAR_ACTIVE}, AUXVAR_SS x VAR_BC_SS_CONDITION. */
+ * AUXVAR_BC x {VAR_BC_SS_CONDITION, VAR_FRAC, VAR_DHS_DT, VAR_ACTIVE}, AUXVAR_SS x VAR_BC_SS_CONDITION.
+ * VAR_FRAC / VAR_DHS_DT / VAR_ACTIVE stand for ThermKSPTempSoilAuxVarSetRValues on the equation's boundary auxvars; as in the
+ * reference (ThermalKSPTemperatureBaseAuxType.F90:56-60) these start inactive with frac = 0: a boundary contributes nothing until
+ * the caller sets VAR_ACTIVE (and VAR_FRAC) for it, as thermal_mms_problem.F90:664-668 does.
+ * Option "thermal_reference_defects" = 1 reproduces GoveqnThermalKSPTemperatureSoilType.F90:906-908 (stale area in the
+ * COND_DIRICHLET right-hand side) and :1215 (dhsdT**area) as written; the default computes what they intend. */
 int mppgpu_thermal_set_soln_prev_clm(mppgpu_handle h, int n, const double *temperature);
 int mppgpu_thermal_pre_step_dt(mppgpu_handle h);
 int mppgpu_thermal_step_dt(mppgpu_handle h, double dt, int *converged, int *linear_its);

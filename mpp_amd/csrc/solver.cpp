@@ -822,7 +822,9 @@ struct Solver {
     }
     if (th) th_setup();
     if (thermal) {
-      h_bc_frac.assign(nb, 1.0); h_bc_dhsdT.assign(nb, 0.0); h_bc_act.assign(nb, 1);
+      // boundary auxvars start as ThermKSPTempBaseAuxVarInit leaves them (ThermalKSPTemperatureBaseAuxType.F90:56-60): inactive,
+      // frac 0 -- the caller switches them on (mppgpu_set_data(AUXVAR_BC, VAR_ACTIVE / VAR_FRAC), as thermal_mms_problem.F90:664-668)
+      h_bc_frac.assign(nb, 0.0); h_bc_dhsdT.assign(nb, 0.0); h_bc_act.assign(nb, 0);
       d_bc_frac.upload(h_bc_frac, stream); d_bc_dhsdT.upload(h_bc_dhsdT, stream);
       d_bc_act.upload(h_bc_act.data(), h_bc_act.size(), stream);
       d_therm_cond.alloc(n); d_heat_cap.alloc(n);

@@ -335,6 +335,9 @@ def to_thermal_gpu(tp: ThermalProblem, options=None, device_id=0):
     mpp.soe.SetRDataFromCLM(C.AUXVAR_INTERNAL, T.VAR_TUNING_FACTOR, 1, np.ones(n))
     mpp.soe.SetRDataFromCLM(C.AUXVAR_INTERNAL, T.VAR_LIQ_AREAL_DEN, 1, np.zeros(n))
     mpp.soe.SetRDataFromCLM(C.AUXVAR_BC, C.VAR_BC_SS_CONDITION, 1, tp.bc_temperature)
+    nb = tp.bc.num_connections          # the driver's is_active_1d / fraction_1d of the boundary auxvars (:664-668)
+    mpp.soe.SetRDataFromCLM(C.AUXVAR_BC, T.VAR_ACTIVE, 1, np.ones(nb))
+    mpp.soe.SetRDataFromCLM(C.AUXVAR_BC, T.VAR_FRAC, 1, np.ones(nb))
     mpp.soe.SetRDataFromCLM(C.AUXVAR_SS, C.VAR_BC_SS_CONDITION, 1, tp.heat_source)
     mpp.soe.PreStepDT()
     return mpp

@@ -57,6 +57,8 @@ def to_thermal_oracle(tp: ThermalProblem, ksp_rtol=0.0):
     o.set_cell_data(TO.VAR_TUNING_FACTOR, 1.0)
     o.set_cell_data(TO.VAR_LIQ_AREAL_DEN, 0.0)
     o.set_condition_values(TO.COND_BC, 1, tp.bc_temperature)
+    o.set_condition_aux(1, "active", np.ones(tp.bc.num_connections))   # thermal_mms_problem.F90:664-668
+    o.set_condition_aux(1, "frac", np.ones(tp.bc.num_connections))
     o.set_condition_values(TO.COND_SS, 1, tp.heat_source)
     o.pre_step_dt()
     return o

@@ -213,6 +213,7 @@ int to_add_condition(to_problem *p, int kind, int cond_type, int n, const int *i
        itype, por and the soil constants to it but not that flag (MultiPhysicsProbThermal.F90:186-204), so its conductivity is
        thk_bedrock for soil and wetland cells -- visible only when the boundary connection has dist_up > 0 */
     c->aux[i].is_soil_shallow = 0;
+    if (kind == TO_COND_BC) { c->aux[i].is_active = 0; c->aux[i].frac = 0.0; }   /* ThermKSPTempBaseAuxVarInit (base auxvar :56-60) */
     if (kind == TO_COND_BC) { c->dist_up[i] = du[i]; c->dist_dn[i] = dd[i]; c->area[i] = area[i]; }
   }
   return ++(*cnt);

@@ -78,6 +78,8 @@ def to_thermal_flux_oracle(case, flux_first, defects=False, ksp_rtol=0.0, land=N
     fid, did = (1, 2) if flux_first else (2, 1)
     o.set_condition_values(TO.COND_BC, did, tdir)
     o.set_condition_values(TO.COND_BC, fid, H)
+    o.set_condition_aux(did, "active", np.ones(tdir.size)); o.set_condition_aux(fid, "active", np.ones(H.size))
+    o.set_condition_aux(did, "frac", np.ones(tdir.size))
     o.set_condition_aux(fid, "frac", frac)
     o.set_condition_aux(fid, "dhsdT", dhsdT)
     o.set_condition_values(TO.COND_SS, 1, tp.heat_source)
@@ -122,6 +124,8 @@ def to_thermal_flux_gpu(case, flux_first, options=None, device_id=0, land=None, 
     fid, did = (1, 2) if flux_first else (2, 1)
     mpp.soe.SetRDataFromCLM(C.AUXVAR_BC, C.VAR_BC_SS_CONDITION, did, tdir)
     mpp.soe.SetRDataFromCLM(C.AUXVAR_BC, C.VAR_BC_SS_CONDITION, fid, H)
+    mpp.soe.SetRDataFromCLM(C.AUXVAR_BC, T.VAR_ACTIVE, did, np.ones(tdir.size)); mpp.soe.SetRDataFromCLM(C.AUXVAR_BC, T.VAR_ACTIVE, fid, np.ones(H.size))
+    mpp.soe.SetRDataFromCLM(C.AUXVAR_BC, T.VAR_FRAC, did, np.ones(tdir.size))
     mpp.soe.SetRDataFromCLM(C.AUXVAR_BC, T.VAR_FRAC, fid, frac)
     mpp.soe.SetRDataFromCLM(C.AUXVAR_BC, T.VAR_DHS_DT, fid, dhsdT)
     mpp.soe.SetRDataFromCLM(C.AUXVAR_SS, C.VAR_BC_SS_CONDITION, 1, tp.heat_source)

@@ -120,3 +120,39 @@ def test_boundary_auxvars_are_never_shallow_soil():
     want = np.zeros_like(b)
     np.add.at(want, cells, kav / (du + dd) * tdir * diri.area)
     assert np.abs((b - b0) - want).max() <= 1e-12 * np.abs(want).max()
+
+
+def test_boundary_auxvars_start_inactive_with_zero_fraction():
+    """ThermKSPTempBaseAuxVarInit (ThermalKSPTemperatureBaseAuxType.F90:56-60): is_active FALSE, frac 0 -- a Dirichlet face does
+    nothing until the caller activates it (the MMS driver does: thermal_mms_problem.F90:664-668), a heat-flux face enters with
+    its fraction"""
+    from oracle import thermal_oracle as TO
+    tp = P.thermal_mms(3, 4, 3, 5)
+    n = tp.mesh.ncells_local
+
+    def build(activate):
+        o = TO.ThermalOracle(n)
+        o.set_mesh(tp.mesh.vol, tp.mesh.dz)
+        o.set_connections(tp.mesh.internal_connections())
+        o.add_condition(TO.COND_BC, TO.COND_DIRICHLET, tp.bc)
+        o.set_soils(TO.SOIL, 1, 0.1, 0.0, tp.tkdry, 0.0)
+        o.set_options(cnfac=0.0)
+        o.set_soln_prev_clm(np.full(n, 290.0))
+        o.set_cell_data(TO.VAR_TUNING_FACTOR, 1.0)
+        o.set_condition_values(TO.COND_BC, 1, tp.bc_temperature)
+        if activate:
+            o.set_condition_aux(1, "active", np.ones(tp.bc.num_connections))
+            o.set_condition_aux(1, "frac", np.ones(tp.bc.num_connections))
+        o.pre_step_dt()
+        b = o.compute_rhs(1.0)
+        rp, cj, val = o.compute_operators()
+        return b, val
+
+    b0, v0 = build(False)
+    b1, v1 = build(True)
+    cells = np.unique(np.asarray(tp.bc.id_dn) - 1)
+    # without activation the right-hand side is the accumulation term alone, the operator has no boundary conductance
+    o = P.to_thermal_oracle(tp)
+    assert np.abs(b1 - b0)[cells].min() > 0 and np.abs(v1 - v0).max() > 0
+    others = np.setdiff1d(np.arange(n), cells)
+    assert np.array_equal(b0[others], b1[others])
