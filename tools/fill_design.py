@@ -83,11 +83,20 @@ def main():
              ("sbc3_ifc67", "smoothed Brooks–Corey bz3, IFC-67 density"),
              ("vg_ifc67", "van Genuchten m = ½, IFC-67 density"),
              ("mixed_tgdpb01", "three functions mixed per column (general-soil march)")]
-    lt = ["| constitutive law | round-2 kernels | round 3 | residual only, round 3 |", "|---|---|---|---|"]
+    pmc = {}
+    pf = os.path.join(ROOT, "profiles", "r03_kbench_laws_pmc.json")
+    if os.path.exists(pf):
+        pmc = json.load(open(pf))["laws"]
+    lt = ["| constitutive law | residual + Jacobian march, round-2 kernels (ms) | round 3 (ms) | HBM bytes moved per cell (PMC) | frac of 8 TB/s on moved bytes | residual only (ms) |",
+          "|---|---|---|---|---|---|"]
     for k, label in names:
         if k in laws and "final" in laws[k]:
-            lt.append("| %s | %.2f | **%.2f** | %.2f |" % (label, laws[k]["r02_code"]["assemble_both"], laws[k]["final"]["assemble_both"],
-                                                          laws[k]["final"]["residual"]))
+            e = pmc.get(k, {})
+            both = e.get("assemble_both", {})
+            lt.append("| %s | %.2f | **%.2f** | %s | %s | %.2f |" % (
+                label, laws[k]["r02_code"]["assemble_both"], both.get("ms", laws[k]["final"]["assemble_both"]),
+                ("%.1f" % both["moved_bytes_per_cell"]) if both else "—", ("%.2f" % both["frac_of_peak_moved"]) if both else "—",
+                e.get("residual", {}).get("ms", laws[k]["final"]["residual"])))
     laws_table = "\n".join(lt)
 
     rb = lambda j: j.get("host_readbacks_per_newton_iteration")
