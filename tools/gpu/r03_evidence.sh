@@ -8,7 +8,7 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 O=gpurun_out/r03_evidence; mkdir -p $O
 python3 -c "import __graft_entry__ as g; g.build()" > $O/build.log 2>&1 || { tail -20 $O/build.log; exit 1; }
-echo "== pytest -m gpu"; timeout -k 10 1100 python3 -m pytest tests -q -m gpu > $O/pytest_gpu.log 2>&1; echo "rc=$?"; tail -4 $O/pytest_gpu.log
+echo "== pytest -m gpu"; timeout -k 10 1500 python3 -m pytest tests -q -m gpu > $O/pytest_gpu.log 2>&1; echo "rc=$?"; tail -4 $O/pytest_gpu.log
 echo "== smoke"; timeout -k 10 300 python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; echo "rc=$?"; tail -2 $O/smoke.log
 echo "== kernel trace of the bench"; timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $O/prof_bench -o b --output-format csv -- python3 bench.py --no-cpu-baseline --no-verify > $O/prof_bench.log 2>&1; echo "rc=$?"; tail -2 $O/prof_bench.log | cut -c1-300
 python3 tools/trace_gaps.py $O/prof_bench > $O/gaps_full.json 2>/dev/null
@@ -27,5 +27,9 @@ echo "== config 2, spmv events only"; timeout -k 10 300 python3 bench.py --nx 25
 echo "== one eighth"; timeout -k 10 300 python3 bench.py --nx 1024 --ny 128 $B --profile spmv > $O/bench_1024x128x100.json 2>> $O/bench2.err; echo "rc=$?"; cut -c1-160 $O/bench_1024x128x100.json
 echo "== kernel trace of one eighth"; timeout -k 10 300 rocprofv3 --kernel-trace -d $O/tr_s8 -o t --output-format csv -- python3 bench.py --nx 1024 --ny 128 $B --profile spmv > $O/tr_s8.log 2>&1; echo "rc=$?"
 python3 tools/trace_gaps.py $O/tr_s8 > $O/gaps_1024x128x100.json; rm -rf $O/tr_s8
+echo "== kernel stats of the TH and thermal runs"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $O/prof_th -o t --output-format csv -- python3 tools/th_bench.py --nx 512 --ny 512 --nz 80 --ksp bcgs --pc bjacobi --cpu-cols 0 --no-events > $O/prof_th.log 2>&1; echo "rc=$?"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $O/prof_thermal -o t --output-format csv -- python3 tools/thermal_bench.py --n 256 --cpu-n 0 --no-events --opt ilu_graph=0 > $O/prof_thermal.log 2>&1; echo "rc=$?"
+rm -f $O/prof_th/*kernel_trace.csv $O/prof_th/*/*kernel_trace.csv $O/prof_thermal/*kernel_trace.csv $O/prof_thermal/*/*kernel_trace.csv
 echo "== th 512x512x80"; timeout -k 10 600 python3 tools/th_bench.py --nx 512 --ny 512 --nz 80 --ksp bcgs --pc bjacobi --cpu-cols 0 --out $O/th_512x512x80.json > $O/th.log 2>&1; echo "rc=$?"; tail -1 $O/th.log | cut -c1-300
 ls $O

@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--cpu-cols", type=int, default=256, help="columns of the CPU-oracle sample (0 = skip)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="extra mppgpu_set_option pairs")
+    ap.add_argument("--no-events", action="store_true", help="no HIP-event timing of the kernel classes (runs under rocprofv3)")
     a = ap.parse_args()
     # one process per GPU under torch.distributed.run (BASELINE config 5 is an 8-GPU run): the columns shard across the
     # ranks, RCCL all-reduces the Krylov / Newton scalars -- the same set-up as bench.py
@@ -76,7 +77,7 @@ def main():
     t_setup = time.perf_counter() - t0
     conv, reason = g.soe.StepDT(tp.dt, 1)          # warm-up (ILU analysis, allocations)
     c0 = g.soe.counters()
-    g.soe.SetOption("profile", 1)
+    g.soe.SetOption("profile", 0 if a.no_events else 1)
     g.soe.reset_stats()
     g.soe.synchronize()
     group.barrier()
