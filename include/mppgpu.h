@@ -141,7 +141,8 @@ int mppgpu_post_step_dt(mppgpu_handle h);
  * Jacobian / SpMV (RCCL grouped send/recv on the solver's stream, or device copies inside an in-process group) and applies
  * the preconditioner rank-locally (PETSc's parallel default: block-Jacobi with ILU(0) per rank).  Vectors passed through
  * the ABI keep their ghost entries (ignored on input, unspecified on output).  Call both before mppgpu_setup, and
- * mppgpu_comm_init(_local) before the first solve. */
+ * mppgpu_comm_init(_local) before the first solve.  The coupled thermal-hydrology system ([P; T] vectors) takes the same
+ * two calls: both fields of a ghost cell are refreshed. */
 int mppgpu_set_ghost_cells(mppgpu_handle h, int nghost);
 int mppgpu_set_halo(mppgpu_handle h, int nneigh, const int *peer_rank, const int *send_ptr, const int *send_cells,
                     const int *recv_count);

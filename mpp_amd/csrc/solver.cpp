@@ -75,6 +75,10 @@ struct Solver {
   // reductions and SpMV rows run over the first nred = nrow - nghost entries only, and the ghost tail of a vector is
   // (a) refreshed from the owners before it is read as a state or as an SpMV operand, (b) zeroed before a preconditioner
   // apply -- which makes the local ILU(0) exactly the block-Jacobi/ILU(0) PETSc applies in parallel.
+  // Coupled thermal-hydrology: the unknowns are field-blocked [P(1..n); T(1..n)], so the ghost rows are two ranges, not a tail.
+  // There nred = nrow and the ghost entries of EVERY vector are zero whenever a vector operation or a reduction can see them:
+  // halo_exchange() fills them right before an assembly pass or an SpMV reads them, ghost_zero() clears them right after
+  // (the operand's, and the identity rows' outputs); residual rows of ghost cells are zero by construction (th_kernels.hip).
   int nghost = 0, nred = 0;
   struct HaloPlan {
     std::vector<int> peer, send_ptr, send_cells, recv_ptr;   // per neighbour: send list (owned cells, 0-based), ghost range
@@ -315,7 +319,6 @@ struct Solver {
   void set_ghost_cells(int ng) {
     need_setup(false);
     if (ng < 0 || ng >= n) throw Error("mppgpu_set_ghost_cells: need 0 <= nghost < ncells");
-    if (th) throw Error("ghost cells are not available for the coupled thermal-hydrology system");
     for (int i = 0; i < n; ++i) if (active[i] == 2) active[i] = 1;
     nghost = ng;
     for (int i = n - ng; i < n; ++i) active[i] = 2;
@@ -626,7 +629,7 @@ struct Solver {
     if (n == 0) throw Error("mppgpu_set_mesh has not been called");
     HIP_CHECK(hipSetDevice(device));
     nrow = th ? 2 * n : n;
-    nred = nrow - nghost;
+    nred = th ? nrow : nrow - nghost;
     if (nghost > 0 && !halo.set) throw Error("ghost cells need a halo plan (mppgpu_set_halo)");
     { PhaseTimer pt("setup: column detection"); detect_columns(); }
     build_pattern();
@@ -1239,14 +1242,25 @@ struct Solver {
     ProfScope ps(prof, KC_VEC);
     double *x = const_cast<double *>(x_const);
     launch_gather((int)halo.send_cells.size(), halo.d_send_idx.p, x, halo.sendbuf.p, stream);
-    comm.exchange(halo.sendbuf.p, halo.peer, halo.send_ptr, x + nred, halo.recv_ptr, stream);
+    comm.exchange(halo.sendbuf.p, halo.peer, halo.send_ptr, x + (n - nghost), halo.recv_ptr, stream);
+    if (th) {   // ... and the temperatures
+      launch_gather((int)halo.send_cells.size(), halo.d_send_idx.p, x + n, halo.sendbuf.p, stream);
+      comm.exchange(halo.sendbuf.p, halo.peer, halo.send_ptr, x + n + (n - nghost), halo.recv_ptr, stream);
+    }
+  }
+  // the ghost entries of a vector back to zero (coupled TH: see the note at nghost; elsewhere the tail is simply never read)
+  void ghost_zero(const double *v_const) {
+    if (nghost <= 0 || !th) return;
+    double *v = const_cast<double *>(v_const);
+    launch_set(nghost, 0.0, v + (n - nghost), stream);
+    launch_set(nghost, 0.0, v + n + (n - nghost), stream);
   }
 
   void op_residual(const double *P, double *Fout) {
     if (dtime <= 0.0) throw Error("time step not set");
     halo_exchange(P);
     ProfScope ps(prof, KC_RESIDUAL);
-    if (th) { launch_th_assemble(0, th_args(P, Fout), stream); ++nfuncs; ++cum_funcs; return; }
+    if (th) { launch_th_assemble(0, th_args(P, Fout), stream); ghost_zero(P); ++nfuncs; ++cum_funcs; return; }
     asm_sums = false;
     if (Fout == fwd_rhs) fwd_rhs = nullptr;
     if (rows_complete()) { assemble_complete_rows(0, P, Fout); ++nfuncs; ++cum_funcs; return; }
@@ -1304,7 +1318,7 @@ struct Solver {
     if (dtime <= 0.0) throw Error("time step not set");
     halo_exchange(P);
     ProfScope ps(prof, KC_JACOBIAN);
-    if (th) { launch_th_assemble(2, th_args(P, Fout), stream); ++nfuncs; ++cum_funcs; pc_ready = false; return; }
+    if (th) { launch_th_assemble(2, th_args(P, Fout), stream); ghost_zero(P); ++nfuncs; ++cum_funcs; pc_ready = false; return; }
     asm_sums = false;
     fwd_rhs = nullptr;
     if (rows_complete()) { assemble_complete_rows(2, P, Fout); ++nfuncs; ++cum_funcs; return; }
@@ -1324,7 +1338,7 @@ struct Solver {
     halo_exchange(P);
     ProfScope ps(prof, KC_JACOBIAN);
     fwd_rhs = nullptr;
-    if (th) { launch_th_assemble(2, th_args(P, th_scratch.p), stream); pc_ready = false; return; }
+    if (th) { launch_th_assemble(2, th_args(P, th_scratch.p), stream); ghost_zero(P); pc_ready = false; return; }
     if (rows_complete()) { assemble_complete_rows(1, P, Fres ? Fres : F.p, Fres != nullptr); return; }
     if (use_cols()) launch_assemble_cols(1, cols_args(P, F.p), stream);
     else launch_assemble_general(1, gen_args(P, F.p), stream);
@@ -1335,7 +1349,7 @@ struct Solver {
   void op_pre_solve() {  // VSFMSOEPreSolve: accum_prev from soln_prev
     halo_exchange(soln_prev.p);
     ProfScope ps(prof, KC_RESIDUAL);
-    if (th) { launch_th_assemble(3, th_args(soln_prev.p, accum_prev.p), stream); return; }  // SOETHPreSolve :119-272
+    if (th) { launch_th_assemble(3, th_args(soln_prev.p, accum_prev.p), stream); ghost_zero(soln_prev.p); return; }  // SOETHPreSolve :119-272
     launch_accum(cells(soln_prev.p), n, 1.0 / dtime, accum_prev.p, stream);
   }
   void op_spmv(const double *x, double *y) {
@@ -1350,6 +1364,7 @@ struct Solver {
       if (!compact_index) throw Error("spmv_variant 20/21 need the compact index (rows of <= 8 entries whose columns lie within 2^15 of their 64-row tile)");
       launch_spmv_compact(opt.spmv_tpw > 0 ? opt.spmv_tpw : (v == 20 ? 2 : 4), nred, max_row_nnz, compact_split, d_tileptr.p, d_roff.p, d_dcol.p, d_val.p, x, y, stream);
     } else launch_spmv(v, nred, max_row_nnz, d_rowptr.p, d_col.p, d_val.p, x, y, stream);
+    ghost_zero(x); ghost_zero(y);   // coupled TH with ghost cells: the operand's copies and the identity rows' outputs
   }
   // the line search's first reductions in one pass over the matrix: out = {y.y, f.(A y), x.x (x != nullptr)}
   bool spmv_dots_fused() const {
@@ -1578,7 +1593,7 @@ struct Solver {
   }
   void op_pc_apply(const double *r, double *z) {
     ProfScope ps(prof, KC_PC_APPLY);
-    if (nghost > 0) launch_set(nghost, 0.0, const_cast<double *>(r) + nred, stream);   // block-Jacobi across ranks
+    if (nghost > 0 && !th) launch_set(nghost, 0.0, const_cast<double *>(r) + nred, stream);   // block-Jacobi across ranks (TH: zero already)
     if (opt.pc_type == 2 && th) launch_th_tri_solve(th_tri_args(), r, z, stream);
     else if (opt.pc_type == 2) launch_tri_solve(tri_args(), r, z, stream);
     else if (opt.pc_type == 3) launch_pointwise_mult(nred, jac_invd.p, r, z, stream);
@@ -2530,6 +2545,7 @@ struct Solver {
   // whole unknown vectors: one field of n cells, or [P; T] for the coupled system
   void put_state(const double *host_ext, double *dev_int) {
     for (int f = 0; f * n < nrow; ++f) put_cells(host_ext + (size_t)f * n, dev_int + (size_t)f * n);
+    ghost_zero(dev_int);
   }
   void get_state(const double *dev_int, double *host_ext) {
     for (int f = 0; f * n < nrow; ++f) get_cells(dev_int + (size_t)f * n, host_ext + (size_t)f * n, n);

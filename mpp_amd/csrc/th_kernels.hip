@@ -22,7 +22,10 @@ namespace {
 
 constexpr int kBlock = 256;
 
+// active[i]: 0 inactive cell, 1 active cell of this rank, 2 ghost cell (a copy of a cell another rank owns: a cell like any other
+// for its neighbours' fluxes, an identity row with a zero right-hand side itself)
 __device__ __forceinline__ bool th_active(const ThArgs &a, size_t i) { return a.active ? a.active[i] != 0 : true; }
+__device__ __forceinline__ bool th_ghost(const ThArgs &a, size_t i) { return a.active ? a.active[i] == 2 : false; }
 
 __device__ __forceinline__ Soil th_load_soil(const ThArgs &a, size_t i) {
   Soil s;
@@ -60,7 +63,7 @@ __global__ __launch_bounds__(kBlock) void k_th_aux(ThArgs a) {
   const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
   const size_t n = (size_t)a.n;
   if (i >= n) return;
-  const bool act = th_active(a, i);
+  const bool ghost = th_ghost(a, i), act = th_active(a, i) && !ghost;
   const Soil s = th_load_soil(a, i);
   const ThSoil ts{a.tc_wet[i], a.tc_dry[i], a.talpha[i]};
   const double P = a.x[i], T = a.x[n + i];
@@ -83,12 +86,13 @@ __global__ __launch_bounds__(kBlock) void k_th_aux(ThArgs a) {
     fe = (por * x.den_e * x.sat * x.ul + (1.0 - por) * dsoil * csoil * (T - 273.15)) * vol * a.dtInv;  // GE(heat):1174-1219
   }
   if (PRE) { a.F[i] = fm; a.F[n + i] = fe; return; }
-  a.F[i] = fm - a.accum_prev[i];
-  a.F[n + i] = fe - a.accum_prev[n + i];
+  a.F[i] = ghost ? 0.0 : fm - a.accum_prev[i];
+  a.F[n + i] = ghost ? 0.0 : fe - a.accum_prev[n + i];
   if (JAC) {
     const int r0 = a.crowptr[i], len = a.crowptr[i + 1] - r0;
     const int sPP = r0 + a.cdiag[i], sPT = sPP + len, sTP = 2 * a.nnzc + sPP, sTT = sTP + len;
     double dPP = 1.0, dPT = 1.0, dTP = 1.0, dTT = 1.0;  // inactive cell: 1 on all four diagonals (GE:1682; 2501; 2136; 1283)
+    if (ghost) dPT = dTP = 0.0;                         // ghost cell: identity rows
     if (act) {
       dPT = (por * x.ddenT_m * x.sat) * vol * a.dtInv;
       dTT = ((por * x.ddenT_e * x.sat * x.ul + por * x.den_e * x.sat * x.dul_dT) + (1.0 - por) * dsoil * csoil) * vol * a.dtInv;
@@ -122,6 +126,7 @@ __global__ __launch_bounds__(kBlock) void k_th_rows(ThArgs a) {
       if (s != sd) { a.val[bPP + s] = 0.0; a.val[bPT + s] = 0.0; a.val[bTP + s] = 0.0; a.val[bTT + s] = 0.0; }
   }
   double fm = a.F[i], fe = a.F[n + i];
+  if (th_ghost(a, i)) { a.F[i] = 0.0; a.F[n + i] = 0.0; return; }   // (the off-diagonal entries were zeroed above)
   if (th_active(a, i)) {
     const ThAux me = th_load_aux(a, i);
     double dPP = 0.0, dPT = 0.0, dTP = 0.0, dTT = 0.0;
@@ -301,7 +306,7 @@ __global__ __launch_bounds__(kBlock) void k_th_bc(ThBcArgs b) {
   if (j >= b.ncond_cells) return;
   const size_t cell = b.cc_cell[j];
   const size_t n = (size_t)a.n;
-  if (!th_active(a, cell)) return;
+  if (!th_active(a, cell) || th_ghost(a, cell)) return;
   const Soil s = th_load_soil(a, cell);
   const ThSoil ts{a.tc_wet[cell], a.tc_dry[cell], a.talpha[cell]};
   const ThAux in = th_auxvar_compute<true>(s.sf, a.density_type, a.ie_type, s, ts, a.x[cell], a.x[n + cell], true, pt);

@@ -604,3 +604,57 @@ def split_thermal_problem(tp: ThermalProblem, nranks):
                                          heat_source=np.asarray(tp.heat_source)[l], exact=np.asarray(tp.exact)[l], t_init=tp.t_init,
                                          cnfac=tp.cnfac, dt=tp.dt)))
     return out
+
+
+def th_vchannel(nx=6, ny=5, nz=7) -> THProblem:
+    """the coupled mass + heat equations on the 3-D v-channel mesh (7-point stencil, sloping surface, gravity along every
+    connection): vchannel's soil and hydrostatic start, a temperature that falls with depth, no boundary conditions (as the
+    v-channel problem), and a heat source in every cell that warms the channel's axis"""
+    vs = vchannel(nx, ny, nz)
+    m = vs.mesh
+    n = m.ncells_local
+    z = np.asarray(m.z); x = np.asarray(m.x)
+    temp_ic = 283.15 + 4.0 * (z - z.min()) / max(z.max() - z.min(), 1e-30)
+    ids = np.arange(1, n + 1)
+    zero = np.zeros(n)
+    allcells = M.ConnectionSet(np.zeros(n, dtype=np.int64), ids, zero, zero, np.ones(n), np.zeros((n, 3)))
+    heat = 40.0 * np.asarray(m.vol) * np.exp(-((x - x.mean()) / (0.25 * (x.max() - x.min() + 1e-30))) ** 2)
+    return THProblem(
+        name="th_vchannel", mesh=m, perm=vs.perm, por=vs.por, satfunc_type=vs.satfunc_type, alpha=vs.alpha, lam=vs.lam,
+        sat_res=vs.sat_res, density_type=C.DENSITY_TGDPB01, ie_type=2,
+        heat_cap=np.full(n, 837.0), tcond_wet=np.full(n, 1.3), tcond_dry=np.full(n, 0.25), talpha=np.full(n, 0.45),
+        den_soil=np.full(n, 2700.0), press_ic=vs.press_ic.copy(), temp_ic=temp_ic,
+        energy_sss=[(C.COND_HEAT_RATE, allcells, heat)], dt=vs.dt, nstep=2)
+
+
+def split_th_problem(tp: THProblem, nranks):
+    """per-rank coupled TH problems of a mesh split into contiguous id ranges (owned cells + ghost cells, halo plan);
+    returns [(part, local problem)]"""
+    from mpp_amd import parallel as PAR
+    out = []
+    n = tp.mesh.ncells_local
+    pick = lambda a, l: None if a is None else np.asarray(a)[l]
+    for part in PAR.partition_mesh(tp.mesh, nranks):
+        g2l = np.full(n, -1, dtype=np.int64)
+        g2l[part.l2g] = np.arange(part.l2g.size)
+        l = part.l2g
+
+        def bc4(entry):
+            t, cs, vals, other = entry[0], entry[1], entry[2], (entry[3] if len(entry) > 3 else None)
+            sub, v = _restrict_conn_set(cs, vals, part, g2l)
+            o = None if other is None else _restrict_conn_set(cs, other, part, g2l)[1]
+            return (t, sub, v, o)
+
+        lp = THProblem(name=tp.name, mesh=part.mesh, perm=np.asarray(tp.perm)[l], por=pick(tp.por, l), satfunc_type=pick(tp.satfunc_type, l),
+                       alpha=pick(tp.alpha, l), lam=pick(tp.lam, l), sat_res=pick(tp.sat_res, l), density_type=tp.density_type,
+                       ie_type=tp.ie_type, heat_cap=pick(tp.heat_cap, l), tcond_wet=pick(tp.tcond_wet, l), tcond_dry=pick(tp.tcond_dry, l),
+                       talpha=pick(tp.talpha, l), den_soil=pick(tp.den_soil, l),
+                       energy_perm=None if tp.energy_perm is None else tuple(np.asarray(a)[l] for a in tp.energy_perm),
+                       por_pressure_reference=pick(tp.por_pressure_reference, l), por_slope=pick(tp.por_slope, l),
+                       press_ic=pick(tp.press_ic, l), temp_ic=pick(tp.temp_ic, l), dt=tp.dt, nstep=tp.nstep)
+        lp.mass_bcs = [bc4(e) for e in tp.mass_bcs]
+        lp.energy_bcs = [bc4(e) for e in tp.energy_bcs]
+        lp.mass_sss = [(t,) + _restrict_conn_set(cs, v, part, g2l) for (t, cs, v) in tp.mass_sss]
+        lp.energy_sss = [(t,) + _restrict_conn_set(cs, v, part, g2l) for (t, cs, v) in tp.energy_sss]
+        out.append((part, lp))
+    return out
