@@ -32,4 +32,7 @@ timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $O/prof_th -o t --output-f
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $O/prof_thermal -o t --output-format csv -- python3 tools/thermal_bench.py --n 256 --cpu-n 0 --no-events --opt ilu_graph=0 > $O/prof_thermal.log 2>&1; echo "rc=$?"
 rm -f $O/prof_th/*kernel_trace.csv $O/prof_th/*/*kernel_trace.csv $O/prof_thermal/*kernel_trace.csv $O/prof_thermal/*/*kernel_trace.csv
 echo "== th 512x512x80"; timeout -k 10 600 python3 tools/th_bench.py --nx 512 --ny 512 --nz 80 --ksp bcgs --pc bjacobi --cpu-cols 0 --out $O/th_512x512x80.json > $O/th.log 2>&1; echo "rc=$?"; tail -1 $O/th.log | cut -c1-300
+echo "== the driver's launch form at N = 1, and the two-ranks-on-one-GPU path up to RCCL's refusal"
+timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --no-verify > $O/bench_torchrun_n1.json 2> $O/bench_torchrun_n1.err; echo "rc=$?"; cut -c1-200 $O/bench_torchrun_n1.json
+timeout -k 10 300 python3 bench.py --gpus 2 --share-gpus --nx 256 --ny 256 --nz 50 --steps 2 --warmup 1 --no-cpu-baseline --no-verify --init-timeout 120 > $O/bench_share_gpus.out 2> $O/bench_share_gpus.err; echo "rc=$? (non-zero expected: RCCL refuses two ranks on one device)"; tail -5 $O/bench_share_gpus.err | cut -c1-300
 ls $O
