@@ -262,6 +262,7 @@ int to_set_condition_values(to_problem *p, int kind, int id, int n, const double
 
 /* sysofeqns_thermal_auxvar_type of a boundary condition: var 1 frac, 2 dhsdT, 3 is_active (SystemOfEquationsThermalAuxType.F90:23-32) */
 int to_set_condition_aux(to_problem *p, int id, int var, int n, const double *v) {
+  if (id < 1 || id > p->nbc) return -1;
   tcond *c = &p->bc[id - 1];
   if (n > c->n) return -1;
   for (int i = 0; i < n; i++) {
