@@ -52,6 +52,54 @@ __device__ __forceinline__ double block_sum(double v, double *lds) {
   return t;
 }
 
+// ---- second stage of a reduction inside the producing kernel (Fold, kernels.hpp) ----
+__device__ void bcgs_scalar_step(int step, double *sc);
+struct Publish { double *host; unsigned long long *seq; unsigned long long value; };
+__device__ __forceinline__ void publish_scalars(const Publish &p, const double *sc);
+// a block's partial sum: an agent-scope store when another block is going to read it in this very launch
+__device__ __forceinline__ void store_partial(double *p, double v, bool folded) {
+  if (folded) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
+}
+// Called by every thread of every block, after `writer` (one thread per block) has stored the block's partial sums
+// partials[j * nb + block], j < f.nvec.  The sum of a vector's nb partial sums is formed exactly as k_finalize's single-pass block
+// forms it (256 strided accumulators, wave sums, the four wave sums in order); BLOCK = 64: one wave stands in for the four.
+template <int BLOCK>
+__device__ __forceinline__ void fold_tail(const Fold &f, const double *partials, int nb, bool writer) {
+  if (!f.counter) return;
+  __shared__ int fold_last;
+  __shared__ double fold_lds[kBlock / 64];
+  if (writer) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the partial sums are acknowledged
+    const unsigned ticket = __hip_atomic_fetch_add(f.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    fold_last = (ticket == (unsigned)nb - 1u);
+  }
+  __syncthreads();
+  if (!fold_last) return;
+  for (int j = 0; j < f.nvec; ++j) {
+    const double *pj = partials + (size_t)j * nb;
+    double t;
+    if (BLOCK == kBlock) {
+      double acc = 0.0;
+      for (int b = threadIdx.x; b < nb; b += kBlock) acc += __hip_atomic_load(pj + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      t = block_sum(acc, fold_lds);
+    } else {
+      t = 0.0;
+#pragma unroll
+      for (int w = 0; w < kBlock / 64; ++w) {
+        double acc = 0.0;
+        for (int b = w * 64 + (int)threadIdx.x; b < nb; b += kBlock) acc += __hip_atomic_load(pj + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t += wave_sum(acc);               // (lane 0 holds the sum)
+      }
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(f.sums + S_SUM0 + j, 0.0 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(f.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (f.step >= 0) bcgs_scalar_step(f.step, f.sc);
+  }
+  publish_scalars(Publish{f.pub_host, f.pub_seq, f.pub_value}, f.sc);
+}
+
 template <int SAT_T = -1, bool NT = false>
 __device__ __forceinline__ Soil load_soil(const CellArrays &ca, size_t i) {
   Soil s;
@@ -360,7 +408,7 @@ __global__ __launch_bounds__(kBlock) void k_assemble_cols(ColsArgs a) {
     }
     if (kend == nz && k1 == nz) finish_row(nz - 1, cbase + (size_t)(nz - 1) * tw, true);  // top row of the column
   }
-  if (FUSE && RES) {
+  if (FUSE && RES) {   // (not folded: the march is at its SGPR limit, the descriptor's kernel arguments would spill)
     double t = block_sum(accF, red);
     if (threadIdx.x == 0) a.partials[blockIdx.x] = t;
     t = block_sum(accP, red);
@@ -1795,7 +1843,7 @@ template <int ND, int G, int RF, int RB, int SPMV>
 __global__ __launch_bounds__(64) void k_tri_solve_lds(TriArgs a, const double *__restrict__ r, double *__restrict__ z,
                                                       const double *__restrict__ w, double *__restrict__ partials,
                                                       double *__restrict__ scratch64, double *__restrict__ xout,
-                                                      const double *__restrict__ vsub, const double *__restrict__ sc) {
+                                                      const double *__restrict__ vsub, const double *__restrict__ sc, Fold fold) {
   extern __shared__ __attribute__((aligned(16))) double dsl[];   // [nz][64]
   const int lane = threadIdx.x, tile = blockIdx.x;
   const int nz = a.nz;
@@ -2010,16 +2058,18 @@ __global__ __launch_bounds__(64) void k_tri_solve_lds(TriArgs a, const double *_
       }
   }
   if (!valid) acc0 = acc1 = accx = 0.0;
+  const bool folded = SPMV && fold.counter != nullptr;
   const double t0 = wave_sum(acc0);
-  if (lane == 0) partials[tile] = t0;
+  if (lane == 0) store_partial(partials + tile, t0, folded);
   if (ND == 2) {
     const double t1 = wave_sum(acc1);
-    if (lane == 0) partials[(size_t)gridDim.x + tile] = t1;
+    if (lane == 0) store_partial(partials + (size_t)gridDim.x + tile, t1, folded);
   }
   if (SPMV == 2) {
     const double t2 = wave_sum(accx);
-    if (lane == 0) partials[2 * (size_t)gridDim.x + tile] = t2;
+    if (lane == 0) store_partial(partials + 2 * (size_t)gridDim.x + tile, t2, folded);
   }
+  if (SPMV) fold_tail<64>(fold, partials, (int)gridDim.x, lane == 0);
 }
 
 // backward substitution only, from a forward-eliminated right-hand side d (left by the assembly pass): z = U^{-1} d with
@@ -2167,7 +2217,6 @@ __device__ void bcgs_scalar_step(int step, double *sc) {
 // device-to-host copy behind the kernel and waiting for the stream (Solver::fetch_scalars).  Called by every thread of the
 // block that holds the final values, after the thread that wrote them has passed a workgroup barrier (`sync_first`: this call
 // places it).  System-scope stores; the sequence word follows the data (release) once every lane's stores are acknowledged.
-struct Publish { double *host; unsigned long long *seq; unsigned long long value; };
 __device__ __forceinline__ void publish_scalars(const Publish &p, const double *sc) {
   if (!p.host) return;
   __syncthreads();
@@ -2419,33 +2468,35 @@ int launch_tri_solve_lds(const TriArgs &a, const double *r, double *z, const dou
                          int group, hipStream_t stream) {
   const dim3 grid(tri_solve_lds_blocks(a.ncols));
   const size_t shmem = (size_t)a.nz * 64 * sizeof(double);
-#define TRI_LDS(ND, G, RF, RB) hipLaunchKernelGGL((k_tri_solve_lds<ND, G, RF, RB, 0>), grid, dim3(64), shmem, stream, a, r, z, w, partials, scratch64, (double *)nullptr, (const double *)nullptr, (const double *)nullptr)
+#define TRI_LDS(ND, G, RF, RB) hipLaunchKernelGGL((k_tri_solve_lds<ND, G, RF, RB, 0>), grid, dim3(64), shmem, stream, a, r, z, w, partials, scratch64, (double *)nullptr, (const double *)nullptr, (const double *)nullptr, Fold())
   // `group` = levels in flight per stream: rings of 4-level groups
   if (w) { if (group <= 8) TRI_LDS(2, 4, 2, 2); else if (group <= 16) TRI_LDS(2, 4, 4, 3); else TRI_LDS(2, 4, 6, 4); }
   else { if (group <= 8) TRI_LDS(1, 4, 2, 2); else if (group <= 16) TRI_LDS(1, 4, 4, 4); else TRI_LDS(1, 4, 6, 5); }
 #undef TRI_LDS
   return (int)grid.x;
 }
-int launch_spmv_tri_lds(const TriArgs &a, const double *x, double *z, const double *w, double *partials, double *scratch64, hipStream_t stream) {
+int launch_spmv_tri_lds(const TriArgs &a, const double *x, double *z, const double *w, double *partials, double *scratch64, hipStream_t stream,
+                        const Fold &fold) {
   const dim3 grid(tri_solve_lds_blocks(a.ncols));
   const size_t shmem = (size_t)a.nz * 64 * sizeof(double);
   // forward: five streams (x, three matrix entries, l) in a ring of 3 groups of 4 levels = 60 loads in flight (the counter holds 63)
-  if (w) hipLaunchKernelGGL((k_tri_solve_lds<2, 4, 3, 4, 1>), grid, dim3(64), shmem, stream, a, x, z, w, partials, scratch64, (double *)nullptr, (const double *)nullptr, (const double *)nullptr);
-  else hipLaunchKernelGGL((k_tri_solve_lds<1, 4, 3, 5, 1>), grid, dim3(64), shmem, stream, a, x, z, w, partials, scratch64, (double *)nullptr, (const double *)nullptr, (const double *)nullptr);
+  if (w) hipLaunchKernelGGL((k_tri_solve_lds<2, 4, 3, 4, 1>), grid, dim3(64), shmem, stream, a, x, z, w, partials, scratch64, (double *)nullptr, (const double *)nullptr, (const double *)nullptr, fold);
+  else hipLaunchKernelGGL((k_tri_solve_lds<1, 4, 3, 5, 1>), grid, dim3(64), shmem, stream, a, x, z, w, partials, scratch64, (double *)nullptr, (const double *)nullptr, (const double *)nullptr, fold);
   return (int)grid.x;
 }
-int launch_back_spmv_tri_lds(const TriArgs &a, const double *d, double *x, double *z, double *partials, double *scratch64, hipStream_t stream) {
+int launch_back_spmv_tri_lds(const TriArgs &a, const double *d, double *x, double *z, double *partials, double *scratch64, hipStream_t stream,
+                             const Fold &fold) {
   const dim3 grid(tri_solve_lds_blocks(a.ncols));
   const size_t shmem = (size_t)a.nz * 64 * sizeof(double);
-  hipLaunchKernelGGL((k_tri_solve_lds<2, 4, 3, 4, 2>), grid, dim3(64), shmem, stream, a, d, z, (const double *)x, partials, scratch64, x, (const double *)nullptr, (const double *)nullptr);
+  hipLaunchKernelGGL((k_tri_solve_lds<2, 4, 3, 4, 2>), grid, dim3(64), shmem, stream, a, d, z, (const double *)x, partials, scratch64, x, (const double *)nullptr, (const double *)nullptr, fold);
   return (int)grid.x;
 }
 int launch_waxpy_spmv_tri_lds(const TriArgs &a, const double *r, const double *v, const double *sc, double *s, double *z, double *partials,
-                              double *scratch64, hipStream_t stream) {
+                              double *scratch64, hipStream_t stream, const Fold &fold) {
   const dim3 grid(tri_solve_lds_blocks(a.ncols));
   const size_t shmem = (size_t)a.nz * 64 * sizeof(double);
   // forward: six streams (r, v, three matrix entries, l) in a ring of 2 groups of 5 levels = 60 loads in flight
-  hipLaunchKernelGGL((k_tri_solve_lds<2, 5, 2, 4, 3>), grid, dim3(64), shmem, stream, a, r, z, (const double *)s, partials, scratch64, s, v, sc);
+  hipLaunchKernelGGL((k_tri_solve_lds<2, 5, 2, 4, 3>), grid, dim3(64), shmem, stream, a, r, z, (const double *)s, partials, scratch64, s, v, sc, fold);
   return (int)grid.x;
 }
 int launch_tri_back_dots(const TriArgs &a, const double *d, double *z, double *partials, hipStream_t stream) {

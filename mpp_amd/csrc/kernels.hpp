@@ -40,6 +40,18 @@ struct ConnArrays {   // internal connections, precomputed geometry
 };
 
 // ---- column-structured (vertical-only) fused assembly: one thread marches one soil column segment ----
+// Second stage of a reduction folded into the kernel that produces the partial sums (option fold_finalize; single-pass sizes only:
+// nb <= kFoldMaxPartials partial sums per vector): every block takes a ticket after its partial sums are acknowledged, the block
+// whose ticket comes last sums them in k_finalize's order (the same bits), runs the scalar step and publishes -- one launch less
+// per reduction.  counter == nullptr: not folded (launch_finalize follows).
+constexpr int kFoldMaxPartials = 4096;
+struct Fold {
+  unsigned *counter = nullptr;   // zero between launches
+  double *sums = nullptr;        // results at sums[S_SUM0 + j]
+  double *sc = nullptr;
+  int step = -1, nvec = 0;
+  double *pub_host = nullptr; unsigned long long *pub_seq = nullptr; unsigned long long pub_value = 0;
+};
 struct ColsArgs {
   CellArrays cell;
   ConnArrays conn;       // vertical connection (k,c)->(k+1,c) stored at the index of cell (k,c)
@@ -187,14 +199,16 @@ int launch_tri_solve_lds(const TriArgs &a, const double *r, double *z, const dou
 // z = M^{-1} (A x) in one pass on a vertical-only grid (A = the CSR values of the column tridiagonals at their computed slots, a.val;
 // row sums as the CSR SpMV kernels form them: same bits as launch_spmv_compact followed by launch_tri_solve_lds), with the same
 // partial sums; nz >= 2
-int launch_spmv_tri_lds(const TriArgs &a, const double *x, double *z, const double *w, double *partials, double *scratch64, hipStream_t stream);
+int launch_spmv_tri_lds(const TriArgs &a, const double *x, double *z, const double *w, double *partials, double *scratch64, hipStream_t stream,
+                        const Fold &fold = Fold());
 // the same with x = U^{-1} d produced first (d: a right-hand side the assembly pass forward-eliminated; x is written): the start of
 // a BiCGStab solve in one kernel.  Partial sums, one per 64-column tile: (z,x), (z,z), (x,x) in rows 0, 1, 2 of `partials`.
-int launch_back_spmv_tri_lds(const TriArgs &a, const double *d, double *x, double *z, double *partials, double *scratch64, hipStream_t stream);
+int launch_back_spmv_tri_lds(const TriArgs &a, const double *d, double *x, double *z, double *partials, double *scratch64, hipStream_t stream,
+                             const Fold &fold = Fold());
 // ... and with s = r - sc[S_ALPHA] v formed on the way (written to `s`): z = M^{-1} A s with (z,s), (z,z) -- BiCGStab's VecWAXPY, second
 // product and omega's two dot products in one kernel
 int launch_waxpy_spmv_tri_lds(const TriArgs &a, const double *r, const double *v, const double *sc, double *s, double *z, double *partials,
-                              double *scratch64, hipStream_t stream);
+                              double *scratch64, hipStream_t stream, const Fold &fold = Fold());
 // z = U^{-1} d for a right-hand side the assembly pass already forward-eliminated, with the partial sums of z.z
 int launch_tri_back_dots(const TriArgs &a, const double *d, double *z, double *partials, hipStream_t stream);
 void launch_jacobi_setup(int n, const int *diag_slot, const double *val, double *invd, hipStream_t stream);

@@ -203,6 +203,7 @@ struct Options {
                                // the CSR SpMV followed by the column solve -- A v is never written or read back
   bool fused_first = true;     // ... and the start of a BiCGStab solve -- rp = U^{-1}(L^{-1} F) and v = M^{-1} A rp -- as one kernel too
   bool thermal_reference_defects = false;   // reproduce GoveqnThermalKSPTemperatureSoilType.F90:906-908 (stale area) and :1215 (dhsdT**area)
+  bool fold_finalize = false;  // reductions of <= 4096 partial sums finished by the fused SpMV + column-solve kernels themselves (measured: see DESIGN 12)
   bool bc_inline = true;       // complete-row march: boundary fluxes of a column's end cells evaluated in the march's prologue
   bool fused_waxpy = true;     // ... and s = r - alpha v inside the kernel of the second product
   bool lazy_r = true;          // BiCGStab: r = s - omega t is not written by an iteration that is expected to be the last (only its norm)

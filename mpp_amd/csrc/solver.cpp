@@ -1631,8 +1631,9 @@ struct Solver {
     }
     {
       ProfScope ps(prof, KC_SPMV_PC);
-      const int nbk = launch_spmv_tri_lds(tri_args(), v, t, w, col_partials.p, tri_scratch.p, stream);
-      finalize(nbk, w ? 2 : 1, col_partials.p, slot, step);
+      const Fold fd = make_fold(tri_solve_lds_blocks(ncols), w ? 2 : 1, slot, step);
+      const int nbk = launch_spmv_tri_lds(tri_args(), v, t, w, col_partials.p, tri_scratch.p, stream, fd);
+      if (!fd.counter) finalize(nbk, w ? 2 : 1, col_partials.p, slot, step);
     }
     if (nreduce < 0) nreduce = w ? 2 : 1;
     if (comm.active() && nreduce > 0) comm.allreduce_sum(sc.p + S_SUM0, nreduce, stream);
@@ -1695,6 +1696,21 @@ struct Solver {
       pub_arm = false;
     }
     launch_finalize(nbk, nvec, partials_, sc.p + slot, f, stream);
+  }
+  // the same second stage finished by the kernel that produces the partial sums (kernels.hpp: Fold) -- option fold_finalize, for
+  // reductions of at most kFoldMaxPartials partial sums; what finalize() decides about the scalar step and the publication is
+  // decided here, before the producer is launched.  A Fold without a counter: the caller follows up with finalize().
+  Fold make_fold(int nbk, int nvec, int slot, int step) {
+    Fold f;
+    if (!opt.fold_finalize || nbk > kFoldMaxPartials || nbk < 1) return f;
+    f.counter = fin_counter.p; f.sums = sc.p + slot; f.sc = sc.p; f.step = comm.active() ? -1 : step; f.nvec = nvec;
+    pub_valid = false;
+    if (pub_arm && !comm.active() && opt.host_poll) {
+      f.pub_host = h_sc_dev; f.pub_seq = h_seq_dev; f.pub_value = ++pub_issued;
+      pub_valid = true;
+      pub_arm = false;
+    }
+    return f;
   }
   void bcgs_step(int step) {
     if (step < 0 || !comm.active()) return;
@@ -1875,8 +1891,9 @@ struct Solver {
     if (first_fused) {
       {
         ProfScope ps(prof, KC_SPMV_PC);
-        const int nbk = launch_back_spmv_tri_lds(tri_args(), fwd_elim.p, RP.p, V.p, col_partials.p, tri_scratch.p, stream);
-        finalize(nbk, 3, col_partials.p, 0, 62);
+        const Fold fd = make_fold(tri_solve_lds_blocks(ncols), 3, 0, 62);
+        const int nbk = launch_back_spmv_tri_lds(tri_args(), fwd_elim.p, RP.p, V.p, col_partials.p, tri_scratch.p, stream, fd);
+        if (!fd.counter) finalize(nbk, 3, col_partials.p, 0, 62);
       }
       if (comm.active()) {
         comm.allreduce_sum(sc.p + S_SUM0, 3, stream);
@@ -1924,8 +1941,9 @@ struct Solver {
       if (opt.fused_waxpy && fused_spmv_pc()) {   // s = r - alpha v, t = M^{-1} A s, (t,s), (t,t): one kernel
         {
           ProfScope ps(prof, KC_SPMV_PC);
-          const int nbk = launch_waxpy_spmv_tri_lds(tri_args(), Rcur, V.p, sc.p, S.p, T.p, col_partials.p, tri_scratch.p, stream);
-          finalize(nbk, 2, col_partials.p, 0, 3);
+          const Fold fd = make_fold(tri_solve_lds_blocks(ncols), 2, 0, 3);
+          const int nbk = launch_waxpy_spmv_tri_lds(tri_args(), Rcur, V.p, sc.p, S.p, T.p, col_partials.p, tri_scratch.p, stream, fd);
+          if (!fd.counter) finalize(nbk, 2, col_partials.p, 0, 3);
         }
         if (comm.active()) comm.allreduce_sum(sc.p + S_SUM0, 2, stream);
         bcgs_step(3);
@@ -3186,6 +3204,7 @@ struct Solver {
     else if (key == "lazy_r") opt.lazy_r = num() != 0;
     else if (key == "fused_waxpy") opt.fused_waxpy = num() != 0;
     else if (key == "bc_inline") opt.bc_inline = num() != 0;
+    else if (key == "fold_finalize") opt.fold_finalize = num() != 0;
     else if (key == "thermal_reference_defects") opt.thermal_reference_defects = num() != 0;
     else if (key == "spmv_tpw") opt.spmv_tpw = (int)num();
     else if (key == "soil_classes") { opt.soil_classes = num() != 0; soil_dirty = true; }

@@ -151,7 +151,9 @@ def test_spmv_fused_with_the_column_solve_changes_no_bit(ncols, nz, ksp):
     # all three fused (the default: the solve's first kernel also does the back substitution of the forward-eliminated residual),
     # the two products fused only, nothing fused
     # (also: s = r - alpha v formed inside the kernel of the second product, fused_waxpy)
-    gs = [P.to_gpu(prob, dict(base, fused_spmv_pc=f, fused_first=ff, fused_waxpy=fw)) for f, ff, fw in ((1, 1, 1), (1, 0, 0), (0, 0, 0), (1, 1, 0))]
+    # (and: the reductions of those kernels finished by the kernels themselves, fold_finalize -- the last block sums in k_finalize's order)
+    gs = [P.to_gpu(prob, dict(base, fused_spmv_pc=f, fused_first=ff, fused_waxpy=fw, fold_finalize=fo))
+          for f, ff, fw, fo in ((1, 1, 1, 0), (1, 0, 0, 0), (0, 0, 0, 0), (1, 1, 0, 0), (1, 1, 1, 1), (1, 0, 0, 1))]
     for g in gs:
         g.soe.SetDtime(prob.dt); g.soe.PreSolve()
         g.soe.ComputeJacobian(x)
@@ -163,7 +165,7 @@ def test_spmv_fused_with_the_column_solve_changes_no_bit(ncols, nz, ksp):
         for s in range(2):
             conv, reason = g.soe.StepDT(prob.dt, s + 1)
             assert conv
-    for g in (gs[0], gs[1], gs[3]):
+    for g in (gs[0], gs[1], gs[3], gs[4], gs[5]):
         assert g.soe.counters() == gs[2].soe.counters()
         assert np.array_equal(g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1),
                               gs[2].soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1))
