@@ -47,6 +47,7 @@ struct PhaseTimer {
   ~PhaseTimer();
 };
 
+bool poison_allocations();   // environment variable MPPGPU_POISON set and not "0"
 template <typename T>
 struct DevBuf {
   T *p = nullptr;
@@ -65,6 +66,9 @@ struct DevBuf {
     if (count == n && p) return;
     release();
     if (count) HIP_CHECK(hipMalloc(&p, count * sizeof(T)));
+    // MPPGPU_POISON=1 (debugging): fresh device memory is filled with 0xFF bytes -- NaN as a double, -1 as an index -- so that a
+    // kernel reading something nobody wrote shows in the results instead of depending on what the allocation happened to hold
+    if (count && poison_allocations()) { HIP_CHECK(hipMemset(p, 0xFF, count * sizeof(T))); HIP_CHECK(hipDeviceSynchronize()); }   // (before any stream's copy into it)
     n = count;
   }
   void upload(const T *src, size_t count, hipStream_t s) {
