@@ -71,9 +71,14 @@ struct DevBuf {
     if (count && poison_allocations()) { HIP_CHECK(hipMemset(p, 0xFF, count * sizeof(T))); HIP_CHECK(hipDeviceSynchronize()); }   // (before any stream's copy into it)
     n = count;
   }
+  // The source is pageable host memory, often a temporary of the caller.  Small copies are staged by the runtime before the call
+  // returns; for large ones (set-up arrays) the runtime may pin the pages and let the DMA run on, so the call waits for the stream:
+  // the caller is then free to release or reuse `src` whatever the runtime does.
   void upload(const T *src, size_t count, hipStream_t s) {
     alloc(count);
-    if (count) HIP_CHECK(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, s));
+    if (!count) return;
+    HIP_CHECK(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, s));
+    if (count * sizeof(T) > (size_t)(64 << 10)) HIP_CHECK(hipStreamSynchronize(s));
   }
   void upload(const std::vector<T> &v, hipStream_t s) { upload(v.data(), v.size(), s); }
   void zero(hipStream_t s) {
