@@ -194,3 +194,38 @@ def test_random_th_columns_problem_matches_the_oracle(seed):
                           density_type=int(rng.choice([C.DENSITY_CONSTANT, C.DENSITY_TGDPB01, C.DENSITY_IFC67])),
                           ie_type=int(rng.choice([1, 2])),
                           jtol=1e-8)   # d(energy)/dP on the diagonal is a difference of accumulation and flux terms 1e3 times its size
+
+
+# ---- soil heat diffusion (thermal KSP path) ----
+@pytest.mark.parametrize("seed", range(24))
+def test_random_thermal_problem_matches_the_oracle(seed):
+    """grid, land units (soil / wetland / land ice, bedrock layers), water / ice / snow contents, tuning factors, inactive cells,
+    Crank-Nicolson factor, Dirichlet + heat-flux faces in either order with and without a gap to the boundary value, the
+    reference-defects switch: right-hand side, operator and one step against the oracle"""
+    rng = np.random.default_rng(7000 + seed)
+    nx, ny, nz = (int(v) for v in rng.integers(2, 9, 3))
+    case = P.thermal_flux_case(nx, ny, nz, bc_dist_up=float(rng.choice([0.0, 0.4])))
+    tp = case[0]
+    n = tp.mesh.ncells_local
+    tp.cnfac = float(rng.choice([0.0, 0.5, 0.9]))   # (1.0 with cells that store no heat -- dry MMS soil, empty land ice -- is singular)
+    land = P.thermal_land_units(n, seed) if rng.random() < 0.7 else None
+    if rng.random() < 0.4:
+        tp.mesh.is_active = (rng.random(n) > 0.1).astype(np.int32)
+    t_prev = 273.15 + 8.0 * (rng.random(n) - 0.5)
+    flux_first, defects = bool(rng.random() < 0.5), bool(rng.random() < 0.3)
+    case = (tp, case[1], 273.15 + 8.0 * (rng.random(case[1].num_connections) - 0.5)) + case[3:]
+    dt = float(rng.choice([60.0, 1800.0]))
+    opts = {"thermal_reference_defects": int(defects), "ksp_type": "gmres", "pc_type": "ilu", "ksp_rtol": 1e-12}
+    g = P.to_thermal_flux_gpu(case, flux_first, opts, land=land, t_prev=t_prev)
+    o = P.to_thermal_flux_oracle(case, flux_first, defects=defects, ksp_rtol=1e-13, land=land, t_prev=t_prev)
+    b_o = o.compute_rhs(dt)
+    rp, cj, val = o.compute_operators()
+    b_g = g.soe.ComputeRHS(dt)
+    rp_g, cj_g, val_g = g.soe.ComputeOperators(dt)
+    assert np.array_equal(rp, rp_g) and np.array_equal(cj, cj_g)
+    assert np.abs(val_g - val).max() <= 1e-13 * np.abs(val).max()
+    assert np.abs(b_g - b_o).max() <= 1e-12 * np.abs(b_o).max()
+    conv, _ = g.soe.StepDT(dt, 1)
+    assert conv == o.step_dt(dt)
+    if conv:
+        assert np.abs(g.soe.GetSoln() - o.get_soln()).max() <= 1e-9 * np.abs(o.get_soln()).max()
