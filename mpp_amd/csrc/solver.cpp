@@ -2750,6 +2750,9 @@ struct Solver {
         throw Error("get_data: unknown var_type " + std::to_string(var_type));
       launch_cell_var(cells(soln.p), n, var_type, tmp_int.p, stream);
       get_cells(tmp_int.p, out, cnt);
+      // inactive cells: RichardsODEPressureSetDataInSOEAuxVar copies nothing for them (GE:1170-1195), so the SoE auxvar keeps the
+      // zeros of VSFMSOEAuxVarInit (SystemOfEquationsVSFMAuxType.F90:64-74)
+      if (any_inactive) for (int i = 0; i < cnt; ++i) if (active[i] == 0) out[i] = 0.0;
     } else if (th) {
       throw Error("get_data: the coupled system exports AUXVAR_INTERNAL only");
     } else if (auxvar_type == MPPGPU_AUXVAR_BC) {

@@ -1644,9 +1644,10 @@ int vo_get(vo_problem *p, int auxvar_type, int var_type, int cond_id, int n, dou
       const auxvar *a = &p->aux[i];
       switch (var_type) {
         case VO_VAR_PRESSURE: out[i] = a->pressure; break;
-        case VO_VAR_LIQ_SAT: out[i] = a->sat; break;
-        case VO_VAR_MASS: out[i] = a->por * a->den * FMWH2O * a->sat * p->vol[i]; break;
-        case VO_VAR_SOIL_MATRIX_POT: out[i] = (a->pressure - PRESSURE_REF) / (a->den * FMWH2O * GRAVITY_CONSTANT); break;
+        /* inactive cells: nothing is copied for them (GE:1172), the SoE auxvar keeps the zeros of VSFMSOEAuxVarInit */
+        case VO_VAR_LIQ_SAT: out[i] = p->active[i] ? a->sat : 0.0; break;
+        case VO_VAR_MASS: out[i] = p->active[i] ? a->por * a->den * FMWH2O * a->sat * p->vol[i] : 0.0; break;
+        case VO_VAR_SOIL_MATRIX_POT: out[i] = p->active[i] ? (a->pressure - PRESSURE_REF) / (a->den * FMWH2O * GRAVITY_CONSTANT) : 0.0; break;
         case VO_VAR_LATERAL_MASS_EXCHANGED: out[i] = p->lat_mass_exc[i]; break;
         case VO_VAR_FRAC_LIQ_SAT: out[i] = a->frac_liq_sat; break;
         default: FAIL("unknown var_type %d", var_type);

@@ -95,6 +95,24 @@ def draw(seed):
     return prob, x, opts, (oksp, opc, ls), what
 
 
+def _compare_exports(prob, o, g, what):
+    """what ELM reads back after a step (VSFMSOEGetDataForCLM :781-845): saturation, mass, matric potential, the fluxes through
+    every boundary condition and every internal connection"""
+    for var in (C.VAR_LIQ_SAT, C.VAR_MASS, C.VAR_SOIL_MATRIX_POT):
+        a_o, a_g = o.get(C.AUXVAR_INTERNAL, var), g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, var, -1)
+        assert np.abs(a_g - a_o).max() <= 1e-7 * max(np.abs(a_o).max(), 1e-300), (var, what)
+    scale = None
+    nconn = prob.mesh.internal_connections().num_connections
+    f_o, f_g = o.get(C.AUXVAR_CONN_INTERNAL, C.VAR_MASS_FLUX, -1, nconn), g.soe.GetDataForCLM(C.AUXVAR_CONN_INTERNAL, C.VAR_MASS_FLUX, -1)
+    if f_o.size:
+        scale = max(np.abs(f_o).max(), 1e-300)
+        assert np.abs(f_g - f_o).max() <= 1e-6 * scale + 1e-11, what      # (1e-11 kg/s: a state at rest has fluxes of rounding size)
+    for b in range(len(prob.bcs)):
+        q_o = o.get(C.AUXVAR_BC, C.VAR_MASS_FLUX, b + 1, prob.bcs[b][1].num_connections)
+        q_g = g.soe.GetDataForCLM(C.AUXVAR_BC, C.VAR_MASS_FLUX, b + 1)
+        assert np.abs(q_g - q_o).max() <= 1e-6 * max(np.abs(q_o).max(), scale or 0.0, 1e-300) + 1e-11, (b, what)
+
+
 @pytest.mark.parametrize("seed", range(96))
 def test_random_vsfm_problem_matches_the_oracle(seed):
     prob, x, opts, (oksp, opc, ls), what = draw(seed)
@@ -107,6 +125,7 @@ def test_random_vsfm_problem_matches_the_oracle(seed):
     assert (cg["newton"], cg["time_cuts"]) == (co["newton"], co["time_cuts"]), what
     p_o, p_g = o.get(C.AUXVAR_INTERNAL, C.VAR_PRESSURE), g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1)
     assert np.abs(p_g - p_o).max() <= 1e-8 * np.abs(p_o).max(), what
+    _compare_exports(prob, o, g, what)
 
 
 # ---- 3-D grids (the v-channel mesh family: 7-point stencil, sloping surface, gravity along every connection) ----
@@ -178,6 +197,7 @@ def test_random_3d_vsfm_problem_matches_the_oracle(seed):
     assert res_g == res_o, what
     assert (cg["newton"], cg["time_cuts"]) == (co["newton"], co["time_cuts"]), what
     assert np.abs(p_g - p_o).max() <= 1e-8 * np.abs(p_o).max(), what
+    _compare_exports(prob, o, g, what)
 
 
 # ---- coupled thermal-hydrology on soil columns ----
