@@ -84,6 +84,8 @@ def draw(seed):
     ksp, pc, oksp, opc = SOLVERS[int(rng.integers(0, len(SOLVERS)))]
     ls = str(rng.choice(["bt", "bt", "basic"]))
     opts = dict({"ksp_type": ksp, "pc_type": pc, "snes_linesearch_type": ls}, **route)
+    if seed % 2:
+        opts["track_mass_exchange"] = 1
     what["options"] = opts
     x = prob.press_ic + rng.uniform(0, 1.2e5, n)
     prob.dt = float(rng.choice([600.0, 3600.0]))
@@ -111,6 +113,13 @@ def _compare_exports(prob, o, g, what):
         q_o = o.get(C.AUXVAR_BC, C.VAR_MASS_FLUX, b + 1, prob.bcs[b][1].num_connections)
         q_g = g.soe.GetDataForCLM(C.AUXVAR_BC, C.VAR_MASS_FLUX, b + 1)
         assert np.abs(q_g - q_o).max() <= 1e-6 * max(np.abs(q_o).max(), scale or 0.0, 1e-300) + 1e-11, (b, what)
+    if what["options"].get("track_mass_exchange"):    # the accumulators over the sub-steps of the last StepDT (GE:1150-1166, 1338-1342)
+        for b in range(len(prob.bcs)):
+            m_o = o.get(C.AUXVAR_BC, C.VAR_BC_MASS_EXCHANGED, b + 1, prob.bcs[b][1].num_connections)
+            m_g = g.soe.GetDataForCLM(C.AUXVAR_BC, C.VAR_BC_MASS_EXCHANGED, b + 1)
+            assert np.abs(m_g - m_o).max() <= 1e-6 * max(np.abs(m_o).max(), 1e-300) + 1e-8, (b, what)
+        l_o, l_g = o.get(C.AUXVAR_INTERNAL, C.VAR_LATERAL_MASS_EXCHANGED), g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_LATERAL_MASS_EXCHANGED)
+        assert np.abs(l_g - l_o).max() <= 1e-6 * max(np.abs(l_o).max(), 1e-300) + 1e-8, what
 
 
 @pytest.mark.parametrize("seed", range(96))
@@ -173,6 +182,8 @@ def draw3d(seed):
         prob.press_ic = prob.press_ic - rng.uniform(0.0, 1.5e5)
     ksp, pc, oksp, opc = SOLVERS_3D[int(rng.integers(0, len(SOLVERS_3D)))]
     opts = dict({"ksp_type": ksp, "pc_type": pc}, **ROUTES_3D[int(rng.integers(0, len(ROUTES_3D)))])
+    if seed % 2:
+        opts["track_mass_exchange"] = 1
     what["options"] = opts
     x = prob.press_ic + rng.uniform(-1.0e5, 2.0e4, n)
     prob.dt = float(rng.choice([600.0, 8640.0]))
