@@ -128,8 +128,13 @@ def test_random_vsfm_problem_matches_the_oracle(seed):
     o, g, _csr, _v = _operator_parity(prob, x, opts)
     o.set_solver(oksp, opc)
     o.set_linesearch(ls)
+    elm = seed % 3 == 0      # ELM's calling sequence: PreStepDT / PostStepDT around every step (VSFMSOE :892-940)
     for s in range(2):
+        if elm:
+            o.pre_step_dt(); g.soe.PreStepDT()
         assert g.soe.StepDT(prob.dt, s + 1) == tuple(o.step_dt(prob.dt, s + 1)), what
+        if elm:
+            o.post_step_dt(); g.soe.PostStepDT()
     cg, co = g.soe.counters(), o.counters()
     assert (cg["newton"], cg["time_cuts"]) == (co["newton"], co["time_cuts"]), what
     p_o, p_g = o.get(C.AUXVAR_INTERNAL, C.VAR_PRESSURE), g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1)
