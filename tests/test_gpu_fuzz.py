@@ -265,3 +265,21 @@ def test_random_thermal_problem_matches_the_oracle(seed):
     assert conv == o.step_dt(dt)
     if conv:
         assert np.abs(g.soe.GetSoln() - o.get_soln()).max() <= 1e-9 * np.abs(o.get_soln()).max()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_3d_th_problem_matches_the_oracle(seed):
+    """the coupled system on the 3-D v-channel mesh (7-point stencil, gravity along every connection, heat sources): random extents,
+    anisotropic permeabilities, retention curves, porosity model, density / internal-energy formulations; general assembly,
+    GMRES + ILU(0); operators, ILU(0) application and two coupled steps against the oracle"""
+    from test_gpu_th import _th_columns_vs_oracle
+    rng = np.random.default_rng(11000 + seed)
+    nx, ny, nz = (int(v) for v in rng.integers(2, 7, 3))
+    tp = P.th_vchannel(nx, ny, nz)
+    n = tp.mesh.ncells_local
+    tp.perm = tp.perm * np.exp(0.3 * rng.standard_normal(n))[:, None] * rng.uniform(0.5, 2.0, 3)[None, :]
+    tp.density_type = int(rng.choice([C.DENSITY_CONSTANT, C.DENSITY_TGDPB01, C.DENSITY_IFC67]))
+    tp.ie_type = int(rng.choice([1, 2]))
+    tp.press_ic = tp.press_ic - rng.uniform(0.0, 1.2e5)          # water table somewhere inside the domain
+    _th_columns_vs_oracle(0, 0, "general", mixed=bool(rng.random() < 0.5), linear_porosity=bool(rng.random() < 0.4), seed=200 + seed,
+                          jtol=1e-8, tp=tp)

@@ -142,9 +142,10 @@ def test_th_columns_with_the_linear_porosity_model(assembly):
 
 
 def _th_columns_vs_oracle(ncols, nz, assembly, mixed, linear_porosity=False, seed=5, density_type=None, ie_type=2,
-                          solver=("gmres", "ilu"), extra=None, jtol=1e-10):
+                          solver=("gmres", "ilu"), extra=None, jtol=1e-10, tp=None):
     rng = np.random.default_rng(seed)
-    tp = P.th_columns(ncols=ncols, nz=nz, perm_mult=np.exp(0.3 * rng.standard_normal(ncols)), density_type=density_type, ie_type=ie_type)
+    if tp is None:
+        tp = P.th_columns(ncols=ncols, nz=nz, perm_mult=np.exp(0.3 * rng.standard_normal(ncols)), density_type=density_type, ie_type=ie_type)
     n = tp.mesh.ncells_local
     if linear_porosity:
         tp.por_pressure_reference = np.full(n, 101325.0) + rng.uniform(-2e4, 2e4, n)
