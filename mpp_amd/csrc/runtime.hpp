@@ -71,14 +71,13 @@ struct DevBuf {
     if (count && poison_allocations()) { HIP_CHECK(hipMemset(p, 0xFF, count * sizeof(T))); HIP_CHECK(hipDeviceSynchronize()); }   // (before any stream's copy into it)
     n = count;
   }
-  // The source is pageable host memory, often a temporary of the caller.  Small copies are staged by the runtime before the call
-  // returns; for large ones (set-up arrays) the runtime may pin the pages and let the DMA run on, so the call waits for the stream:
-  // the caller is then free to release or reuse `src` whatever the runtime does.
+  // The source is pageable host memory, often a temporary of the caller: hipMemcpyAsync then goes through the runtime's staging
+  // buffer and has consumed `src` when it returns ("if host or dst are not pinned, the memory copy will be performed
+  // synchronously", hip_runtime_api.h), while the staged data may still be on its way -- the caller may release `src` at once.
+  // (A stream synchronisation here was tried as a belt-and-braces measure: + 4 s of set-up at 134 M cells, nothing gained.)
   void upload(const T *src, size_t count, hipStream_t s) {
     alloc(count);
-    if (!count) return;
-    HIP_CHECK(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, s));
-    if (count * sizeof(T) > (size_t)(64 << 10)) HIP_CHECK(hipStreamSynchronize(s));
+    if (count) HIP_CHECK(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, s));
   }
   void upload(const std::vector<T> &v, hipStream_t s) { upload(v.data(), v.size(), s); }
   void zero(hipStream_t s) {
