@@ -633,6 +633,7 @@ struct Solver {
     if (nghost > 0 && !halo.set) throw Error("ghost cells need a halo plan (mppgpu_set_halo)");
     { PhaseTimer pt("setup: column detection"); detect_columns(); }
     build_pattern();
+    PhaseTimer *ptu = new PhaseTimer("setup: pattern + mesh uploads");
     d_ext2int.upload(ext2int, stream);
     d_int2ext.upload(int2ext, stream);
     d_rowptr.upload(h_rowptr, stream);
@@ -649,11 +650,13 @@ struct Solver {
       host_parallel_for(n, [&](long long i) { a[i] = (signed char)active[int2ext[i]]; });
       d_active.upload(a.data(), a.size(), stream);
     }
+    delete ptu;
     // connection end cells (internal numbering both ways)
     {
-      std::vector<int> up(nc_int, 0), dn(nc_int, 0);
+      PhaseTimer pt("setup: connection end cells");
+      Scratch<int> up(nc_int, 0), dn(nc_int, 0);
       host_parallel_for(nc, [&](long long c) { up[cext2int[c]] = ext2int[cup_e[c]]; dn[cext2int[c]] = ext2int[cdn_e[c]]; });
-      d_cup.upload(up, stream); d_cdn.upload(dn, stream);
+      d_cup.upload(up.p, (size_t)nc_int, stream); d_cdn.upload(dn.p, (size_t)nc_int, stream);
     }
     // per-row incident connection lists, in the caller's connection order (general kernels only)
     if (!vertical_only || opt.assembly == 0 || thermal || th) {
@@ -720,6 +723,7 @@ struct Solver {
       tri_l.alloc(n); tri_invb.alloc(n); tri_c.alloc(n); jac_invd.alloc(nrow);
     }
     // boundary conditions: entries grouped by cell, (condition, connection) order kept inside a cell
+    PhaseTimer *ptc = new PhaseTimer("setup: conditions, vectors, geometry");
     nb = 0;
     for (auto &c : bcs) { c.offset = nb; nb += c.n; }
     ns = 0;
@@ -797,9 +801,11 @@ struct Solver {
     HIP_CHECK(hipHostGetDevicePointer((void **)&h_seq_dev, h_seq, 0));
     d_Dq.alloc(nc_int); d_upw.alloc(nc_int); d_dgrav.alloc(nc_int); d_area.alloc(nc_int);
     if (thermal || th) {
-      std::vector<double> du(nc_int, 0.0), dd(nc_int, 0.0), ar(nc_int, 0.0);
-      for (int c = 0; c < nc; ++c) { du[cext2int[c]] = cdu[c]; dd[cext2int[c]] = cdd[c]; ar[cext2int[c]] = carea[c]; }
-      d_cdu.upload(du, stream); d_cdd.upload(dd, stream); d_carea.upload(ar, stream);
+      {   // (cext2int is one-to-one; holes of the lateral numbering carry zeros; first touch and fill by all host threads)
+        Scratch<double> du(nc_int, 0.0), dd(nc_int, 0.0), ar(nc_int, 0.0);
+        host_parallel_for(nc, [&](long long c) { du[cext2int[c]] = cdu[c]; dd[cext2int[c]] = cdd[c]; ar[cext2int[c]] = carea[c]; });
+        d_cdu.upload(du.p, (size_t)nc_int, stream); d_cdd.upload(dd.p, (size_t)nc_int, stream); d_carea.upload(ar.p, (size_t)nc_int, stream);
+      }
       std::vector<double> bdu(nb, 0.0), bdd(nb, 0.0), bar(nb, 0.0);
       for (auto &cd : bcs)
         for (int i = 0; i < cd.n; ++i) {
@@ -844,6 +850,7 @@ struct Solver {
         }
       }
     }
+    delete ptc;
     { PhaseTimer pt("setup: SpMV indices"); build_compact_index(); build_multibase_index(); }
     plan_complete_rows();
     if (nghost > 0) {
@@ -993,7 +1000,7 @@ struct Solver {
     }
     // internal connection geometry (RichardsMod.F90:236-272)
     {
-      std::vector<double> Dq(nc_int, 0.0), upw(nc_int, 0.0), dg(nc_int, 0.0), ar(nc_int, 0.0);
+      Scratch<double> Dq(nc_int, 0.0), upw(nc_int, 0.0), dg(nc_int, 0.0), ar(nc_int, 0.0);   // (first touch by all host threads)
       host_parallel_for(nc, [&](long long cidx) {   // (cext2int is one-to-one: no two connections write the same entry)
         const int u = cup_e[cidx], dn = cdn_e[cidx];
         const double pu[3] = {permx[u], permy[u], permz[u]}, pd[3] = {permx[dn], permy[dn], permz[dn]};
@@ -1001,11 +1008,12 @@ struct Solver {
         const int ic = cext2int[cidx];
         Dq[ic] = g.Dq; upw[ic] = g.upweight; dg[ic] = g.dist_gravity; ar[ic] = g.area;
       });
-      d_Dq.upload(Dq, stream); d_upw.upload(upw, stream); d_dgrav.upload(dg, stream); d_area.upload(ar, stream);
+      d_Dq.upload(Dq.p, (size_t)nc_int, stream); d_upw.upload(upw.p, (size_t)nc_int, stream);
+      d_dgrav.upload(dg.p, (size_t)nc_int, stream); d_area.upload(ar.p, (size_t)nc_int, stream);
       if (vertical_only && columns && !th) {   // ... and conductance x face area
         HIP_CHECK(hipStreamSynchronize(stream));   // (Dq is about to be reused)
         host_parallel_for(nc_int, [&](long long ic) { Dq[ic] = Dq[ic] * ar[ic]; });
-        d_DqA.upload(Dq, stream);
+        d_DqA.upload(Dq.p, (size_t)nc_int, stream);
         // extruded grids: the connection below level k has the same upwind weight and gravity distance in every column
         lev_geo = opt.level_geometry && nz >= 2;
         std::vector<double> lu(nz, 0.0), lg(nz, 0.0);
