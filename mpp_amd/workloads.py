@@ -587,6 +587,9 @@ def split_problem(prob: Problem, nranks):
                      press_ic=prob.press_ic[l], dt=prob.dt, nstep=prob.nstep)
         lp.bcs = [(t,) + _restrict_conn_set(cs, v, part, g2l) for (t, cs, v) in prob.bcs]
         lp.sss = [(t,) + _restrict_conn_set(cs, v, part, g2l) for (t, cs, v) in prob.sss]
+        if prob.por_slope is not None:
+            lp.por_pressure_reference = np.asarray(prob.por_pressure_reference)[l]
+            lp.por_slope = np.asarray(prob.por_slope)[l]
         out.append((part, lp))
     return out
 
