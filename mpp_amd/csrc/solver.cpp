@@ -633,7 +633,7 @@ struct Solver {
     if (nghost > 0 && !halo.set) throw Error("ghost cells need a halo plan (mppgpu_set_halo)");
     { PhaseTimer pt("setup: column detection"); detect_columns(); }
     build_pattern();
-    PhaseTimer *ptu = new PhaseTimer("setup: pattern + mesh uploads");
+    auto ptu = std::make_unique<PhaseTimer>("setup: pattern + mesh uploads");
     d_ext2int.upload(ext2int, stream);
     d_int2ext.upload(int2ext, stream);
     d_rowptr.upload(h_rowptr, stream);
@@ -650,7 +650,7 @@ struct Solver {
       host_parallel_for(n, [&](long long i) { a[i] = (signed char)active[int2ext[i]]; });
       d_active.upload(a.data(), a.size(), stream);
     }
-    delete ptu;
+    ptu.reset();
     // connection end cells (internal numbering both ways)
     {
       PhaseTimer pt("setup: connection end cells");
@@ -723,7 +723,7 @@ struct Solver {
       tri_l.alloc(n); tri_invb.alloc(n); tri_c.alloc(n); jac_invd.alloc(nrow);
     }
     // boundary conditions: entries grouped by cell, (condition, connection) order kept inside a cell
-    PhaseTimer *ptc = new PhaseTimer("setup: conditions, vectors, geometry");
+    auto ptc = std::make_unique<PhaseTimer>("setup: conditions, vectors, geometry");
     nb = 0;
     for (auto &c : bcs) { c.offset = nb; nb += c.n; }
     ns = 0;
@@ -850,7 +850,7 @@ struct Solver {
         }
       }
     }
-    delete ptc;
+    ptc.reset();
     { PhaseTimer pt("setup: SpMV indices"); build_compact_index(); build_multibase_index(); }
     plan_complete_rows();
     if (nghost > 0) {
