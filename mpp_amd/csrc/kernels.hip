@@ -1450,12 +1450,52 @@ __device__ __forceinline__ T *at_lane(T *row, unsigned lane_bytes) {
   return reinterpret_cast<T *>(reinterpret_cast<B *>(row) + lane_bytes);   // (pointer arithmetic: the address space stays known)
 }
 constexpr int kFaceBatch = 8;   // face elements per lane requested up front (B1 * 8 / 64 of a 3-D box: all of them up to B1 = 64)
-template <int DP>
-__global__ __launch_bounds__(64) void k_box_lower(BoxGrid g, const int *__restrict__ boxes, const double *__restrict__ Ld,
-                                                  const double *__restrict__ Ls, const double *__restrict__ Lw, double *y,
-                                                  double *scratch) {
-  extern __shared__ double face[];
-  const int b = boxes[blockIdx.x], lane = threadIdx.x, S = g.S, NP = S >> 1;
+// One launch per triangle instead of one per box level (round 4): the boxes are handed out by TICKET in level order to a fixed set of
+// resident waves (BoxQueue); a box waits for the flags of its three predecessor boxes (all of a lower level, hence lower tickets,
+// hence taken by waves that are already running: liveness does not depend on the order workgroups are dispatched in), solves, and
+// raises its own flag.  What another wave wrote during the launch -- the faces -- is read with agent-scope loads, and the solution is
+// stored with agent-scope stores (served at the device's coherence point: the L2 of one XCD is not coherent with the others' inside a
+// launch), acknowledged (vmcnt(0)) before the flag goes up.  A box's own operands (factor entries, right-hand side: written by
+// earlier launches) are requested BEFORE it waits.  A wait has a spin budget; exhausting it sets sc[S_ERR] and the host redoes the
+// application with one launch per level (Solver::op_pc_apply).
+struct BoxQueue {
+  const int *order = nullptr;      // boxes in the order they are handed out (ascending level; the upper solve: descending)
+  int nboxes = 0;
+  unsigned *flags = nullptr;       // flags[b] == epoch: box b is solved in this application
+  unsigned epoch = 0;
+  unsigned *ticket = nullptr;      // monotonic ticket counter (never reset) ...
+  unsigned ticket_base = 0;        // ... and what earlier launches took from it
+  unsigned max_spins = 0;
+  double *sc = nullptr;
+};
+template <bool COH>
+__device__ __forceinline__ double ld_shared_result(const double *p) {   // a value another wave of this launch may have written
+  return COH ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+template <bool COH>
+__device__ __forceinline__ void st_result_pair(dpair *dst, unsigned lane_bytes, dpair v) {
+  if (COH) {
+    double *d = reinterpret_cast<double *>(at_lane(dst, lane_bytes));
+    __hip_atomic_store(d, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(d + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else *at_lane(dst, lane_bytes) = v;
+}
+// lanes 0, 1, 2 wait for the flags of boxes p0, p1, p2 (-1: nobody)
+__device__ __forceinline__ void box_wait(const BoxQueue &q, int lane, int p0, int p1, int p2) {
+  const int pred = lane == 0 ? p0 : (lane == 1 ? p1 : (lane == 2 ? p2 : -1));
+  if (pred >= 0) {
+    unsigned spins = 0;
+    while (__hip_atomic_load(q.flags + pred, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != q.epoch) {
+      __builtin_amdgcn_s_sleep(4);
+      if (++spins > q.max_spins) { q.sc[S_ERR] = 1.0; break; }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+template <int DP, bool COH>
+__device__ __forceinline__ void box_lower_body(const BoxGrid &g, const int b, const double *__restrict__ Ld, const double *__restrict__ Ls,
+                                               const double *__restrict__ Lw, double *y, double *scratch, double *face, const BoxQueue &q) {
+  const int lane = threadIdx.x, S = g.S, NP = S >> 1;
   const int jp = lane & (g.B2 - 1), kp = lane >> g.lg2;
   const int I = b % g.NB1, J = (b / g.NB1) % g.NB2, K = b / (g.NB1 * g.NB2);
   const bool useS = g.NB2 > 1, useD = g.NB3 > 1;
@@ -1470,15 +1510,19 @@ __global__ __launch_bounds__(64) void k_box_lower(BoxGrid g, const int *__restri
   auto dstS = [&](int e) { const int i = e / g.B3, k = e - i * g.B3; return fS + (i + g.B3 - 1) * g.B3 + k; };
   auto dstD = [&](int e) { const int i = e >> g.lg2, j = e & (g.B2 - 1); return fD + (i + g.B2 - 1) * g.B2 + j; };
   double vS[kFaceBatch], vD[kFaceBatch];
-#pragma unroll
-  for (int q = 0; q < kFaceBatch; ++q) {
-    const int e = q * 64 + lane;
-    vS[q] = *(e < nfS ? srcS(e) : y + (size_t)b * S * 64);      // (nobody behind, or past the face: any valid address)
-    vD[q] = *(e < nfD ? srcD(e) : y + (size_t)b * S * 64);
-  }
   const int hW = jp + kp;                                       // the step at which the lane is on the west face
-  double yW = *(I > 0 ? y + box_slot(g, b - 1, g.B1 - 1 + hW, lane) : y + (size_t)b * S * 64);
-  if (I == 0) yW = 0.0;
+  double yW = 0.0;
+  auto request_faces = [&]() {
+#pragma unroll
+    for (int qq = 0; qq < kFaceBatch; ++qq) {
+      const int e = qq * 64 + lane;
+      vS[qq] = ld_shared_result<COH>(e < nfS ? srcS(e) : y + (size_t)b * S * 64);      // (nobody behind, or past the face: any valid address)
+      vD[qq] = ld_shared_result<COH>(e < nfD ? srcD(e) : y + (size_t)b * S * 64);
+    }
+    yW = ld_shared_result<COH>(I > 0 ? y + box_slot(g, b - 1, g.B1 - 1 + hW, lane) : y + (size_t)b * S * 64);
+    if (I == 0) yW = 0.0;
+  };
+  if (!COH) request_faces();                                    // one launch per level: behind nobody, first in the queue
   const size_t row0 = (size_t)b * S * 64;                       // the box's first slot (uniform); row pair p is 64 dpairs further on
   const dpair *Ld2 = reinterpret_cast<const dpair *>(Ld + row0), *Ls2 = reinterpret_cast<const dpair *>(Ls + row0),
               *Lw2 = reinterpret_cast<const dpair *>(Lw + row0);
@@ -1492,16 +1536,20 @@ __global__ __launch_bounds__(64) void k_box_lower(BoxGrid g, const int *__restri
   };
 #pragma unroll
   for (int u = 0; u < DP; ++u) { fetch(u, u); __builtin_amdgcn_sched_barrier(0); }
+  if (COH) {   // the box's own operands are on their way: now wait for the three boxes behind it, then ask for their faces
+    box_wait(q, lane, I > 0 ? b - 1 : -1, J > 0 ? b - g.NB1 : -1, K > 0 ? b - g.NB1 * g.NB2 : -1);
+    request_faces();
+  }
   __syncthreads();                                              // (one wave: the zeros are in place before the face values)
 #pragma unroll
-  for (int q = 0; q < kFaceBatch; ++q) {
-    const int e = q * 64 + lane;
-    if (e < nfS) *dstS(e) = vS[q];
-    if (e < nfD) *dstD(e) = vD[q];
+  for (int qq = 0; qq < kFaceBatch; ++qq) {
+    const int e = qq * 64 + lane;
+    if (e < nfS) *dstS(e) = vS[qq];
+    if (e < nfD) *dstD(e) = vD[qq];
   }
   for (int e = kFaceBatch * 64 + lane; e < max(nfS, nfD); e += 64) {
-    if (e < nfS) *dstS(e) = *srcS(e);
-    if (e < nfD) *dstD(e) = *srcD(e);
+    if (e < nfS) *dstS(e) = ld_shared_result<COH>(srcS(e));
+    if (e < nfD) *dstD(e) = ld_shared_result<COH>(srcD(e));
   }
   __syncthreads();
   const double *pS = useS ? fS + (g.B3 - 1 - kp) * g.B3 + kp : face, *pD = useD ? fD + (g.B2 - 1 - jp) * g.B2 + jp : face;   // (face[0] = 0)
@@ -1529,18 +1577,47 @@ __global__ __launch_bounds__(64) void k_box_lower(BoxGrid g, const int *__restri
       out.x = step(2 * p, rr[u].x, ld[u].x, ls[u].x, lw[u].x);
       out.y = step(2 * p + 1, rr[u].y, ld[u].y, ls[u].y, lw[u].y);
       dpair *dst = p < NP ? y2 + (size_t)p * 64 : sink;         // past the box: a scratch row (keeps the loop body straight)
-      *at_lane(dst, lane16) = out;
+      st_result_pair<COH>(dst, lane16, out);
       fetch(u, p + DP);
       __builtin_amdgcn_sched_barrier(0);   // keep the issue order pair by pair: the wait of a pair then counts the younger loads
     }
   }
 }
 template <int DP>
-__global__ __launch_bounds__(64) void k_box_upper(BoxGrid g, const int *__restrict__ boxes, const double *__restrict__ Ue,
-                                                  const double *__restrict__ Un, const double *__restrict__ Uu,
-                                                  const double *__restrict__ Di, double *x, double *scratch) {
+__global__ __launch_bounds__(64) void k_box_lower(BoxGrid g, const int *__restrict__ boxes, const double *__restrict__ Ld,
+                                                  const double *__restrict__ Ls, const double *__restrict__ Lw, double *y,
+                                                  double *scratch) {
   extern __shared__ double face[];
-  const int b = boxes[blockIdx.x], lane = threadIdx.x, S = g.S, NP = S >> 1;
+  box_lower_body<DP, false>(g, boxes[blockIdx.x], Ld, Ls, Lw, y, scratch, face, BoxQueue());
+}
+// the ticket of the wave's next box (uniform), or -1 when the queue is empty
+__device__ __forceinline__ int box_next(const BoxQueue &q) {
+  unsigned t = 0;
+  if (threadIdx.x == 0) t = __hip_atomic_fetch_add(q.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - q.ticket_base;
+  t = __builtin_amdgcn_readfirstlane(t);
+  return t < (unsigned)q.nboxes ? (int)t : -1;
+}
+__device__ __forceinline__ void box_done(const BoxQueue &q, int b) {
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): every store of this wave has been acknowledged at the coherence point
+  __builtin_amdgcn_wave_barrier();
+  if (threadIdx.x == 0) __hip_atomic_store(q.flags + b, q.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();                      // (the faces in LDS are free again)
+}
+template <int DP>
+__global__ __launch_bounds__(64) void k_box_lower_queue(BoxGrid g, BoxQueue q, const double *__restrict__ Ld, const double *__restrict__ Ls,
+                                                        const double *__restrict__ Lw, double *y, double *scratch) {
+  extern __shared__ double face[];
+  for (int t = box_next(q); t >= 0; t = box_next(q)) {
+    const int b = q.order[t];
+    box_lower_body<DP, true>(g, b, Ld, Ls, Lw, y, scratch, face, q);
+    box_done(q, b);
+  }
+}
+template <int DP, bool COH>
+__device__ __forceinline__ void box_upper_body(const BoxGrid &g, const int b, const double *__restrict__ Ue, const double *__restrict__ Un,
+                                               const double *__restrict__ Uu, const double *__restrict__ Di, double *x, double *scratch,
+                                               double *face, const BoxQueue &q) {
+  const int lane = threadIdx.x, S = g.S, NP = S >> 1;
   const int jp = lane & (g.B2 - 1), kp = lane >> g.lg2;
   const int I = b % g.NB1, J = (b / g.NB1) % g.NB2, K = b / (g.NB1 * g.NB2);
   const bool useN = g.NB2 > 1, useU = g.NB3 > 1;
@@ -1556,15 +1633,19 @@ __global__ __launch_bounds__(64) void k_box_upper(BoxGrid g, const int *__restri
   auto dstN = [&](int e) { const int i = e / g.B3, k = e - i * g.B3; return fN + (i + M) * g.B3 + k; };
   auto dstU = [&](int e) { const int i = e >> g.lg2, j = e & (g.B2 - 1); return fU + (i + M) * g.B2 + j; };
   double vN[kFaceBatch], vU[kFaceBatch];
-#pragma unroll
-  for (int q = 0; q < kFaceBatch; ++q) {
-    const int e = q * 64 + lane;
-    vN[q] = *(e < nfN ? srcN(e) : x + (size_t)b * S * 64);
-    vU[q] = *(e < nfU ? srcU(e) : x + (size_t)b * S * 64);
-  }
   const int hE = g.B1 - 1 + jp + kp;                            // the step at which the lane is on the east face
-  double xE = *(I < g.NB1 - 1 ? x + box_slot(g, b + 1, jp + kp, lane) : x + (size_t)b * S * 64);
-  if (I == g.NB1 - 1) xE = 0.0;
+  double xE = 0.0;
+  auto request_faces = [&]() {
+#pragma unroll
+    for (int qq = 0; qq < kFaceBatch; ++qq) {
+      const int e = qq * 64 + lane;
+      vN[qq] = ld_shared_result<COH>(e < nfN ? srcN(e) : x + (size_t)b * S * 64);
+      vU[qq] = ld_shared_result<COH>(e < nfU ? srcU(e) : x + (size_t)b * S * 64);
+    }
+    xE = ld_shared_result<COH>(I < g.NB1 - 1 ? x + box_slot(g, b + 1, jp + kp, lane) : x + (size_t)b * S * 64);
+    if (I == g.NB1 - 1) xE = 0.0;
+  };
+  if (!COH) request_faces();
   const size_t row0 = (size_t)b * S * 64;
   const dpair *Ue2 = reinterpret_cast<const dpair *>(Ue + row0), *Un2 = reinterpret_cast<const dpair *>(Un + row0),
               *Uu2 = reinterpret_cast<const dpair *>(Uu + row0), *Di2 = reinterpret_cast<const dpair *>(Di + row0);
@@ -1579,16 +1660,20 @@ __global__ __launch_bounds__(64) void k_box_upper(BoxGrid g, const int *__restri
   };
 #pragma unroll
   for (int u = 0; u < DP; ++u) { fetch(u, NP - 1 - u); __builtin_amdgcn_sched_barrier(0); }
+  if (COH) {   // the boxes ahead: east, north, up
+    box_wait(q, lane, I < g.NB1 - 1 ? b + 1 : -1, J < g.NB2 - 1 ? b + g.NB1 : -1, K < g.NB3 - 1 ? b + g.NB1 * g.NB2 : -1);
+    request_faces();
+  }
   __syncthreads();
 #pragma unroll
-  for (int q = 0; q < kFaceBatch; ++q) {
-    const int e = q * 64 + lane;
-    if (e < nfN) *dstN(e) = vN[q];
-    if (e < nfU) *dstU(e) = vU[q];
+  for (int qq = 0; qq < kFaceBatch; ++qq) {
+    const int e = qq * 64 + lane;
+    if (e < nfN) *dstN(e) = vN[qq];
+    if (e < nfU) *dstU(e) = vU[qq];
   }
   for (int e = kFaceBatch * 64 + lane; e < max(nfN, nfU); e += 64) {
-    if (e < nfN) *dstN(e) = *srcN(e);
-    if (e < nfU) *dstU(e) = *srcU(e);
+    if (e < nfN) *dstN(e) = ld_shared_result<COH>(srcN(e));
+    if (e < nfU) *dstU(e) = ld_shared_result<COH>(srcU(e));
   }
   __syncthreads();
   // first step h = S - 1: i' = S - 1 - (B2 - 1) - kp on the north face, S - 1 - jp - (B3 - 1) on the upper one
@@ -1619,10 +1704,27 @@ __global__ __launch_bounds__(64) void k_box_upper(BoxGrid g, const int *__restri
       out.y = step(2 * p + 1, rr[u].y, ue[u].y, un[u].y, uu[u].y, di[u].y);
       out.x = step(2 * p, rr[u].x, ue[u].x, un[u].x, uu[u].x, di[u].x);
       dpair *dst = p >= 0 ? x2 + (size_t)p * 64 : sink;
-      *at_lane(dst, lane16) = out;
+      st_result_pair<COH>(dst, lane16, out);
       fetch(u, p - DP);
       __builtin_amdgcn_sched_barrier(0);
     }
+  }
+}
+template <int DP>
+__global__ __launch_bounds__(64) void k_box_upper(BoxGrid g, const int *__restrict__ boxes, const double *__restrict__ Ue,
+                                                  const double *__restrict__ Un, const double *__restrict__ Uu,
+                                                  const double *__restrict__ Di, double *x, double *scratch) {
+  extern __shared__ double face[];
+  box_upper_body<DP, false>(g, boxes[blockIdx.x], Ue, Un, Uu, Di, x, scratch, face, BoxQueue());
+}
+template <int DP>
+__global__ __launch_bounds__(64) void k_box_upper_queue(BoxGrid g, BoxQueue q, const double *__restrict__ Ue, const double *__restrict__ Un,
+                                                        const double *__restrict__ Uu, const double *__restrict__ Di, double *x, double *scratch) {
+  extern __shared__ double face[];
+  for (int t = box_next(q); t >= 0; t = box_next(q)) {
+    const int b = q.order[t];
+    box_upper_body<DP, true>(g, b, Ue, Un, Uu, Di, x, scratch, face, q);
+    box_done(q, b);
   }
 }
 
@@ -2600,6 +2702,18 @@ void launch_box_upper(const BoxGrid &g, const int *boxes, int nboxes, const doub
                       hipStream_t stream) {
   const size_t lds = (size_t)box_face_doubles(g) * sizeof(double);
   if (nboxes > 0) hipLaunchKernelGGL((k_box_upper<kBoxRingUpper>), dim3(nboxes), dim3(64), lds, stream, g, boxes, U[0], U[1], U[2], Di, x, scratch);
+}
+void launch_box_solve_queue(const BoxGrid &g, const BoxQueueArgs &lo, const BoxQueueArgs &up, const double *const L[3], const double *const U[3],
+                            const double *Di, double *v, double *scratch, hipStream_t stream) {
+  const size_t lds = (size_t)box_face_doubles(g) * sizeof(double);
+  if (lo.nboxes <= 0) return;
+  BoxQueue ql, qu;
+  ql.order = lo.order; ql.nboxes = lo.nboxes; ql.flags = lo.flags; ql.epoch = lo.epoch; ql.ticket = lo.ticket; ql.ticket_base = lo.ticket_base;
+  ql.max_spins = lo.max_spins; ql.sc = lo.sc;
+  qu.order = up.order; qu.nboxes = up.nboxes; qu.flags = up.flags; qu.epoch = up.epoch; qu.ticket = up.ticket; qu.ticket_base = up.ticket_base;
+  qu.max_spins = up.max_spins; qu.sc = up.sc;
+  hipLaunchKernelGGL((k_box_lower_queue<kBoxRing>), dim3(lo.nworkers), dim3(64), lds, stream, g, ql, L[0], L[1], L[2], v, scratch);
+  hipLaunchKernelGGL((k_box_upper_queue<kBoxRingUpper>), dim3(up.nworkers), dim3(64), lds, stream, g, qu, U[0], U[1], U[2], Di, v, scratch);
 }
 void launch_gather(int n, const int *idx, const double *in, double *out, hipStream_t stream) {
   if (n > 0) LAUNCH(k_gather, dim3(nblk(n)), n, idx, in, out);

@@ -298,6 +298,18 @@ void launch_box_gather_in(const BoxGrid &g, const int *ext2int, const double *r,
 void launch_box_lower(const BoxGrid &g, const int *boxes, int nboxes, const double *const L[3], double *y, double *scratch, hipStream_t stream);
 void launch_box_upper(const BoxGrid &g, const int *boxes, int nboxes, const double *const U[3], const double *Di, double *x, double *scratch,
                       hipStream_t stream);
+// Both solves with ONE launch per triangle: boxes handed out by ticket, in level order, to `nworkers` resident waves; a box waits for the
+// flags of its three predecessor boxes and raises its own (see k_box_lower_queue).  flags: one word per box and triangle, epoch: this
+// application's stamp (never 0); ticket: one monotonic counter per triangle, ticket_base = what earlier launches took from it (every
+// launch takes nboxes + nworkers tickets).  A wait that exhausts max_spins polls sets sc[S_ERR] = 1: the caller redoes the application
+// with one launch per level.
+struct BoxQueueArgs {
+  const int *order; int nboxes, nworkers;
+  unsigned *flags; unsigned epoch; unsigned *ticket; unsigned ticket_base, max_spins;
+  double *sc;
+};
+void launch_box_solve_queue(const BoxGrid &g, const BoxQueueArgs &lower, const BoxQueueArgs &upper, const double *const L[3],
+                            const double *const U[3], const double *Di, double *v, double *scratch, hipStream_t stream);
 
 // ---- soil heat diffusion (thermal KSP path) ----
 struct ThermalArgs {

@@ -323,6 +323,10 @@ bool poison_allocations() {
   static const bool on = [] { const char *e = std::getenv("MPPGPU_POISON"); return e && *e && std::strcmp(e, "0") != 0; }();
   return on;
 }
+hipStream_t &poison_stream() {
+  static thread_local hipStream_t s = nullptr;
+  return s;
+}
 PhaseTimer::PhaseTimer(const char *n) : name(n), t0(std::getenv("MPPGPU_TIMING") ? wall_seconds() : -1.0) {}
 PhaseTimer::~PhaseTimer() {
   if (t0 >= 0.0) std::fprintf(stderr, "[mppgpu] %-28s %8.3f s (%d host threads)\n", name, wall_seconds() - t0, host_threads());

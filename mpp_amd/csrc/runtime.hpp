@@ -48,6 +48,10 @@ struct PhaseTimer {
 };
 
 bool poison_allocations();   // environment variable MPPGPU_POISON set and not "0"
+// the stream of the handle the calling thread is working for (set at every entry point of the C ABI): MPPGPU_POISON fills fresh
+// allocations on THAT stream and waits for it alone, so that several handles -- each driven by its own host thread, one of them
+// possibly capturing a graph -- can run poisoned side by side (a hipMemset on the legacy stream + hipDeviceSynchronize could not)
+hipStream_t &poison_stream();
 template <typename T>
 struct DevBuf {
   T *p = nullptr;
@@ -68,13 +72,16 @@ struct DevBuf {
     if (count) HIP_CHECK(hipMalloc(&p, count * sizeof(T)));
     // MPPGPU_POISON=1 (debugging): fresh device memory is filled with 0xFF bytes -- NaN as a double, -1 as an index -- so that a
     // kernel reading something nobody wrote shows in the results instead of depending on what the allocation happened to hold
-    if (count && poison_allocations()) { HIP_CHECK(hipMemset(p, 0xFF, count * sizeof(T))); HIP_CHECK(hipDeviceSynchronize()); }   // (before any stream's copy into it)
+    if (count && poison_allocations()) {   // (before any copy into it: uploads follow on the same stream)
+      HIP_CHECK(hipMemsetAsync(p, 0xFF, count * sizeof(T), poison_stream()));
+      HIP_CHECK(hipStreamSynchronize(poison_stream()));
+    }
     n = count;
   }
-  // The source is pageable host memory, often a temporary of the caller: hipMemcpyAsync then goes through the runtime's staging
-  // buffer and has consumed `src` when it returns ("if host or dst are not pinned, the memory copy will be performed
-  // synchronously", hip_runtime_api.h), while the staged data may still be on its way -- the caller may release `src` at once.
-  // (A stream synchronisation here was tried as a belt-and-braces measure: + 4 s of set-up at 134 M cells, nothing gained.)
+  // The source is pageable host memory, often a temporary of the caller that dies (or is refilled) right after the call.  On this
+  // runtime hipMemcpyAsync from pageable memory returns only after the source has been consumed -- measured, 8 B to 1 GiB, source
+  // overwritten or freed and reused at once, no corrupted element (tools/upload_probe.hip, profiles/r04/upload_probe.json); the
+  // call takes the time of the copy and a stream synchronisation behind it ~10 us.
   void upload(const T *src, size_t count, hipStream_t s) {
     alloc(count);
     if (count) HIP_CHECK(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, s));
@@ -202,6 +209,9 @@ struct Options {
   bool th_fused_dots = true;   // coupled TH, bjacobi: the Krylov dot products of M^{-1} r come out of the block column solve
   int ilu_box = 1;             // ILU(0) solves box by box when the pattern is a structured grid in natural ordering (BoxGrid); 0: never, 2: or fail
   bool ilu_box_factor = true;  // ... and the numeric factorisation too (extents other than 2); false: by the elimination program of the general path
+  bool ilu_box_queue = false;  // ... with ONE launch per triangle: boxes handed out by ticket in level order to ilu_box_workers resident waves, a box
+                               // waits for its three predecessors' flags (k_box_lower_queue; liveness independent of the dispatch order)
+  int ilu_box_workers = 1024;
   int ilu_box_len = 0;         // box extent along the fastest direction (0: 64 from 2^25 rows, else 32)
   bool ilu_chain_tickets = false;  // chained ILU(0): tiles handed out by an atomic ticket instead of in dispatch order (kernels.hpp):
                                    // liveness then does not depend on the dispatch order, at +50-75 % per application

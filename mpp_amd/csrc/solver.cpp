@@ -272,6 +272,11 @@ struct Solver {
   std::vector<int> box_lptr;                 // boxes of box level l: box_order[box_lptr[l] .. box_lptr[l+1])
   DevBuf<double> box_L[3], box_U[3], box_Di, box_v, box_scratch, box_T[3];
   GraphSeq box_graph, box_fgraph;
+  // one launch per triangle (k_box_lower_queue / k_box_upper_queue): boxes by ticket in level order, completion flags
+  DevBuf<int> box_order_rev;
+  DevBuf<unsigned> box_flags, box_ticket;     // flags: [lower: nboxes][upper: nboxes]; ticket: one counter per triangle
+  unsigned box_epoch = 0, box_ticket_base[2] = {0, 0};
+  long long box_queue_fallbacks = 0;
 
   double dtime = 0.0, time = 0.0;
   long long cum_newton = 0, cum_linear = 0, cum_cuts = 0, cum_funcs = 0;
@@ -1554,6 +1559,18 @@ struct Solver {
     for (int l = 0; l < nl; ++l) graph_tick(), launch_box_lower(box, box_order.p + box_lptr[l], box_lptr[l + 1] - box_lptr[l], L, box_v.p, box_scratch.p, stream);
     for (int l = nl - 1; l >= 0; --l) graph_tick(), launch_box_upper(box, box_order.p + box_lptr[l], box_lptr[l + 1] - box_lptr[l], U, box_Di.p, box_v.p, box_scratch.p, stream);
   }
+  // both box solves with one launch per triangle (tickets + flags)
+  void box_solve_queue() {
+    const double *const L[3] = {box_L[0].p, box_L[1].p, box_L[2].p}, *const U[3] = {box_U[0].p, box_U[1].p, box_U[2].p};
+    const int nboxes = box.NB1 * box.NB2 * box.NB3;
+    const int nworkers = std::max(1, std::min(nboxes, opt.ilu_box_workers));
+    if (++box_epoch == 0) box_epoch = 1;   // (0 is what fresh flags hold)
+    BoxQueueArgs lo{box_order.p, nboxes, nworkers, box_flags.p, box_epoch, box_ticket.p, box_ticket_base[0], opt.ilu_chain_spins, sc.p};
+    BoxQueueArgs up{box_order_rev.p, nboxes, nworkers, box_flags.p + nboxes, box_epoch, box_ticket.p + 1, box_ticket_base[1], opt.ilu_chain_spins, sc.p};
+    launch_box_solve_queue(box, lo, up, L, U, box_Di.p, box_v.p, box_scratch.p, stream);
+    box_ticket_base[0] += (unsigned)nboxes + (unsigned)nworkers;   // every wave's last ticket finds the queue empty
+    box_ticket_base[1] += (unsigned)nboxes + (unsigned)nworkers;
+  }
   bool box_active() const { return box_ok && opt.ilu_box != 0; }
   bool box_factored() const { return box_active() && opt.ilu_box_factor && box_factor_applies(box); }
   // A fixed sequence of launches, captured the first time and replayed afterwards -- as SEVERAL hipGraphs of at most
@@ -1608,7 +1625,17 @@ struct Solver {
     else if (opt.pc_type == 1 && box_active()) {
       if (box_gather_in_fits(box)) launch_box_gather_in(box, d_ext2int.p, r, box_v.p, stream);   // r into the box layout, padding zero
       else launch_gather_or_zero(box_slots, box_cellmap.p, r, box_v.p, stream);
-      run_graph(box_graph, [&] { box_solve_levels(); });
+      bool solved = false;
+      if (opt.ilu_box_queue) {
+        box_solve_queue();
+        solved = !chain_timed_out();   // (a wait ran out of spins: the application is redone per level, the queue stays off)
+        if (!solved) {
+          ++box_queue_fallbacks;
+          if (box_gather_in_fits(box)) launch_box_gather_in(box, d_ext2int.p, r, box_v.p, stream);
+          else launch_gather_or_zero(box_slots, box_cellmap.p, r, box_v.p, stream);
+        }
+      }
+      if (!solved) run_graph(box_graph, [&] { box_solve_levels(); });
       launch_gather(nred, box_cellpos.p, box_v.p, z, stream);                // back to the internal row order
       if (nghost > 0) launch_set(nghost, 0.0, z + nred, stream);             // (identity rows, zero right-hand side)
     } else if (opt.pc_type == 1) {
@@ -2878,10 +2905,10 @@ struct Solver {
     HIP_CHECK(hipMemcpyAsync(&e, sc.p + S_ERR, sizeof(double), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
     if (e == 0.0) return false;
-    opt.ilu_chain = 0;
+    opt.ilu_chain = 0; opt.ilu_box_queue = false;
     if (chain_fallbacks++ == 0)
-      std::fprintf(stderr, "mppgpu: a chained ILU(0) solve timed out waiting for a tile (spin budget %u); redone with one launch per "
-                           "level, the chain is off for this handle from now on\n", opt.ilu_chain_spins);
+      std::fprintf(stderr, "mppgpu: a flag-chained ILU(0) solve timed out waiting for a tile or box (spin budget %u); redone with one launch per "
+                           "level, chained solves are off for this handle from now on\n", opt.ilu_chain_spins);
     launch_set(1, 0.0, sc.p + S_ERR, stream);
     return true;
   }
@@ -3113,6 +3140,13 @@ struct Solver {
     for (int K = 0; K < g.NB3; ++K) for (int J = 0; J < g.NB2; ++J) for (int I = 0; I < g.NB1; ++I)
       order[fill[I + J + K]++] = I + g.NB1 * (J + g.NB2 * K);
     box_cellmap.upload(cellmap, stream); box_cellpos.upload(cellpos, stream); box_order.upload(order, stream);
+    {
+      std::vector<int> rev(order.rbegin(), order.rend());
+      box_order_rev.upload(rev, stream);
+      box_flags.alloc(2 * (size_t)nboxes); box_flags.zero(stream);
+      box_ticket.alloc(2); box_ticket.zero(stream);
+      box_epoch = 0; box_ticket_base[0] = box_ticket_base[1] = 0;
+    }
     for (int k = 0; k < 3; ++k) { box_L[k].alloc((size_t)slots); box_U[k].alloc((size_t)slots); }
     box_Di.alloc((size_t)slots); box_v.alloc((size_t)slots); box_scratch.alloc(128);
     HIP_CHECK(hipStreamSynchronize(stream));
@@ -3192,6 +3226,8 @@ struct Solver {
     else if (key == "th_fused_dots") opt.th_fused_dots = num() != 0;
     else if (key == "ilu_box") { opt.ilu_box = (int)num(); pc_ready = false; }   // the factors are repacked for the other solve path
     else if (key == "ilu_box_factor") { opt.ilu_box_factor = num() != 0; pc_ready = false; }
+    else if (key == "ilu_box_queue") opt.ilu_box_queue = num() != 0;       // box solves: one launch per triangle (tickets + flags)
+    else if (key == "ilu_box_workers") opt.ilu_box_workers = std::max(1, (int)num());   // ... on this many resident waves
     else if (key == "ilu_box_len") {
       const int v = (int)num();
       if (v < 0 || v > kBoxMaxLen) throw Error("ilu_box_len must be between 0 and " + std::to_string(kBoxMaxLen));
@@ -3278,7 +3314,8 @@ static thread_local std::string g_create_error;
   if (!(h)) return 1;                   \
   Solver &S = (h)->s;                   \
   try {                                 \
-    (void)hipSetDevice(S.device);
+    (void)hipSetDevice(S.device);       \
+    mpp::poison_stream() = S.stream;
 #define API_END()                       \
   }                                     \
   catch (const std::exception &e) {     \
@@ -3678,7 +3715,7 @@ int mppgpu_get_pc_info(mppgpu_handle h, int *path, int *launches, int *box_exten
   int p = 0, n = 0, ext[3] = {0, 0, 0};
   if (S.opt.pc_type == 1 && S.pc_ready) {
     if (S.box_active()) {
-      p = 3; n = 2 * ((int)S.box_lptr.size() - 1) + 2;
+      p = 3; n = S.opt.ilu_box_queue ? 4 : 2 * ((int)S.box_lptr.size() - 1) + 2;
       ext[0] = S.box.B1; ext[1] = S.box.B2; ext[2] = S.box.B3;
     } else if (S.ilu_chained()) { p = 2; n = 5; }
     else { p = 1; n = (int)S.h_lptr.size() - 2 + (int)S.h_uptr.size() - 1 + 3; }
@@ -3853,6 +3890,7 @@ int mppgpu_comm_init_local(mppgpu_handle *handles, int nranks) {
     auto g = std::make_shared<mpp::LocalGroup>(nranks);
     for (int r = 0; r < nranks; ++r) {
       (void)hipSetDevice(handles[r]->s.device);
+      mpp::poison_stream() = handles[r]->s.stream;
       handles[r]->s.comm.init_local(g, r);
     }
   } catch (const std::exception &e) {

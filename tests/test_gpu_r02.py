@@ -372,6 +372,16 @@ def test_box_ilu_solves_reproduce_the_level_scheduled_ones_bit_for_bit(dims, box
     bi, li = box.soe.pc_info(), lev.soe.pc_info()
     assert bi["path"] == "boxes" and li["path"] == "levels" and bi["launches"] < li["launches"] or min(dims) == 1
     assert bi["box_extents"][1] * bi["box_extents"][2] == 64
+    # ... and with ONE launch per triangle (boxes by ticket in level order, completion flags; round 4): the same bits again, on many
+    # resident waves and on three (every box then waits for boxes the same wave solved a moment ago, or that two others are solving)
+    for workers in (1024, 3):
+        que = P.to_thermal_gpu(tp, {"ksp_type": "gmres", "pc_type": "ilu", "ilu_box": 2, "ilu_box_len": box_len, "ilu_box_queue": 1,
+                                    "ilu_box_workers": workers})
+        assert que.soe.StepDT(tp.dt, 1)[0]
+        assert que.soe.last_linear_iterations == lev.soe.last_linear_iterations
+        assert np.array_equal(que.soe.GetSoln(), lev.soe.GetSoln())
+        assert que.soe.comm_stats()["chain_fallbacks"] == 0
+        assert que.soe.pc_info()["launches"] == 4 or min(dims) == 1
 
 
 @pytest.mark.parametrize("dims", [(2, 9, 5), (9, 2, 5), (11, 7, 2), (13, 2, 1), (3, 3, 3)])
@@ -399,14 +409,18 @@ def test_box_ilu_applications_on_the_3d_vsfm_jacobian():
     n = prob.mesh.ncells_local
     x = prob.press_ic - np.random.default_rng(2).uniform(0, 2.5e5, n)
     box = P.to_gpu(prob, {"ksp_type": "gmres", "pc_type": "ilu", "ilu_box": 2})
+    que = P.to_gpu(prob, {"ksp_type": "gmres", "pc_type": "ilu", "ilu_box": 2, "ilu_box_queue": 1})   # one launch per triangle
     lev = P.to_gpu(prob, {"ksp_type": "gmres", "pc_type": "ilu", "ilu_box": 0, "ilu_chain": 0})
-    for g in (box, lev):
+    for g in (box, que, lev):
         g.soe.SetDtime(prob.dt); g.soe.PreSolve()
         g.soe.ComputeJacobian(x)
     rng = np.random.default_rng(17)
     for rep in range(40):
         v = rng.standard_normal(n)
-        assert np.array_equal(box.soe.PCApply(v), lev.soe.PCApply(v)), rep
+        z = lev.soe.PCApply(v)
+        assert np.array_equal(box.soe.PCApply(v), z), rep
+        assert np.array_equal(que.soe.PCApply(v), z), rep
+    assert que.soe.comm_stats()["chain_fallbacks"] == 0
     assert box.soe.StepDT(prob.dt, 1) == lev.soe.StepDT(prob.dt, 1)
     assert box.soe.counters() == lev.soe.counters()
     assert np.array_equal(box.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1),
