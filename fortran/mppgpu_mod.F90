@@ -31,7 +31,7 @@ module mppgpu_mod
         mppgpu_set_lateral_connections, mppgpu_compute_lateral_flux, mppgpu_get_condition_values, &
         mppgpu_set_source_sink_auxvar, mppgpu_thermal_set_soils, mppgpu_thermal_set_soln_prev_clm, &
         mppgpu_thermal_pre_step_dt, mppgpu_thermal_step_dt, mppgpu_thermal_get_soln, mppgpu_thermal_compute_rhs, &
-        mppgpu_thermal_compute_operators, mppgpu_th_add_condition, mppgpu_th_set_soils, mppgpu_kernel_stats, &
+        mppgpu_thermal_compute_operators, mppgpu_th_add_condition, mppgpu_th_set_soils, mppgpu_kernel_stats, mppgpu_kernel_calls, &
         mppgpu_reset_stats, mppgpu_get_comm_stats, mppgpu_get_pc_info, mppgpu_get_assembly_info, mppgpu_bench_kernel, &
         mppgpu_comm_get_unique_id, mppgpu_comm_runtime_version, mppgpu_comm_init, &
         mppgpu_comm_init_local, mppgpu_set_ghost_cells, mppgpu_set_halo, &
@@ -235,6 +235,9 @@ module mppgpu_mod
        real(c_double) :: values(*)
      end function
      ! ---- thermal KSP path (sysofeqns_thermal_type) ----
+     ! NOTE: by default the thermal operator uses a Dirichlet connection's OWN area in the right-hand side and dhsdT*area in the
+     ! heat-flux term; the reference has a stale `area` (GoveqnThermalKSPTemperatureSoilType.F90:906-911) and dhsdT**area (:1215).
+     ! mppgpu_set_option(h, 'thermal_reference_defects', '1') reproduces the reference to the letter (INTEGRATION.md section 7).
      integer(c_int) function mppgpu_thermal_set_soils(h, itype, is_soil_shallow, watsat, csol, tkmg, tkdry, dz) &
           bind(C, name='mppgpu_thermal_set_soils')
        import :: c_int, c_ptr, c_double
@@ -301,6 +304,13 @@ module mppgpu_mod
        character(kind=c_char) :: kclass(*)
        integer(c_long_long) :: launches
        real(c_double) :: total_ms, bytes_per_launch
+     end function
+     integer(c_int) function mppgpu_kernel_calls(h, kclass, calls, stride) bind(C, name='mppgpu_kernel_calls')
+       import :: c_int, c_ptr, c_char, c_long_long
+       type(c_ptr), value :: h
+       character(kind=c_char) :: kclass(*)
+       integer(c_long_long) :: calls
+       integer(c_int) :: stride
      end function
      integer(c_int) function mppgpu_reset_stats(h) bind(C, name='mppgpu_reset_stats')
        import :: c_int, c_ptr

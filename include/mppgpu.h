@@ -303,6 +303,10 @@ int mppgpu_thermal_compute_operators(mppgpu_handle h, double dt, int *rowptr, in
  * bytes = algorithmic bytes per launch as defined in DESIGN.md. */
 int mppgpu_kernel_stats(mppgpu_handle h, const char *name, long long *launches, double *total_ms,
                         double *algorithmic_bytes_per_launch);
+/* ... and how the timed launches were sampled: `calls` = launches of the class since the last reset (timed or not), `stride` = every
+ * stride-th of them was bracketed by a HIP-event pair (option "profile_stride"): total_ms * calls / launches estimates the class's
+ * total.  No counterpart in the reference (PETSc's -log_view counts calls per event the same way). */
+int mppgpu_kernel_calls(mppgpu_handle h, const char *name, long long *calls, int *stride);
 int mppgpu_reset_stats(mppgpu_handle h);
 /* collectives this handle issued since the last mppgpu_reset_stats: all-reduces (RCCL ncclAllReduce or the in-process
  * group) and halo exchanges; how many chained ILU(0) applications had to be redone with per-level launches because a

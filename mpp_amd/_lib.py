@@ -66,6 +66,7 @@ SIGNATURES = {
     "mppgpu_th_add_condition": (ct.c_int, [_h, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _ip, _dp, _dp, _dp, _dp, ct.c_int, _ip]),
     "mppgpu_th_set_soils": (ct.c_int, [_h, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
     "mppgpu_kernel_stats": (ct.c_int, [_h, ct.c_char_p, _llp, _dp, _dp]),
+    "mppgpu_kernel_calls": (ct.c_int, [_h, ct.c_char_p, _llp, _ip]),
     "mppgpu_reset_stats": (ct.c_int, [_h]),
     "mppgpu_get_comm_stats": (ct.c_int, [_h, _llp, _llp, _llp, _llp]),
     "mppgpu_get_pc_info": (ct.c_int, [_h, _ip, _ip, _ip]),

@@ -108,11 +108,14 @@ __host__ __device__ inline double fpow(double x, double y, const PowTab &pt) {
   const double ehi = y * s2;
   const double elo = fma(y, s2, -ehi) + y * lo;
   const double z = ehi * InvLn2N;
-  const double kz = rint(z);
+  // |y log2 x| beyond 2^11: the result over- or underflows whatever the fraction is -- the multiple of ln2/128 is clamped (2^18 / 128 =
+  // 2048 binades: ldexp saturates to inf / 0, as the library pow does) instead of converting an arbitrarily large double to int
+  const bool sat = !(fabs(z) < 0x1p18);
+  const double kz = sat ? copysign(0x1p18, z) : rint(z);
   const int ki = (int)kz;
   double rr = fma(kz, NegLn2hiN, ehi);
   rr = fma(kz, NegLn2loN, rr);
-  rr = rr + elo;
+  rr = sat ? 0.0 : rr + elo;
   const int idx = ki & (kPowExpEntries - 1), top = ki >> 7;
   const double thi = pt.expt[2 * idx], tlo = pt.expt[2 * idx + 1];
   // e^rr - 1 = rr + rr^2/2 + rr^3/6 + rr^4/24 + rr^5/120
@@ -122,6 +125,9 @@ __host__ __device__ inline double fpow(double x, double y, const PowTab &pt) {
   q = fma(rr, q, 0.5);
   q = fma(q2, q, rr);
   const double res = ldexp(thi + fma(thi, q, tlo), top);
+  // 0^y as the library pow the host laws use: 0 (y > 0), inf (y < 0), 1 (y == 0) -- the van Genuchten branch reaches it when (alpha pc)^n
+  // underflows (AA = 0: kr = (1 - 0^m)^2 ... = 1, as the reference computes it)
+  if (x == 0.0) return y > 0.0 ? 0.0 : (y < 0.0 ? INFINITY : 1.0);
   return ok ? res : NAN;
 }
 

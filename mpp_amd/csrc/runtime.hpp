@@ -236,6 +236,7 @@ struct Options {
   int tri_lds = -1;            // column solve with L^{-1} r parked in LDS between the sweeps: 0 off, 1 on, -1 auto (Solver::tri_lds)
   int tri_group = 24;          // ... and levels kept in flight per stream and wave (8, 16, 24)
   int spmv_tpw = 0;            // > 0: 64-row tiles per wave of the compact-index SpMV (default 2 / 4 by variant)
+  bool ls_trace = false;       // one line per bt line search on stderr: Newton iteration, trial points, accepted lambda (development aid)
   bool fused_predict = true;   // skip the fused Jacobian at the first trial when the previous line search backtracked
   int fused_trials = 2;        // ... for the first `fused_trials` trial points of a line search (later ones: F only)
 };

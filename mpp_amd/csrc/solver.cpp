@@ -282,6 +282,8 @@ struct Solver {
   long long cum_newton = 0, cum_linear = 0, cum_cuts = 0, cum_funcs = 0;
   int nfuncs = 0;
   bool ls_backtracked_last = false;
+  bool ls_first_fused = false;    // option ls_trace: what the line search's first trial point evaluated
+  int ls_trace_it = 0;
   double ls_ynorm = -1.0;         // linesearch->ynorm as the previous application left it (cp reads it at entry)
   long long cum_ls_switches = 0;  // line searches swapped in by use_dynamic_linesearch
   std::vector<double> last_substeps;   // sub-steps the most recent StepDT accepted (dt, dt/2 ... after time-step cuts)
@@ -498,7 +500,7 @@ struct Solver {
 
   void detect_columns() {
     // vertical chains of the internal connection set (any cell numbering)
-    Scratch<int> nxt(n, -1), below(n, -1);
+    Scratch<int> nxt(n, -1), below(n, -1), deg_up(n, 0), deg_dn(n, 0);
     Scratch<char> is_vert(nc, 0);
     std::atomic<bool> ok{true};
     std::atomic<long long> nvert{0};
@@ -509,14 +511,15 @@ struct Solver {
         if (std::fabs(uz) > 0.5 * std::sqrt(ux * ux + uy * uy + uz * uz)) {
           is_vert[c] = 1;
           ++mine;
-          put(&nxt[cup_e[c]], cdn_e[c]); put(&below[cdn_e[c]], cup_e[c]);   // (plain stores; a cell with two links is found below)
+          put(&nxt[cup_e[c]], cdn_e[c]); put(&below[cdn_e[c]], cup_e[c]);
+          // a chain has at most ONE link above and one below every cell: counted, because two links between the SAME pair of cells
+          // store the same values twice and cannot be told from one by comparing what was stored
+          fetch_inc(&deg_up[cup_e[c]]); fetch_inc(&deg_dn[cdn_e[c]]);
         }
       }
       nvert += mine;
     });
-    host_parallel_for(nc, [&](long long c) {   // two vertical links at one cell: one of them lost its store
-      if (is_vert[c] && (nxt[cup_e[c]] != cdn_e[c] || below[cdn_e[c]] != cup_e[c])) ok = false;
-    });
+    host_parallel_for(n, [&](long long i) { if (deg_up[i] > 1 || deg_dn[i] > 1) ok = false; });
     PhaseTimer pt2("  columns: chains and numbering");
     ext2int.resize(n); int2ext.resize(n);   // (every entry is written below)
     columns = false;
@@ -2251,6 +2254,7 @@ struct Solver {
       if (spec) {   // trial 0, lambda = 1: already evaluated (into Wv, Gv), its sums came with the Krylov solver's read-back
         spec = false;
         last_fused = ls_ahead.spec_fused;
+        ls_first_fused = last_fused;
         ++trial;
         gnorm = std::sqrt(ls_ahead.g2); wnorm2 = ls_ahead.w2;
         return gnorm * gnorm;
@@ -2260,6 +2264,7 @@ struct Solver {
       // a trial point's Jacobian is assembled together with its residual when the point is likely to be accepted:
       // the full step unless the previous line search of this solve had to backtrack, and always the second trial
       last_fused = opt.fused_assembly && trial < opt.fused_trials && !(trial == 0 && opt.fused_predict && ls_backtracked_last);
+      if (trial == 0) ls_first_fused = last_fused;
       ++trial;
       if (last_fused) op_residual_jacobian(Wv, Gv); else op_residual(Wv, Gv);
       double r2[2];
@@ -2305,6 +2310,7 @@ struct Solver {
       }
     }
     ls_backtracked_last = trial > 1;
+    if (opt.ls_trace) std::fprintf(stderr, "[mppgpu ls] newton %d trials %d lambda %.6g first_fused %d\n", ls_trace_it, trial, lambda, (int)ls_first_fused);
     std::swap(X, Wv);   // X <- W, F <- G by pointer exchange (no copies)
     std::swap(Fv, Gv);
     jac_valid = last_fused;
@@ -2458,6 +2464,7 @@ struct Solver {
       *linear_its += its;
       if (kreason < 0) { reason = -3; break; }
       int lsfail, ls_reason = 0;
+      ls_trace_it = i;
       switch (opt.linesearch_type) {
         case 1: lsfail = linesearch_basic(X, Fv, Yv, Wv, Gv, fnorm, xnorm, ynorm, jac_valid); break;
         case 3: lsfail = linesearch_l2(X, Fv, Yv, Wv, Gv, fnorm, xnorm, ynorm, jac_valid); break;
@@ -3246,6 +3253,7 @@ struct Solver {
     else if (key == "host_poll") opt.host_poll = num() != 0;
     else if (key == "collective_timeout") opt.collective_timeout = num();
     else if (key == "ls_spec") opt.ls_spec = num() != 0;
+    else if (key == "ls_trace") opt.ls_trace = num() != 0;   // one line per bt line search on stderr (development aid)
     else if (key == "fused_spmv_pc") opt.fused_spmv_pc = num() != 0;
     else if (key == "fused_first") opt.fused_first = num() != 0;
     else if (key == "lazy_r") opt.lazy_r = num() != 0;
@@ -3680,6 +3688,16 @@ int mppgpu_kernel_stats(mppgpu_handle h, const char *name, long long *launches, 
   if (launches) *launches = S.prof.launches[cls];
   if (total_ms) *total_ms = S.prof.total_ms[cls];
   if (algorithmic_bytes_per_launch) *algorithmic_bytes_per_launch = S.algorithmic_bytes(cls);
+  API_END()
+}
+int mppgpu_kernel_calls(mppgpu_handle h, const char *name, long long *calls, int *stride) {
+  API_BEGIN(h)
+  int cls = -1;
+  for (int k = 0; k < mpp::KC_COUNT; ++k)
+    if (name && std::strcmp(name, mpp::kclass_name(k)) == 0) cls = k;
+  if (cls < 0) throw mpp::Error(std::string("unknown kernel class '") + (name ? name : "") + "'");
+  if (calls) *calls = S.prof.calls[cls];
+  if (stride) *stride = S.prof.stride;
   API_END()
 }
 int mppgpu_reset_stats(mppgpu_handle h) {

@@ -225,7 +225,9 @@ class SystemOfEquationsVSFM:
     def kernel_stats(self, name):
         n, ms, by = ct.c_longlong(), ct.c_double(), ct.c_double()
         self._chk(self.L.mppgpu_kernel_stats(self.h, name.encode(), ct.byref(n), ct.byref(ms), ct.byref(by)))
-        return dict(launches=n.value, total_ms=ms.value, bytes_per_launch=by.value)
+        calls, stride = ct.c_longlong(), ct.c_int()
+        self._chk(self.L.mppgpu_kernel_calls(self.h, name.encode(), ct.byref(calls), ct.byref(stride)))
+        return dict(launches=n.value, total_ms=ms.value, bytes_per_launch=by.value, calls=calls.value, stride=stride.value)
 
     def reset_stats(self):
         self._chk(self.L.mppgpu_reset_stats(self.h))

@@ -609,6 +609,111 @@ def split_thermal_problem(tp: ThermalProblem, nranks):
     return out
 
 
+def thermal_mms_rank(nx, ny, nz, world, rank):
+    """Rank `rank`'s share of thermal_mms(3, nx, ny, nz, replicate_reference_soil_indexing=False) split over `world` ranks into
+    contiguous id ranges (mpp_amd.parallel.shard_columns over the cells: z-slabs for the x-fastest numbering) -- built WITHOUT the
+    global problem when the ranges are whole planes (nz a multiple of world), which is what a rank process of
+    `bench.py --workload thermal --gpus N` calls: a 512^3 mesh per rank would cost every rank the memory and the minute of the
+    whole problem.  Same cells, order, connections, halo plan and boundary entries as split_thermal_problem(...)[rank]
+    (tests/test_parallel_gloo.py compares the two array by array); returns (part, local problem)."""
+    from mpp_amd import parallel as PAR
+    if world == 1:
+        tp = thermal_mms(3, nx, ny, nz, replicate_reference_soil_indexing=False)
+        n = tp.mesh.ncells_local
+        return PAR.MeshPart(tp.mesh, np.arange(n), 0, np.zeros(0, np.int32), np.zeros(1, np.int32), np.zeros(0, np.int32), np.zeros(0, np.int32)), tp
+    if nz % world != 0:
+        return split_thermal_problem(thermal_mms(3, nx, ny, nz, replicate_reference_soil_indexing=False), world)[rank]
+    nxy, npl = nx * ny, nz // world
+    k0 = rank * npl                                   # owned planes k0 .. k0 + npl - 1 (0-based)
+    lo_ghost, hi_ghost = rank > 0, rank < world - 1
+    planes = list(range(k0, k0 + npl)) + ([k0 - 1] if lo_ghost else []) + ([k0 + npl] if hi_ghost else [])
+    planes = np.asarray(planes, dtype=np.int64)
+    nown, nloc = npl * nxy, len(planes) * nxy
+    dx, dy, dz = 1.0 / nx, 1.0 / ny, 1.0 / nz
+    # local cell [p, jj, ii] (p: position in `planes`): centroids by MeshCreate's expression in the GLOBAL indices (mesh.mesh_create)
+    kk = (planes + 1)[:, None, None]
+    jj = np.arange(1, ny + 1)[None, :, None]
+    ii = np.arange(1, nx + 1)[None, None, :]
+    shape = (len(planes), ny, nx)
+    X = np.broadcast_to(dx / 2.0 + dx * (ii - 1) + 0.0, shape).astype(np.float64)
+    Y = np.broadcast_to(dy / 2.0 + dy * (jj - 1) + 0.0, shape).astype(np.float64)
+    Z = np.broadcast_to(dz / 2.0 + dz * (kk - 1) + 0.0, shape).astype(np.float64)
+    l2g = (planes[:, None, None] * nxy + (jj - 1) * nx + (ii - 1)).reshape(-1)
+    lm = M.Mesh(name="Soil mesh", ncells_local=nloc, nlev=nz, orientation=C.MESH_AGAINST_GRAVITY)
+    lm.x, lm.y, lm.z = X.ravel().copy(), Y.ravel().copy(), Z.ravel().copy()
+    lm.dx, lm.dy, lm.dz = np.full(nloc, dx), np.full(nloc, dy), np.full(nloc, dz)
+    lm.area_xy = np.full(nloc, dx * dy)
+    lm.is_active = np.ones(nloc, dtype=np.int32)
+    lm.compute_volume()
+    # local id (1-based) of the cell (plane position p, jj, ii): owned planes first, then the ghost planes -- the order of `planes`
+    lid = (np.arange(nloc, dtype=np.int64) + 1).reshape(shape)
+    pos = {int(k): p for p, k in enumerate(planes)}
+    # internal connections with at least one owned end, in the global order: x set, y set, z set; within a set ii outer, jj, kk inner
+    own = lid[:npl]                                    # [kk_owned, jj, ii]
+    sets = []
+    if nx > 1:
+        sets.append((own[:, :, :-1], own[:, :, 1:], dx, dy * dz, 0))
+    if ny > 1:
+        sets.append((own[:, :-1, :], own[:, 1:, :], dy, dx * dz, 1))
+    zlo = [k for k in range(k0 - 1, k0 + npl) if 0 <= k < nz - 1 and (k in pos) and (k + 1 in pos)]   # pairs (k, k + 1)
+    if zlo:
+        up = np.stack([lid[pos[k]] for k in zlo]); dn = np.stack([lid[pos[k + 1]] for k in zlo])
+        sets.append((up, dn, dz, dx * dy, 2))
+    ups, dns, dus, ars, uvs = [], [], [], [], []
+    for up, dn, dist, area, axis in sets:
+        u = np.ascontiguousarray(up.transpose(2, 1, 0)).ravel(); d = np.ascontiguousarray(dn.transpose(2, 1, 0)).ravel()
+        ups.append(u); dns.append(d); dus.append(np.full(u.size, 0.5 * dist)); ars.append(np.full(u.size, area))
+        uv = np.zeros((u.size, 3)); uv[:, axis] = 1.0
+        uvs.append(uv)
+    up, dn, du, ar, uv = np.concatenate(ups), np.concatenate(dns), np.concatenate(dus), np.concatenate(ars), np.concatenate(uvs)
+    lm.intrn_conn_sets.append(M.ConnectionSet(up, dn, du, du.copy(), ar, uv, np.full(up.size, C.CONN_HORIZONTAL, dtype=np.int32)))
+    lm.ncols, lm.ordering = nxy, "x-fastest"
+    nghost = nloc - nown
+    peers = [q for q, there in ((rank - 1, lo_ghost), (rank + 1, hi_ghost)) if there]
+    send_cells, send_ptr = [], [0]
+    for q in peers:    # my plane next to q, ascending id
+        plane = 0 if q < rank else npl - 1
+        send_cells.append(np.arange(plane * nxy, (plane + 1) * nxy, dtype=np.int64) + 1)
+        send_ptr.append(send_ptr[-1] + nxy)
+    lm.nghost = nghost
+    lm.halo = (np.asarray(peers, dtype=np.int32), np.asarray(send_ptr, dtype=np.int32),
+               np.concatenate(send_cells).astype(np.int32) if send_cells else np.zeros(0, np.int32), np.full(len(peers), nxy, dtype=np.int32))
+    part = PAR.MeshPart(lm, l2g, nghost, *lm.halo)
+    # the manufactured problem on these cells; boundary faces of owned cells in the driver's order (x faces per (kk, jj) low then
+    # high, y faces per (kk, ii), z faces per (jj, ii): thermal_mms above)
+    T, lam, src = _mms_funcs(3)
+    out_cells, out_dd, out_ar, out_tb = [], [], [], []
+
+    def emit(cell, xyz, d, area):
+        out_cells.append(cell.ravel()); out_dd.append(np.full(cell.size, d / 2)); out_ar.append(np.full(cell.size, area))
+        out_tb.append(T(xyz[0].ravel(), xyz[1].ravel(), xyz[2].ravel()))
+
+    Xo, Yo, Zo = X[:npl], Y[:npl], Z[:npl]
+
+    def pair(sel_lo, sel_hi, axis, d, area):
+        cell = np.stack([own[sel_lo], own[sel_hi]], axis=-1)
+        xyz = [np.stack([A[sel_lo] + ((-d / 2) if a == axis else 0.0), A[sel_hi] + ((d / 2) if a == axis else 0.0)], axis=-1)
+               for a, A in enumerate((Xo, Yo, Zo))]
+        emit(cell, xyz, d, area)
+
+    if nx > 1:
+        pair((slice(None), slice(None), 0), (slice(None), slice(None), nx - 1), 0, dx, dy * dz)
+    if ny > 1:
+        pair((slice(None), 0, slice(None)), (slice(None), ny - 1, slice(None)), 1, dy, dx * dz)
+    if nz > 1:   # the bottom plane belongs to rank 0, the top plane to the last rank
+        if rank == 0:
+            emit(own[0], [Xo[0], Yo[0], Zo[0] - dz / 2], dz, dx * dy)
+        if rank == world - 1:
+            emit(own[npl - 1], [Xo[npl - 1], Yo[npl - 1], Zo[npl - 1] + dz / 2], dz, dx * dy)
+    idd = np.concatenate(out_cells); dd = np.concatenate(out_dd); arb = np.concatenate(out_ar); tb = np.concatenate(out_tb)
+    nb = idd.size
+    uvb = np.zeros((nb, 3)); uvb[:, 0] = 1.0
+    bc = M.ConnectionSet(np.zeros(nb, dtype=np.int64), idd.astype(np.int64), np.zeros(nb), dd, arb, uvb)
+    tp = ThermalProblem(name="thermal_mms_3d", mesh=lm, tkdry=lam(X, Y, Z).ravel().copy(), bc=bc, bc_temperature=tb,
+                        heat_source=(src(X, Y, Z) * dx * dy * dz).ravel(), exact=T(X, Y, Z).ravel())
+    return part, tp
+
+
 def th_vchannel(nx=6, ny=5, nz=7) -> THProblem:
     """the coupled mass + heat equations on the 3-D v-channel mesh (7-point stencil, sloping surface, gravity along every
     connection): vchannel's soil and hydrostatic start, a temperature that falls with depth, no boundary conditions (as the

@@ -44,8 +44,12 @@ int main() {
     probe(x, y);
   }
   probe(0x1p-1060, 0.5); probe(0x1p-1030, -0.25); probe(1.0, 123.0);
-  const bool special = std::isnan(mpp::fpow(-1.0, 0.5, pt)) && std::isnan(mpp::fpow(0.0, 0.5, pt)) && std::isnan(mpp::fpow(INFINITY, 0.5, pt)) &&
-                       std::isnan(mpp::fpow(NAN, 0.5, pt)) && mpp::fpow(1.0, 3.7, pt) == 1.0 && mpp::fpow(4.0, 0.5, pt) == 2.0;
+  // outside the domain: NaN; 0^y like libm's pow (0, inf, 1); results that over- or underflow saturate (no int conversion of a huge double)
+  const bool special = std::isnan(mpp::fpow(-1.0, 0.5, pt)) && std::isnan(mpp::fpow(INFINITY, 0.5, pt)) &&
+                       std::isnan(mpp::fpow(NAN, 0.5, pt)) && mpp::fpow(1.0, 3.7, pt) == 1.0 && mpp::fpow(4.0, 0.5, pt) == 2.0 &&
+                       mpp::fpow(0.0, 0.5, pt) == 0.0 && std::isinf(mpp::fpow(0.0, -0.5, pt)) && mpp::fpow(0.0, 0.0, pt) == 1.0 &&
+                       mpp::fpow(1e-300, 1e6, pt) == 0.0 && std::isinf(mpp::fpow(1e-300, -1e6, pt)) && mpp::fpow(1e300, -1e300, pt) == 0.0 &&
+                       std::isinf(mpp::fpow(1e300, 1e300, pt)) && mpp::fpow(2.0, -1074.0, pt) == 0x1p-1074 && mpp::fpow(2.0, 1023.0, pt) == 0x1p1023;
   std::printf("%lld %.4f %.17g %.17g %d\n", n, worst, wx, wy, special ? 1 : 0);
   return 0;
 }

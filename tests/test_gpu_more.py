@@ -255,3 +255,23 @@ def test_3d_mesh_split_across_ranks_vsfm():
     for (part, lp), g in zip(parts, gs):
         p = g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE)
         assert np.abs(p[:part.nowned] - p_ref[part.l2g[:part.nowned]]).max() <= 1e-7 * np.abs(p_ref).max()
+
+
+def test_two_vertical_connections_between_the_same_pair_of_cells_are_not_taken_for_a_column():
+    """a mesh whose internal connection set joins one pair of cells TWICE (each with half the face area) is not a set of
+    soil columns -- the column layout stores one link per cell and would drop one of the two.  Column detection must see it and the
+    general assembly (which supports repeated pairs: both fluxes land in the same matrix entries) must run; operators against the oracle"""
+    from mpp_amd import mesh as M
+    from test_gpu_parity import _hetero, _operator_parity
+    prob, x = _hetero(ncols=5, nz=8, seed=13)
+    cs = prob.mesh.intrn_conn_sets[0]
+    k = 10                                           # the connection that is split in two
+    area = np.asarray(cs.area, dtype=float).copy()
+    area[k] *= 0.5
+    dup = lambda a: np.concatenate([np.asarray(a), np.asarray(a)[k:k + 1]])
+    prob.mesh.intrn_conn_sets = [M.ConnectionSet(dup(cs.id_up), dup(cs.id_dn), dup(cs.dist_up), dup(cs.dist_dn), dup(area),
+                                                 dup(cs.unit_vec), None if cs.itype is None else dup(cs.itype))]
+    o, g, _, _ = _operator_parity(prob, x, {})
+    info = g.soe.assembly_info()
+    assert info["column_segments"] == 0 and not info["complete_rows"]      # not the column march
+    _operator_parity(prob, x, {"assembly": "general"})

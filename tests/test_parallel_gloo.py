@@ -179,6 +179,61 @@ def test_bench_launcher_starts_its_own_ranks(world):
     assert out["first_column_of_rank"] == [float(PAR.shard_columns(70, world, k)[0]) for k in range(world)]
 
 
+def test_bench_launcher_thermal_workload_builds_every_ranks_slab():
+    """`bench.py --workload thermal --gpus 4` (BASELINE config 4's rank count) up to, not including, the first GPU call: every rank
+    builds its own z-slab (owned planes + one ghost plane per neighbour) without the global mesh; the slabs tile the grid, what is
+    sent equals what is received, every boundary face belongs to exactly one rank"""
+    import json
+    n, world = 8, 4
+    r = _run_bench("--gpus", str(world), "--dry-run-ranks", "--workload", "thermal", "--n", str(n))
+    assert r.returncode == 0, r.stderr
+    out = json.loads([l for l in r.stdout.splitlines() if l.strip()][0])
+    assert out["workload"] == "thermal" and out["n_gpus"] == world and out["unique_id_ok"]
+    assert out["cells"] == out["owned_cells"] == float(n ** 3)
+    assert out["ghost_cells"] == out["halo_values_sent"] == float(2 * (world - 1) * n * n)
+    assert out["boundary_faces"] == float(6 * n * n)
+    assert out["first_cell_of_rank"] == [float(k * n ** 3 // world) for k in range(world)]
+
+
+def test_bench_launcher_th_workload_shards_the_columns():
+    """`bench.py --workload th --gpus 8` (config 5's rank count): the coupled problem's columns shard like the VSFM grid's"""
+    import json
+    r = _run_bench("--gpus", "8", "--dry-run-ranks", "--workload", "th", "--nx", "6", "--ny", "5", "--nz", "7")
+    assert r.returncode == 0, r.stderr
+    out = json.loads([l for l in r.stdout.splitlines() if l.strip()][0])
+    assert out["workload"] == "th" and out["n_gpus"] == 8 and out["columns"] == 30.0
+    assert out["cells"] == 210.0 and out["unknowns"] == 420.0
+
+
+@pytest.mark.parametrize("dims,world", [((5, 4, 6), 2), ((5, 4, 6), 3), ((7, 3, 8), 4), ((6, 5, 9), 3), ((4, 3, 5), 2)])
+def test_thermal_slab_built_directly_equals_the_split_of_the_global_problem(dims, world):
+    """workloads.thermal_mms_rank (what a rank of `bench.py --workload thermal` builds: its slab only) against
+    split_thermal_problem of the whole problem: the same cells in the same order, connections, halo plan, boundary faces, soil,
+    sources and exact solution, array by array ((4, 3, 5) over 2 ranks cuts a plane: the generic route is taken)"""
+    nx, ny, nz = dims
+    ref = P.split_thermal_problem(P.thermal_mms(3, nx, ny, nz, replicate_reference_soil_indexing=False), world)
+
+    def same(a, b):
+        return (a is None and b is None) or (np.asarray(a).shape == np.asarray(b).shape and np.array_equal(np.asarray(a), np.asarray(b)))
+
+    for rank in range(world):
+        part, lp = P.thermal_mms_rank(nx, ny, nz, world, rank)
+        rpart, rlp = ref[rank]
+        assert part.nghost == rpart.nghost and same(part.l2g, rpart.l2g)
+        for f in ("peer", "send_ptr", "send_cells", "recv_count"):
+            assert same(getattr(part, f), getattr(rpart, f)), f
+        for f in ("x", "y", "z", "dx", "dy", "dz", "area_xy", "vol", "is_active"):
+            assert same(getattr(lp.mesh, f), getattr(rlp.mesh, f)), f
+        assert (lp.mesh.ncells_local, lp.mesh.nlev, lp.mesh.ncols) == (rlp.mesh.ncells_local, rlp.mesh.nlev, rlp.mesh.ncols)
+        a, b = lp.mesh.internal_connections(), rlp.mesh.internal_connections()
+        for f in ("id_up", "id_dn", "dist_up", "dist_dn", "area", "unit_vec", "itype"):
+            assert same(getattr(a, f), getattr(b, f)), f
+        for f in ("id_up", "id_dn", "dist_up", "dist_dn", "area", "unit_vec"):
+            assert same(getattr(lp.bc, f), getattr(rlp.bc, f)), f
+        for f in ("tkdry", "bc_temperature", "heat_source", "exact"):
+            assert same(getattr(lp, f), getattr(rlp, f)), f
+
+
 def test_bench_launcher_reports_a_failed_rank_and_stops_the_others():
     r = _run_bench("--gpus", "2", "--dry-run-ranks", "--nx", "4", "--ny", "4", "--fail-rank", "1")
     assert r.returncode != 0

@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="extra mppgpu_set_option pairs")
     ap.add_argument("--rtol-sweep", default="", help="comma-separated ksp_rtol values solved one after the other on the same problem "
                                                      "(time, iterations and error against the manufactured solution for each)")
+    ap.add_argument("--then", action="append", default=[], metavar="KEY=VALUE[,KEY=VALUE]",
+                    help="after the timed step: set these options and time the step again (repeatable; A/B on one set-up)")
     ap.add_argument("--no-events", action="store_true", help="no HIP-event timing of the kernel classes")
     ap.add_argument("--dump-maps", default="", help="write /proc/self/maps there before the timed step (to attribute stack frames)")
     a = ap.parse_args()
@@ -84,6 +86,28 @@ def main():
                            "bytes_per_launch": by, "avg_apply_ms": round(ms, 4), "dependency_levels": 2 * (3 * a.n - 2),
                            "launches_per_application": info["launches"],
                            "note": "algorithmic bytes 12 nnz + 24 N (SURVEY 8d) over the average application; latency-bound by the dependency levels"}
+    # further timed steps of the same problem with options changed in between (A/B pairs on one box, one set-up)
+    variants = []
+    for spec in a.then:
+        for kv in spec.split(","):
+            k, v = kv.split("=", 1)
+            g.soe.SetOption(k, v)
+        g.soe.PreStepDT()
+        g.soe.reset_stats()
+        g.soe.synchronize()
+        t0 = time.perf_counter()
+        conv_v, _ = g.soe.StepDT(tp.dt, 1)
+        g.soe.synchronize()
+        dt_v = time.perf_counter() - t0
+        pa_v = g.soe.kernel_stats("pc_apply")
+        variants.append({"options": spec, "converged": conv_v, "linear_iterations": g.soe.last_linear_iterations, "step_s": round(dt_v, 4),
+                         "pc_apply_avg_ms": round(pa_v["total_ms"] / max(pa_v["launches"], 1), 4), "pc_apply_launches_timed": pa_v["launches"],
+                         "chain_fallbacks": g.soe.comm_stats()["chain_fallbacks"],
+                         "max_error_vs_manufactured_solution": float(np.abs(g.soe.GetSoln() - tp.exact).max())})
+        print("then %s: %d its, %.3f s, ILU(0) application %.3f ms" % (spec, variants[-1]["linear_iterations"], dt_v, variants[-1]["pc_apply_avg_ms"]),
+              file=sys.stderr, flush=True)
+    if variants:
+        out["then"] = variants
     if a.rtol_sweep:
         # time to a given accuracy: PETSc's default rtol 1e-5 (on the preconditioned residual) stops far above the discretisation
         # error on fine grids, so every timing is reported next to the error it bought
