@@ -1729,6 +1729,242 @@ __global__ __launch_bounds__(64) void k_box_upper_queue(BoxGrid g, BoxQueue q, c
   }
 }
 
+// ---- the same two solves as STREAMS (round 4): one launch per triangle, fine-grained hand-over of the box faces ----
+// What the per-level launches cost at 512^3 (profiles/r04/box_trace_512_len64.json): 134 box levels per triangle, 13 us each even
+// when the level holds ONE box (dispatch + the 78 dependent steps of a box), 27 us for the largest levels: 2.5 ms per triangle for
+// 6.5 GB, a third of what the memory system does.  Here a wave owns a PENCIL -- the NB1 boxes (I = 0 .. NB1-1) of one (J, K) -- and
+// streams through it; the pencil behind it in J and the one behind it in K are at most a few steps ahead of it:
+//   * a lane on the south (down) side of its box at step h needs the value the producer pencil's lane on the opposite side computed
+//     at ITS step h + B2 - 1 (h + B3 - 1) of the same box: all B3 (B2) values of one consumer step come from one producer step;
+//   * so every step a producer stores one line of 8 values per outgoing face -- agent-scope stores into a face buffer of its own,
+//     line (h - 7) of box I -- and a consumer, every 8 steps, loads the next 8 lines of its two incoming faces with one coalesced
+//     agent-scope load each (512 B), waits until none of the values it needs is the SENTINEL the buffer was initialised with (the
+//     payload is the flag: measured 0.6-0.7 us from store to sight on an idle chip, tools/handoff_bench.hip), parks them in LDS
+//     for its next 8 steps, and puts the sentinel back (the buffer is ready for the next application).
+// Pencils are handed out by ticket in the order of J + K (the upper solve: descending), so a pencil's producers hold lower tickets
+// and are running: liveness does not depend on the dispatch order.  Nothing else crosses between waves: the solution itself is
+// stored with plain stores (the other triangle is another launch), the west face of a box is the wave's own previous box.
+// Arithmetic and order per row are those of k_box_lower / k_box_upper: the same bits.  Needs B2 = B3 = 8 and S a multiple of 8.
+constexpr int kStreamLead = 24, kStreamTail = 40;   // lines of margin in front of / behind the S lines of a box in a face buffer
+                                                    // (steps outside 0 .. S-1 of the loops' rounded-up trip counts land there)
+__host__ __device__ inline int stream_lines(const BoxGrid &g) { return kStreamLead + g.S + kStreamTail; }   // lines per box and face
+__device__ __forceinline__ bool is_sentinel(double v) { return __double_as_longlong(v) == -1LL; }
+struct StreamArgs {
+  const int *order;        // pencils (J + NB2 * K) in ticket order
+  int npencils;
+  unsigned *ticket; unsigned ticket_base, max_spins;
+  double *sc;
+  double *faceJ, *faceK;   // this triangle's face buffers: [pencil][box I][line][8]
+};
+template <int DP>
+__global__ __launch_bounds__(64) void k_box_lower_stream(BoxGrid g, StreamArgs q, const double *__restrict__ Ld, const double *__restrict__ Ls,
+                                                         const double *__restrict__ Lw, double *y, double *scratch) {
+  static_assert(DP % 4 == 0, "a chunk of 8 steps is 4 row pairs");
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x, S = g.S, NP = S >> 1, NCH = S >> 3;
+  const int jp = lane & 7, kp = lane >> 3;
+  const int LB = stream_lines(g);
+  double *lineJ = lds, *lineK = lds + (size_t)(S + 2 * DP + 8) * 8;
+  const size_t pen_stride = (size_t)g.NB1 * LB * 8;
+  const bool inS = jp != 0, inD = kp != 0, mJ = jp == 7, mK = kp == 7;
+  const int addrB = ((lane - 8) & 63) << 2;
+  const int hW = jp + kp;
+  const unsigned lane16 = threadIdx.x * 16u;
+  dpair *sink = reinterpret_cast<dpair *>(scratch);
+  for (;;) {
+    unsigned t = 0;
+    if (lane == 0) t = __hip_atomic_fetch_add(q.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - q.ticket_base;
+    t = __builtin_amdgcn_readfirstlane(t);
+    if (t >= (unsigned)q.npencils) return;
+    const int pen = q.order[t];
+    const int J = pen % g.NB2, K = pen / g.NB2;
+    const bool hasJ = J > 0, hasK = K > 0, outJ = J < g.NB2 - 1, outK = K < g.NB3 - 1;
+    const double *inJ = q.faceJ + (size_t)(hasJ ? pen - 1 : pen) * pen_stride, *inK = q.faceK + (size_t)(hasK ? pen - g.NB2 : pen) * pen_stride;
+    double *myJ = q.faceJ + (size_t)pen * pen_stride, *myK = q.faceK + (size_t)pen * pen_stride;
+    for (int I = 0; I < g.NB1; ++I) {
+      const int b = I + g.NB1 * pen;
+      const size_t row0 = (size_t)b * S * 64;
+      const dpair *Ld2 = reinterpret_cast<const dpair *>(Ld + row0), *Ls2 = reinterpret_cast<const dpair *>(Ls + row0),
+                  *Lw2 = reinterpret_cast<const dpair *>(Lw + row0);
+      dpair *y2 = reinterpret_cast<dpair *>(y + row0);
+      dpair ld[DP], ls[DP], lw[DP], rr[DP];
+      auto fetch = [&](int u, int p) {
+        const size_t o = (size_t)min(p, NP - 1) * 64;
+        ld[u] = ldnt(at_lane(Ld2 + o, lane16)); ls[u] = ldnt(at_lane(Ls2 + o, lane16)); lw[u] = ldnt(at_lane(Lw2 + o, lane16));
+        rr[u] = *at_lane(y2 + o, lane16);
+      };
+#pragma unroll
+      for (int u = 0; u < DP; ++u) { fetch(u, u); __builtin_amdgcn_sched_barrier(0); }
+      double yW = *(I > 0 ? y + box_slot(g, b - 1, g.B1 - 1 + hW, lane) : y + row0);   // (the wave's own store of the box before)
+      if (I == 0) yW = 0.0;
+      // the incoming faces of this box: chunk c = lines 8c .. 8c+7, lane l holds element (line 8c + l/8, l%8)
+      const double *bJ = inJ + ((size_t)I * LB + kStreamLead) * 8, *bK = inK + ((size_t)I * LB + kStreamLead) * 8;
+      double cJ = 0.0, cK = 0.0;
+      auto request = [&](int c) {
+        if (hasJ) cJ = __hip_atomic_load(bJ + 64 * c + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (hasK) cK = __hip_atomic_load(bK + 64 * c + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      };
+      auto accept = [&](int c) {   // chunk c is in cJ / cK or on its way: wait for its values, park them in LDS, put the sentinel back
+        const bool need = 8 * c + (lane >> 3) < S - 7;   // (lines from S-7 on have no producer step: no real cell reads them)
+        unsigned spins = 0;
+        while (__any((need && hasJ && is_sentinel(cJ)) || (need && hasK && is_sentinel(cK)))) {
+          __builtin_amdgcn_s_sleep(2);
+          request(c);
+          if (++spins > q.max_spins) { if (lane == 0) q.sc[S_ERR] = 1.0; break; }
+        }
+        lineJ[64 * c + lane] = (need && hasJ) ? cJ : 0.0;
+        lineK[64 * c + lane] = (need && hasK) ? cK : 0.0;
+        if (need && hasJ) const_cast<double *>(bJ)[64 * c + lane] = __longlong_as_double(-1LL);
+        if (need && hasK) const_cast<double *>(bK)[64 * c + lane] = __longlong_as_double(-1LL);
+        __builtin_amdgcn_wave_barrier();
+      };
+      request(0);
+      accept(0);
+      if (NCH > 1) request(1);
+      const double *pS = lineJ + kp, *pD = lineK + jp;
+      double *oJ = myJ + ((size_t)I * LB + kStreamLead - 7) * 8 + kp, *oK = myK + ((size_t)I * LB + kStreamLead - 7) * 8 + jp;   // line h - 7
+      double yprev = 0.0;
+      auto step = [&](int h, double r, double cd, double cs, double cw) {
+        const double a1 = lane_dpp<0x138>(yprev), aB = lane_shift(yprev, addrB);
+        const double nS = *pS, nD = *pD;
+        pS += 8; pD += 8;
+        const double yd = inD ? aB : nD, ys = inS ? a1 : nS, yw = h == hW ? yW : yprev;
+        double s = r;
+        s -= cd * yd;
+        s -= cs * ys;
+        s -= cw * yw;
+        yprev = s;
+        if (outJ && mJ) __hip_atomic_store(oJ, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (outK && mK) __hip_atomic_store(oK, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        oJ += 8; oK += 8;
+        return s;
+      };
+      for (int p0 = 0; p0 < NP; p0 += DP) {
+#pragma unroll
+        for (int u = 0; u < DP; ++u) {
+          const int p = p0 + u;
+          if (u % 4 == 0) {   // a chunk boundary: steps 2p .. 2p+7 read lines 8c .. 8c+7, c = p / 4
+            const int c = p >> 2;
+            if (p > 0 && c < NCH) { accept(c); if (c + 1 < NCH) request(c + 1); }
+          }
+          dpair out;
+          out.x = step(2 * p, rr[u].x, ld[u].x, ls[u].x, lw[u].x);
+          out.y = step(2 * p + 1, rr[u].y, ld[u].y, ls[u].y, lw[u].y);
+          dpair *dst = p < NP ? y2 + (size_t)p * 64 : sink;
+          *at_lane(dst, lane16) = out;
+          fetch(u, p + DP);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  }
+}
+template <int DP>
+__global__ __launch_bounds__(64) void k_box_upper_stream(BoxGrid g, StreamArgs q, const double *__restrict__ Ue, const double *__restrict__ Un,
+                                                         const double *__restrict__ Uu, const double *__restrict__ Di, double *x, double *scratch) {
+  static_assert(DP % 4 == 0, "a chunk of 8 steps is 4 row pairs");
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x, S = g.S, NP = S >> 1, NCH = S >> 3;
+  const int jp = lane & 7, kp = lane >> 3;
+  const int LB = stream_lines(g);
+  const int MRG = 2 * DP + 8;                         // lines of LDS in front of line 0 (the loop's last round runs below step 0)
+  double *lineJ = lds + (size_t)MRG * 8, *lineK = lineJ + (size_t)(S + MRG) * 8;
+  const size_t pen_stride = (size_t)g.NB1 * LB * 8;
+  const bool inN = jp != 7, inU = kp != 7, mJ = jp == 0, mK = kp == 0;
+  const int addrB = ((lane + 8) & 63) << 2;
+  const int hE = g.B1 - 1 + jp + kp;
+  const unsigned lane16 = threadIdx.x * 16u;
+  dpair *sink = reinterpret_cast<dpair *>(scratch);
+  for (;;) {
+    unsigned t = 0;
+    if (lane == 0) t = __hip_atomic_fetch_add(q.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - q.ticket_base;
+    t = __builtin_amdgcn_readfirstlane(t);
+    if (t >= (unsigned)q.npencils) return;
+    const int pen = q.order[t];
+    const int J = pen % g.NB2, K = pen / g.NB2;
+    const bool hasJ = J < g.NB2 - 1, hasK = K < g.NB3 - 1, outJ = J > 0, outK = K > 0;
+    const double *inJ = q.faceJ + (size_t)(hasJ ? pen + 1 : pen) * pen_stride, *inK = q.faceK + (size_t)(hasK ? pen + g.NB2 : pen) * pen_stride;
+    double *myJ = q.faceJ + (size_t)pen * pen_stride, *myK = q.faceK + (size_t)pen * pen_stride;
+    for (int I = g.NB1 - 1; I >= 0; --I) {
+      const int b = I + g.NB1 * pen;
+      const size_t row0 = (size_t)b * S * 64;
+      const dpair *Ue2 = reinterpret_cast<const dpair *>(Ue + row0), *Un2 = reinterpret_cast<const dpair *>(Un + row0),
+                  *Uu2 = reinterpret_cast<const dpair *>(Uu + row0), *Di2 = reinterpret_cast<const dpair *>(Di + row0);
+      dpair *x2 = reinterpret_cast<dpair *>(x + row0);
+      dpair ue[DP], un[DP], uu[DP], di[DP], rr[DP];
+      auto fetch = [&](int u, int p) {
+        const size_t o = (size_t)max(p, 0) * 64;
+        ue[u] = ldnt(at_lane(Ue2 + o, lane16)); un[u] = ldnt(at_lane(Un2 + o, lane16)); uu[u] = ldnt(at_lane(Uu2 + o, lane16));
+        di[u] = ldnt(at_lane(Di2 + o, lane16));
+        rr[u] = *at_lane(x2 + o, lane16);
+      };
+#pragma unroll
+      for (int u = 0; u < DP; ++u) { fetch(u, NP - 1 - u); __builtin_amdgcn_sched_barrier(0); }
+      double xE = *(I < g.NB1 - 1 ? x + box_slot(g, b + 1, jp + kp, lane) : x + row0);   // (the wave's own store of the box before)
+      if (I == g.NB1 - 1) xE = 0.0;
+      const double *bJ = inJ + ((size_t)I * LB + kStreamLead) * 8, *bK = inK + ((size_t)I * LB + kStreamLead) * 8;
+      double cJ = 0.0, cK = 0.0;
+      auto request = [&](int c) {
+        if (hasJ) cJ = __hip_atomic_load(bJ + 64 * c + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (hasK) cK = __hip_atomic_load(bK + 64 * c + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      };
+      auto accept = [&](int c) {
+        const bool need = 8 * c + (lane >> 3) >= 7;   // (lines below 7 have no producer step)
+        unsigned spins = 0;
+        while (__any((need && hasJ && is_sentinel(cJ)) || (need && hasK && is_sentinel(cK)))) {
+          __builtin_amdgcn_s_sleep(2);
+          request(c);
+          if (++spins > q.max_spins) { if (lane == 0) q.sc[S_ERR] = 1.0; break; }
+        }
+        lineJ[64 * c + lane] = (need && hasJ) ? cJ : 0.0;
+        lineK[64 * c + lane] = (need && hasK) ? cK : 0.0;
+        if (need && hasJ) const_cast<double *>(bJ)[64 * c + lane] = __longlong_as_double(-1LL);
+        if (need && hasK) const_cast<double *>(bK)[64 * c + lane] = __longlong_as_double(-1LL);
+        __builtin_amdgcn_wave_barrier();
+      };
+      request(NCH - 1);
+      accept(NCH - 1);
+      if (NCH > 1) request(NCH - 2);
+      const double *pN = lineJ + (size_t)(S - 1) * 8 + kp, *pU = lineK + (size_t)(S - 1) * 8 + jp;
+      double *oJ = myJ + ((size_t)I * LB + kStreamLead + S - 1 + 7) * 8 + kp, *oK = myK + ((size_t)I * LB + kStreamLead + S - 1 + 7) * 8 + jp;   // line h + 7
+      double xprev = 0.0;
+      auto step = [&](int h, double r, double ce, double cn, double cu, double d) {
+        const double a1 = lane_dpp<0x130>(xprev), aB = lane_shift(xprev, addrB);
+        const double nN = *pN, nU = *pU;
+        pN -= 8; pU -= 8;
+        const double xe = h == hE ? xE : xprev, xn = inN ? a1 : nN, xu = inU ? aB : nU;
+        double s = r;
+        s -= ce * xe;
+        s -= cn * xn;
+        s -= cu * xu;
+        s *= d;
+        xprev = s;
+        if (outJ && mJ) __hip_atomic_store(oJ, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (outK && mK) __hip_atomic_store(oK, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        oJ -= 8; oK -= 8;
+        return s;
+      };
+      for (int p0 = NP - 1; p0 >= 0; p0 -= DP) {
+#pragma unroll
+        for (int u = 0; u < DP; ++u) {
+          const int p = p0 - u;
+          if (u % 4 == 0) {   // steps 2p+1 .. 2p-6 read lines 8c+7 .. 8c, c = p / 4 (NP is a multiple of 4: p = 3 mod 4 here)
+            const int c = p >> 2;
+            if (p < NP - 1 && c >= 0 && p >= 0) { accept(c); if (c >= 1) request(c - 1); }
+          }
+          dpair out;
+          out.y = step(2 * p + 1, rr[u].y, ue[u].y, un[u].y, uu[u].y, di[u].y);
+          out.x = step(2 * p, rr[u].x, ue[u].x, un[u].x, uu[u].x, di[u].x);
+          dpair *dst = p >= 0 ? x2 + (size_t)p * 64 : sink;
+          *at_lane(dst, lane16) = out;
+          fetch(u, p - DP);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  }
+}
+
 // Numeric ILU(0) of the same grids, box by box.  On a 7-point pattern (extents other than 2) no upper entry of a pivot row meets
 // an off-diagonal entry of the row being eliminated, so only the diagonal changes: with the pivots in ascending order (down,
 // south, west) m = a(c,k) / u(k,k) replaces a(c,k) and u(c,c) -= m * a(k,c) -- the arithmetic of the elimination program of
@@ -2715,6 +2951,19 @@ void launch_box_solve_queue(const BoxGrid &g, const BoxQueueArgs &lo, const BoxQ
   qu.max_spins = up.max_spins; qu.sc = up.sc;
   hipLaunchKernelGGL((k_box_lower_queue<kBoxRing>), dim3(lo.nworkers), dim3(64), lds, stream, g, ql, L[0], L[1], L[2], v, scratch);
   hipLaunchKernelGGL((k_box_upper_queue<kBoxRingUpper>), dim3(up.nworkers), dim3(64), lds, stream, g, qu, U[0], U[1], U[2], Di, v, scratch);
+}
+bool box_stream_applies(const BoxGrid &g) { return g.B2 == 8 && g.B3 == 8 && g.S % 8 == 0 && g.S >= 16; }
+size_t box_stream_face_doubles(const BoxGrid &g) { return (size_t)g.NB1 * g.NB2 * g.NB3 * stream_lines(g) * 8; }
+void launch_box_solve_stream(const BoxGrid &g, const BoxStreamArgs &a, const double *const L[3], const double *const U[3], const double *Di,
+                             double *v, double *scratch, hipStream_t stream) {
+  constexpr int DPS = 8;
+  if (a.npencils <= 0) return;
+  const size_t one = box_stream_face_doubles(g);
+  StreamArgs lo{a.order_lower, a.npencils, a.ticket, a.ticket_base[0], a.max_spins, a.sc, a.faces, a.faces + one};
+  StreamArgs up{a.order_upper, a.npencils, a.ticket + 1, a.ticket_base[1], a.max_spins, a.sc, a.faces + 2 * one, a.faces + 3 * one};
+  const size_t lds_lo = (size_t)2 * (g.S + 2 * DPS + 8) * 8 * sizeof(double), lds_up = (size_t)2 * (g.S + 2 * DPS + 8) * 8 * sizeof(double);
+  hipLaunchKernelGGL((k_box_lower_stream<DPS>), dim3(a.nworkers), dim3(64), lds_lo, stream, g, lo, L[0], L[1], L[2], v, scratch);
+  hipLaunchKernelGGL((k_box_upper_stream<DPS>), dim3(a.nworkers), dim3(64), lds_up, stream, g, up, U[0], U[1], U[2], Di, v, scratch);
 }
 void launch_gather(int n, const int *idx, const double *in, double *out, hipStream_t stream) {
   if (n > 0) LAUNCH(k_gather, dim3(nblk(n)), n, idx, in, out);

@@ -308,6 +308,19 @@ struct BoxQueueArgs {
   unsigned *flags; unsigned epoch; unsigned *ticket; unsigned ticket_base, max_spins;
   double *sc;
 };
+// Both solves as streams (k_box_lower_stream): a wave owns a pencil (the NB1 boxes of one (J, K)), pencils handed out by ticket in the
+// order of J + K, faces handed over 8 steps at a time through face buffers whose initial value (all bits set) is the "not yet" mark.
+// faces: 4 x box_stream_face_doubles(g) doubles, every byte 0xFF before the first application (each application leaves them so);
+// ticket: two counters (lower, upper), ticket_base what earlier launches took (npencils + nworkers per launch).
+bool box_stream_applies(const BoxGrid &g);   // B2 = B3 = 8, S a multiple of 8
+size_t box_stream_face_doubles(const BoxGrid &g);
+struct BoxStreamArgs {
+  const int *order_lower, *order_upper; int npencils, nworkers;
+  unsigned *ticket; unsigned ticket_base[2]; unsigned max_spins;
+  double *sc, *faces;
+};
+void launch_box_solve_stream(const BoxGrid &g, const BoxStreamArgs &a, const double *const L[3], const double *const U[3], const double *Di,
+                             double *v, double *scratch, hipStream_t stream);
 void launch_box_solve_queue(const BoxGrid &g, const BoxQueueArgs &lower, const BoxQueueArgs &upper, const double *const L[3],
                             const double *const U[3], const double *Di, double *v, double *scratch, hipStream_t stream);
 

@@ -209,6 +209,8 @@ struct Options {
   bool th_fused_dots = true;   // coupled TH, bjacobi: the Krylov dot products of M^{-1} r come out of the block column solve
   int ilu_box = 1;             // ILU(0) solves box by box when the pattern is a structured grid in natural ordering (BoxGrid); 0: never, 2: or fail
   bool ilu_box_factor = true;  // ... and the numeric factorisation too (extents other than 2); false: by the elimination program of the general path
+  bool ilu_box_stream = false; // ... as streams: a wave owns the NB1 boxes of one (J, K), pencils by ticket in the order of J + K, faces handed over 8 steps
+                               // at a time through sentinel-initialised face buffers (k_box_lower_stream); needs 8 x 8 box cross-sections
   bool ilu_box_queue = false;  // ... with ONE launch per triangle: boxes handed out by ticket in level order to ilu_box_workers resident waves, a box
                                // waits for its three predecessors' flags (k_box_lower_queue; liveness independent of the dispatch order)
   int ilu_box_workers = 1024;

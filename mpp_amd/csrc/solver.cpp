@@ -273,7 +273,10 @@ struct Solver {
   DevBuf<double> box_L[3], box_U[3], box_Di, box_v, box_scratch, box_T[3];
   GraphSeq box_graph, box_fgraph;
   // one launch per triangle (k_box_lower_queue / k_box_upper_queue): boxes by ticket in level order, completion flags
-  DevBuf<int> box_order_rev;
+  DevBuf<int> box_order_rev, pen_order, pen_order_rev;   // pencils (J + NB2 K) by J + K, ascending / descending
+  DevBuf<double> box_faces;                               // face buffers of the streamed solves (4 x box_stream_face_doubles), all bits set when idle
+  unsigned pen_ticket_base[2] = {0, 0};
+  bool box_stream_ready = false;
   DevBuf<unsigned> box_flags, box_ticket;     // flags: [lower: nboxes][upper: nboxes]; ticket: one counter per triangle
   unsigned box_epoch = 0, box_ticket_base[2] = {0, 0};
   long long box_queue_fallbacks = 0;
@@ -1562,6 +1565,28 @@ struct Solver {
     for (int l = 0; l < nl; ++l) graph_tick(), launch_box_lower(box, box_order.p + box_lptr[l], box_lptr[l + 1] - box_lptr[l], L, box_v.p, box_scratch.p, stream);
     for (int l = nl - 1; l >= 0; --l) graph_tick(), launch_box_upper(box, box_order.p + box_lptr[l], box_lptr[l + 1] - box_lptr[l], U, box_Di.p, box_v.p, box_scratch.p, stream);
   }
+  // both box solves as streams (k_box_lower_stream): set-up on first use
+  bool box_stream() const { return opt.ilu_box_stream && box_stream_applies(box); }
+  void box_solve_stream() {
+    const int npen = box.NB2 * box.NB3;
+    if (!box_stream_ready) {
+      std::vector<int> ord(npen);
+      std::iota(ord.begin(), ord.end(), 0);
+      std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return a % box.NB2 + a / box.NB2 < b % box.NB2 + b / box.NB2; });
+      pen_order.upload(ord, stream);
+      std::vector<int> rev(ord.rbegin(), ord.rend());
+      pen_order_rev.upload(rev, stream);
+      box_faces.alloc(4 * box_stream_face_doubles(box));
+      HIP_CHECK(hipMemsetAsync(box_faces.p, 0xFF, box_faces.n * sizeof(double), stream));   // "not yet": every value a NaN with all bits set
+      box_stream_ready = true;
+    }
+    const double *const L[3] = {box_L[0].p, box_L[1].p, box_L[2].p}, *const U[3] = {box_U[0].p, box_U[1].p, box_U[2].p};
+    const int nworkers = std::max(1, std::min(npen, opt.ilu_box_workers));
+    BoxStreamArgs a{pen_order.p, pen_order_rev.p, npen, nworkers, box_ticket.p + 2, {pen_ticket_base[0], pen_ticket_base[1]}, opt.ilu_chain_spins, sc.p, box_faces.p};
+    launch_box_solve_stream(box, a, L, U, box_Di.p, box_v.p, box_scratch.p, stream);
+    pen_ticket_base[0] += (unsigned)npen + (unsigned)nworkers;
+    pen_ticket_base[1] += (unsigned)npen + (unsigned)nworkers;
+  }
   // both box solves with one launch per triangle (tickets + flags)
   void box_solve_queue() {
     const double *const L[3] = {box_L[0].p, box_L[1].p, box_L[2].p}, *const U[3] = {box_U[0].p, box_U[1].p, box_U[2].p};
@@ -1629,8 +1654,8 @@ struct Solver {
       if (box_gather_in_fits(box)) launch_box_gather_in(box, d_ext2int.p, r, box_v.p, stream);   // r into the box layout, padding zero
       else launch_gather_or_zero(box_slots, box_cellmap.p, r, box_v.p, stream);
       bool solved = false;
-      if (opt.ilu_box_queue) {
-        box_solve_queue();
+      if (box_stream() || opt.ilu_box_queue) {
+        if (box_stream()) box_solve_stream(); else box_solve_queue();
         solved = !chain_timed_out();   // (a wait ran out of spins: the application is redone per level, the queue stays off)
         if (!solved) {
           ++box_queue_fallbacks;
@@ -2912,7 +2937,7 @@ struct Solver {
     HIP_CHECK(hipMemcpyAsync(&e, sc.p + S_ERR, sizeof(double), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
     if (e == 0.0) return false;
-    opt.ilu_chain = 0; opt.ilu_box_queue = false;
+    opt.ilu_chain = 0; opt.ilu_box_queue = false; opt.ilu_box_stream = false;   // (a streamed solve that gave up leaves its face buffers unusable)
     if (chain_fallbacks++ == 0)
       std::fprintf(stderr, "mppgpu: a flag-chained ILU(0) solve timed out waiting for a tile or box (spin budget %u); redone with one launch per "
                            "level, chained solves are off for this handle from now on\n", opt.ilu_chain_spins);
@@ -3127,7 +3152,7 @@ struct Solver {
     g.B1 = opt.ilu_box_len > 0 ? opt.ilu_box_len : (N >= (1 << 25) ? 64 : 32);   // longer boxes: less padding, fewer levels
     g.B1 = std::max(1, std::min(std::min(g.B1, g.n1), kBoxMaxLen));
     g.NB1 = (g.n1 + g.B1 - 1) / g.B1; g.NB2 = (g.n2 + g.B2 - 1) / g.B2; g.NB3 = (g.n3 + g.B3 - 1) / g.B3;
-    g.S = (g.B1 + g.B2 + g.B3 - 2 + 1) / 2 * 2;
+    g.S = (g.B1 + g.B2 + g.B3 - 2 + 7) / 8 * 8;   // step rows per box: a multiple of 8 (rows go in pairs; the streamed solves hand faces over 8 steps at a time)
     const long long nboxes = (long long)g.NB1 * g.NB2 * g.NB3, slots = nboxes * g.S * 64;
     if (slots >= (1ll << 31)) return;
     std::vector<int> cellmap((size_t)slots, -1), cellpos(N), order((size_t)nboxes);
@@ -3151,7 +3176,7 @@ struct Solver {
       std::vector<int> rev(order.rbegin(), order.rend());
       box_order_rev.upload(rev, stream);
       box_flags.alloc(2 * (size_t)nboxes); box_flags.zero(stream);
-      box_ticket.alloc(2); box_ticket.zero(stream);
+      box_ticket.alloc(4); box_ticket.zero(stream);   // [0, 1]: the queued solves' counters, [2, 3]: the streamed solves'
       box_epoch = 0; box_ticket_base[0] = box_ticket_base[1] = 0;
     }
     for (int k = 0; k < 3; ++k) { box_L[k].alloc((size_t)slots); box_U[k].alloc((size_t)slots); }
@@ -3233,6 +3258,7 @@ struct Solver {
     else if (key == "th_fused_dots") opt.th_fused_dots = num() != 0;
     else if (key == "ilu_box") { opt.ilu_box = (int)num(); pc_ready = false; }   // the factors are repacked for the other solve path
     else if (key == "ilu_box_factor") { opt.ilu_box_factor = num() != 0; pc_ready = false; }
+    else if (key == "ilu_box_stream") opt.ilu_box_stream = num() != 0;     // box solves as streams: pencils by ticket, faces handed over 8 steps at a time
     else if (key == "ilu_box_queue") opt.ilu_box_queue = num() != 0;       // box solves: one launch per triangle (tickets + flags)
     else if (key == "ilu_box_workers") opt.ilu_box_workers = std::max(1, (int)num());   // ... on this many resident waves
     else if (key == "ilu_box_len") {
@@ -3733,7 +3759,7 @@ int mppgpu_get_pc_info(mppgpu_handle h, int *path, int *launches, int *box_exten
   int p = 0, n = 0, ext[3] = {0, 0, 0};
   if (S.opt.pc_type == 1 && S.pc_ready) {
     if (S.box_active()) {
-      p = 3; n = S.opt.ilu_box_queue ? 4 : 2 * ((int)S.box_lptr.size() - 1) + 2;
+      p = 3; n = (S.box_stream() || S.opt.ilu_box_queue) ? 4 : 2 * ((int)S.box_lptr.size() - 1) + 2;
       ext[0] = S.box.B1; ext[1] = S.box.B2; ext[2] = S.box.B3;
     } else if (S.ilu_chained()) { p = 2; n = 5; }
     else { p = 1; n = (int)S.h_lptr.size() - 2 + (int)S.h_uptr.size() - 1 + 3; }

@@ -197,16 +197,23 @@ struct ThRowAcc {      // what a row accumulates before it is written
   double aPP, aPT, aTP, aTT;        // diagonal entries: accumulation part
   double lPP, lPT, lTP, lTT;        // coupling to the cell below
 };
-template <int MODE>
-__global__ __launch_bounds__(kBlock) void k_th_cols(ThArgs a) {
+// Registers (round 4): the march carried the level below (15 auxvar values) and its unfinished row (14 sums) through the evaluation
+// of the current cell's equation of state -- the part that needs the most registers -- and ran at 256 + 60 registers, one wave per
+// SIMD, on code that is bound by instruction issue.  The 29 values are parked in LDS across that evaluation (one column of a
+// [29][block] array per thread: no bank conflicts, no barrier) and the kernel is compiled for two waves per SIMD.
+constexpr int kColsBlock = 128, kParked = 29;
+template <int MODE, int EOS_T>   // EOS_T: th_auxvar_compute's (1: IFC-67 density + enthalpy at compile time, -1: run-time choice)
+__global__ __launch_bounds__(kColsBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_th_cols(ThArgs a) {
   constexpr bool JAC = (MODE == 2);
-  MPP_STAGE_POW(a.powtab);
-  const int c = blockIdx.x * kBlock + threadIdx.x;
+  __shared__ double pow_lds_[kPowTableDoubles];
+  __shared__ double park[kParked][kColsBlock];
+  const PowTab pt = stage_pow_tables(a.powtab, pow_lds_);
+  const int c = blockIdx.x * kColsBlock + threadIdx.x;
   if (c >= a.ncols) return;
   const int nz = a.nz;
   const int tile = c >> 6, tw = min(64, a.ncols - (tile << 6));
   const size_t cbase = (size_t)tile * 64 * nz + (c & 63), n = (size_t)a.n;
-  ThAux prev;
+  ThAux prev = {};
   bool prev_act = false;
   ThRowAcc rp = {};
   for (int k = 0; k <= nz; ++k) {
@@ -220,7 +227,28 @@ __global__ __launch_bounds__(kBlock) void k_th_cols(ThArgs a) {
       const Soil s = th_load_soil(a, i);
       const ThSoil ts{a.tc_wet[i], a.tc_dry[i], a.talpha[i]};
       const double P = a.x[i], T = a.x[n + i];
-      cur = th_auxvar_compute<true>(s.sf, a.density_type, a.ie_type, s, ts, P, T, true, pt);
+      {   // park the carried state across the equation of state
+        const int t = threadIdx.x;
+        const double v[kParked] = {prev.P, prev.T, prev.kr, prev.dkr, prev.den_m, prev.ddenP_m, prev.ddenT_m, prev.den_e, prev.ddenP_e, prev.ddenT_e,
+                                   prev.hl, prev.dhl_dP, prev.dhl_dT, prev.tc, prev.dtc_dP, rp.fm, rp.fe, rp.dPP, rp.dPT, rp.dTP, rp.dTT, rp.aPP, rp.aPT,
+                                   rp.aTP, rp.aTT, rp.lPP, rp.lPT, rp.lTP, rp.lTT};
+#pragma unroll
+        for (int q = 0; q < kParked; ++q) park[q][t] = v[q];
+        asm volatile("" ::: "memory");
+      }
+      cur = th_auxvar_compute<true, EOS_T>(s.sf, a.density_type, a.ie_type, s, ts, P, T, true, pt);
+      {
+        asm volatile("" ::: "memory");
+        const int t = threadIdx.x;
+        double v[kParked];
+#pragma unroll
+        for (int q = 0; q < kParked; ++q) v[q] = park[q][t];
+        prev.P = v[0]; prev.T = v[1]; prev.kr = v[2]; prev.dkr = v[3]; prev.den_m = v[4]; prev.ddenP_m = v[5]; prev.ddenT_m = v[6];
+        prev.den_e = v[7]; prev.ddenP_e = v[8]; prev.ddenT_e = v[9]; prev.hl = v[10]; prev.dhl_dP = v[11]; prev.dhl_dT = v[12];
+        prev.tc = v[13]; prev.dtc_dP = v[14];
+        rp.fm = v[15]; rp.fe = v[16]; rp.dPP = v[17]; rp.dPT = v[18]; rp.dTP = v[19]; rp.dTT = v[20]; rp.aPP = v[21]; rp.aPT = v[22];
+        rp.aTP = v[23]; rp.aTT = v[24]; rp.lPP = v[25]; rp.lPT = v[26]; rp.lTP = v[27]; rp.lTT = v[28];
+      }
       const double vol = a.vol[i], dsoil = a.den_soil[i], csoil = a.heat_cap[i];
       double fm = 0.0, fe = 0.0;
       rc.aPP = rc.aPT = rc.aTP = rc.aTT = 1.0;
@@ -502,7 +530,12 @@ void launch_th_assemble(int mode, const ThBcArgs &b, hipStream_t stream) {
   const dim3 grid = nblk(a.n);
   if (mode == 3) { TH_LAUNCH(k_th_aux<3>, grid, a); return; }
   if (a.use_cols) {
-    if (mode == 0) TH_LAUNCH(k_th_cols<0>, nblk(a.ncols), a); else TH_LAUNCH(k_th_cols<2>, nblk(a.ncols), a);
+    const bool ifc = a.density_type == kDenIFC67 && a.ie_type == kIEIFC67;
+    const dim3 gc((unsigned)((a.ncols + kColsBlock - 1) / kColsBlock));
+#define TH_COLS(M, E) hipLaunchKernelGGL((k_th_cols<M, E>), gc, dim3(kColsBlock), 0, stream, a)
+    if (mode == 0) { if (ifc) TH_COLS(0, 1); else TH_COLS(0, -1); }
+    else { if (ifc) TH_COLS(2, 1); else TH_COLS(2, -1); }
+#undef TH_COLS
   } else if (mode == 0) { TH_LAUNCH(k_th_aux<0>, grid, a); TH_LAUNCH(k_th_rows<0>, grid, a); }
   else { TH_LAUNCH(k_th_aux<2>, grid, a); TH_LAUNCH(k_th_rows<2>, grid, a); }
   if (b.ncond_cells > 0) {

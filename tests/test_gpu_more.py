@@ -275,3 +275,35 @@ def test_two_vertical_connections_between_the_same_pair_of_cells_are_not_taken_f
     info = g.soe.assembly_info()
     assert info["column_segments"] == 0 and not info["complete_rows"]      # not the column march
     _operator_parity(prob, x, {"assembly": "general"})
+
+
+def test_thermal_workload_on_four_in_process_ranks_equals_the_single_handle_solve():
+    """`bench.py --workload thermal --gpus 4` (BASELINE config 4's rank count) on one GPU: every rank builds its own z-slab
+    (workloads.thermal_mms_rank: no global mesh), the four handles form one global GMRES(30) + rank-local ILU(0) solve through the
+    in-process group (halo exchange before the operator assembly and every SpMV, all-reduced dots); at ksp_rtol 1e-11 the owned
+    cells reproduce the single-handle solution, and every rank took the same number of iterations"""
+    from mpp_amd import vsfm as V
+    n, world = 16, 4
+    opts = {"ksp_type": "gmres", "pc_type": "ilu", "ksp_rtol": 1e-11}
+    tp = P.thermal_mms(3, n, n, n, replicate_reference_soil_indexing=False)
+    ref = P.to_thermal_gpu(tp, opts)
+    ref.soe.PreStepDT()
+    assert ref.soe.StepDT(tp.dt)[0]
+    t_ref = ref.soe.GetSoln()
+    ranks = [P.thermal_mms_rank(n, n, n, world, r) for r in range(world)]
+    gs = [P.to_thermal_gpu(lp, opts) for _, lp in ranks]
+    V.comm_init_local([g.soe for g in gs])
+
+    def step(g):
+        g.soe.PreStepDT()
+        conv, _ = g.soe.StepDT(tp.dt)
+        return conv, g.soe.last_linear_iterations
+
+    res = _run_ranks([lambda g=g: step(g) for g in gs])
+    assert all(c for c, _ in res) and len({its for _, its in res}) == 1
+    for (part, lp), g in zip(ranks, gs):
+        t = g.soe.GetSoln()
+        # two different preconditioners stopped at 1e-11 of their own preconditioned residual norms: measured 1.1e-8 K on 270 K
+        assert np.abs(t[:part.nowned] - t_ref[part.l2g[:part.nowned]]).max() <= 1e-7
+        assert np.abs(t[:part.nowned] - lp.exact[:part.nowned]).max() < 0.5      # ... and the manufactured solution to the discretisation error
+    assert gs[0].soe.pc_info()["path"] == "boxes"                                # whole z-slabs are structured grids: solved by boxes

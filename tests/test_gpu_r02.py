@@ -374,14 +374,18 @@ def test_box_ilu_solves_reproduce_the_level_scheduled_ones_bit_for_bit(dims, box
     assert bi["box_extents"][1] * bi["box_extents"][2] == 64
     # ... and with ONE launch per triangle (boxes by ticket in level order, completion flags; round 4): the same bits again, on many
     # resident waves and on three (every box then waits for boxes the same wave solved a moment ago, or that two others are solving)
-    for workers in (1024, 3):
-        que = P.to_thermal_gpu(tp, {"ksp_type": "gmres", "pc_type": "ilu", "ilu_box": 2, "ilu_box_len": box_len, "ilu_box_queue": 1,
-                                    "ilu_box_workers": workers})
-        assert que.soe.StepDT(tp.dt, 1)[0]
-        assert que.soe.last_linear_iterations == lev.soe.last_linear_iterations
-        assert np.array_equal(que.soe.GetSoln(), lev.soe.GetSoln())
-        assert que.soe.comm_stats()["chain_fallbacks"] == 0
-        assert que.soe.pc_info()["launches"] == 4 or min(dims) == 1
+    for mode in ("ilu_box_queue", "ilu_box_stream"):   # (streams: pencils of boxes with faces handed over 8 steps at a time; 8 x 8 cross-sections only)
+        for workers in (1024, 3):
+            que = P.to_thermal_gpu(tp, {"ksp_type": "gmres", "pc_type": "ilu", "ilu_box": 2, "ilu_box_len": box_len, mode: 1,
+                                        "ilu_box_workers": workers})
+            assert que.soe.StepDT(tp.dt, 1)[0]
+            assert que.soe.last_linear_iterations == lev.soe.last_linear_iterations
+            assert np.array_equal(que.soe.GetSoln(), lev.soe.GetSoln())
+            assert que.soe.comm_stats()["chain_fallbacks"] == 0
+            if mode == "ilu_box_queue":
+                assert que.soe.pc_info()["launches"] == 4 or min(dims) == 1
+            elif dims[2] >= 8:
+                assert que.soe.pc_info()["launches"] == 4      # the streamed route was really taken
 
 
 @pytest.mark.parametrize("dims", [(2, 9, 5), (9, 2, 5), (11, 7, 2), (13, 2, 1), (3, 3, 3)])
@@ -410,8 +414,9 @@ def test_box_ilu_applications_on_the_3d_vsfm_jacobian():
     x = prob.press_ic - np.random.default_rng(2).uniform(0, 2.5e5, n)
     box = P.to_gpu(prob, {"ksp_type": "gmres", "pc_type": "ilu", "ilu_box": 2})
     que = P.to_gpu(prob, {"ksp_type": "gmres", "pc_type": "ilu", "ilu_box": 2, "ilu_box_queue": 1})   # one launch per triangle
+    stm = P.to_gpu(prob, {"ksp_type": "gmres", "pc_type": "ilu", "ilu_box": 2, "ilu_box_stream": 1})  # ... as streams of pencils
     lev = P.to_gpu(prob, {"ksp_type": "gmres", "pc_type": "ilu", "ilu_box": 0, "ilu_chain": 0})
-    for g in (box, que, lev):
+    for g in (box, que, stm, lev):
         g.soe.SetDtime(prob.dt); g.soe.PreSolve()
         g.soe.ComputeJacobian(x)
     rng = np.random.default_rng(17)
@@ -420,7 +425,9 @@ def test_box_ilu_applications_on_the_3d_vsfm_jacobian():
         z = lev.soe.PCApply(v)
         assert np.array_equal(box.soe.PCApply(v), z), rep
         assert np.array_equal(que.soe.PCApply(v), z), rep
-    assert que.soe.comm_stats()["chain_fallbacks"] == 0
+        assert np.array_equal(stm.soe.PCApply(v), z), rep
+    assert que.soe.comm_stats()["chain_fallbacks"] == 0 and stm.soe.comm_stats()["chain_fallbacks"] == 0
+    assert stm.soe.pc_info()["launches"] == 4
     assert box.soe.StepDT(prob.dt, 1) == lev.soe.StepDT(prob.dt, 1)
     assert box.soe.counters() == lev.soe.counters()
     assert np.array_equal(box.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1),

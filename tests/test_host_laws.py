@@ -1,6 +1,8 @@
 """The constitutive laws the library evaluates on the host for drivers (mppgpu_host_density / _internal_energy_enthalpy /
 _sat_relperm, mpp_amd.laws) against the CPU oracle, and the product's th_mms workload (manufactured sources formed with
 them, th_mms_problem.F90:901-934, 1262-1452) against the oracle-side builder of the same problem.  No GPU."""
+import os
+
 import numpy as np
 import pytest
 
@@ -73,3 +75,26 @@ def test_th_mms_workload_equals_the_oracle_side_builder():
     ha, hb = a.energy_sss[0][2], b.energy_sss[0][2]
     assert np.abs(ma - mb).max() <= 1e-14 * np.abs(mb).max()
     assert np.abs(ha - hb).max() <= 1e-11 * np.abs(hb).max()
+
+
+def test_shared_ifc67_evaluation_of_the_coupled_kernels_matches_the_term_by_term_functions():
+    """th_physics.hpp's ifc67_temperature_terms / ifc67_at_pressure (one temperature, two pressures, reciprocals formed once: what
+    k_th_cols evaluates per cell) against density_ifc67_pt<true> / enthalpy_ifc67<true> of the same header (the reference's formulas
+    with libm's pow, what the oracle restates), 0.05-100 degC x 100 Pa-20 MPa, on the host (tests/th_eos_check.cpp).  Differences
+    are rounding-level against the size of the terms; the enthalpy and dH/dT pass through cancellations near 0 degC and 4 degC"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    out = os.path.join(root, "tests", "_build")
+    os.makedirs(out, exist_ok=True)
+    exe, src = os.path.join(out, "th_eos_check"), os.path.join(root, "tests", "th_eos_check.cpp")
+    hdrs = [os.path.join(root, "mpp_amd", "csrc", h) for h in ("th_physics.hpp", "physics.hpp", "fastpow.hpp")]
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(map(os.path.getmtime, [src] + hdrs)):
+        subprocess.check_call([hipcc, "-O2", "-o", exe, src], stderr=subprocess.DEVNULL)
+    vals = subprocess.check_output([exe], text=True).split()
+    n, (d, dp, dt, h, hp, ht) = int(vals[0]), map(float, vals[1:])
+    assert n > 100_000
+    assert d < 1e-14 and dp < 1e-13 and dt < 1e-12 and hp < 1e-13      # measured 6e-16, 1.5e-15, 3.5e-14, 1.2e-15
+    assert h < 1e-8 and ht < 1e-10                                     # measured 1.3e-10 (of |H| + 1e4 J/kmol, H -> 0 at 0 degC), 2.3e-12
