@@ -162,6 +162,10 @@ __global__ __launch_bounds__(kBlock) void k_accum(CellArrays ca, int n, double d
 // cell state, source, the residual to eliminate); fetches are unconditional loads with the level index clamped, so every
 // path issues the same number of operations and the compiler can count them instead of draining the queue.  The first CSR
 // slot of a row is computed, not loaded: rows of a column tile are level-major with 2 entries in the end rows and 3 between.
+#ifndef MPP_MARCH_DEPTH_RESIDUAL
+#define MPP_MARCH_DEPTH_RESIDUAL 2
+#endif
+constexpr int kMarchDepthResidual = MPP_MARCH_DEPTH_RESIDUAL;
 template <int MODE, int SAT_T, int DEN_T, bool FUSE>  // MODE 0 residual, 1 Jacobian, 2 both; SAT_T / DEN_T: see physics.hpp
 __global__ __launch_bounds__(kBlock) void k_assemble_cols(ColsArgs a) {
   __shared__ double red[kBlock / 64];
@@ -390,20 +394,22 @@ __global__ __launch_bounds__(kBlock) void k_assemble_cols(ColsArgs a) {
       src_prev = L.src; Fin_prev = L.Fin;
     };
 
-    Level LA = fetch(kstart);
-    __builtin_amdgcn_sched_barrier(0);
-    Level LB = fetch(kstart + 1);
-    __builtin_amdgcn_sched_barrier(0);
-    for (int k = kstart; k < kend; k += 2) {
-      process(k, LA);
-      __builtin_amdgcn_sched_barrier(0);   // program order = issue order: a register set is refilled right after its use
-      LA = fetch(k + 2);
-      __builtin_amdgcn_sched_barrier(0);
-      if (k + 1 < kend) {
-        process(k + 1, LB);
-        __builtin_amdgcn_sched_barrier(0);
-        LB = fetch(k + 3);
-        __builtin_amdgcn_sched_barrier(0);
+    // DEPTH register sets rotate (named by a compile-time index: no copies).  Two levels in flight per wave; the residual-only pass (which
+    // streams least per level) was also built 3 and 4 deep in round 4: 0.716 / 0.709 / 0.713 ms at depth 3 / 2 / 4, 1024 x 1024 x 100
+    // (profiles/r04/kbench_march_depth.json): depth is not what holds it at 0.67 of the peak on the bytes it moves
+    constexpr int DEPTH = (MODE == 0 && !GEN) ? kMarchDepthResidual : 2;
+    Level LV[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) { LV[d] = fetch(kstart + d); __builtin_amdgcn_sched_barrier(0); }
+    for (int k = kstart; k < kend; k += DEPTH) {
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) {
+        if (d == 0 || k + d < kend) {
+          process(k + d, LV[d]);
+          __builtin_amdgcn_sched_barrier(0);   // program order = issue order: a register set is refilled right after its use
+          LV[d] = fetch(k + d + DEPTH);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
     if (kend == nz && k1 == nz) finish_row(nz - 1, cbase + (size_t)(nz - 1) * tw, true);  // top row of the column
@@ -1756,9 +1762,16 @@ struct StreamArgs {
   double *sc;
   double *faceJ, *faceK;   // this triangle's face buffers: [pencil][box I][line][8]
 };
-template <int DP>
-__global__ __launch_bounds__(64) void k_box_lower_stream(BoxGrid g, StreamArgs q, const double *__restrict__ Ld, const double *__restrict__ Ls,
-                                                         const double *__restrict__ Lw, double *y, double *scratch) {
+// GATHER: the right-hand side is read from `rvec` (the Krylov vector, internal row order) through the slot map `cellmap` (internal row
+// of every slot, -1 for padding) instead of from y -- no k_box_gather_in pass in front of the solve.  A lane walks consecutive cells
+// of one grid line, i.e. consecutive rows of a column tile: its 8-byte reads fill whole cache lines over 8 steps.  A padding slot
+// reads row 0 instead of a zero: its value only ever meets zero coefficients (and stays finite).  The indices of a row pair travel
+// with its factor entries (DP pairs ahead), the values DP / 2 pairs ahead.
+typedef int ipair __attribute__((ext_vector_type(2)));
+template <int DP, bool GATHER>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_box_lower_stream(BoxGrid g, StreamArgs q, const double *__restrict__ Ld, const double *__restrict__ Ls,
+                                                         const double *__restrict__ Lw, double *y, double *scratch,
+                                                         const double *__restrict__ rvec, const int *__restrict__ cellmap) {
   static_assert(DP % 4 == 0, "a chunk of 8 steps is 4 row pairs");
   extern __shared__ double lds[];
   const int lane = threadIdx.x, S = g.S, NP = S >> 1, NCH = S >> 3;
@@ -1787,14 +1800,22 @@ __global__ __launch_bounds__(64) void k_box_lower_stream(BoxGrid g, StreamArgs q
       const dpair *Ld2 = reinterpret_cast<const dpair *>(Ld + row0), *Ls2 = reinterpret_cast<const dpair *>(Ls + row0),
                   *Lw2 = reinterpret_cast<const dpair *>(Lw + row0);
       dpair *y2 = reinterpret_cast<dpair *>(y + row0);
+      const ipair *cm2 = reinterpret_cast<const ipair *>(cellmap + row0);
       dpair ld[DP], ls[DP], lw[DP], rr[DP];
+      ipair ix[GATHER ? DP : 1];
       auto fetch = [&](int u, int p) {
         const size_t o = (size_t)min(p, NP - 1) * 64;
         ld[u] = ldnt(at_lane(Ld2 + o, lane16)); ls[u] = ldnt(at_lane(Ls2 + o, lane16)); lw[u] = ldnt(at_lane(Lw2 + o, lane16));
-        rr[u] = *at_lane(y2 + o, lane16);
+        if (GATHER) ix[u] = ldnt(at_lane(cm2 + o, threadIdx.x * 8u));
+        else rr[u] = *at_lane(y2 + o, lane16);
+      };
+      auto gather = [&](int u) {   // the two right-hand side values of the row pair whose indices sit in ix[u]
+        if (GATHER) { rr[u].x = rvec[max(ix[u].x, 0)]; rr[u].y = rvec[max(ix[u].y, 0)]; }
       };
 #pragma unroll
       for (int u = 0; u < DP; ++u) { fetch(u, u); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+      for (int u = 0; u < DP / 2; ++u) { gather(u); __builtin_amdgcn_sched_barrier(0); }
       double yW = *(I > 0 ? y + box_slot(g, b - 1, g.B1 - 1 + hW, lane) : y + row0);   // (the wave's own store of the box before)
       if (I == 0) yW = 0.0;
       // the incoming faces of this box: chunk c = lines 8c .. 8c+7, lane l holds element (line 8c + l/8, l%8)
@@ -1853,15 +1874,18 @@ __global__ __launch_bounds__(64) void k_box_lower_stream(BoxGrid g, StreamArgs q
           dpair *dst = p < NP ? y2 + (size_t)p * 64 : sink;
           *at_lane(dst, lane16) = out;
           fetch(u, p + DP);
+          gather((u + DP / 2) % DP);   // (the indices of pair p + DP / 2 were requested DP / 2 pairs ago)
           __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
   }
 }
-template <int DP>
-__global__ __launch_bounds__(64) void k_box_upper_stream(BoxGrid g, StreamArgs q, const double *__restrict__ Ue, const double *__restrict__ Un,
-                                                         const double *__restrict__ Uu, const double *__restrict__ Di, double *x, double *scratch) {
+// SCATTER: the solution is also written to `zvec` (internal row order) through the slot map: no k_gather pass behind the solve
+template <int DP, bool SCATTER>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_box_upper_stream(BoxGrid g, StreamArgs q, const double *__restrict__ Ue, const double *__restrict__ Un,
+                                                         const double *__restrict__ Uu, const double *__restrict__ Di, double *x, double *scratch,
+                                                         double *__restrict__ zvec, const int *__restrict__ cellmap) {
   static_assert(DP % 4 == 0, "a chunk of 8 steps is 4 row pairs");
   extern __shared__ double lds[];
   const int lane = threadIdx.x, S = g.S, NP = S >> 1, NCH = S >> 3;
@@ -1891,12 +1915,15 @@ __global__ __launch_bounds__(64) void k_box_upper_stream(BoxGrid g, StreamArgs q
       const dpair *Ue2 = reinterpret_cast<const dpair *>(Ue + row0), *Un2 = reinterpret_cast<const dpair *>(Un + row0),
                   *Uu2 = reinterpret_cast<const dpair *>(Uu + row0), *Di2 = reinterpret_cast<const dpair *>(Di + row0);
       dpair *x2 = reinterpret_cast<dpair *>(x + row0);
+      const ipair *cm2 = reinterpret_cast<const ipair *>(cellmap + row0);
       dpair ue[DP], un[DP], uu[DP], di[DP], rr[DP];
+      ipair ix[SCATTER ? DP : 1];
       auto fetch = [&](int u, int p) {
         const size_t o = (size_t)max(p, 0) * 64;
         ue[u] = ldnt(at_lane(Ue2 + o, lane16)); un[u] = ldnt(at_lane(Un2 + o, lane16)); uu[u] = ldnt(at_lane(Uu2 + o, lane16));
         di[u] = ldnt(at_lane(Di2 + o, lane16));
         rr[u] = *at_lane(x2 + o, lane16);
+        if (SCATTER) ix[u] = ldnt(at_lane(cm2 + o, threadIdx.x * 8u));
       };
 #pragma unroll
       for (int u = 0; u < DP; ++u) { fetch(u, NP - 1 - u); __builtin_amdgcn_sched_barrier(0); }
@@ -1957,6 +1984,10 @@ __global__ __launch_bounds__(64) void k_box_upper_stream(BoxGrid g, StreamArgs q
           out.x = step(2 * p, rr[u].x, ue[u].x, un[u].x, uu[u].x, di[u].x);
           dpair *dst = p >= 0 ? x2 + (size_t)p * 64 : sink;
           *at_lane(dst, lane16) = out;
+          if (SCATTER && p >= 0) {
+            if (ix[u].x >= 0) zvec[ix[u].x] = out.x;
+            if (ix[u].y >= 0) zvec[ix[u].y] = out.y;
+          }
           fetch(u, p - DP);
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -2955,15 +2986,17 @@ void launch_box_solve_queue(const BoxGrid &g, const BoxQueueArgs &lo, const BoxQ
 bool box_stream_applies(const BoxGrid &g) { return g.B2 == 8 && g.B3 == 8 && g.S % 8 == 0 && g.S >= 16; }
 size_t box_stream_face_doubles(const BoxGrid &g) { return (size_t)g.NB1 * g.NB2 * g.NB3 * stream_lines(g) * 8; }
 void launch_box_solve_stream(const BoxGrid &g, const BoxStreamArgs &a, const double *const L[3], const double *const U[3], const double *Di,
-                             double *v, double *scratch, hipStream_t stream) {
+                             double *v, double *scratch, hipStream_t stream, const double *r, double *z, const int *cellmap) {
   constexpr int DPS = 8;
   if (a.npencils <= 0) return;
   const size_t one = box_stream_face_doubles(g);
   StreamArgs lo{a.order_lower, a.npencils, a.ticket, a.ticket_base[0], a.max_spins, a.sc, a.faces, a.faces + one};
   StreamArgs up{a.order_upper, a.npencils, a.ticket + 1, a.ticket_base[1], a.max_spins, a.sc, a.faces + 2 * one, a.faces + 3 * one};
   const size_t lds_lo = (size_t)2 * (g.S + 2 * DPS + 8) * 8 * sizeof(double), lds_up = (size_t)2 * (g.S + 2 * DPS + 8) * 8 * sizeof(double);
-  hipLaunchKernelGGL((k_box_lower_stream<DPS>), dim3(a.nworkers), dim3(64), lds_lo, stream, g, lo, L[0], L[1], L[2], v, scratch);
-  hipLaunchKernelGGL((k_box_upper_stream<DPS>), dim3(a.nworkers), dim3(64), lds_up, stream, g, up, U[0], U[1], U[2], Di, v, scratch);
+  if (r) hipLaunchKernelGGL((k_box_lower_stream<DPS, true>), dim3(a.nworkers), dim3(64), lds_lo, stream, g, lo, L[0], L[1], L[2], v, scratch, r, cellmap);
+  else hipLaunchKernelGGL((k_box_lower_stream<DPS, false>), dim3(a.nworkers), dim3(64), lds_lo, stream, g, lo, L[0], L[1], L[2], v, scratch, r, cellmap);
+  if (z) hipLaunchKernelGGL((k_box_upper_stream<DPS, true>), dim3(a.nworkers), dim3(64), lds_up, stream, g, up, U[0], U[1], U[2], Di, v, scratch, z, cellmap);
+  else hipLaunchKernelGGL((k_box_upper_stream<DPS, false>), dim3(a.nworkers), dim3(64), lds_up, stream, g, up, U[0], U[1], U[2], Di, v, scratch, z, cellmap);
 }
 void launch_gather(int n, const int *idx, const double *in, double *out, hipStream_t stream) {
   if (n > 0) LAUNCH(k_gather, dim3(nblk(n)), n, idx, in, out);

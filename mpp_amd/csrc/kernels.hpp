@@ -319,8 +319,11 @@ struct BoxStreamArgs {
   unsigned *ticket; unsigned ticket_base[2]; unsigned max_spins;
   double *sc, *faces;
 };
+// r != nullptr: the lower solve takes its right-hand side from r (internal row order) through `cellmap` (internal row of every slot, -1
+// padding) instead of from v; z != nullptr: the upper solve writes the solution to z through the same map as well as to v
 void launch_box_solve_stream(const BoxGrid &g, const BoxStreamArgs &a, const double *const L[3], const double *const U[3], const double *Di,
-                             double *v, double *scratch, hipStream_t stream);
+                             double *v, double *scratch, hipStream_t stream, const double *r = nullptr, double *z = nullptr,
+                             const int *cellmap = nullptr);
 void launch_box_solve_queue(const BoxGrid &g, const BoxQueueArgs &lower, const BoxQueueArgs &upper, const double *const L[3],
                             const double *const U[3], const double *Di, double *v, double *scratch, hipStream_t stream);
 
@@ -377,6 +380,14 @@ struct ThArgs {
   double dtInv;
   int ncols, nz, use_cols;                 // vertical-only grids: fused column march instead of passes 1 + 2
   const double *powtab;                    // the tables of fpow (fastpow.hpp) in device memory
+  // column march with the boundary contributions and the block factorisation folded in (mode 2, use_cols; boundary cells on column
+  // ends only): the boundary kernel runs FIRST and leaves, per condition cell j, its sums side[q * nside + j], q = mass-row flux,
+  // heat-row flux, d(P,P), d(T,P), d(T,T); col_bc[c] / col_bc[ncols + c] = the condition cell of column c's bottom / top cell (-1 none);
+  // the march adds them to its end rows and eliminates the finished block row (k_th_tri_factor's arithmetic) into triL / triInv / triC
+  const int *col_bc = nullptr;
+  double *side = nullptr;
+  int nside = 0;
+  double *triL = nullptr, *triInv = nullptr, *triC = nullptr;
 };
 struct ThBcArgs {
   ThArgs t;

@@ -206,11 +206,15 @@ struct Options {
   int ilu_chain = 0;           // ILU(0) solves: 0 one launch per level (graph replay; the default), 1 / 2 one launch per triangle with
                                // tiles chained by flags (1: where it pays, 2: always).  Opt-in: without ilu_chain_tickets the chain's
                                // progress relies on workgroups being dispatched in index order, which HIP does not promise
+  bool th_fused_factor = true; // coupled TH, bjacobi, boundary cells on column ends: boundary sums and the block factorisation inside the column march
   bool th_fused_dots = true;   // coupled TH, bjacobi: the Krylov dot products of M^{-1} r come out of the block column solve
   int ilu_box = 1;             // ILU(0) solves box by box when the pattern is a structured grid in natural ordering (BoxGrid); 0: never, 2: or fail
   bool ilu_box_factor = true;  // ... and the numeric factorisation too (extents other than 2); false: by the elimination program of the general path
-  bool ilu_box_stream = false; // ... as streams: a wave owns the NB1 boxes of one (J, K), pencils by ticket in the order of J + K, faces handed over 8 steps
+  bool ilu_box_stream = true;  // ... as streams: a wave owns the NB1 boxes of one (J, K), pencils by ticket in the order of J + K, faces handed over 8 steps
                                // at a time through sentinel-initialised face buffers (k_box_lower_stream); needs 8 x 8 box cross-sections
+  bool ilu_box_fused_io = false; // streamed box solves: the lower solve gathers its right-hand side from the Krylov vector, the upper one scatters the
+                                 // solution into it (no k_box_gather_in / k_gather passes around the solves).  Measured no faster at 512^3 (5.09 against
+                                 // 4.99 ms per application: a lane-per-line gather costs the solve what the two coalescing passes cost): off
   bool ilu_box_queue = false;  // ... with ONE launch per triangle: boxes handed out by ticket in level order to ilu_box_workers resident waves, a box
                                // waits for its three predecessors' flags (k_box_lower_queue; liveness independent of the dispatch order)
   int ilu_box_workers = 1024;

@@ -230,6 +230,8 @@ struct Solver {
   DevBuf<double> d_tcw, d_tcd, d_talpha, d_hcap, d_dsoil, d_Dq_e, d_bc_other, th_scratch;
   DevBuf<double> tha[13];
   DevBuf<double> thtri_L, thtri_inv, thtri_C;   // block-Thomas factors of the per-column blocks (4 planes each)
+  DevBuf<double> th_side;                       // boundary sums per condition cell (5 planes), for the march that folds them in
+  bool th_rows_plan = false;                    // every condition cell is the bottom or top cell of its column (d_col_bc holds the map)
   std::vector<double> h_bc_other;
   // ---------------- ILU(0) ----------------
   DevBuf<int> d_ord, d_lrows, d_urows;
@@ -878,8 +880,8 @@ struct Solver {
   // conditions are the end cells of their columns and nothing else touches F or the diagonal afterwards: then ||F||,
   // ||X|| and the block-Jacobi factors come out of the assembly pass (k_assemble_cols<.., FUSE>).
   void plan_complete_rows() {
-    rows_plan = false;
-    if (th || thermal || !vertical_only || !columns || nghost > 0 || ndr_cells > 0 || nz < 2) return;
+    rows_plan = false; th_rows_plan = false;
+    if (thermal || !vertical_only || !columns || nghost > 0 || ndr_cells > 0 || nz < 2) return;
     std::vector<int> cb(2 * (size_t)ncols, -1);
     for (int j = 0; j < ncond_cells; ++j) {
       const long long cell = h_cc_cell[j];
@@ -891,6 +893,11 @@ struct Solver {
       else return;
     }
     d_col_bc.upload(cb, stream);
+    if (th) {   // coupled system: the column march folds the boundary sums in and factorises its block rows (k_th_cols<2, ., true>)
+      th_side.alloc(5 * (size_t)std::max(ncond_cells, 1));
+      th_rows_plan = true;
+      return;
+    }
     bc_side_f.alloc(std::max(ncond_cells, 1)); bc_side_d.alloc(std::max(ncond_cells, 1));
     rows_plan = true;
   }
@@ -1187,6 +1194,18 @@ struct Solver {
     b.value = d_bc_value.p; b.other = d_bc_other.p;
     return b;
   }
+  // mode-2 assembly of the coupled system with the boundary sums and the block factorisation inside the column march
+  bool th_fold() const { return th && opt.th_fused_factor && th_rows_plan && opt.pc_type == 2 && vertical_only && columns && opt.assembly != 0 &&
+                                (opt.assembly == 1 || ncols >= 16384); }
+  ThBcArgs th_args_jac(const double *x, double *Fout) {
+    ThBcArgs b = th_args(x, Fout);
+    if (th_fold()) {
+      if (!thtri_L.p) { thtri_L.alloc(4 * (size_t)n); thtri_inv.alloc(4 * (size_t)n); thtri_C.alloc(4 * (size_t)n); }
+      b.t.col_bc = d_col_bc.p; b.t.side = th_side.p; b.t.nside = std::max(ncond_cells, 1);
+      b.t.triL = thtri_L.p; b.t.triInv = thtri_inv.p; b.t.triC = thtri_C.p;
+    }
+    return b;
+  }
 
   // =====================================================================================
   // kernel argument packs
@@ -1337,7 +1356,7 @@ struct Solver {
     if (dtime <= 0.0) throw Error("time step not set");
     halo_exchange(P);
     ProfScope ps(prof, KC_JACOBIAN);
-    if (th) { launch_th_assemble(2, th_args(P, Fout), stream); ghost_zero(P); ++nfuncs; ++cum_funcs; pc_ready = false; return; }
+    if (th) { launch_th_assemble(2, th_args_jac(P, Fout), stream); ghost_zero(P); ++nfuncs; ++cum_funcs; pc_ready = th_fold(); return; }
     asm_sums = false;
     fwd_rhs = nullptr;
     if (rows_complete()) { assemble_complete_rows(2, P, Fout); ++nfuncs; ++cum_funcs; return; }
@@ -1357,7 +1376,7 @@ struct Solver {
     halo_exchange(P);
     ProfScope ps(prof, KC_JACOBIAN);
     fwd_rhs = nullptr;
-    if (th) { launch_th_assemble(2, th_args(P, th_scratch.p), stream); ghost_zero(P); pc_ready = false; return; }
+    if (th) { launch_th_assemble(2, th_args_jac(P, th_scratch.p), stream); ghost_zero(P); pc_ready = th_fold(); return; }
     if (rows_complete()) { assemble_complete_rows(1, P, Fres ? Fres : F.p, Fres != nullptr); return; }
     if (use_cols()) launch_assemble_cols(1, cols_args(P, F.p), stream);
     else launch_assemble_general(1, gen_args(P, F.p), stream);
@@ -1567,7 +1586,7 @@ struct Solver {
   }
   // both box solves as streams (k_box_lower_stream): set-up on first use
   bool box_stream() const { return opt.ilu_box_stream && box_stream_applies(box); }
-  void box_solve_stream() {
+  void box_solve_stream(const double *r = nullptr, double *z = nullptr) {
     const int npen = box.NB2 * box.NB3;
     if (!box_stream_ready) {
       std::vector<int> ord(npen);
@@ -1583,7 +1602,7 @@ struct Solver {
     const double *const L[3] = {box_L[0].p, box_L[1].p, box_L[2].p}, *const U[3] = {box_U[0].p, box_U[1].p, box_U[2].p};
     const int nworkers = std::max(1, std::min(npen, opt.ilu_box_workers));
     BoxStreamArgs a{pen_order.p, pen_order_rev.p, npen, nworkers, box_ticket.p + 2, {pen_ticket_base[0], pen_ticket_base[1]}, opt.ilu_chain_spins, sc.p, box_faces.p};
-    launch_box_solve_stream(box, a, L, U, box_Di.p, box_v.p, box_scratch.p, stream);
+    launch_box_solve_stream(box, a, L, U, box_Di.p, box_v.p, box_scratch.p, stream, r, z, box_cellmap.p);
     pen_ticket_base[0] += (unsigned)npen + (unsigned)nworkers;
     pen_ticket_base[1] += (unsigned)npen + (unsigned)nworkers;
   }
@@ -1601,11 +1620,16 @@ struct Solver {
   }
   bool box_active() const { return box_ok && opt.ilu_box != 0; }
   bool box_factored() const { return box_active() && opt.ilu_box_factor && box_factor_applies(box); }
-  // A fixed sequence of launches, captured the first time and replayed afterwards -- as SEVERAL hipGraphs of at most
-  // opt.ilu_graph_nodes kernel nodes each (graph_tick, called in front of every launch of such a sequence, cuts the capture).
-  // One graph of several hundred nodes is what rocprofv3's kernel tracing (rocprofiler-sdk, ROCm 7.2) could not take: SIGSEGV
-  // inside the graph launch at 764 nodes, clean at 141 (profiles/r02_rocprofv3_graph_replay_{128,24}.log).  With the chunks
-  // profiled and unprofiled runs take the same path; no environment sniffing.
+  // A fixed sequence of launches, captured the first time and replayed afterwards as hipGraphs of at most opt.ilu_graph_nodes kernel
+  // nodes each (graph_tick, called in front of every launch of such a sequence, cuts the capture).
+  // Profilers: rocprofv3 --kernel-trace (rocprofiler-sdk 1.1.0, ROCm 7.2) dies inside its queue-write interceptor when a graph replay
+  // is submitted next to this library's HIP-event records.  The faulting instruction is the interceptor's read of a packet header
+  // (`cmpb $0x2,(%rax)` at librocprofiler-sdk +0x1e72fb, in a loop that copies 64-byte AQL packets) at the first byte past the mapping
+  // that holds the queue's ring: a multi-packet submission that wraps around the end of the ring is walked linearly
+  // (profiles/r03_rocprofv3_graph_crash_attribution.md, disassembly added in round 4).  Only batched submissions can wrap, and the
+  // event records next to the replays are what made it happen within a run: chunk sizes did not matter (16-node chunks died too), so
+  // the chunking is not a remedy.  The remedy taken: while the library's own event profiling is on (option "profile"), the
+  // sequences are issued launch by launch -- one packet per submission cannot wrap -- and replayed as graphs otherwise.
   void graph_chunk_begin() {
     HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
     cap_nodes = 0;
@@ -1625,7 +1649,7 @@ struct Solver {
   }
   template <class F>
   void run_graph(GraphSeq &gs, F &&launches) {
-    if (!opt.ilu_graph) { launches(); return; }
+    if (!opt.ilu_graph || prof.enabled) { launches(); return; }
     if (gs.execs.empty()) {
       capturing = &gs;
       try {
@@ -1651,20 +1675,21 @@ struct Solver {
     else if (opt.pc_type == 2) launch_tri_solve(tri_args(), r, z, stream);
     else if (opt.pc_type == 3) launch_pointwise_mult(nred, jac_invd.p, r, z, stream);
     else if (opt.pc_type == 1 && box_active()) {
-      if (box_gather_in_fits(box)) launch_box_gather_in(box, d_ext2int.p, r, box_v.p, stream);   // r into the box layout, padding zero
-      else launch_gather_or_zero(box_slots, box_cellmap.p, r, box_v.p, stream);
+      auto gather_in = [&] {   // r into the box layout, padding zero
+        if (box_gather_in_fits(box)) launch_box_gather_in(box, d_ext2int.p, r, box_v.p, stream);
+        else launch_gather_or_zero(box_slots, box_cellmap.p, r, box_v.p, stream);
+      };
+      // the streamed solves read r and write z themselves, through the slot map (no pass over the vectors in front of / behind them)
+      const bool fused_io = box_stream() && opt.ilu_box_fused_io;
+      if (!fused_io) gather_in();
       bool solved = false;
       if (box_stream() || opt.ilu_box_queue) {
-        if (box_stream()) box_solve_stream(); else box_solve_queue();
+        if (box_stream()) box_solve_stream(fused_io ? r : nullptr, fused_io ? z : nullptr); else box_solve_queue();
         solved = !chain_timed_out();   // (a wait ran out of spins: the application is redone per level, the queue stays off)
-        if (!solved) {
-          ++box_queue_fallbacks;
-          if (box_gather_in_fits(box)) launch_box_gather_in(box, d_ext2int.p, r, box_v.p, stream);
-          else launch_gather_or_zero(box_slots, box_cellmap.p, r, box_v.p, stream);
-        }
+        if (!solved) { ++box_queue_fallbacks; gather_in(); }
       }
       if (!solved) run_graph(box_graph, [&] { box_solve_levels(); });
-      launch_gather(nred, box_cellpos.p, box_v.p, z, stream);                // back to the internal row order
+      if (!(solved && fused_io)) launch_gather(nred, box_cellpos.p, box_v.p, z, stream);   // back to the internal row order
       if (nghost > 0) launch_set(nghost, 0.0, z + nred, stream);             // (identity rows, zero right-hand side)
     } else if (opt.pc_type == 1) {
       launch_gather(nrow, d_lrows.p, r, ilu_y.p, stream);            // r into the L level order
@@ -3256,9 +3281,11 @@ struct Solver {
       ilu_graph.destroy(); box_graph.destroy(); box_fgraph.destroy();
     }
     else if (key == "th_fused_dots") opt.th_fused_dots = num() != 0;
+    else if (key == "th_fused_factor") { opt.th_fused_factor = num() != 0; pc_ready = false; }
     else if (key == "ilu_box") { opt.ilu_box = (int)num(); pc_ready = false; }   // the factors are repacked for the other solve path
     else if (key == "ilu_box_factor") { opt.ilu_box_factor = num() != 0; pc_ready = false; }
     else if (key == "ilu_box_stream") opt.ilu_box_stream = num() != 0;     // box solves as streams: pencils by ticket, faces handed over 8 steps at a time
+    else if (key == "ilu_box_fused_io") opt.ilu_box_fused_io = num() != 0; // ... reading r and writing z through the slot map themselves
     else if (key == "ilu_box_queue") opt.ilu_box_queue = num() != 0;       // box solves: one launch per triangle (tickets + flags)
     else if (key == "ilu_box_workers") opt.ilu_box_workers = std::max(1, (int)num());   // ... on this many resident waves
     else if (key == "ilu_box_len") {

@@ -415,8 +415,9 @@ def test_box_ilu_applications_on_the_3d_vsfm_jacobian():
     box = P.to_gpu(prob, {"ksp_type": "gmres", "pc_type": "ilu", "ilu_box": 2})
     que = P.to_gpu(prob, {"ksp_type": "gmres", "pc_type": "ilu", "ilu_box": 2, "ilu_box_queue": 1})   # one launch per triangle
     stm = P.to_gpu(prob, {"ksp_type": "gmres", "pc_type": "ilu", "ilu_box": 2, "ilu_box_stream": 1})  # ... as streams of pencils
+    stm0 = P.to_gpu(prob, {"ksp_type": "gmres", "pc_type": "ilu", "ilu_box": 2, "ilu_box_stream": 1, "ilu_box_fused_io": 0})   # (gather passes kept)
     lev = P.to_gpu(prob, {"ksp_type": "gmres", "pc_type": "ilu", "ilu_box": 0, "ilu_chain": 0})
-    for g in (box, que, stm, lev):
+    for g in (box, que, stm, stm0, lev):
         g.soe.SetDtime(prob.dt); g.soe.PreSolve()
         g.soe.ComputeJacobian(x)
     rng = np.random.default_rng(17)
@@ -426,6 +427,7 @@ def test_box_ilu_applications_on_the_3d_vsfm_jacobian():
         assert np.array_equal(box.soe.PCApply(v), z), rep
         assert np.array_equal(que.soe.PCApply(v), z), rep
         assert np.array_equal(stm.soe.PCApply(v), z), rep
+        assert np.array_equal(stm0.soe.PCApply(v), z), rep
     assert que.soe.comm_stats()["chain_fallbacks"] == 0 and stm.soe.comm_stats()["chain_fallbacks"] == 0
     assert stm.soe.pc_info()["launches"] == 4
     assert box.soe.StepDT(prob.dt, 1) == lev.soe.StepDT(prob.dt, 1)

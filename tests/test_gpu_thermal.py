@@ -75,6 +75,37 @@ def test_thermal_mms_second_order_at_128_and_256_cubed_with_petsc_defaults():
     assert err[256] < 2e-3 and 3.6 <= err[128] / err[256] <= 4.4, err
 
 
+def test_config_4_at_full_size_512_cubed_with_petsc_defaults():
+    """BASELINE config 4 at its full size on one GPU -- thermal_mms_3d on 512^3 = 134 M cells, GMRES(30) + ILU(0) by boxes -- solved to
+    ksp_rtol 1e-8: size-independent properties of the problem and of the kernels instead of an oracle run (the oracle would take hours):
+    the manufactured solution is met to the discretisation + linear-solve error measured for this size (0.0052 K; 5.3 K at PETSc's
+    default 1e-5); the operator's interior rows sum to zero (pure diffusion, no heat capacity in this problem) and its boundary rows do
+    not; the ILU(0) application is linear to rounding; the true residual of the answer is small against the right-hand side"""
+    n = 512
+    tp = P.thermal_mms(3, n, n, n, replicate_reference_soil_indexing=False)
+    g = P.to_thermal_gpu(tp, {"ksp_type": "gmres", "pc_type": "ilu", "ksp_rtol": 1e-8, "ksp_max_it": 6000})
+    conv, _ = g.soe.StepDT(tp.dt, 1)
+    assert conv and g.soe.pc_info()["path"] == "boxes"
+    t = g.soe.GetSoln()
+    assert np.isfinite(t).all()
+    assert np.abs(t - tp.exact).max() < 8e-3
+    b = g.soe.ComputeRHS(tp.dt)                       # (assembles with the same soln_prev; the operator values stay those of the step)
+    r = b - g.soe.MatMult(t)
+    assert np.linalg.norm(r) <= 1e-5 * np.linalg.norm(b)
+    del r
+    ones = np.ones(n ** 3)
+    y = g.soe.MatMult(ones).reshape(n, n, n)
+    inner = np.abs(y[1:-1, 1:-1, 1:-1]).max()
+    assert inner <= 1e-9 * np.abs(y).max() and y[0].min() > 0.0 and y[-1].min() > 0.0
+    del y, ones
+    rng = np.random.default_rng(3)
+    v1, v2 = rng.standard_normal(n ** 3), rng.standard_normal(n ** 3)
+    z1, z2 = g.soe.PCApply(v1), g.soe.PCApply(v2)
+    z3 = g.soe.PCApply(2.0 * v1 - 3.0 * v2)
+    assert np.abs(z3 - (2.0 * z1 - 3.0 * z2)).max() <= 1e-9 * max(np.abs(z1).max(), np.abs(z2).max())
+    assert g.soe.comm_stats()["chain_fallbacks"] == 0
+
+
 def test_ilu0_apply_matches_the_oracle_on_the_vchannel_jacobian():
     """level-scheduled ILU(0) in the caller's natural ordering == sequential ILU(0) of the oracle / PETSc"""
     prob = P.vchannel(nx=9, ny=7, nz=8)
