@@ -380,14 +380,6 @@ struct ThArgs {
   double dtInv;
   int ncols, nz, use_cols;                 // vertical-only grids: fused column march instead of passes 1 + 2
   const double *powtab;                    // the tables of fpow (fastpow.hpp) in device memory
-  // column march with the boundary contributions and the block factorisation folded in (mode 2, use_cols; boundary cells on column
-  // ends only): the boundary kernel runs FIRST and leaves, per condition cell j, its sums side[q * nside + j], q = mass-row flux,
-  // heat-row flux, d(P,P), d(T,P), d(T,T); col_bc[c] / col_bc[ncols + c] = the condition cell of column c's bottom / top cell (-1 none);
-  // the march adds them to its end rows and eliminates the finished block row (k_th_tri_factor's arithmetic) into triL / triInv / triC
-  const int *col_bc = nullptr;
-  double *side = nullptr;
-  int nside = 0;
-  double *triL = nullptr, *triInv = nullptr, *triC = nullptr;
 };
 struct ThBcArgs {
   ThArgs t;

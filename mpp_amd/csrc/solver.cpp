@@ -206,6 +206,7 @@ struct Solver {
   bool pub_valid = false;              // ... and nothing has written sc since
   long long n_fetch = 0;               // scalar read-backs since the last mppgpu_reset_stats
   std::vector<DevBuf<double>> vv;
+  DevBuf<double> gs_h;                 // Gram-Schmidt coefficients of a GMRES step with more than kMaxMultiDot basis vectors
 
   // ---------------- thermal KSP path ----------------
   bool thermal = false;
@@ -230,8 +231,6 @@ struct Solver {
   DevBuf<double> d_tcw, d_tcd, d_talpha, d_hcap, d_dsoil, d_Dq_e, d_bc_other, th_scratch;
   DevBuf<double> tha[13];
   DevBuf<double> thtri_L, thtri_inv, thtri_C;   // block-Thomas factors of the per-column blocks (4 planes each)
-  DevBuf<double> th_side;                       // boundary sums per condition cell (5 planes), for the march that folds them in
-  bool th_rows_plan = false;                    // every condition cell is the bottom or top cell of its column (d_col_bc holds the map)
   std::vector<double> h_bc_other;
   // ---------------- ILU(0) ----------------
   DevBuf<int> d_ord, d_lrows, d_urows;
@@ -289,6 +288,14 @@ struct Solver {
   bool ls_backtracked_last = false;
   bool ls_first_fused = false;    // option ls_trace: what the line search's first trial point evaluated
   int ls_trace_it = 0;
+  // Will the line search of Newton iteration `ls_trace_it` reject the full step?  (Then its first trial point is evaluated without the
+  // Jacobian.)  Yes if the previous iteration's did, or if the iteration of the same index did in the previous solve: on the
+  // benchmark's steps the first k iterations backtrack and k moves slowly from step to step -- 33 instead of 50 wrong guesses in 274
+  // line searches, profiles/r04/linesearch_trace_warmup5_steps20.txt.  Changes which passes assemble the Jacobian, never a result.
+  std::vector<char> bt_hist_prev, bt_hist_cur;
+  bool predict_backtrack() const {
+    return ls_backtracked_last || (ls_trace_it < (int)bt_hist_prev.size() && bt_hist_prev[ls_trace_it]);
+  }
   double ls_ynorm = -1.0;         // linesearch->ynorm as the previous application left it (cp reads it at entry)
   long long cum_ls_switches = 0;  // line searches swapped in by use_dynamic_linesearch
   std::vector<double> last_substeps;   // sub-steps the most recent StepDT accepted (dt, dt/2 ... after time-step cuts)
@@ -880,8 +887,8 @@ struct Solver {
   // conditions are the end cells of their columns and nothing else touches F or the diagonal afterwards: then ||F||,
   // ||X|| and the block-Jacobi factors come out of the assembly pass (k_assemble_cols<.., FUSE>).
   void plan_complete_rows() {
-    rows_plan = false; th_rows_plan = false;
-    if (thermal || !vertical_only || !columns || nghost > 0 || ndr_cells > 0 || nz < 2) return;
+    rows_plan = false;
+    if (th || thermal || !vertical_only || !columns || nghost > 0 || ndr_cells > 0 || nz < 2) return;
     std::vector<int> cb(2 * (size_t)ncols, -1);
     for (int j = 0; j < ncond_cells; ++j) {
       const long long cell = h_cc_cell[j];
@@ -893,11 +900,6 @@ struct Solver {
       else return;
     }
     d_col_bc.upload(cb, stream);
-    if (th) {   // coupled system: the column march folds the boundary sums in and factorises its block rows (k_th_cols<2, ., true>)
-      th_side.alloc(5 * (size_t)std::max(ncond_cells, 1));
-      th_rows_plan = true;
-      return;
-    }
     bc_side_f.alloc(std::max(ncond_cells, 1)); bc_side_d.alloc(std::max(ncond_cells, 1));
     rows_plan = true;
   }
@@ -1194,18 +1196,6 @@ struct Solver {
     b.value = d_bc_value.p; b.other = d_bc_other.p;
     return b;
   }
-  // mode-2 assembly of the coupled system with the boundary sums and the block factorisation inside the column march
-  bool th_fold() const { return th && opt.th_fused_factor && th_rows_plan && opt.pc_type == 2 && vertical_only && columns && opt.assembly != 0 &&
-                                (opt.assembly == 1 || ncols >= 16384); }
-  ThBcArgs th_args_jac(const double *x, double *Fout) {
-    ThBcArgs b = th_args(x, Fout);
-    if (th_fold()) {
-      if (!thtri_L.p) { thtri_L.alloc(4 * (size_t)n); thtri_inv.alloc(4 * (size_t)n); thtri_C.alloc(4 * (size_t)n); }
-      b.t.col_bc = d_col_bc.p; b.t.side = th_side.p; b.t.nside = std::max(ncond_cells, 1);
-      b.t.triL = thtri_L.p; b.t.triInv = thtri_inv.p; b.t.triC = thtri_C.p;
-    }
-    return b;
-  }
 
   // =====================================================================================
   // kernel argument packs
@@ -1356,7 +1346,7 @@ struct Solver {
     if (dtime <= 0.0) throw Error("time step not set");
     halo_exchange(P);
     ProfScope ps(prof, KC_JACOBIAN);
-    if (th) { launch_th_assemble(2, th_args_jac(P, Fout), stream); ghost_zero(P); ++nfuncs; ++cum_funcs; pc_ready = th_fold(); return; }
+    if (th) { launch_th_assemble(2, th_args(P, Fout), stream); ghost_zero(P); ++nfuncs; ++cum_funcs; pc_ready = false; return; }
     asm_sums = false;
     fwd_rhs = nullptr;
     if (rows_complete()) { assemble_complete_rows(2, P, Fout); ++nfuncs; ++cum_funcs; return; }
@@ -1376,7 +1366,7 @@ struct Solver {
     halo_exchange(P);
     ProfScope ps(prof, KC_JACOBIAN);
     fwd_rhs = nullptr;
-    if (th) { launch_th_assemble(2, th_args_jac(P, th_scratch.p), stream); ghost_zero(P); pc_ready = th_fold(); return; }
+    if (th) { launch_th_assemble(2, th_args(P, th_scratch.p), stream); ghost_zero(P); pc_ready = false; return; }
     if (rows_complete()) { assemble_complete_rows(1, P, Fres ? Fres : F.p, Fres != nullptr); return; }
     if (use_cols()) launch_assemble_cols(1, cols_args(P, F.p), stream);
     else launch_assemble_general(1, gen_args(P, F.p), stream);
@@ -2069,7 +2059,7 @@ struct Solver {
       }
       if (spec) {    // ... and so is the line search's first trial point X - x
         ls_point = Trial{ls_ahead.Xv, x, -1.0};
-        ls_ahead.spec_fused = opt.fused_assembly && opt.fused_trials > 0 && !(opt.fused_predict && ls_backtracked_last);
+        ls_ahead.spec_fused = opt.fused_assembly && opt.fused_trials > 0 && !(opt.fused_predict && predict_backtrack());
         asm_slot = 1 + ahead_nv; asm_defer = true;
         if (ls_ahead.spec_fused) op_residual_jacobian(ls_ahead.Wv, ls_ahead.Gv); else op_residual(ls_ahead.Wv, ls_ahead.Gv);
         asm_slot = 0; asm_defer = false;
@@ -2162,6 +2152,43 @@ struct Solver {
         const bool dots_in_solve = it == 0 && fused_pc_dots();   // (w, v0) reduced by the column solve that produces w
         if (dots_in_solve) op_BA_dots(vv[0].p, vnew, vv[0].p);
         else op_BA(vv[it].p, vnew);
+        // Restart lengths above 31 (PETSc takes any, -ksp_gmres_restart): the Gram-Schmidt kernels take up to kMaxMultiDot vectors per
+        // launch, so the basis is walked in chunks of that many -- ALL the dot products first (classical Gram-Schmidt reads the
+        // unmodified w), parked in gs_h, then the updates in the same ascending order a single launch would apply them
+        const int nvt = it + 1;
+        const bool chunked = nvt > kMaxMultiDot;
+        const size_t nbm = (size_t)maxpy_blocks(nred), needm = nbm + nbm / 2048 + 1;
+        if (xr_partials.n < needm) xr_partials.alloc(needm);
+        if (chunked) {
+          if (gs_h.n < (size_t)m + 2) gs_h.alloc((size_t)m + 2);
+          for (int c0 = 0; c0 < nvt; c0 += kMaxMultiDot) {
+            ProfScope ps(prof, KC_REDUCE);
+            DotArgs a;
+            a.n = nred; a.nvec = std::min(kMaxMultiDot, nvt - c0);
+            for (int j = 0; j < a.nvec; ++j) { a.x[j] = vnew; a.y[j] = vv[c0 + j].p; }
+            const int nbk = launch_dots(a, partials.p, stream);
+            finalize(nbk, a.nvec, partials.p);
+            if (comm.active()) comm.allreduce_sum(sc.p + S_SUM0, a.nvec, stream);
+            HIP_CHECK(hipMemcpyAsync(gs_h.p + c0, sc.p + S_SUM0, (size_t)a.nvec * sizeof(double), hipMemcpyDeviceToDevice, stream));
+          }
+          for (int c0 = 0; c0 < nvt; c0 += kMaxMultiDot) {
+            ProfScope ps(prof, KC_VEC);
+            MaxpyArgs ma;
+            ma.n = nred; ma.nvec = std::min(kMaxMultiDot, nvt - c0);
+            for (int j = 0; j < ma.nvec; ++j) ma.v[j] = vv[c0 + j].p;
+            const bool last = c0 + kMaxMultiDot >= nvt;
+            // (the kernel reads its coefficients at sc[S_SUM0 + j]: handed the parked block of this chunk)
+            const int nbk = launch_maxpy_neg(ma, gs_h.p + c0 - S_SUM0, vnew, last ? xr_partials.p : nullptr, stream);
+            if (last) {
+              pub_arm = true;
+              finalize(nbk, 1, xr_partials.p, kNormSlot);
+              if (comm.active()) comm.allreduce_sum(sc.p + S_SUM0 + kNormSlot, 1, stream);
+            }
+          }
+          HIP_CHECK(hipMemcpyAsync(hh.data(), gs_h.p, (size_t)nvt * sizeof(double), hipMemcpyDeviceToHost, stream));   // (complete when the
+          fetch_scalars();                                                                                            // published scalars are)
+          HIP_CHECK(hipStreamSynchronize(stream));
+        } else {
         if (!dots_in_solve) {  // classical Gram-Schmidt: all dots, then one fused update
           ProfScope ps(prof, KC_REDUCE);
           DotArgs a;
@@ -2177,8 +2204,6 @@ struct Solver {
           ma.n = nred; ma.nvec = it + 1;
           for (int j = 0; j <= it; ++j) ma.v[j] = vv[j].p;
           // the update also reduces ||vnew||^2 (slot kNormSlot, clear of the h_j it reads): one pass and one read-back fewer
-          const size_t nb = (size_t)maxpy_blocks(nred), need = nb + nb / 2048 + 1;
-          if (xr_partials.n < need) xr_partials.alloc(need);
           const int nbk = launch_maxpy_neg(ma, sc.p, vnew, xr_partials.p, stream);
           pub_arm = true;
           finalize(nbk, 1, xr_partials.p, kNormSlot);
@@ -2186,6 +2211,7 @@ struct Solver {
         }
         fetch_scalars();
         for (int j = 0; j <= it; ++j) hh[j] = h_sc[S_SUM0 + j];
+        }
         const double tt = std::sqrt(h_sc[S_SUM0 + kNormSlot]);
         const bool hapend = tt == 0.0;   // v_{it+1} = vnew / tt is formed below, and only if another step will use it
         double *hcol = H.data() + (size_t)it * (m + 1);
@@ -2214,11 +2240,11 @@ struct Solver {
         for (int j = i + 1; j < it; ++j) s -= H[(size_t)j * (m + 1) + i] * y[j];
         y[i] = s / H[(size_t)i * (m + 1) + i];
       }
-      if (it > 0) {
+      for (int c0 = 0; c0 < it; c0 += kMaxMultiDot) {   // x += sum_j y_j v_j, kMaxMultiDot vectors per launch, ascending j
         ProfScope ps(prof, KC_VEC);
         MaxpyValArgs ma;
-        ma.n = nred; ma.nvec = it;
-        for (int j = 0; j < it; ++j) { ma.v[j] = vv[j].p; ma.c[j] = y[j]; }
+        ma.n = nred; ma.nvec = std::min(kMaxMultiDot, it - c0);
+        for (int j = 0; j < ma.nvec; ++j) { ma.v[j] = vv[c0 + j].p; ma.c[j] = y[c0 + j]; }
         ma.zero_x = x_is_zero;
         launch_maxpy_val(ma, x, stream);
         x_is_zero = false;
@@ -2313,7 +2339,7 @@ struct Solver {
       if (rows_complete()) ls_point = Trial{X, Yv, -lam}; else vec_waxpy(Wv, -lam, Yv, X);
       // a trial point's Jacobian is assembled together with its residual when the point is likely to be accepted:
       // the full step unless the previous line search of this solve had to backtrack, and always the second trial
-      last_fused = opt.fused_assembly && trial < opt.fused_trials && !(trial == 0 && opt.fused_predict && ls_backtracked_last);
+      last_fused = opt.fused_assembly && trial < opt.fused_trials && !(trial == 0 && opt.fused_predict && predict_backtrack());
       if (trial == 0) ls_first_fused = last_fused;
       ++trial;
       if (last_fused) op_residual_jacobian(Wv, Gv); else op_residual(Wv, Gv);
@@ -2360,6 +2386,7 @@ struct Solver {
       }
     }
     ls_backtracked_last = trial > 1;
+    bt_hist_cur.push_back(trial > 1);
     if (opt.ls_trace) std::fprintf(stderr, "[mppgpu ls] newton %d trials %d lambda %.6g first_fused %d\n", ls_trace_it, trial, lambda, (int)ls_first_fused);
     std::swap(X, Wv);   // X <- W, F <- G by pointer exchange (no copies)
     std::swap(Fv, Gv);
@@ -2494,6 +2521,7 @@ struct Solver {
     double ttol = 0, rnorm0 = 0, xnorm = 0, ynorm = 0;
     nfuncs = 0;
     ls_backtracked_last = false;
+    bt_hist_cur.clear();
     *newton_its = 0; *linear_its = 0;
     bool jac_valid = false;
     if (opt.fused_assembly) { op_residual_jacobian(X, Fv); jac_valid = true; } else op_residual(X, Fv);
@@ -2503,6 +2531,7 @@ struct Solver {
     for (int i = 0; !reason && i < opt.snes_max_it; ++i) {
       if (!jac_valid) op_jacobian(X, Fv);
       int its = 0;
+      ls_trace_it = i;
       ls_ahead.armed = opt.ls_ahead && ksp_one_shot && opt.ksp_type == 2 && spmv_dots_fused() && opt.linesearch_type == 2;
       ls_ahead.done = false; ls_ahead.spec_done = false; ls_ahead.spec_issued = false;
       ls_ahead.F = Fv; ls_ahead.X = i > 0 ? nullptr : X;
@@ -2531,6 +2560,7 @@ struct Solver {
       reason = snes_converged(i + 1, xnorm, ynorm, fnorm, ttol, rnorm0);
     }
     if (!reason) reason = -5;
+    if (reason > 0) bt_hist_prev = bt_hist_cur;   // (a converged solve: what the next one is predicted from)
     if (X != soln.p) {  // an odd number of pointer swaps: move the iterate back into soln
       vec_copy(X, soln.p);
     }
@@ -3249,9 +3279,7 @@ struct Solver {
     else if (key == "ksp_max_it") opt.ksp_max_it = (int)num();
     else if (key == "ksp_gmres_restart") {
       const int m = (int)num();
-      if (m < 1 || m > kMaxMultiDot - 1)
-        throw Error("ksp_gmres_restart must lie in [1, " + std::to_string(kMaxMultiDot - 1) + "] (the Gram-Schmidt kernels take up to " +
-                    std::to_string(kMaxMultiDot) + " vectors per launch)");
+      if (m < 1 || m > 4096) throw Error("ksp_gmres_restart must lie in [1, 4096]");   // (m + 1 basis vectors are held on the device)
       opt.gmres_restart = m; vv.clear();
     }
     else if (key == "debug_fail_at_fetch") debug_fail_at_fetch = (int)num();
@@ -3281,7 +3309,6 @@ struct Solver {
       ilu_graph.destroy(); box_graph.destroy(); box_fgraph.destroy();
     }
     else if (key == "th_fused_dots") opt.th_fused_dots = num() != 0;
-    else if (key == "th_fused_factor") { opt.th_fused_factor = num() != 0; pc_ready = false; }
     else if (key == "ilu_box") { opt.ilu_box = (int)num(); pc_ready = false; }   // the factors are repacked for the other solve path
     else if (key == "ilu_box_factor") { opt.ilu_box_factor = num() != 0; pc_ready = false; }
     else if (key == "ilu_box_stream") opt.ilu_box_stream = num() != 0;     // box solves as streams: pencils by ticket, faces handed over 8 steps at a time

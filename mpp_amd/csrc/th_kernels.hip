@@ -216,12 +216,12 @@ struct ThRowAcc {      // what a row accumulates before it is written
 // SIMD, on code that is bound by instruction issue.  The 29 values are parked in LDS across that evaluation (one column of a
 // [29][block] array per thread: no bank conflicts, no barrier) and the kernel is compiled for two waves per SIMD.
 constexpr int kColsBlock = 128, kParked = 29;
-// FUSE (mode 2): boundary contributions from the side arrays the boundary kernel left (it runs first), and the finished block row
-// eliminated at once -- no k_th_bc pass over F and the matrix behind the march, no k_th_tri_factor pass over the matrix
-template <int MODE, int EOS_T, bool FUSE>   // EOS_T: th_auxvar_compute's (1: IFC-67 density + enthalpy at compile time, -1: run-time choice)
+// (Round 4 also built a variant that took the boundary sums from side arrays and eliminated every finished block row itself -- no
+// k_th_bc pass behind the march, no k_th_tri_factor: the extra live values spilled (212 bytes of scratch per thread) and the pass took
+// 4.15 ms against 2.21 + 0.78 ms for march + factorisation at 512 x 512 x 80, gpurun_out/r04_run10; not kept.)
+template <int MODE, int EOS_T>   // EOS_T: th_auxvar_compute's (1: IFC-67 density + enthalpy at compile time, -1: run-time choice)
 __global__ __launch_bounds__(kColsBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_th_cols(ThArgs a) {
   constexpr bool JAC = (MODE == 2);
-  static_assert(!FUSE || MODE == 2, "the folded march assembles residual and Jacobian");
   __shared__ double pow_lds_[kPowTableDoubles];
   __shared__ double park[JAC ? kParked : 1][kColsBlock];
   const PowTab pt = stage_pow_tables(a.powtab, pow_lds_);
@@ -321,38 +321,16 @@ __global__ __launch_bounds__(kColsBlock) __attribute__((amdgpu_waves_per_eu(2, 2
       const int kp = k - 1;
       double fm = rp.fm, fe = rp.fe;
       if (a.src) { fm -= a.src[ip]; fe += a.src[n + ip]; }
-      double sPP = 0.0, sTP = 0.0, sTT = 0.0;
-      if (FUSE) {   // what k_th_bc would add to this row afterwards (same operands, same order: one mass and one heat entry per cell)
-        const int j = kp == 0 ? a.col_bc[c] : (kp == nz - 1 ? a.col_bc[a.ncols + c] : -1);
-        if (j >= 0) {
-          fm += a.side[j]; fe += a.side[(size_t)a.nside + j];
-          sPP = a.side[(size_t)2 * a.nside + j]; sTP = a.side[(size_t)3 * a.nside + j]; sTT = a.side[(size_t)4 * a.nside + j];
-        }
-      }
       a.F[ip] = fm; a.F[n + ip] = fe;
       if (JAC) {
         const int r0 = a.crowptr[ip], len = a.crowptr[ip + 1] - r0;
         size_t g0 = (size_t)2 * r0, g1 = g0 + len, h0 = (size_t)2 * a.nnzc + g0, h1 = h0 + len;   // first entry of each block
         if (kp > 0) { a.val[g0++] = rp.lPP; a.val[g1++] = rp.lPT; a.val[h0++] = rp.lTP; a.val[h1++] = rp.lTT; }
-        // divergence first, accumulation last (GE:425-453; heat :1092-1120); accumulation first, then connections for the coupling blocks
-        // (GE:2501-2597; heat :2136-2250); the boundary entries last, as k_th_bc adds them
-        const double dgPP = FUSE ? (rp.dPP + rp.aPP) + sPP : rp.dPP + rp.aPP;
-        const double dgTT = FUSE ? (rp.dTT + rp.aTT) + sTT : rp.dTT + rp.aTT;
-        const double dgPT = rp.aPT + rp.dPT;
-        const double dgTP = FUSE ? (rp.aTP + rp.dTP) + sTP : rp.aTP + rp.dTP;
-        a.val[g0++] = dgPP; a.val[h1++] = dgTT; a.val[g1++] = dgPT; a.val[h0++] = dgTP;
+        a.val[g0++] = rp.dPP + rp.aPP;   // divergence first, accumulation last (GE:425-453; heat :1092-1120)
+        a.val[h1++] = rp.dTT + rp.aTT;
+        a.val[g1++] = rp.aPT + rp.dPT;   // accumulation first, then connections (GE:2501-2597; heat :2136-2250)
+        a.val[h0++] = rp.aTP + rp.dTP;
         if (kp < nz - 1) { a.val[g0] = uPP; a.val[g1] = uPT; a.val[h0] = uTP; a.val[h1] = uTT; }
-        if (FUSE) {   // block Thomas, k_th_tri_factor's arithmetic; the factors of the row below were written a moment ago by this thread
-          const B2 zero{0, 0, 0, 0};
-          const B2 inv_prev = kp > 0 ? b2_load(a.triInv, n, ip - tw) : zero, c_prev = kp > 0 ? b2_load(a.triC, n, ip - tw) : zero;
-          const B2 lo = kp > 0 ? B2{rp.lPP, rp.lPT, rp.lTP, rp.lTT} : zero;
-          const B2 up = kp < nz - 1 ? B2{uPP, uPT, uTP, uTT} : zero;
-          const B2 l = b2_mul(lo, inv_prev);
-          const B2 lc = b2_mul(l, c_prev);
-          const B2 piv{dgPP - lc.pp, dgPT - lc.pt, dgTP - lc.tp, dgTT - lc.tt};
-          const B2 inv = b2_inv(piv);
-          b2_store(a.triL, n, ip, l); b2_store(a.triInv, n, ip, inv); b2_store(a.triC, n, ip, up);
-        }
       }
     }
     prev = cur; prev_act = act; rp = rc;
@@ -365,7 +343,7 @@ __global__ __launch_bounds__(kColsBlock) __attribute__((amdgpu_waves_per_eu(2, 2
 // auxvar has the soil of its id_dn cell; the mass equation's carries a temperature, the heat equation's a pressure
 // (assigned by the caller, as the reference drivers do).
 // ------------------------------------------------------------------------------------------------
-template <int MODE, bool SIDE>   // SIDE: the sums go to the side arrays (ThArgs::side), for the march that folds them in, not into F / the matrix
+template <int MODE>
 __global__ __launch_bounds__(kBlock) void k_th_bc(ThBcArgs b) {
   constexpr bool JAC = (MODE == 2);
   const ThArgs &a = b.t;
@@ -374,14 +352,11 @@ __global__ __launch_bounds__(kBlock) void k_th_bc(ThBcArgs b) {
   if (j >= b.ncond_cells) return;
   const size_t cell = b.cc_cell[j];
   const size_t n = (size_t)a.n;
-  if (!th_active(a, cell) || th_ghost(a, cell)) {
-    if (SIDE) for (int q = 0; q < 5; ++q) a.side[(size_t)q * a.nside + j] = 0.0;
-    return;
-  }
+  if (!th_active(a, cell) || th_ghost(a, cell)) return;
   const Soil s = th_load_soil(a, cell);
   const ThSoil ts{a.tc_wet[cell], a.tc_dry[cell], a.talpha[cell]};
   const ThAux in = th_auxvar_compute<true>(s.sf, a.density_type, a.ie_type, s, ts, a.x[cell], a.x[n + cell], true, pt);
-  double fm = SIDE ? 0.0 : a.F[cell], fe = SIDE ? 0.0 : a.F[n + cell];
+  double fm = a.F[cell], fe = a.F[n + cell];
   double dPP = 0.0, dTP = 0.0, dTT = 0.0;
   for (int e = b.cc_ptr[j]; e < b.cc_ptr[j + 1]; ++e) {
     const int t = b.type[e];
@@ -411,11 +386,6 @@ __global__ __launch_bounds__(kBlock) void k_th_bc(ThBcArgs b) {
         dTT += Hd;
       }
     }
-  }
-  if (SIDE) {
-    a.side[j] = fm; a.side[(size_t)a.nside + j] = fe;
-    a.side[(size_t)2 * a.nside + j] = dPP; a.side[(size_t)3 * a.nside + j] = dTP; a.side[(size_t)4 * a.nside + j] = dTT;
-    return;
   }
   a.F[cell] = fm;
   a.F[n + cell] = fe;
@@ -567,20 +537,15 @@ void launch_th_assemble(int mode, const ThBcArgs &b, hipStream_t stream) {
   if (a.use_cols) {
     const bool ifc = a.density_type == kDenIFC67 && a.ie_type == kIEIFC67;
     const dim3 gc((unsigned)((a.ncols + kColsBlock - 1) / kColsBlock));
-#define TH_COLS(M, E, F) hipLaunchKernelGGL((k_th_cols<M, E, F>), gc, dim3(kColsBlock), 0, stream, a)
-    if (mode == 2 && a.col_bc) {   // boundary sums first, then the march that folds them in and factorises
-      if (b.ncond_cells > 0) TH_LAUNCH((k_th_bc<2, true>), nblk(b.ncond_cells), b);
-      if (ifc) TH_COLS(2, 1, true); else TH_COLS(2, -1, true);
-      return;
-    }
-    if (mode == 0) { if (ifc) TH_COLS(0, 1, false); else TH_COLS(0, -1, false); }
-    else { if (ifc) TH_COLS(2, 1, false); else TH_COLS(2, -1, false); }
+#define TH_COLS(M, E) hipLaunchKernelGGL((k_th_cols<M, E>), gc, dim3(kColsBlock), 0, stream, a)
+    if (mode == 0) { if (ifc) TH_COLS(0, 1); else TH_COLS(0, -1); }
+    else { if (ifc) TH_COLS(2, 1); else TH_COLS(2, -1); }
 #undef TH_COLS
   } else if (mode == 0) { TH_LAUNCH(k_th_aux<0>, grid, a); TH_LAUNCH(k_th_rows<0>, grid, a); }
   else { TH_LAUNCH(k_th_aux<2>, grid, a); TH_LAUNCH(k_th_rows<2>, grid, a); }
   if (b.ncond_cells > 0) {
-    if (mode == 0) TH_LAUNCH((k_th_bc<0, false>), nblk(b.ncond_cells), b);
-    else TH_LAUNCH((k_th_bc<2, false>), nblk(b.ncond_cells), b);
+    if (mode == 0) TH_LAUNCH(k_th_bc<0>, nblk(b.ncond_cells), b);
+    else TH_LAUNCH(k_th_bc<2>, nblk(b.ncond_cells), b);
   }
 }
 

@@ -812,6 +812,13 @@ int vo_set_solver(vo_problem *p, int ksp_type, int pc_type, double ksp_rtol, dou
   return 0;
 }
 
+/* -ksp_gmres_restart (PETSc takes any positive restart length: KSPSetFromOptions, MultiPhysicsProbBaseType.F90:1205, 1317) */
+int vo_set_gmres_restart(vo_problem *p, int restart) {
+  if (restart < 1) return 1;
+  p->gmres_restart = restart;
+  return 0;
+}
+
 /* ------------------------------------------------------------------ */
 /* Governing equation: GoveqnRichardsODEPressureType.F90                */
 /* ------------------------------------------------------------------ */

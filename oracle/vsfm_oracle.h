@@ -97,6 +97,7 @@ int vo_get_condition_values(vo_problem *p, int kind, int cond_id, int n, double 
  * source-sink connections of the equation */
 int vo_set_source_sink_auxvar(vo_problem *p, int var_type, int n, const double *values);
 int vo_restart(vo_problem *p, const double *pressure);
+int vo_set_gmres_restart(vo_problem *p, int restart);
 /* soe%PreStepDT / PostStepDT of ELM's calling sequence (SystemOfEquationsVSFMType.F90:892-940; GE:2773-2785): soln_prev_clm ->
  * soln_prev, soln and reset of the exchanged-mass accumulators; soln_prev -> soln_prev_clm */
 int vo_pre_step_dt(vo_problem *p);

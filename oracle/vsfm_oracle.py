@@ -53,7 +53,7 @@ def lib():
         L.vo_last_error.restype = ct.c_char_p
         for name in ("vo_destroy", "vo_set_mesh", "vo_set_connections", "vo_add_condition", "vo_set_soil_permeability",
                      "vo_set_soil_porosity", "vo_set_soil_porosity_linear", "vo_set_saturation_function", "vo_set_density_type",
-                     "vo_set_condition_values", "vo_set_source_sink_auxvar", "vo_set_lateral_connections", "vo_get_condition_values", "vo_pre_step_dt", "vo_post_step_dt", "vo_set_frac_liq_sat", "vo_restart", "vo_set_blocks", "vo_set_solver", "vo_set_linesearch", "vo_set_dtime",
+                     "vo_set_condition_values", "vo_set_source_sink_auxvar", "vo_set_lateral_connections", "vo_get_condition_values", "vo_pre_step_dt", "vo_post_step_dt", "vo_set_frac_liq_sat", "vo_restart", "vo_set_gmres_restart", "vo_set_blocks", "vo_set_solver", "vo_set_linesearch", "vo_set_dtime",
                      "vo_pre_solve", "vo_residual", "vo_jacobian_nnz", "vo_jacobian", "vo_pc_setup_apply",
                      "vo_ksp_solve", "vo_step_dt", "vo_get", "vo_get_counters"):
             getattr(L, name).argtypes = None
@@ -217,6 +217,9 @@ class OracleProblem:
 
     def set_solver(self, ksp_type, pc_type, ksp_rtol=0.0, snes_rtol=0.0, snes_atol=0.0, snes_stol=0.0, snes_max_it=0):
         _chk(self.L.vo_set_solver(self.h, ksp_type, pc_type, ksp_rtol, snes_rtol, snes_atol, snes_stol, snes_max_it))
+
+    def set_gmres_restart(self, restart):
+        _chk(self.L.vo_set_gmres_restart(self.h, int(restart)))
 
     # operator level
     LINESEARCH = {"basic": 1, "bt": 2, "l2": 3, "cp": 4}

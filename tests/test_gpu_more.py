@@ -307,3 +307,24 @@ def test_thermal_workload_on_four_in_process_ranks_equals_the_single_handle_solv
         assert np.abs(t[:part.nowned] - t_ref[part.l2g[:part.nowned]]).max() <= 1e-7
         assert np.abs(t[:part.nowned] - lp.exact[:part.nowned]).max() < 0.5      # ... and the manufactured solution to the discretisation error
     assert gs[0].soe.pc_info()["path"] == "boxes"                                # whole z-slabs are structured grids: solved by boxes
+
+
+@pytest.mark.parametrize("restart", [45, 70])
+def test_gmres_restart_lengths_above_31_follow_the_oracle(restart):
+    """-ksp_gmres_restart beyond what one Gram-Schmidt launch takes (32 vectors): the basis is walked in chunks -- all dot products
+    of the unmodified vector first, then the updates in ascending order -- so the iterates are those of the oracle's GMRES(m) with
+    classical Gram-Schmidt: same iteration counts over two steps of the 3-D v-channel problem with a preconditioner weak enough
+    (the column blocks only) that a solve takes 48-63 iterations -- past 32 in both cases, past the restart length with 45 -- and
+    the same pressures"""
+    prob = P.vchannel(nx=9, ny=7, nz=8)
+    g = P.to_gpu(prob, {"ksp_type": "gmres", "pc_type": "bjacobi", "ksp_gmres_restart": restart, "ksp_rtol": 1e-10})
+    o = P.to_oracle(prob)
+    o.set_solver(C.KSP_GMRES, C.PC_BJACOBI, ksp_rtol=1e-10)
+    o.set_gmres_restart(restart)
+    for s in range(2):
+        assert g.soe.StepDT(prob.dt, s + 1) == tuple(o.step_dt(prob.dt, s + 1))
+    cg, co = g.soe.counters(), o.counters()
+    assert cg["newton"] == co["newton"] and cg["linear"] == co["linear"]
+    assert cg["linear"] > 40 * cg["newton"]      # solves of more than 32 iterations were really run (oracle: 254 and 191 over 4)
+    pg, po = g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1), o.get(C.AUXVAR_INTERNAL, C.VAR_PRESSURE)
+    assert np.abs(pg - po).max() <= 1e-8 * np.abs(po).max()

@@ -226,36 +226,6 @@ def test_th_block_jacobi_is_the_exact_column_solve(ncols, nz):
         assert np.abs(a - b).max() <= tol * np.abs(b).max()
 
 
-@pytest.mark.parametrize("ncols,nz", [(3, 20), (130, 7), (70, 9)])
-def test_th_march_that_folds_boundaries_and_factorisation_changes_no_bit(ncols, nz):
-    """round 4: with boundary cells on column ends only, the coupled column march takes the boundary sums from side arrays the boundary
-    kernel left (it runs first) and eliminates every finished block row itself -- no boundary pass behind it, no k_th_tri_factor.  Same
-    operands in the same order (one mass and one heat entry per end cell): residual, matrix, preconditioner application and two
-    time steps are equal bit for bit to the separate passes (option th_fused_factor = 0), and the operators equal the oracle's"""
-    rng = np.random.default_rng(8)
-    tp = P.th_columns(ncols=ncols, nz=nz, perm_mult=np.exp(0.3 * rng.standard_normal(ncols)))
-    opts = {"ksp_type": "bcgs", "pc_type": "bjacobi", "assembly": "columns"}
-    on, off = P.to_th_gpu(tp, opts), P.to_th_gpu(tp, dict(opts, th_fused_factor=0))
-    x = _state(tp, seed=2, dp=(0.0, 9e4), dt=(0.0, 15.0))
-    for g in (on, off):
-        g.soe.SetDtime(tp.dt); g.soe.PreSolve()
-    (rp, cj, v_on), (_, _, v_off) = on.soe.ComputeJacobian(x), off.soe.ComputeJacobian(x)
-    assert np.array_equal(v_on, v_off)
-    o = P.to_th_oracle(tp)
-    P.th_set_conditions(tp, o)
-    o.set_dtime(tp.dt); o.pre_solve()
-    _, _, v_o = o.jacobian(x)
-    assert np.abs(v_on - v_o).max() <= 1e-11 * np.abs(v_o).max()
-    w = np.random.default_rng(1).standard_normal(x.size)
-    assert np.array_equal(on.soe.PCApply(w), off.soe.PCApply(w))
-    for s in range(2):
-        P.th_gpu_set_conditions(tp, on); P.th_gpu_set_conditions(tp, off)
-        assert on.soe.StepDT(tp.dt, s + 1) == off.soe.StepDT(tp.dt, s + 1)
-    assert on.soe.counters() == off.soe.counters()
-    for var in (C.VAR_PRESSURE, 605):
-        assert np.array_equal(on.soe.GetDataForCLM(C.AUXVAR_INTERNAL, var), off.soe.GetDataForCLM(C.AUXVAR_INTERNAL, var))
-
-
 @pytest.mark.parametrize("ksp,pc", [("bcgs", "bjacobi"), ("gmres", "ilu")])
 def test_th_columns_sharded_over_ranks_equals_the_single_handle_solve(ksp, pc):
     """BASELINE config 5 is a multi-GPU run: the soil columns of the coupled problem split over 3 handles (ranks) of this
