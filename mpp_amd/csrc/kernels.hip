@@ -1400,24 +1400,29 @@ __global__ __launch_bounds__(kBlock) void k_box_load(long long nslots, BoxGrid g
 // direction (consecutive cells of the caller's numbering: coalesced reads of ext2int and, in the layouts the library uses, of r),
 // placed in an LDS image of the box (padding zero) and written out row by row -- k_gather_or_zero reads r through the slot
 // order, two cells per 64-byte sector (PMC: 55 bytes per cell at 256^3)
+// (Round 4 tried the image padded by two doubles per 128 -- consecutive cells of a grid line sit 128 doubles apart in the box layout,
+// one LDS bank -- and the way back through the same image instead of k_gather's per-row slot map: 1.03 and 0.99 ms at 512^3 against
+// 0.82 and 0.73 ms: the padding costs the fourth workgroup per CU (41.6 instead of 40 KB), the image a barrier k_gather does not
+// have; gpurun_out/r04_run13.  Not kept.)
+__device__ __forceinline__ int box_img(int t) { return t; }
 __global__ __launch_bounds__(kBlock) void k_box_gather_in(BoxGrid g, const int *__restrict__ ext2int, const double *__restrict__ r,
                                                           double *__restrict__ v) {
-  extern __shared__ double img[];   // S * 64 doubles
+  extern __shared__ double img[];   // box_img(S * 64) doubles
   const int b = blockIdx.x, nslot = g.S * 64;
   const int I = b % g.NB1, J = (b / g.NB1) % g.NB2, K = b / (g.NB1 * g.NB2);
-  for (int t = threadIdx.x; t < nslot; t += kBlock) img[t] = 0.0;
+  for (int t = threadIdx.x; t < nslot; t += kBlock) img[box_img(t)] = 0.0;
   __syncthreads();
   for (int q = threadIdx.x; q < 64 * g.B1; q += kBlock) {
     const int line = q / g.B1, ip = q - line * g.B1, jp = line & (g.B2 - 1), kp = line >> g.lg2;
     const int i = I * g.B1 + ip, j = J * g.B2 + jp, k = K * g.B3 + kp;
     if (i < g.n1 && j < g.n2 && k < g.n3) {
       const int row = ip + jp + kp;
-      img[(row & ~1) * 64 + 2 * line + (row & 1)] = r[ext2int[i + g.n1 * (j + g.n2 * k)]];
+      img[box_img((row & ~1) * 64 + 2 * line + (row & 1))] = r[ext2int[i + g.n1 * (j + g.n2 * k)]];
     }
   }
   __syncthreads();
   double *out = v + (size_t)b * nslot;
-  for (int t = threadIdx.x; t < nslot; t += kBlock) out[t] = img[t];
+  for (int t = threadIdx.x; t < nslot; t += kBlock) out[t] = img[box_img(t)];
 }
 __global__ __launch_bounds__(kBlock) void k_gather_or_zero(long long n, const int *idx, const double *in, double *out) {
   const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
@@ -1769,7 +1774,7 @@ struct StreamArgs {
 // with its factor entries (DP pairs ahead), the values DP / 2 pairs ahead.
 typedef int ipair __attribute__((ext_vector_type(2)));
 template <int DP, bool GATHER>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_box_lower_stream(BoxGrid g, StreamArgs q, const double *__restrict__ Ld, const double *__restrict__ Ls,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4))) void k_box_lower_stream(BoxGrid g, StreamArgs q, const double *__restrict__ Ld, const double *__restrict__ Ls,
                                                          const double *__restrict__ Lw, double *y, double *scratch,
                                                          const double *__restrict__ rvec, const int *__restrict__ cellmap) {
   static_assert(DP % 4 == 0, "a chunk of 8 steps is 4 row pairs");
@@ -1883,7 +1888,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 }
 // SCATTER: the solution is also written to `zvec` (internal row order) through the slot map: no k_gather pass behind the solve
 template <int DP, bool SCATTER>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_box_upper_stream(BoxGrid g, StreamArgs q, const double *__restrict__ Ue, const double *__restrict__ Un,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4))) void k_box_upper_stream(BoxGrid g, StreamArgs q, const double *__restrict__ Ue, const double *__restrict__ Un,
                                                          const double *__restrict__ Uu, const double *__restrict__ Di, double *x, double *scratch,
                                                          double *__restrict__ zvec, const int *__restrict__ cellmap) {
   static_assert(DP % 4 == 0, "a chunk of 8 steps is 4 row pairs");
@@ -2954,10 +2959,11 @@ void launch_box_factor(const BoxGrid &g, const int *boxes, int nboxes, double *c
   if (nboxes > 0) hipLaunchKernelGGL((k_box_factor<kBoxRingFactor>), dim3(nboxes), dim3(64), lds, stream, g, boxes, L[0], L[1], L[2], T[0], T[1], T[2],
                                      Di, scratch);
 }
-bool box_gather_in_fits(const BoxGrid &g) { return (size_t)g.S * 64 * sizeof(double) <= 48 * 1024; }
+static size_t box_img_bytes(const BoxGrid &g) { return (size_t)g.S * 64 * sizeof(double); }
+bool box_gather_in_fits(const BoxGrid &g) { return box_img_bytes(g) <= 48 * 1024; }
 void launch_box_gather_in(const BoxGrid &g, const int *ext2int, const double *r, double *v, hipStream_t stream) {
   const long long nboxes = (long long)g.NB1 * g.NB2 * g.NB3;
-  if (nboxes > 0) hipLaunchKernelGGL(k_box_gather_in, dim3((unsigned)nboxes), dim3(kBlock), (size_t)g.S * 64 * sizeof(double), stream, g, ext2int, r, v);
+  if (nboxes > 0) hipLaunchKernelGGL(k_box_gather_in, dim3((unsigned)nboxes), dim3(kBlock), box_img_bytes(g), stream, g, ext2int, r, v);
 }
 void launch_gather_or_zero(long long n, const int *idx, const double *in, double *out, hipStream_t stream) {
   if (n > 0) LAUNCH(k_gather_or_zero, dim3(nblk(n)), n, idx, in, out);
@@ -2987,7 +2993,10 @@ bool box_stream_applies(const BoxGrid &g) { return g.B2 == 8 && g.B3 == 8 && g.S
 size_t box_stream_face_doubles(const BoxGrid &g) { return (size_t)g.NB1 * g.NB2 * g.NB3 * stream_lines(g) * 8; }
 void launch_box_solve_stream(const BoxGrid &g, const BoxStreamArgs &a, const double *const L[3], const double *const U[3], const double *Di,
                              double *v, double *scratch, hipStream_t stream, const double *r, double *z, const int *cellmap) {
-  constexpr int DPS = 8;
+#ifndef MPP_BOX_STREAM_DP
+#define MPP_BOX_STREAM_DP 8
+#endif
+  constexpr int DPS = MPP_BOX_STREAM_DP;   // row pairs of operands in flight per wave (a multiple of 4)
   if (a.npencils <= 0) return;
   const size_t one = box_stream_face_doubles(g);
   StreamArgs lo{a.order_lower, a.npencils, a.ticket, a.ticket_base[0], a.max_spins, a.sc, a.faces, a.faces + one};

@@ -402,6 +402,8 @@ struct ThTriArgs {
   double *L, *inv, *C;                             // 2 x 2 blocks as four planes of n doubles each: [q*n + i], q = pp, pt, tp, tt
 };
 void launch_th_tri_factor(const ThTriArgs &a, hipStream_t stream);
+// y = A x of the coupled system on a vertical-only grid from the values at their computed places (no index; a.L / a.inv / a.C unused)
+void launch_th_spmv_cols(const ThTriArgs &a, const double *x, double *y, hipStream_t stream);
 void launch_th_tri_solve(const ThTriArgs &a, const double *r, double *z, hipStream_t stream);   // r, z: [P; T]
 // ... with the partial sums of z.z (w == nullptr) or of z.w and z.z over both fields, one per block of 256 columns (returns the
 // number of blocks; layout partials[j * blocks + block]); finish with launch_finalize

@@ -962,6 +962,7 @@ struct Solver {
   void ensure_ready() {
     PhaseTimer pt("ensure_ready");
     need_setup(true);
+    if (thermal) return;   // (the heat-diffusion operator has no Richards soils: its cell properties go up in thermal_upload_cells)
     if (!soil_dirty) return;
     if ((int)permx.size() != n || (int)por.size() != n || (int)alpha.size() != n)
       throw Error("soil properties are incomplete: set permeability, porosity and saturation function");
@@ -1384,7 +1385,9 @@ struct Solver {
     halo_exchange(x);
     ProfScope ps(prof, KC_SPMV);
     const int v = spmv_variant();
-    if (v == 22 || v == 23) {
+    if (th && opt.th_spmv_cols && opt.spmv_variant < 0 && vertical_only && columns && nghost == 0 && nz >= 2) {
+      launch_th_spmv_cols(th_tri_args(), x, y, stream);   // coupled system on soil columns: no index at all (k_th_spmv_cols)
+    } else if (v == 22 || v == 23) {
       if (!multibase_index) throw Error("spmv_variant 22/23 need the multi-base compact index (built when 20/21 are not available: rows of <= 8 entries, at most 8 windows of 8192 rows per tile)");
       launch_spmv_multibase(opt.spmv_tpw > 0 ? opt.spmv_tpw : (v == 22 ? 2 : 4), nred, max_row_nnz, d_tileptr.p, d_roff.p, d_mcol.p,
                             d_tbase.p, d_val.p, x, y, stream);
@@ -3309,6 +3312,7 @@ struct Solver {
       ilu_graph.destroy(); box_graph.destroy(); box_fgraph.destroy();
     }
     else if (key == "th_fused_dots") opt.th_fused_dots = num() != 0;
+    else if (key == "th_spmv_cols") opt.th_spmv_cols = num() != 0;
     else if (key == "ilu_box") { opt.ilu_box = (int)num(); pc_ready = false; }   // the factors are repacked for the other solve path
     else if (key == "ilu_box_factor") { opt.ilu_box_factor = num() != 0; pc_ready = false; }
     else if (key == "ilu_box_stream") opt.ilu_box_stream = num() != 0;     // box solves as streams: pencils by ticket, faces handed over 8 steps at a time

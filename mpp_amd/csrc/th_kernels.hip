@@ -508,6 +508,37 @@ __global__ __launch_bounds__(kBlock) void k_th_tri_solve_dots(ThTriArgs a, const
   }
 }
 
+// y = A x of the coupled system on a vertical-only grid without an index: the 2N x 2N CSR matrix is, per soil column, block
+// tridiagonal with 2 x 2 blocks whose entries sit at computed places (see the header: (P,P) at crp + s, (P,T) behind them, the heat
+// rows 2 nnzc further on), and a row's columns are the cell below, the cell and the cell above in either field.  One lane per cell
+// forms both of its rows -- 12 values, 6 operands -- in the entry order of the CSR kernels (products rounded one by one, no fused
+// multiply-add): the same bits as k_spmv_c on the compact index, 128 instead of 152 bytes per cell.
+__global__ __launch_bounds__(kBlock) void k_th_spmv_cols(ThTriArgs a, const double *__restrict__ x, double *__restrict__ y) {
+#pragma clang fp contract(off)
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x, n = (size_t)a.n;
+  if (i >= n) return;
+  // cell i = (level k, column c) of tile t: i = t 64 nz + k tw + lane
+  const size_t per_tile = (size_t)64 * a.nz;
+  const int tile = (int)(i / per_tile), tw = min(64, a.ncols - (tile << 6));
+  const int k = (int)((i - (size_t)tile * per_tile) / tw);
+  const int r0 = a.crowptr[i], len = a.crowptr[i + 1] - r0;
+  const double *vP = a.val + (size_t)2 * r0, *vT = a.val + (size_t)2 * a.nnzc + (size_t)2 * r0;
+  const bool lo = k > 0, up = k < a.nz - 1;
+  const double xPl = lo ? x[i - tw] : 0.0, xPd = x[i], xPu = up ? x[i + tw] : 0.0;
+  const double xTl = lo ? x[n + i - tw] : 0.0, xTd = x[n + i], xTu = up ? x[n + i + tw] : 0.0;
+  double sp = 0.0, st = 0.0;
+  int e = 0;
+  if (lo) { const double p = vP[e] * xPl, q = vT[e] * xPl; sp += p; st += q; ++e; }
+  { const double p = vP[e] * xPd, q = vT[e] * xPd; sp += p; st += q; ++e; }
+  if (up) { const double p = vP[e] * xPu, q = vT[e] * xPu; sp += p; st += q; }
+  e = len;
+  if (lo) { const double p = vP[e] * xTl, q = vT[e] * xTl; sp += p; st += q; ++e; }
+  { const double p = vP[e] * xTd, q = vT[e] * xTd; sp += p; st += q; ++e; }
+  if (up) { const double p = vP[e] * xTu, q = vT[e] * xTu; sp += p; st += q; }
+  __builtin_nontemporal_store(sp, y + i);
+  __builtin_nontemporal_store(st, y + n + i);
+}
+
 inline dim3 nblk(long long n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
 
 }  // namespace
@@ -516,6 +547,9 @@ inline dim3 nblk(long long n) { return dim3((unsigned)((n + kBlock - 1) / kBlock
 
 void launch_th_tri_factor(const ThTriArgs &a, hipStream_t stream) {
   if (a.ncols > 0) TH_LAUNCH(k_th_tri_factor, nblk(a.ncols), a);
+}
+void launch_th_spmv_cols(const ThTriArgs &a, const double *x, double *y, hipStream_t stream) {
+  if (a.n > 0) TH_LAUNCH(k_th_spmv_cols, nblk(a.n), a, x, y);
 }
 void launch_th_tri_solve(const ThTriArgs &a, const double *r, double *z, hipStream_t stream) {
   if (a.ncols > 0) TH_LAUNCH(k_th_tri_solve, nblk(a.ncols), a, r, z);

@@ -292,17 +292,19 @@ def test_th_compact_spmv_index_of_the_field_blocked_system():
     base = {"ksp_type": "bcgs", "pc_type": "bjacobi"}
     a = P.to_th_gpu(tp, dict(base, spmv_variant=20))
     b = P.to_th_gpu(tp, dict(base, spmv_variant=1, fused_ls_dots=0))
+    c = P.to_th_gpu(tp, base)            # default: the index-free product of the column-structured coupled system (k_th_spmv_cols, round 4)
     o = P.to_th_oracle(tp)
     x = _state(tp, seed=4, dp=(0.0, 9e4), dt=(0.0, 15.0))
-    for h in (a, b):
+    for h in (a, b, c):
         h.soe.SetDtime(tp.dt); h.soe.PreSolve()
     o.set_dtime(tp.dt); o.pre_solve()
     rp, cj, val = o.jacobian(x)
-    a.soe.ComputeJacobian(x); b.soe.ComputeJacobian(x)
+    a.soe.ComputeJacobian(x); b.soe.ComputeJacobian(x); c.soe.ComputeJacobian(x)
     v = np.random.default_rng(1).standard_normal(2 * n)
     from oracle import vsfm_oracle as VO
     y_a, y_b, y_o = a.soe.MatMult(v), b.soe.MatMult(v), VO.spmv(rp, cj, val, v)
     assert np.array_equal(y_a, y_b)
+    assert np.array_equal(c.soe.MatMult(v), y_b)       # same entry order, products rounded one by one: the same bits
     assert np.abs(y_a - y_o).max() <= 1e-12 * np.abs(y_o).max()
     for s in range(2):
         P.th_gpu_set_conditions(tp, a); P.th_gpu_set_conditions(tp, b)
