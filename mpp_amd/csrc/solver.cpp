@@ -3207,7 +3207,8 @@ struct Solver {
     g.B2 = 64 / g.B3;
     g.lg2 = 0;
     while ((1 << g.lg2) < g.B2) ++g.lg2;
-    g.B1 = opt.ilu_box_len > 0 ? opt.ilu_box_len : (N >= (1 << 25) ? 64 : 32);   // longer boxes: less padding, fewer levels
+    g.B1 = opt.ilu_box_len > 0 ? opt.ilu_box_len : (N >= (1 << 24) ? 64 : 32);   // longer boxes: less padding of the skewed layout
+                                                                                  // (256^3: 1.18 / 1.09 / 1.06 ms at 32 / 64 / 128; 512^3: 5.09 / 4.98 at 64 / 128 -- profiles/r04/thermal_box_length_streams.json)
     g.B1 = std::max(1, std::min(std::min(g.B1, g.n1), kBoxMaxLen));
     g.NB1 = (g.n1 + g.B1 - 1) / g.B1; g.NB2 = (g.n2 + g.B2 - 1) / g.B2; g.NB3 = (g.n3 + g.B3 - 1) / g.B3;
     g.S = (g.B1 + g.B2 + g.B3 - 2 + 7) / 8 * 8;   // step rows per box: a multiple of 8 (rows go in pairs; the streamed solves hand faces over 8 steps at a time)
