@@ -2093,6 +2093,14 @@ __global__ __launch_bounds__(kBlock) void k_gather(int n, const int *idx, const 
   const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (i < (size_t)n) out[i] = in[idx[i]];
 }
+__global__ __launch_bounds__(kBlock) void k_gather_flags(int n, const int *idx, const int *in, signed char *out, int zero_is_one) {
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < (size_t)n) { const int v = in[idx[i]]; out[i] = (signed char)(zero_is_one ? (v == 0) : v); }
+}
+__global__ __launch_bounds__(kBlock) void k_scatter_mapped(int n, const int *idx, const int *map, const int *in, int *out) {
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < (size_t)n) out[idx[i]] = map[in[i]];
+}
 __global__ __launch_bounds__(kBlock) void k_scatter(int n, const int *idx, const double *in, double *out) {
   const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (i < (size_t)n) out[idx[i]] = in[i];
@@ -3009,6 +3017,12 @@ void launch_box_solve_stream(const BoxGrid &g, const BoxStreamArgs &a, const dou
 }
 void launch_gather(int n, const int *idx, const double *in, double *out, hipStream_t stream) {
   if (n > 0) LAUNCH(k_gather, dim3(nblk(n)), n, idx, in, out);
+}
+void launch_gather_flags(int n, const int *idx, const int *in, signed char *out, int zero_is_one, hipStream_t stream) {
+  if (n > 0) LAUNCH(k_gather_flags, dim3(nblk(n)), n, idx, in, out, zero_is_one);
+}
+void launch_scatter_mapped(int n, const int *idx, const int *map, const int *in, int *out, hipStream_t stream) {
+  if (n > 0) LAUNCH(k_scatter_mapped, dim3(nblk(n)), n, idx, map, in, out);
 }
 void launch_scatter(int n, const int *idx, const double *in, double *out, hipStream_t stream) {
   if (n > 0) LAUNCH(k_scatter, dim3(nblk(n)), n, idx, in, out);

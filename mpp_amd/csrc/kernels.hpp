@@ -400,6 +400,7 @@ struct ThTriArgs {
   const int *crowptr, *tri_lo, *cdiag, *tri_up;   // cell-pattern slots of the (k-1), k, (k+1) entries of cell row (k,c); -1 absent
   const double *val;                               // the 2N x 2N CSR values
   double *L, *inv, *C;                             // 2 x 2 blocks as four planes of n doubles each: [q*n + i], q = pp, pt, tp, tt
+  int stage = 1;                                   // rows of `val` through LDS (option th_stage; 0 for the A/B)
 };
 void launch_th_tri_factor(const ThTriArgs &a, hipStream_t stream);
 // y = A x of the coupled system on a vertical-only grid from the values at their computed places (no index; a.L / a.inv / a.C unused)
@@ -413,6 +414,10 @@ int launch_th_tri_solve_dots(const ThTriArgs &a, const double *r, double *z, con
 void launch_copy(int n, const double *x, double *y, hipStream_t stream);
 void launch_set(int n, double v, double *y, hipStream_t stream);
 void launch_gather(int n, const int *idx, const double *in, double *out, hipStream_t stream);   // out[i] = in[idx[i]]
+// out[i] = in[idx[i]] as a flag byte (zero_is_one: out[i] = in[idx[i]] == 0)
+void launch_gather_flags(int n, const int *idx, const int *in, signed char *out, int zero_is_one, hipStream_t stream);
+// out[idx[i]] = map[in[i]] (set-up: connection end cells into the internal numberings)
+void launch_scatter_mapped(int n, const int *idx, const int *map, const int *in, int *out, hipStream_t stream);
 void launch_scatter(int n, const int *idx, const double *in, double *out, hipStream_t stream);  // out[idx[i]] = in[i] (idx without repeats)
 void launch_pointwise_mult(int n, const double *a, const double *x, double *y, hipStream_t stream);
 // w = y + a*x with a = sign * sc[slot] (or the literal `aval` when slot < 0)

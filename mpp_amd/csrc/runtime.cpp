@@ -1,6 +1,7 @@
 // runtime.cpp -- HIP-event profiler, run-time RCCL binding, host-side helpers of the set-up passes.
 #include "runtime.hpp"
 
+#include <atomic>
 #include <sched.h>
 
 #include <algorithm>
@@ -315,6 +316,44 @@ void host_parallel_ranges(long long n, const std::function<void(long long, long 
     });
   for (auto &th : pool) th.join();
   if (err) std::rethrow_exception(err);
+}
+void host_parallel_tasks(int ntasks, const std::function<void(int)> &fn) {
+  if (ntasks <= 0) return;
+  const int nt = std::min(host_threads(), ntasks);
+  if (nt <= 1) { for (int q = 0; q < ntasks; ++q) fn(q); return; }
+  std::vector<std::thread> pool;
+  std::exception_ptr err;
+  std::mutex m;
+  std::atomic<int> next{0};
+  for (int t = 0; t < nt; ++t)
+    pool.emplace_back([&] {
+      try { for (int q = next++; q < ntasks; q = next++) fn(q); }
+      catch (...) { std::lock_guard<std::mutex> g(m); if (!err) err = std::current_exception(); }
+    });
+  for (auto &th : pool) th.join();
+  if (err) std::rethrow_exception(err);
+}
+int host_prefix_sums(int *a, long long n) {
+  if (n <= 0) return 0;
+  const int nchunk = (int)std::min<long long>(4 * (long long)host_threads(), (n + 65535) / 65536);
+  std::vector<long long> sum((size_t)nchunk + 1, 0);
+  std::vector<int> mx((size_t)nchunk, 0);
+  host_parallel_tasks(nchunk, [&](int q) {
+    const long long b = n * q / nchunk, e = n * (q + 1) / nchunk;
+    long long t = 0;
+    int m = 0;
+    for (long long i = b; i < e; ++i) { t += a[i + 1]; m = std::max(m, a[i + 1]); }
+    sum[(size_t)q + 1] = t; mx[(size_t)q] = m;
+  });
+  sum[0] = a[0];
+  for (int q = 0; q < nchunk; ++q) sum[(size_t)q + 1] += sum[(size_t)q];
+  if (sum[(size_t)nchunk] > 0x7fffffffLL) throw Error("more than 2^31 - 1 entries: the 32-bit pointer arrays cannot hold the pattern");
+  host_parallel_tasks(nchunk, [&](int q) {
+    const long long b = n * q / nchunk, e = n * (q + 1) / nchunk;
+    int run = (int)sum[(size_t)q];
+    for (long long i = b; i < e; ++i) { run += a[i + 1]; a[i + 1] = run; }
+  });
+  return *std::max_element(mx.begin(), mx.end());
 }
 static double wall_seconds() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();

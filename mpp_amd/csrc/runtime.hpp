@@ -39,6 +39,11 @@ template <class F>
 inline void host_parallel_for(long long n, F &&body) {   // body(i) for every i in [0, n); iterations must be independent
   host_parallel_ranges(n, [&](long long b, long long e) { for (long long i = b; i < e; ++i) body(i); });
 }
+// fn(q) for q in [0, ntasks): a few large tasks, one thread each (host_parallel_for would run so few items on one thread)
+void host_parallel_tasks(int ntasks, const std::function<void(int)> &fn);
+// a[i + 1] += a[i] for i = 0 .. n-1 (a holds n + 1 counts, a[0] stays): the running sums of a pointer array, in two parallel passes
+// over fixed chunks; returns the largest a[i + 1] before the sums (the longest list)
+int host_prefix_sums(int *a, long long n);
 // wall-clock of a set-up phase on stderr when MPPGPU_TIMING is set
 struct PhaseTimer {
   const char *name;
@@ -52,6 +57,17 @@ bool poison_allocations();   // environment variable MPPGPU_POISON set and not "
 // allocations on THAT stream and waits for it alone, so that several handles -- each driven by its own host thread, one of them
 // possibly capturing a graph -- can run poisoned side by side (a hipMemset on the legacy stream + hipDeviceSynchronize could not)
 hipStream_t &poison_stream();
+// std::vector whose resize() leaves trivially constructible elements untouched: the set-up arrays of a 10^8-cell mesh are sized
+// first and then written by all host threads (first touch in parallel); value-initialising them on one thread was most of the set-up
+template <class T>
+struct DefaultInitAllocator : std::allocator<T> {
+  template <class U> struct rebind { using other = DefaultInitAllocator<U>; };
+  using std::allocator<T>::allocator;
+  template <class U> void construct(U *p) noexcept(std::is_nothrow_default_constructible<U>::value) { ::new (static_cast<void *>(p)) U; }
+  template <class U, class... A> void construct(U *p, A &&...a) { ::new (static_cast<void *>(p)) U(std::forward<A>(a)...); }
+};
+template <class T> using BigVec = std::vector<T, DefaultInitAllocator<T>>;
+
 template <typename T>
 struct DevBuf {
   T *p = nullptr;
@@ -87,6 +103,7 @@ struct DevBuf {
     if (count) HIP_CHECK(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, s));
   }
   void upload(const std::vector<T> &v, hipStream_t s) { upload(v.data(), v.size(), s); }
+  void upload(const BigVec<T> &v, hipStream_t s) { upload(v.data(), v.size(), s); }
   void zero(hipStream_t s) {
     if (n) HIP_CHECK(hipMemsetAsync(p, 0, n * sizeof(T), s));
   }
@@ -206,6 +223,7 @@ struct Options {
   int ilu_chain = 0;           // ILU(0) solves: 0 one launch per level (graph replay; the default), 1 / 2 one launch per triangle with
                                // tiles chained by flags (1: where it pays, 2: always).  Opt-in: without ilu_chain_tickets the chain's
                                // progress relies on workgroups being dispatched in index order, which HIP does not promise
+  bool th_stage = true;        // TH factorisation / index-free SpMV: matrix rows staged through LDS (off: the lane-by-lane reads, for the A/B)
   bool th_spmv_cols = true;    // coupled TH on soil columns: y = A x from the block-tridiagonal values at their computed places (no index)
   bool th_fused_dots = true;   // coupled TH, bjacobi: the Krylov dot products of M^{-1} r come out of the block column solve
   int ilu_box = 1;             // ILU(0) solves box by box when the pattern is a structured grid in natural ordering (BoxGrid); 0: never, 2: or fail

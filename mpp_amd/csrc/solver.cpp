@@ -86,12 +86,12 @@ struct Solver {
     DevBuf<double> sendbuf;
     bool set = false;
   } halo;
-  std::vector<double> vol;
-  std::vector<int> active;
+  BigVec<double> vol;
+  BigVec<int> active;
   bool any_inactive = false;
   int nc = 0;
-  std::vector<int> cup_e, cdn_e;
-  std::vector<double> cdu, cdd, carea, cuv;
+  BigVec<int> cup_e, cdn_e;
+  BigVec<double> cdu, cdd, carea, cuv;
   std::vector<Condition> bcs, sss;
   // mesh%lateral_conn_set_list (operator split: RichardsODEComputeLateralFlux, GE:2615-2743)
   int nlat = 0;
@@ -121,9 +121,9 @@ struct Solver {
   // ---------------- layout ----------------
   bool columns = false, vertical_only = false, identity_perm = true;
   int ncols = 0, nz = 0;
-  std::vector<int> ext2int, int2ext, cext2int;
+  BigVec<int> ext2int, int2ext, cext2int;
   int nc_int = 0;
-  std::vector<int> h_rowptr, h_col, h_diag;
+  BigVec<int> h_rowptr, h_col, h_diag;
   int nnz = 0, max_row_nnz = 0;
   int nb = 0, ns = 0;
   std::vector<int> bc_pos_of_g, h_bc_cell_int;
@@ -225,7 +225,7 @@ struct Solver {
   bool th = false;
   int ie_type = 1;                    // INT_ENERGY_ENTHALPY_CONSTANT (ThermEnthalpyAuxVarInit :97)
   std::vector<double> the_heat_cap, the_tcw, the_tcd, the_talpha, the_dsoil, the_permx, the_permy, the_permz;
-  std::vector<int> hc_rowptr, hc_diag;   // the mesh (cell) pattern; h_rowptr / h_col / h_diag hold the 2N x 2N one
+  BigVec<int> hc_rowptr, hc_diag;   // the mesh (cell) pattern; h_rowptr / h_col / h_diag hold the 2N x 2N one
   int nnzc = 0;
   DevBuf<int> d_crowptr, d_cdiag;
   DevBuf<double> d_tcw, d_tcd, d_talpha, d_hcap, d_dsoil, d_Dq_e, d_bc_other, th_scratch;
@@ -328,10 +328,14 @@ struct Solver {
     need_setup(false);
     if (ncells <= 0) throw Error("ncells must be positive");
     n = ncells; nlev = nlev_;
-    vol.assign(v, v + n);
-    active.assign(n, 1);
-    any_inactive = false;
-    if (act) for (int i = 0; i < n; ++i) { active[i] = act[i] != 0; any_inactive |= !active[i]; }
+    vol.resize(n); active.resize(n);   // (first touched by the threads that fill them)
+    std::atomic<bool> inact{false};
+    host_parallel_for(n, [&](long long i) {
+      vol[i] = v[i];
+      active[i] = act ? (act[i] != 0) : 1;
+      if (!active[i]) inact.store(true, std::memory_order_relaxed);
+    });
+    any_inactive = inact;
     nghost = 0;
   }
 
@@ -537,8 +541,16 @@ struct Solver {
     columns = false;
     if (nghost > 0) ok = false;   // ghost cells stay last: identity layout
     if (ok) {
-      std::vector<int> starts;
-      for (int i = 0; i < n; ++i) if (below[i] == -1) starts.push_back(i);
+      std::vector<int> starts;   // (ascending, gathered chunk by chunk)
+      {
+        const int nchunk = 4 * host_threads();
+        std::vector<std::vector<int>> part((size_t)nchunk);
+        host_parallel_tasks(nchunk, [&](int q) {
+          for (long long i = (long long)n * q / nchunk, e = (long long)n * (q + 1) / nchunk; i < e; ++i)
+            if (below[i] == -1) part[(size_t)q].push_back((int)i);
+        });
+        for (auto &v : part) starts.insert(starts.end(), v.begin(), v.end());
+      }
       const int nchains = (int)starts.size();
       if (nchains > 0 && n % nchains == 0) {
         const int len = n / nchains;
@@ -580,17 +592,17 @@ struct Solver {
       // lateral connections: the j-th one (in the caller's order) whose upwind cell is u sits at n + j*n + u, so that the rows
       // of a column tile (consecutive u) read consecutive geometry entries whichever end of the connection they are (holes
       // carry zeros).  j = the rank of the connection in its upwind cell's list: lists filled in any order, then sorted.
-      std::vector<int> ptr((size_t)n + 1, 0);
+      Scratch<int> ptr((size_t)n + 1, 0);
       host_parallel_for(nc, [&](long long c) {
         if (is_vert[c]) cext2int[c] = ext2int[cup_e[c]];
         else fetch_inc(&ptr[(size_t)ext2int[cup_e[c]] + 1]);
       });
-      int jmax = 0;
-      for (int i = 0; i < n; ++i) { jmax = std::max(jmax, ptr[i + 1]); ptr[i + 1] += ptr[i]; }
+      const int jmax = host_prefix_sums(ptr.p, n);
       const int nlat = ptr[n];
       if (nlat > 0) {
         if ((long long)n * (jmax + 1) > 0x3fffffffLL) throw Error("too many lateral connections per cell for 32-bit connection ids");
-        std::vector<int> fill(ptr.begin(), ptr.end() - 1), list(nlat);
+        Scratch<int> fill((size_t)n), list((size_t)nlat);
+        host_parallel_for(n, [&](long long i) { fill[i] = ptr[i]; });
         host_parallel_for(nc, [&](long long c) { if (!is_vert[c]) list[fetch_inc(&fill[ext2int[cup_e[c]]])] = (int)c; });
         host_parallel_for(n, [&](long long u) {
           std::sort(list.begin() + ptr[u], list.begin() + ptr[u + 1]);
@@ -619,7 +631,7 @@ struct Solver {
     Scratch<int> cnt((size_t)n + 1, 1);   // (the diagonal)
     cnt[0] = 0;
     host_parallel_for(nc, [&](long long c) { fetch_inc(&cnt[(size_t)ext2int[cup_e[c]] + 1]); fetch_inc(&cnt[(size_t)ext2int[cdn_e[c]] + 1]); });
-    for (int i = 0; i < n; ++i) cnt[i + 1] += cnt[i];
+    host_prefix_sums(cnt.p, n);
     Scratch<int> col((size_t)cnt[n]), fill((size_t)n);
     host_parallel_for(n, [&](long long i) { fill[i] = cnt[i]; col[fill[i]++] = (int)i; });   // (each row's first entry: no other writer yet)
     host_parallel_for(nc, [&](long long c) {
@@ -627,20 +639,19 @@ struct Solver {
       col[fetch_inc(&fill[u])] = d; col[fetch_inc(&fill[d])] = u;
     });
     // sort every row, drop repeated columns (two connections between the same pair of cells), compact
-    h_rowptr.assign((size_t)n + 1, 0);
+    h_rowptr.resize((size_t)n + 1);   // ([i + 1] written row by row below)
+    h_rowptr[0] = 0;
     host_parallel_for(n, [&](long long i) {
       int *b = col.p + cnt[i], *e = col.p + cnt[i + 1];
       std::sort(b, e);
       h_rowptr[i + 1] = (int)(std::unique(b, e) - b);
     });
-    for (int i = 0; i < n; ++i) h_rowptr[i + 1] += h_rowptr[i];
+    max_row_nnz = host_prefix_sums(h_rowptr.data(), n);
     nnz = h_rowptr[n];
     h_col.resize(nnz);
     host_parallel_for(n, [&](long long i) { std::copy(col.p + cnt[i], col.p + cnt[i] + (h_rowptr[i + 1] - h_rowptr[i]), h_col.begin() + h_rowptr[i]); });
     h_diag.resize(n);
     host_parallel_for(n, [&](long long i) { h_diag[i] = find_slot((int)i, (int)i); });
-    max_row_nnz = 0;
-    for (int i = 0; i < n; ++i) max_row_nnz = std::max(max_row_nnz, h_rowptr[i + 1] - h_rowptr[i]);
   }
 
   void setup() {
@@ -662,29 +673,40 @@ struct Solver {
     d_val.alloc(nnz); d_val.zero(stream);
 
     // mesh arrays in internal order
-    std::vector<double> v(n);
+    BigVec<double> v(n);
     host_parallel_for(n, [&](long long i) { v[i] = vol[int2ext[i]]; });
     d_vol.upload(v, stream);
     if (any_inactive) {
-      std::vector<signed char> a(n);
+      BigVec<signed char> a(n);
       host_parallel_for(n, [&](long long i) { a[i] = (signed char)active[int2ext[i]]; });
       d_active.upload(a.data(), a.size(), stream);
     }
     ptu.reset();
     // connection end cells (internal numbering both ways)
+    DevBuf<int> c2i;   // cext2int on the device while set-up needs it
     {
       PhaseTimer pt("setup: connection end cells");
-      Scratch<int> up(nc_int, 0), dn(nc_int, 0);
-      host_parallel_for(nc, [&](long long c) { up[cext2int[c]] = ext2int[cup_e[c]]; dn[cext2int[c]] = ext2int[cdn_e[c]]; });
-      d_cup.upload(up.p, (size_t)nc_int, stream); d_cdn.upload(dn.p, (size_t)nc_int, stream);
+      // on the device: out[cext2int[c]] = ext2int[end cell of c] from the caller's lists as they are (holes of the lateral numbering: 0)
+      c2i.upload(cext2int.data(), (size_t)nc, stream);
+      DevBuf<int> raw;
+      raw.alloc((size_t)nc);
+      const std::pair<const int *, DevBuf<int> *> ends[2] = {{cup_e.data(), &d_cup}, {cdn_e.data(), &d_cdn}};
+      for (const auto &e : ends) {
+        e.second->alloc((size_t)nc_int); e.second->zero(stream);
+        if (nc > 0) HIP_CHECK(hipMemcpyAsync(raw.p, e.first, (size_t)nc * sizeof(int), hipMemcpyHostToDevice, stream));
+        launch_scatter_mapped(nc, c2i.p, d_ext2int.p, raw.p, e.second->p, stream);
+        HIP_CHECK(hipStreamSynchronize(stream));   // (raw is reused)
+      }
     }
     // per-row incident connection lists, in the caller's connection order (general kernels only)
     if (!vertical_only || opt.assembly == 0 || thermal || th) {
       PhaseTimer pt("setup: incidence lists");
-      std::vector<int> ptr((size_t)n + 1, 0);
+      Scratch<int> ptr((size_t)n + 1, 0);
       host_parallel_for(nc, [&](long long c) { fetch_inc(&ptr[(size_t)ext2int[cup_e[c]] + 1]); fetch_inc(&ptr[(size_t)ext2int[cdn_e[c]] + 1]); });
-      for (int i = 0; i < n; ++i) ptr[i + 1] += ptr[i];
-      std::vector<int> fill(ptr.begin(), ptr.end() - 1), rconn(ptr[n]), rslot(ptr[n]), roth(ptr[n]);
+      const int kmax_rows = host_prefix_sums(ptr.p, n);
+      Scratch<int> fill((size_t)n);
+      host_parallel_for(n, [&](long long i) { fill[i] = ptr[i]; });
+      BigVec<int> rconn(ptr[n]), rslot(ptr[n]), roth(ptr[n]);   // (every entry is written below)
       // a row's list keeps the caller's connection order: filled in any order as (connection << 1 | side), sorted per row
       if ((long long)nc * 2 > 0x7fffffffLL) throw Error("too many connections for the 32-bit incidence keys");
       host_parallel_for(nc, [&](long long c) {
@@ -700,13 +722,12 @@ struct Solver {
           rslot[e] = find_slot((int)i, roth[e]);
         }
       });
-      d_rc_ptr.upload(ptr, stream); d_rc_conn.upload(rconn, stream); d_rc_slot.upload(rslot, stream);
+      d_rc_ptr.upload(ptr.p, (size_t)n + 1, stream); d_rc_conn.upload(rconn, stream); d_rc_slot.upload(rslot, stream);
       aux_kr.alloc(n); aux_dkr.alloc(n); aux_den.alloc(n); aux_dden.alloc(n);
       // ELL copy for k_flux_rows_ell (rows of <= 8 incident connections, one connection per matrix entry)
       ell_k = 0;
       if (!thermal && !th) {
-        int kmax = 0;
-        for (int i = 0; i < n; ++i) kmax = std::max(kmax, ptr[i + 1] - ptr[i]);
+        const int kmax = kmax_rows;
         std::atomic<bool> one_to_one{true};
         host_parallel_for(n, [&](long long i) {
           for (int e = ptr[i]; e < ptr[i + 1]; ++e)
@@ -714,21 +735,21 @@ struct Solver {
               if (rslot[e2] == rslot[e]) one_to_one = false;
         });
         if (kmax > 0 && kmax <= 8 && one_to_one) {
-          std::vector<int> enc((size_t)kmax * n, -1), oth((size_t)kmax * n, 0), slt((size_t)kmax * n, -1);
+          Scratch<int> enc((size_t)kmax * n, -1), oth((size_t)kmax * n, 0), slt((size_t)kmax * n, -1);
           host_parallel_for(n, [&](long long i) {
             for (int e = ptr[i], k = 0; e < ptr[i + 1]; ++e, ++k) {
               const size_t q = (size_t)k * n + i;
               enc[q] = rconn[e]; slt[q] = rslot[e]; oth[q] = roth[e];   // the other end of the incidence (internal numbering)
             }
           });
-          d_ell_enc.upload(enc, stream); d_ell_o.upload(oth, stream); d_ell_slot.upload(slt, stream);
+          d_ell_enc.upload(enc.p, enc.n, stream); d_ell_o.upload(oth.p, oth.n, stream); d_ell_slot.upload(slt.p, slt.n, stream);
           ell_k = kmax;
         }
       }
     }
     // tridiagonal slots of the per-column blocks
     {
-      std::vector<int> lo(n, -1), up(n, -1);
+      Scratch<int> lo((size_t)n, -1), up((size_t)n, -1);
       if (columns) {
         PhaseTimer pt("setup: column block slots");
         host_parallel_for(ncols, [&](long long col) {
@@ -739,7 +760,7 @@ struct Solver {
           }
         });
       }
-      d_tri_lo.upload(lo, stream); d_tri_up.upload(up, stream);
+      d_tri_lo.upload(lo.p, lo.n, stream); d_tri_up.upload(up.p, up.n, stream);
       tri_l.alloc(n); tri_invb.alloc(n); tri_c.alloc(n); jac_invd.alloc(nrow);
     }
     // boundary conditions: entries grouped by cell, (condition, connection) order kept inside a cell
@@ -821,10 +842,17 @@ struct Solver {
     HIP_CHECK(hipHostGetDevicePointer((void **)&h_seq_dev, h_seq, 0));
     d_Dq.alloc(nc_int); d_upw.alloc(nc_int); d_dgrav.alloc(nc_int); d_area.alloc(nc_int);
     if (thermal || th) {
-      {   // (cext2int is one-to-one; holes of the lateral numbering carry zeros; first touch and fill by all host threads)
-        Scratch<double> du(nc_int, 0.0), dd(nc_int, 0.0), ar(nc_int, 0.0);
-        host_parallel_for(nc, [&](long long c) { du[cext2int[c]] = cdu[c]; dd[cext2int[c]] = cdd[c]; ar[cext2int[c]] = carea[c]; });
-        d_cdu.upload(du.p, (size_t)nc_int, stream); d_cdd.upload(dd.p, (size_t)nc_int, stream); d_carea.upload(ar.p, (size_t)nc_int, stream);
+      {   // connection geometry into the internal connection order, on the device: the caller's arrays are uploaded as they are and
+          // scattered through cext2int there (one-to-one; the holes of the lateral numbering keep zeros)
+        DevBuf<double> raw;
+        raw.alloc((size_t)nc);
+        const std::pair<const BigVec<double> *, DevBuf<double> *> geo[3] = {{&cdu, &d_cdu}, {&cdd, &d_cdd}, {&carea, &d_carea}};
+        for (const auto &g : geo) {
+          g.second->alloc((size_t)nc_int); g.second->zero(stream);
+          if (nc > 0) HIP_CHECK(hipMemcpyAsync(raw.p, g.first->data(), (size_t)nc * sizeof(double), hipMemcpyHostToDevice, stream));
+          launch_scatter(nc, c2i.p, raw.p, g.second->p, stream);
+          HIP_CHECK(hipStreamSynchronize(stream));   // (raw is reused; the temporaries are freed at the end of the block)
+        }
       }
       std::vector<double> bdu(nb, 0.0), bdd(nb, 0.0), bar(nb, 0.0);
       for (auto &cd : bcs)
@@ -837,8 +865,8 @@ struct Solver {
         // option thermal_reference_defects: the value the reference routine's local `area` holds when it reaches a COND_DIRICHLET
         // connection (GoveqnThermalKSPTemperatureSoilType.F90:787, 906-911): the last internal connection between two active cells,
         // or the last COND_HEAT_FLUX connection of an active cell met before it; undefined in the reference without either (0 here)
-        double stale = 0.0;
-        for (int c = 0; c < nc; ++c) if (active[cup_e[c]] == 1 && active[cdn_e[c]] == 1) stale = carea[c];
+        double stale = 0.0;   // (the LAST such internal connection: found from the end, not by walking all 4 x 10^8 of a 512^3 mesh)
+        for (int c = nc - 1; c >= 0; --c) if (active[cup_e[c]] == 1 && active[cdn_e[c]] == 1) { stale = carea[c]; break; }
         std::vector<double> bst(nb, 0.0);
         for (auto &cd : bcs)
           for (int i = 0; i < cd.n; ++i) {
@@ -858,7 +886,8 @@ struct Solver {
       d_bc_act.upload(h_bc_act.data(), h_bc_act.size(), stream);
       d_therm_cond.alloc(n); d_heat_cap.alloc(n);
       if (ns > 0 && !has_src) { d_src.alloc(n); d_src.zero(stream); has_src = true; }
-      th_liq.assign(n, 0.0); th_ice.assign(n, 0.0); th_snow.assign(n, 0.0); th_tuning.assign(n, 1.0); th_nsnow.assign(n, 0);
+      // (liquid / ice / snow water, tuning factor 1, snow layers 0: host copies only once the caller sets them -- thermal_set_data)
+      th_liq.clear(); th_ice.clear(); th_snow.clear(); th_tuning.clear(); th_nsnow.clear();
     }
     if (vertical_only && columns && !th && !thermal) {   // the column march computes the first slot of a row instead of loading it
       for (int col = 0; col < ncols; col += std::max(1, ncols / 257)) {
@@ -935,7 +964,7 @@ struct Solver {
   // the per-cell auxvar store and the boundary "other field" array
   void th_setup() {
     hc_rowptr = h_rowptr; hc_diag = h_diag; nnzc = nnz;
-    const std::vector<int> ccol = h_col;
+    const BigVec<int> ccol = h_col;
     d_crowptr.upload(hc_rowptr, stream); d_cdiag.upload(hc_diag, stream);
     h_rowptr.assign((size_t)nrow + 1, 0); h_col.assign(4 * (size_t)nnzc, 0); h_diag.assign(nrow, 0);
     int k = 0;
@@ -967,7 +996,7 @@ struct Solver {
     if ((int)permx.size() != n || (int)por.size() != n || (int)alpha.size() != n)
       throw Error("soil properties are incomplete: set permeability, porosity and saturation function");
     // (the per-cell passes of this function run on the host's cores: they were 4.5 of the 9 s the 105 M-cell grid took to set up)
-    std::vector<double> a(n), b(n), c(n), d(n);
+    BigVec<double> a(n), b(n), c(n), d(n);   // (first touched by the threads that fill them)
     host_parallel_for(n, [&](long long i) { const int e = int2ext[i]; a[i] = por[e]; b[i] = sat_res[e]; c[i] = alpha[e]; d[i] = lam[e]; });
     d_por.upload(a, stream); d_sat_res.upload(b, stream); d_alpha.upload(c, stream); d_m.upload(d, stream);
     if (vertical_only && columns && !th) {   // the column march streams porosity x volume as one operand
@@ -990,34 +1019,43 @@ struct Solver {
     }
     build_soil_classes();
     if (mixed_satf) {
-      std::vector<signed char> t(n);
-      for (int i = 0; i < n; ++i) t[i] = (signed char)map_sat_func(satf[int2ext[i]]);
+      BigVec<signed char> t(n);
+      host_parallel_for(n, [&](long long i) { t[i] = (signed char)map_sat_func(satf[int2ext[i]]); });
       d_satf.upload(t.data(), t.size(), stream);
     } else d_satf.release();
     if (!por_slope.empty()) {
-      for (int i = 0; i < n; ++i) { a[i] = por_pref[int2ext[i]]; b[i] = por_slope[int2ext[i]]; }
+      HIP_CHECK(hipStreamSynchronize(stream));   // (a and b are reused)
+      host_parallel_for(n, [&](long long i) { a[i] = por_pref[int2ext[i]]; b[i] = por_slope[int2ext[i]]; });
       d_por_pref.upload(a, stream); d_por_slope.upload(b, stream);
     } else { d_por_pref.release(); d_por_slope.release(); }
     bool any_sbc = false;
     sbc_kind = 0;
     {   // which smoothing kinds occur: 2 = bz2 only, 3 = bz3 only, 0 = none or both
-      bool bz2 = false, bz3 = false;
-      for (int i = 0; i < n; ++i) {
-        bz2 |= satf[i] == MPPGPU_SAT_FUNC_SMOOTHED_BROOKS_COREY_BZ2;
-        bz3 |= satf[i] == MPPGPU_SAT_FUNC_SMOOTHED_BROOKS_COREY_BZ3;
-      }
+      std::atomic<bool> f2{false}, f3{false};
+      host_parallel_ranges(n, [&](long long i0, long long i1) {
+        bool m2 = false, m3 = false;
+        for (long long i = i0; i < i1; ++i) {
+          m2 |= satf[i] == MPPGPU_SAT_FUNC_SMOOTHED_BROOKS_COREY_BZ2;
+          m3 |= satf[i] == MPPGPU_SAT_FUNC_SMOOTHED_BROOKS_COREY_BZ3;
+        }
+        if (m2) f2 = true;
+        if (m3) f3 = true;
+      });
+      const bool bz2 = f2, bz3 = f3;
       any_sbc = bz2 || bz3;
       if (bz2 != bz3) sbc_kind = bz2 ? 2 : 3;
     }
     if (any_sbc) {
       // SatFunc_Set_SBC_bz2 / _bz3 (SaturationFunction.F90:260-372), ps = -0.9/alpha (:1409,1412)
-      std::vector<double> pu(n, 0.0), ps(n, 0.0), b2(n, 0.0), b3(n, 0.0);
-      for (int i = 0; i < n; ++i) {
+      BigVec<double> pu(n), ps(n), b2(n), b3(n);   // (per cell, two real powers each: on all host threads)
+      host_parallel_for(n, [&](long long i) {
         const int e = int2ext[i];
-        if (map_sat_func(satf[e]) != kSatSBC) continue;
+        pu[i] = ps[i] = b2[i] = b3[i] = 0.0;
+        if (map_sat_func(satf[e]) != kSatSBC) return;
         sbc_coefficients(satf[e], alpha[e], lam[e], pu[i], ps[i], b2[i], b3[i]);
-      }
+      });
       d_pu.upload(pu, stream); d_ps.upload(ps, stream); d_b2.upload(b2, stream); d_b3.upload(b3, stream);
+      HIP_CHECK(hipStreamSynchronize(stream));   // (the host arrays go out of scope)
     }
     // internal connection geometry (RichardsMod.F90:236-272)
     {
@@ -1094,17 +1132,19 @@ struct Solver {
     }
     if (th) {
       if ((int)the_heat_cap.size() != n) throw Error("heat-equation soil properties are not set (mppgpu_th_set_soils)");
-      std::vector<double> Dq(nc_int, 0.0);
-      for (int cidx = 0; cidx < nc; ++cidx) {
+      Scratch<double> Dq((size_t)nc_int, 0.0);
+      host_parallel_for(nc, [&](long long cidx) {
         double pu[3], pd[3];
         th_energy_perm(cup_e[cidx], pu); th_energy_perm(cdn_e[cidx], pd);
         Dq[cext2int[cidx]] = make_conn_geom(true, carea[cidx], cdu[cidx], cdd[cidx], &cuv[3 * (size_t)cidx], pu, pd).Dq;
-      }
-      d_Dq_e.upload(Dq, stream);
+      });
+      d_Dq_e.upload(Dq.p, (size_t)nc_int, stream);
+      HIP_CHECK(hipStreamSynchronize(stream));
       auto perm_d = [&](const std::vector<double> &v, DevBuf<double> &d) {
-        std::vector<double> t(n);
-        for (int i = 0; i < n; ++i) t[i] = v[int2ext[i]];
+        BigVec<double> t(n);
+        host_parallel_for(n, [&](long long i) { t[i] = v[int2ext[i]]; });
         d.upload(t, stream);
+        HIP_CHECK(hipStreamSynchronize(stream));   // (t goes out of scope)
       };
       perm_d(the_heat_cap, d_hcap); perm_d(the_tcw, d_tcw); perm_d(the_tcd, d_tcd); perm_d(the_talpha, d_talpha);
       perm_d(the_dsoil, d_dsoil);
@@ -1435,8 +1475,8 @@ struct Solver {
     const int split = th ? n : 0;                // field-blocked [P; T]: offsets per block, block bit in the entry
     const int ntiles = (nrow + 63) / 64;
     std::vector<int> tp((size_t)ntiles + 2, 0);
-    std::vector<unsigned short> ro(nrow);
-    std::vector<short> dc(nnz);
+    BigVec<unsigned short> ro(nrow);   // (every entry is written below)
+    BigVec<short> dc(nnz);
     std::atomic<bool> fits{true};
     host_parallel_for(ntiles, [&](long long t) {
       if (!fits) return;
@@ -1474,7 +1514,7 @@ struct Solver {
     if ((compact_index && !asked) || th || max_row_nnz > 8 || nghost > 0) return;
     const int ntiles = (nrow + 63) / 64;
     std::vector<int> tp((size_t)ntiles + 2, 0), tb((size_t)ntiles * 8, 0);
-    std::vector<unsigned short> ro(nrow), mc(nnz);
+    BigVec<unsigned short> ro(nrow), mc(nnz);   // (every entry is written below)
     std::atomic<bool> fits{true};
     host_parallel_ranges(ntiles, [&](long long t0, long long t1) {
       std::vector<int> cols;
@@ -1520,7 +1560,7 @@ struct Solver {
     return TriArgs{ncols, nz, d_tri_lo.p, d_diag.p, d_tri_up.p, d_val.p, tri_l.p, tri_invb.p, tri_c.p};
   }
   ThTriArgs th_tri_args() const {
-    return ThTriArgs{ncols, nz, n, nnzc, d_crowptr.p, d_tri_lo.p, d_cdiag.p, d_tri_up.p, d_val.p, thtri_L.p, thtri_inv.p, thtri_C.p};
+    return ThTriArgs{ncols, nz, n, nnzc, d_crowptr.p, d_tri_lo.p, d_cdiag.p, d_tri_up.p, d_val.p, thtri_L.p, thtri_inv.p, thtri_C.p, opt.th_stage ? 1 : 0};
   }
   void op_pc_setup() {
     if (pc_ready) return;
@@ -1880,21 +1920,27 @@ struct Solver {
     if (!th_cell_dirty) return;
     if ((int)th_dz.size() != n) throw Error("thermal soils are not set (mppgpu_thermal_set_soils)");
     PhaseTimer pt("thermal cell properties");
-    auto perm_d = [&](const std::vector<double> &v, DevBuf<double> &d) {
-      std::vector<double> t(n);
-      host_parallel_for(n, [&](long long i) { t[i] = v[int2ext[i]]; });
-      d.upload(t, stream);
-      HIP_CHECK(hipStreamSynchronize(stream));   // (t goes out of scope)
+    // the caller's arrays go to the device as they are and are brought into the internal cell order there (a host-side permutation
+    // touched a fresh gigabyte per property at 512^3: 2.6 s); properties nobody set are filled with their defaults on the device
+    auto perm_d = [&](const std::vector<double> &v, DevBuf<double> &d, double dflt) {
+      d.alloc(n);
+      if (v.empty()) { launch_set(n, dflt, d.p, stream); return; }
+      if (identity_perm) { d.upload(v, stream); HIP_CHECK(hipStreamSynchronize(stream)); return; }
+      HIP_CHECK(hipMemcpyAsync(tmp_ext.p, v.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, stream));
+      launch_gather(n, d_int2ext.p, tmp_ext.p, d.p, stream);
+      HIP_CHECK(hipStreamSynchronize(stream));   // (tmp_ext is used again by the next property)
     };
     auto perm_c = [&](const std::vector<int> &v, DevBuf<signed char> &d, bool zero_is_one) {
-      std::vector<signed char> t(n);
-      host_parallel_for(n, [&](long long i) { t[i] = (signed char)(zero_is_one ? (v[int2ext[i]] == 0) : v[int2ext[i]]); });
-      d.upload(t.data(), t.size(), stream);
+      d.alloc(n);
+      if (v.empty()) { HIP_CHECK(hipMemsetAsync(d.p, zero_is_one ? 1 : 0, (size_t)n, stream)); return; }
+      int *stage = reinterpret_cast<int *>(tmp_ext.p);   // (n ints fit in n doubles)
+      HIP_CHECK(hipMemcpyAsync(stage, v.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, stream));
+      launch_gather_flags(n, d_int2ext.p, stage, d.p, zero_is_one ? 1 : 0, stream);
       HIP_CHECK(hipStreamSynchronize(stream));
     };
-    perm_d(th_dz, d_th_dz); perm_d(th_por, d_th_por); perm_d(th_tkmg, d_th_tkmg); perm_d(th_tkdry, d_th_tkdry);
-    perm_d(th_csol, d_th_csol); perm_d(th_liq, d_th_liq); perm_d(th_ice, d_th_ice); perm_d(th_snow, d_th_snow);
-    perm_d(th_tuning, d_th_tuning);
+    perm_d(th_dz, d_th_dz, 0.0); perm_d(th_por, d_th_por, 0.0); perm_d(th_tkmg, d_th_tkmg, 0.0); perm_d(th_tkdry, d_th_tkdry, 0.0);
+    perm_d(th_csol, d_th_csol, 0.0); perm_d(th_liq, d_th_liq, 0.0); perm_d(th_ice, d_th_ice, 0.0); perm_d(th_snow, d_th_snow, 0.0);
+    perm_d(th_tuning, d_th_tuning, 1.0);
     perm_c(th_itype, d_th_itype, false); perm_c(th_shallow, d_th_shallow, false); perm_c(th_nsnow, d_th_nsnow0, true);
     HIP_CHECK(hipStreamSynchronize(stream));
     th_cell_dirty = false;
@@ -2712,9 +2758,14 @@ struct Solver {
         case MPPGPU_VAR_ICE_AREAL_DEN: dst = &th_ice; break;
         case MPPGPU_VAR_SNOW_WATER: dst = &th_snow; break;
         case MPPGPU_VAR_TUNING_FACTOR: dst = &th_tuning; break;
-        case MPPGPU_VAR_NUM_SNOW_LYR: for (int i = 0; i < cnt; ++i) th_nsnow[i] = (int)data[i]; th_cell_dirty = true; return;
+        case MPPGPU_VAR_NUM_SNOW_LYR:
+          if (th_nsnow.empty()) th_nsnow.assign(n, 0);
+          for (int i = 0; i < cnt; ++i) th_nsnow[i] = (int)data[i];
+          th_cell_dirty = true;
+          return;
         default: throw Error("set_data: unknown var_type " + std::to_string(var_type));
       }
+      if (dst->empty()) dst->assign(n, dst == &th_tuning ? 1.0 : 0.0);
       for (int i = 0; i < cnt; ++i) (*dst)[i] = data[i];
       th_cell_dirty = true;
     } else if (auxvar_type == MPPGPU_AUXVAR_BC) {
@@ -3214,7 +3265,9 @@ struct Solver {
     g.S = (g.B1 + g.B2 + g.B3 - 2 + 7) / 8 * 8;   // step rows per box: a multiple of 8 (rows go in pairs; the streamed solves hand faces over 8 steps at a time)
     const long long nboxes = (long long)g.NB1 * g.NB2 * g.NB3, slots = nboxes * g.S * 64;
     if (slots >= (1ll << 31)) return;
-    std::vector<int> cellmap((size_t)slots, -1), cellpos(N), order((size_t)nboxes);
+    Scratch<int> cellmap((size_t)slots, -1);   // (filled and first touched by all host threads)
+    BigVec<int> cellpos(N);
+    std::vector<int> order((size_t)nboxes);
     host_parallel_for(N, [&](long long e) {
       const int i = (int)(e % n1), j = (int)((e / n1) % n2), k = (int)(e / s3);
       const int I = i / g.B1, J = j / g.B2, K = k / g.B3, ip = i % g.B1, jp = j % g.B2, kp = k % g.B3;
@@ -3230,7 +3283,7 @@ struct Solver {
     std::vector<int> fill(box_lptr.begin(), box_lptr.end() - 1);
     for (int K = 0; K < g.NB3; ++K) for (int J = 0; J < g.NB2; ++J) for (int I = 0; I < g.NB1; ++I)
       order[fill[I + J + K]++] = I + g.NB1 * (J + g.NB2 * K);
-    box_cellmap.upload(cellmap, stream); box_cellpos.upload(cellpos, stream); box_order.upload(order, stream);
+    box_cellmap.upload(cellmap.p, cellmap.n, stream); box_cellpos.upload(cellpos, stream); box_order.upload(order, stream);
     {
       std::vector<int> rev(order.rbegin(), order.rend());
       box_order_rev.upload(rev, stream);
@@ -3314,6 +3367,7 @@ struct Solver {
     }
     else if (key == "th_fused_dots") opt.th_fused_dots = num() != 0;
     else if (key == "th_spmv_cols") opt.th_spmv_cols = num() != 0;
+    else if (key == "th_stage") opt.th_stage = num() != 0;
     else if (key == "ilu_box") { opt.ilu_box = (int)num(); pc_ready = false; }   // the factors are repacked for the other solve path
     else if (key == "ilu_box_factor") { opt.ilu_box_factor = num() != 0; pc_ready = false; }
     else if (key == "ilu_box_stream") opt.ilu_box_stream = num() != 0;     // box solves as streams: pencils by ticket, faces handed over 8 steps at a time

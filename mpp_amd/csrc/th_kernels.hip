@@ -426,7 +426,7 @@ __global__ __launch_bounds__(kBlock) void k_th_tri_factor(ThTriArgs a) {
     const B2 zero{0, 0, 0, 0};
     B2 lo = zero, di = zero, up = zero;
     bool staged = false;
-    if (tw == 64) {   // (every lane is a column)
+    if (tw == 64 && a.stage) {   // (every lane is a column)
       const int len = 3 - (k == 0) - (k == a.nz - 1);
       const int base = a.crowptr[i - lane], r0 = a.crowptr[i], sl = a.tri_lo[i], sd = a.cdiag[i], su = a.tri_up[i];
       const bool mine = a.crowptr[i - lane + 64] - base == 64 * len && r0 - base == lane * len && sl == (k > 0 ? r0 : -1) &&
@@ -589,7 +589,7 @@ __global__ __launch_bounds__(kBlock) void k_th_spmv_cols(ThTriArgs a, const doub
   const int tile = (int)(i0 / per_tile), tw = min(64, a.ncols - (tile << 6));
   bool staged = false;
   int len = 0;
-  if (tw == 64 && i0 + 64 <= n) {   // (a full tile: the wave's rows are one level, all of the same length)
+  if (a.stage && tw == 64 && i0 + 64 <= n) {   // (a full tile: the wave's rows are one level, all of the same length)
     const int k0 = (int)((i0 - (size_t)tile * per_tile) >> 6);
     len = 3 - (k0 == 0) - (k0 == a.nz - 1);
     const int base = a.crowptr[i0];
