@@ -416,6 +416,22 @@ void launch_set(int n, double v, double *y, hipStream_t stream);
 void launch_gather(int n, const int *idx, const double *in, double *out, hipStream_t stream);   // out[i] = in[idx[i]]
 // out[i] = in[idx[i]] as a flag byte (zero_is_one: out[i] = in[idx[i]] == 0)
 void launch_gather_flags(int n, const int *idx, const int *in, signed char *out, int zero_is_one, hipStream_t stream);
+// ---- set-up on the device (setup_kernels.hip) ----
+// per-row incident-connection lists: ptr (n + 1), rconn = (internal connection << 1 | side), rslot = matrix slot of the other end's
+// column (-1: none), roth = the other end (internal cell); inputs: the caller's connection ends (0-based) and the numberings
+struct IncidenceArgs {
+  int n, nc;
+  const int *ext2int, *cup, *cdn, *c2i, *rowptr, *col;
+  int *ptr, *rconn, *rslot, *roth, *flags;
+};
+long long device_inclusive_scan(int *a, long long n, hipStream_t stream);
+void device_fill_int(int *a, long long n, int v, hipStream_t stream);
+long long device_incidence_pointers(const IncidenceArgs &a, hipStream_t stream);
+void device_incidence_fill(const IncidenceArgs &a, int *cursor, hipStream_t stream);
+long long device_csr_pointers(const IncidenceArgs &a, int *rowptr, hipStream_t stream);
+void device_csr_columns(const IncidenceArgs &a, const int *rowptr, int *col, int *diag, int *max_row, hipStream_t stream);
+void device_incidence_slots(const IncidenceArgs &a, hipStream_t stream);
+void device_incidence_ell(const IncidenceArgs &a, int *enc, int *oth, int *slt, hipStream_t stream);
 // out[idx[i]] = map[in[i]] (set-up: connection end cells into the internal numberings)
 void launch_scatter_mapped(int n, const int *idx, const int *map, const int *in, int *out, hipStream_t stream);
 void launch_scatter(int n, const int *idx, const double *in, double *out, hipStream_t stream);  // out[idx[i]] = in[i] (idx without repeats)

@@ -223,6 +223,8 @@ struct Options {
   int ilu_chain = 0;           // ILU(0) solves: 0 one launch per level (graph replay; the default), 1 / 2 one launch per triangle with
                                // tiles chained by flags (1: where it pays, 2: always).  Opt-in: without ilu_chain_tickets the chain's
                                // progress relies on workgroups being dispatched in index order, which HIP does not promise
+  bool setup_device = true;    // set-up passes that have a device route (setup_kernels.hip) take it
+  bool setup_verify = false;   // ... and the host route as well, compared entry by entry (tests)
   bool th_stage = true;        // TH factorisation / index-free SpMV: matrix rows staged through LDS (off: the lane-by-lane reads, for the A/B)
   bool th_spmv_cols = true;    // coupled TH on soil columns: y = A x from the block-tridiagonal values at their computed places (no index)
   bool th_fused_dots = true;   // coupled TH, bjacobi: the Krylov dot products of M^{-1} r come out of the block column solve

@@ -1,0 +1,211 @@
+// Set-up passes that run on the device (once per mesh): the per-row incident-connection lists of the general assembly kernels
+// (mppgpu_setup, "incidence lists") built from the connection list as the caller gave it.  On the host these were two passes of
+// atomic counters over 8 x 10^8 incidences plus a sort and a binary search per row: 4.6 s of the 512^3 thermal mesh's set-up on
+// the 16 host threads a GPU box grants (profiles/NOTES.md, round 4); here they are a count, a scan, a fill and one pass per row.
+// The lists come out exactly as the host builds them (solver.cpp keeps that code as option setup_device = 0 and, with
+// setup_verify = 1, compares the two): a row's entries are ordered by (connection, side) of the caller's numbering, which does not
+// depend on the order the atomics ran in.
+#include "kernels.hpp"
+#include "runtime.hpp"
+
+#include <vector>
+
+namespace mpp {
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kScanItems = 8;                       // consecutive items per thread of a scan block
+constexpr int kScanTile = kBlock * kScanItems;
+
+inline dim3 nblk(long long n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
+
+__global__ __launch_bounds__(kBlock) void k_inc_count(int nc, const int *__restrict__ ext2int, const int *__restrict__ cup,
+                                                      const int *__restrict__ cdn, int *__restrict__ cnt) {
+  const size_t c = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (c >= (size_t)nc) return;
+  atomicAdd(&cnt[(size_t)ext2int[cup[c]] + 1], 1);
+  atomicAdd(&cnt[(size_t)ext2int[cdn[c]] + 1], 1);
+}
+
+// a[i] <- a[0] + ... + a[i] within tiles of kScanTile items; the tile's total goes to tile_sum
+__global__ __launch_bounds__(kBlock) void k_scan_tiles(long long n, int *__restrict__ a, int *__restrict__ tile_sum) {
+  __shared__ int part[kBlock];
+  const long long base = (long long)blockIdx.x * kScanTile + (long long)threadIdx.x * kScanItems;
+  int v[kScanItems], run = 0;
+#pragma unroll
+  for (int j = 0; j < kScanItems; ++j) {
+    v[j] = base + j < n ? a[base + j] : 0;
+    run += v[j];
+    v[j] = run;
+  }
+  part[threadIdx.x] = run;
+  __syncthreads();
+  for (int off = 1; off < kBlock; off <<= 1) {   // inclusive scan of the threads' sums
+    const int add = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+    __syncthreads();
+    part[threadIdx.x] += add;
+    __syncthreads();
+  }
+  const int before = part[threadIdx.x] - run;
+#pragma unroll
+  for (int j = 0; j < kScanItems; ++j)
+    if (base + j < n) a[base + j] = v[j] + before;
+  if (threadIdx.x == kBlock - 1) tile_sum[blockIdx.x] = part[kBlock - 1];
+}
+__global__ __launch_bounds__(kBlock) void k_scan_add(long long n, int *__restrict__ a, const int *__restrict__ tile_off) {
+  const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) a[i] += tile_off[i / kScanTile];
+}
+
+__global__ __launch_bounds__(kBlock) void k_inc_fill(int nc, const int *__restrict__ ext2int, const int *__restrict__ cup,
+                                                     const int *__restrict__ cdn, const int *__restrict__ ptr,
+                                                     int *__restrict__ cursor, int *__restrict__ rconn) {
+  const size_t c = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (c >= (size_t)nc) return;
+  const int u = ext2int[cup[c]], d = ext2int[cdn[c]];
+  rconn[ptr[u] + atomicAdd(&cursor[u], 1)] = (int)(c << 1);
+  rconn[ptr[d] + atomicAdd(&cursor[d], 1)] = (int)(c << 1) | 1;
+}
+
+// one row per thread: its list in the caller's (connection, side) order and the other end of every entry (internal cell)
+__global__ __launch_bounds__(kBlock) void k_inc_sort(IncidenceArgs a) {
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= (size_t)a.n) return;
+  const int b = a.ptr[i], e = a.ptr[i + 1];
+  for (int p = b + 1; p < e; ++p) {   // insertion sort: a handful of entries
+    const int v = a.rconn[p];
+    int q = p - 1;
+    while (q >= b && a.rconn[q] > v) { a.rconn[q + 1] = a.rconn[q]; --q; }
+    a.rconn[q + 1] = v;
+  }
+  for (int p = b; p < e; ++p) {
+    const int v = a.rconn[p], c = v >> 1;
+    a.roth[p] = (v & 1) ? a.ext2int[a.cup[c]] : a.ext2int[a.cdn[c]];
+  }
+}
+// CSR pattern = the diagonal + the distinct other ends of a row's incidences (GoveqnRichardsODEPressureType.F90:1689, 2051-2069):
+// the row's length into cnt[i + 1] ...
+__global__ __launch_bounds__(kBlock) void k_csr_count(IncidenceArgs a, int *__restrict__ cnt) {
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= (size_t)a.n) return;
+  const int b = a.ptr[i], e = a.ptr[i + 1];
+  int m = 1;
+  for (int p = b; p < e; ++p) {
+    const int o = a.roth[p];
+    bool seen = o == (int)i;
+    for (int q = b; q < p && !seen; ++q) seen = a.roth[q] == o;
+    m += !seen;
+  }
+  cnt[i + 1] = m;
+}
+// ... then, with the row pointers known, its sorted columns and the place of the diagonal
+__global__ __launch_bounds__(kBlock) void k_csr_write(IncidenceArgs a, const int *__restrict__ rowptr, int *__restrict__ col,
+                                                      int *__restrict__ diag, int *__restrict__ max_row) {
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= (size_t)a.n) return;
+  const int b = a.ptr[i], e = a.ptr[i + 1], r0 = rowptr[i];
+  int m = 0;
+  auto insert = [&](int v) {   // into the sorted col[r0 .. r0 + m) unless it is there
+    int q = m - 1;
+    while (q >= 0 && col[r0 + q] > v) --q;
+    if (q >= 0 && col[r0 + q] == v) return;
+    for (int t = m - 1; t > q; --t) col[r0 + t + 1] = col[r0 + t];
+    col[r0 + q + 1] = v;
+    ++m;
+  };
+  insert((int)i);
+  for (int p = b; p < e; ++p) insert(a.roth[p]);
+  for (int t = 0; t < m; ++t) if (col[r0 + t] == (int)i) diag[i] = r0 + t;
+  atomicMax(max_row, m);
+}
+// ... and the incidence entries' matrix slots, their final encoding, the longest list, rows that meet a slot twice
+__global__ __launch_bounds__(kBlock) void k_inc_slots(IncidenceArgs a) {
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= (size_t)a.n) return;
+  const int b = a.ptr[i], e = a.ptr[i + 1];
+  const int rb = a.rowptr[i], re = a.rowptr[i + 1];
+  bool dup = false;
+  for (int p = b; p < e; ++p) {
+    const int v = a.rconn[p], c = v >> 1, side = v & 1, oth = a.roth[p];
+    int lo = rb, hi = re;   // lower bound of oth in the row's sorted columns
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (a.col[mid] < oth) lo = mid + 1; else hi = mid; }
+    const int slot = (lo < re && a.col[lo] == oth) ? lo : -1;
+    for (int q = b; q < p; ++q) dup |= a.rslot[q] == slot;
+    a.rconn[p] = (a.c2i[c] << 1) | side;
+    a.rslot[p] = slot;
+  }
+  atomicMax(&a.flags[0], e - b);
+  if (dup) a.flags[1] = 1;
+}
+
+__global__ __launch_bounds__(kBlock) void k_inc_ell(int n, const int *__restrict__ ptr, const int *__restrict__ rconn,
+                                                    const int *__restrict__ rslot, const int *__restrict__ roth, int *__restrict__ enc,
+                                                    int *__restrict__ oth, int *__restrict__ slt) {
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= (size_t)n) return;
+  for (int e = ptr[i], k = 0; e < ptr[i + 1]; ++e, ++k) {
+    const size_t q = (size_t)k * n + i;
+    enc[q] = rconn[e]; slt[q] = rslot[e]; oth[q] = roth[e];
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_fill_int(long long n, int v, int *__restrict__ a) {
+  const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) a[i] = v;
+}
+
+}  // namespace
+
+#define SLAUNCH(kern, grid, ...) hipLaunchKernelGGL(kern, grid, dim3(kBlock), 0, stream, __VA_ARGS__)
+
+// a[i] <- a[0] + ... + a[i] for i in [0, n) on the device; returns the total (a[n - 1] afterwards).  Throws past 2^31 - 1.
+long long device_inclusive_scan(int *a, long long n, hipStream_t stream) {
+  if (n <= 0) return 0;
+  const long long ntile = (n + kScanTile - 1) / kScanTile;
+  DevBuf<int> tile;
+  tile.alloc((size_t)ntile);
+  SLAUNCH(k_scan_tiles, dim3((unsigned)ntile), n, a, tile.p);
+  std::vector<int> h((size_t)ntile);
+  HIP_CHECK(hipMemcpyAsync(h.data(), tile.p, (size_t)ntile * sizeof(int), hipMemcpyDeviceToHost, stream));
+  HIP_CHECK(hipStreamSynchronize(stream));
+  long long run = 0;
+  for (long long t = 0; t < ntile; ++t) { const long long s = h[(size_t)t]; h[(size_t)t] = (int)run; run += s; if (run > 0x7fffffffLL) throw Error("more than 2^31 - 1 entries: the 32-bit pointer arrays cannot hold the pattern"); }
+  HIP_CHECK(hipMemcpyAsync(tile.p, h.data(), (size_t)ntile * sizeof(int), hipMemcpyHostToDevice, stream));
+  SLAUNCH(k_scan_add, nblk(n), n, a, tile.p);
+  HIP_CHECK(hipStreamSynchronize(stream));   // (h and tile go out of scope)
+  return run;
+}
+
+void device_fill_int(int *a, long long n, int v, hipStream_t stream) {
+  if (n > 0) SLAUNCH(k_fill_int, nblk(n), n, v, a);
+}
+
+// a.ptr: n + 1 ints, zeroed by the caller; on return the row pointers.  Returns the number of incidences (= 2 nc); the caller then
+// allocates rconn / rslot / roth of that size and calls device_incidence_rows.
+long long device_incidence_pointers(const IncidenceArgs &a, hipStream_t stream) {
+  if (a.nc > 0) SLAUNCH(k_inc_count, nblk(a.nc), a.nc, a.ext2int, a.cup, a.cdn, a.ptr);
+  return device_inclusive_scan(a.ptr + 1, a.n, stream);
+}
+// cursor: n ints, zeroed by the caller (scratch).  Leaves rconn as (caller's connection << 1 | side), sorted per row, and roth.
+void device_incidence_fill(const IncidenceArgs &a, int *cursor, hipStream_t stream) {
+  if (a.nc > 0) SLAUNCH(k_inc_fill, nblk(a.nc), a.nc, a.ext2int, a.cup, a.cdn, a.ptr, cursor, a.rconn);
+  if (a.n > 0) SLAUNCH(k_inc_sort, nblk(a.n), a);
+}
+// the CSR pattern from the incidence lists: rowptr (n + 1 ints, the caller zeroes [0]) gets the row pointers, the return value is nnz;
+// then device_csr_columns fills col (nnz), diag (n) and *max_row (zeroed by the caller)
+long long device_csr_pointers(const IncidenceArgs &a, int *rowptr, hipStream_t stream) {
+  if (a.n > 0) SLAUNCH(k_csr_count, nblk(a.n), a, rowptr);
+  return device_inclusive_scan(rowptr + 1, a.n, stream);
+}
+void device_csr_columns(const IncidenceArgs &a, const int *rowptr, int *col, int *diag, int *max_row, hipStream_t stream) {
+  if (a.n > 0) SLAUNCH(k_csr_write, nblk(a.n), a, rowptr, col, diag, max_row);
+}
+// flags: 2 ints, zeroed: [0] <- the longest list, [1] <- 1 if a row meets a matrix slot twice; a.rowptr / a.col = the CSR pattern
+void device_incidence_slots(const IncidenceArgs &a, hipStream_t stream) {
+  if (a.n > 0) SLAUNCH(k_inc_slots, nblk(a.n), a);
+}
+void device_incidence_ell(const IncidenceArgs &a, int *enc, int *oth, int *slt, hipStream_t stream) {
+  if (a.n > 0) SLAUNCH(k_inc_ell, nblk(a.n), a.n, a.ptr, a.rconn, a.rslot, a.roth, enc, oth, slt);
+}
+
+}  // namespace mpp

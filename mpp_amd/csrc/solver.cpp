@@ -278,6 +278,7 @@ struct Solver {
   DevBuf<double> box_faces;                               // face buffers of the streamed solves (4 x box_stream_face_doubles), all bits set when idle
   unsigned pen_ticket_base[2] = {0, 0};
   bool box_stream_ready = false;
+  int setup_verified = 0;   // option setup_verify: device-built set-up structures found equal to the host-built ones
   DevBuf<unsigned> box_flags, box_ticket;     // flags: [lower: nboxes][upper: nboxes]; ticket: one counter per triangle
   unsigned box_epoch = 0, box_ticket_base[2] = {0, 0};
   long long box_queue_fallbacks = 0;
@@ -624,7 +625,48 @@ struct Solver {
     return (p != e && *p == col) ? (int)(p - h_col.data()) : -1;
   }
 
+  // soil columns with nothing but chain links: a cell's row is the cell below, the cell, the cell above -- written down directly
+  // (no counting, no sorting; mppgpu_setup on the headline grid spent 0.7 s in the general route)
+  void build_pattern_columns() {
+    PhaseTimer pt("setup: CSR pattern (soil columns)");
+    const long long per_tile = 64LL * nz;
+    auto where = [&](long long i, int &k, int &tw) {
+      const long long tile = i / per_tile;
+      tw = (int)std::min<long long>(64, ncols - tile * 64);
+      k = (int)((i - tile * per_tile) / tw);
+    };
+    h_rowptr.resize((size_t)n + 1);
+    h_rowptr[0] = 0;
+    host_parallel_for(n, [&](long long i) { int k, tw; where(i, k, tw); h_rowptr[i + 1] = 1 + (k > 0) + (k < nz - 1); });
+    max_row_nnz = host_prefix_sums(h_rowptr.data(), n);
+    nnz = h_rowptr[n];
+    h_col.resize(nnz); h_diag.resize(n);
+    host_parallel_for(n, [&](long long i) {
+      int k, tw;
+      where(i, k, tw);
+      int q = h_rowptr[i];
+      if (k > 0) h_col[q++] = (int)i - tw;
+      h_diag[i] = q;
+      h_col[q++] = (int)i;
+      if (k < nz - 1) h_col[q++] = (int)i + tw;
+    });
+  }
   void build_pattern() {
+    if (columns && vertical_only && opt.setup_device) {
+      build_pattern_columns();
+      if (opt.setup_verify) {
+        const BigVec<int> rp = h_rowptr, cj = h_col, dg = h_diag;
+        const int mx = max_row_nnz;
+        build_pattern_general();
+        if (rp != h_rowptr || cj != h_col || dg != h_diag || mx != max_row_nnz)
+          throw Error("setup_verify: the column layout's CSR pattern differs from the one built from the connection list");
+        ++setup_verified;
+      }
+      return;
+    }
+    build_pattern_general();
+  }
+  void build_pattern_general() {
     PhaseTimer pt("setup: CSR pattern");
     // CSR pattern = diagonal + both directions of every internal connection: exactly the entries the reference
     // creates with MatSetValuesLocal (GoveqnRichardsODEPressureType.F90:1689, 2051-2069), rows in internal order
@@ -663,13 +705,63 @@ struct Solver {
     nred = th ? nrow : nrow - nghost;
     if (nghost > 0 && !halo.set) throw Error("ghost cells need a halo plan (mppgpu_set_halo)");
     { PhaseTimer pt("setup: column detection"); detect_columns(); }
-    build_pattern();
-    auto ptu = std::make_unique<PhaseTimer>("setup: pattern + mesh uploads");
+    // per-row incident connection lists, in the caller's connection order (general kernels only)
+    const bool want_incidence = !vertical_only || opt.assembly == 0 || thermal || th;
+    const bool dev_lists = want_incidence && opt.setup_device;   // incidence lists and CSR pattern on the device (setup_kernels.hip)
+    if ((long long)nc * 2 > 0x7fffffffLL && want_incidence) throw Error("too many connections for the 32-bit incidence keys");
     d_ext2int.upload(ext2int, stream);
     d_int2ext.upload(int2ext, stream);
-    d_rowptr.upload(h_rowptr, stream);
-    d_col.upload(h_col, stream);
-    d_diag.upload(h_diag, stream);
+    DevBuf<int> c2i, raw_up, raw_dn;   // cext2int and the caller's connection ends on the device while set-up needs them
+    c2i.upload(cext2int.data(), (size_t)nc, stream);
+    raw_up.upload(cup_e.data(), (size_t)nc, stream); raw_dn.upload(cdn_e.data(), (size_t)nc, stream);
+    DevBuf<int> inc_roth, inc_flags;
+    IncidenceArgs ia{n, nc, d_ext2int.p, raw_up.p, raw_dn.p, c2i.p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (dev_lists) {
+      // count, scan, fill in any order, one pass per row (sort by the caller's (connection, side), other end); the CSR pattern is
+      // the diagonal plus the distinct other ends of a row; only the pattern comes back to the host (find_slot and the index builders)
+      PhaseTimer pt("setup: incidence lists + CSR pattern (device)");
+      d_rc_ptr.alloc((size_t)n + 1); d_rc_ptr.zero(stream);
+      inc_flags.alloc(3); inc_flags.zero(stream);
+      ia.ptr = d_rc_ptr.p; ia.flags = inc_flags.p;
+      const long long ninc = device_incidence_pointers(ia, stream);
+      d_rc_conn.alloc((size_t)ninc); d_rc_slot.alloc((size_t)ninc); inc_roth.alloc((size_t)ninc);
+      ia.rconn = d_rc_conn.p; ia.rslot = d_rc_slot.p; ia.roth = inc_roth.p;
+      {
+        DevBuf<int> cursor;
+        cursor.alloc((size_t)n); cursor.zero(stream);
+        device_incidence_fill(ia, cursor.p, stream);
+        HIP_CHECK(hipStreamSynchronize(stream));   // (cursor goes out of scope)
+      }
+      d_rowptr.alloc((size_t)n + 1); d_rowptr.zero(stream);
+      nnz = (int)device_csr_pointers(ia, d_rowptr.p, stream);
+      d_col.alloc((size_t)nnz); d_diag.alloc((size_t)n);
+      device_csr_columns(ia, d_rowptr.p, d_col.p, d_diag.p, inc_flags.p + 2, stream);
+      ia.rowptr = d_rowptr.p; ia.col = d_col.p;
+      h_rowptr.resize((size_t)n + 1); h_col.resize((size_t)nnz); h_diag.resize((size_t)n);
+      host_parallel_for(n, [&](long long i) { h_rowptr[i] = 0; h_diag[i] = 0; });   // (pages touched by all threads before the copies land)
+      host_parallel_for(nnz, [&](long long k) { h_col[k] = 0; });
+      HIP_CHECK(hipMemcpyAsync(h_rowptr.data(), d_rowptr.p, ((size_t)n + 1) * sizeof(int), hipMemcpyDeviceToHost, stream));
+      HIP_CHECK(hipMemcpyAsync(h_col.data(), d_col.p, (size_t)nnz * sizeof(int), hipMemcpyDeviceToHost, stream));
+      HIP_CHECK(hipMemcpyAsync(h_diag.data(), d_diag.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, stream));
+      HIP_CHECK(hipMemcpyAsync(&max_row_nnz, inc_flags.p + 2, sizeof(int), hipMemcpyDeviceToHost, stream));
+      HIP_CHECK(hipStreamSynchronize(stream));
+      if (opt.setup_verify) {   // the host-built pattern against it
+        const BigVec<int> rp = h_rowptr, cj = h_col, dg = h_diag;
+        const int mx = max_row_nnz;
+        build_pattern();
+        if (rp != h_rowptr || cj != h_col || dg != h_diag || mx != max_row_nnz)
+          throw Error("setup_verify: the device-built CSR pattern differs from the host-built one");
+        ++setup_verified;
+      }
+    } else {
+      build_pattern();
+    }
+    auto ptu = std::make_unique<PhaseTimer>("setup: pattern + mesh uploads");
+    if (!dev_lists) {
+      d_rowptr.upload(h_rowptr, stream);
+      d_col.upload(h_col, stream);
+      d_diag.upload(h_diag, stream);
+    }
     d_val.alloc(nnz); d_val.zero(stream);
 
     // mesh arrays in internal order
@@ -683,23 +775,46 @@ struct Solver {
     }
     ptu.reset();
     // connection end cells (internal numbering both ways)
-    DevBuf<int> c2i;   // cext2int on the device while set-up needs it
     {
       PhaseTimer pt("setup: connection end cells");
       // on the device: out[cext2int[c]] = ext2int[end cell of c] from the caller's lists as they are (holes of the lateral numbering: 0)
-      c2i.upload(cext2int.data(), (size_t)nc, stream);
-      DevBuf<int> raw;
-      raw.alloc((size_t)nc);
-      const std::pair<const int *, DevBuf<int> *> ends[2] = {{cup_e.data(), &d_cup}, {cdn_e.data(), &d_cdn}};
+      const std::pair<const int *, DevBuf<int> *> ends[2] = {{raw_up.p, &d_cup}, {raw_dn.p, &d_cdn}};
       for (const auto &e : ends) {
         e.second->alloc((size_t)nc_int); e.second->zero(stream);
-        if (nc > 0) HIP_CHECK(hipMemcpyAsync(raw.p, e.first, (size_t)nc * sizeof(int), hipMemcpyHostToDevice, stream));
-        launch_scatter_mapped(nc, c2i.p, d_ext2int.p, raw.p, e.second->p, stream);
-        HIP_CHECK(hipStreamSynchronize(stream));   // (raw is reused)
+        launch_scatter_mapped(nc, c2i.p, d_ext2int.p, e.first, e.second->p, stream);
+      }
+      HIP_CHECK(hipStreamSynchronize(stream));
+    }
+    std::vector<int> v_ptr, v_conn, v_slot, v_enc, v_o, v_slt;   // option setup_verify: what the device route built
+    int v_ellk = -1;
+    if (dev_lists) {
+      PhaseTimer pt("setup: incidence slots (device)");
+      device_incidence_slots(ia, stream);
+      int hf[2] = {0, 0};
+      HIP_CHECK(hipMemcpyAsync(hf, inc_flags.p, sizeof hf, hipMemcpyDeviceToHost, stream));
+      HIP_CHECK(hipStreamSynchronize(stream));
+      aux_kr.alloc(n); aux_dkr.alloc(n); aux_den.alloc(n); aux_dden.alloc(n);
+      ell_k = 0;
+      if (!thermal && !th && hf[0] > 0 && hf[0] <= 8 && hf[1] == 0) {   // ELL copy for k_flux_rows_ell (see the host route below)
+        const size_t cnt = (size_t)hf[0] * n;
+        d_ell_enc.alloc(cnt); d_ell_o.alloc(cnt); d_ell_slot.alloc(cnt);
+        device_fill_int(d_ell_enc.p, (long long)cnt, -1, stream); d_ell_o.zero(stream); device_fill_int(d_ell_slot.p, (long long)cnt, -1, stream);
+        device_incidence_ell(ia, d_ell_enc.p, d_ell_o.p, d_ell_slot.p, stream);
+        ell_k = hf[0];
+      }
+      HIP_CHECK(hipStreamSynchronize(stream));
+      if (opt.setup_verify) {
+        auto down = [&](std::vector<int> &h, const DevBuf<int> &d) {
+          h.resize(d.n);
+          if (d.n) HIP_CHECK(hipMemcpyAsync(h.data(), d.p, d.n * sizeof(int), hipMemcpyDeviceToHost, stream));
+        };
+        down(v_ptr, d_rc_ptr); down(v_conn, d_rc_conn); down(v_slot, d_rc_slot);
+        if (ell_k) { down(v_enc, d_ell_enc); down(v_o, d_ell_o); down(v_slt, d_ell_slot); }
+        HIP_CHECK(hipStreamSynchronize(stream));
+        v_ellk = ell_k;
       }
     }
-    // per-row incident connection lists, in the caller's connection order (general kernels only)
-    if (!vertical_only || opt.assembly == 0 || thermal || th) {
+    if (want_incidence && (!opt.setup_device || opt.setup_verify)) {
       PhaseTimer pt("setup: incidence lists");
       Scratch<int> ptr((size_t)n + 1, 0);
       host_parallel_for(nc, [&](long long c) { fetch_inc(&ptr[(size_t)ext2int[cup_e[c]] + 1]); fetch_inc(&ptr[(size_t)ext2int[cdn_e[c]] + 1]); });
@@ -744,7 +859,20 @@ struct Solver {
           });
           d_ell_enc.upload(enc.p, enc.n, stream); d_ell_o.upload(oth.p, oth.n, stream); d_ell_slot.upload(slt.p, slt.n, stream);
           ell_k = kmax;
+          if (v_ellk > 0 && (v_enc.size() != enc.n || !std::equal(v_enc.begin(), v_enc.end(), enc.p) || !std::equal(v_o.begin(), v_o.end(), oth.p) ||
+                             !std::equal(v_slt.begin(), v_slt.end(), slt.p)))
+            throw Error("setup_verify: the device-built ELL incidence arrays differ from the host-built ones");
         }
+      }
+      if (v_ellk >= 0) {   // option setup_verify: the device route ran first; its arrays against these
+        if (v_ellk != ell_k) throw Error("setup_verify: ELL width " + std::to_string(v_ellk) + " (device) vs " + std::to_string(ell_k) + " (host)");
+        if (v_ptr.size() != (size_t)n + 1 || !std::equal(v_ptr.begin(), v_ptr.end(), ptr.p))
+          throw Error("setup_verify: the device-built incidence pointers differ from the host-built ones");
+        if (v_conn.size() != rconn.size() || !std::equal(v_conn.begin(), v_conn.end(), rconn.begin()))
+          throw Error("setup_verify: the device-built incidence lists differ from the host-built ones");
+        if (!std::equal(v_slot.begin(), v_slot.end(), rslot.begin()))
+          throw Error("setup_verify: the device-built incidence slots differ from the host-built ones");
+        ++setup_verified;
       }
     }
     // tridiagonal slots of the per-column blocks
@@ -3368,6 +3496,8 @@ struct Solver {
     else if (key == "th_fused_dots") opt.th_fused_dots = num() != 0;
     else if (key == "th_spmv_cols") opt.th_spmv_cols = num() != 0;
     else if (key == "th_stage") opt.th_stage = num() != 0;
+    else if (key == "setup_device") { need_setup(false); opt.setup_device = num() != 0; }   // incidence lists built on the device (0: on the host)
+    else if (key == "setup_verify") { need_setup(false); opt.setup_verify = num() != 0; }   // ... both, compared (an error if they differ)
     else if (key == "ilu_box") { opt.ilu_box = (int)num(); pc_ready = false; }   // the factors are repacked for the other solve path
     else if (key == "ilu_box_factor") { opt.ilu_box_factor = num() != 0; pc_ready = false; }
     else if (key == "ilu_box_stream") opt.ilu_box_stream = num() != 0;     // box solves as streams: pencils by ticket, faces handed over 8 steps at a time
@@ -3860,11 +3990,11 @@ int mppgpu_get_assembly_info(mppgpu_handle h, int n, int *info) {
   API_BEGIN(h)
   S.ensure_ready();
   const bool cols = S.use_cols() && !S.th && !S.thermal;
-  const int v[10] = {cols ? S.ncls : 0, cols && S.lev_geo ? 1 : 0, cols && S.lev_pv ? 1 : 0, cols && S.rows_complete() ? 1 : 0,
+  const int v[11] = {cols ? S.ncls : 0, cols && S.lev_geo ? 1 : 0, cols && S.lev_pv ? 1 : 0, cols && S.rows_complete() ? 1 : 0,
                      cols ? S.pick_nseg() : 0, S.spmv_variant(), (S.opt.pc_type == 2 && !S.th && S.tri_lds()) ? 1 : 0,
                      (int)std::min<long long>(S.spec_misses, 2147483647LL), S.opt.ilu_graph ? 1 : 0,
-                     (int)(S.box_graph.execs.size() + S.ilu_graph.execs.size())};
-  for (int i = 0; i < n && i < 10; ++i) info[i] = v[i];
+                     (int)(S.box_graph.execs.size() + S.ilu_graph.execs.size()), S.setup_verified};
+  for (int i = 0; i < n && i < 11; ++i) info[i] = v[i];
   API_END()
 }
 int mppgpu_get_pc_info(mppgpu_handle h, int *path, int *launches, int *box_extents) {
