@@ -424,6 +424,15 @@ struct IncidenceArgs {
   const int *ext2int, *cup, *cdn, *c2i, *rowptr, *col;
   int *ptr, *rconn, *rslot, *roth, *flags;
 };
+// column detection: scratch arrays of n ints each (nxt, below, deg_up, deg_dn) and 8 flags, all allocated by the caller
+struct ColumnArgs {
+  int n, nc;
+  const int *cup, *cdn;
+  const signed char *is_vert;
+  int *nxt, *below, *deg_up, *deg_dn, *flags;
+};
+struct ColumnLayout { bool columns, vertical_only, identity_perm; int ncols, nz, nc_int; };
+void device_detect_columns(const ColumnArgs &a, bool allow_columns, int *ext2int, int *int2ext, int *c2i, ColumnLayout &out, hipStream_t stream);
 long long device_inclusive_scan(int *a, long long n, hipStream_t stream);
 void device_fill_int(int *a, long long n, int v, hipStream_t stream);
 long long device_incidence_pointers(const IncidenceArgs &a, hipStream_t stream);

@@ -149,6 +149,88 @@ __global__ __launch_bounds__(kBlock) void k_inc_ell(int n, const int *__restrict
   }
 }
 
+// ---- column detection (Solver::detect_columns): the vertical chains of the internal connection set, any cell numbering ----
+__global__ __launch_bounds__(kBlock) void k_col_links(ColumnArgs a) {
+  const size_t c = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (c >= (size_t)a.nc || !a.is_vert[c]) return;
+  const int u = a.cup[c], d = a.cdn[c];
+  a.nxt[u] = d; a.below[d] = u;
+  // a chain has at most ONE link above and one below every cell: counted (two links between the same pair store the same values)
+  atomicAdd(&a.deg_up[u], 1); atomicAdd(&a.deg_dn[d], 1);
+  atomicAdd(&a.flags[0], 1);
+}
+__global__ __launch_bounds__(kBlock) void k_col_starts(ColumnArgs a, int *__restrict__ start) {   // start[i + 1] = 1 for the first cell of a chain
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= (size_t)a.n) return;
+  if (a.deg_up[i] > 1 || a.deg_dn[i] > 1) a.flags[1] = 1;
+  start[i + 1] = a.below[i] == -1;
+}
+__global__ __launch_bounds__(kBlock) void k_col_walk(ColumnArgs a, const int *__restrict__ start, int len, int *__restrict__ lev,
+                                                     int *__restrict__ colof) {
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= (size_t)a.n || start[i + 1] == start[i]) return;   // (after the scan: the rank of a start is start[i + 1] - 1)
+  const int ch = start[i + 1] - 1;
+  int cur = (int)i, k = 0;
+  while (cur != -1 && k <= len) { lev[cur] = k; colof[cur] = ch; cur = a.nxt[cur]; ++k; }
+  if (k != len) a.flags[2] = 1;
+}
+__device__ __forceinline__ int cell_index_dev(int lev, int col, int ncols, int nz) {   // Solver::cell_index: tiled level-major
+  const int t = col >> 6, tw = min(64, ncols - (t << 6));
+  return t * 64 * nz + lev * tw + (col & 63);
+}
+__global__ __launch_bounds__(kBlock) void k_col_number(ColumnArgs a, int ncols, int nz, const int *__restrict__ lev,
+                                                       const int *__restrict__ colof, int *__restrict__ ext2int) {
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= (size_t)a.n) return;
+  if (lev[i] < 0) { a.flags[3] = 1; ext2int[i] = 0; return; }
+  ext2int[i] = cell_index_dev(lev[i], colof[i], ncols, nz);
+}
+__global__ __launch_bounds__(kBlock) void k_col_identity(int n, int *__restrict__ ext2int) {
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < (size_t)n) ext2int[i] = (int)i;
+}
+__global__ __launch_bounds__(kBlock) void k_col_inverse(ColumnArgs a, const int *__restrict__ ext2int, int *__restrict__ int2ext) {
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= (size_t)a.n) return;
+  int2ext[ext2int[i]] = (int)i;
+  if (ext2int[i] != (int)i) a.flags[4] = 1;
+}
+// internal connection numbering: chain links at the index of their lower cell; a lateral connection counts towards its upwind cell
+__global__ __launch_bounds__(kBlock) void k_conn_vertical(ColumnArgs a, const int *__restrict__ ext2int, int *__restrict__ c2i,
+                                                          int *__restrict__ cnt) {
+  const size_t c = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (c >= (size_t)a.nc) return;
+  const int u = ext2int[a.cup[c]];
+  if (a.is_vert[c]) c2i[c] = u;
+  else atomicAdd(&cnt[(size_t)u + 1], 1);
+}
+__global__ __launch_bounds__(kBlock) void k_conn_lateral_fill(ColumnArgs a, const int *__restrict__ ext2int, const int *__restrict__ ptr,
+                                                              int *__restrict__ cursor, int *__restrict__ list) {
+  const size_t c = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (c >= (size_t)a.nc || a.is_vert[c]) return;
+  const int u = ext2int[a.cup[c]];
+  list[ptr[u] + atomicAdd(&cursor[u], 1)] = (int)c;
+}
+// the j-th lateral connection (in the caller's order) whose upwind cell is u sits at n + j n + u
+__global__ __launch_bounds__(kBlock) void k_conn_lateral_number(ColumnArgs a, const int *__restrict__ ptr, int *__restrict__ list,
+                                                                int *__restrict__ c2i) {
+  const size_t u = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (u >= (size_t)a.n) return;
+  const int b = ptr[u], e = ptr[u + 1];
+  for (int p = b + 1; p < e; ++p) {
+    const int v = list[p];
+    int q = p - 1;
+    while (q >= b && list[q] > v) { list[q + 1] = list[q]; --q; }
+    list[q + 1] = v;
+  }
+  for (int p = b, j = 0; p < e; ++p, ++j) c2i[list[p]] = a.n + j * a.n + (int)u;
+  atomicMax(&a.flags[5], e - b);
+}
+__global__ __launch_bounds__(kBlock) void k_conn_identity(int nc, int *__restrict__ c2i) {
+  const size_t c = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (c < (size_t)nc) c2i[c] = (int)c;
+}
+
 __global__ __launch_bounds__(kBlock) void k_fill_int(long long n, int v, int *__restrict__ a) {
   const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
   if (i < n) a[i] = v;
@@ -206,6 +288,72 @@ void device_incidence_slots(const IncidenceArgs &a, hipStream_t stream) {
 }
 void device_incidence_ell(const IncidenceArgs &a, int *enc, int *oth, int *slt, hipStream_t stream) {
   if (a.n > 0) SLAUNCH(k_inc_ell, nblk(a.n), a.n, a.ptr, a.rconn, a.rslot, a.roth, enc, oth, slt);
+}
+
+// Column detection and the two numberings on the device.  In: the caller's connection ends (0-based) and the vertical flags.
+// Out: ext2int, int2ext (n ints), c2i (nc ints) on the device, the layout in `out`.  ghost cells (identity layout) are the caller's
+// business: pass allow_columns = false.
+void device_detect_columns(const ColumnArgs &a, bool allow_columns, int *ext2int, int *int2ext, int *c2i, ColumnLayout &out,
+                           hipStream_t stream) {
+  const int n = a.n, nc = a.nc;
+  device_fill_int(a.nxt, n, -1, stream); device_fill_int(a.below, n, -1, stream);
+  HIP_CHECK(hipMemsetAsync(a.deg_up, 0, (size_t)n * sizeof(int), stream));
+  HIP_CHECK(hipMemsetAsync(a.deg_dn, 0, (size_t)n * sizeof(int), stream));
+  HIP_CHECK(hipMemsetAsync(a.flags, 0, 8 * sizeof(int), stream));
+  if (nc > 0) SLAUNCH(k_col_links, nblk(nc), a);
+  DevBuf<int> start, lev, colof;
+  start.alloc((size_t)n + 1); start.zero(stream);
+  SLAUNCH(k_col_starts, nblk(n), a, start.p);
+  const int nchains = (int)device_inclusive_scan(start.p + 1, n, stream);
+  int hf[8];
+  auto flags = [&] {
+    HIP_CHECK(hipMemcpyAsync(hf, a.flags, sizeof hf, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+  };
+  flags();
+  const long long nvert = hf[0];
+  bool columns = false;
+  out.ncols = n; out.nz = 1;
+  if (allow_columns && hf[1] == 0 && nchains > 0 && n % nchains == 0) {
+    const int len = n / nchains;
+    lev.alloc((size_t)n); colof.alloc((size_t)n);
+    device_fill_int(lev.p, n, -1, stream); device_fill_int(colof.p, n, -1, stream);
+    SLAUNCH(k_col_walk, nblk(n), a, start.p, len, lev.p, colof.p);
+    flags();
+    if (hf[2] == 0) {
+      SLAUNCH(k_col_number, nblk(n), a, nchains, len, lev.p, colof.p, ext2int);
+      flags();
+      if (hf[3] == 0) { columns = true; out.ncols = nchains; out.nz = len; }
+    }
+  }
+  if (!columns) SLAUNCH(k_col_identity, nblk(n), n, ext2int);
+  SLAUNCH(k_col_inverse, nblk(n), a, ext2int, int2ext);
+  out.columns = columns;
+  if (columns && nvert == nc) {
+    if (nc > 0) SLAUNCH(k_conn_vertical, nblk(nc), a, ext2int, c2i, start.p);   // (no lateral connection: the counters stay untouched)
+    out.nc_int = n; out.vertical_only = true;
+  } else if (columns) {
+    start.zero(stream);   // reused: lateral connections per upwind cell
+    SLAUNCH(k_conn_vertical, nblk(nc), a, ext2int, c2i, start.p);
+    const long long nlat = device_inclusive_scan(start.p + 1, n, stream);
+    int jmax = 0;
+    if (nlat > 0) {
+      DevBuf<int> cursor, list;
+      cursor.alloc((size_t)n); cursor.zero(stream);
+      list.alloc((size_t)nlat);
+      SLAUNCH(k_conn_lateral_fill, nblk(nc), a, ext2int, start.p, cursor.p, list.p);
+      SLAUNCH(k_conn_lateral_number, nblk(n), a, start.p, list.p, c2i);
+      flags();
+      jmax = hf[5];
+      if ((long long)n * (jmax + 1) > 0x3fffffffLL) throw Error("too many lateral connections per cell for 32-bit connection ids");
+    }
+    out.nc_int = n + jmax * n; out.vertical_only = nlat == 0;
+  } else {
+    if (nc > 0) SLAUNCH(k_conn_identity, nblk(nc), nc, c2i);
+    out.nc_int = nc; out.vertical_only = false;
+  }
+  flags();
+  out.identity_perm = hf[4] == 0;
 }
 
 }  // namespace mpp

@@ -91,6 +91,7 @@ struct Solver {
   bool any_inactive = false;
   int nc = 0;
   BigVec<int> cup_e, cdn_e;
+  BigVec<signed char> cvert;   // 1: the connection is (mostly) vertical -- a chain link of the column layout
   BigVec<double> cdu, cdd, carea, cuv;
   std::vector<Condition> bcs, sss;
   // mesh%lateral_conn_set_list (operator split: RichardsODEComputeLateralFlux, GE:2615-2743)
@@ -372,7 +373,7 @@ struct Solver {
     PhaseTimer pt("set_connections");
     nc = nconn;
     cup_e.resize(nc); cdn_e.resize(nc);
-    cdu.resize(nc); cdd.resize(nc); carea.resize(nc); cuv.resize(3 * (size_t)nc);
+    cdu.resize(nc); cdd.resize(nc); carea.resize(nc); cuv.resize(3 * (size_t)nc); cvert.resize(nc);
     host_parallel_for(nc, [&](long long c) {   // (the first exception any thread throws reaches the caller)
       if (up[c] < 1 || up[c] > n || dn[c] < 1 || dn[c] > n)
         throw Error("connection " + std::to_string(c + 1) + ": cell id out of range");
@@ -380,6 +381,7 @@ struct Solver {
       cup_e[c] = up[c] - 1; cdn_e[c] = dn[c] - 1;
       cdu[c] = du[c]; cdd[c] = dd[c]; carea[c] = ar[c];
       cuv[3 * (size_t)c] = uv[3 * (size_t)c]; cuv[3 * (size_t)c + 1] = uv[3 * (size_t)c + 1]; cuv[3 * (size_t)c + 2] = uv[3 * (size_t)c + 2];
+      cvert[c] = is_vertical(&uv[3 * (size_t)c]);
     });
   }
 
@@ -515,6 +517,7 @@ struct Solver {
   static int fetch_inc(int *p) { return __atomic_fetch_add(p, 1, __ATOMIC_RELAXED); }
   static void put(int *p, int v) { __atomic_store_n(p, v, __ATOMIC_RELAXED); }
 
+  static bool is_vertical(const double *u) { return std::fabs(u[2]) > 0.5 * std::sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]); }
   void detect_columns() {
     // vertical chains of the internal connection set (any cell numbering)
     Scratch<int> nxt(n, -1), below(n, -1), deg_up(n, 0), deg_dn(n, 0);
@@ -524,8 +527,7 @@ struct Solver {
     host_parallel_ranges(nc, [&](long long c0, long long c1) {
       long long mine = 0;
       for (long long c = c0; c < c1; ++c) {
-        const double ux = cuv[3 * (size_t)c], uy = cuv[3 * (size_t)c + 1], uz = cuv[3 * (size_t)c + 2];
-        if (std::fabs(uz) > 0.5 * std::sqrt(ux * ux + uy * uy + uz * uz)) {
+        if (is_vertical(&cuv[3 * (size_t)c])) {
           is_vert[c] = 1;
           ++mine;
           put(&nxt[cup_e[c]], cdn_e[c]); put(&below[cdn_e[c]], cup_e[c]);
@@ -704,16 +706,50 @@ struct Solver {
     nrow = th ? 2 * n : n;
     nred = th ? nrow : nrow - nghost;
     if (nghost > 0 && !halo.set) throw Error("ghost cells need a halo plan (mppgpu_set_halo)");
-    { PhaseTimer pt("setup: column detection"); detect_columns(); }
+    DevBuf<int> c2i, raw_up, raw_dn;   // cext2int and the caller's connection ends on the device while set-up needs them
+    raw_up.upload(cup_e.data(), (size_t)nc, stream); raw_dn.upload(cdn_e.data(), (size_t)nc, stream);
+    if (opt.setup_device) {
+      // chains, the tiled level-major cell numbering and the connection numbering by kernels (setup_kernels.hip); the three maps
+      // come back to the host, which keeps them for the caller-facing permutations and the conditions
+      PhaseTimer pt("setup: column detection (device)");
+      DevBuf<int> scratch[4], flags;
+      DevBuf<signed char> vert;
+      for (auto &b : scratch) b.alloc((size_t)n);
+      flags.alloc(8);
+      vert.upload(cvert.data(), (size_t)nc, stream);
+      d_ext2int.alloc((size_t)n); d_int2ext.alloc((size_t)n); c2i.alloc((size_t)nc);
+      ColumnLayout lay{};
+      device_detect_columns(ColumnArgs{n, nc, raw_up.p, raw_dn.p, vert.p, scratch[0].p, scratch[1].p, scratch[2].p, scratch[3].p, flags.p},
+                            nghost == 0, d_ext2int.p, d_int2ext.p, c2i.p, lay, stream);
+      columns = lay.columns; vertical_only = lay.vertical_only; identity_perm = lay.identity_perm;
+      ncols = lay.ncols; nz = lay.nz; nc_int = lay.nc_int;
+      ext2int.resize(n); int2ext.resize(n); cext2int.resize(nc);
+      host_parallel_for(n, [&](long long i) { ext2int[i] = 0; int2ext[i] = 0; });   // (pages touched by all threads before the copies land)
+      host_parallel_for(nc, [&](long long c) { cext2int[c] = 0; });
+      HIP_CHECK(hipMemcpyAsync(ext2int.data(), d_ext2int.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, stream));
+      HIP_CHECK(hipMemcpyAsync(int2ext.data(), d_int2ext.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, stream));
+      if (nc > 0) HIP_CHECK(hipMemcpyAsync(cext2int.data(), c2i.p, (size_t)nc * sizeof(int), hipMemcpyDeviceToHost, stream));
+      HIP_CHECK(hipStreamSynchronize(stream));
+      if (opt.setup_verify) {
+        const BigVec<int> e2i = ext2int, i2e = int2ext, ce = cext2int;
+        const ColumnLayout dev = lay;
+        detect_columns();
+        if (dev.columns != columns || dev.vertical_only != vertical_only || dev.identity_perm != identity_perm || dev.ncols != ncols ||
+            dev.nz != nz || dev.nc_int != nc_int || e2i != ext2int || i2e != int2ext || ce != cext2int)
+          throw Error("setup_verify: the device-built column layout differs from the host-built one");
+        ++setup_verified;
+      }
+    } else {
+      PhaseTimer pt("setup: column detection");
+      detect_columns();
+      d_ext2int.upload(ext2int, stream);
+      d_int2ext.upload(int2ext, stream);
+      c2i.upload(cext2int.data(), (size_t)nc, stream);
+    }
     // per-row incident connection lists, in the caller's connection order (general kernels only)
     const bool want_incidence = !vertical_only || opt.assembly == 0 || thermal || th;
     const bool dev_lists = want_incidence && opt.setup_device;   // incidence lists and CSR pattern on the device (setup_kernels.hip)
     if ((long long)nc * 2 > 0x7fffffffLL && want_incidence) throw Error("too many connections for the 32-bit incidence keys");
-    d_ext2int.upload(ext2int, stream);
-    d_int2ext.upload(int2ext, stream);
-    DevBuf<int> c2i, raw_up, raw_dn;   // cext2int and the caller's connection ends on the device while set-up needs them
-    c2i.upload(cext2int.data(), (size_t)nc, stream);
-    raw_up.upload(cup_e.data(), (size_t)nc, stream); raw_dn.upload(cdn_e.data(), (size_t)nc, stream);
     DevBuf<int> inc_roth, inc_flags;
     IncidenceArgs ia{n, nc, d_ext2int.p, raw_up.p, raw_dn.p, c2i.p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (dev_lists) {
