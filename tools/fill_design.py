@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """Fill the measured numbers of DESIGN.md from the evidence files of a round (the @@NAME@@ placeholders of DESIGN.md.in).
 
-    python3 tools/fill_design.py profiles/r03_evidence > DESIGN.md
+    python3 tools/fill_design.py profiles/r04_evidence > DESIGN.md
 
 Reads bench.json, bench2.json, bench_256x256x50*.json, bench_1024x128x100.json, kernel_traffic.json,
-rocprofv3_kernel_stats_bench.csv, th_512x512x80.json of that directory, profiles/r03_kbench_laws.json and
-profiles/r03_thermal_512.json."""
+rocprofv3_kernel_stats_bench.csv, th_512x512x80.json, thermal_512.json, pmc_th_512x512x80.json, pmc_thermal_512.json and the
+rocprofv3_kernel_stats_{th_512x512x80,thermal_512}.csv of that directory, and profiles/r03_kbench_laws*.json (the column march
+per constitutive law: those kernels did not change in round 4)."""
 from __future__ import annotations
 
 import csv
@@ -110,7 +111,7 @@ def main():
     roof = bench["roofline"]
     cb = bench.get("cpu_baseline", {})
     results.append("")
-    results.append("Round 2's driver run: 105.7 Newton it/s (`BENCH_r02.json`); box-to-box spread of this pool ≈ ±4 %% (the column march "
+    results.append("Driver runs: 105.7 (`BENCH_r02.json`), 125.5 (`BENCH_r03.json`) Newton it/s; box-to-box spread of this pool ≈ ±4 %% (the column march "
                    "follows the box's clocks: %.2f ms here, 1.83–2.30 ms over the round's boxes)." % bench["kernels"]["jacobian"]["avg_ms"])
     results.append("`roofline` of that line: %s → **%.0f GB/s of algorithmic CSR bytes = %.3f of peak** (%.5f ms per launch, HIP events); "
                    "%.0f GB/s = %.3f of peak on the bytes it moves (PMC %.3f GB per launch); the plain `y = A x` kernel timed behind the "
@@ -125,21 +126,64 @@ def main():
                                            cb["value_one_core"], bench["value"] / cb["value"], bench["value"] / cb["same_solver_as_gpu"]["value"]))
     results_txt = "\n".join(results)
 
+    ex = bench.get("extra_configs") or []
+    extra_rows = []
+    for e in ex:
+        extra_rows.append("%s: **%.1f** Newton it/s (%.3f ms per Newton iteration, set-up %.1f s)" % (
+            e.get("config", "?"), e.get("value", 0.0), e.get("ms_per_newton_iteration", 0.0), e.get("setup_s", 0.0)))
+    extra_txt = "; ".join(extra_rows) if extra_rows else "(none in this line)"
     per_newton = 0.0
     out = open(os.path.join(ROOT, "DESIGN.md.in")).read()
-    th_line = "%.1f Newton it/s (BiCGStab + per-column 2×2 block-Jacobi; round 2: 95.8), column march %.2f ms" % (
+    th_line = "%.1f Newton it/s (BiCGStab + per-column 2×2 block-Jacobi; round 2: 95.8, round 3: 103.6), column march %.2f ms" % (
         th["newton_its_per_s"], th["kernels"]["jacobian"]["avg_ms"])
-    thermal = "see `profiles/r03_thermal_512.json`"
-    tf = os.path.join(ROOT, "profiles", "r03_thermal_512.json")
+
+    def kstats(fname):
+        d = {}
+        f = os.path.join(ev, fname)
+        if os.path.exists(f):
+            for r in csv.DictReader(open(f)):
+                d[short(r["Name"])] = (int(r["Calls"]), float(r["AverageNs"]) * 1e-6)
+        return d
+
+    def pmc(fname):
+        f = os.path.join(ev, fname)
+        if not os.path.exists(f):
+            return {}
+        return {short(k): v["hbm_bytes_per_launch"] for k, v in json.load(open(f))["kernels"].items()}
+
+    def frac_rows(stats_file, pmc_file, cells, picks):
+        st, mv = kstats(stats_file), pmc(pmc_file)
+        out = []
+        for kern, label in picks:
+            if kern in st and kern in mv:
+                calls, ms = st[kern]
+                out.append("%s %.2f ms, %.0f B per cell, **%.2f** of peak" % (label, ms, mv[kern] / cells, mv[kern] / (ms * 1e-3) / 8e12))
+        return "; ".join(out)
+
+    th_pmc = frac_rows("rocprofv3_kernel_stats_th_512x512x80.csv", "pmc_th_512x512x80.json", 512 * 512 * 80, (
+        ("k_th_spmv_cols", "index-free SpMV `k_th_spmv_cols`"), ("k_th_tri_solve_dots<2>", "block-Thomas solve + dots"),
+        ("k_th_tri_solve_dots<1>", "… with one dot"), ("k_th_tri_factor", "block factorisation"), ("k_bcgs_xr<true>", "`k_bcgs_xr`"),
+        ("k_th_cols<2, 1>", "column march `k_th_cols<2>` (residual + Jacobian)"), ("k_th_cols<0, 1>", "`k_th_cols<0>` (residual)")))
+    thermal_pmc = frac_rows("rocprofv3_kernel_stats_thermal_512.csv", "pmc_thermal_512.json", 512 ** 3, (
+        ("k_box_lower_stream<8, false>", "lower stream"), ("k_box_upper_stream<8, false>", "upper stream"),
+        ("k_box_gather_in", "gather into the box layout"), ("k_gather", "gather back"), ("k_spmv_pipe_mb<7>", "SpMV"),
+        ("k_mdot", "`k_mdot`"), ("k_maxpy_neg", "`k_maxpy_neg`")))
+    thermal = "see `%s/thermal_512.json`" % ev
+    tf = os.path.join(ev, "thermal_512.json")
+    if not os.path.exists(tf):
+        tf = os.path.join(ROOT, "profiles", "r03_thermal_512.json")
     if os.path.exists(tf):
         t = json.load(open(tf))
         sw = {("%g" % x["ksp_rtol"]): x for x in t.get("rtol_sweep", [])}
-        thermal = ("mesh build %.0f s (r02: 58), library set-up %.1f s (r02: 88), %d GMRES(30) iterations in %.1f s at PETSc's default "
-                   "`ksp_rtol` 1e-5 (error vs the manufactured solution %.2f K), %d iterations / %.1f s at 1e-8 (%.4f K); ILU(0) "
-                   "application %.2f ms" % (t["build_s"], t["setup_s"], t["linear_iterations"], t["step_s"],
-                                            t["max_error_vs_manufactured_solution"], sw.get("1e-08", {}).get("linear_iterations", 0),
-                                            sw.get("1e-08", {}).get("step_s", 0), sw.get("1e-08", {}).get("max_error_vs_manufactured_solution", 0),
-                                            t["roofline"]["avg_apply_ms"]))
+        its = t["linear_iterations"]
+        thermal = ("library set-up %.1f s in all (r02: 88, r03: 34.3; `mppgpu_setup` itself 25.6 → 3.0 s with the index analysis on "
+                   "the device, `profiles/r04/setup_phase_timing_device.log`), %d GMRES(30) iterations in %.1f s at PETSc's default "
+                   "`ksp_rtol` 1e-5 = %.1f ms per iteration (r03: 16.3; error vs the manufactured solution %.2f K), %d iterations / "
+                   "%.1f s at 1e-8 (%.4f K); ILU(0) application %.2f ms in %d launches (r03: 6.59 ms in 270)" % (
+                       t["setup_s"], its, t["step_s"], 1e3 * t["step_s"] / max(its, 1),
+                       t["max_error_vs_manufactured_solution"], sw.get("1e-08", {}).get("linear_iterations", 0),
+                       sw.get("1e-08", {}).get("step_s", 0), sw.get("1e-08", {}).get("max_error_vs_manufactured_solution", 0),
+                       t["roofline"]["avg_apply_ms"], t["roofline"].get("launches_per_application", 0)))
     share = "%.0f Newton it/s on 1024×128 columns = %.1f %% of 8× the full-grid rate of the same box" % (s8["value"], 100.0 * s8["value"] / (8 * bench2["value"]))
     # bytes per cell and Newton iteration from the moved bytes and the launch counts of the profiled run
     tot = 0.0
@@ -153,7 +197,9 @@ def main():
     bytes_txt = "%.0f" % (tot / N / newton_prof) if newton_prof else "?"
     subs = {"KERNEL_TABLE": kernel_table, "LAWS_TABLE": laws_table, "RESULTS": results_txt,
             "READBACKS": "%.2f–%.2f" % (min(rb(s8), rb(c2s)), max(rb(bench), rb(bench2))),
-            "ANSWER": "%.1e" % bench["answer_check"]["max_rel_err"], "SHARE": share, "THERMAL": thermal, "TH": th_line, "BYTES": bytes_txt}
+            "ANSWER": "%.1e" % bench["answer_check"]["max_rel_err"], "SHARE": share, "THERMAL": thermal, "TH": th_line, "BYTES": bytes_txt,
+            "TH_PMC": th_pmc or "(PMC passes not in the evidence directory)", "THERMAL_PMC": thermal_pmc or "(PMC passes not in the evidence directory)",
+            "EXTRA": extra_txt}
     for k, v in subs.items():
         out = out.replace("@@%s@@" % k, v)
     sys.stdout.write(out)
