@@ -180,8 +180,13 @@ int mppgpu_set_source_sink_auxvar(mppgpu_handle h, int var_type, int n, const do
  * the column LU), "fused_ls_dots" (0|1: line-search reductions inside the SpMV), "ilu_graph", "ilu_chain" (0 one launch
  * per level | 1 chained tiles where they pay | 2 always chained), "ilu_box" (ILU(0) of a structured grid in natural ordering
  * factorised and solved box by box: 0 never | 1 when the pattern is such a grid | 2 or fail), "ilu_box_len" (box extent along the
- * fastest direction), "ilu_box_factor" (0: factorise by the general elimination program, solve by boxes), "ell_assembly",
- * "defer_test0", "ls_ahead", "wide_xr", "track_mass_exchange".
+ * fastest direction), "ilu_box_factor" (0: factorise by the general elimination program, solve by boxes), "ilu_box_stream"
+ * (1: the box solves as two streams of pencils per application, faces handed over inside the launch; 0: one launch per box
+ * level), "ilu_box_workers", "ilu_box_fused_io", "ilu_box_queue", "th_spmv_cols" / "th_stage" (coupled system on soil columns:
+ * index-free SpMV, matrix rows staged through LDS), "ksp_gmres_restart" (1..4096, default 30), "ell_assembly", "defer_test0",
+ * "ls_ahead", "wide_xr", "track_mass_exchange".
+ * Set-up keys (before mppgpu_setup): "setup_device" (1: column detection, numberings, incidence lists and the CSR pattern are
+ * built by kernels; 0: on the host's cores), "setup_verify" (1: both, every array compared -- an error if they differ).
  * Environment: MPPGPU_HOST_THREADS (threads of the set-up passes on the host; default: the cores the process may run on, at
  * most 32), MPPGPU_TIMING (set: wall-clock of the set-up phases on stderr). */
 int mppgpu_set_option(mppgpu_handle h, const char *key, const char *value);
