@@ -124,6 +124,12 @@ def main():
                        "defaults; %.3f with the GPU's own BiCGStab + block-Jacobi; %.4f on one core — the reference itself is serial) → "
                        "%.0f× / %.0f×." % (cb["value"], cb["cores"], cb.get("cpu_model", "?"), cb["same_solver_as_gpu"]["value"],
                                            cb["value_one_core"], bench["value"] / cb["value"], bench["value"] / cb["same_solver_as_gpu"]["value"]))
+        xp = cb.get("extrapolated_all_physical_cores")
+        if xp:
+            results[-1] += ("  The box has %d physical cores of which the process may use %d: `extrapolated_all_physical_cores` scales "
+                            "linearly (an upper bound for a bandwidth-bound solve) to %.2f–%.2f Newton it/s → **%.0f×** against the "
+                            "whole host (north-star: ≥ 10×)." % (xp["physical_cores"], cb["cores"], xp["from_threads_measured"],
+                                                                 xp["from_one_core"], xp["gpu_over_cpu"]))
     results_txt = "\n".join(results)
 
     ex = bench.get("extra_configs") or []
@@ -166,8 +172,11 @@ def main():
         ("k_th_cols<2, 1>", "column march `k_th_cols<2>` (residual + Jacobian)"), ("k_th_cols<0, 1>", "`k_th_cols<0>` (residual)")))
     thermal_pmc = frac_rows("rocprofv3_kernel_stats_thermal_512.csv", "pmc_thermal_512.json", 512 ** 3, (
         ("k_box_lower_stream<8, false>", "lower stream"), ("k_box_upper_stream<8, false>", "upper stream"),
-        ("k_box_gather_in", "gather into the box layout"), ("k_gather", "gather back"), ("k_spmv_pipe_mb<7>", "SpMV"),
+        ("k_box_gather_in", "gather into the box layout"), ("k_gather", "gather back"), ("k_spmv_pipe_mb<7>", "SpMV")))
+    gs = frac_rows("rocprofv3_kernel_stats_thermal_512_short.csv", "pmc_thermal_512.json", 512 ** 3, (
         ("k_mdot", "`k_mdot`"), ("k_maxpy_neg", "`k_maxpy_neg`")))
+    if gs:   # (their work per launch grows with the basis: averages of the short command the PMC passes ran, 20 iterations)
+        thermal_pmc += "; Gram–Schmidt kernels, averaged over the 20 iterations of the PMC passes' own command: " + gs
     thermal = "see `%s/thermal_512.json`" % ev
     tf = os.path.join(ev, "thermal_512.json")
     if not os.path.exists(tf):

@@ -52,5 +52,8 @@ timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE -d $O/f_tm -o f --output-format csv
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE -d $O/w_tm -o w --output-format csv -- python3 $TM > $O/tm_w.log 2>&1; echo "thermal write rc=$?"
 python3 tools/pmc_summary.py $O/f_tm $O/w_tm k_box k_thermal k_spmv k_mdot k_maxpy k_gather k_copy k_scale > $O/pmc_thermal_512.json 2> $O/pmc_tm.err; echo "rc=$?"
 rm -rf $O/f_tm $O/w_tm
+# kernel stats of the same short command (the Gram-Schmidt kernels' work per launch grows with the basis: averages of runs of the same length)
+timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $O/prof_thermal_short -o t --output-format csv -- python3 $TM > $O/prof_thermal_short.log 2>&1; echo "rc=$?"
+rm -f $O/prof_thermal_short/*kernel_trace.csv $O/prof_thermal_short/*/*kernel_trace.csv
 fi
 ls $O
