@@ -1404,25 +1404,75 @@ __global__ __launch_bounds__(kBlock) void k_box_load(long long nslots, BoxGrid g
 // one LDS bank -- and the way back through the same image instead of k_gather's per-row slot map: 1.03 and 0.99 ms at 512^3 against
 // 0.82 and 0.73 ms: the padding costs the fourth workgroup per CU (41.6 instead of 40 KB), the image a barrier k_gather does not
 // have; gpurun_out/r04_run13.  Not kept.)
-__device__ __forceinline__ int box_img(int t) { return t; }
+// The LDS image is written line by line: a wave's 64 cells of a grid line land 128 doubles apart (two step rows), i.e. in ONE pair of
+// banks -- a 32-way conflict.  Swizzle: the row-pair number (bits 7..10 of the slot) is XORed into bits 1..4, a permutation inside
+// every aligned group of 32 doubles: the line-order accesses spread over all banks, the slot-order copies stay conflict-free, the
+// image keeps its size (padding it instead cost the fourth workgroup per CU and was slower).
+__device__ __forceinline__ int box_img(int t) { return t ^ (((t >> 7) & 15) << 1); }
+// (Eight cells per thread and pass: their index loads go out together, then their value loads -- one dependent pair at a time left
+// the 16 waves a CU holds of this kernel with too little in flight.  Padding slots are recognised when the image is written out, so
+// the image is not cleared first: one barrier less.)
+constexpr int kBoxIoUnroll = 8;
+__device__ __forceinline__ bool box_slot_is_cell(const BoxGrid &g, int I, int J, int K, int t) {   // slot t of box (I, J, K) holds a grid cell
+  const int row = ((t >> 7) << 1) | (t & 1), line = (t & 127) >> 1, jp = line & (g.B2 - 1), kp = line >> g.lg2, ip = row - jp - kp;
+  return ip >= 0 && ip < g.B1 && I * g.B1 + ip < g.n1 && J * g.B2 + jp < g.n2 && K * g.B3 + kp < g.n3;
+}
 __global__ __launch_bounds__(kBlock) void k_box_gather_in(BoxGrid g, const int *__restrict__ ext2int, const double *__restrict__ r,
                                                           double *__restrict__ v) {
-  extern __shared__ double img[];   // box_img(S * 64) doubles
-  const int b = blockIdx.x, nslot = g.S * 64;
+  extern __shared__ double img[];   // S * 64 doubles, swizzled (box_img)
+  const int b = blockIdx.x, nslot = g.S * 64, ncell = 64 * g.B1;
   const int I = b % g.NB1, J = (b / g.NB1) % g.NB2, K = b / (g.NB1 * g.NB2);
-  for (int t = threadIdx.x; t < nslot; t += kBlock) img[box_img(t)] = 0.0;
-  __syncthreads();
-  for (int q = threadIdx.x; q < 64 * g.B1; q += kBlock) {
-    const int line = q / g.B1, ip = q - line * g.B1, jp = line & (g.B2 - 1), kp = line >> g.lg2;
-    const int i = I * g.B1 + ip, j = J * g.B2 + jp, k = K * g.B3 + kp;
-    if (i < g.n1 && j < g.n2 && k < g.n3) {
-      const int row = ip + jp + kp;
-      img[box_img((row & ~1) * 64 + 2 * line + (row & 1))] = r[ext2int[i + g.n1 * (j + g.n2 * k)]];
+  for (int q0 = threadIdx.x; q0 < ncell; q0 += kBlock * kBoxIoUnroll) {
+    int src[kBoxIoUnroll], dst[kBoxIoUnroll];
+#pragma unroll
+    for (int u = 0; u < kBoxIoUnroll; ++u) {
+      const int q = q0 + u * kBlock;
+      const int line = q / g.B1, ip = q - line * g.B1, jp = line & (g.B2 - 1), kp = line >> g.lg2;
+      const int i = I * g.B1 + ip, j = J * g.B2 + jp, k = K * g.B3 + kp, row = ip + jp + kp;
+      const bool ok = q < ncell && i < g.n1 && j < g.n2 && k < g.n3;
+      src[u] = ok ? ext2int[i + g.n1 * (j + g.n2 * k)] : -1;
+      dst[u] = box_img((row & ~1) * 64 + 2 * line + (row & 1));
     }
+    double val[kBoxIoUnroll];
+#pragma unroll
+    for (int u = 0; u < kBoxIoUnroll; ++u) val[u] = src[u] >= 0 ? r[src[u]] : 0.0;
+#pragma unroll
+    for (int u = 0; u < kBoxIoUnroll; ++u) if (src[u] >= 0) img[dst[u]] = val[u];
   }
   __syncthreads();
   double *out = v + (size_t)b * nslot;
-  for (int t = threadIdx.x; t < nslot; t += kBlock) out[t] = img[box_img(t)];
+  for (int t = threadIdx.x; t < nslot; t += kBlock) out[t] = box_slot_is_cell(g, I, J, K, t) ? img[box_img(t)] : 0.0;
+}
+// ... and the way back: a box's solution rows into the image as they lie, then out line by line (coalesced writes of z and reads of
+// ext2int; k_gather reads the solution through the per-row slot map, 16 useful bytes of every 32-byte sector)
+__global__ __launch_bounds__(kBlock) void k_box_gather_out(BoxGrid g, const int *__restrict__ ext2int, const double *__restrict__ v,
+                                                           double *__restrict__ z) {
+  extern __shared__ double img[];
+  const int b = blockIdx.x, nslot = g.S * 64, ncell = 64 * g.B1;
+  const int I = b % g.NB1, J = (b / g.NB1) % g.NB2, K = b / (g.NB1 * g.NB2);
+  const double *in = v + (size_t)b * nslot;
+  for (int t0 = threadIdx.x; t0 < nslot; t0 += kBlock * kBoxIoUnroll) {
+    double val[kBoxIoUnroll];
+#pragma unroll
+    for (int u = 0; u < kBoxIoUnroll; ++u) { const int t = t0 + u * kBlock; val[u] = t < nslot ? __builtin_nontemporal_load(in + t) : 0.0; }
+#pragma unroll
+    for (int u = 0; u < kBoxIoUnroll; ++u) { const int t = t0 + u * kBlock; if (t < nslot) img[box_img(t)] = val[u]; }
+  }
+  __syncthreads();
+  for (int q0 = threadIdx.x; q0 < ncell; q0 += kBlock * kBoxIoUnroll) {
+    int dst[kBoxIoUnroll], slot[kBoxIoUnroll];
+#pragma unroll
+    for (int u = 0; u < kBoxIoUnroll; ++u) {
+      const int q = q0 + u * kBlock;
+      const int line = q / g.B1, ip = q - line * g.B1, jp = line & (g.B2 - 1), kp = line >> g.lg2;
+      const int i = I * g.B1 + ip, j = J * g.B2 + jp, k = K * g.B3 + kp, row = ip + jp + kp;
+      const bool ok = q < ncell && i < g.n1 && j < g.n2 && k < g.n3;
+      dst[u] = ok ? ext2int[i + g.n1 * (j + g.n2 * k)] : -1;
+      slot[u] = box_img((row & ~1) * 64 + 2 * line + (row & 1));
+    }
+#pragma unroll
+    for (int u = 0; u < kBoxIoUnroll; ++u) if (dst[u] >= 0) z[dst[u]] = img[slot[u]];
+  }
 }
 __global__ __launch_bounds__(kBlock) void k_gather_or_zero(long long n, const int *idx, const double *in, double *out) {
   const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
@@ -2969,6 +3019,10 @@ void launch_box_factor(const BoxGrid &g, const int *boxes, int nboxes, double *c
 }
 static size_t box_img_bytes(const BoxGrid &g) { return (size_t)g.S * 64 * sizeof(double); }
 bool box_gather_in_fits(const BoxGrid &g) { return box_img_bytes(g) <= 48 * 1024; }
+void launch_box_gather_out(const BoxGrid &g, const int *ext2int, const double *v, double *z, hipStream_t stream) {
+  const long long nboxes = (long long)g.NB1 * g.NB2 * g.NB3;
+  if (nboxes > 0) hipLaunchKernelGGL(k_box_gather_out, dim3((unsigned)nboxes), dim3(kBlock), box_img_bytes(g), stream, g, ext2int, v, z);
+}
 void launch_box_gather_in(const BoxGrid &g, const int *ext2int, const double *r, double *v, hipStream_t stream) {
   const long long nboxes = (long long)g.NB1 * g.NB2 * g.NB3;
   if (nboxes > 0) hipLaunchKernelGGL(k_box_gather_in, dim3((unsigned)nboxes), dim3(kBlock), box_img_bytes(g), stream, g, ext2int, r, v);

@@ -293,6 +293,7 @@ void launch_gather_or_zero(long long n, const int *idx, const double *in, double
 // LDS image of the box (box_gather_in_fits: S * 64 doubles within 48 KB; otherwise launch_gather_or_zero through the slot map)
 bool box_gather_in_fits(const BoxGrid &g);
 void launch_box_gather_in(const BoxGrid &g, const int *ext2int, const double *r, double *v, hipStream_t stream);
+void launch_box_gather_out(const BoxGrid &g, const int *ext2int, const double *v, double *z, hipStream_t stream);
 // the boxes of one box level (ids in boxes[0 .. nboxes)), in place on the vector in box layout
 // scratch: 128 doubles anybody may overwrite
 void launch_box_lower(const BoxGrid &g, const int *boxes, int nboxes, const double *const L[3], double *y, double *scratch, hipStream_t stream);

@@ -230,6 +230,8 @@ struct Options {
   bool th_fused_dots = true;   // coupled TH, bjacobi: the Krylov dot products of M^{-1} r come out of the block column solve
   int ilu_box = 1;             // ILU(0) solves box by box when the pattern is a structured grid in natural ordering (BoxGrid); 0: never, 2: or fail
   bool ilu_box_factor = true;  // ... and the numeric factorisation too (extents other than 2); false: by the elimination program of the general path
+  bool ilu_box_img_out = true;   // box solves: the way back to the row order through an LDS image of the box (k_box_gather_out: 0.53 ms at 512^3)
+                                 // instead of the per-row slot map (k_gather: 0.79 ms)
   bool ilu_box_stream = true;  // ... as streams: a wave owns the NB1 boxes of one (J, K), pencils by ticket in the order of J + K, faces handed over 8 steps
                                // at a time through sentinel-initialised face buffers (k_box_lower_stream); needs 8 x 8 box cross-sections
   bool ilu_box_fused_io = false; // streamed box solves: the lower solve gathers its right-hand side from the Krylov vector, the upper one scatters the

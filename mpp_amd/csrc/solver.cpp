@@ -1886,7 +1886,10 @@ struct Solver {
         if (!solved) { ++box_queue_fallbacks; gather_in(); }
       }
       if (!solved) run_graph(box_graph, [&] { box_solve_levels(); });
-      if (!(solved && fused_io)) launch_gather(nred, box_cellpos.p, box_v.p, z, stream);   // back to the internal row order
+      if (!(solved && fused_io)) {   // back to the internal row order
+        if (opt.ilu_box_img_out && box_gather_in_fits(box)) launch_box_gather_out(box, d_ext2int.p, box_v.p, z, stream);
+        else launch_gather(nred, box_cellpos.p, box_v.p, z, stream);
+      }
       if (nghost > 0) launch_set(nghost, 0.0, z + nred, stream);             // (identity rows, zero right-hand side)
     } else if (opt.pc_type == 1) {
       launch_gather(nrow, d_lrows.p, r, ilu_y.p, stream);            // r into the L level order
@@ -3536,6 +3539,7 @@ struct Solver {
     else if (key == "setup_verify") { need_setup(false); opt.setup_verify = num() != 0; }   // ... both, compared (an error if they differ)
     else if (key == "ilu_box") { opt.ilu_box = (int)num(); pc_ready = false; }   // the factors are repacked for the other solve path
     else if (key == "ilu_box_factor") { opt.ilu_box_factor = num() != 0; pc_ready = false; }
+    else if (key == "ilu_box_img_out") opt.ilu_box_img_out = num() != 0;   // the solution leaves the box layout through an LDS image (k_box_gather_out)
     else if (key == "ilu_box_stream") opt.ilu_box_stream = num() != 0;     // box solves as streams: pencils by ticket, faces handed over 8 steps at a time
     else if (key == "ilu_box_fused_io") opt.ilu_box_fused_io = num() != 0; // ... reading r and writing z through the slot map themselves
     else if (key == "ilu_box_queue") opt.ilu_box_queue = num() != 0;       // box solves: one launch per triangle (tickets + flags)

@@ -387,6 +387,11 @@ def test_box_ilu_solves_reproduce_the_level_scheduled_ones_bit_for_bit(dims, box
                 assert que.soe.pc_info()["launches"] == 4 or min(dims) == 1
             elif dims[2] >= 8:
                 assert que.soe.pc_info()["launches"] == 4      # the streamed route was really taken
+    # ... and with the solution leaving the box layout through the LDS image of a box instead of the per-row slot map
+    img = P.to_thermal_gpu(tp, {"ksp_type": "gmres", "pc_type": "ilu", "ilu_box": 2, "ilu_box_len": box_len, "ilu_box_img_out": 1})
+    assert img.soe.StepDT(tp.dt, 1)[0]
+    assert img.soe.last_linear_iterations == lev.soe.last_linear_iterations
+    assert np.array_equal(img.soe.GetSoln(), lev.soe.GetSoln())
 
 
 @pytest.mark.parametrize("dims", [(2, 9, 5), (9, 2, 5), (11, 7, 2), (13, 2, 1), (3, 3, 3)])
@@ -417,8 +422,9 @@ def test_box_ilu_applications_on_the_3d_vsfm_jacobian():
     que = P.to_gpu(prob, {"ksp_type": "gmres", "pc_type": "ilu", "ilu_box": 2, "ilu_box_queue": 1})   # one launch per triangle
     stm = P.to_gpu(prob, {"ksp_type": "gmres", "pc_type": "ilu", "ilu_box": 2, "ilu_box_stream": 1})  # ... as streams of pencils
     stm0 = P.to_gpu(prob, {"ksp_type": "gmres", "pc_type": "ilu", "ilu_box": 2, "ilu_box_stream": 1, "ilu_box_fused_io": 0})   # (gather passes kept)
+    img = P.to_gpu(prob, {"ksp_type": "gmres", "pc_type": "ilu", "ilu_box": 2, "ilu_box_img_out": 1})   # the way back through an LDS image
     lev = P.to_gpu(prob, {"ksp_type": "gmres", "pc_type": "ilu", "ilu_box": 0, "ilu_chain": 0})
-    for g in (box, que, stm, stm0, lev):
+    for g in (box, que, stm, stm0, img, lev):
         g.soe.SetDtime(prob.dt); g.soe.PreSolve()
         g.soe.ComputeJacobian(x)
     rng = np.random.default_rng(17)
@@ -429,6 +435,7 @@ def test_box_ilu_applications_on_the_3d_vsfm_jacobian():
         assert np.array_equal(que.soe.PCApply(v), z), rep
         assert np.array_equal(stm.soe.PCApply(v), z), rep
         assert np.array_equal(stm0.soe.PCApply(v), z), rep
+        assert np.array_equal(img.soe.PCApply(v), z), rep
     assert que.soe.comm_stats()["chain_fallbacks"] == 0 and stm.soe.comm_stats()["chain_fallbacks"] == 0
     assert stm.soe.pc_info()["launches"] == 4
     assert box.soe.StepDT(prob.dt, 1) == lev.soe.StepDT(prob.dt, 1)

@@ -172,7 +172,7 @@ def main():
         ("k_th_cols<2, 1>", "column march `k_th_cols<2>` (residual + Jacobian)"), ("k_th_cols<0, 1>", "`k_th_cols<0>` (residual)")))
     thermal_pmc = frac_rows("rocprofv3_kernel_stats_thermal_512.csv", "pmc_thermal_512.json", 512 ** 3, (
         ("k_box_lower_stream<8, false>", "lower stream"), ("k_box_upper_stream<8, false>", "upper stream"),
-        ("k_box_gather_in", "gather into the box layout"), ("k_gather", "gather back"), ("k_spmv_pipe_mb<7>", "SpMV")))
+        ("k_box_gather_in", "into the box layout"), ("k_box_gather_out", "out of it"), ("k_spmv_pipe_mb<7>", "SpMV")))
     gs = frac_rows("rocprofv3_kernel_stats_thermal_512_short.csv", "pmc_thermal_512.json", 512 ** 3, (
         ("k_mdot", "`k_mdot`"), ("k_maxpy_neg", "`k_maxpy_neg`")))
     if gs:   # (their work per launch grows with the basis: averages of the short command the PMC passes ran, 20 iterations)
