@@ -16,6 +16,8 @@
 #include "kernels.hpp"
 
 #include <algorithm>
+#include <cstdint>
+#include <stdexcept>
 #include <type_traits>
 
 namespace mpp {
@@ -2584,6 +2586,8 @@ __global__ __launch_bounds__(kBlock) void k_mdot(DotArgs a, int j0, int nv, doub
 #pragma unroll
   for (int j = 0; j < kMdotGroup; ++j) acc[j] = 0.0;
   const double *x = a.x[j0];
+  // (pairs of rows with 16-byte accesses were measured here as well: 1.19 -> 1.38 ms per launch at 512^3, not kept; the update
+  // kernel k_maxpy_neg gained 6 % from them)
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < (size_t)a.n; i += (size_t)gridDim.x * kBlock) {
     const double xv = x[i];
 #pragma unroll
@@ -2712,17 +2716,41 @@ __global__ __launch_bounds__(kBlock) void k_finalize(int nb, int chunk, const do
 }
 
 // partials != nullptr: also the partial sums of y.y of the result (the norm GMRES takes next), one per block
+// (two rows per thread as one 16-byte access per vector, four vectors' loads issued together: with one 8-byte load per vector and
+// thread the update of a 134 M-row vector against 13 basis vectors ran at 0.67 of peak)
 __global__ __launch_bounds__(kBlock) void k_maxpy_neg(MaxpyArgs a, const double *sc, double *y, double *partials) {
   __shared__ double lds[kBlock / 64];
-  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-  double v = 0.0;
-  if (i < (size_t)a.n) {
-    v = y[i];
+  const size_t i = 2 * ((size_t)blockIdx.x * kBlock + threadIdx.x), n = (size_t)a.n;
+  double sq = 0.0;
+  if (i + 1 < n) {
+    dpair v = *reinterpret_cast<const dpair *>(y + i);
+    int j = 0;
+    for (; j + 4 <= a.nvec; j += 4) {
+      const dpair b0 = __builtin_nontemporal_load(reinterpret_cast<const dpair *>(a.v[j] + i)),
+                  b1 = __builtin_nontemporal_load(reinterpret_cast<const dpair *>(a.v[j + 1] + i)),
+                  b2 = __builtin_nontemporal_load(reinterpret_cast<const dpair *>(a.v[j + 2] + i)),
+                  b3 = __builtin_nontemporal_load(reinterpret_cast<const dpair *>(a.v[j + 3] + i));
+      const double s0 = sc[S_SUM0 + j], s1 = sc[S_SUM0 + j + 1], s2 = sc[S_SUM0 + j + 2], s3 = sc[S_SUM0 + j + 3];
+      v.x -= s0 * b0.x; v.y -= s0 * b0.y;
+      v.x -= s1 * b1.x; v.y -= s1 * b1.y;
+      v.x -= s2 * b2.x; v.y -= s2 * b2.y;
+      v.x -= s3 * b3.x; v.y -= s3 * b3.y;
+    }
+    for (; j < a.nvec; ++j) {
+      const dpair b0 = __builtin_nontemporal_load(reinterpret_cast<const dpair *>(a.v[j] + i));
+      const double s0 = sc[S_SUM0 + j];
+      v.x -= s0 * b0.x; v.y -= s0 * b0.y;
+    }
+    *reinterpret_cast<dpair *>(y + i) = v;
+    sq = v.x * v.x + v.y * v.y;
+  } else if (i < n) {   // the last row of an odd count
+    double v = y[i];
     for (int j = 0; j < a.nvec; ++j) v -= sc[S_SUM0 + j] * a.v[j][i];
     y[i] = v;
+    sq = v * v;
   }
   if (partials) {
-    const double t = block_sum(v * v, lds);
+    const double t = block_sum(sq, lds);
     if (threadIdx.x == 0) partials[blockIdx.x] = t;
   }
 }
@@ -3134,10 +3162,12 @@ void launch_finalize(int nblocks, int nvec, const double *partials, double *sums
   LAUNCH(k_finalize, dim3(nchunk, nvec), nblocks, nchunk == 1 ? nblocks : kFinalizeChunk, partials, f.stage, sums, f.counter, f.sc, f.step,
          Publish{f.pub_host, f.pub_seq, f.pub_value});
 }
-int maxpy_blocks(int n) { return nblk(n); }
+int maxpy_blocks(int n) { return nblk(((long long)n + 1) / 2); }   // two rows per thread
 int launch_maxpy_neg(const MaxpyArgs &a, const double *sc, double *y, double *partials, hipStream_t stream) {
   if (a.n <= 0 || a.nvec <= 0) return 0;
-  const dim3 grid(nblk(a.n));
+  for (int j = 0; j < a.nvec; ++j)   // (16-byte accesses)
+    if (((uintptr_t)a.v[j] | (uintptr_t)y) & 15) throw std::runtime_error("internal: multi-axpy operands must be 16-byte aligned");
+  const dim3 grid(maxpy_blocks(a.n));
   LAUNCH(k_maxpy_neg, grid, a, sc, y, partials);
   return (int)grid.x;
 }
