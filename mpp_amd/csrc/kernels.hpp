@@ -406,6 +406,12 @@ struct ThTriArgs {
 void launch_th_tri_factor(const ThTriArgs &a, hipStream_t stream);
 // y = A x of the coupled system on a vertical-only grid from the values at their computed places (no index; a.L / a.inv / a.C unused)
 void launch_th_spmv_cols(const ThTriArgs &a, const double *x, double *y, hipStream_t stream);
+// the same product with the line search's sums: partials[j * blocks + b] = x.x, f.(A x), q.q (q may be null: two sums), A x not written;
+// returns the blocks (= th_spmv_dots_blocks(n))
+int th_spmv_dots_blocks(int n);
+int launch_th_spmv_cols_dots(const ThTriArgs &a, const double *x, const double *f, const double *q, double *partials, hipStream_t stream);
+// z = M^{-1} (A x) with its dot products (w: z.w and z.z; else z.z), A x never written; partials as launch_th_tri_solve_dots; returns the blocks
+int launch_th_spmv_tri(const ThTriArgs &a, const double *x, double *z, const double *w, double *partials, hipStream_t stream);
 void launch_th_tri_solve(const ThTriArgs &a, const double *r, double *z, hipStream_t stream);   // r, z: [P; T]
 // ... with the partial sums of z.z (w == nullptr) or of z.w and z.z over both fields, one per block of 256 columns (returns the
 // number of blocks; layout partials[j * blocks + block]); finish with launch_finalize

@@ -1589,7 +1589,7 @@ struct Solver {
     halo_exchange(x);
     ProfScope ps(prof, KC_SPMV);
     const int v = spmv_variant();
-    if (th && opt.th_spmv_cols && opt.spmv_variant < 0 && vertical_only && columns && nghost == 0 && nz >= 2) {
+    if (th_index_free()) {
       launch_th_spmv_cols(th_tri_args(), x, y, stream);   // coupled system on soil columns: no index at all (k_th_spmv_cols)
     } else if (v == 22 || v == 23) {
       if (!multibase_index) throw Error("spmv_variant 22/23 need the multi-base compact index (built when 20/21 are not available: rows of <= 8 entries, at most 8 windows of 8192 rows per tile)");
@@ -1602,7 +1602,12 @@ struct Solver {
     ghost_zero(x); ghost_zero(y);   // coupled TH with ghost cells: the operand's copies and the identity rows' outputs
   }
   // the line search's first reductions in one pass over the matrix: out = {y.y, f.(A y), x.x (x != nullptr)}
+  // coupled system on soil columns: the index-free block-tridiagonal product (k_th_spmv_cols)
+  bool th_index_free() const {
+    return th && opt.th_spmv_cols && opt.spmv_variant < 0 && vertical_only && columns && nghost == 0 && nz >= 2;
+  }
   bool spmv_dots_fused() const {
+    if (opt.fused_ls_dots && th_index_free()) return true;
     const int v = spmv_variant();
     return opt.fused_ls_dots && (v == 20 || v == 21) && compact_index && nghost == 0;
   }
@@ -1611,6 +1616,16 @@ struct Solver {
     // (with the reductions the kernel carries three more streams and one partial sum per block: 6 tiles per wave measured best,
     // 0.958 ms against 1.07 at 2 and 0.977 at 4: profiles/r02_kbench_spmv_dots_tpw.json)
     const int tpw = opt.spmv_tpw > 0 ? opt.spmv_tpw : 6, nv = x ? 3 : 2;
+    if (th_index_free()) {
+      const size_t nb = (size_t)th_spmv_dots_blocks(n), need = 3 * (nb + nb / 2048 + 1);
+      if (spmv_partials.n < need) spmv_partials.alloc(need);
+      int nbk;
+      { ProfScope ps(prof, KC_SPMV); nbk = launch_th_spmv_cols_dots(th_tri_args(), y, f, x, spmv_partials.p, stream); }
+      ProfScope ps(prof, KC_REDUCE);
+      finalize(nbk, nv, spmv_partials.p, slot);
+      if (comm.active() && nreduce > 0) comm.allreduce_sum(sc.p + S_SUM0, nreduce, stream);
+      return nv;
+    }
     const size_t nbmax = (size_t)spmv_compact_dots_blocks(tpw, nred);
     const size_t need = 3 * (nbmax + nbmax / 2048 + 1);
     if (spmv_partials.n < need) spmv_partials.alloc(need);
@@ -1911,7 +1926,23 @@ struct Solver {
     return opt.fused_spmv_pc && opt.pc_type == 2 && !th && !thermal && vertical_only && columns && nghost == 0 && nz >= 2 && tri_lds() &&
            pc_ready && fused_pc_dots();
   }
+  // coupled system on soil columns: t = M^{-1} A v with its dot products as one kernel (k_th_spmv_tri), where the index-free SpMV and
+  // the block-Thomas solve with fused dots would run one after the other
+  bool th_fused_spmv_tri() const {
+    return opt.th_spmv_tri && th_index_free() && pc_ready && fused_pc_dots();
+  }
   void op_BA_dots(const double *v, double *t, const double *w, int slot = 0, int nreduce = -1, int step = -1) {
+    if (th_fused_spmv_tri()) {
+      {
+        ProfScope ps(prof, KC_SPMV_PC);
+        const int nbk = launch_th_spmv_tri(th_tri_args(), v, t, w, col_partials.p, stream);
+        finalize(nbk, w ? 2 : 1, col_partials.p, slot, step);
+      }
+      if (nreduce < 0) nreduce = w ? 2 : 1;
+      if (comm.active() && nreduce > 0) comm.allreduce_sum(sc.p + S_SUM0, nreduce, stream);
+      bcgs_step(step);
+      return;
+    }
     if (!fused_spmv_pc()) {
       op_spmv(v, Wk.p);
       op_pc_apply_dots(Wk.p, t, w, slot, nreduce, step);
@@ -3534,6 +3565,7 @@ struct Solver {
     }
     else if (key == "th_fused_dots") opt.th_fused_dots = num() != 0;
     else if (key == "th_spmv_cols") opt.th_spmv_cols = num() != 0;
+    else if (key == "th_spmv_tri") opt.th_spmv_tri = num() != 0;   // coupled system on columns: M^{-1} A v + dots in one kernel
     else if (key == "th_stage") opt.th_stage = num() != 0;
     else if (key == "setup_device") { need_setup(false); opt.setup_device = num() != 0; }   // incidence lists built on the device (0: on the host)
     else if (key == "setup_verify") { need_setup(false); opt.setup_verify = num() != 0; }   // ... both, compared (an error if they differ)

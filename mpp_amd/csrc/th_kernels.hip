@@ -472,36 +472,40 @@ __global__ __launch_bounds__(kBlock) void k_th_tri_factor(ThTriArgs a) {
 // they are fetched kThDepth levels ahead into a ring of registers (the compiler's loop waits for every level's loads before it
 // starts the next ones: 0.71 ms at 512 x 512 x 80 with 3 KB per wave in flight).  ND = 0: no dot products; 1: z.z; 2: z.w and z.z.
 constexpr int kThDepth = 4;
-template <int ND>
-__device__ __forceinline__ void th_tri_solve_column(const ThTriArgs &a, const double *__restrict__ r, double *__restrict__ z,
-                                                    const double *__restrict__ w, int c, double &acc0, double &acc1) {
-  const int tile = c >> 6, tw = min(64, a.ncols - (tile << 6));
-  const size_t cbase = (size_t)tile * 64 * a.nz + (c & 63), n = (size_t)a.n;
-  {
-    B2 l[kThDepth];
-    double rp[kThDepth], rt[kThDepth];
-    auto fetch = [&](int slot, int k) {
-      const size_t i = cbase + (size_t)min(k, a.nz - 1) * tw;   // (past the last level: a harmless repeat)
-      l[slot] = b2_load(a.L, n, i); rp[slot] = r[i]; rt[slot] = r[n + i];
-    };
+__device__ __forceinline__ void th_tri_forward_column(const ThTriArgs &a, const double *__restrict__ r, double *__restrict__ z,
+                                                      size_t cbase, int tw) {
+#pragma clang fp contract(off)   // (every product and sum rounded by itself: the fused k_th_spmv_tri must reproduce these bits, and
+                                 // which multiply-adds the compiler would fuse depends on the code around them)
+  const size_t n = (size_t)a.n;
+  B2 l[kThDepth];
+  double rp[kThDepth], rt[kThDepth];
+  auto fetch = [&](int slot, int k) {
+    const size_t i = cbase + (size_t)min(k, a.nz - 1) * tw;   // (past the last level: a harmless repeat)
+    l[slot] = b2_load(a.L, n, i); rp[slot] = r[i]; rt[slot] = r[n + i];
+  };
 #pragma unroll
-    for (int j = 0; j < kThDepth; ++j) fetch(j, j);
-    double dp = 0.0, dt = 0.0;
-    for (int k0 = 0; k0 < a.nz; k0 += kThDepth) {
+  for (int j = 0; j < kThDepth; ++j) fetch(j, j);
+  double dp = 0.0, dt = 0.0;
+  for (int k0 = 0; k0 < a.nz; k0 += kThDepth) {
 #pragma unroll
-      for (int j = 0; j < kThDepth; ++j) {
-        const int k = k0 + j;
-        if (k < a.nz) {
-          const size_t i = cbase + (size_t)k * tw;
-          const double np = rp[j] - (l[j].pp * dp + l[j].pt * dt);
-          const double nt = rt[j] - (l[j].tp * dp + l[j].tt * dt);
-          z[i] = np; z[n + i] = nt;
-          dp = np; dt = nt;
-          fetch(j, k + kThDepth);
-        }
+    for (int j = 0; j < kThDepth; ++j) {
+      const int k = k0 + j;
+      if (k < a.nz) {
+        const size_t i = cbase + (size_t)k * tw;
+        const double np = rp[j] - (l[j].pp * dp + l[j].pt * dt);
+        const double nt = rt[j] - (l[j].tp * dp + l[j].tt * dt);
+        z[i] = np; z[n + i] = nt;
+        dp = np; dt = nt;
+        fetch(j, k + kThDepth);
       }
     }
   }
+}
+template <int ND>
+__device__ __forceinline__ void th_tri_backward_column(const ThTriArgs &a, double *__restrict__ z, const double *__restrict__ w,
+                                                       size_t cbase, int tw, double &acc0, double &acc1) {
+#pragma clang fp contract(off)
+  const size_t n = (size_t)a.n;
   B2 cc[kThDepth], inv[kThDepth];
   double zp[kThDepth], zt[kThDepth], wp[kThDepth], wt[kThDepth];
   auto fetch = [&](int slot, int k) {
@@ -530,6 +534,14 @@ __device__ __forceinline__ void th_tri_solve_column(const ThTriArgs &a, const do
       }
     }
   }
+}
+template <int ND>
+__device__ __forceinline__ void th_tri_solve_column(const ThTriArgs &a, const double *__restrict__ r, double *__restrict__ z,
+                                                    const double *__restrict__ w, int c, double &acc0, double &acc1) {
+  const int tile = c >> 6, tw = min(64, a.ncols - (tile << 6));
+  const size_t cbase = (size_t)tile * 64 * a.nz + (c & 63);
+  th_tri_forward_column(a, r, z, cbase, tw);
+  th_tri_backward_column<ND>(a, z, w, cbase, tw, acc0, acc1);
 }
 
 __global__ __launch_bounds__(kBlock) void k_th_tri_solve(ThTriArgs a, const double *__restrict__ r, double *__restrict__ z) {
@@ -567,12 +579,144 @@ __global__ __launch_bounds__(kBlock) void k_th_tri_solve_dots(ThTriArgs a, const
   }
 }
 
+// z = M^{-1} (A x) with the dot products of z, in ONE kernel (the role k_tri_solve_lds plays for the scalar system): the forward
+// sweep of the block-Thomas solve forms its right-hand side -- the two rows of A x of its cell -- from the level's matrix rows
+// (staged through LDS as in k_th_spmv_cols, the next level's pieces already in flight) and three levels of x kept in registers;
+// A x is never written or read back (32 of the pair's 304 bytes per cell).  Row sums in the entry order of k_th_spmv_cols, the
+// elimination in the order of th_tri_forward_column: the same bits as the two kernels.
+template <int ND>
+__global__ __launch_bounds__(kBlock) void k_th_spmv_tri(ThTriArgs a, const double *__restrict__ x, double *__restrict__ z,
+                                                        const double *__restrict__ w, double *__restrict__ partials) {
+#pragma clang fp contract(off)
+  typedef double dpair __attribute__((ext_vector_type(2)));
+  __shared__ dpair stage[kBlock / 64][2][64 * 3];
+  __shared__ double lds[kBlock / 64];
+  const int c = blockIdx.x * kBlock + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double acc0 = 0.0, acc1 = 0.0;
+  if (c - lane < a.ncols) {   // (the whole wave)
+    const bool live = c < a.ncols;
+    const int tile = c >> 6, tw = min(64, a.ncols - (tile << 6));
+    const size_t cbase = (size_t)tile * 64 * a.nz + lane, n = (size_t)a.n;
+    dpair *sP = stage[wave][0], *sT = stage[wave][1];
+    dpair nP[3], nT[3];
+    bool nstaged = false;
+    auto prefetch = [&](int k) {   // the pieces of level k into registers, if the level lies where the column layout puts it
+      nstaged = false;
+      if (tw != 64 || !a.stage) return;
+      const size_t i = cbase + (size_t)k * tw;
+      const int len = 3 - (k == 0) - (k == a.nz - 1);
+      const int base = a.crowptr[i - lane];
+      const bool mine = a.crowptr[i - lane + 64] - base == 64 * len && a.crowptr[i] - base == lane * len;
+      if (__builtin_amdgcn_ballot_w64(mine) != ~0ull) return;
+      const dpair *gP = reinterpret_cast<const dpair *>(a.val + (size_t)2 * base),
+                  *gT = reinterpret_cast<const dpair *>(a.val + (size_t)2 * a.nnzc + (size_t)2 * base);
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        if (j < len) { nP[j] = __builtin_nontemporal_load(gP + j * 64 + lane); nT[j] = __builtin_nontemporal_load(gT + j * 64 + lane); }
+      nstaged = true;
+    };
+    prefetch(0);
+    // x of the levels k - 1, k, k + 1 (zero outside the column), L of level k one level ahead
+    double xPm = 0.0, xTm = 0.0, xP0 = 0.0, xT0 = 0.0, xPp = 0.0, xTp = 0.0;
+    B2 lnext{0, 0, 0, 0};
+    if (live) {
+      xP0 = x[cbase]; xT0 = x[n + cbase];
+      if (a.nz > 1) { xPp = x[cbase + tw]; xTp = x[n + cbase + tw]; }
+      lnext = b2_load(a.L, n, cbase);
+    }
+    double dp = 0.0, dt = 0.0;
+    for (int k = 0; k < a.nz; ++k) {
+      const size_t i = cbase + (size_t)k * tw;
+      const int len = 3 - (k == 0) - (k == a.nz - 1);
+      const bool staged = nstaged;
+      if (staged) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          if (j < len) { sP[j * 64 + lane] = nP[j]; sT[j * 64 + lane] = nT[j]; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+      if (k + 1 < a.nz) prefetch(k + 1);
+      const B2 l = lnext;
+      double xPn = 0.0, xTn = 0.0;
+      if (live) {
+        if (k + 2 < a.nz) { xPn = x[i + 2 * (size_t)tw]; xTn = x[n + i + 2 * (size_t)tw]; }
+        if (k + 1 < a.nz) lnext = b2_load(a.L, n, i + tw);
+      }
+      double sp = 0.0, st = 0.0;
+      const bool lo = k > 0, up = k < a.nz - 1;
+#define TH_ROW_PRODUCT(vP, vT, LEN)                                                         \
+      {                                                                                     \
+        int e = 0;                                                                          \
+        if (lo) { const double p = vP[e] * xPm, q = vT[e] * xPm; sp += p; st += q; ++e; }   \
+        { const double p = vP[e] * xP0, q = vT[e] * xP0; sp += p; st += q; ++e; }           \
+        if (up) { const double p = vP[e] * xPp, q = vT[e] * xPp; sp += p; st += q; }        \
+        e = LEN;                                                                            \
+        if (lo) { const double p = vP[e] * xTm, q = vT[e] * xTm; sp += p; st += q; ++e; }   \
+        { const double p = vP[e] * xT0, q = vT[e] * xT0; sp += p; st += q; ++e; }           \
+        if (up) { const double p = vP[e] * xTp, q = vT[e] * xTp; sp += p; st += q; }        \
+      }
+      if (staged) {
+        const double *vP = reinterpret_cast<const double *>(sP) + lane * 2 * len, *vT = reinterpret_cast<const double *>(sT) + lane * 2 * len;
+        TH_ROW_PRODUCT(vP, vT, len)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (the reads above precede the next level's writes)
+        __builtin_amdgcn_wave_barrier();
+      } else if (live) {
+        const int r0 = a.crowptr[i], rl = a.crowptr[i + 1] - r0;
+        const double *vP = a.val + (size_t)2 * r0, *vT = a.val + (size_t)2 * a.nnzc + (size_t)2 * r0;
+        TH_ROW_PRODUCT(vP, vT, rl)
+      }
+#undef TH_ROW_PRODUCT
+      if (live) {
+        const double np = sp - (l.pp * dp + l.pt * dt);
+        const double nt = st - (l.tp * dp + l.tt * dt);
+        z[i] = np; z[n + i] = nt;
+        dp = np; dt = nt;
+      }
+      xPm = xP0; xTm = xT0; xP0 = xPp; xT0 = xTp; xPp = xPn; xTp = xTn;
+    }
+    if (live) th_tri_backward_column<ND>(a, z, w, cbase, tw, acc0, acc1);
+  }
+  auto block_total = [&](double v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+    if (threadIdx.x == 0) for (int q = 0; q < kBlock / 64; ++q) t += lds[q];
+    return t;
+  };
+  const double t0 = block_total(acc0);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t0;
+  if (ND == 2) {
+    const double t1 = block_total(acc1);
+    if (threadIdx.x == 0) partials[(size_t)gridDim.x + blockIdx.x] = t1;
+  }
+}
+
 // y = A x of the coupled system on a vertical-only grid without an index: the 2N x 2N CSR matrix is, per soil column, block
 // tridiagonal with 2 x 2 blocks whose entries sit at computed places (see the header: (P,P) at crp + s, (P,T) behind them, the heat
 // rows 2 nnzc further on), and a row's columns are the cell below, the cell and the cell above in either field.  One lane per cell
 // forms both of its rows -- 12 values, 6 operands -- in the entry order of the CSR kernels (products rounded one by one, no fused
 // multiply-add): the same bits as k_spmv_c on the compact index, 128 instead of 152 bytes per cell.
-__global__ __launch_bounds__(kBlock) void k_th_spmv_cols(ThTriArgs a, const double *__restrict__ x, double *__restrict__ y) {
+// DOTS: the line search's pass -- x.x, f.(A x) and q.q (q may be null) reduced on the way, A x not written (the role k_spmv_c's DOTS
+// variant plays on the compact index); a block then walks kThDotsChunks pieces of 256 rows so that the second stage sums a few
+// thousand partial sums, not 10^5.  Partial sums: partials[j * gridDim.x + block], j = 0 (x.x), 1 (f.(A x)), 2 (q.q).
+constexpr int kThDotsChunks = 8;
+__device__ __forceinline__ double th_block_sum(double v, double *lds) {   // lanes -> wave leaders -> thread 0 (fixed order)
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = 0.0;
+  if (threadIdx.x == 0) for (int q = 0; q < kBlock / 64; ++q) t += lds[q];
+  return t;
+}
+template <bool DOTS>
+__global__ __launch_bounds__(kBlock) void k_th_spmv_cols(ThTriArgs a, const double *__restrict__ x, double *__restrict__ y,
+                                                         const double *__restrict__ f, const double *__restrict__ q,
+                                                         double *__restrict__ partials) {
 #pragma clang fp contract(off)
   // A wave's 64 rows are the cells of one level of one column tile: their entries are one contiguous piece of `val` per block row
   // ([P rows; T rows]), 2 len doubles a row.  Read lane by lane a row is a 48-byte stride (a load instruction touches 24 cache
@@ -580,64 +724,91 @@ __global__ __launch_bounds__(kBlock) void k_th_spmv_cols(ThTriArgs a, const doub
   // order, then every lane takes its row from the wave's own staging area (no workgroup barrier: nothing is shared across waves).
   typedef double dpair __attribute__((ext_vector_type(2)));   // two doubles, one 16-byte access
   __shared__ dpair stage[kBlock / 64][2][64 * 3];
-  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x, n = (size_t)a.n;
+  __shared__ double red[kBlock / 64];
+  const size_t n = (size_t)a.n;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const size_t i0 = i - lane;
-  if (i0 >= n) return;
-  // cell i = (level k, column c) of tile t: i = t 64 nz + k tw + lane
   const size_t per_tile = (size_t)64 * a.nz;
-  const int tile = (int)(i0 / per_tile), tw = min(64, a.ncols - (tile << 6));
-  bool staged = false;
-  int len = 0;
-  if (a.stage && tw == 64 && i0 + 64 <= n) {   // (a full tile: the wave's rows are one level, all of the same length)
-    const int k0 = (int)((i0 - (size_t)tile * per_tile) >> 6);
-    len = 3 - (k0 == 0) - (k0 == a.nz - 1);
-    const int base = a.crowptr[i0];
-    const bool mine = a.crowptr[i0 + 64] - base == 64 * len && a.crowptr[i] - base == lane * len;
-    if (__builtin_amdgcn_ballot_w64(mine) == ~0ull) {   // the pattern of the column layout, row for row: otherwise no staging
-      const dpair *gP = reinterpret_cast<const dpair *>(a.val + (size_t)2 * base),
-                  *gT = reinterpret_cast<const dpair *>(a.val + (size_t)2 * a.nnzc + (size_t)2 * base);
-      dpair *sP = stage[wave][0], *sT = stage[wave][1];
-      for (int j = 0; j < len; ++j) {
-        sP[j * 64 + lane] = __builtin_nontemporal_load(gP + j * 64 + lane);
-        sT[j * 64 + lane] = __builtin_nontemporal_load(gT + j * 64 + lane);
+  double acc_xx = 0.0, acc_fw = 0.0, acc_qq = 0.0;
+  constexpr int kChunks = DOTS ? kThDotsChunks : 1;
+  for (int ch = 0; ch < kChunks; ++ch) {
+    const size_t i = ((size_t)blockIdx.x * kChunks + ch) * kBlock + threadIdx.x;
+    const size_t i0 = i - lane;
+    if (i0 >= n) continue;   // (the whole wave)
+    // cell i = (level k, column c) of tile t: i = t 64 nz + k tw + lane
+    const int tile = (int)(i0 / per_tile), tw = min(64, a.ncols - (tile << 6));
+    bool staged = false;
+    int len = 0;
+    if (a.stage && tw == 64 && i0 + 64 <= n) {   // (a full tile: the wave's rows are one level, all of the same length)
+      const int k0 = (int)((i0 - (size_t)tile * per_tile) >> 6);
+      len = 3 - (k0 == 0) - (k0 == a.nz - 1);
+      const int base = a.crowptr[i0];
+      const bool mine = a.crowptr[i0 + 64] - base == 64 * len && a.crowptr[i] - base == lane * len;
+      if (__builtin_amdgcn_ballot_w64(mine) == ~0ull) {   // the pattern of the column layout, row for row: otherwise no staging
+        const dpair *gP = reinterpret_cast<const dpair *>(a.val + (size_t)2 * base),
+                    *gT = reinterpret_cast<const dpair *>(a.val + (size_t)2 * a.nnzc + (size_t)2 * base);
+        dpair *sP = stage[wave][0], *sT = stage[wave][1];
+        for (int j = 0; j < len; ++j) {
+          sP[j * 64 + lane] = __builtin_nontemporal_load(gP + j * 64 + lane);
+          sT[j * 64 + lane] = __builtin_nontemporal_load(gT + j * 64 + lane);
+        }
+        staged = true;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
-      staged = true;
+    }
+    if (i < n) {
+      const int k = (int)((i - (size_t)tile * per_tile) / tw);
+      const bool lo = k > 0, up = k < a.nz - 1;
+      const double xPl = lo ? x[i - tw] : 0.0, xPd = x[i], xPu = up ? x[i + tw] : 0.0;
+      const double xTl = lo ? x[n + i - tw] : 0.0, xTd = x[n + i], xTu = up ? x[n + i + tw] : 0.0;
+      double sp = 0.0, st = 0.0;
+#define TH_ROW_PRODUCT(vP, vT)                                                              \
+      {                                                                                     \
+        int e = 0;                                                                          \
+        if (lo) { const double p = vP[e] * xPl, q_ = vT[e] * xPl; sp += p; st += q_; ++e; } \
+        { const double p = vP[e] * xPd, q_ = vT[e] * xPd; sp += p; st += q_; ++e; }         \
+        if (up) { const double p = vP[e] * xPu, q_ = vT[e] * xPu; sp += p; st += q_; }      \
+        e = len;                                                                            \
+        if (lo) { const double p = vP[e] * xTl, q_ = vT[e] * xTl; sp += p; st += q_; ++e; } \
+        { const double p = vP[e] * xTd, q_ = vT[e] * xTd; sp += p; st += q_; ++e; }         \
+        if (up) { const double p = vP[e] * xTu, q_ = vT[e] * xTu; sp += p; st += q_; }      \
+      }
+      if (staged) {   // (two copies of the arithmetic so that the LDS reads are LDS instructions, not flat ones)
+        const double *sP = reinterpret_cast<const double *>(stage[wave][0]) + lane * 2 * len,
+                     *sT = reinterpret_cast<const double *>(stage[wave][1]) + lane * 2 * len;
+        TH_ROW_PRODUCT(sP, sT)
+      } else {
+        const int r0 = a.crowptr[i];
+        len = a.crowptr[i + 1] - r0;
+        const double *vP = a.val + (size_t)2 * r0, *vT = a.val + (size_t)2 * a.nnzc + (size_t)2 * r0;
+        TH_ROW_PRODUCT(vP, vT)
+      }
+#undef TH_ROW_PRODUCT
+      if (DOTS) {
+        acc_xx += xPd * xPd; acc_xx += xTd * xTd;
+        acc_fw += f[i] * sp; acc_fw += f[n + i] * st;
+        if (q) { const double qp = q[i], qt = q[n + i]; acc_qq += qp * qp; acc_qq += qt * qt; }
+      } else {
+        __builtin_nontemporal_store(sp, y + i);
+        __builtin_nontemporal_store(st, y + n + i);
+      }
+    }
+    if (DOTS && staged) {   // (this piece's reads of the staging area precede the next piece's writes)
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
   }
-  if (i >= n) return;
-  const int k = (int)((i - (size_t)tile * per_tile) / tw);
-  const bool lo = k > 0, up = k < a.nz - 1;
-  const double xPl = lo ? x[i - tw] : 0.0, xPd = x[i], xPu = up ? x[i + tw] : 0.0;
-  const double xTl = lo ? x[n + i - tw] : 0.0, xTd = x[n + i], xTu = up ? x[n + i + tw] : 0.0;
-  double sp = 0.0, st = 0.0;
-#define TH_ROW_PRODUCT(vP, vT)                                                              \
-  {                                                                                         \
-    int e = 0;                                                                              \
-    if (lo) { const double p = vP[e] * xPl, q = vT[e] * xPl; sp += p; st += q; ++e; }       \
-    { const double p = vP[e] * xPd, q = vT[e] * xPd; sp += p; st += q; ++e; }               \
-    if (up) { const double p = vP[e] * xPu, q = vT[e] * xPu; sp += p; st += q; }            \
-    e = len;                                                                                \
-    if (lo) { const double p = vP[e] * xTl, q = vT[e] * xTl; sp += p; st += q; ++e; }       \
-    { const double p = vP[e] * xTd, q = vT[e] * xTd; sp += p; st += q; ++e; }               \
-    if (up) { const double p = vP[e] * xTu, q = vT[e] * xTu; sp += p; st += q; }            \
+  if (DOTS) {
+    double t = th_block_sum(acc_xx, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+    t = th_block_sum(acc_fw, red);
+    if (threadIdx.x == 0) partials[(size_t)gridDim.x + blockIdx.x] = t;
+    if (q) {
+      t = th_block_sum(acc_qq, red);
+      if (threadIdx.x == 0) partials[(size_t)2 * gridDim.x + blockIdx.x] = t;
+    }
   }
-  if (staged) {   // (two copies of the arithmetic so that the LDS reads are LDS instructions, not flat ones)
-    const double *sP = reinterpret_cast<const double *>(stage[wave][0]) + lane * 2 * len,
-                 *sT = reinterpret_cast<const double *>(stage[wave][1]) + lane * 2 * len;
-    TH_ROW_PRODUCT(sP, sT)
-  } else {
-    const int r0 = a.crowptr[i];
-    len = a.crowptr[i + 1] - r0;
-    const double *vP = a.val + (size_t)2 * r0, *vT = a.val + (size_t)2 * a.nnzc + (size_t)2 * r0;
-    TH_ROW_PRODUCT(vP, vT)
-  }
-#undef TH_ROW_PRODUCT
-  __builtin_nontemporal_store(sp, y + i);
-  __builtin_nontemporal_store(st, y + n + i);
 }
 
 inline dim3 nblk(long long n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
@@ -650,10 +821,24 @@ void launch_th_tri_factor(const ThTriArgs &a, hipStream_t stream) {
   if (a.ncols > 0) TH_LAUNCH(k_th_tri_factor, nblk(a.ncols), a);
 }
 void launch_th_spmv_cols(const ThTriArgs &a, const double *x, double *y, hipStream_t stream) {
-  if (a.n > 0) TH_LAUNCH(k_th_spmv_cols, nblk(a.n), a, x, y);
+  if (a.n > 0) TH_LAUNCH(k_th_spmv_cols<false>, nblk(a.n), a, x, y, nullptr, nullptr, nullptr);
+}
+int th_spmv_dots_blocks(int n) { return (int)(((long long)n + (long long)kBlock * kThDotsChunks - 1) / ((long long)kBlock * kThDotsChunks)); }
+int launch_th_spmv_cols_dots(const ThTriArgs &a, const double *x, const double *f, const double *q, double *partials, hipStream_t stream) {
+  if (a.n <= 0) return 0;
+  const dim3 grid((unsigned)th_spmv_dots_blocks(a.n));
+  TH_LAUNCH(k_th_spmv_cols<true>, grid, a, x, nullptr, f, q, partials);
+  return (int)grid.x;
 }
 void launch_th_tri_solve(const ThTriArgs &a, const double *r, double *z, hipStream_t stream) {
   if (a.ncols > 0) TH_LAUNCH(k_th_tri_solve, nblk(a.ncols), a, r, z);
+}
+int launch_th_spmv_tri(const ThTriArgs &a, const double *x, double *z, const double *w, double *partials, hipStream_t stream) {
+  if (a.ncols <= 0) return 0;
+  const dim3 grid = nblk(a.ncols);
+  if (w) TH_LAUNCH(k_th_spmv_tri<2>, grid, a, x, z, w, partials);
+  else TH_LAUNCH(k_th_spmv_tri<1>, grid, a, x, z, w, partials);
+  return (int)grid.x;
 }
 int launch_th_tri_solve_dots(const ThTriArgs &a, const double *r, double *z, const double *w, double *partials, hipStream_t stream) {
   if (a.ncols <= 0) return 0;

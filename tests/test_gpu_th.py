@@ -399,3 +399,27 @@ def test_th_mesh_split_across_ranks_with_ghost_cells(case, nranks):
         t = g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, 605)
         assert np.abs(p[:part.nowned] - p_ref[own]).max() <= 1e-9 * np.abs(p_ref).max()     # measured: 3e-7 Pa of 3e5
         assert np.abs(t[:part.nowned] - t_ref[own]).max() <= 1e-8                          # measured: 6e-11 K
+
+
+@pytest.mark.parametrize("ncols,nz", [(70, 9), (128, 5), (5, 2)])
+def test_th_fused_spmv_and_block_solve_reproduces_the_two_kernels_bit_for_bit(ncols, nz):
+    """k_th_spmv_tri (round 4): t = M^-1 A v with its dot products in one kernel -- the forward sweep forms A v from the matrix rows of
+    its level instead of reading it -- against the index-free SpMV followed by the block-Thomas solve with fused dots: the same
+    entry order and the same elimination order, so two coupled time steps must give the same bits, Newton and linear counts
+    (full column tiles take the staged route, the ragged tile of 70 = 64 + 6 columns and the 5-column mesh the direct one)"""
+    tp = P.th_columns(ncols=ncols, nz=nz, perm_mult=np.exp(0.3 * np.random.default_rng(5).standard_normal(ncols)))
+    base = {"ksp_type": "bcgs", "pc_type": "bjacobi", "profile": 1}   # (profile: the library counts the launches of a kernel class)
+    f = P.to_th_gpu(tp, dict(base, th_spmv_tri=1))
+    u = P.to_th_gpu(tp, dict(base, th_spmv_tri=0))
+    s0 = P.to_th_gpu(tp, dict(base, th_spmv_tri=1, th_stage=0))     # (rows read lane by lane)
+    for s in range(2):
+        for g in (f, u, s0):
+            P.th_gpu_set_conditions(tp, g)
+        ru = u.soe.StepDT(tp.dt, s + 1)
+        assert f.soe.StepDT(tp.dt, s + 1) == ru and s0.soe.StepDT(tp.dt, s + 1) == ru and ru[0]
+    assert f.soe.counters() == u.soe.counters() == s0.soe.counters()
+    for var in (C.VAR_PRESSURE, 605):
+        vu = u.soe.GetDataForCLM(C.AUXVAR_INTERNAL, var)
+        assert np.array_equal(f.soe.GetDataForCLM(C.AUXVAR_INTERNAL, var), vu)
+        assert np.array_equal(s0.soe.GetDataForCLM(C.AUXVAR_INTERNAL, var), vu)
+    assert f.soe.kernel_stats("spmv_pc")["calls"] > 0 and u.soe.kernel_stats("spmv_pc")["calls"] == 0   # the fused kernel really ran

@@ -167,7 +167,8 @@ def main():
         return "; ".join(out)
 
     th_pmc = frac_rows("rocprofv3_kernel_stats_th_512x512x80.csv", "pmc_th_512x512x80.json", 512 * 512 * 80, (
-        ("k_th_spmv_cols", "index-free SpMV `k_th_spmv_cols`"), ("k_th_tri_solve_dots<2>", "block-Thomas solve + dots"),
+        ("k_th_spmv_tri<2>", "`k_th_spmv_tri` (SpMV + block-Thomas solve + dots)"), ("k_th_spmv_cols<true>", "index-free SpMV with the line search's sums"),
+        ("k_th_spmv_cols<false>", "index-free SpMV"), ("k_th_tri_solve_dots<2>", "block-Thomas solve + dots"),
         ("k_th_tri_solve_dots<1>", "… with one dot"), ("k_th_tri_factor", "block factorisation"), ("k_bcgs_xr<true>", "`k_bcgs_xr`"),
         ("k_th_cols<2, 1>", "column march `k_th_cols<2>` (residual + Jacobian)"), ("k_th_cols<0, 1>", "`k_th_cols<0>` (residual)")))
     thermal_pmc = frac_rows("rocprofv3_kernel_stats_thermal_512.csv", "pmc_thermal_512.json", 512 ** 3, (
