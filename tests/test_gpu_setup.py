@@ -99,3 +99,17 @@ def test_pattern_of_soil_columns_written_down_directly_or_built_on_the_device(as
     o, g, _, _ = _operator_parity(prob, x, {"assembly": assembly, "setup_verify": 1})
     assert _verified(g.soe) >= (1 if assembly == "columns" else 2)
     _operator_parity(prob, x, {"assembly": assembly, "setup_device": 0})
+
+
+def test_meshes_with_ghost_cells_keep_the_identity_layout_on_either_route():
+    """a rank's share of a split 3-D mesh (ghost cells last, mppgpu_set_ghost_cells): no column layout is allowed there, cells and
+    connections keep the caller's numbering -- the device route must decide the same and build the same lists and pattern as the
+    host's; thermal (z-slabs of the MMS grid) and VSFM (v-channel)"""
+    tp = P.thermal_mms(3, 7, 6, 9, replicate_reference_soil_indexing=False)
+    for _, lp in P.split_thermal_problem(tp, 3):
+        g = P.to_thermal_gpu(lp, {"ksp_type": "gmres", "pc_type": "ilu", "setup_verify": 1})
+        assert _verified(g.soe) >= 3          # layout, pattern, incidence lists
+    prob = P.vchannel(8, 6, 9)
+    for _, lp in P.split_problem(prob, 2):
+        g = P.to_gpu(lp, {"setup_verify": 1})
+        assert _verified(g.soe) >= 3
