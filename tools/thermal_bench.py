@@ -80,12 +80,14 @@ def main():
         by = 12.0 * nnz + 24.0 * N
         info = g.soe.pc_info() if a.pc == "ilu" else {"path": "none", "launches": 0, "box_extents": (0, 0, 0)}
         what = {"levels": "level-ordered ELL, one launch per dependency level", "chained": "level-ordered ELL, tiles chained by flags",
-                "boxes": "box wavefronts of %d x %d x %d cells, one launch per box level" % info["box_extents"]}.get(info["path"], a.pc)
+                "boxes": ("box wavefronts of %d x %d x %d cells, " % info["box_extents"]) +
+                         ("two streams of box pencils + two layout passes per application" if info["launches"] == 4
+                          else "one launch per box level")}.get(info["path"], a.pc)
         out["roofline"] = {"kernel": "ILU(0) triangular solves (%s)" % what, "bound": "hbm", "unit": "GB/s",
                            "peak": 8000.0, "achieved": round(by / (ms * 1e-3) / 1e9, 1), "frac": round(by / (ms * 1e-3) / 1e9 / 8000.0, 4),
                            "bytes_per_launch": by, "avg_apply_ms": round(ms, 4), "dependency_levels": 2 * (3 * a.n - 2),
                            "launches_per_application": info["launches"],
-                           "note": "algorithmic bytes 12 nnz + 24 N (SURVEY 8d) over the average application; latency-bound by the dependency levels"}
+                           "note": "algorithmic bytes 12 nnz + 24 N (SURVEY 8d) over the average application (layout passes included); the solves are chains of dependent steps"}
     # further timed steps of the same problem with options changed in between (A/B pairs on one box, one set-up)
     variants = []
     for spec in a.then:
