@@ -1398,18 +1398,15 @@ __global__ __launch_bounds__(kBlock) void k_box_load(long long nslots, BoxGrid g
   }
   Ld[t] = ld; Ls[t] = ls; Lw[t] = lw; Ue[t] = ue; Un[t] = un; Uu[t] = uu; Di[t] = di; Td[t] = td; Ts[t] = ts; Tw[t] = tw;
 }
-// The right-hand side into the box layout, one workgroup per box: a box's cells are read line by line along the fastest
-// direction (consecutive cells of the caller's numbering: coalesced reads of ext2int and, in the layouts the library uses, of r),
-// placed in an LDS image of the box (padding zero) and written out row by row -- k_gather_or_zero reads r through the slot
-// order, two cells per 64-byte sector (PMC: 55 bytes per cell at 256^3)
-// (Round 4 tried the image padded by two doubles per 128 -- consecutive cells of a grid line sit 128 doubles apart in the box layout,
-// one LDS bank -- and the way back through the same image instead of k_gather's per-row slot map: 1.03 and 0.99 ms at 512^3 against
-// 0.82 and 0.73 ms: the padding costs the fourth workgroup per CU (41.6 instead of 40 KB), the image a barrier k_gather does not
-// have; gpurun_out/r04_run13.  Not kept.)
-// The LDS image is written line by line: a wave's 64 cells of a grid line land 128 doubles apart (two step rows), i.e. in ONE pair of
-// banks -- a 32-way conflict.  Swizzle: the row-pair number (bits 7..10 of the slot) is XORed into bits 1..4, a permutation inside
-// every aligned group of 32 doubles: the line-order accesses spread over all banks, the slot-order copies stay conflict-free, the
-// image keeps its size (padding it instead cost the fourth workgroup per CU and was slower).
+// The right-hand side into the box layout (and the solution out of it), one workgroup per box: a box's cells are read (written)
+// line by line along the fastest direction -- consecutive cells of the caller's numbering: coalesced accesses of ext2int and, in the
+// layouts the library uses, of the vector -- through an LDS image of the box that is written out (read in) row by row.  Reading r
+// through the slot order instead (k_gather_or_zero) moves two cells per 64-byte sector (PMC: 55 bytes per cell at 256^3).
+// The image is written line by line: a wave's 64 cells of a grid line land 128 doubles apart (two step rows), i.e. in ONE pair of
+// banks.  Swizzle: the row-pair number (bits 7..10 of the slot) is XORed into bits 1..4, a permutation inside every aligned group of
+// 32 doubles: the line-order accesses spread over all banks, the slot-order copies stay conflict-free, the image keeps its size.
+// (Padding the image by two doubles per 128 instead cost the fourth workgroup per CU: 1.03 against 0.82 ms, round 4, not kept.  The
+// swizzle by itself changed nothing measurable -- 0.84 ms -- what the passes lacked was loads in flight: see kBoxIoUnroll.)
 __device__ __forceinline__ int box_img(int t) { return t ^ (((t >> 7) & 15) << 1); }
 // (Eight cells per thread and pass: their index loads go out together, then their value loads -- one dependent pair at a time left
 // the 16 waves a CU holds of this kernel with too little in flight.  Padding slots are recognised when the image is written out, so

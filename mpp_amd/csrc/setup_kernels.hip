@@ -1,10 +1,13 @@
-// Set-up passes that run on the device (once per mesh): the per-row incident-connection lists of the general assembly kernels
-// (mppgpu_setup, "incidence lists") built from the connection list as the caller gave it.  On the host these were two passes of
-// atomic counters over 8 x 10^8 incidences plus a sort and a binary search per row: 4.6 s of the 512^3 thermal mesh's set-up on
-// the 16 host threads a GPU box grants (profiles/NOTES.md, round 4); here they are a count, a scan, a fill and one pass per row.
-// The lists come out exactly as the host builds them (solver.cpp keeps that code as option setup_device = 0 and, with
-// setup_verify = 1, compares the two): a row's entries are ordered by (connection, side) of the caller's numbering, which does not
-// depend on the order the atomics ran in.
+// Set-up passes that run on the device (once per mesh, mppgpu_setup), from the connection list as the caller gave it:
+//  * column detection: the vertical chains of the internal connection set, the tiled level-major cell numbering and the numbering
+//    of the connections (Solver::detect_columns is the host route);
+//  * the per-row incident-connection lists of the general assembly kernels: a count, a scan, a fill in any order and one short sort
+//    per row by the caller's (connection, side);
+//  * the CSR pattern derived from them: the diagonal plus the distinct other ends of a row, sorted.
+// On the host these were passes of atomic counters over 8 x 10^8 incidences with a sort and binary searches per row: 15 of the
+// 25.6 s the 512^3 thermal mesh's mppgpu_setup took on the 16 host threads a GPU box grants; here they take 0.9 s
+// (profiles/r04/setup_phase_timing_device.log).  Every array comes out exactly as the host builds it -- nothing depends on the
+// order the atomics ran in -- and option setup_verify = 1 makes the library build both and compare (tests/test_gpu_setup.py).
 #include "kernels.hpp"
 #include "runtime.hpp"
 
@@ -263,7 +266,7 @@ void device_fill_int(int *a, long long n, int v, hipStream_t stream) {
 }
 
 // a.ptr: n + 1 ints, zeroed by the caller; on return the row pointers.  Returns the number of incidences (= 2 nc); the caller then
-// allocates rconn / rslot / roth of that size and calls device_incidence_rows.
+// allocates rconn / rslot / roth of that size and calls device_incidence_fill, device_csr_* and device_incidence_slots.
 long long device_incidence_pointers(const IncidenceArgs &a, hipStream_t stream) {
   if (a.nc > 0) SLAUNCH(k_inc_count, nblk(a.nc), a.nc, a.ext2int, a.cup, a.cdn, a.ptr);
   return device_inclusive_scan(a.ptr + 1, a.n, stream);

@@ -469,8 +469,9 @@ __global__ __launch_bounds__(kBlock) void k_th_tri_factor(ThTriArgs a) {
 }
 
 // Both sweeps of a column's block-Thomas solve.  The operands of a level do not depend on the recurrence, only the arithmetic does:
-// they are fetched kThDepth levels ahead into a ring of registers (the compiler's loop waits for every level's loads before it
-// starts the next ones: 0.71 ms at 512 x 512 x 80 with 3 KB per wave in flight).  ND = 0: no dot products; 1: z.z; 2: z.w and z.z.
+// they are fetched kThDepth levels ahead into a ring of registers (the compiler's own loop waits for every level's loads before it
+// starts the next ones).  Measured: 0.68-0.71 ms at 512 x 512 x 80 either way -- the solve already runs at 5.5 TB/s of its 176 bytes
+// per cell -- so the ring buys robustness at low occupancy, not time.  ND = 0: no dot products; 1: z.z; 2: z.w and z.z.
 constexpr int kThDepth = 4;
 __device__ __forceinline__ void th_tri_forward_column(const ThTriArgs &a, const double *__restrict__ r, double *__restrict__ z,
                                                       size_t cbase, int tw) {
