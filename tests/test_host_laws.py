@@ -98,3 +98,26 @@ def test_shared_ifc67_evaluation_of_the_coupled_kernels_matches_the_term_by_term
     assert n > 100_000
     assert d < 1e-14 and dp < 1e-13 and dt < 1e-12 and hp < 1e-13      # measured 6e-16, 1.5e-15, 3.5e-14, 1.2e-15
     assert h < 1e-8 and ht < 1e-10                                     # measured 1.3e-10 (of |H| + 1e4 J/kmol, H -> 0 at 0 degC), 2.3e-12
+
+
+def test_host_side_helpers_of_the_setup_passes():
+    """parallel running sums against a serial loop (sizes around the chunking), the overflow error, the task pool and the
+    no-initialisation vector type of mpp_amd/csrc/runtime.{hpp,cpp} -- host code, no GPU needed (tests/host_setup_check.cpp, linked
+    with the library's runtime.o)"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    import __graft_entry__ as G
+    G.build()                                       # (runtime.o)
+    out = os.path.join(root, "tests", "_build")
+    os.makedirs(out, exist_ok=True)
+    exe, src = os.path.join(out, "host_setup_check"), os.path.join(root, "tests", "host_setup_check.cpp")
+    obj = os.path.join(root, "mpp_amd", "_build", "runtime.o")
+    deps = [src, obj, os.path.join(root, "mpp_amd", "csrc", "runtime.hpp")]
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(map(os.path.getmtime, deps)):
+        subprocess.check_call([hipcc, "-O2", "-std=c++17", "-c", src, "-o", exe + ".o"], stderr=subprocess.DEVNULL)
+        subprocess.check_call([hipcc, "-o", exe, exe + ".o", obj, "-ldl", "-lpthread"], stderr=subprocess.DEVNULL)
+    res = subprocess.run([exe], capture_output=True, text=True)
+    assert res.returncode == 0 and res.stdout.startswith("ok "), res.stdout + res.stderr
