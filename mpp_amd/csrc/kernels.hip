@@ -278,9 +278,10 @@ __global__ __launch_bounds__(kBlock) void k_assemble_cols(ColsArgs a) {
         if (!last) a.val[slot] = up_prev;
         if (factor) {
           const double l = lo_prev * inv_pp;
-          const double piv = di - l * c_pp;
+          const double piv = fma(-l, c_pp, di);   // (written as the fma it is: k_tri_solve_lds recomputes l and must round alike)
           const double inv = 1.0 / piv;
-          stnt(l, a.tl + ip); stnt(inv, a.tinvb + ip); stnt(up_prev, a.tc + ip);
+          if (a.store_l) stnt(l, a.tl + ip);
+          stnt(inv, a.tinvb + ip); stnt(up_prev, a.tc + ip);
           inv_pp = inv; c_pp = up_prev;
           if (a.fwd) {   // forward elimination of the residual as well: the Krylov solver's first M^{-1} F starts from here
             const double d = (RES ? f_row : Fin_prev) - l * d_pp;
@@ -983,6 +984,17 @@ __global__ __launch_bounds__(kBlock) void k_spmv_pipe_mb(int n, int tpw, const i
 // block-Jacobi preconditioner, one block per soil column = exact LU of the column's tridiagonal (Thomas).
 // factor: l_k = a_k / b'_{k-1}, b'_k = b_k - l_k c_{k-1};  stored: l, 1/b', c   (level-major, coalesced)
 // ------------------------------------------------------------------------------------------------
+// the elimination factors alone, from a factorisation that kept only the reciprocal pivots and the upper entries
+__global__ __launch_bounds__(kBlock) void k_tri_l(TriArgs a) {
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= (size_t)a.ncols * a.nz) return;
+  const size_t per_tile = (size_t)64 * a.nz;
+  const int tile = (int)(i / per_tile), tw = min(64, a.ncols - (tile << 6));
+  const int k = (int)((i - (size_t)tile * per_tile) / tw);
+  const int sl = a.tri_lo[i];
+  const double lo = sl >= 0 ? a.val[sl] : 0.0;
+  a.l[i] = lo * (k > 0 ? a.invb[i - tw] : 0.0);
+}
 __global__ __launch_bounds__(kBlock) void k_tri_factor(TriArgs a) {
   const int c = blockIdx.x * kBlock + threadIdx.x;
   if (c >= a.ncols) return;
@@ -997,7 +1009,7 @@ __global__ __launch_bounds__(kBlock) void k_tri_factor(TriArgs a) {
     const double di = a.val[a.tri_di[i]];
     const double up = su >= 0 ? a.val[su] : 0.0;
     const double l = lo * inv_prev;
-    const double piv = di - l * c_prev;
+    const double piv = fma(-l, c_prev, di);
     const double inv = 1.0 / piv;
     a.l[i] = l; a.invb[i] = inv; a.c[i] = up;
     inv_prev = inv; c_prev = up;
@@ -2339,7 +2351,7 @@ __global__ __launch_bounds__(64) void k_tri_solve_lds(TriArgs a, const double *_
     // 3l + 2 -- through a 1.5 KB LDS scratch when the level is used; three 8-byte loads at a 24-byte lane stride would touch every
     // line of the segment three times.  The two end levels (2 entries per row) are read directly.
     __shared__ double tr[3 * 64];
-    double xb[RF][G], lb[RF][G], v0[RF][G], v1[RF][G], v2[RF][G], sb[SPMV == 3 ? RF : 1][SPMV == 3 ? G : 1];
+    double xb[RF][G], v0[RF][G], v1[RF][G], v2[RF][G], sb[SPMV == 3 ? RF : 1][SPMV == 3 ? G : 1];
     const double na = (SPMV == 3) ? -1.0 * sc[S_ALPHA] : 0.0;
     double *ss = (SPMV == 3) ? (valid ? xout + cbase : scratch64 + lane) : nullptr;
     auto fetch = [&](int q, int kfirst) {   // levels kfirst .. kfirst+G-1 (clamped) into group q
@@ -2349,7 +2361,6 @@ __global__ __launch_bounds__(64) void k_tri_solve_lds(TriArgs a, const double *_
         const size_t i = cbase + (size_t)k * tw;
         xb[q][j] = (SPMV == 1 || SPMV == 3) ? ldnt(r + i) : 0.0;   // (SPMV == 2: x is in the slab)
         if (SPMV == 3) sb[q][j] = ldnt(vsub + i);
-        lb[q][j] = ldnt(a.l + i);
         if (k == 0) {                 // [di up]: lower slot harmless (meets x = 0)
           v0[q][j] = ldnt(vt + 2 * vl); v1[q][j] = v0[q][j]; v2[q][j] = ldnt(vt + 2 * vl + 1);
         } else if (k == nz - 1) {     // [lo di]: upper slot harmless
@@ -2364,7 +2375,10 @@ __global__ __launch_bounds__(64) void k_tri_solve_lds(TriArgs a, const double *_
 #pragma unroll
     for (int q = 0; q < RF; ++q) { fetch(q, q * G); __builtin_amdgcn_sched_barrier(0); }
     // level k arrives: row k-1 is complete (its upper neighbour is x_k).  Carried: x_{k-2}, x_{k-1}, row k-1's entries and factor
-    double xm2 = 0.0, xm1 = 0.0, plo = 0.0, pdi = 0.0, pup = 0.0, pl = 0.0, prev = 0.0;
+    // The elimination factor l_k = lo_k / piv_{k-1} is not read: the row's entries are here anyway, so the factorisation is redone on
+    // the way (k_tri_factor's arithmetic: l = lo inv_prev, piv = fma(-l, up_prev, di), inv = 1 / piv -- one division per level in a
+    // chain the memory stream leaves room for), 8 of the kernel's ~90 bytes per cell.  The stored factors stay for the back sweep.
+    double xm2 = 0.0, xm1 = 0.0, plo = 0.0, pdi = 0.0, pup = 0.0, pl = 0.0, prev = 0.0, finv = 0.0;
     auto finish = [&](int kr, double xnext) {   // row kr from the carried values and x_{kr+1}
       const double p0 = plo * xm2, p1 = pdi * xm1, p2 = pup * xnext;
       const double rk = (p0 + p1) + p2;
@@ -2372,7 +2386,7 @@ __global__ __launch_bounds__(64) void k_tri_solve_lds(TriArgs a, const double *_
       prev = d;
       dsl[kr * 64 + lane] = d;
     };
-    auto step = [&](int k, double xk, double lo, double di, double up, double lk, double vk) {
+    auto step = [&](int k, double xk, double lo, double di, double up, double vk) {
       if (SPMV == 2) xk = dsl[k * 64 + lane];   // (rows below k have been replaced by their eliminated sums already: not needed any more)
       if (SPMV == 3) { xk = fma(na, vk, xk); stnt(xk, ss + (size_t)k * tws); }   // s = r - alpha v (k_waxpy's arithmetic), kept for the update kernel
       if (k > 0 && k < nz - 1) {   // a middle level: (lo, di, up) hold segment entries l, tw + l, 2 tw + l -> this lane's row
@@ -2382,6 +2396,8 @@ __global__ __launch_bounds__(64) void k_tri_solve_lds(TriArgs a, const double *_
         __builtin_amdgcn_wave_barrier();
       }
       if (k > 0) finish(k - 1, xk);
+      const double lk = lo * finv;              // (row 0: finv = 0, whatever the harmless lower slot holds)
+      finv = 1.0 / fma(-lk, pup, di);           // pup: still row k-1's upper entry
       xm2 = (k > 0) ? xm1 : 0.0;   // x_{-1} = 0 meets the lower entry row 0 does not have
       xm1 = xk;
       plo = lo; pdi = di; pup = up; pl = lk;
@@ -2391,7 +2407,7 @@ __global__ __launch_bounds__(64) void k_tri_solve_lds(TriArgs a, const double *_
 #pragma unroll
       for (int q = 0; q < RF; ++q) {
 #pragma unroll
-        for (int j = 0; j < G; ++j) step(k0 + q * G + j, xb[q][j], v0[q][j], v1[q][j], v2[q][j], lb[q][j], SPMV == 3 ? sb[q][j] : 0.0);
+        for (int j = 0; j < G; ++j) step(k0 + q * G + j, xb[q][j], v0[q][j], v1[q][j], v2[q][j], SPMV == 3 ? sb[q][j] : 0.0);
         __builtin_amdgcn_sched_barrier(0);
         fetch(q, k0 + (RF + q) * G);
         __builtin_amdgcn_sched_barrier(0);
@@ -2402,7 +2418,7 @@ __global__ __launch_bounds__(64) void k_tri_solve_lds(TriArgs a, const double *_
 #pragma unroll
       for (int j = 0; j < G; ++j) {
         const int k = k0 + q * G + j;
-        if (k < nz) step(k, xb[q][j], v0[q][j], v1[q][j], v2[q][j], lb[q][j], SPMV == 3 ? sb[q][j] : 0.0);
+        if (k < nz) step(k, xb[q][j], v0[q][j], v1[q][j], v2[q][j], SPMV == 3 ? sb[q][j] : 0.0);
       }
     finish(nz - 1, 0.0);   // the top row: no upper neighbour
   } else {
@@ -2909,6 +2925,10 @@ void launch_spmv(int variant, int n, int max_row_nnz, const int *rowptr, const i
   else LAUNCH(k_spmv_row, dim3(nblk(n)), n, rowptr, col, val, x, y);   // variant 0, and rows of more than 8 entries
 }
 
+void launch_tri_l(const TriArgs &a, hipStream_t stream) {
+  const long long n = (long long)a.ncols * a.nz;
+  if (n > 0) LAUNCH(k_tri_l, dim3(nblk(n)), a);
+}
 void launch_tri_factor(const TriArgs &a, hipStream_t stream) {
   if (a.ncols > 0) LAUNCH(k_tri_factor, dim3(nblk(a.ncols)), a);
 }

@@ -86,6 +86,7 @@ struct ColsArgs {
   const int *bc_ptr = nullptr, *bc_type = nullptr;
   const double *bc_Dq = nullptr, *bc_dgrav = nullptr, *bc_area = nullptr, *bc_value = nullptr;
   double *tl = nullptr, *tinvb = nullptr, *tc = nullptr;
+  bool store_l = true;   // false: the elimination factors l are not written (the fused solves redo them; launch_tri_l rebuilds them on demand)
   double *fwd = nullptr;    // with tl: L^{-1} F as well (F = the residual of this pass, or the one in `F` in mode 1)
   double *partials = nullptr;
   // optional trial point (complete-row variant): the state is trial_x + trial_a * trial_y, written to trial_w
@@ -185,6 +186,9 @@ struct TriArgs {
   double *l, *invb, *c;                 // factors, level-major
 };
 void launch_tri_factor(const TriArgs &a, hipStream_t stream);
+// l_k = lower_k inv_{k-1} from the CSR values and the stored reciprocal pivots (k_tri_factor's arithmetic): the elimination factors of
+// a factorisation whose march did not store them (ColsArgs::store_l = false)
+void launch_tri_l(const TriArgs &a, hipStream_t stream);
 void launch_tri_solve(const TriArgs &a, const double *r, double *z, hipStream_t stream);
 // the same solve with fused dot products of the result: z.z (w == nullptr) or z.w and z.z; returns the number of partial
 // blocks (<= kMaxPartialBlocks is the caller's responsibility); finish with launch_finalize

@@ -1523,7 +1523,13 @@ struct Solver {
     ls_point = Trial{};
     a.col_bc = d_col_bc.p; a.side_f = bc_side_f.p; a.side_d = bc_side_d.p; a.partials = col_partials.p;
     const bool factor = mode != 0 && opt.pc_type == 2;
-    if (factor) { a.tl = tri_l.p; a.tinvb = tri_invb.p; a.tc = tri_c.p; }
+    if (factor) {
+      a.tl = tri_l.p; a.tinvb = tri_invb.p; a.tc = tri_c.p;
+      // the solves that form A x on the way redo the elimination factors from the rows they read: where those are the ones a solve
+      // will use, l is not written (8 of the march's 107 bytes per cell) and rebuilt only if a plain solve asks (ensure_tri_l)
+      a.store_l = !(opt.lazy_tri_l && fused_spmv_pc_possible());
+      tri_l_valid = a.store_l;
+    }
     if (mode != 1 || Fout == fwd_rhs) fwd_rhs = nullptr;   // the residual in Fout or the factors are being replaced
     if (factor && have_F) {
       if (!fwd_elim.p) fwd_elim.alloc(nrow);
@@ -1748,7 +1754,7 @@ struct Solver {
       if (!vertical_only || !columns) throw Error("pc_type bjacobi of the coupled system needs a grid whose connections are all vertical (use ilu)");
       if (!thtri_L.p) { thtri_L.alloc(4 * (size_t)n); thtri_inv.alloc(4 * (size_t)n); thtri_C.alloc(4 * (size_t)n); }
       launch_th_tri_factor(th_tri_args(), stream);
-    } else if (opt.pc_type == 2) launch_tri_factor(tri_args(), stream);
+    } else if (opt.pc_type == 2) { launch_tri_factor(tri_args(), stream); tri_l_valid = true; }
     else if (opt.pc_type == 3) launch_jacobi_setup(nrow, d_diag.p, d_val.p, jac_invd.p, stream);
     else if (opt.pc_type == 1) {
       ilu_box_analyse();
@@ -1884,7 +1890,7 @@ struct Solver {
     ProfScope ps(prof, KC_PC_APPLY);
     if (nghost > 0 && !th) launch_set(nghost, 0.0, const_cast<double *>(r) + nred, stream);   // block-Jacobi across ranks (TH: zero already)
     if (opt.pc_type == 2 && th) launch_th_tri_solve(th_tri_args(), r, z, stream);
-    else if (opt.pc_type == 2) launch_tri_solve(tri_args(), r, z, stream);
+    else if (opt.pc_type == 2) { ensure_tri_l(); launch_tri_solve(tri_args(), r, z, stream); }
     else if (opt.pc_type == 3) launch_pointwise_mult(nred, jac_invd.p, r, z, stream);
     else if (opt.pc_type == 1 && box_active()) {
       auto gather_in = [&] {   // r into the box layout, padding zero
@@ -1922,6 +1928,18 @@ struct Solver {
     } else launch_copy(nred, r, z, stream);
   }
   // t = M^{-1} A v with the Krylov dot products of t, in ONE kernel: vertical-only grids, column preconditioner, LDS column solve
+  // everything fused_spmv_pc() asks for except the state of the factors (decided while they are being made)
+  bool fused_spmv_pc_possible() const {
+    return opt.fused_spmv_pc && opt.pc_type == 2 && !th && !thermal && vertical_only && columns && nghost == 0 && nz >= 2 && tri_lds() &&
+           fused_pc_dots();
+  }
+  bool tri_l_valid = true;
+  void ensure_tri_l() {
+    if (tri_l_valid || th || thermal) return;
+    ProfScope ps(prof, KC_PC_SETUP);
+    launch_tri_l(tri_args(), stream);
+    tri_l_valid = true;
+  }
   bool fused_spmv_pc() const {
     return opt.fused_spmv_pc && opt.pc_type == 2 && !th && !thermal && vertical_only && columns && nghost == 0 && nz >= 2 && tri_lds() &&
            pc_ready && fused_pc_dots();
@@ -1991,8 +2009,8 @@ struct Solver {
       if (th) nbk = launch_th_tri_solve_dots(th_tri_args(), r, z, w, col_partials.p, stream);
       else if (!w && r == fwd_rhs && pc_ready)
         nbk = launch_tri_back_dots(tri_args(), fwd_elim.p, z, col_partials.p, stream);
-      else if (tri_lds()) nbk = launch_tri_solve_lds(tri_args(), r, z, w, col_partials.p, tri_scratch.p, opt.tri_group, stream);
-      else nbk = launch_tri_solve_dots(tri_args(), r, z, w, col_partials.p, stream);
+      else if (tri_lds()) { ensure_tri_l(); nbk = launch_tri_solve_lds(tri_args(), r, z, w, col_partials.p, tri_scratch.p, opt.tri_group, stream); }
+      else { ensure_tri_l(); nbk = launch_tri_solve_dots(tri_args(), r, z, w, col_partials.p, stream); }
       finalize(nbk, w ? 2 : 1, col_partials.p, slot, step);
     }
     if (nreduce < 0) nreduce = w ? 2 : 1;
@@ -3565,6 +3583,7 @@ struct Solver {
     }
     else if (key == "th_fused_dots") opt.th_fused_dots = num() != 0;
     else if (key == "th_spmv_cols") opt.th_spmv_cols = num() != 0;
+    else if (key == "lazy_tri_l") opt.lazy_tri_l = num() != 0;   // column LU: elimination factors not stored by the march where the fused solves redo them
     else if (key == "th_spmv_tri") opt.th_spmv_tri = num() != 0;   // coupled system on columns: M^{-1} A v + dots in one kernel
     else if (key == "th_stage") opt.th_stage = num() != 0;
     else if (key == "setup_device") { need_setup(false); opt.setup_device = num() != 0; }   // incidence lists built on the device (0: on the host)

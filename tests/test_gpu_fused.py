@@ -193,3 +193,33 @@ def test_a_krylov_solve_that_goes_on_discards_the_speculative_work():
     assert np.array_equal(out[0][2], out[1][2])
     assert gs[0].soe.assembly_info()["speculative_trials_discarded"] > 0
     assert gs[1].soe.assembly_info()["speculative_trials_discarded"] == 0
+
+
+@pytest.mark.parametrize("ncols,nz", [(70, 19), (130, 2), (200, 50)])
+def test_elimination_factors_rebuilt_on_demand_are_the_ones_the_march_would_have_stored(ncols, nz):
+    """Round 4: the fused SpMV + column solve kernels redo l_k = lower_k / pivot_{k-1} from the matrix rows they read, so the march does
+    not store l where they will run (lazy_tri_l) and a plain column solve asked for afterwards rebuilds it (k_tri_l).  Against a
+    handle whose march stores l: the same bits from a plain PCApply (which triggers the rebuild), from a Krylov solve and after two
+    time steps; and again with the rebuild in between two fused solves of the same factorisation"""
+    prob, x = _hetero(ncols=ncols, nz=nz, seed=17)
+    n = x.size
+    base = dict(ROWS, tri_lds=1)
+    lazy, stored = P.to_gpu(prob, dict(base, lazy_tri_l=1)), P.to_gpu(prob, dict(base, lazy_tri_l=0))
+    for g in (lazy, stored):
+        g.soe.SetDtime(prob.dt); g.soe.PreSolve()
+        g.soe.ComputeResidual(x)
+        g.soe.ComputeJacobian(x)
+    rng = np.random.default_rng(8)
+    b = rng.standard_normal(n)
+    s1 = [g.soe.KSPSolve(b) for g in (lazy, stored)]                 # fused kernels (no l read)
+    assert np.array_equal(s1[0][0], s1[1][0]) and s1[0][1:] == s1[1][1:] and s1[0][1] > 0
+    v = rng.standard_normal(n)
+    assert np.array_equal(lazy.soe.PCApply(v), stored.soe.PCApply(v))   # plain solve: l rebuilt from the rows and the pivots
+    s2 = [g.soe.KSPSolve(v) for g in (lazy, stored)]
+    assert np.array_equal(s2[0][0], s2[1][0]) and s2[0][1:] == s2[1][1:]
+    for g in (lazy, stored):
+        for s in range(2):
+            assert g.soe.StepDT(prob.dt, s + 1)[0]
+    assert lazy.soe.counters() == stored.soe.counters()
+    assert np.array_equal(lazy.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1),
+                          stored.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1))
