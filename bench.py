@@ -803,21 +803,36 @@ def main():
                     if alg > HBM_PEAK_GBS or (mv and mv["hbm_bytes_per_launch"] < 0.9 * s["bytes_per_launch"]):
                         kernels[k]["structure_exploited"] = True
         fused = stats["spmv_pc"]["launches"] > 0
-        roof = {"kernel": ("csr_spmv_fp64 (k_spmv_c: CSR values + compact 16-bit index; the launches timed are the line search's pass "
-                           "-- x.x, f.(A x), ||x|| reduced on the way, A x not written -- because the two products of a BiCGStab iteration "
-                           "run fused with the column solve: kernels.spmv_pc, DESIGN.md section 4)" if fused else
-                           "csr_spmv_fp64 (k_spmv_c: CSR values + compact 16-bit index, see DESIGN.md section 4)")
-                          if compact else "csr_spmv_fp64",
+        index_free = bool(layout.get("line_search_product_index_free"))
+        if fused and index_free:
+            kernel_txt = ("csr_spmv_fp64 as the timed region runs it: the line search's product J Y with x.x, f.(A x), ||x|| reduced on the way "
+                          "and A x not written (the two products of a BiCGStab iteration run fused with the column solve: kernels.spmv_pc, "
+                          "DESIGN.md section 4).  On this soil-column grid it is k_spmv_cols_dots: the CSR VALUES read at their computed places, "
+                          "no column index and no row pointer -- it moves fewer bytes than SURVEY's CSR count, so `achieved` (that count / time) "
+                          "can exceed the peak; `traffic` / `achieved_physical` are what it moves; plain_spmv_kernel = k_spmv_c (values + compact "
+                          "16-bit index, y written), the kernel of 3-D and multi-iteration solves, timed right behind the region")
+        elif fused and compact:
+            kernel_txt = ("csr_spmv_fp64 (k_spmv_c: CSR values + compact 16-bit index; the launches timed are the line search's pass "
+                          "-- x.x, f.(A x), ||x|| reduced on the way, A x not written -- because the two products of a BiCGStab iteration "
+                          "run fused with the column solve: kernels.spmv_pc, DESIGN.md section 4)")
+        elif compact:
+            kernel_txt = "csr_spmv_fp64 (k_spmv_c: CSR values + compact 16-bit index, see DESIGN.md section 4)"
+        else:
+            kernel_txt = "csr_spmv_fp64"
+        roof = {"kernel": kernel_txt,
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "achieved_is": ("algorithmic CSR bytes (12 nnz + 20 N + 4, SURVEY 8d) / HIP-event average launch time of the CSR SpMV launches "
                                 "inside the timed region.  Byte model of those launches: values 8 nnz + column index 4 nnz + row pointer 4 N + x 8 N, "
                                 "and f read (8 N) where y = A x would be written (8 N): the same count; the first launch of a time step also reads X "
                                 "for ||X|| (8 N more, not counted).  plain_spmv_kernel = the kernel that does write y, timed right behind the region"
+                                + ("  [index-free launches: values 8 nnz + x 8 N + f 8 N only]" if index_free else "")
                                 if fused else "algorithmic CSR bytes (12 nnz + 20 N + 4, SURVEY 8d) / HIP-event average launch time"),
                 "bytes_per_launch": sp["bytes_per_launch"], "avg_launch_ms": round(avg_ms, 5), "launches_timed": sp["launches"]}
         if plain_spmv:
             roof["plain_spmv_kernel"] = plain_spmv
+        if index_free:
+            roof["structure_exploited"] = True
         if stale:
             roof["traffic_refused"] = stale
         if traffic:

@@ -333,7 +333,8 @@ int mppgpu_get_pc_info(mppgpu_handle h, int *path, int *launches, int *box_exten
  * variant, [6] column solve through LDS, [7] speculative line-search trial points that had to be discarded since
  * mppgpu_setup, [8] the level / box launches of the ILU(0) solves are replayed from hipGraphs (option ilu_graph), [9] graphs
  * instantiated for them so far, [10] set-up structures built on the device that option setup_verify found equal to the host-built
- * ones.  n = entries of info the caller provides (at most 11 are written). */
+ * ones, [11] the line search's product J Y (with its sums) is formed from the column tridiagonals at their computed places, without an
+ * index (soil-column grids).  n = entries of info the caller provides (at most 12 are written). */
 int mppgpu_get_assembly_info(mppgpu_handle h, int n, int *info);
 /* device-resident micro-benchmark of one kernel class on the current state: `reps` launches, average ms */
 int mppgpu_bench_kernel(mppgpu_handle h, const char *name, int variant, int reps, double *avg_ms,

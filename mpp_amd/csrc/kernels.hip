@@ -906,6 +906,76 @@ __global__ __launch_bounds__(kBlock) void k_spmv_c(int n, int tpw, int split, co
   }
 }
 
+// The line search's product on a vertical-only column grid without an index (round 4): x.x, f.(A x), q.q (q may be null) with A the
+// block diagonal of column tridiagonals whose entries lie at computed places -- rows of a column tile are level-major, 2 entries in
+// the end rows and 3 between (the layout k_tri_solve_lds reads).  One lane per row; a wave's 64 rows of a middle level of a full
+// tile are 192 consecutive values: three coalesced loads and a transposition through LDS, as there; any other row reads its two or
+// three values directly.  Row sums as k_spmv_c forms them (products rounded one by one, lower + diagonal + upper in that order).
+// 41 instead of 49 bytes per row; a block walks kColsDotsChunks pieces of 256 rows so that the second stage sums a few thousand
+// partial sums.  Partial sums: partials[j * gridDim.x + block], j = 0 (x.x), 1 (f.(A x)), 2 (q.q).
+constexpr int kColsDotsChunks = 8;
+__global__ __launch_bounds__(kBlock) void k_spmv_cols_dots(int n, int ncols, int nz, const double *__restrict__ val,
+                                                           const double *__restrict__ x, const double *__restrict__ f,
+                                                           const double *__restrict__ q, double *__restrict__ partials) {
+#pragma clang fp contract(off)
+  __shared__ double tr[kBlock / 64][3 * 64];
+  __shared__ double red[kBlock / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t per_tile = (size_t)64 * nz;
+  double acc_xx = 0.0, acc_fw = 0.0, acc_qq = 0.0;
+  for (int ch = 0; ch < kColsDotsChunks; ++ch) {
+    const size_t i = ((size_t)blockIdx.x * kColsDotsChunks + ch) * kBlock + threadIdx.x;
+    const size_t i0 = i - lane;
+    if (i0 >= (size_t)n) continue;   // (the whole wave)
+    const int tile = (int)(i0 / per_tile), tw = min(64, ncols - (tile << 6));
+    const double *vt = val + (size_t)tile * 64 * (3 * (size_t)nz - 2);   // this tile's values (tiles before it are full)
+    const bool row = i < (size_t)n;
+    // a full tile: the wave's rows are one level
+    const int k0 = (int)((i0 - (size_t)tile * per_tile) >> 6);
+    const bool staged = tw == 64 && k0 > 0 && k0 < nz - 1;
+    double lo = 0.0, di = 0.0, up = 0.0;
+    int k = 0, c = 0;
+    if (row) {
+      const size_t rel = i - (size_t)tile * per_tile;
+      k = (int)(rel / tw); c = (int)(rel - (size_t)k * tw);
+    }
+    if (staged) {
+      const size_t b = (size_t)2 * 64 + (size_t)3 * (k0 - 1) * 64 + lane;
+      const double e0 = ldnt(vt + b), e1 = ldnt(vt + b + 64), e2 = ldnt(vt + b + 128);
+      tr[wave][lane] = e0; tr[wave][64 + lane] = e1; tr[wave][128 + lane] = e2;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      lo = tr[wave][3 * lane]; di = tr[wave][3 * lane + 1]; up = tr[wave][3 * lane + 2];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (these reads precede the next piece's writes)
+      __builtin_amdgcn_wave_barrier();
+    } else if (row) {
+      if (k == 0) { di = ldnt(vt + 2 * c); up = ldnt(vt + 2 * c + 1); }
+      else if (k == nz - 1) { const size_t s0 = (size_t)2 * tw + (size_t)3 * (nz - 2) * tw + 2 * c; lo = ldnt(vt + s0); di = ldnt(vt + s0 + 1); }
+      else { const size_t s0 = (size_t)2 * tw + (size_t)3 * (k - 1) * tw + 3 * c; lo = ldnt(vt + s0); di = ldnt(vt + s0 + 1); up = ldnt(vt + s0 + 2); }
+    }
+    if (row) {
+      const double xm = k > 0 ? x[i - tw] : 0.0, x0 = x[i], xp = k < nz - 1 ? x[i + tw] : 0.0;
+      // (an entry the row does not have is 0 here and meets x = 0: the sum of the products that exist, in entry order)
+      double sum = 0.0;
+      if (k > 0) sum += lo * xm;
+      sum += di * x0;
+      if (k < nz - 1) sum += up * xp;
+      acc_fw += ldnt(f + i) * sum;
+      acc_xx += x0 * x0;
+      if (q) { const double qv = ldnt(q + i); acc_qq += qv * qv; }
+    }
+  }
+  double t = block_sum(acc_xx, red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+  t = block_sum(acc_fw, red);
+  if (threadIdx.x == 0) partials[(size_t)gridDim.x + blockIdx.x] = t;
+  if (q) {
+    t = block_sum(acc_qq, red);
+    if (threadIdx.x == 0) partials[(size_t)2 * gridDim.x + blockIdx.x] = t;
+  }
+}
+
 // variants 22/23: the compact index for patterns whose columns lie further than 2^15 rows from their tile (3-D grids: the
 // y-neighbour of a cell sits nx/64 column tiles away).  A tile's columns cluster around a few places -- its own rows, the
 // tiles next to it, the two y-neighbour tiles -- so each tile carries up to 8 window bases (int32) and an entry is
@@ -2894,6 +2964,14 @@ void launch_spmv_multibase(int tpw, int n, int max_row_nnz, const int *tileptr, 
 int spmv_compact_dots_blocks(int tpw, int n) {
   const long long tiles = ((long long)n + 63) / 64, waves = (tiles + tpw - 1) / tpw;
   return (int)((waves + 3) / 4);
+}
+int spmv_cols_dots_blocks(int n) { return (int)(((long long)n + (long long)kBlock * kColsDotsChunks - 1) / ((long long)kBlock * kColsDotsChunks)); }
+int launch_spmv_cols_dots(int n, int ncols, int nz, const double *val, const double *x, const double *f, const double *q, double *partials,
+                          hipStream_t stream) {
+  if (n <= 0) return 0;
+  const dim3 grid((unsigned)spmv_cols_dots_blocks(n));
+  LAUNCH(k_spmv_cols_dots, grid, n, ncols, nz, val, x, f, q, partials);
+  return (int)grid.x;
 }
 int launch_spmv_compact_dots(int tpw, int n, int max_row_nnz, int split, const int *tileptr, const unsigned short *roff,
                              const short *dcol, const double *val, const double *x, const double *f, const double *xx,

@@ -175,6 +175,11 @@ void launch_spmv_multibase(int tpw, int n, int max_row_nnz, const int *tileptr, 
 // x.x, f.(A x) and optionally xx.xx without writing A x: partial sums in partials[j*nb + b], nb = the return value
 // (= spmv_compact_dots_blocks, which sizes the buffer: 3*nb doubles); finish with launch_finalize
 int spmv_compact_dots_blocks(int tpw, int n);
+// the same sums on a vertical-only column grid from the values at their computed places (no index): partials[j * blocks + b] = x.x,
+// f.(A x), q.q (q may be null: two sums); returns the blocks (= spmv_cols_dots_blocks(n))
+int spmv_cols_dots_blocks(int n);
+int launch_spmv_cols_dots(int n, int ncols, int nz, const double *val, const double *x, const double *f, const double *q, double *partials,
+                          hipStream_t stream);
 int launch_spmv_compact_dots(int tpw, int n, int max_row_nnz, int split, const int *tileptr, const unsigned short *roff,
                              const short *dcol, const double *val, const double *x, const double *f, const double *xx,
                              double *partials, hipStream_t stream);

@@ -225,6 +225,7 @@ struct Options {
                                // progress relies on workgroups being dispatched in index order, which HIP does not promise
   bool setup_device = true;    // set-up passes that have a device route (setup_kernels.hip) take it
   bool setup_verify = false;   // ... and the host route as well, compared entry by entry (tests)
+  bool spmv_cols_dots = true;  // scalar system on soil columns: the line search's product + sums from the column tridiagonals at their computed places
   bool lazy_tri_l = true;      // column LU of the scalar system: the march does not store l where the fused SpMV + solve kernels will run
   bool th_spmv_tri = true;     // coupled TH on soil columns, block-Jacobi: SpMV + block-Thomas solve + dots as one kernel (k_th_spmv_tri)
   bool th_stage = true;        // TH factorisation / index-free SpMV: matrix rows staged through LDS (off: the lane-by-lane reads, for the A/B)

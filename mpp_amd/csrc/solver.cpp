@@ -1612,8 +1612,13 @@ struct Solver {
   bool th_index_free() const {
     return th && opt.th_spmv_cols && opt.spmv_variant < 0 && vertical_only && columns && nghost == 0 && nz >= 2;
   }
+  // scalar system on soil columns: the line search's product from the column tridiagonals at their computed places (k_spmv_cols_dots)
+  bool cols_index_free() const {
+    return opt.spmv_cols_dots && !th && !thermal && opt.spmv_variant < 0 && vertical_only && columns && nghost == 0 && nz >= 2 &&
+           max_row_nnz <= 3;
+  }
   bool spmv_dots_fused() const {
-    if (opt.fused_ls_dots && th_index_free()) return true;
+    if (opt.fused_ls_dots && (th_index_free() || cols_index_free())) return true;
     const int v = spmv_variant();
     return opt.fused_ls_dots && (v == 20 || v == 21) && compact_index && nghost == 0;
   }
@@ -1622,6 +1627,16 @@ struct Solver {
     // (with the reductions the kernel carries three more streams and one partial sum per block: 6 tiles per wave measured best,
     // 0.958 ms against 1.07 at 2 and 0.977 at 4: profiles/r02_kbench_spmv_dots_tpw.json)
     const int tpw = opt.spmv_tpw > 0 ? opt.spmv_tpw : 6, nv = x ? 3 : 2;
+    if (cols_index_free()) {
+      const size_t nb = (size_t)spmv_cols_dots_blocks(n), need = 3 * (nb + nb / 2048 + 1);
+      if (spmv_partials.n < need) spmv_partials.alloc(need);
+      int nbk;
+      { ProfScope ps(prof, KC_SPMV); nbk = launch_spmv_cols_dots(n, ncols, nz, d_val.p, y, f, x, spmv_partials.p, stream); }
+      ProfScope ps(prof, KC_REDUCE);
+      finalize(nbk, nv, spmv_partials.p, slot);
+      if (comm.active() && nreduce > 0) comm.allreduce_sum(sc.p + S_SUM0, nreduce, stream);
+      return nv;
+    }
     if (th_index_free()) {
       const size_t nb = (size_t)th_spmv_dots_blocks(n), need = 3 * (nb + nb / 2048 + 1);
       if (spmv_partials.n < need) spmv_partials.alloc(need);
@@ -3583,6 +3598,7 @@ struct Solver {
     }
     else if (key == "th_fused_dots") opt.th_fused_dots = num() != 0;
     else if (key == "th_spmv_cols") opt.th_spmv_cols = num() != 0;
+    else if (key == "spmv_cols_dots") opt.spmv_cols_dots = num() != 0;   // line-search product on soil columns without an index
     else if (key == "lazy_tri_l") opt.lazy_tri_l = num() != 0;   // column LU: elimination factors not stored by the march where the fused solves redo them
     else if (key == "th_spmv_tri") opt.th_spmv_tri = num() != 0;   // coupled system on columns: M^{-1} A v + dots in one kernel
     else if (key == "th_stage") opt.th_stage = num() != 0;
@@ -4081,11 +4097,12 @@ int mppgpu_get_assembly_info(mppgpu_handle h, int n, int *info) {
   API_BEGIN(h)
   S.ensure_ready();
   const bool cols = S.use_cols() && !S.th && !S.thermal;
-  const int v[11] = {cols ? S.ncls : 0, cols && S.lev_geo ? 1 : 0, cols && S.lev_pv ? 1 : 0, cols && S.rows_complete() ? 1 : 0,
+  const int v[12] = {cols ? S.ncls : 0, cols && S.lev_geo ? 1 : 0, cols && S.lev_pv ? 1 : 0, cols && S.rows_complete() ? 1 : 0,
                      cols ? S.pick_nseg() : 0, S.spmv_variant(), (S.opt.pc_type == 2 && !S.th && S.tri_lds()) ? 1 : 0,
                      (int)std::min<long long>(S.spec_misses, 2147483647LL), S.opt.ilu_graph ? 1 : 0,
-                     (int)(S.box_graph.execs.size() + S.ilu_graph.execs.size()), S.setup_verified};
-  for (int i = 0; i < n && i < 11; ++i) info[i] = v[i];
+                     (int)(S.box_graph.execs.size() + S.ilu_graph.execs.size()), S.setup_verified,
+                     (S.opt.fused_ls_dots && (S.cols_index_free() || S.th_index_free())) ? 1 : 0};
+  for (int i = 0; i < n && i < 12; ++i) info[i] = v[i];
   API_END()
 }
 int mppgpu_get_pc_info(mppgpu_handle h, int *path, int *launches, int *box_extents) {

@@ -55,7 +55,8 @@ def main():
     rows = ["| kernel | what it restates | algorithmic bytes / launch | moved (PMC) | rocprofv3 average in the bench | frac of 8 TB/s (algorithmic / moved) |",
             "|---|---|---|---|---|---|"]
     for r in (
-        row("k_spmv_c<3, false, true>", "PETSc `MatMult` + the line search's `VecDot` / `VecNorm`s (A x not written) — the CSR SpMV launches of a Newton iteration; **the `roofline` kernel**", bspmv),
+        row("k_spmv_cols_dots", "PETSc `MatMult` + the line search's `VecDot` / `VecNorm`s (A x not written), from the CSR values at their computed places — the product launches of a Newton iteration on soil columns; **the `roofline` kernel**", bspmv),
+        row("k_spmv_c<3, false, true>", "… on the compact 16-bit index (grids that are not soil columns)", bspmv),
         row("k_spmv_c<3, false, false>", "PETSc `MatMult_SeqAIJ` (y = A x): multi-iteration Krylov solves, 3-D problems; timed stand-alone behind the bench", bspmv),
         row("k_tri_solve_lds<2, 4, 3, 4, 2>", "start of `KSPSolve_BCGS`: `PCApply` (back substitution of L⁻¹F), `MatMult`, `PCApply`, 3 dots", 32 + bspmv + 48),
         row("k_tri_solve_lds<2, 5, 2, 4, 3>", "`VecWAXPY` (s = r − αv), `MatMult`, `PCApply`, 2 dots", 24 + bspmv + 48),

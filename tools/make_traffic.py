@@ -19,7 +19,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # kernel class of bench.py's `kernels` object -> how a launch of that class is made up: ("sum", ...) = every launch of the class runs
 # all of these kernels (substrings of the demangled name); ("mean", ...) = launches of the class alternate between them
 CLASSES = {
-    "spmv": ("sum", ["k_spmv_c<3, false, true>"]),          # the launches bench.py times in the SpMV class (the line search's pass)
+    "spmv": ("first", ["k_spmv_cols_dots", "k_spmv_c<3, false, true>"]),   # the launches bench.py times in the SpMV class (the line search's
+                                                                          # pass): index-free on soil columns (round 4), else the compact index
     "spmv_plain": ("sum", ["k_spmv_c<3, false, false>"]),
     "spmv_pc": ("mean", ["k_tri_solve_lds<2, 4, 3, 4, 2>", "k_tri_solve_lds<2, 5, 2, 4, 3>"]),   # first kernel of a solve / second product
     "residual": ("sum", ["k_assemble_cols<0,", "k_bc<0>"]),
@@ -55,6 +56,11 @@ def main():
                 short = re.sub(r"\(.*$", "", name.replace("mpp::(anonymous namespace)::", "").replace("void ", ""))
                 if sub in short:
                     ks[short] = v["hbm_bytes_per_launch"]
+            if mode == "first" and ks:     # the first of the alternatives that ran
+                mode = "sum"
+                break
+        if mode == "first":
+            mode = "sum"
         if ks:
             total = sum(ks.values())
             out["classes"][cls] = {"kernels": ks, "hbm_bytes_per_launch": total if mode == "sum" else total / len(ks),
