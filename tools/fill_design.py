@@ -117,7 +117,7 @@ def main():
     results.append("`roofline` of that line: %s → **%.0f GB/s of algorithmic CSR bytes = %.3f of peak** (%.5f ms per launch, HIP events); "
                    "%.0f GB/s = %.3f of peak on the bytes it moves (PMC %.3f GB per launch); the plain `y = A x` kernel timed behind the "
                    "region: %.5f ms = %.3f of peak." % (
-                       "the CSR SpMV launches of the timed region", roof["achieved"], roof["frac"], roof["avg_launch_ms"],
+                       ("the line search's product launches of the timed region (`k_spmv_cols_dots`: the CSR values at their computed places, no index — it moves less than SURVEY's CSR count, hence above 1.0 on it)" if roof.get("structure_exploited") else "the CSR SpMV launches of the timed region"), roof["achieved"], roof["frac"], roof["avg_launch_ms"],
                        roof.get("achieved_physical", 0), roof.get("frac_physical", 0), (roof.get("traffic") or 0) / 1e9,
                        roof.get("plain_spmv_kernel", {}).get("avg_launch_ms", 0), roof.get("plain_spmv_kernel", {}).get("frac", 0)))
     if cb.get("value"):
