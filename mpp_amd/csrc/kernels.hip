@@ -2374,7 +2374,8 @@ __global__ __launch_bounds__(64) void k_tri_solve_lds(TriArgs a, const double *_
 #pragma unroll
       for (int j = 0; j < G; ++j) {
         const size_t i = cbase + (size_t)max(ktop - j, 0) * tw;
-        cb[q][j] = ldnt(a.c + i); ib[q][j] = ldnt(a.invb + i); db[q][j] = ldnt(r + i);
+        // (c and 1 / pivot are read again by this kernel's last sweep, a tile's worth later: plain loads, so that the caches may keep them)
+        cb[q][j] = a.c[i]; ib[q][j] = a.invb[i]; db[q][j] = ldnt(r + i);
       }
     };
 #pragma unroll
@@ -2389,7 +2390,7 @@ __global__ __launch_bounds__(64) void k_tri_solve_lds(TriArgs a, const double *_
           const int k = k0 - q * G - j;
           const double xk = (db[q][j] - cb[q][j] * next) * ib[q][j];
           next = xk;
-          stnt(xk, xs + (size_t)k * tws);
+          xs[(size_t)k * tws] = xk;   // (plain store: the last sweep reads it back as the dot products' w)
           dsl[k * 64 + lane] = xk;
           accx += xk * xk;
         }
@@ -2406,7 +2407,7 @@ __global__ __launch_bounds__(64) void k_tri_solve_lds(TriArgs a, const double *_
         if (k >= 0) {
           const double xk = (db[q][j] - cb[q][j] * next) * ib[q][j];
           next = xk;
-          stnt(xk, xs + (size_t)k * tws);
+          xs[(size_t)k * tws] = xk;   // (plain store: the last sweep reads it back as the dot products' w)
           dsl[k * 64 + lane] = xk;
           accx += xk * xk;
         }
@@ -2458,7 +2459,7 @@ __global__ __launch_bounds__(64) void k_tri_solve_lds(TriArgs a, const double *_
     };
     auto step = [&](int k, double xk, double lo, double di, double up, double vk) {
       if (SPMV == 2) xk = dsl[k * 64 + lane];   // (rows below k have been replaced by their eliminated sums already: not needed any more)
-      if (SPMV == 3) { xk = fma(na, vk, xk); stnt(xk, ss + (size_t)k * tws); }   // s = r - alpha v (k_waxpy's arithmetic), kept for the update kernel
+      if (SPMV == 3) { xk = fma(na, vk, xk); ss[(size_t)k * tws] = xk; }   // s = r - alpha v (k_waxpy's arithmetic), kept for the update kernel
       if (k > 0 && k < nz - 1) {   // a middle level: (lo, di, up) hold segment entries l, tw + l, 2 tw + l -> this lane's row
         if (valid) { tr[lane] = lo; tr[tw + lane] = di; tr[2 * tw + lane] = up; }
         __builtin_amdgcn_wave_barrier();
@@ -2539,7 +2540,8 @@ __global__ __launch_bounds__(64) void k_tri_solve_lds(TriArgs a, const double *_
       for (int j = 0; j < G; ++j) {
         const size_t i = cbase + (size_t)max(ktop - j, 0) * tw;
         cb[q][j] = ldnt(a.c + i); ib[q][j] = ldnt(a.invb + i);
-        if (ND == 2) wb[q][j] = (SPMV >= 2) ? ldnt(xout + i) : ldnt(w + i);   // (SPMV >= 2: w is the x this kernel wrote -- same pointer)
+        if (ND == 2) wb[q][j] = (SPMV >= 2) ? xout[i] : ldnt(w + i);   // (SPMV >= 2: w is the x this kernel wrote a tile's worth
+                                                                         // ago -- same pointer, plain store and load: the caches may still hold it)
       }
     };
 #pragma unroll
