@@ -349,6 +349,21 @@ def dry_run_rank(args, group, rank, world):
         sent = float(part.send_ptr[-1]) if len(part.send_ptr) else 0.0
         tot = group.allreduce([float(part.nowned), float(part.nghost), sent, float(tp.bc.num_connections)], op="sum")
         extra = {"owned_cells": tot[0], "ghost_cells": tot[1], "halo_values_sent": tot[2], "boundary_faces": tot[3]}
+    elif args.workload == "vsfm3d" or (args.workload == "th" and args.mesh == "3d"):
+        # 7-point grids: a rank owns an x-y block of WHOLE soil columns (rows of the grid), its ghosts are the neighbours' edge columns
+        from mpp_amd import workloads as P
+        build = P.vchannel_rank if args.workload == "vsfm3d" else P.th_vchannel_rank
+        part, lp = build(args.nx, args.ny, args.nz, world, rank)
+        sent = float(part.send_ptr[-1]) if len(part.send_ptr) else 0.0
+        fields = 2.0 if args.workload == "th" else 1.0
+        tot = group.allreduce([float(part.nowned), float(part.nghost), sent, float(part.ncols_owned), float(part.nghost) / args.nz], op="sum")
+        first_col = group.allreduce([float(part.l2g[0] % (args.nx * args.ny)) if r == rank else 0.0 for r in range(world)], op="sum")
+        per_nb = group.allreduce([float(max(part.recv_count)) if len(part.recv_count) else 0.0], op="max")[0]
+        extra = {"cells": tot[0], "owned_cells": tot[0], "ghost_cells": tot[1], "halo_values_sent": tot[2], "columns": tot[3],
+                 "ghost_columns": tot[4], "first_column_of_rank": first_col, "mesh": "3d", "partition": getattr(part, "mode", "?"),
+                 "halo_bytes_per_neighbour_per_exchange": per_nb * 8.0 * fields,
+                 "unknowns": fields * tot[0]}
+        ncols_local = part.ncols_owned
     elif args.workload == "th":
         from mpp_amd import workloads as P
         tp = P.th_columns(ncols=ncols_local, nz=args.nz, perm_mult=perm_multipliers(ncols_global)[col0:col0 + ncols_local])
@@ -612,14 +627,175 @@ def run_th(args, group, rank, world, local_rank, launched, dog):
     group.close()
 
 
+def vsfm3d_measure(soe, prob, steps, warmup, nx, ny, nz, n_owned, group=None, dog=None, profile=1):
+    """times `steps` StepDT calls of a 7-point VSFM problem after `warmup`; returns the pieces of a bench line.  The roofline object
+    is the CSR SpMV proper (k_spmv_* on 7-entry rows: values + index + x gathered + y written) INSIDE this timed region -- here
+    BiCGStab runs tens of iterations per Newton step, so the product is the hot loop (12 nnz + 20 N + 4 bytes per launch)."""
+    from mpp_amd import constants as C
+
+    def barrier():
+        soe.synchronize()
+        if group is not None:
+            group.barrier()
+
+    def step(i):
+        conv, reason = soe.StepDT(prob.dt, i + 1)
+        if not conv:
+            raise RuntimeError("StepDT did not converge (reason %d)" % reason)
+
+    mass0 = float(np.sum(soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_MASS, -1)[:n_owned]))
+    for i in range(warmup):
+        step(i)
+    if dog:
+        dog.done()
+    soe.SetOption("profile_stride", EVENT_STRIDE)
+    soe.SetOption("profile", profile)
+    soe.reset_stats()
+    c0 = soe.counters()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if group is not None:
+        elapsed = group.allreduce([elapsed], op="max")[0]
+    c1 = soe.counters()
+    comm = soe.comm_stats()
+    kernels = class_stats(soe, elapsed, EVENT_STRIDE)
+    sp = soe.kernel_stats("spmv")
+    soe.SetOption("profile", 0)
+    mass1 = float(np.sum(soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_MASS, -1)[:n_owned]))
+    if group is not None:
+        mass0, mass1 = group.allreduce([mass0, mass1], op="sum")
+    newton, linear = c1["newton"] - c0["newton"], c1["linear"] - c0["linear"]
+    out = {"value": newton / elapsed, "unit": "Newton iters/s", "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+           "newton_iterations": newton, "linear_iterations": linear, "linear_per_newton": round(linear / max(newton, 1), 2),
+           "ms_per_newton_iteration": elapsed / max(newton, 1) * 1e3, "time_step_cuts": c1["time_cuts"] - c0["time_cuts"],
+           "halo_exchanges": comm["halo_exchanges"], "allreduces": comm["allreduces"],
+           # no boundary condition, no source: the water in the domain is conserved (a size-independent check of the whole step)
+           "answer_check": {"property": "total water mass conserved over the %d steps (no boundary, no source)" % (steps + warmup),
+                            "mass_kg_before": mass0, "mass_kg_after": mass1, "relative_drift": abs(mass1 - mass0) / abs(mass0)},
+           "kernels": kernels}
+    if sp["launches"]:
+        ms = sp["total_ms"] / sp["launches"]
+        ach = sp["bytes_per_launch"] / (ms * 1e-3) / 1e9
+        out["roofline"] = {"kernel": "csr_spmv_fp64 on 7-point rows (values + index + gathered x + y written), inside this timed region",
+                           "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(min(ach / HBM_PEAK_GBS, 1.0), 4), "traffic": None,
+                           "achieved_is": "algorithmic CSR bytes (12 nnz + 20 N + 4, SURVEY 8d) / HIP-event average launch time",
+                           "bytes_per_launch": sp["bytes_per_launch"], "avg_launch_ms": round(ms, 5), "launches_timed": sp["launches"],
+                           "launches": sp["calls"]}
+    return out
+
+
+def run_vsfm3d(args, group, rank, world, local_rank, launched, dog):
+    """SURVEY 8(d)'s 7-point VSFM variant: the v-channel soil and geometry (dx = dy = 10 m, dz = 0.5 m, hydrostatic start, no boundary
+    condition) on nx x ny x nz cells.  N > 1: ranks own x-y blocks of WHOLE soil columns (MeshType.F90:293-460), ghosts are
+    the neighbours' edge columns, halo exchange (nz x nx cells per neighbour) before every assembly pass and SpMV; the per-column
+    block-Jacobi preconditioner is the same operator for every N, so are the iteration counts."""
+    from mpp_amd import workloads as P
+    t_setup = time.perf_counter()
+    part, prob = P.vchannel_rank(args.nx, args.ny, args.nz, world, rank)
+    opts = {"ksp_type": args.ksp, "pc_type": args.pc, "ksp_rtol": args.ksp_rtol}
+    opts.update(kv.split("=", 1) for kv in args.opt)
+    g = P.to_gpu(prob, opts, device_id=pick_device(args, local_rank))
+    soe = g.soe
+    if launched:
+        init_comm(soe, group, rank, world)
+    t_setup = time.perf_counter() - t_setup
+    m = vsfm3d_measure(soe, prob, args.steps, args.warmup, args.nx, args.ny, args.nz, part.nowned, group=group if launched else None, dog=dog,
+                       profile=1 if args.profile in ("all", "auto") and world == 1 else 2)
+    layout = soe.assembly_info()
+    if rank == 0:
+        N = args.nx * args.ny * args.nz
+        out = {"metric": "Newton iters/sec (VSFM 7-point %dx%dx%d)" % (args.nx, args.ny, args.nz), "value": m.pop("value"), "unit": m.pop("unit"),
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": m.pop("ms_per_step"),
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "VSFM v-channel 7-point grid %dx%dx%d, %s+%s" % (args.nx, args.ny, args.nz, args.ksp, args.pc),
+                          "cells": N, "cells_per_gpu": part.nowned, "ghost_cells_rank0": part.nghost,
+                          "halo_bytes_per_neighbour_per_exchange": int(max(part.recv_count)) * 8 if len(part.recv_count) else 0,
+                          "column_segments": layout["column_segments"], "spmv_variant": layout["spmv_variant"],
+                          "parallelism": "x-y blocks of whole soil columns over %d GPU(s), RCCL halo exchange + all-reduce" % world},
+               "setup_s": round(t_setup, 2)}
+        out.update(m)
+        print(json.dumps(out), flush=True)
+    group.barrier()
+    group.close()
+
+
+def run_th3d(args, group, rank, world, local_rank, launched, dog):
+    """the coupled thermal-hydrology system on the 7-point v-channel grid (workloads.th_vchannel), ranks owning whole soil columns with
+    ghost columns; GMRES(30) + rank-local ILU(0) unless --ksp / --pc say otherwise.  One step = one soe%StepDT."""
+    from mpp_amd import constants as C
+    from mpp_amd import workloads as P
+    t_setup = time.perf_counter()
+    part, tp = P.th_vchannel_rank(args.nx, args.ny, args.nz, world, rank)
+    opts = {"ksp_type": args.ksp, "pc_type": args.pc, "ksp_rtol": args.ksp_rtol}
+    opts.update(kv.split("=", 1) for kv in args.opt)
+    g = P.to_th_gpu(tp, opts, device_id=pick_device(args, local_rank))
+    soe = g.soe
+    if launched:
+        init_comm(soe, group, rank, world)
+    t_setup = time.perf_counter() - t_setup
+
+    def barrier():
+        soe.synchronize()
+        group.barrier()
+
+    def step(i):
+        P.th_gpu_set_conditions(tp, g)
+        conv, reason = soe.StepDT(tp.dt, i + 1)
+        if not conv:
+            raise RuntimeError("StepDT did not converge (reason %d)" % reason)
+
+    for i in range(args.warmup):
+        step(i)
+    if dog:
+        dog.done()
+    soe.SetOption("profile_stride", EVENT_STRIDE)
+    soe.SetOption("profile", 1 if args.profile in ("all", "auto") and world == 1 else 0)
+    soe.reset_stats()
+    c0 = soe.counters()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    barrier()
+    elapsed = group.allreduce([time.perf_counter() - t0], op="max")[0]
+    c1 = soe.counters()
+    comm = soe.comm_stats()
+    kernels = class_stats(soe, elapsed, EVENT_STRIDE)
+    soe.SetOption("profile", 0)
+    newton = c1["newton"] - c0["newton"]
+    if rank == 0:
+        N = args.nx * args.ny * args.nz
+        out = {"metric": "Newton iters/sec (TH 7-point %dx%dx%d)" % (args.nx, args.ny, args.nz), "value": newton / elapsed, "unit": "Newton iters/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "coupled thermal-hydrology on the v-channel 7-point grid %dx%dx%d, 2x2-block Jacobian, %s+%s"
+                                      % (args.nx, args.ny, args.nz, args.ksp, args.pc),
+                          "cells": N, "unknowns": 2 * N, "cells_per_gpu": part.nowned, "ghost_cells_rank0": part.nghost,
+                          "halo_bytes_per_neighbour_per_exchange": int(max(part.recv_count)) * 16 if len(part.recv_count) else 0,
+                          "parallelism": "x-y blocks of whole soil columns over %d GPU(s), RCCL halo exchange + all-reduce" % world},
+               "newton_iterations": newton, "linear_iterations": c1["linear"] - c0["linear"], "time_step_cuts": c1["time_cuts"] - c0["time_cuts"],
+               "halo_exchanges": comm["halo_exchanges"], "setup_s": round(t_setup, 2), "kernels": kernels}
+        print(json.dumps(out), flush=True)
+    group.barrier()
+    group.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=["vsfm", "thermal", "th"], default="vsfm",
-                    help="vsfm: the headline (BASELINE configs 2 / 3); thermal: n^3 heat diffusion, GMRES(30) + ILU(0) (config 4); "
-                         "th: coupled thermal-hydrology columns (config 5)")
+    ap.add_argument("--workload", choices=["vsfm", "vsfm3d", "thermal", "th"], default="vsfm",
+                    help="vsfm: the headline (BASELINE configs 2 / 3); vsfm3d: the 7-point VSFM grid of SURVEY 8(d) (v-channel soil and "
+                         "geometry, lateral + vertical connections; ranks own x-y blocks of whole columns); thermal: n^3 heat diffusion, "
+                         "GMRES(30) + ILU(0) (config 4); th: coupled thermal-hydrology columns (config 5; --mesh 3d: on the 7-point grid)")
+    ap.add_argument("--mesh", choices=["columns", "3d"], default="columns",
+                    help="th: independent soil columns (config 5) or the 7-point v-channel grid split by whole columns with ghost columns")
     ap.add_argument("--nx", type=int, default=0, help="columns in x (default 1024; th: 512)")
     ap.add_argument("--ny", type=int, default=0, help="columns in y (default 1024; th: 512)")
     ap.add_argument("--nz", type=int, default=0, help="layers (default 100; th: 80)")
@@ -649,11 +825,13 @@ def main():
     ap.add_argument("--fail-rank", type=int, default=-1, help="with --dry-run-ranks: this rank exits with an error")
     args = ap.parse_args()
     th_like = args.workload == "th"
-    args.nx = args.nx or (512 if th_like else 1024)
-    args.ny = args.ny or (512 if th_like else 1024)
+    three_d = args.workload == "vsfm3d" or (th_like and args.mesh == "3d")
+    args.nx = args.nx or (256 if three_d and th_like else 512 if th_like or three_d else 1024)
+    args.ny = args.ny or (256 if three_d and th_like else 512 if th_like or three_d else 1024)
     args.nz = args.nz or (80 if th_like else 100)
-    args.ksp = args.ksp or ("gmres" if args.workload == "thermal" else "bcgs")
-    args.pc = args.pc or ("ilu" if args.workload == "thermal" else "bjacobi")
+    gmres_ilu = args.workload == "thermal" or (th_like and three_d)      # (the coupled column preconditioner needs a vertical-only grid)
+    args.ksp = args.ksp or ("gmres" if gmres_ilu else "bcgs")
+    args.pc = args.pc or ("ilu" if gmres_ilu else "bjacobi")
 
     launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ
     if not launched and args.gpus > 1:
@@ -678,7 +856,8 @@ def main():
         return
 
     if args.workload != "vsfm":
-        (run_thermal if args.workload == "thermal" else run_th)(args, group, rank, world, local_rank, launched, dog)
+        run = {"thermal": run_thermal, "th": run_th3d if args.mesh == "3d" else run_th, "vsfm3d": run_vsfm3d}[args.workload]
+        run(args, group, rank, world, local_rank, launched, dog)
         return
 
     # the HIP extension (fails loudly if missing)

@@ -186,27 +186,83 @@ class MeshPart:
         self.nowned = mesh.ncells_local - nghost
 
 
-def partition_mesh(mesh, nranks):
-    """Split `mesh` into `nranks` contiguous id ranges (z-slabs for the x-fastest numbering of MeshCreate).  A cell is a
-    ghost on rank r when an internal connection joins it to a cell r owns; connections with at least one owned end are
-    kept (in the global connection order); both neighbours list shared cells in ascending global id, which makes rank
-    q's send list match the order of its cells among rank r's ghosts."""
+def column_of_cells(mesh):
+    """0-based soil-column number of every cell, from the vertical chains of the internal connection set (any cell numbering; a
+    connection is vertical when its unit vector is mostly along z -- the library's own rule, solver.cpp `is_vertical`).  Columns are
+    numbered in the order of their lowest cells' ids (for MeshCreate's x-fastest numbering: jj outer, ii inner).  A cell without a
+    vertical connection is a column of its own."""
+    import numpy as np
+    n = mesh.ncells_local
+    cs = mesh.internal_connections()
+    up, dn = np.asarray(cs.id_up, dtype=np.int64) - 1, np.asarray(cs.id_dn, dtype=np.int64) - 1
+    if cs.unit_vec is None:
+        vert = np.ones(up.size, dtype=bool)
+    else:
+        uv = np.asarray(cs.unit_vec, dtype=np.float64)
+        vert = np.abs(uv[:, 2]) > 0.5 * np.sqrt((uv * uv).sum(axis=1))
+    below = np.arange(n, dtype=np.int64)           # the cell under this one in its chain (itself at the chain's lower end)
+    below[dn[vert]] = up[vert]
+    root = below
+    while True:                                    # pointer jumping: log2(longest chain) rounds
+        nxt = root[root]
+        if np.array_equal(nxt, root):
+            break
+        root = nxt
+    _, col = np.unique(root, return_inverse=True)  # roots ascending = columns in the order of their lowest cells
+    return col.astype(np.int64)
+
+
+def partition_mesh(mesh, nranks, mode="auto"):
+    """Split `mesh` over `nranks` ranks.
+
+    mode "columns" (the default whenever the mesh has a vertical connection): ranks own WHOLE soil columns -- the column set,
+    in the order of the columns' lowest cells, is cut into `nranks` contiguous blocks (x-y blocks: for MeshCreate's x-fastest
+    numbering a block is a range of jj) -- which is how the reference distributes a 3-D mesh (MeshCreateFromCLMCols,
+    src/mpp/dtypes/MeshType.F90:293-460: a rank holds ncols_local columns of nlevgrnd cells and its ghosts are whole ghost columns,
+    :362 ncells_ghost = ncols_ghost*nlevgrnd) and what SURVEY.md section 8(e) asks for.  No soil column is cut: the strong vertical
+    couplings stay inside a rank's block of the rank-local preconditioner, and the halo of a 7-point grid is nz x edge cells per
+    neighbour.
+    mode "ranges": contiguous id ranges (z-slabs for the x-fastest numbering) -- kept for the isotropic thermal cube
+    (workloads.thermal_mms_rank builds exactly these slabs without the global mesh).
+
+    A cell is a ghost on rank r when an internal connection joins it to a cell r owns; connections with at least one owned end are
+    kept (in the global connection order); owned cells come first in ascending global id, ghosts after them grouped by owner in
+    ascending id; both neighbours list shared cells in ascending global id, which makes rank q's send list match the order of its
+    cells among rank r's ghosts."""
     import numpy as np
     from . import mesh as M
     n = mesh.ncells_local
     cs = mesh.internal_connections()
     up, dn = np.asarray(cs.id_up) - 1, np.asarray(cs.id_dn) - 1
-    bounds = [shard_columns(n, nranks, r) for r in range(nranks)]
+    if mode not in ("auto", "columns", "ranges"):
+        raise ValueError("partition_mesh: mode must be auto, columns or ranges")
     owner = np.empty(n, dtype=np.int64)
-    for r, (c0, cnt) in enumerate(bounds):
-        owner[c0:c0 + cnt] = r
+    col = None
+    if mode != "ranges":
+        col = column_of_cells(mesh)
+        if mode == "auto" and int(col.max()) + 1 == n:
+            col = None                                 # no vertical connection anywhere: columns are single cells = id ranges
+    if col is not None:
+        ncol = int(col.max()) + 1
+        if ncol < nranks:
+            raise ValueError("partition_mesh: %d columns cannot be split over %d ranks" % (ncol, nranks))
+        col_owner = np.empty(ncol, dtype=np.int64)
+        for r in range(nranks):
+            c0, cnt = shard_columns(ncol, nranks, r)
+            col_owner[c0:c0 + cnt] = r
+        owner[:] = col_owner[col]
+    else:
+        for r in range(nranks):
+            c0, cnt = shard_columns(n, nranks, r)
+            owner[c0:c0 + cnt] = r
+    bounds = [np.nonzero(owner == r)[0] for r in range(nranks)]
     parts = []
-    for r, (c0, cnt) in enumerate(bounds):
+    for r, own_g in enumerate(bounds):
         mine_up, mine_dn = owner[up] == r, owner[dn] == r
         keep = mine_up | mine_dn
         ghost_g = np.unique(np.concatenate([dn[mine_up & ~mine_dn], up[mine_dn & ~mine_up]]))
         ghost_g = ghost_g[np.lexsort((ghost_g, owner[ghost_g]))]          # grouped by owner, ascending id inside a group
-        l2g = np.concatenate([np.arange(c0, c0 + cnt), ghost_g])
+        l2g = np.concatenate([own_g, ghost_g])
         g2l = np.full(n, -1, dtype=np.int64)
         g2l[l2g] = np.arange(l2g.size)
         peers = np.unique(owner[ghost_g])
@@ -228,5 +284,8 @@ def partition_mesh(mesh, nranks):
         lm.nghost = int(ghost_g.size)
         lm.halo = (np.asarray(peers, dtype=np.int32), np.asarray(send_ptr, dtype=np.int32), np.asarray(send_cells, dtype=np.int32),
                    np.asarray(recv_count, dtype=np.int32))
-        parts.append(MeshPart(lm, l2g, int(ghost_g.size), *lm.halo))
+        part = MeshPart(lm, l2g, int(ghost_g.size), *lm.halo)
+        part.mode = "columns" if col is not None else "ranges"
+        part.ncols_owned = int(np.unique(col[own_g]).size) if col is not None else 0
+        parts.append(part)
     return parts

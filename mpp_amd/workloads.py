@@ -77,9 +77,10 @@ def celia1990(ncols=1, nz=100, perm_mult=None) -> Problem:
         dt=3600.0, nstep=24)
 
 
-def vchannel(nx=20, ny=10, nz=30) -> Problem:
-    dx, dy, dz, slope_x, slope_y = 10.0, 10.0, 0.5, 0.1, 0.2
-    n = nx * ny * nz
+def _vchannel_surface(nx, ny):
+    """cell-centre coordinates of the v-channel's columns (vsfm_vchannel_problem.F90: a valley along y, sloping in x towards the
+    axis and in y downstream): xc2, yc2, zc2 shaped (nx, ny)"""
+    dx, dy, slope_x, slope_y = 10.0, 10.0, 0.1, 0.2
     zv_x = np.zeros(nx + 1)
     for ii in range(1, nx // 2 + 2):
         zv_x[ii - 1] = slope_x * dx * (nx // 2) - (ii - 1) * slope_x * dx
@@ -93,50 +94,144 @@ def vchannel(nx=20, ny=10, nz=30) -> Problem:
     def c4(a):
         return (a[:-1, :-1] + a[1:, :-1] + a[:-1, 1:] + a[1:, 1:]) / 4.0
 
-    xc2, yc2, zc2 = c4(xv), c4(yv), c4(zv)                  # (nx, ny)
-    kk = np.arange(1, nz + 1)
-    # ids are x-fastest: count over kk, jj, ii  -> arrays shaped [kk, jj, ii]
-    xc = np.broadcast_to(xc2.T[None, :, :], (nz, ny, nx)).ravel()
-    yc = np.broadcast_to(yc2.T[None, :, :], (nz, ny, nx)).ravel()
-    zc = (zc2.T[None, :, :] - (dz / 2.0 + (nz - kk)[:, None, None] * dz)).ravel()
-    m = M.Mesh(name="Soil mesh", ncells_local=n, nlev=nz, orientation=C.MESH_AGAINST_GRAVITY)
-    m.x, m.y, m.z = xc.copy(), yc.copy(), zc.copy()
-    m.dx, m.dy, m.dz = np.full(n, dx), np.full(n, dy), np.full(n, dz)
-    m.area_xy = np.full(n, dx * dy)
-    m.is_active = np.ones(n, dtype=np.int32)
+    return c4(xv), c4(yv), c4(zv)
+
+
+def _vchannel_block(nx, ny, nz, rows, nown_rows):
+    """The v-channel mesh restricted to the grid rows `rows` (0-based jj; every ii and kk of a row): the first `nown_rows` rows
+    are owned, the others are ghost rows.  Local cells: owned cells in ascending global id (kk, jj, ii), then each ghost row in
+    ascending global id (kk, ii).  Internal connections with at least one owned end, in the driver's global order (vertical: kk,
+    ii, jj; x: ii, kk, jj; y: jj, kk, ii), geometry by the driver's expressions in the GLOBAL indices.  With rows = all rows this
+    is the driver's mesh.  Returns (mesh, l2g [0-based global ids], number of owned cells)."""
+    dx, dy, dz = 10.0, 10.0, 0.5
+    rows = np.asarray(rows, dtype=np.int64)
+    own_rows, ghost_rows = rows[:nown_rows], rows[nown_rows:]
+    xc2, yc2, zc2 = _vchannel_surface(nx, ny)
+    nxy = nx * ny
+    kk = np.arange(nz, dtype=np.int64)
+    ii = np.arange(nx, dtype=np.int64)
+    gid_own = (kk[:, None, None] * nxy + own_rows[None, :, None] * nx + ii[None, None, :])            # [kk, jj_own, ii]
+    l2g = [gid_own.ravel()] + [(kk[:, None] * nxy + g * nx + ii[None, :]).ravel() for g in ghost_rows]
+    l2g = np.concatenate(l2g)
+    nloc, nown = l2g.size, gid_own.size
+    gk, grem = np.divmod(l2g, nxy)
+    gj, gi = np.divmod(grem, nx)
+    m = M.Mesh(name="Soil mesh", ncells_local=int(nloc), nlev=nz, orientation=C.MESH_AGAINST_GRAVITY)
+    m.x, m.y = xc2[gi, gj].copy(), yc2[gi, gj].copy()
+    m.z = zc2[gi, gj] - (dz / 2.0 + (nz - (gk + 1)) * dz)
+    m.dx, m.dy, m.dz = np.full(nloc, dx), np.full(nloc, dy), np.full(nloc, dz)
+    m.area_xy = np.full(nloc, dx * dy)
+    m.is_active = np.ones(nloc, dtype=np.int32)
     m.compute_volume()
-    ids = (np.arange(n, dtype=np.int64) + 1).reshape(nz, ny, nx)
+    # local 1-based id of the cell (kk, row position p, ii); row position p indexes `rows`
+    lid = np.empty((nz, rows.size, nx), dtype=np.int64)
+    lid[:, :nown_rows, :] = (np.arange(nown, dtype=np.int64) + 1).reshape(nz, nown_rows, nx)
+    for g in range(ghost_rows.size):
+        lid[:, nown_rows + g, :] = nown + g * nz * nx + (np.arange(nz * nx, dtype=np.int64) + 1).reshape(nz, nx)
+    pos = {int(j): p for p, j in enumerate(rows)}
+    own_sorted = np.sort(own_rows)
+    op = [pos[int(j)] for j in own_sorted]                    # owned rows in ascending jj
     ups, dns, dus, dds, areas = [], [], [], [], []
-    # vertical: do kk, ii, jj
-    up = ids[:-1].transpose(0, 2, 1).ravel(); dn = ids[1:].transpose(0, 2, 1).ravel()
-    ups.append(up); dns.append(dn)
-    dus.append(np.full(up.size, 0.5 * dz)); dds.append(np.full(up.size, 0.5 * dz)); areas.append(np.full(up.size, dx * dy))
 
     def dist_of(u, d):
         ddx = m.x[u - 1] - m.x[d - 1]; ddy = m.y[u - 1] - m.y[d - 1]; ddz = m.z[u - 1] - m.z[d - 1]
         return (ddx ** 2.0 + ddy ** 2.0 + ddz ** 2.0) ** 0.5
 
+    # vertical: do kk, ii, jj (owned rows only: a connection between two ghost cells is not kept)
+    L = lid[:, op, :]
+    up = L[:-1].transpose(0, 2, 1).ravel(); dn = L[1:].transpose(0, 2, 1).ravel()
+    ups.append(up); dns.append(dn)
+    dus.append(np.full(up.size, 0.5 * dz)); dds.append(np.full(up.size, 0.5 * dz)); areas.append(np.full(up.size, dx * dy))
     # horizontal x: do ii, kk, jj
-    up = ids[:, :, :-1].transpose(2, 0, 1).ravel(); dn = ids[:, :, 1:].transpose(2, 0, 1).ravel()
+    up = L[:, :, :-1].transpose(2, 0, 1).ravel(); dn = L[:, :, 1:].transpose(2, 0, 1).ravel()
     dist = dist_of(up, dn)
     ups.append(up); dns.append(dn); dus.append(0.5 * dist); dds.append(0.5 * dist); areas.append(np.full(up.size, dz * dy))
-    # horizontal y: do jj, kk, ii
-    up = ids[:, :-1, :].transpose(1, 0, 2).ravel(); dn = ids[:, 1:, :].transpose(1, 0, 2).ravel()
-    dist = dist_of(up, dn)
-    ups.append(up); dns.append(dn); dus.append(0.5 * dist); dds.append(0.5 * dist); areas.append(np.full(up.size, dz * dx))
+    # horizontal y: do jj, kk, ii -- pairs (jj, jj + 1) of present rows with at least one owned
+    owned = set(int(j) for j in own_rows)
+    pairs = [j for j in range(ny - 1) if j in pos and (j + 1) in pos and (j in owned or (j + 1) in owned)]
+    if pairs:
+        up = np.stack([lid[:, pos[j], :] for j in pairs]).ravel(); dn = np.stack([lid[:, pos[j + 1], :] for j in pairs]).ravel()
+        dist = dist_of(up, dn)
+        ups.append(up); dns.append(dn); dus.append(0.5 * dist); dds.append(0.5 * dist); areas.append(np.full(up.size, dz * dx))
     up, dn = np.concatenate(ups), np.concatenate(dns)
     cs = M.ConnectionSet(up, dn, np.concatenate(dus), np.concatenate(dds), np.concatenate(areas), None, None)
     cs.unit_vec = M.unit_vec_from_centroids(m, up, dn)
     m.intrn_conn_sets.append(cs)
-    m.ncols, m.ordering = nx * ny, "x-fastest"
+    m.ncols, m.ordering = nxy, "x-fastest"
+    return m, l2g, int(nown)
+
+
+def _vchannel_soil(m, l2g, nx, ny, nz) -> Problem:
+    n = m.ncells_local
     perm, alpha, lam = clm_soil_conversion(8.3913e-12, 3.4257e-4, 0.5, C.GRAV_CLM)
-    jj = np.repeat(np.arange(1, nz + 1), nx * ny)
+    jj = l2g // (nx * ny) + 1                                    # the level (the driver's loop variable is called jj)
     press_ic = (18.75 - 0.5 * (jj - 1) - 2.0) * 997.18 * 9.8 + 101325.0
     return Problem(
         name="vsfm_vchannel", mesh=m, perm=np.full((n, 3), perm), por=np.full(n, 0.368),
         satfunc_type=np.full(n, C.SAT_FUNC_VAN_GENUCHTEN, dtype=np.int32), alpha=np.full(n, alpha),
         lam=np.full(n, lam), sat_res=np.full(n, 0.2772), density_type=C.DENSITY_TGDPB01, press_ic=press_ic,
         dt=8640.0, nstep=3)
+
+
+def vchannel(nx=20, ny=10, nz=30) -> Problem:
+    """src/driver/standalone/vsfm/vsfm_vchannel_problem.F90 (20 x 10 x 30, 7-point, no boundary condition, dt = 8640 s x 3)"""
+    m, l2g, _ = _vchannel_block(nx, ny, nz, np.arange(ny), ny)
+    return _vchannel_soil(m, l2g, nx, ny, nz)
+
+
+def _rank_rows(ny, world, rank):
+    """grid rows of rank `rank` when the nx x ny columns are cut into `world` blocks of whole rows: (owned rows, ghost rows grouped by
+    owner [lower neighbour's row first], peers)"""
+    npl = ny // world
+    j0 = rank * npl
+    own = np.arange(j0, j0 + npl)
+    ghosts, peers = [], []
+    if rank > 0:
+        ghosts.append(j0 - 1); peers.append(rank - 1)
+    if rank < world - 1:
+        ghosts.append(j0 + npl); peers.append(rank + 1)
+    return own, np.asarray(ghosts, dtype=np.int64), peers
+
+
+def _block_part(m, l2g, nown, nx, nz, own_rows, peers, rank):
+    """MeshPart of a block of whole grid rows built directly: each neighbour receives my row next to it -- nz x nx cells, ascending
+    global id -- and sends me as many"""
+    from mpp_amd import parallel as PAR
+    nrows = own_rows.size
+    send_cells, send_ptr = [], [0]
+    base = (np.arange(nz, dtype=np.int64)[:, None] * nrows * nx + np.arange(nx, dtype=np.int64)[None, :])
+    for q in peers:
+        p = 0 if q < rank else nrows - 1          # my row next to that neighbour
+        send_cells.append((base + p * nx).ravel() + 1)
+        send_ptr.append(send_ptr[-1] + nz * nx)
+    m.nghost = int(l2g.size - nown)
+    m.halo = (np.asarray(peers, dtype=np.int32), np.asarray(send_ptr, dtype=np.int32),
+              np.concatenate(send_cells).astype(np.int32) if send_cells else np.zeros(0, np.int32),
+              np.full(len(peers), nz * nx, dtype=np.int32))
+    part = PAR.MeshPart(m, l2g, m.nghost, *m.halo)
+    part.mode, part.ncols_owned = "columns", int(nrows * nx)
+    return part
+
+
+def vchannel_rank(nx, ny, nz, world, rank):
+    """Rank `rank`'s share of vchannel(nx, ny, nz) split over `world` ranks by whole soil columns (mpp_amd.parallel.partition_mesh's
+    default: x-y blocks of the column set) -- built WITHOUT the global problem when the blocks are whole grid rows (ny a multiple of
+    world), which is what a rank process of `bench.py --workload vsfm3d --gpus N` calls.  Same cells, order, connections, halo plan
+    as split_problem(vchannel(...), world)[rank] (tests/test_parallel_gloo.py compares the two array by array);
+    returns (part, local problem)."""
+    from mpp_amd import parallel as PAR
+    if world == 1:
+        prob = vchannel(nx, ny, nz)
+        n = prob.mesh.ncells_local
+        part = PAR.MeshPart(prob.mesh, np.arange(n), 0, np.zeros(0, np.int32), np.zeros(1, np.int32), np.zeros(0, np.int32), np.zeros(0, np.int32))
+        part.mode, part.ncols_owned = "columns", nx * ny
+        return part, prob
+    if ny % world != 0:
+        return split_problem(vchannel(nx, ny, nz), world)[rank]
+    own, ghosts, peers = _rank_rows(ny, world, rank)
+    m, l2g, nown = _vchannel_block(nx, ny, nz, np.concatenate([own, ghosts]), own.size)
+    part = _block_part(m, l2g, nown, nx, nz, own, peers, rank)
+    return part, _vchannel_soil(m, l2g, nx, ny, nz)
 
 
 def vchannel_operator_split(nx=6, ny=5, nz=7) -> Problem:
@@ -573,12 +668,13 @@ def _restrict_conn_set(cs, vals, part, g2l):
     return sub, np.asarray(vals)[keep]
 
 
-def split_problem(prob: Problem, nranks):
-    """per-rank VSFM problems of a 3-D problem (no column structure is assumed); returns [(part, local problem)]"""
+def split_problem(prob: Problem, nranks, mode="auto"):
+    """per-rank VSFM problems of a 3-D problem: ranks own whole soil columns (x-y blocks of the column set, ghosts = the neighbour
+    columns' cells; mpp_amd.parallel.partition_mesh, SURVEY.md 8e, MeshType.F90:293-460); returns [(part, local problem)]"""
     from mpp_amd import parallel as PAR
     out = []
     n = prob.mesh.ncells_local
-    for part in PAR.partition_mesh(prob.mesh, nranks):
+    for part in PAR.partition_mesh(prob.mesh, nranks, mode):
         g2l = np.full(n, -1, dtype=np.int64)
         g2l[part.l2g] = np.arange(part.l2g.size)
         l = part.l2g
@@ -594,11 +690,13 @@ def split_problem(prob: Problem, nranks):
     return out
 
 
-def split_thermal_problem(tp: ThermalProblem, nranks):
+def split_thermal_problem(tp: ThermalProblem, nranks, mode="ranges"):
+    """per-rank thermal problems; the isotropic cube is indifferent to the axis of the cut, so the default stays contiguous id ranges
+    (z-slabs), which thermal_mms_rank builds without the global mesh; mode="columns" cuts x-y blocks of whole columns instead"""
     from mpp_amd import parallel as PAR
     out = []
     n = tp.mesh.ncells_local
-    for part in PAR.partition_mesh(tp.mesh, nranks):
+    for part in PAR.partition_mesh(tp.mesh, nranks, mode):
         g2l = np.full(n, -1, dtype=np.int64)
         g2l[part.l2g] = np.arange(part.l2g.size)
         l = part.l2g
@@ -714,19 +812,21 @@ def thermal_mms_rank(nx, ny, nz, world, rank):
     return part, tp
 
 
-def th_vchannel(nx=6, ny=5, nz=7) -> THProblem:
-    """the coupled mass + heat equations on the 3-D v-channel mesh (7-point stencil, sloping surface, gravity along every
-    connection): vchannel's soil and hydrostatic start, a temperature that falls with depth, no boundary conditions (as the
-    v-channel problem), and a heat source in every cell that warms the channel's axis"""
-    vs = vchannel(nx, ny, nz)
+def _th_on_vchannel(vs: Problem, nx, ny, nz) -> THProblem:
+    """the coupled problem's extra inputs on a (piece of a) v-channel mesh; the extents that enter are those of the WHOLE grid, from
+    the surface, so that a rank's piece carries the values of the global problem"""
     m = vs.mesh
     n = m.ncells_local
     z = np.asarray(m.z); x = np.asarray(m.x)
-    temp_ic = 283.15 + 4.0 * (z - z.min()) / max(z.max() - z.min(), 1e-30)
+    xc2, _yc2, zc2 = _vchannel_surface(nx, ny)
+    dz = 0.5
+    zmin, zmax = float(zc2.min()) - (dz / 2.0 + (nz - 1) * dz), float(zc2.max()) - dz / 2.0
+    xmin, xmax = float(xc2.min()), float(xc2.max())
+    temp_ic = 283.15 + 4.0 * (z - zmin) / max(zmax - zmin, 1e-30)
     ids = np.arange(1, n + 1)
     zero = np.zeros(n)
     allcells = M.ConnectionSet(np.zeros(n, dtype=np.int64), ids, zero, zero, np.ones(n), np.zeros((n, 3)))
-    heat = 40.0 * np.asarray(m.vol) * np.exp(-((x - x.mean()) / (0.25 * (x.max() - x.min() + 1e-30))) ** 2)
+    heat = 40.0 * np.asarray(m.vol) * np.exp(-((x - 0.5 * (xmin + xmax)) / (0.25 * (xmax - xmin + 1e-30))) ** 2)
     return THProblem(
         name="th_vchannel", mesh=m, perm=vs.perm, por=vs.por, satfunc_type=vs.satfunc_type, alpha=vs.alpha, lam=vs.lam,
         sat_res=vs.sat_res, density_type=C.DENSITY_TGDPB01, ie_type=2,
@@ -735,14 +835,38 @@ def th_vchannel(nx=6, ny=5, nz=7) -> THProblem:
         energy_sss=[(C.COND_HEAT_RATE, allcells, heat)], dt=vs.dt, nstep=2)
 
 
-def split_th_problem(tp: THProblem, nranks):
-    """per-rank coupled TH problems of a mesh split into contiguous id ranges (owned cells + ghost cells, halo plan);
-    returns [(part, local problem)]"""
+def th_vchannel(nx=6, ny=5, nz=7) -> THProblem:
+    """the coupled mass + heat equations on the 3-D v-channel mesh (7-point stencil, sloping surface, gravity along every
+    connection): vchannel's soil and hydrostatic start, a temperature that falls with depth, no boundary conditions (as the
+    v-channel problem), and a heat source in every cell that warms the channel's axis"""
+    return _th_on_vchannel(vchannel(nx, ny, nz), nx, ny, nz)
+
+
+def th_vchannel_rank(nx, ny, nz, world, rank):
+    """rank `rank`'s share of th_vchannel(nx, ny, nz) over `world` ranks that own whole soil columns, built without the global
+    problem when ny is a multiple of world (`bench.py --workload th --mesh 3d --gpus N`); equals split_th_problem(...)[rank]
+    array by array (tests/test_parallel_gloo.py); returns (part, local problem)"""
+    if world > 1 and ny % world != 0:
+        return split_th_problem(th_vchannel(nx, ny, nz), world)[rank]
+    part, vs = vchannel_rank(nx, ny, nz, world, rank)
+    tp = _th_on_vchannel(vs, nx, ny, nz)
+    if part.nghost > 0:          # sources act on owned cells only (workloads._restrict_conn_set)
+        t, cs, vals = tp.energy_sss[0]
+        k = part.nowned
+        sub = M.ConnectionSet(np.asarray(cs.id_up)[:k], np.asarray(cs.id_dn)[:k], np.asarray(cs.dist_up)[:k], np.asarray(cs.dist_dn)[:k],
+                              np.asarray(cs.area)[:k], np.asarray(cs.unit_vec)[:k], None)
+        tp.energy_sss = [(t, sub, np.asarray(vals)[:k])]
+    return part, tp
+
+
+def split_th_problem(tp: THProblem, nranks, mode="auto"):
+    """per-rank coupled TH problems of a mesh split by whole soil columns (owned cells + ghost cells, halo plan; mode="ranges":
+    contiguous id ranges, the z-slabs rounds 3-4 used); returns [(part, local problem)]"""
     from mpp_amd import parallel as PAR
     out = []
     n = tp.mesh.ncells_local
     pick = lambda a, l: None if a is None else np.asarray(a)[l]
-    for part in PAR.partition_mesh(tp.mesh, nranks):
+    for part in PAR.partition_mesh(tp.mesh, nranks, mode):
         g2l = np.full(n, -1, dtype=np.int64)
         g2l[part.l2g] = np.arange(part.l2g.size)
         l = part.l2g

@@ -219,9 +219,10 @@ def test_3d_mesh_split_across_ranks_thermal(nranks):
 
 
 def test_3d_mesh_split_across_ranks_vsfm():
-    """the 7-point v-channel problem on 3 ranks (ghost planes, halo exchange before every residual / Jacobian / SpMV,
-    rank-local ILU(0)) against the single-handle solve: residual rows of the owned cells at a random state, then three
-    time steps"""
+    """the 7-point v-channel problem on 3 ranks that own whole soil columns (x-y blocks; ghost columns, halo exchange before every
+    residual / Jacobian / SpMV, GMRES(30) + rank-local ILU(0) = the reference's defaults) against the single-handle solve: residual
+    rows of the owned cells at a random state, then three time steps with the single handle's Newton count and its linear
+    iterations +- 2 per solve"""
     from mpp_amd import vsfm as V
     prob = P.vchannel(6, 5, 9)
     n = prob.mesh.ncells_local
@@ -231,6 +232,8 @@ def test_3d_mesh_split_across_ranks_vsfm():
     ref.soe.SetDtime(prob.dt); ref.soe.PreSolve()
     f_ref = ref.soe.ComputeResidual(x)
     parts = P.split_problem(prob, 3)
+    assert all(part.mode == "columns" and part.ncols_owned == 10 for part, _ in parts)
+    assert [part.recv_count.tolist() for part, _ in parts] == [[6 * 9], [6 * 9, 6 * 9], [6 * 9]]   # nz x edge cells per neighbour
     gs = [P.to_gpu(lp, opts) for _, lp in parts]
     V.comm_init_local([g.soe for g in gs])
 
@@ -252,7 +255,10 @@ def test_3d_mesh_split_across_ranks_vsfm():
 
     res = _run_ranks([lambda g=g: steps(g) for g in gs])
     assert all(c for r in res for (c, _) in r)
+    c_ref = ref.soe.counters()
     for (part, lp), g in zip(parts, gs):
+        c = g.soe.counters()
+        assert c["newton"] == c_ref["newton"] and abs(c["linear"] - c_ref["linear"]) <= 2 * c_ref["newton"], (c, c_ref)
         p = g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE)
         assert np.abs(p[:part.nowned] - p_ref[part.l2g[:part.nowned]]).max() <= 1e-7 * np.abs(p_ref).max()
 

@@ -343,18 +343,18 @@ def test_th_at_config_5_size_every_column_gives_the_single_column_answer():
 
 @pytest.mark.parametrize("case,nranks", [("vchannel", 3), ("vchannel", 2), ("th_mms", 2)])
 def test_th_mesh_split_across_ranks_with_ghost_cells(case, nranks):
-    """SURVEY 8(e) for the coupled system: a TH mesh split into contiguous id ranges over `nranks` handles of this process --
-    owned cells + ghost cells, both fields of the ghosts refreshed from their owners before every assembly pass and SpMV, ghost
-    rows identity rows.  The unknowns are field-blocked [P; T], so the ghost rows are two ranges of
-    every vector (kept zero outside the kernels that read them), BiCGStab + rank-local ILU(0).  Residual rows of the owned cells equal the single-handle rows at
-    a random state; the time steps reach the single-handle solution to the linear tolerance."""
+    """SURVEY 8(e) for the coupled system: a TH mesh split by WHOLE SOIL COLUMNS (x-y blocks of the column set; th_mms has no
+    vertical connection: id ranges) over `nranks` handles of this process -- owned cells + ghost cells, both fields of the ghosts
+    refreshed from their owners before every assembly pass and SpMV, ghost rows identity rows.  The unknowns are field-blocked
+    [P; T], so the ghost rows are two ranges of every vector (kept zero outside the kernels that read them).  The reference's
+    default solver, GMRES(30) + (rank-local) ILU(0): residual rows of the owned cells equal the single-handle rows at a random
+    state; the time steps reach the single-handle solution to the linear tolerance, with the single handle's Newton count and its
+    linear iterations +- 2 per solve (dense algebra on the oracle's Jacobian: tests/test_oracle_th_split_krylov.py, 29 / 29 / 29)."""
     from mpp_amd import vsfm as V
     from test_gpu_more import _run_ranks
     tp = P.th_vchannel(6, 5, 7) if case == "vchannel" else P.th_mms(24)
     n = tp.mesh.ncells_local
-    # BiCGStab: with the rank-local ILU(0) (block Jacobi across ranks) this system needs a Krylov space of a few hundred vectors,
-    # and restarted GMRES(30) stagnates on it (single handle: 28 iterations; three ranks: BiCGStab 215, GMRES(30) none in 10^4)
-    opts = {"ksp_type": "bcgs", "pc_type": "ilu", "ksp_rtol": 1e-11}
+    opts = {"ksp_type": "gmres", "pc_type": "ilu", "ksp_rtol": 1e-11}
     ref = P.to_th_gpu(tp, opts)
     x = _state(tp, seed=4, dp=(0.0, 3e4), dt=(0.0, 8.0))
     ref.soe.SetDtime(tp.dt); ref.soe.PreSolve()
@@ -393,6 +393,16 @@ def test_th_mesh_split_across_ranks_with_ghost_cells(case, nranks):
     res = _run_ranks([lambda lp=lp, g=g: steps(lp, g) for (_, lp), g in zip(parts, gs)])
     assert all(c for r in res for (c, _) in r)
     assert len({tuple(r) for r in map(tuple, res)}) == 1          # every rank took the same decisions
+    c_ref = ref.soe.counters()
+    for g in gs:
+        c = g.soe.counters()
+        assert c["newton"] == c_ref["newton"], (c, c_ref)
+        assert abs(c["linear"] - c_ref["linear"]) <= 2 * c_ref["newton"], (c, c_ref)      # whole columns per rank: the split ILU(0) is as good
+    if case == "vchannel":
+        assert all(part.mode == "columns" for part, _ in parts)
+        # halo bytes per SpMV and neighbour = nz x (cells of the edge) x 8 B per field
+        for part, _ in parts:
+            assert all(int(cnt) % 7 == 0 for cnt in part.recv_count)
     for (part, lp), g in zip(parts, gs):
         own = part.l2g[:part.nowned]
         p = g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE)

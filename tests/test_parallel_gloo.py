@@ -123,8 +123,9 @@ def test_host_group_single_rank_is_trivial():
     g.close()
 
 
-def test_partition_mesh_halo_plans_are_consistent():
-    """mpp_amd.parallel.partition_mesh: every rank's ghosts from rank q are, in order, the cells of q's send list to it;
+@pytest.mark.parametrize("mode", ["columns", "ranges"])
+def test_partition_mesh_halo_plans_are_consistent(mode):
+    """mpp_amd.parallel.partition_mesh, both modes: every rank's ghosts from rank q are, in order, the cells of q's send list to it;
     owned cells partition the mesh; every kept connection has an owned end and no connection joins two ghosts"""
     import numpy as np
     import problems as P
@@ -132,11 +133,13 @@ def test_partition_mesh_halo_plans_are_consistent():
     prob = P.vchannel(5, 4, 7)
     n = prob.mesh.ncells_local
     for nranks in (2, 3, 4):
-        parts = PAR.partition_mesh(prob.mesh, nranks)
+        parts = PAR.partition_mesh(prob.mesh, nranks, mode)
+        assert all(pt.mode == mode for pt in parts)
         owned = np.concatenate([pt.l2g[:pt.nowned] for pt in parts])
         assert np.array_equal(np.sort(owned), np.arange(n))
         nconn_owned_both = 0
         for r, pr in enumerate(parts):
+            assert np.array_equal(pr.l2g[:pr.nowned], np.sort(pr.l2g[:pr.nowned]))       # owned cells in ascending global id
             off = pr.nowned
             for k, q in enumerate(pr.peer):
                 gl = pr.l2g[off:off + pr.recv_count[k]]
@@ -151,6 +154,48 @@ def test_partition_mesh_halo_plans_are_consistent():
             assert (up_owned | dn_owned).all()
             nconn_owned_both += int((up_owned & dn_owned).sum()) * 2 + int((up_owned ^ dn_owned).sum())
         assert nconn_owned_both == 2 * prob.mesh.internal_connections().num_connections
+
+
+def test_partition_mesh_by_default_gives_every_rank_whole_soil_columns():
+    """SURVEY 8(e) / MeshCreateFromCLMCols (src/mpp/dtypes/MeshType.F90:293-460; :362 ncells_ghost = ncols_ghost*nlevgrnd): ranks
+    own x-y blocks of WHOLE columns, ghosts are whole neighbour columns, and the halo of a 7-point nx x ny x nz grid cut in y is
+    nz x nx cells per neighbour (SURVEY.md:381-382: nz*nx*8 B per neighbour per SpMV)"""
+    import numpy as np
+    import problems as P
+    from mpp_amd import parallel as PAR
+    nx, ny, nz = 5, 6, 7
+    prob = P.vchannel(nx, ny, nz)
+    col = PAR.column_of_cells(prob.mesh)
+    ids = np.arange(nx * ny * nz)
+    assert np.array_equal(col, ids % (nx * ny))                  # x-fastest ids: column = (jj, ii), numbered by the lowest cell
+    for nranks in (2, 3, 6):
+        parts = PAR.partition_mesh(prob.mesh, nranks)            # mode "auto": the mesh has vertical connections -> columns
+        rows = ny // nranks
+        for r, pt in enumerate(parts):
+            assert pt.mode == "columns" and pt.ncols_owned == rows * nx and pt.nowned == rows * nx * nz
+            own_cols = np.unique(col[pt.l2g[:pt.nowned]])
+            assert np.array_equal(own_cols, np.arange(r * rows * nx, (r + 1) * rows * nx))          # a contiguous range of jj
+            for c in own_cols:                                    # no column is cut
+                assert np.isin(ids[col == c], pt.l2g[:pt.nowned]).all()
+            ghost_cols = np.unique(col[pt.l2g[pt.nowned:]])
+            for c in ghost_cols:                                  # ghosts are whole columns too
+                assert np.isin(ids[col == c], pt.l2g[pt.nowned:]).all()
+            assert pt.recv_count.tolist() == [nz * nx] * len(pt.peer)
+            assert np.diff(pt.send_ptr).tolist() == [nz * nx] * len(pt.peer)
+            assert pt.peer.tolist() == [q for q in (r - 1, r + 1) if 0 <= q < nranks]
+            # the local numbering of the owned block is again x-fastest: natural-order ILU(0) of a rank = PETSc's on that block
+            jj0 = r * rows
+            kk, rem = np.divmod(pt.l2g[:pt.nowned], nx * ny)
+            assert np.array_equal(np.arange(pt.nowned), kk * rows * nx + (rem - jj0 * nx))
+    # a mesh of independent soil columns (vertical-only): the same call shards the columns, no ghosts
+    cols = P.celia1990(ncols=10, nz=6)
+    for pt in PAR.partition_mesh(cols.mesh, 3):
+        assert pt.nghost == 0 and pt.mode == "columns" and pt.nowned % 6 == 0
+    # no vertical connection at all (the 1-D-in-x MMS meshes): id ranges
+    flat = P.th_mms(12)
+    assert all(pt.mode == "ranges" for pt in PAR.partition_mesh(flat.mesh, 2))
+    with pytest.raises(ValueError):
+        PAR.partition_mesh(prob.mesh, nx * ny + 1)
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -203,6 +248,61 @@ def test_bench_launcher_th_workload_shards_the_columns():
     out = json.loads([l for l in r.stdout.splitlines() if l.strip()][0])
     assert out["workload"] == "th" and out["n_gpus"] == 8 and out["columns"] == 30.0
     assert out["cells"] == 210.0 and out["unknowns"] == 420.0
+
+
+@pytest.mark.parametrize("workload,world", [("vsfm3d", 4), ("vsfm3d", 8), ("th", 4)])
+def test_bench_launcher_3d_workloads_give_every_rank_whole_columns_and_their_ghost_columns(workload, world):
+    """`bench.py --workload vsfm3d --gpus N` / `--workload th --mesh 3d --gpus N` up to, not including, the first GPU call: every rank
+    builds its own x-y block of WHOLE soil columns (workloads.vchannel_rank / th_vchannel_rank: no global mesh) + the neighbours' edge
+    columns as ghosts; the blocks tile the grid, what is sent equals what is received, the halo per neighbour is nz x nx cells
+    (nz * nx * 8 B per neighbour per SpMV), every rank's first column is the first of its rows"""
+    import json
+    nx, ny, nz = 6, 8, 5
+    argv = ["--gpus", str(world), "--dry-run-ranks", "--workload", workload, "--nx", str(nx), "--ny", str(ny), "--nz", str(nz)]
+    if workload == "th":
+        argv += ["--mesh", "3d"]
+    r = _run_bench(*argv)
+    assert r.returncode == 0, r.stderr
+    out = json.loads([l for l in r.stdout.splitlines() if l.strip()][0])
+    assert out["workload"] == workload and out["n_gpus"] == world and out["unique_id_ok"] and out["mesh"] == "3d"
+    assert out["partition"] == "columns"
+    assert out["cells"] == out["owned_cells"] == float(nx * ny * nz) and out["columns"] == float(nx * ny)
+    assert out["ghost_columns"] == float(2 * (world - 1) * nx)
+    assert out["ghost_cells"] == out["halo_values_sent"] == float(2 * (world - 1) * nx * nz)
+    assert out["halo_bytes_per_neighbour_per_exchange"] == float(nz * nx * 8 * (2 if workload == "th" else 1))
+    assert out["first_column_of_rank"] == [float(k * (ny // world) * nx) for k in range(world)]
+    assert out["unknowns"] == float(nx * ny * nz * (2 if workload == "th" else 1))
+
+
+@pytest.mark.parametrize("dims,world", [((5, 4, 6), 2), ((4, 6, 5), 3), ((3, 8, 4), 4), ((5, 5, 4), 2)])
+def test_3d_blocks_built_directly_equal_the_split_of_the_global_problem(dims, world):
+    """workloads.vchannel_rank / th_vchannel_rank (what a rank of `bench.py --workload vsfm3d` / `--workload th --mesh 3d` builds: its
+    rows and ghost rows only) against split_problem / split_th_problem of the whole problem: the same cells in the same order,
+    connections, halo plan, soils, start and sources, array by array ((5, 5, 4) over 2 ranks cuts a row: the generic route is taken)"""
+    def same(a, b):
+        return (a is None and b is None) or (np.asarray(a).shape == np.asarray(b).shape and np.array_equal(np.asarray(a), np.asarray(b)))
+
+    ref = P.split_problem(P.vchannel(*dims), world)
+    tref = P.split_th_problem(P.th_vchannel(*dims), world)
+    for rank in range(world):
+        part, lp = P.vchannel_rank(*dims, world, rank)
+        tpart, tlp = P.th_vchannel_rank(*dims, world, rank)
+        rpart, rlp = ref[rank]
+        assert part.nghost == rpart.nghost and same(part.l2g, rpart.l2g) and same(tpart.l2g, rpart.l2g)
+        assert part.mode == rpart.mode == "columns" and part.ncols_owned == rpart.ncols_owned
+        for f in ("peer", "send_ptr", "send_cells", "recv_count"):
+            assert same(getattr(part, f), getattr(rpart, f)), f
+        for f in ("x", "y", "z", "dx", "dy", "dz", "area_xy", "vol", "is_active"):
+            assert same(getattr(lp.mesh, f), getattr(rlp.mesh, f)), f
+        a, b = lp.mesh.internal_connections(), rlp.mesh.internal_connections()
+        for f in ("id_up", "id_dn", "dist_up", "dist_dn", "area", "unit_vec", "itype"):
+            assert same(getattr(a, f), getattr(b, f)), f
+        for f in ("perm", "por", "alpha", "lam", "sat_res", "press_ic", "satfunc_type"):
+            assert same(getattr(lp, f), getattr(rlp, f)), f
+        for f in ("perm", "por", "press_ic", "temp_ic", "heat_cap", "tcond_wet", "tcond_dry", "talpha", "den_soil"):
+            assert same(getattr(tlp, f), getattr(tref[rank][1], f)), f
+        (t1, c1, v1), (t2, c2, v2) = tlp.energy_sss[0], tref[rank][1].energy_sss[0]
+        assert t1 == t2 and same(v1, v2) and same(c1.id_dn, c2.id_dn)
 
 
 @pytest.mark.parametrize("dims,world", [((5, 4, 6), 2), ((5, 4, 6), 3), ((7, 3, 8), 4), ((6, 5, 9), 3), ((4, 3, 5), 2)])
