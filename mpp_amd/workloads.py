@@ -40,6 +40,7 @@ class Problem:
     sink_exponent: np.ndarray = None
     dt: float = 3600.0
     nstep: int = 1
+    exact: np.ndarray = None                  # manufactured solution at the cell centres (vsfm_mms)
 
 
 def clm_soil_conversion(perm, alpha, lam, sucsat_grav):
@@ -251,6 +252,62 @@ def vchannel_operator_split(nx=6, ny=5, nz=7) -> Problem:
     allcells = M.ConnectionSet(np.full(n, -1), np.arange(1, n + 1), z, z, np.ones(n), np.zeros((n, 3)))
     prob.sss = [(C.COND_MASS_RATE, allcells, np.zeros(n))]
     prob.name = "vsfm_vchannel_operator_split"
+    return prob
+
+
+def vsfm_mms(nx=20, fully_saturated=False) -> Problem:
+    """src/driver/standalone/vsfm/vsfm_mms_problem.F90 + vsfm_mms_steady_state_soil_only_1D.F90: the reference's analytic check of
+    the VSFM that does not depend on PETSc -- a steady 1-D horizontal column x in [0, 10] m of nx cells (ny = nz = 1, so no gravity
+    term along the connections), porosity 0 (no accumulation), manufactured pressure
+    P(x) = 15000 sin(pi x / 10) - 20000 + 101325 (:52-60; `fully_saturated`: + 20000), permeability
+    k(x) = 1e-11 (2 + cos(pi x / 10)) (:74-75), van Genuchten alpha = 1/4000, m = 1/2, residual saturation 1/2 (:89-121),
+    DENSITY_TGDPB01, Dirichlet ends at x = 0 and 10 (ComputeBoundaryDomainConnection: dist_up 0, dist_dn dx/2, unit vectors +-x),
+    mass source = -d/dx(rho k kr / mu dP/dx) dx per cell (DATA_MASS_SOURCE :263-302, the constitutive laws called on the host as
+    the driver calls Density / SatFunc_* there), start = the mean of the manufactured pressures (:196-203), one StepDT(1.0)
+    (vsfm_mms_problem.F90:97-102).  The per-cell-array setters VSFMMPPSetSoilPorosity / Permeability / SaturationFunction /
+    DensityType (:405-418) are what to_gpu calls.  `exact` = P at the cell centres (DATA_PRESSURE)."""
+    from mpp_amd import laws as L
+    pi = 4.0 * np.arctan(1.0)
+    x_min, x_max = 0.0, 10.0
+    xlim = x_max - x_min
+    m = M.mesh_create("Soil mesh", x_max, 1.0, 1.0, nx, 1, 1, C.CONN_IN_XYZ_DIR, x_min=x_min)
+    n = m.ncells_local
+    dx = (x_max - x_min) / nx
+    xc = np.asarray(m.x)
+    a0, a1 = 15000.0, -20000.0
+
+    def pres(x):      # compute_pressure_or_deriv :43-63
+        val = a0 * np.sin((x - x_min) / xlim * pi) + (-a1 if fully_saturated else a1) + C.PRESSURE_REF
+        return val, a0 * pi / xlim * np.cos((x - x_min) / xlim * pi), -a0 * pi * pi / xlim / xlim * np.sin((x - x_min) / xlim * pi)
+
+    def permf(x):     # compute_permeability_or_deriv :66-79
+        p0 = 1e-11
+        return p0 * (2.0 + np.cos((x - x_min) / xlim * pi)), p0 * pi / xlim * (-np.sin((x - x_min) / xlim * pi))
+
+    alpha0, lam0, sr0 = 1.0 / 4000.0, 0.5, 0.5
+    mu = 8.904156e-4                                                       # Viscosity (EOSWaterMod.F90:582)
+    k, dk_dx = permf(xc)
+    P, dP_dx, d2P_dx2 = pres(xc)
+    den, dden_dP, _ = L.density(P, 298.15, C.DENSITY_TGDPB01)
+    rho, drho_dP = den * C.FMWH2O, dden_dP * C.FMWH2O
+    _se, _dse_dP, kr, dkr_dP = L.sat_relperm(P, C.SAT_FUNC_VAN_GENUCHTEN, sr0, alpha0, lam0)
+    dkr_dx = dkr_dP * dP_dx                                                # (dse_dp0 = 0: alpha does not vary)
+    drho_dx = drho_dP * dP_dx
+    src = (-((k * kr / mu) * drho_dx + (rho * kr / mu) * dk_dx + (rho * k / mu) * dkr_dx) * dP_dx - (rho * k * kr / mu) * d2P_dx2) * dx
+    P0 = 0.0
+    for i in range(n):                                                     # DATA_INITIAL_PRESSURE: running mean, same summation order
+        P0 = P0 + 1.0 / nx * P[i]
+    pres_bc = np.array([pres(xc[0] - dx / 2.0)[0], pres(xc[-1] + dx / 2.0)[0]])
+    ends = M.ConnectionSet(np.array([0, 0]), np.array([1, nx]), np.zeros(2), np.full(2, dx / 2.0), np.full(2, 1.0 * 1.0),
+                           np.array([[1.0, 0.0, 0.0], [-1.0, 0.0, 0.0]]))      # ComputeXBoundaryDomainConnection (mpp_mesh_utils.F90:783-812)
+    z = np.zeros(n)
+    allcells = M.ConnectionSet(np.full(n, -1), np.arange(1, n + 1), z, z, np.ones(n), np.zeros((n, 3)))
+    prob = Problem(
+        name="vsfm_mms", mesh=m, perm=np.stack([k] * 3, axis=1), por=np.zeros(n),
+        satfunc_type=np.full(n, C.SAT_FUNC_VAN_GENUCHTEN, dtype=np.int32), alpha=np.full(n, alpha0), lam=np.full(n, lam0),
+        sat_res=np.full(n, sr0), density_type=C.DENSITY_TGDPB01, press_ic=np.full(n, P0),
+        bcs=[(C.COND_DIRICHLET, ends, pres_bc)], sss=[(C.COND_MASS_RATE, allcells, src)], dt=1.0, nstep=1)
+    prob.exact = P
     return prob
 
 

@@ -204,3 +204,60 @@ def th_mms(nx=20) -> THProblem:
         mass_bcs=[(C.COND_DIRICHLET, ends, pres_bc, temp_bc)], mass_sss=[(C.COND_MASS_RATE, allcells, mass_src)],
         energy_bcs=[(C.COND_DIRICHLET, ends, temp_bc, pres_bc)], energy_sss=[(C.COND_HEAT_RATE, allcells, heat_src)],
         dt=1.0, nstep=1)
+
+
+def vsfm_mms(nx=20, fully_saturated=False) -> Problem:
+    """src/driver/standalone/vsfm/vsfm_mms_problem.F90 + vsfm_mms_steady_state_soil_only_1D.F90 (STEADY_STATE_SOIL_ONLY_1D), built
+    with the ORACLE's constitutive laws (the product's builder, mpp_amd.workloads.vsfm_mms, uses the library's host laws: the two
+    are compared input by input in tests/test_oracle_vsfm_mms.py): steady 1-D horizontal column x in [0, 10], porosity 0,
+    P(x) = 15000 sin(pi x / 10) -+ 20000 + 101325 (:52-60), k(x) = 1e-11 (2 + cos(pi x / 10)) (:74-75), van Genuchten
+    alpha = 1/4000, m = 1/2, sr = 1/2 (:89-121), TGDPB01, Dirichlet ends, mass source -d/dx(rho k kr / mu dP/dx) dx (:263-302)."""
+    from oracle import vsfm_oracle as VO
+    pi = 4.0 * np.arctan(1.0)
+    x_min, x_max = 0.0, 10.0
+    xlim = x_max - x_min
+    dx = (x_max - x_min) / nx
+    m = M.mesh_create("Soil mesh", x_max, 1.0, 1.0, nx, 1, 1, C.CONN_IN_XYZ_DIR, x_min=x_min)
+    n = m.ncells_local
+    xc = m.x
+    FMW = 18.01534
+    a0, a1 = 15000.0, -20000.0
+    alpha0, lam0, sr0 = 1.0 / 4000.0, 0.5, 0.5
+    mu = 8.904156e-4
+
+    def pres(x):
+        s, c = np.sin((x - x_min) / xlim * pi), np.cos((x - x_min) / xlim * pi)
+        return a0 * s + (-a1 if fully_saturated else a1) + 101325.0, a0 * pi / xlim * c, -a0 * pi * pi / xlim / xlim * s
+
+    def permf(x):
+        p0 = 1e-11
+        return p0 * (2.0 + np.cos((x - x_min) / xlim * pi)), p0 * pi / xlim * (-np.sin((x - x_min) / xlim * pi))
+
+    src, P_all, perm = np.zeros(n), np.zeros(n), np.zeros(n)
+    for i in range(n):
+        x = xc[i]
+        k, dk_dx = permf(x)
+        P, dP_dx, d2P_dx2 = pres(x)
+        den, ddp, _ddt = VO.density(P, 298.15, C.DENSITY_TGDPB01)
+        rho, drho_dP = den * FMW, ddp * FMW
+        a = VO.auxvar_compute(C.SAT_FUNC_VAN_GENUCHTEN, sr0, alpha0, lam0, 0.0, C.DENSITY_TGDPB01, P)
+        kr, dkr_dP = a["kr"], a["dkr_dP"]
+        dkr_dx = dkr_dP * dP_dx
+        drho_dx = drho_dP * dP_dx
+        src[i] = (-((k * kr / mu) * drho_dx + (rho * kr / mu) * dk_dx + (rho * k / mu) * dkr_dx) * dP_dx - (rho * k * kr / mu) * d2P_dx2) * dx
+        P_all[i], perm[i] = P, k
+    P0 = 0.0
+    for i in range(n):
+        P0 = P0 + 1.0 / nx * P_all[i]
+    pres_bc = np.array([pres(xc[0] - dx / 2.0)[0], pres(xc[-1] + dx / 2.0)[0]])
+    ends = M.ConnectionSet(np.array([0, 0]), np.array([1, nx]), np.zeros(2), np.full(2, dx / 2.0), np.full(2, 1.0 * 1.0),
+                           np.array([[1.0, 0.0, 0.0], [-1.0, 0.0, 0.0]]))
+    z = np.zeros(n)
+    allcells = M.ConnectionSet(np.full(n, -1), np.arange(1, n + 1), z, z, np.ones(n), np.zeros((n, 3)))
+    prob = Problem(
+        name="vsfm_mms", mesh=m, perm=np.stack([perm] * 3, axis=1), por=np.zeros(n),
+        satfunc_type=np.full(n, C.SAT_FUNC_VAN_GENUCHTEN, dtype=np.int32), alpha=np.full(n, alpha0), lam=np.full(n, lam0),
+        sat_res=np.full(n, sr0), density_type=C.DENSITY_TGDPB01, press_ic=np.full(n, P0),
+        bcs=[(C.COND_DIRICHLET, ends, pres_bc)], sss=[(C.COND_MASS_RATE, allcells, src)], dt=1.0, nstep=1)
+    prob.exact = P_all
+    return prob

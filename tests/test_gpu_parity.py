@@ -365,3 +365,69 @@ def test_elm_surface_frac_liq_sat_and_exchanged_mass(golden_dir):
     l_g = g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_LATERAL_MASS_EXCHANGED)
     assert np.abs(l_g).max() > 0 and abs(l_g.sum()) <= 1e-10 * np.abs(l_g).sum()
     assert np.abs(l_g - l_o).max() <= 1e-7 * np.abs(l_o).max()
+
+
+@pytest.mark.parametrize("sat", [False, True])
+def test_vsfm_mms_analytic_check_through_the_abi(sat):
+    """vsfm_mms (src/driver/standalone/vsfm/vsfm_mms_problem.F90:97-102: PreStepDT, sources, boundary values, one StepDT(1.0)) through
+    the per-cell-array setters (:405-418): the library against the oracle at nx = 20 (operators, Newton count, pressures), then the
+    discretisation error against P(x) = 15000 sin(pi x / 10) -+ 20000 + 101325 over nx = 20, 40, 80, 160 -- second order on the
+    -fully_saturated branch, first order with the upwinded relative permeability of the default branch (RichardsMod.F90:289-293;
+    tests/test_oracle_vsfm_mms.py has the oracle's own numbers)"""
+    from oracle import adapters as A
+    prob = P.vsfm_mms(20, sat)
+    x = prob.exact + np.random.default_rng(3).uniform(-3e3, 3e3, prob.exact.size)
+    _operator_parity(prob, x, {})
+    o = A.to_oracle(A.vsfm_mms(20, sat), with_blocks=False)
+    g = P.to_gpu(prob)
+    o.pre_step_dt(); g.soe.PreStepDT()
+    assert g.soe.StepDT(prob.dt, 1) == tuple(o.step_dt(prob.dt, 1))
+    assert g.soe.counters()["newton"] == o.counters()["newton"]
+    pg, po = g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1), o.get(C.AUXVAR_INTERNAL, C.VAR_PRESSURE)
+    assert np.abs(pg - po).max() <= RTOL_E2E * np.abs(po).max()
+    sg, so = g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_LIQ_SAT, -1), o.get(C.AUXVAR_INTERNAL, C.VAR_LIQ_SAT)
+    assert np.abs(sg - so).max() <= 1e-9
+    errs = []
+    for nx in (20, 40, 80, 160):
+        pr = P.vsfm_mms(nx, sat)
+        h = P.to_gpu(pr, {"snes_rtol": 1e-12, "snes_stol": 1e-13, "ksp_rtol": 1e-12})
+        h.soe.PreStepDT()
+        conv, reason = h.soe.StepDT(pr.dt, 1)
+        assert conv and reason > 0
+        errs.append(float(np.abs(h.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1) - pr.exact).max()))
+    lo, hi = (3.9, 4.1) if sat else (1.9, 2.1)
+    assert all(lo < a / b < hi for a, b in zip(errs, errs[1:])), errs
+    assert errs[0] < (40.0 if sat else 1000.0), errs
+
+
+def test_vsfm_mms_many_columns_side_by_side():
+    """the manufactured column replicated as rows of a 2-D mesh (nx x ny, connections along x only inside a row plus y connections
+    between rows that carry no flux: every row holds the same manufactured state) -- the general-assembly route at a size where
+    kernels run more than one block; every row reproduces the single column's answer"""
+    nx, ny = 40, 70
+    one = P.vsfm_mms(nx)
+    g1 = P.to_gpu(one, {"snes_rtol": 1e-12, "snes_stol": 1e-13, "ksp_rtol": 1e-12})
+    g1.soe.PreStepDT()
+    assert g1.soe.StepDT(one.dt, 1)[0]
+    p1 = g1.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1)
+    from mpp_amd import mesh as M
+    m = M.mesh_create("Soil mesh", 10.0, float(ny), 1.0, nx, ny, 1, C.CONN_IN_XYZ_DIR)
+    n = m.ncells_local
+    tile = lambda a: np.tile(np.asarray(a), ny)
+    cells_lo, cells_hi = np.arange(ny) * nx + 1, np.arange(ny) * nx + nx
+    dxh = 10.0 / nx / 2.0
+    uv = np.zeros((2 * ny, 3)); uv[:ny, 0] = 1.0; uv[ny:, 0] = -1.0
+    ends = M.ConnectionSet(np.zeros(2 * ny, dtype=np.int64), np.concatenate([cells_lo, cells_hi]), np.zeros(2 * ny), np.full(2 * ny, dxh),
+                           np.ones(2 * ny), uv)
+    _t, _cs, bcv = one.bcs[0]
+    z = np.zeros(n)
+    allcells = M.ConnectionSet(np.full(n, -1), np.arange(1, n + 1), z, z, np.ones(n), np.zeros((n, 3)))
+    prob = P.Problem(name="vsfm_mms_rows", mesh=m, perm=np.tile(one.perm, (ny, 1)), por=np.zeros(n), satfunc_type=tile(one.satfunc_type),
+                     alpha=tile(one.alpha), lam=tile(one.lam), sat_res=tile(one.sat_res), density_type=one.density_type,
+                     press_ic=tile(one.press_ic), bcs=[(C.COND_DIRICHLET, ends, np.concatenate([np.full(ny, bcv[0]), np.full(ny, bcv[1])]))],
+                     sss=[(C.COND_MASS_RATE, allcells, tile(one.sss[0][2]))], dt=1.0, nstep=1)
+    g = P.to_gpu(prob, {"snes_rtol": 1e-12, "snes_stol": 1e-13, "ksp_rtol": 1e-12})
+    g.soe.PreStepDT()
+    assert g.soe.StepDT(prob.dt, 1)[0]
+    p = g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1).reshape(ny, nx)
+    assert np.abs(p - p1[None, :]).max() <= 1e-8 * np.abs(p1).max()
