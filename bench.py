@@ -442,6 +442,26 @@ def extra_config(label, nx, ny, nz, elm_default, steps, warmup, opts, device_id)
         soe.close()
 
 
+def extra_vsfm3d(nx, ny, nz, steps, warmup, ksp, pc, device_id):
+    """The 7-point VSFM grid (SURVEY 8d's 3-D variant: v-channel soil and geometry) behind the headline's timed region (N = 1): the one
+    VSFM workload where BiCGStab runs tens of iterations per Newton step, i.e. where the CSR SpMV proper -- values + index + gathered
+    x, y written -- is the hot loop; its `roofline` is that kernel inside this run's own timed region (vsfm3d_measure)."""
+    from mpp_amd import workloads as P
+    t0 = time.perf_counter()
+    part, prob = P.vchannel_rank(nx, ny, nz, 1, 0)
+    g = P.to_gpu(prob, {"ksp_type": ksp, "pc_type": pc}, device_id=device_id)
+    t_setup = time.perf_counter() - t0
+    try:
+        m = vsfm3d_measure(g.soe, prob, steps, warmup, nx, ny, nz, part.nowned)
+        layout = g.soe.assembly_info()
+        m.update({"config": "vsfm3d: VSFM v-channel 7-point grid %dx%dx%d, %s+%s" % (nx, ny, nz, ksp, pc), "cells": nx * ny * nz,
+                  "setup_s": round(t_setup, 2), "spmv_variant": layout["spmv_variant"],
+                  "columns_plus_lateral_assembly": bool(layout.get("columns_plus_lateral_assembly"))})
+        return m
+    finally:
+        g.soe.close()
+
+
 def pick_device(args, local_rank):
     if not args.share_gpus:
         return local_rank
@@ -932,7 +952,10 @@ def main():
             plain_spmv = {"error": repr(e)}
 
     # rank-local SpMV of every rank (the roofline kernel): average launch time, gathered on the host
-    sp = stats["spmv"]
+    # (round 5: where every line search took its sums from the Krylov solve's own kernels -- option ls_fold -- no product launch is left
+    # in the timed region by itself: the roofline kernel is then the fused product + column solve, kernels.spmv_pc)
+    folded = stats["spmv"]["launches"] == 0 and stats["spmv_pc"]["launches"] > 0
+    sp = stats["spmv_pc"] if folded else stats["spmv"]
     avg_ms = sp["total_ms"] / max(sp["launches"], 1)
     all_ms = group.allreduce([avg_ms if r == rank else 0.0 for r in range(world)], op="sum")
     all_bytes = group.allreduce([sp["bytes_per_launch"] if r == rank else 0.0 for r in range(world)], op="sum")
@@ -956,7 +979,7 @@ def main():
                     stale = "kernel sources changed since the PMC passes (%s then, %s now)" % (tj.get("kernel_source_sha16"), kernel_source_hash())
                 else:
                     moved = tj.get("classes", {})
-                    traffic = moved.get("spmv", {}).get("hbm_bytes_per_launch")
+                    traffic = moved.get("spmv_pc" if folded else "spmv", {}).get("hbm_bytes_per_launch")
                     traffic_src = "profiles/kernel_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, %s; kernel sources %s)" % (
                         tj.get("run"), tj.get("kernel_source_sha16"))
             except Exception as e:
@@ -983,7 +1006,15 @@ def main():
                         kernels[k]["structure_exploited"] = True
         fused = stats["spmv_pc"]["launches"] > 0
         index_free = bool(layout.get("line_search_product_index_free"))
-        if fused and index_free:
+        if folded:
+            kernel_txt = ("csr_spmv_fp64 fused with the column solve, as the timed region runs it: t = M^-1 (A v) in one kernel per product of a "
+                          "BiCGStab iteration (k_tri_solve_lds<.., SPMV>: the CSR VALUES of the column tridiagonals read at their computed places, "
+                          "row sums in the CSR kernels' order, A v never written; DESIGN.md section 4), with the Krylov dot products and -- "
+                          "round 5, ls_fold -- the line search's F.(J p), F.(J s) reduced on the way, so that no product launch of the search's "
+                          "own is left in the timed region.  `achieved` / `frac`: that kernel pair's own byte model; plain_spmv_kernel = k_spmv_c "
+                          "(values + compact 16-bit index, y written) timed right behind the region; the CSR kernel inside a timed region of "
+                          "its own: extra_configs[vsfm3d].roofline")
+        elif fused and index_free:
             kernel_txt = ("csr_spmv_fp64 as the timed region runs it: the line search's product J Y with x.x, f.(A x), ||x|| reduced on the way "
                           "and A x not written (the two products of a BiCGStab iteration run fused with the column solve: kernels.spmv_pc, "
                           "DESIGN.md section 4).  On this soil-column grid it is k_spmv_cols_dots: the CSR VALUES read at their computed places, "
@@ -1002,15 +1033,26 @@ def main():
         # index-free product (no column index, no row pointer, A x not written) the byte model is that kernel's own --
         # values 8 nnz + x 8 N + f 8 N, plus X for ||X|| on the first launch of a time step (not counted) -- and SURVEY 8(d)'s CSR
         # count over the same time is reported beside it as achieved_algorithmic (it can exceed the peak: that kernel moves less)
-        csr_bytes = float(sp["bytes_per_launch"])                       # 12 nnz + 20 N + 4
+        csr_bytes = float(stats["spmv"]["bytes_per_launch"])           # 12 nnz + 20 N + 4
         nnz_local = (csr_bytes - 20.0 * n_local - 4.0) / 12.0
-        own_bytes = 8.0 * nnz_local + 16.0 * n_local if index_free else csr_bytes
+        if folded:
+            # the two kernels of an iteration, averaged: values 8 nnz; first kernel d, c, 1/pivot in, x out, then F in, c, 1/pivot, x again,
+            # z out = 72 N; second kernel r, v, F in, s out, c, 1/pivot, s again, z out = 64 N
+            own_bytes = 8.0 * nnz_local + 68.0 * n_local
+            csr_bytes = float(sp["bytes_per_launch"])                   # SURVEY's count of the SpMV + PCApply pair it replaces
+        else:
+            own_bytes = 8.0 * nnz_local + 16.0 * n_local if index_free else csr_bytes
         achieved_alg = achieved
         achieved = own_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         roof = {"kernel": kernel_txt,
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(min(achieved / HBM_PEAK_GBS, 1.0), 4), "traffic": traffic,
-                "achieved_is": (("the timed kernel's own byte model (index-free launches: values 8 nnz + x 8 N + f 8 N; no column index, no row "
+                "achieved_is": ("the timed kernels' own byte model, averaged over the two fused kernels of a BiCGStab iteration: values 8 nnz + "
+                                "68 N (first: d, c, 1/pivot in, x out, F in, c, 1/pivot, x again, z out; second: r, v, F in, s out, c, 1/pivot, s "
+                                "again, z out) / HIP-event average launch time of those launches inside the timed region.  achieved_algorithmic = "
+                                "SURVEY 8(d)'s count of the CSR SpMV + PCApply pair each launch replaces (12 nnz + 60 N + 4) over the same time")
+                               if folded else
+                               (("the timed kernel's own byte model (index-free launches: values 8 nnz + x 8 N + f 8 N; no column index, no row "
                                  "pointer, A x not written) / HIP-event average launch time of those launches inside the timed region.  "
                                  "achieved_algorithmic = SURVEY 8(d)'s CSR count (12 nnz + 20 N + 4) over the same time -- a rate the CSR kernel "
                                  "would have had to reach, not bytes this kernel moves.  The CSR kernel proper (values + index + y written) is "
@@ -1022,12 +1064,15 @@ def main():
                                  "for ||X|| (8 N more, not counted).  plain_spmv_kernel = the kernel that does write y, timed right behind the region"))
                                if fused else "algorithmic CSR bytes (12 nnz + 20 N + 4, SURVEY 8d) / HIP-event average launch time",
                 "bytes_per_launch": own_bytes, "avg_launch_ms": round(avg_ms, 5), "launches_timed": sp["launches"]}
-        if index_free:
+        if index_free or folded:
             roof["achieved_algorithmic"] = round(achieved_alg, 1)
             roof["bytes_per_launch_csr_count"] = csr_bytes
+        if folded:
+            roof["roofline_kernel_class"] = "spmv_pc"
+            roof["line_search_sums_folded"] = layout.get("line_search_sums_folded")
         if plain_spmv:
             roof["plain_spmv_kernel"] = plain_spmv
-        if index_free:
+        if index_free or folded:
             roof["structure_exploited"] = True
         if stale:
             roof["traffic_refused"] = stale
@@ -1090,6 +1135,11 @@ def main():
                 extras.append(extra_config(label, dims[0], dims[1], dims[2], elm, 3 if big else 8, 1 if big else 2, opts, pick_device(args, local_rank)))
             except Exception as e:   # never hides the headline
                 extras.append({"config": label, "error": repr(e)})
+        try:
+            sys.stderr.write("bench.py: extra configuration: 7-point VSFM grid 512x512x100 ...\n"); sys.stderr.flush()
+            extras.append(extra_vsfm3d(512, 512, 100, 2, 1, args.ksp, args.pc, pick_device(args, local_rank)))
+        except Exception as e:
+            extras.append({"config": "vsfm3d", "error": repr(e)})
         out["extra_configs"] = extras
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:   # the CPU baseline is reported at N = 1 only

@@ -334,7 +334,10 @@ int mppgpu_get_pc_info(mppgpu_handle h, int *path, int *launches, int *box_exten
  * mppgpu_setup, [8] the level / box launches of the ILU(0) solves are replayed from hipGraphs (option ilu_graph), [9] graphs
  * instantiated for them so far, [10] set-up structures built on the device that option setup_verify found equal to the host-built
  * ones, [11] the line search's product J Y (with its sums) is formed from the column tridiagonals at their computed places, without an
- * index (soil-column grids).  n = entries of info the caller provides (at most 12 are written). */
+ * index (soil-column grids), [12] line searches since mppgpu_setup whose F . (J Y) and ||Y|| came out of the kernels of the Krylov solve
+ * that produced Y (one-iteration BiCGStab solves on soil-column grids, option ls_fold) instead of a product pass of their own, [13] the
+ * assembly of a 3-D mesh of complete soil columns runs as column march + lateral pass (option assembly, round 5).  n = entries of info
+ * the caller provides (at most 14 are written). */
 int mppgpu_get_assembly_info(mppgpu_handle h, int n, int *info);
 /* device-resident micro-benchmark of one kernel class on the current state: `reps` launches, average ms */
 int mppgpu_bench_kernel(mppgpu_handle h, const char *name, int variant, int reps, double *avg_ms,

@@ -272,10 +272,16 @@ __global__ __launch_bounds__(kBlock) void k_assemble_cols(ColsArgs a) {
       if (JAC) {
         double di = dconn_prev + dacc_prev;
         if (FUSE && js >= 0) di += bc_inline ? (kp == 0 ? sD0 : sD1) : a.side_d[js];
-        int slot = row_slot(kp);
-        if (kp > 0) a.val[slot++] = lo_prev;
-        a.val[slot++] = di;
-        if (!last) a.val[slot] = up_prev;
+        if (a.slot_di) {   // 7-point rows: the column's tridiagonal at its CSR slots (the lateral pass adds to the diagonal afterwards)
+          if (kp > 0) a.val[a.slot_lo[ip]] = lo_prev;
+          a.val[a.slot_di[ip]] = di;
+          if (!last) a.val[a.slot_up[ip]] = up_prev;
+        } else {
+          int slot = row_slot(kp);
+          if (kp > 0) a.val[slot++] = lo_prev;
+          a.val[slot++] = di;
+          if (!last) a.val[slot] = up_prev;
+        }
         if (factor) {
           const double l = lo_prev * inv_pp;
           const double piv = fma(-l, c_pp, di);   // (written as the fma it is: k_tri_solve_lds recomputes l and must round alike)
@@ -365,6 +371,10 @@ __global__ __launch_bounds__(kBlock) void k_assemble_cols(ColsArgs a) {
           if (SAT_T == kSatSBC) { s.pu = t[3 * nc]; s.ps = t[4 * nc]; s.b2 = t[5 * nc]; s.b3 = t[6 * nc]; }
         }
         cur = auxvar_compute<JAC, SAT_T, DEN_T>(L.sf, ca.eos, s, Pi, L.frac, pt);
+        if (!FUSE && a.aux.kr && owned) {   // for the lateral pass of a 3-D mesh (k_flux_rows_ell<.., LAT>)
+          a.aux.kr[i] = cur.kr; a.aux.den[i] = cur.den;
+          if (JAC) { a.aux.dkr[i] = cur.dkr; a.aux.dden[i] = cur.dden; }
+        }
         if (owned) {
           const double vol = L.vol;
           if (lin_por) {
@@ -377,6 +387,10 @@ __global__ __launch_bounds__(kBlock) void k_assemble_cols(ColsArgs a) {
             if (JAC) dacc_cur = (s.por * cur.dden * cur.sat + s.por * cur.den * cur.dsat) * vol * a.dtInv;
           }
         }
+      }
+      if (!FUSE && a.aux.kr && owned && !act) {   // (k_auxvars leaves zeros for an inactive cell)
+        a.aux.kr[i] = 0.0; a.aux.den[i] = 0.0;
+        if (JAC) { a.aux.dkr[i] = 0.0; a.aux.dden[i] = 0.0; }
       }
       if (RES && owned) f_cur = f_cur - L.accp;
       double dconn_cur = 0.0, lo_cur = 0.0;
@@ -515,7 +529,9 @@ __global__ __launch_bounds__(kBlock) void k_flux_rows(GenArgs a) {
 // connection order, -1 when the row has fewer): every index a row needs arrives with one coalesced load, so the loads of
 // all its neighbours are in flight together instead of a chain of dependent look-ups per connection; off-diagonal entries
 // are stored once (every pattern entry of a row belongs to exactly one incident connection: checked at set-up).
-template <int MODE, int K>
+// LAT (round 5): the lateral half of a 3-D mesh of complete soil columns -- the column march has done the accumulation term and the
+// chain links (connection index < n in the internal numbering) and left the auxvars; those entries of the lists are skipped here.
+template <int MODE, int K, bool LAT = false>
 __global__ __launch_bounds__(kBlock) void k_flux_rows_ell(GenArgs a) {
   constexpr bool RES = (MODE == 0 || MODE == 2), JAC = (MODE == 1 || MODE == 2);
   const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
@@ -526,6 +542,7 @@ __global__ __launch_bounds__(kBlock) void k_flux_rows_ell(GenArgs a) {
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     enc[k] = k < a.ell_k ? a.ell_enc[k * n + i] : -1;
+    if (LAT && enc[k] >= 0 && (enc[k] >> 1) < a.n) enc[k] = -1;   // a chain link: the march's
     oth[k] = enc[k] >= 0 ? a.ell_o[k * n + i] : (int)i;
     slot[k] = (JAC && enc[k] >= 0) ? a.ell_slot[k * n + i] : -1;
   }
@@ -2262,7 +2279,8 @@ inline int red_grid(int n) {
 // x <- alpha p + omega s + x ; r <- s - omega t ; partial sums of r.r   (bcgs.c)
 // FIRST: x is known to be zero (first iteration, zero initial guess) and is not read.  Later iterations also reduce
 // (r,rp), the next iteration's rho, while r is in registers (partials row 1).
-template <bool FIRST>
+// XX (with FIRST): the partial sums of x.x as well, in row 1 -- the line search's ||Y||^2 when the solve ends with this iteration
+template <bool FIRST, bool XX = false>
 __global__ __launch_bounds__(kBlock) void k_bcgs_xr(int n, double *X, double *R, const double *P, const double *S,
                                                     const double *T, const double *RP, const double *sc, double *partials) {
   __shared__ double lds[kBlock / 64];
@@ -2270,7 +2288,9 @@ __global__ __launch_bounds__(kBlock) void k_bcgs_xr(int n, double *X, double *R,
   double acc = 0.0, acc2 = 0.0;
   vec2_loop(n, [&](size_t q) {
               const double2 s = CD2(S)[q], p = CD2(P)[q], t = CD2(T)[q], x = FIRST ? make_double2(0.0, 0.0) : CD2(X)[q];
-              D2(X)[q] = make_double2(alpha * p.x + omega * s.x + x.x, alpha * p.y + omega * s.y + x.y);
+              const double2 xn = make_double2(alpha * p.x + omega * s.x + x.x, alpha * p.y + omega * s.y + x.y);
+              D2(X)[q] = xn;
+              if (XX) { acc2 += xn.x * xn.x; acc2 += xn.y * xn.y; }
               const double r0 = s.x - omega * t.x, r1 = s.y - omega * t.y;
               if (R) D2(R)[q] = make_double2(r0, r1);   // (R == nullptr: only ||r|| is wanted -- the solve is expected to end here)
               acc += r0 * r0;
@@ -2278,7 +2298,9 @@ __global__ __launch_bounds__(kBlock) void k_bcgs_xr(int n, double *X, double *R,
               if (!FIRST) { const double2 rp = CD2(RP)[q]; acc2 += r0 * rp.x; acc2 += r1 * rp.y; }
             }, [&](size_t i) {
               const double s = S[i];
-              X[i] = alpha * P[i] + omega * s + (FIRST ? 0.0 : X[i]);
+              const double xn = alpha * P[i] + omega * s + (FIRST ? 0.0 : X[i]);
+              X[i] = xn;
+              if (XX) acc2 += xn * xn;
               const double r = s - omega * T[i];
               if (R) R[i] = r;
               acc += r * r;
@@ -2286,7 +2308,7 @@ __global__ __launch_bounds__(kBlock) void k_bcgs_xr(int n, double *X, double *R,
             });
   double t = block_sum(acc, lds);
   if (threadIdx.x == 0) partials[blockIdx.x] = t;
-  if (!FIRST) {
+  if (!FIRST || XX) {
     t = block_sum(acc2, lds);
     if (threadIdx.x == 0) partials[(size_t)gridDim.x + blockIdx.x] = t;
   }
@@ -2353,11 +2375,15 @@ __global__ __launch_bounds__(kBlock) void k_tri_solve_dots(TriArgs a, const doub
 // x taken from the slab: the start of a BiCGStab solve (rp = M^{-1} F, v = M^{-1} A rp) in one kernel, with (z,x), (z,z), (x,x).
 // SPMV == 3: x = r + a v with a = -sc[S_ALPHA] (BiCGStab's s = r - alpha v, VecWAXPY) is formed on the way, written to `xout`, and is
 // also the w of the dot products: the second half of a BiCGStab iteration's products -- s, t = M^{-1} A s, (t,s), (t,t) -- in one kernel.
-template <int ND, int G, int RF, int RB, int SPMV>
+// FDOT (round 5, with SPMV): the partial sums of fdot . (A x) as well -- row k's sum is in a register when the sweep eliminates it,
+// so the line search's F . (J Y) of a one-iteration BiCGStab solve (Y = alpha p + omega s) costs one more 8-byte stream in the two
+// kernels that form J p and J s instead of a product pass of its own; partial sums in row ND (+ 1 with SPMV == 2) of `partials`.
+template <int ND, int G, int RF, int RB, int SPMV, bool FDOT = false>
 __global__ __launch_bounds__(64) void k_tri_solve_lds(TriArgs a, const double *__restrict__ r, double *__restrict__ z,
                                                       const double *__restrict__ w, double *__restrict__ partials,
                                                       double *__restrict__ scratch64, double *__restrict__ xout,
-                                                      const double *__restrict__ vsub, const double *__restrict__ sc, Fold fold) {
+                                                      const double *__restrict__ vsub, const double *__restrict__ sc, Fold fold,
+                                                      const double *__restrict__ fdot = nullptr) {
   extern __shared__ __attribute__((aligned(16))) double dsl[];   // [nz][64]
   const int lane = threadIdx.x, tile = blockIdx.x;
   const int nz = a.nz;
@@ -2366,7 +2392,7 @@ __global__ __launch_bounds__(64) void k_tri_solve_lds(TriArgs a, const double *_
   const size_t cbase = (size_t)tile * 64 * nz + (valid ? lane : 0);   // idle lanes of the last tile shadow lane 0 ...
   double *zs = valid ? z + cbase : scratch64 + lane;                  // ... and store into a scratch line
   const size_t tws = valid ? (size_t)tw : 0;
-  double accx = 0.0;
+  double accx = 0.0, accf = 0.0;
   if (SPMV == 2) {   // x = U^{-1} d, top down
     double *xs = valid ? xout + cbase : scratch64 + lane;
     double cb[RB][G], ib[RB][G], db[RB][G];
@@ -2422,7 +2448,7 @@ __global__ __launch_bounds__(64) void k_tri_solve_lds(TriArgs a, const double *_
     // 3l + 2 -- through a 1.5 KB LDS scratch when the level is used; three 8-byte loads at a 24-byte lane stride would touch every
     // line of the segment three times.  The two end levels (2 entries per row) are read directly.
     __shared__ double tr[3 * 64];
-    double xb[RF][G], v0[RF][G], v1[RF][G], v2[RF][G], sb[SPMV == 3 ? RF : 1][SPMV == 3 ? G : 1];
+    double xb[RF][G], v0[RF][G], v1[RF][G], v2[RF][G], sb[SPMV == 3 ? RF : 1][SPMV == 3 ? G : 1], fb[FDOT ? RF : 1][FDOT ? G : 1];
     const double na = (SPMV == 3) ? -1.0 * sc[S_ALPHA] : 0.0;
     double *ss = (SPMV == 3) ? (valid ? xout + cbase : scratch64 + lane) : nullptr;
     auto fetch = [&](int q, int kfirst) {   // levels kfirst .. kfirst+G-1 (clamped) into group q
@@ -2432,6 +2458,7 @@ __global__ __launch_bounds__(64) void k_tri_solve_lds(TriArgs a, const double *_
         const size_t i = cbase + (size_t)k * tw;
         xb[q][j] = (SPMV == 1 || SPMV == 3) ? ldnt(r + i) : 0.0;   // (SPMV == 2: x is in the slab)
         if (SPMV == 3) sb[q][j] = ldnt(vsub + i);
+        if (FDOT) fb[q][j] = ldnt(fdot + i);
         if (k == 0) {                 // [di up]: lower slot harmless (meets x = 0)
           v0[q][j] = ldnt(vt + 2 * vl); v1[q][j] = v0[q][j]; v2[q][j] = ldnt(vt + 2 * vl + 1);
         } else if (k == nz - 1) {     // [lo di]: upper slot harmless
@@ -2449,15 +2476,16 @@ __global__ __launch_bounds__(64) void k_tri_solve_lds(TriArgs a, const double *_
     // The elimination factor l_k = lo_k / piv_{k-1} is not read: the row's entries are here anyway, so the factorisation is redone on
     // the way (k_tri_factor's arithmetic: l = lo inv_prev, piv = fma(-l, up_prev, di), inv = 1 / piv -- one division per level in a
     // chain the memory stream leaves room for), 8 of the kernel's ~90 bytes per cell.  The stored factors stay for the back sweep.
-    double xm2 = 0.0, xm1 = 0.0, plo = 0.0, pdi = 0.0, pup = 0.0, pl = 0.0, prev = 0.0, finv = 0.0;
+    double xm2 = 0.0, xm1 = 0.0, plo = 0.0, pdi = 0.0, pup = 0.0, pl = 0.0, prev = 0.0, finv = 0.0, pf = 0.0;
     auto finish = [&](int kr, double xnext) {   // row kr from the carried values and x_{kr+1}
       const double p0 = plo * xm2, p1 = pdi * xm1, p2 = pup * xnext;
       const double rk = (p0 + p1) + p2;
+      if (FDOT) accf += pf * rk;                // (row kr of A x meets fdot_kr: the line search's F . (J Y), see FDOT above)
       const double d = fma(-pl, prev, rk);
       prev = d;
       dsl[kr * 64 + lane] = d;
     };
-    auto step = [&](int k, double xk, double lo, double di, double up, double vk) {
+    auto step = [&](int k, double xk, double lo, double di, double up, double vk, double fk) {
       if (SPMV == 2) xk = dsl[k * 64 + lane];   // (rows below k have been replaced by their eliminated sums already: not needed any more)
       if (SPMV == 3) { xk = fma(na, vk, xk); ss[(size_t)k * tws] = xk; }   // s = r - alpha v (k_waxpy's arithmetic), kept for the update kernel
       if (k > 0 && k < nz - 1) {   // a middle level: (lo, di, up) hold segment entries l, tw + l, 2 tw + l -> this lane's row
@@ -2472,13 +2500,14 @@ __global__ __launch_bounds__(64) void k_tri_solve_lds(TriArgs a, const double *_
       xm2 = (k > 0) ? xm1 : 0.0;   // x_{-1} = 0 meets the lower entry row 0 does not have
       xm1 = xk;
       plo = lo; pdi = di; pup = up; pl = lk;
+      if (FDOT) pf = fk;
     };
     int k0 = 0;
     for (; k0 + RF * G <= nz; k0 += RF * G) {
 #pragma unroll
       for (int q = 0; q < RF; ++q) {
 #pragma unroll
-        for (int j = 0; j < G; ++j) step(k0 + q * G + j, xb[q][j], v0[q][j], v1[q][j], v2[q][j], SPMV == 3 ? sb[q][j] : 0.0);
+        for (int j = 0; j < G; ++j) step(k0 + q * G + j, xb[q][j], v0[q][j], v1[q][j], v2[q][j], SPMV == 3 ? sb[q][j] : 0.0, FDOT ? fb[q][j] : 0.0);
         __builtin_amdgcn_sched_barrier(0);
         fetch(q, k0 + (RF + q) * G);
         __builtin_amdgcn_sched_barrier(0);
@@ -2489,7 +2518,7 @@ __global__ __launch_bounds__(64) void k_tri_solve_lds(TriArgs a, const double *_
 #pragma unroll
       for (int j = 0; j < G; ++j) {
         const int k = k0 + q * G + j;
-        if (k < nz) step(k, xb[q][j], v0[q][j], v1[q][j], v2[q][j], SPMV == 3 ? sb[q][j] : 0.0);
+        if (k < nz) step(k, xb[q][j], v0[q][j], v1[q][j], v2[q][j], SPMV == 3 ? sb[q][j] : 0.0, FDOT ? fb[q][j] : 0.0);
       }
     finish(nz - 1, 0.0);   // the top row: no upper neighbour
   } else {
@@ -2577,7 +2606,7 @@ __global__ __launch_bounds__(64) void k_tri_solve_lds(TriArgs a, const double *_
         }
       }
   }
-  if (!valid) acc0 = acc1 = accx = 0.0;
+  if (!valid) acc0 = acc1 = accx = accf = 0.0;
   const bool folded = SPMV && fold.counter != nullptr;
   const double t0 = wave_sum(acc0);
   if (lane == 0) store_partial(partials + tile, t0, folded);
@@ -2588,6 +2617,10 @@ __global__ __launch_bounds__(64) void k_tri_solve_lds(TriArgs a, const double *_
   if (SPMV == 2) {
     const double t2 = wave_sum(accx);
     if (lane == 0) store_partial(partials + 2 * (size_t)gridDim.x + tile, t2, folded);
+  }
+  if (FDOT) {
+    const double t3 = wave_sum(accf);
+    if (lane == 0) store_partial(partials + (size_t)(ND + (SPMV == 2 ? 1 : 0)) * gridDim.x + tile, t3, folded);
   }
   if (SPMV) fold_tail<64>(fold, partials, (int)gridDim.x, lane == 0);
 }
@@ -2705,6 +2738,7 @@ __device__ void bcgs_scalar_step(int step, double *sc) {
   } else if (step == 3) {  // d1 = (s,t), d2 = (t,t); omega = d1/d2
     const double d1 = sc[S_SUM0], d2 = sc[S_SUM0 + 1];
     sc[S_ST] = d1; sc[S_D2] = d2;
+    sc[S_FJS] = sc[S_SUM0 + 2];   // F . (J s), likewise
     if (d2 == 0.0) { sc[S_OMEGA] = 0.0; sc[S_FLAG] = 1.0; }  // t == 0: x += alpha p is the candidate solution
     else sc[S_OMEGA] = d1 / d2;
   } else if (step == 6) {  // steps 0 and 1 when the initial (rp,rp) was all-reduced together with the first (v,rp): it sits in S_SUM0+2
@@ -2723,6 +2757,7 @@ __device__ void bcgs_scalar_step(int step, double *sc) {
     const double d1 = sc[S_SUM0];
     sc[S_D1] = d1;
     sc[S_ALPHA] = sc[S_RHO] / d1;
+    sc[S_FJP] = sc[S_SUM0 + 3];   // F . (J p) when the kernel reduced it (k_tri_solve_lds FDOT; otherwise whatever the slot holds: not read)
   }
   if (step == 4 || step == 45) {  // end of iteration: dp^2 = (r,r); rhoold = rho; omegaold = omega; (r,rp) if it was reduced
     sc[S_DP] = sqrt(sc[S_SUM0]);
@@ -2803,7 +2838,8 @@ __global__ __launch_bounds__(kBlock) void k_finalize(int nb, int chunk, const do
 // partials != nullptr: also the partial sums of y.y of the result (the norm GMRES takes next), one per block
 // (two rows per thread as one 16-byte access per vector, four vectors' loads issued together: with one 8-byte load per vector and
 // thread the update of a 134 M-row vector against 13 basis vectors ran at 0.67 of peak)
-__global__ __launch_bounds__(kBlock) void k_maxpy_neg(MaxpyArgs a, const double *sc, double *y, double *partials) {
+// h: the nvec Gram-Schmidt coefficients, h[j] for a.v[j]
+__global__ __launch_bounds__(kBlock) void k_maxpy_neg(MaxpyArgs a, const double *__restrict__ h, double *y, double *partials) {
   __shared__ double lds[kBlock / 64];
   const size_t i = 2 * ((size_t)blockIdx.x * kBlock + threadIdx.x), n = (size_t)a.n;
   double sq = 0.0;
@@ -2815,7 +2851,7 @@ __global__ __launch_bounds__(kBlock) void k_maxpy_neg(MaxpyArgs a, const double 
                   b1 = __builtin_nontemporal_load(reinterpret_cast<const dpair *>(a.v[j + 1] + i)),
                   b2 = __builtin_nontemporal_load(reinterpret_cast<const dpair *>(a.v[j + 2] + i)),
                   b3 = __builtin_nontemporal_load(reinterpret_cast<const dpair *>(a.v[j + 3] + i));
-      const double s0 = sc[S_SUM0 + j], s1 = sc[S_SUM0 + j + 1], s2 = sc[S_SUM0 + j + 2], s3 = sc[S_SUM0 + j + 3];
+      const double s0 = h[j], s1 = h[j + 1], s2 = h[j + 2], s3 = h[j + 3];
       v.x -= s0 * b0.x; v.y -= s0 * b0.y;
       v.x -= s1 * b1.x; v.y -= s1 * b1.y;
       v.x -= s2 * b2.x; v.y -= s2 * b2.y;
@@ -2823,14 +2859,14 @@ __global__ __launch_bounds__(kBlock) void k_maxpy_neg(MaxpyArgs a, const double 
     }
     for (; j < a.nvec; ++j) {
       const dpair b0 = __builtin_nontemporal_load(reinterpret_cast<const dpair *>(a.v[j] + i));
-      const double s0 = sc[S_SUM0 + j];
+      const double s0 = h[j];
       v.x -= s0 * b0.x; v.y -= s0 * b0.y;
     }
     *reinterpret_cast<dpair *>(y + i) = v;
     sq = v.x * v.x + v.y * v.y;
   } else if (i < n) {   // the last row of an odd count
     double v = y[i];
-    for (int j = 0; j < a.nvec; ++j) v -= sc[S_SUM0 + j] * a.v[j][i];
+    for (int j = 0; j < a.nvec; ++j) v -= h[j] * a.v[j][i];
     y[i] = v;
     sq = v * v;
   }
@@ -2911,6 +2947,19 @@ void launch_assemble_general(int mode, const GenArgs &a, hipStream_t stream) {
   if (mode == 0) { LAUNCH(k_auxvars<0>, grid, a); LAUNCH(k_flux_rows<0>, grid, a); }
   else if (mode == 1) { LAUNCH(k_auxvars<1>, grid, a); LAUNCH(k_flux_rows<1>, grid, a); }
   else { LAUNCH(k_auxvars<2>, grid, a); LAUNCH(k_flux_rows<2>, grid, a); }
+}
+
+void launch_assemble_cols_lateral(int mode, const GenArgs &a, hipStream_t stream) {
+  if (a.n <= 0) return;
+  if (!a.ell_enc || a.ell_k > 8) throw std::runtime_error("internal: the lateral pass needs the ELL incidence lists");
+  dim3 grid(nblk(a.n));
+  if (a.ell_k <= 6) {
+    if (mode == 0) LAUNCH((k_flux_rows_ell<0, 6, true>), grid, a); else if (mode == 1) LAUNCH((k_flux_rows_ell<1, 6, true>), grid, a);
+    else LAUNCH((k_flux_rows_ell<2, 6, true>), grid, a);
+  } else {
+    if (mode == 0) LAUNCH((k_flux_rows_ell<0, 8, true>), grid, a); else if (mode == 1) LAUNCH((k_flux_rows_ell<1, 8, true>), grid, a);
+    else LAUNCH((k_flux_rows_ell<2, 8, true>), grid, a);
+  }
 }
 
 void launch_bc(int mode, const BcArgs &a, hipStream_t stream) {
@@ -3026,7 +3075,7 @@ int launch_tri_solve_lds(const TriArgs &a, const double *r, double *z, const dou
                          int group, hipStream_t stream) {
   const dim3 grid(tri_solve_lds_blocks(a.ncols));
   const size_t shmem = (size_t)a.nz * 64 * sizeof(double);
-#define TRI_LDS(ND, G, RF, RB) hipLaunchKernelGGL((k_tri_solve_lds<ND, G, RF, RB, 0>), grid, dim3(64), shmem, stream, a, r, z, w, partials, scratch64, (double *)nullptr, (const double *)nullptr, (const double *)nullptr, Fold())
+#define TRI_LDS(ND, G, RF, RB) hipLaunchKernelGGL((k_tri_solve_lds<ND, G, RF, RB, 0>), grid, dim3(64), shmem, stream, a, r, z, w, partials, scratch64, (double *)nullptr, (const double *)nullptr, (const double *)nullptr, Fold(), (const double *)nullptr)
   // `group` = levels in flight per stream: rings of 4-level groups
   if (w) { if (group <= 8) TRI_LDS(2, 4, 2, 2); else if (group <= 16) TRI_LDS(2, 4, 4, 3); else TRI_LDS(2, 4, 6, 4); }
   else { if (group <= 8) TRI_LDS(1, 4, 2, 2); else if (group <= 16) TRI_LDS(1, 4, 4, 4); else TRI_LDS(1, 4, 6, 5); }
@@ -3038,23 +3087,25 @@ int launch_spmv_tri_lds(const TriArgs &a, const double *x, double *z, const doub
   const dim3 grid(tri_solve_lds_blocks(a.ncols));
   const size_t shmem = (size_t)a.nz * 64 * sizeof(double);
   // forward: five streams (x, three matrix entries, l) in a ring of 3 groups of 4 levels = 60 loads in flight (the counter holds 63)
-  if (w) hipLaunchKernelGGL((k_tri_solve_lds<2, 4, 3, 4, 1>), grid, dim3(64), shmem, stream, a, x, z, w, partials, scratch64, (double *)nullptr, (const double *)nullptr, (const double *)nullptr, fold);
-  else hipLaunchKernelGGL((k_tri_solve_lds<1, 4, 3, 5, 1>), grid, dim3(64), shmem, stream, a, x, z, w, partials, scratch64, (double *)nullptr, (const double *)nullptr, (const double *)nullptr, fold);
+  if (w) hipLaunchKernelGGL((k_tri_solve_lds<2, 4, 3, 4, 1>), grid, dim3(64), shmem, stream, a, x, z, w, partials, scratch64, (double *)nullptr, (const double *)nullptr, (const double *)nullptr, fold, (const double *)nullptr);
+  else hipLaunchKernelGGL((k_tri_solve_lds<1, 4, 3, 5, 1>), grid, dim3(64), shmem, stream, a, x, z, w, partials, scratch64, (double *)nullptr, (const double *)nullptr, (const double *)nullptr, fold, (const double *)nullptr);
   return (int)grid.x;
 }
 int launch_back_spmv_tri_lds(const TriArgs &a, const double *d, double *x, double *z, double *partials, double *scratch64, hipStream_t stream,
-                             const Fold &fold) {
+                             const Fold &fold, const double *fdot) {
   const dim3 grid(tri_solve_lds_blocks(a.ncols));
   const size_t shmem = (size_t)a.nz * 64 * sizeof(double);
-  hipLaunchKernelGGL((k_tri_solve_lds<2, 4, 3, 4, 2>), grid, dim3(64), shmem, stream, a, d, z, (const double *)x, partials, scratch64, x, (const double *)nullptr, (const double *)nullptr, fold);
+  if (fdot) hipLaunchKernelGGL((k_tri_solve_lds<2, 4, 3, 4, 2, true>), grid, dim3(64), shmem, stream, a, d, z, (const double *)x, partials, scratch64, x, (const double *)nullptr, (const double *)nullptr, fold, fdot);
+  else hipLaunchKernelGGL((k_tri_solve_lds<2, 4, 3, 4, 2>), grid, dim3(64), shmem, stream, a, d, z, (const double *)x, partials, scratch64, x, (const double *)nullptr, (const double *)nullptr, fold, (const double *)nullptr);
   return (int)grid.x;
 }
 int launch_waxpy_spmv_tri_lds(const TriArgs &a, const double *r, const double *v, const double *sc, double *s, double *z, double *partials,
-                              double *scratch64, hipStream_t stream, const Fold &fold) {
+                              double *scratch64, hipStream_t stream, const Fold &fold, const double *fdot) {
   const dim3 grid(tri_solve_lds_blocks(a.ncols));
   const size_t shmem = (size_t)a.nz * 64 * sizeof(double);
-  // forward: six streams (r, v, three matrix entries, l) in a ring of 2 groups of 5 levels = 60 loads in flight
-  hipLaunchKernelGGL((k_tri_solve_lds<2, 5, 2, 4, 3>), grid, dim3(64), shmem, stream, a, r, z, (const double *)s, partials, scratch64, s, v, sc, fold);
+  // forward: six streams (r, v, three matrix entries, l) in a ring of 2 groups of 5 levels = 60 loads in flight (fdot: one more stream, 60 loads)
+  if (fdot) hipLaunchKernelGGL((k_tri_solve_lds<2, 5, 2, 4, 3, true>), grid, dim3(64), shmem, stream, a, r, z, (const double *)s, partials, scratch64, s, v, sc, fold, fdot);
+  else hipLaunchKernelGGL((k_tri_solve_lds<2, 5, 2, 4, 3>), grid, dim3(64), shmem, stream, a, r, z, (const double *)s, partials, scratch64, s, v, sc, fold, (const double *)nullptr);
   return (int)grid.x;
 }
 int launch_tri_back_dots(const TriArgs &a, const double *d, double *z, double *partials, hipStream_t stream) {
@@ -3219,11 +3270,12 @@ void launch_bcgs_p(int n, double *P, const double *Pold, const double *R, const 
 }
 int bcgs_xr_blocks(int n, bool wide) { return wide ? vec_grid(n) : red_grid(n); }
 int launch_bcgs_xr(int n, bool first, bool wide, double *X, double *R, const double *P, const double *S, const double *T,
-                   const double *RP, const double *sc, double *partials, hipStream_t stream) {
+                   const double *RP, const double *sc, double *partials, hipStream_t stream, bool xx) {
   // a kernel that writes two vectors wants one pair per lane (a capped grid streams ~20 % slower, tools/membench.hip);
   // its many partial sums go through the two-stage finalisation
   const int g = wide ? vec_grid(n) : red_grid(n);
-  if (first) LAUNCH(k_bcgs_xr<true>, dim3(g), n, X, R, P, S, T, RP, sc, partials);
+  if (first && xx) LAUNCH((k_bcgs_xr<true, true>), dim3(g), n, X, R, P, S, T, RP, sc, partials);
+  else if (first) LAUNCH(k_bcgs_xr<true>, dim3(g), n, X, R, P, S, T, RP, sc, partials);
   else LAUNCH(k_bcgs_xr<false>, dim3(g), n, X, R, P, S, T, RP, sc, partials);
   return g;
 }
@@ -3260,12 +3312,12 @@ void launch_finalize(int nblocks, int nvec, const double *partials, double *sums
          Publish{f.pub_host, f.pub_seq, f.pub_value});
 }
 int maxpy_blocks(int n) { return nblk(((long long)n + 1) / 2); }   // two rows per thread
-int launch_maxpy_neg(const MaxpyArgs &a, const double *sc, double *y, double *partials, hipStream_t stream) {
+int launch_maxpy_neg(const MaxpyArgs &a, const double *h, double *y, double *partials, hipStream_t stream) {
   if (a.n <= 0 || a.nvec <= 0) return 0;
   for (int j = 0; j < a.nvec; ++j)   // (16-byte accesses)
     if (((uintptr_t)a.v[j] | (uintptr_t)y) & 15) throw std::runtime_error("internal: multi-axpy operands must be 16-byte aligned");
   const dim3 grid(maxpy_blocks(a.n));
-  LAUNCH(k_maxpy_neg, grid, a, sc, y, partials);
+  LAUNCH(k_maxpy_neg, grid, a, h, y, partials);
   return (int)grid.x;
 }
 void launch_maxpy_val(const MaxpyValArgs &a, double *x, hipStream_t stream) {

@@ -11,6 +11,7 @@ namespace mpp {
 // device-resident scalar block shared by the Krylov/Newton kernels (doubles)
 enum ScalarSlot : int {
   S_RHO = 0, S_RHOOLD, S_ALPHA, S_OMEGA, S_OMEGAOLD, S_BETA, S_D1, S_D2, S_DP, S_FLAG, S_ST, S_DP0, S_RRP, S_ERR,
+  S_FJP, S_FJS,   // F . (J p), F . (J s) of a BiCGStab iteration whose fused product kernels reduced them (option ls_fold)
   S_SUM0 = 16,  // reduction results land in S_SUM0 .. S_SUM0+63
   S_COUNT = 96
 };
@@ -52,6 +53,7 @@ struct Fold {
   int step = -1, nvec = 0;
   double *pub_host = nullptr; unsigned long long *pub_seq = nullptr; unsigned long long pub_value = 0;
 };
+struct AuxOut { double *kr, *dkr, *den, *dden; };
 struct ColsArgs {
   CellArrays cell;
   ConnArrays conn;       // vertical connection (k,c)->(k+1,c) stored at the index of cell (k,c)
@@ -93,6 +95,13 @@ struct ColsArgs {
   const double *trial_x = nullptr, *trial_y = nullptr;
   double trial_a = 0.0;
   double *trial_w = nullptr;
+  // 3-D meshes of complete soil columns (round 5; lateral connections on top of the vertical chains): the march does the accumulation
+  // term and the vertical fluxes of a column as on a vertical-only grid, writes the column's tridiagonal at the CSR slots of the
+  // 7-point rows (slot_lo / slot_di / slot_up, -1 where a row has no such entry) and leaves the auxvars its lateral pass needs
+  // (aux: kr, d kr, density, d density per cell); the lateral connections are added row by row afterwards
+  // (launch_assemble_cols_lateral).  Never together with col_bc.
+  const int *slot_lo = nullptr, *slot_di = nullptr, *slot_up = nullptr;
+  AuxOut aux = {nullptr, nullptr, nullptr, nullptr};
 };
 // mode 0 residual, 1 Jacobian, 2 both
 void launch_assemble_cols(int mode, const ColsArgs &a, hipStream_t stream);
@@ -100,7 +109,6 @@ void launch_assemble_cols(int mode, const ColsArgs &a, hipStream_t stream);
 void launch_accum(const CellArrays &cell, int n, double dtInv, double *out, hipStream_t stream);
 
 // ---- general (any connection list) assembly: auxvar pass + row-gather pass ----
-struct AuxOut { double *kr, *dkr, *den, *dden; };
 struct GenArgs {
   CellArrays cell;
   ConnArrays conn;
@@ -118,6 +126,10 @@ struct GenArgs {
   double dtInv;
 };
 void launch_assemble_general(int mode, const GenArgs &a, hipStream_t stream);
+// the lateral half of the assembly of a 3-D mesh of complete soil columns: after launch_assemble_cols with ColsArgs::slot_di / aux set,
+// every row adds the fluxes of its lateral connections (the ELL incidence lists, entries of chain links skipped: their connection
+// index is below n) to F and to its diagonal, writes its off-column entries, and subtracts the source term
+void launch_assemble_cols_lateral(int mode, const GenArgs &a, hipStream_t stream);
 
 // ---- boundary conditions: one thread per cell that carries at least one BC connection ----
 struct BcArgs {
@@ -212,12 +224,14 @@ int launch_spmv_tri_lds(const TriArgs &a, const double *x, double *z, const doub
                         const Fold &fold = Fold());
 // the same with x = U^{-1} d produced first (d: a right-hand side the assembly pass forward-eliminated; x is written): the start of
 // a BiCGStab solve in one kernel.  Partial sums, one per 64-column tile: (z,x), (z,z), (x,x) in rows 0, 1, 2 of `partials`.
+// fdot != nullptr: also the partial sums of fdot . (A x) in row 3 of `partials` (the line search's F . (J p), see k_tri_solve_lds FDOT)
 int launch_back_spmv_tri_lds(const TriArgs &a, const double *d, double *x, double *z, double *partials, double *scratch64, hipStream_t stream,
-                             const Fold &fold = Fold());
+                             const Fold &fold = Fold(), const double *fdot = nullptr);
 // ... and with s = r - sc[S_ALPHA] v formed on the way (written to `s`): z = M^{-1} A s with (z,s), (z,z) -- BiCGStab's VecWAXPY, second
 // product and omega's two dot products in one kernel
+// fdot != nullptr: also the partial sums of fdot . (A s) in row 2 of `partials`
 int launch_waxpy_spmv_tri_lds(const TriArgs &a, const double *r, const double *v, const double *sc, double *s, double *z, double *partials,
-                              double *scratch64, hipStream_t stream, const Fold &fold = Fold());
+                              double *scratch64, hipStream_t stream, const Fold &fold = Fold(), const double *fdot = nullptr);
 // z = U^{-1} d for a right-hand side the assembly pass already forward-eliminated, with the partial sums of z.z
 int launch_tri_back_dots(const TriArgs &a, const double *d, double *z, double *partials, hipStream_t stream);
 void launch_jacobi_setup(int n, const int *diag_slot, const double *val, double *invd, hipStream_t stream);
@@ -473,8 +487,9 @@ void launch_bcgs_p(int n, double *P, const double *Pold, const double *R, const 
 // wide: one 16-byte pair per lane (bcgs_xr_blocks(n, true) partial sums per vector: finish with
 // launch_finalize) instead of the capped reduction grid
 int bcgs_xr_blocks(int n, bool wide);
+// xx (with first): x.x as a second sum (row 1 of `partials`)
 int launch_bcgs_xr(int n, bool first, bool wide, double *X, double *R, const double *P, const double *S, const double *T,
-                   const double *RP, const double *sc, double *partials, hipStream_t stream);
+                   const double *RP, const double *sc, double *partials, hipStream_t stream, bool xx = false);
 // multi-dot: sums[j] = x . ys[j], j < nvec; two-stage deterministic reduction (partials -> sc[S_SUM0+j])
 struct DotArgs { int n, nvec; const double *x[kMaxMultiDot]; const double *y[kMaxMultiDot]; };
 // stage 1 only (returns number of partial blocks); stage 2 is launch_finalize
@@ -495,7 +510,7 @@ struct MaxpyArgs { int n, nvec; const double *v[kMaxMultiDot]; };
 // partials (maxpy_blocks(n) doubles + maxpy_blocks(n) / 2048 + 1 more, or nullptr): also y.y of the result;
 // returns the number of blocks
 int maxpy_blocks(int n);
-int launch_maxpy_neg(const MaxpyArgs &a, const double *sc, double *y, double *partials, hipStream_t stream);
+int launch_maxpy_neg(const MaxpyArgs &a, const double *h, double *y, double *partials, hipStream_t stream);   // h[j]: coefficient of a.v[j]
 void launch_scale(int n, double *x, const double *sc, int slot_inv_of, hipStream_t stream);  // x *= 1/sc[slot]
 // x += sum_j yv[j]*v_j with yv passed by value
 struct MaxpyValArgs { int n, nvec; const double *v[kMaxMultiDot]; double c[kMaxMultiDot]; bool zero_x = false; /* x = sum (x not read) */ };

@@ -199,8 +199,9 @@ struct Condition {
 
 struct Options {
   int ksp_type = 1;        // 0 preonly, 1 gmres, 2 bcgs       (PETSc default: gmres)
-  int pc_type = 2;         // 0 none, 2 bjacobi (per soil column), 3 jacobi
-  bool pc_is_ilu = false;  // "ilu" requested: served by the column solver on vertical-only grids
+  int pc_type = 2;         // 0 none, 1 ilu (level / box solves), 2 bjacobi (per soil column), 3 jacobi
+  bool pc_is_ilu = true;   // "ilu" -- PETSc's default PC, and this library's since round 5 -- served by the column solver on vertical-only
+                           // grids (ILU(0) of a block-tridiagonal matrix in natural ordering IS the per-column LU), by ILU(0) elsewhere
   double ksp_rtol = 1e-5, ksp_atol = 1e-50, ksp_dtol = 1e4;
   int ksp_max_it = 10000, gmres_restart = 30;
   double snes_rtol = 1e-8, snes_atol = 1e-50, snes_stol = 1e-10, snes_divtol = 1e4;  // stol: MultiPhysicsProbBaseType.F90:1112
@@ -257,6 +258,10 @@ struct Options {
   bool fused_waxpy = true;     // ... and s = r - alpha v inside the kernel of the second product
   bool lazy_r = true;          // BiCGStab: r = s - omega t is not written by an iteration that is expected to be the last (only its norm)
   bool ls_spec = true;         // ... and the search's first trial point (the full step) is evaluated there too (LsAhead::spec)
+  bool cols3d = true;          // 3-D meshes of complete soil columns: column march (accumulation + chain links) + lateral pass instead of the
+                               // general auxvar pass + row gather over every connection (Solver::use_cols3d)
+  bool ls_fold = true;         // the search's F . (J Y) and ||Y|| out of the kernels of a one-iteration BiCGStab solve (F . (J p), F . (J s) reduced by the
+                               // two fused product kernels, Y . Y by the update): no product pass of the search's own (Solver::ksp_bcgs, fold_ls)
   bool wide_xr = true;         // BiCGStab update kernel on a one-pair-per-lane grid (large vectors)
   double collective_timeout = 900.0;   // seconds a rank waits for device scalars that depend on the other ranks (an all-reduce) before it
                                // gives up with an error -- a peer that failed or never arrived must not leave this rank waiting forever

@@ -188,6 +188,7 @@ struct Solver {
     double g2 = 0.0, w2 = 0.0;
   } ls_ahead;
   long long spec_misses = 0;
+  long long ls_folds = 0;    // line searches whose F . (J Y) came out of the Krylov solve's own kernels (option ls_fold)
   int asm_slot = 0;          // complete-row march: where its two sums go (sc[S_SUM0 + asm_slot ..]) ...
   bool asm_defer = false;    // ... and whether the caller all-reduces and reads them itself
   bool ksp_one_shot = false;   // pending X + a Y of the line search
@@ -993,7 +994,7 @@ struct Solver {
     partials.alloc((size_t)kMaxPartialBlocks * kMaxMultiDot);
     {  // one partial sum per block of 256 columns (column solves, complete-row march): two vectors + the staging tail
       const size_t nbc = ((size_t)ncols + 63) / 64;   // (the LDS column solve leaves one per 64-column tile)
-      col_partials.alloc(3 * (nbc + nbc / 2048 + 1));
+      col_partials.alloc(4 * (nbc + nbc / 2048 + 1));   // (up to four sums per launch: k_tri_solve_lds FDOT)
       tri_scratch.alloc(64);
     }
     sc.alloc(S_COUNT); sc.zero(stream);
@@ -1163,7 +1164,7 @@ struct Solver {
     BigVec<double> a(n), b(n), c(n), d(n);   // (first touched by the threads that fill them)
     host_parallel_for(n, [&](long long i) { const int e = int2ext[i]; a[i] = por[e]; b[i] = sat_res[e]; c[i] = alpha[e]; d[i] = lam[e]; });
     d_por.upload(a, stream); d_sat_res.upload(b, stream); d_alpha.upload(c, stream); d_m.upload(d, stream);
-    if (vertical_only && columns && !th) {   // the column march streams porosity x volume as one operand
+    if (col_operands()) {   // the column march streams porosity x volume as one operand
       HIP_CHECK(hipStreamSynchronize(stream));   // (a is about to be reused)
       host_parallel_for(n, [&](long long i) { a[i] = a[i] * vol[int2ext[i]]; });
       d_porvol.upload(a, stream);
@@ -1233,7 +1234,7 @@ struct Solver {
       });
       d_Dq.upload(Dq.p, (size_t)nc_int, stream); d_upw.upload(upw.p, (size_t)nc_int, stream);
       d_dgrav.upload(dg.p, (size_t)nc_int, stream); d_area.upload(ar.p, (size_t)nc_int, stream);
-      if (vertical_only && columns && !th) {   // ... and conductance x face area
+      if (col_operands()) {   // ... and conductance x face area
         HIP_CHECK(hipStreamSynchronize(stream));   // (Dq is about to be reused)
         host_parallel_for(nc_int, [&](long long ic) { Dq[ic] = Dq[ic] * ar[ic]; });
         d_DqA.upload(Dq.p, (size_t)nc_int, stream);
@@ -1324,7 +1325,7 @@ struct Solver {
   void build_soil_classes() {
     ncls = 0;
     d_soil_cls.release();
-    if (!opt.soil_classes || !(vertical_only && columns) || th || thermal || mixed_satf) return;
+    if (!opt.soil_classes || !col_operands() || mixed_satf) return;
     struct Key { int f; double a, b, c; bool operator<(const Key &o) const { return std::tie(f, a, b, c) < std::tie(o.f, o.a, o.b, o.c); } };
     std::vector<Key> keys;             // sorted, <= 256 entries: binary search per cell, early exit on the 257th tuple
     std::vector<unsigned char> cls(n);
@@ -1420,6 +1421,16 @@ struct Solver {
   }
   ConnArrays conns() const { return ConnArrays{d_Dq.p, d_upw.p, d_dgrav.p, d_area.p}; }
   bool use_cols() const { return vertical_only && opt.assembly != 0 && !th; }
+  // a 3-D mesh whose cells form complete soil columns (tiled level-major layout) with lateral connections on top: the column march
+  // for the accumulation term and the chain links, then the lateral connections row by row from the ELL incidence lists (round 5;
+  // launch_assemble_cols_lateral).  Per-row sum order: chain links first, then the lateral connections in the caller's order -- the
+  // reference's order where the caller lists the vertical connections first (vsfm_vchannel_problem.F90 does), a permutation of it
+  // otherwise (MeshCreate lists x, y, then z): residual rows then agree to rounding, not to the bit.
+  bool use_cols3d() const {
+    return opt.cols3d && columns && !vertical_only && !th && !thermal && opt.assembly != 0 && nghost == 0 && nz >= 2 && ell_k > 0 &&
+           ell_k <= 8 && opt.ell_assembly;
+  }
+  bool col_operands() const { return columns && !th && !thermal && (vertical_only || use_cols3d()); }   // porosity x volume, Dq x area, per-level data
   int pick_nseg() const {
     if (opt.nseg > 0) return std::min(opt.nseg, nz);
     // The complete-row march (one thread per column: rows_complete) folds the column LU, the forward elimination, the trial
@@ -1442,6 +1453,11 @@ struct Solver {
     if (lev_geo) { a.lev_upw = d_lev_upw.p; a.lev_dgrav = d_lev_dgrav.p; }
     if (lev_pv) a.lev_porvol = d_lev_porvol.p;
     if (sbc_kind == 2) { a.sbc_b = d_b3.p; a.sbc_b_is_b3 = 1; } else if (sbc_kind == 3) a.sbc_b = d_b2.p;
+    if (use_cols3d()) {   // 7-point rows: tridiagonal at its CSR slots, auxvars for the lateral pass, the source term left to that pass
+      a.slot_lo = d_tri_lo.p; a.slot_di = d_diag.p; a.slot_up = d_tri_up.p;
+      a.aux = AuxOut{aux_kr.p, aux_dkr.p, aux_den.p, aux_dden.p};
+      a.src = nullptr;
+    }
     return a;
   }
   GenArgs gen_args(const double *P, double *Fout) const {
@@ -1498,6 +1514,7 @@ struct Solver {
     if (Fout == fwd_rhs) fwd_rhs = nullptr;
     if (rows_complete()) { assemble_complete_rows(0, P, Fout); ++nfuncs; ++cum_funcs; return; }
     if (use_cols()) launch_assemble_cols(0, cols_args(P, Fout), stream);
+    else if (use_cols3d()) { launch_assemble_cols(0, cols_args(P, Fout), stream); launch_assemble_cols_lateral(0, gen_args(P, Fout), stream); }
     else {
       if (!d_rc_ptr.p) throw Error("option assembly=general must be set before mppgpu_setup");
       launch_assemble_general(0, gen_args(P, Fout), stream);
@@ -1527,7 +1544,9 @@ struct Solver {
       a.tl = tri_l.p; a.tinvb = tri_invb.p; a.tc = tri_c.p;
       // the solves that form A x on the way redo the elimination factors from the rows they read: where those are the ones a solve
       // will use, l is not written (8 of the march's 107 bytes per cell) and rebuilt only if a plain solve asks (ensure_tri_l)
-      a.store_l = !(opt.lazy_tri_l && fused_spmv_pc_possible());
+      // (BiCGStab only: every product of its iterations goes through op_BA_dots; GMRES uses the fused kernel for its first product alone
+      // and would pay a k_tri_l pass -- 28 bytes per cell -- per Newton iteration for the 8 the march saves: ADVICE r04)
+      a.store_l = !(opt.lazy_tri_l && opt.ksp_type == 2 && fused_spmv_pc_possible());
       tri_l_valid = a.store_l;
     }
     if (mode != 1 || Fout == fwd_rhs) fwd_rhs = nullptr;   // the residual in Fout or the factors are being replaced
@@ -1562,6 +1581,7 @@ struct Solver {
     fwd_rhs = nullptr;
     if (rows_complete()) { assemble_complete_rows(2, P, Fout); ++nfuncs; ++cum_funcs; return; }
     if (use_cols()) launch_assemble_cols(2, cols_args(P, Fout), stream);
+    else if (use_cols3d()) { launch_assemble_cols(2, cols_args(P, Fout), stream); launch_assemble_cols_lateral(2, gen_args(P, Fout), stream); }
     else {
       if (!d_rc_ptr.p) throw Error("option assembly=general must be set before mppgpu_setup");
       launch_assemble_general(2, gen_args(P, Fout), stream);
@@ -1580,6 +1600,7 @@ struct Solver {
     if (th) { launch_th_assemble(2, th_args(P, th_scratch.p), stream); ghost_zero(P); pc_ready = false; return; }
     if (rows_complete()) { assemble_complete_rows(1, P, Fres ? Fres : F.p, Fres != nullptr); return; }
     if (use_cols()) launch_assemble_cols(1, cols_args(P, F.p), stream);
+    else if (use_cols3d()) { launch_assemble_cols(1, cols_args(P, F.p), stream); launch_assemble_cols_lateral(1, gen_args(P, F.p), stream); }
     else launch_assemble_general(1, gen_args(P, F.p), stream);
     launch_bc(1, bc_args(P, F.p), stream);
     launch_sinks(1, sink_args(P, F.p), stream);
@@ -2246,15 +2267,23 @@ struct Solver {
     // rp = M^{-1} b by back substitution of the right-hand side the assembly pass forward-eliminated AND v = M^{-1} A rp in one
     // kernel (k_tri_solve_lds<..., 2>): (v,rp), (v,v), (rp,rp) come out together, one scalar step (62) runs both recurrences
     const bool first_fused = opt.fused_first && fused_spmv_pc() && b == fwd_rhs && opt.defer_test0;
+    // The line search's F . (J Y) without a product pass of its own (round 5, option ls_fold): a solve that ends with its first iteration
+    // returns Y = alpha p + omega s, and the two fused kernels of that iteration hold the rows of J p and J s in registers -- they
+    // reduce F . (J p) and F . (J s) on the way (one more 8-byte stream each), the update kernel reduces Y . Y, and the host forms
+    // alpha F.(J p) + omega F.(J s): equal to PETSc's MatMult + VecDot up to the rounding of the recombination.  Only where the search's
+    // reductions would have been issued behind this iteration anyway (ls_ahead) and ||X|| is known.
+    const bool fold_ls = first_fused && opt.ls_fold && opt.fused_waxpy && ls_ahead.armed && ls_ahead.X == nullptr && b == ls_ahead.F;
     if (first_fused) {
+      const int nv1 = fold_ls ? 4 : 3;
       {
         ProfScope ps(prof, KC_SPMV_PC);
-        const Fold fd = make_fold(tri_solve_lds_blocks(ncols), 3, 0, 62);
-        const int nbk = launch_back_spmv_tri_lds(tri_args(), fwd_elim.p, RP.p, V.p, col_partials.p, tri_scratch.p, stream, fd);
-        if (!fd.counter) finalize(nbk, 3, col_partials.p, 0, 62);
+        const Fold fd = make_fold(tri_solve_lds_blocks(ncols), nv1, 0, 62);
+        const int nbk = launch_back_spmv_tri_lds(tri_args(), fwd_elim.p, RP.p, V.p, col_partials.p, tri_scratch.p, stream, fd,
+                                                 fold_ls ? ls_ahead.F : nullptr);
+        if (!fd.counter) finalize(nbk, nv1, col_partials.p, 0, 62);
       }
       if (comm.active()) {
-        comm.allreduce_sum(sc.p + S_SUM0, 3, stream);
+        comm.allreduce_sum(sc.p + S_SUM0, nv1, stream);
         launch_bcgs_scalars(62, sc.p, stream);
         pub_valid = false;
       }
@@ -2296,14 +2325,17 @@ struct Solver {
         pub_valid = false;
       } else op_BA_dots(Pcur, V.p, RP.p, 0, -1, 2);   // (v,rp) in sc[S_SUM0]  [(v,v) in S_SUM0+1 is not used]; alpha
       int end_step = 4;
+      const bool fold_now = fold_ls && i == 0;
       if (opt.fused_waxpy && fused_spmv_pc()) {   // s = r - alpha v, t = M^{-1} A s, (t,s), (t,t): one kernel
+        const int nv2 = fold_now ? 3 : 2;
         {
           ProfScope ps(prof, KC_SPMV_PC);
-          const Fold fd = make_fold(tri_solve_lds_blocks(ncols), 2, 0, 3);
-          const int nbk = launch_waxpy_spmv_tri_lds(tri_args(), Rcur, V.p, sc.p, S.p, T.p, col_partials.p, tri_scratch.p, stream, fd);
-          if (!fd.counter) finalize(nbk, 2, col_partials.p, 0, 3);
+          const Fold fd = make_fold(tri_solve_lds_blocks(ncols), nv2, 0, 3);
+          const int nbk = launch_waxpy_spmv_tri_lds(tri_args(), Rcur, V.p, sc.p, S.p, T.p, col_partials.p, tri_scratch.p, stream, fd,
+                                                    fold_now ? ls_ahead.F : nullptr);
+          if (!fd.counter) finalize(nbk, nv2, col_partials.p, 0, 3);
         }
-        if (comm.active()) comm.allreduce_sum(sc.p + S_SUM0, 2, stream);
+        if (comm.active()) comm.allreduce_sum(sc.p + S_SUM0, nv2, stream);
         bcgs_step(3);
       } else {
         { ProfScope ps(prof, KC_VEC); launch_waxpy(nred, S.p, sc.p, S_ALPHA, -1.0, 0.0, V.p, Rcur, stream); }
@@ -2321,18 +2353,23 @@ struct Solver {
         // r = s - omega t is written only if somebody will read it: where the solve is expected to end with this iteration (the
         // line search's reductions are already queued behind it) only its norm is formed; a solve that goes on forms r then
         lazy_r = opt.lazy_r && ls_ahead.armed && i == 0;
-        const int nbk = launch_bcgs_xr(nred, i == 0, wide, x, lazy_r ? nullptr : R.p, Pcur, S.p, T.p, RP.p, sc.p, pbuf, stream);
+        const int nbk = launch_bcgs_xr(nred, i == 0, wide, x, lazy_r ? nullptr : R.p, Pcur, S.p, T.p, RP.p, sc.p, pbuf, stream, fold_now);
         // end of the iteration: dp, rhoold, omegaold (step 4) and, from the second iteration on, the next one's rho = (r,rp)
         // and beta (step 5) -- harmless when the test below ends the solve
         end_step = i == 0 ? 4 : 45;
-        pub_arm = !(ls_ahead.armed && i == 0);   // the last writer of the scalars before the read-back publishes them
-        finalize(nbk, i == 0 ? 1 : 2, pbuf, 0, end_step);
+        // the last writer of the scalars before the read-back publishes them (folded line-search sums without a speculative trial
+        // point: this reduction is the last one)
+        pub_arm = !(ls_ahead.armed && i == 0) || (fold_now && !ls_ahead.spec);
+        finalize(nbk, (i == 0 && !fold_now) ? 1 : 2, pbuf, 0, end_step);
         if (!(ls_ahead.armed && i == 0) && comm.active()) comm.allreduce_sum(sc.p + S_SUM0, i == 0 ? 1 : 2, stream);
       }
       const bool ahead = ls_ahead.armed && i == 0;
       int ahead_nv = 0;
       const bool spec = ahead && ls_ahead.spec;
-      if (ahead) {   // x is final if we stop here
+      if (ahead && fold_now) {   // ||r||^2 and Y . Y are in S_SUM0, S_SUM0 + 1; F . (J p), F . (J s) in S_FJP, S_FJS (scalar steps 62, 3)
+        ahead_nv = 1;
+        if (!spec && comm.active()) comm.allreduce_sum(sc.p + S_SUM0, 2, stream);
+      } else if (ahead) {   // x is final if we stop here
         const int nv = ls_ahead.X ? 3 : 2;
         pub_arm = !spec;
         ahead_nv = op_spmv_dots_launch(x, ls_ahead.F, ls_ahead.X, 1, spec ? 0 : 1 + nv);
@@ -2369,6 +2406,7 @@ struct Solver {
       if (reason > 0 && ahead) {
         ls_ahead.done = true;
         for (int j = 0; j < ahead_nv; ++j) ls_ahead.r3[j] = h_sc[S_SUM0 + 1 + j];
+        if (fold_now) { ls_ahead.r3[1] = h_sc[S_ALPHA] * h_sc[S_FJP] + h_sc[S_OMEGA] * h_sc[S_FJS]; ls_ahead.r3[2] = 0.0; ++ls_folds; }
         if (ls_ahead.spec_issued) {
           ls_ahead.spec_issued = false;
           ls_ahead.spec_done = true;
@@ -2457,8 +2495,7 @@ struct Solver {
             ma.n = nred; ma.nvec = std::min(kMaxMultiDot, nvt - c0);
             for (int j = 0; j < ma.nvec; ++j) ma.v[j] = vv[c0 + j].p;
             const bool last = c0 + kMaxMultiDot >= nvt;
-            // (the kernel reads its coefficients at sc[S_SUM0 + j]: handed the parked block of this chunk)
-            const int nbk = launch_maxpy_neg(ma, gs_h.p + c0 - S_SUM0, vnew, last ? xr_partials.p : nullptr, stream);
+            const int nbk = launch_maxpy_neg(ma, gs_h.p + c0, vnew, last ? xr_partials.p : nullptr, stream);   // (the parked block of this chunk)
             if (last) {
               pub_arm = true;
               finalize(nbk, 1, xr_partials.p, kNormSlot);
@@ -2484,7 +2521,7 @@ struct Solver {
           ma.n = nred; ma.nvec = it + 1;
           for (int j = 0; j <= it; ++j) ma.v[j] = vv[j].p;
           // the update also reduces ||vnew||^2 (slot kNormSlot, clear of the h_j it reads): one pass and one read-back fewer
-          const int nbk = launch_maxpy_neg(ma, sc.p, vnew, xr_partials.p, stream);
+          const int nbk = launch_maxpy_neg(ma, sc.p + S_SUM0, vnew, xr_partials.p, stream);
           pub_arm = true;
           finalize(nbk, 1, xr_partials.p, kNormSlot);
           if (comm.active()) comm.allreduce_sum(sc.p + S_SUM0 + kNormSlot, 1, stream);
@@ -2806,7 +2843,13 @@ struct Solver {
     bool jac_valid = false;
     if (opt.fused_assembly) { op_residual_jacobian(X, Fv); jac_valid = true; } else op_residual(X, Fv);
     double fnorm;
-    if (asm_sums) { double r2[2]; residual_sums(X, Fv, r2); fnorm = std::sqrt(r2[0]); } else fnorm = norm_host(Fv);
+    bool xnorm0_known = false;   // ||X|| of the first iteration's line search from the assembly pass that also reduced ||F|| (option ls_fold)
+    if (asm_sums) {
+      double r2[2];
+      residual_sums(X, Fv, r2);
+      fnorm = std::sqrt(r2[0]);
+      if (opt.ls_fold) { xnorm = std::sqrt(r2[1]); xnorm0_known = true; }
+    } else fnorm = norm_host(Fv);
     int reason = snes_converged(0, 0.0, 0.0, fnorm, ttol, rnorm0);
     for (int i = 0; !reason && i < opt.snes_max_it; ++i) {
       if (!jac_valid) op_jacobian(X, Fv);
@@ -2814,7 +2857,7 @@ struct Solver {
       ls_trace_it = i;
       ls_ahead.armed = opt.ls_ahead && ksp_one_shot && opt.ksp_type == 2 && spmv_dots_fused() && opt.linesearch_type == 2;
       ls_ahead.done = false; ls_ahead.spec_done = false; ls_ahead.spec_issued = false;
-      ls_ahead.F = Fv; ls_ahead.X = i > 0 ? nullptr : X;
+      ls_ahead.F = Fv; ls_ahead.X = (i > 0 || xnorm0_known) ? nullptr : X;
       ls_ahead.spec = ls_ahead.armed && opt.ls_spec && rows_complete();
       ls_ahead.Xv = X; ls_ahead.Wv = Wv; ls_ahead.Gv = Gv;
       const int kreason = ksp_solve(Fv, Yv, &its);
@@ -2828,7 +2871,7 @@ struct Solver {
         case 1: lsfail = linesearch_basic(X, Fv, Yv, Wv, Gv, fnorm, xnorm, ynorm, jac_valid); break;
         case 3: lsfail = linesearch_l2(X, Fv, Yv, Wv, Gv, fnorm, xnorm, ynorm, jac_valid); break;
         case 4: lsfail = linesearch_cp(X, Fv, Yv, Wv, Gv, fnorm, xnorm, ynorm, jac_valid, ls_reason); break;
-        default: lsfail = linesearch_bt(X, Fv, Yv, Wv, Gv, fnorm, xnorm, ynorm, jac_valid, i > 0); ls_ynorm = ynorm; break;
+        default: lsfail = linesearch_bt(X, Fv, Yv, Wv, Gv, fnorm, xnorm, ynorm, jac_valid, i > 0 || xnorm0_known); ls_ynorm = ynorm; break;
       }
       if (ls_reason) { reason = ls_reason; break; }                 // if (snes->reason) break;
       if (!std::isfinite(fnorm)) { reason = -4; break; }            // SNESCheckFunctionNorm
@@ -3629,6 +3672,8 @@ struct Solver {
     else if (key == "host_poll") opt.host_poll = num() != 0;
     else if (key == "collective_timeout") opt.collective_timeout = num();
     else if (key == "ls_spec") opt.ls_spec = num() != 0;
+    else if (key == "ls_fold") opt.ls_fold = num() != 0;
+    else if (key == "cols3d") opt.cols3d = num() != 0;
     else if (key == "ls_trace") opt.ls_trace = num() != 0;   // one line per bt line search on stderr (development aid)
     else if (key == "fused_spmv_pc") opt.fused_spmv_pc = num() != 0;
     else if (key == "fused_first") opt.fused_first = num() != 0;
@@ -4097,12 +4142,13 @@ int mppgpu_get_assembly_info(mppgpu_handle h, int n, int *info) {
   API_BEGIN(h)
   S.ensure_ready();
   const bool cols = S.use_cols() && !S.th && !S.thermal;
-  const int v[12] = {cols ? S.ncls : 0, cols && S.lev_geo ? 1 : 0, cols && S.lev_pv ? 1 : 0, cols && S.rows_complete() ? 1 : 0,
+  const int v[14] = {cols ? S.ncls : 0, cols && S.lev_geo ? 1 : 0, cols && S.lev_pv ? 1 : 0, cols && S.rows_complete() ? 1 : 0,
                      cols ? S.pick_nseg() : 0, S.spmv_variant(), (S.opt.pc_type == 2 && !S.th && S.tri_lds()) ? 1 : 0,
                      (int)std::min<long long>(S.spec_misses, 2147483647LL), S.opt.ilu_graph ? 1 : 0,
                      (int)(S.box_graph.execs.size() + S.ilu_graph.execs.size()), S.setup_verified,
-                     (S.opt.fused_ls_dots && (S.cols_index_free() || S.th_index_free())) ? 1 : 0};
-  for (int i = 0; i < n && i < 12; ++i) info[i] = v[i];
+                     (S.opt.fused_ls_dots && (S.cols_index_free() || S.th_index_free())) ? 1 : 0,
+                     (int)std::min<long long>(S.ls_folds, 2147483647LL), S.use_cols3d() ? 1 : 0};
+  for (int i = 0; i < n && i < 14; ++i) info[i] = v[i];
   API_END()
 }
 int mppgpu_get_pc_info(mppgpu_handle h, int *path, int *launches, int *box_extents) {

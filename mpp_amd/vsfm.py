@@ -239,11 +239,11 @@ class SystemOfEquationsVSFM:
 
     def assembly_info(self):
         """layout and kernel selection of this handle (mppgpu_get_assembly_info)"""
-        v = (ct.c_int * 12)()
-        self._chk(self.L.mppgpu_get_assembly_info(self.h, 12, v))
+        v = (ct.c_int * 14)()
+        self._chk(self.L.mppgpu_get_assembly_info(self.h, 14, v))
         keys = ("soil_classes", "level_geometry", "level_porosity_volume", "complete_rows", "column_segments", "spmv_variant",
                 "column_solve_in_lds", "speculative_trials_discarded", "ilu_graph_replay", "ilu_graphs_instantiated",
-                "setup_structures_verified", "line_search_product_index_free")
+                "setup_structures_verified", "line_search_product_index_free", "line_search_sums_folded", "columns_plus_lateral_assembly")
         return dict(zip(keys, (int(x) for x in v)))
 
     def pc_info(self):

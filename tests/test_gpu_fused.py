@@ -147,7 +147,7 @@ def test_spmv_fused_with_the_column_solve_changes_no_bit(ncols, nz, ksp):
         act = np.ones(n, dtype=np.int32)
         act[[1, nz, 2 * nz + 1]] = 0
         prob.mesh.is_active = act
-    base = dict(ROWS, ksp_type=ksp, tri_lds=1)
+    base = dict(ROWS, ksp_type=ksp, tri_lds=1, ls_fold=0)   # (ls_fold recombines the search's F . (J Y): rounding, its own test below)
     # all three fused (the default: the solve's first kernel also does the back substitution of the forward-eliminated residual),
     # the two products fused only, nothing fused
     # (also: s = r - alpha v formed inside the kernel of the second product, fused_waxpy)
@@ -177,7 +177,7 @@ def test_a_krylov_solve_that_goes_on_discards_the_speculative_work():
     ksp_rtol the first iteration cannot reach -- all of that is void: the matrix and factors are assembled again, r is formed, the
     function evaluation is not counted.  Same decisions, counters and pressures as the plain sequence of operations"""
     prob, x = _hetero(ncols=70, nz=19, seed=41)
-    big = dict(ROWS, spmv_variant=20, tri_lds=1)   # the kernels a large grid selects by itself (the look-ahead needs the compact-index SpMV)
+    big = dict(ROWS, spmv_variant=20, tri_lds=1, ls_fold=0)   # the kernels a large grid selects by itself (the look-ahead needs the compact-index SpMV)
     gs = [P.to_gpu(prob, dict(big, **o)) for o in ({}, {"ls_spec": 0, "ls_ahead": 0, "lazy_r": 0, "fused_first": 0, "fused_spmv_pc": 0})]
     out = []
     for g in gs:
@@ -223,3 +223,45 @@ def test_elimination_factors_rebuilt_on_demand_are_the_ones_the_march_would_have
     assert lazy.soe.counters() == stored.soe.counters()
     assert np.array_equal(lazy.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1),
                           stored.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1))
+
+
+@pytest.mark.parametrize("ncols,nz,spec", [(70, 19, 1), (200, 50, 1), (130, 7, 0), (64, 3, 1)])
+def test_line_search_sums_out_of_the_krylov_kernels(ncols, nz, spec):
+    """Round 5 (option ls_fold): when a BiCGStab solve ends with its first iteration, Y = alpha p + omega s, and the two fused product
+    kernels of that iteration held the rows of J p and J s in registers -- they reduce F . (J p) and F . (J s) on the way, the update
+    kernel reduces Y . Y, and the line search takes F . (J Y) = alpha F.(J p) + omega F.(J s) from the host instead of launching a
+    product pass of its own.  Equal to MatMult + VecDot up to the rounding of the recombination: same Newton / linear / function
+    counts as the separate pass, pressures equal to 1e-12, and both as close to the oracle; a solve that goes on (second step:
+    ksp_rtol out of reach) falls back to the product pass"""
+    prob, x = _hetero(ncols=ncols, nz=nz, seed=53)
+    base = dict(ROWS, tri_lds=1, ls_spec=spec)
+    on, off = P.to_gpu(prob, dict(base, ls_fold=1)), P.to_gpu(prob, dict(base, ls_fold=0))
+    o = P.to_oracle(prob)
+    o.set_solver(C.KSP_BCGS, C.PC_BJACOBI)
+    for s in range(3):
+        r_on, r_off = on.soe.StepDT(prob.dt, s + 1), off.soe.StepDT(prob.dt, s + 1)
+        assert r_on == r_off == tuple(o.step_dt(prob.dt, s + 1))
+    assert on.soe.counters() == off.soe.counters()
+    assert on.soe.counters()["newton"] == o.counters()["newton"]
+    folds = on.soe.assembly_info()["line_search_sums_folded"]
+    assert folds > 0 and off.soe.assembly_info()["line_search_sums_folded"] == 0
+    # every Newton iteration but the first of a run (the look-ahead is armed by a one-iteration solve) took its sums from the solve
+    assert folds >= on.soe.counters()["newton"] - 3
+    p_on = on.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1)
+    p_off = off.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1)
+    p_o = o.get(C.AUXVAR_INTERNAL, C.VAR_PRESSURE)
+    assert np.abs(p_on - p_off).max() <= 1e-12 * np.abs(p_off).max()
+    assert np.abs(p_on - p_o).max() <= 1e-9 * np.abs(p_o).max()
+    # the product launches of the search are gone where the fold ran (profile: the library counts the launches of a kernel class)
+    for g in (on, off):
+        g.soe.SetOption("profile", 1); g.soe.reset_stats()
+        assert g.soe.StepDT(prob.dt, 4)[0]
+    assert on.soe.kernel_stats("spmv")["calls"] < off.soe.kernel_stats("spmv")["calls"]
+    # a solve that needs a second iteration: the folded sums are void, the search launches its product
+    for g in (on, off):
+        g.soe.SetOption("ksp_rtol", 1e-17)
+    r = [g.soe.StepDT(prob.dt, 5) for g in (on, off)]
+    assert r[0] == r[1]
+    assert on.soe.counters() == off.soe.counters()
+    assert np.abs(on.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1)
+                  - off.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1)).max() <= 1e-12 * np.abs(p_off).max()

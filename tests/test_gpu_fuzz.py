@@ -144,7 +144,8 @@ def test_random_vsfm_problem_matches_the_oracle(seed):
 
 # ---- 3-D grids (the v-channel mesh family: 7-point stencil, sloping surface, gravity along every connection) ----
 ROUTES_3D = [{}, {"ilu_box": 0}, {"ilu_box": 0, "ilu_chain": 1}, {"ilu_graph": 0}, {"spmv_variant": 0}, {"spmv_variant": 1},
-             {"ilu_box": 1, "ilu_box_len": 4}, {"host_poll": 0}]
+             {"ilu_box": 1, "ilu_box_len": 4}, {"host_poll": 0}, {"cols3d": 0}, {"assembly": "general"}, {"cols3d": 1, "nseg": 2}]
+# (default since round 5: the column march + lateral pass, Solver::use_cols3d; cols3d = 0 / assembly = general: the auxvar pass + row gather)
 SOLVERS_3D = [("gmres", "ilu", C.KSP_GMRES, C.PC_ILU0), ("bcgs", "ilu", C.KSP_BCGS, C.PC_ILU0), ("gmres", "jacobi", C.KSP_GMRES, C.PC_JACOBI)]
 
 
@@ -200,8 +201,14 @@ def test_random_3d_vsfm_problem_matches_the_oracle(seed):
     prob, x, opts, (oksp, opc), what = draw3d(seed)
     o, g, _csr, _v = _operator_parity(prob, x, opts)
     o.set_solver(oksp, opc)
-    res_g = [g.soe.StepDT(prob.dt, s + 1) for s in range(2)]
-    res_o = [tuple(o.step_dt(prob.dt, s + 1)) for s in range(2)]
+    # No boundary condition + incompressible water: the Jacobian is singular up to a constant wherever the soil is saturated, and the
+    # v-channel has drained to rest after one step -- the second step's right-hand side is rounding noise (max |F| ~ 5e-13 of fluxes
+    # ~ 1e-3: measured, tools/dbg/r05_dbg3.py) and whether a Krylov solve on that noise ends as "converged" or "diverged" is decided
+    # by the last bit of the residual (the column march + lateral pass sums a row in another order than the general route: seeds 25,
+    # 34 flipped).  Those draws are compared over the first step only; test_random_split_3d_... swaps the density for the same reason.
+    nsteps = 1 if (prob.density_type == C.DENSITY_CONSTANT and not prob.bcs) else 2
+    res_g = [g.soe.StepDT(prob.dt, s + 1) for s in range(nsteps)]
+    res_o = [tuple(o.step_dt(prob.dt, s + 1)) for s in range(nsteps)]
     cg, co = g.soe.counters(), o.counters()
     p_o, p_g = o.get(C.AUXVAR_INTERNAL, C.VAR_PRESSURE), g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1)
     if co["linear"] > 500 * max(1, co["newton"]):

@@ -390,7 +390,7 @@ def test_vsfm_mms_analytic_check_through_the_abi(sat):
     errs = []
     for nx in (20, 40, 80, 160):
         pr = P.vsfm_mms(nx, sat)
-        h = P.to_gpu(pr, {"snes_rtol": 1e-12, "snes_stol": 1e-13, "ksp_rtol": 1e-12})
+        h = P.to_gpu(pr, {"snes_rtol": 1e-10, "snes_stol": 1e-12, "ksp_rtol": 1e-10})
         h.soe.PreStepDT()
         conv, reason = h.soe.StepDT(pr.dt, 1)
         assert conv and reason > 0
@@ -406,7 +406,7 @@ def test_vsfm_mms_many_columns_side_by_side():
     kernels run more than one block; every row reproduces the single column's answer"""
     nx, ny = 40, 70
     one = P.vsfm_mms(nx)
-    g1 = P.to_gpu(one, {"snes_rtol": 1e-12, "snes_stol": 1e-13, "ksp_rtol": 1e-12})
+    g1 = P.to_gpu(one, {"snes_rtol": 1e-10, "snes_stol": 1e-12, "ksp_rtol": 1e-10})
     g1.soe.PreStepDT()
     assert g1.soe.StepDT(one.dt, 1)[0]
     p1 = g1.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1)
@@ -426,7 +426,7 @@ def test_vsfm_mms_many_columns_side_by_side():
                      alpha=tile(one.alpha), lam=tile(one.lam), sat_res=tile(one.sat_res), density_type=one.density_type,
                      press_ic=tile(one.press_ic), bcs=[(C.COND_DIRICHLET, ends, np.concatenate([np.full(ny, bcv[0]), np.full(ny, bcv[1])]))],
                      sss=[(C.COND_MASS_RATE, allcells, tile(one.sss[0][2]))], dt=1.0, nstep=1)
-    g = P.to_gpu(prob, {"snes_rtol": 1e-12, "snes_stol": 1e-13, "ksp_rtol": 1e-12})
+    g = P.to_gpu(prob, {"snes_rtol": 1e-10, "snes_stol": 1e-12, "ksp_rtol": 1e-10})
     g.soe.PreStepDT()
     assert g.soe.StepDT(prob.dt, 1)[0]
     p = g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE, -1).reshape(ny, nx)
