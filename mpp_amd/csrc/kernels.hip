@@ -2735,6 +2735,7 @@ __device__ void bcgs_scalar_step(int step, double *sc) {
     const double d1 = sc[S_SUM0];
     sc[S_D1] = d1;
     sc[S_ALPHA] = sc[S_RHO] / d1;
+    sc[S_FJP] = sc[S_SUM0 + 2];   // F . (J p) when the product kernel reduced it as its third sum (coupled system, ls_fold); else not read
   } else if (step == 3) {  // d1 = (s,t), d2 = (t,t); omega = d1/d2
     const double d1 = sc[S_SUM0], d2 = sc[S_SUM0 + 1];
     sc[S_ST] = d1; sc[S_D2] = d2;

@@ -434,7 +434,9 @@ void launch_th_spmv_cols(const ThTriArgs &a, const double *x, double *y, hipStre
 int th_spmv_dots_blocks(int n);
 int launch_th_spmv_cols_dots(const ThTriArgs &a, const double *x, const double *f, const double *q, double *partials, hipStream_t stream);
 // z = M^{-1} (A x) with its dot products (w: z.w and z.z; else z.z), A x never written; partials as launch_th_tri_solve_dots; returns the blocks
-int launch_th_spmv_tri(const ThTriArgs &a, const double *x, double *z, const double *w, double *partials, hipStream_t stream);
+// fdot != nullptr (with w): also the partial sums of fdot . (A x) over both fields, row 2 of `partials`
+int launch_th_spmv_tri(const ThTriArgs &a, const double *x, double *z, const double *w, double *partials, hipStream_t stream,
+                       const double *fdot = nullptr);
 void launch_th_tri_solve(const ThTriArgs &a, const double *r, double *z, hipStream_t stream);   // r, z: [P; T]
 // ... with the partial sums of z.z (w == nullptr) or of z.w and z.z over both fields, one per block of 256 columns (returns the
 // number of blocks; layout partials[j * blocks + block]); finish with launch_finalize

@@ -1884,6 +1884,11 @@ struct Solver {
   // event records next to the replays are what made it happen within a run: chunk sizes did not matter (16-node chunks died too), so
   // the chunking is not a remedy.  The remedy taken: while the library's own event profiling is on (option "profile"), the
   // sequences are issued launch by launch -- one packet per submission cannot wrap -- and replayed as graphs otherwise.
+  // That keys on THIS library's profiling, not on the tool's presence (the library does not look at the environment): a run under
+  // rocprofv3 with the library's events OFF still replays graphs and can still meet the interceptor's bug -- such runs pass
+  // ilu_graph=0 (the scripts under tools/gpu/ do).  Round 5 re-ran the combination that crashed with the
+  // remedy in place (events on, per-level box solves, rocprofv3 --kernel-trace --stats): exit code 0,
+  // profiles/r05/rocprofv3_graph_events_on.log.
   void graph_chunk_begin() {
     HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
     cap_nodes = 0;
@@ -1985,14 +1990,16 @@ struct Solver {
   bool th_fused_spmv_tri() const {
     return opt.th_spmv_tri && th_index_free() && pc_ready && fused_pc_dots();
   }
-  void op_BA_dots(const double *v, double *t, const double *w, int slot = 0, int nreduce = -1, int step = -1) {
+  // fdot (coupled system's fused kernel only, with w): a third sum, fdot . (A v), lands in sc[S_SUM0 + slot + 2] (ls_fold)
+  void op_BA_dots(const double *v, double *t, const double *w, int slot = 0, int nreduce = -1, int step = -1, const double *fdot = nullptr) {
     if (th_fused_spmv_tri()) {
+      const int nv = (w ? 2 : 1) + ((fdot && w) ? 1 : 0);
       {
         ProfScope ps(prof, KC_SPMV_PC);
-        const int nbk = launch_th_spmv_tri(th_tri_args(), v, t, w, col_partials.p, stream);
-        finalize(nbk, w ? 2 : 1, col_partials.p, slot, step);
+        const int nbk = launch_th_spmv_tri(th_tri_args(), v, t, w, col_partials.p, stream, w ? fdot : nullptr);
+        finalize(nbk, nv, col_partials.p, slot, step);
       }
-      if (nreduce < 0) nreduce = w ? 2 : 1;
+      if (nreduce < 0) nreduce = nv;
       if (comm.active() && nreduce > 0) comm.allreduce_sum(sc.p + S_SUM0, nreduce, stream);
       bcgs_step(step);
       return;
@@ -2272,7 +2279,8 @@ struct Solver {
     // reduce F . (J p) and F . (J s) on the way (one more 8-byte stream each), the update kernel reduces Y . Y, and the host forms
     // alpha F.(J p) + omega F.(J s): equal to PETSc's MatMult + VecDot up to the rounding of the recombination.  Only where the search's
     // reductions would have been issued behind this iteration anyway (ls_ahead) and ||X|| is known.
-    const bool fold_ls = first_fused && opt.ls_fold && opt.fused_waxpy && ls_ahead.armed && ls_ahead.X == nullptr && b == ls_ahead.F;
+    const bool fold_th = th && th_fused_spmv_tri() && opt.ls_fold && !comm.active() && ls_ahead.armed && ls_ahead.X == nullptr && b == ls_ahead.F;
+    const bool fold_ls = (first_fused && opt.ls_fold && opt.fused_waxpy && ls_ahead.armed && ls_ahead.X == nullptr && b == ls_ahead.F) || fold_th;
     if (first_fused) {
       const int nv1 = fold_ls ? 4 : 3;
       {
@@ -2323,7 +2331,7 @@ struct Solver {
         launch_bcgs_scalars(6, sc.p, stream);
         launch_bcgs_scalars(2, sc.p, stream);
         pub_valid = false;
-      } else op_BA_dots(Pcur, V.p, RP.p, 0, -1, 2);   // (v,rp) in sc[S_SUM0]  [(v,v) in S_SUM0+1 is not used]; alpha
+      } else op_BA_dots(Pcur, V.p, RP.p, 0, -1, 2, (fold_th && i == 0) ? ls_ahead.F : nullptr);   // (v,rp) in sc[S_SUM0]  [(v,v) in S_SUM0+1 is not used]; alpha
       int end_step = 4;
       const bool fold_now = fold_ls && i == 0;
       if (opt.fused_waxpy && fused_spmv_pc()) {   // s = r - alpha v, t = M^{-1} A s, (t,s), (t,t): one kernel
@@ -2339,7 +2347,7 @@ struct Solver {
         bcgs_step(3);
       } else {
         { ProfScope ps(prof, KC_VEC); launch_waxpy(nred, S.p, sc.p, S_ALPHA, -1.0, 0.0, V.p, Rcur, stream); }
-        op_BA_dots(S.p, T.p, S.p, 0, -1, 3);    // (t,s), (t,t) in sc[S_SUM0], sc[S_SUM0+1]; omega
+        op_BA_dots(S.p, T.p, S.p, 0, -1, 3, (fold_th && i == 0) ? ls_ahead.F : nullptr);    // (t,s), (t,t) in sc[S_SUM0], sc[S_SUM0+1]; omega
       }
       {
         ProfScope ps(prof, KC_REDUCE);

@@ -585,15 +585,18 @@ __global__ __launch_bounds__(kBlock) void k_th_tri_solve_dots(ThTriArgs a, const
 // (staged through LDS as in k_th_spmv_cols, the next level's pieces already in flight) and three levels of x kept in registers;
 // A x is never written or read back (32 of the pair's 304 bytes per cell).  Row sums in the entry order of k_th_spmv_cols, the
 // elimination in the order of th_tri_forward_column: the same bits as the two kernels.
-template <int ND>
+// FDOT (round 5): the partial sums of fdot . (A x) over both fields as well, in row ND of `partials` -- the line search's F . (J p) /
+// F . (J s) of a one-iteration BiCGStab solve out of the kernels that hold those rows anyway (Solver::ksp_bcgs, ls_fold)
+template <int ND, bool FDOT = false>
 __global__ __launch_bounds__(kBlock) void k_th_spmv_tri(ThTriArgs a, const double *__restrict__ x, double *__restrict__ z,
-                                                        const double *__restrict__ w, double *__restrict__ partials) {
+                                                        const double *__restrict__ w, double *__restrict__ partials,
+                                                        const double *__restrict__ fdot) {
 #pragma clang fp contract(off)
   typedef double dpair __attribute__((ext_vector_type(2)));
   __shared__ dpair stage[kBlock / 64][2][64 * 3];
   __shared__ double lds[kBlock / 64];
   const int c = blockIdx.x * kBlock + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double acc0 = 0.0, acc1 = 0.0;
+  double acc0 = 0.0, acc1 = 0.0, accf = 0.0;
   if (c - lane < a.ncols) {   // (the whole wave)
     const bool live = c < a.ncols;
     const int tile = c >> 6, tw = min(64, a.ncols - (tile << 6));
@@ -670,6 +673,7 @@ __global__ __launch_bounds__(kBlock) void k_th_spmv_tri(ThTriArgs a, const doubl
       }
 #undef TH_ROW_PRODUCT
       if (live) {
+        if (FDOT) { accf += fdot[i] * sp; accf += fdot[n + i] * st; }   // (the two rows of A x of this cell meet fdot)
         const double np = sp - (l.pp * dp + l.pt * dt);
         const double nt = st - (l.tp * dp + l.tt * dt);
         z[i] = np; z[n + i] = nt;
@@ -693,6 +697,10 @@ __global__ __launch_bounds__(kBlock) void k_th_spmv_tri(ThTriArgs a, const doubl
   if (ND == 2) {
     const double t1 = block_total(acc1);
     if (threadIdx.x == 0) partials[(size_t)gridDim.x + blockIdx.x] = t1;
+  }
+  if (FDOT) {
+    const double t2 = block_total(accf);
+    if (threadIdx.x == 0) partials[(size_t)ND * gridDim.x + blockIdx.x] = t2;
   }
 }
 
@@ -834,11 +842,12 @@ int launch_th_spmv_cols_dots(const ThTriArgs &a, const double *x, const double *
 void launch_th_tri_solve(const ThTriArgs &a, const double *r, double *z, hipStream_t stream) {
   if (a.ncols > 0) TH_LAUNCH(k_th_tri_solve, nblk(a.ncols), a, r, z);
 }
-int launch_th_spmv_tri(const ThTriArgs &a, const double *x, double *z, const double *w, double *partials, hipStream_t stream) {
+int launch_th_spmv_tri(const ThTriArgs &a, const double *x, double *z, const double *w, double *partials, hipStream_t stream, const double *fdot) {
   if (a.ncols <= 0) return 0;
   const dim3 grid = nblk(a.ncols);
-  if (w) TH_LAUNCH(k_th_spmv_tri<2>, grid, a, x, z, w, partials);
-  else TH_LAUNCH(k_th_spmv_tri<1>, grid, a, x, z, w, partials);
+  if (w && fdot) TH_LAUNCH((k_th_spmv_tri<2, true>), grid, a, x, z, w, partials, fdot);
+  else if (w) TH_LAUNCH(k_th_spmv_tri<2>, grid, a, x, z, w, partials, (const double *)nullptr);
+  else TH_LAUNCH(k_th_spmv_tri<1>, grid, a, x, z, w, partials, (const double *)nullptr);
   return (int)grid.x;
 }
 int launch_th_tri_solve_dots(const ThTriArgs &a, const double *r, double *z, const double *w, double *partials, hipStream_t stream) {
