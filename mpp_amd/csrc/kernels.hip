@@ -2950,11 +2950,35 @@ void launch_assemble_general(int mode, const GenArgs &a, hipStream_t stream) {
   else { LAUNCH(k_auxvars<2>, grid, a); LAUNCH(k_flux_rows<2>, grid, a); }
 }
 
+// the lateral entries of the K-wide ELL incidence lists, compacted into KL-wide ones (order kept); *overflow: a row has more than KL
+__global__ __launch_bounds__(kBlock) void k_ell_lateral(int n, int K, const int *__restrict__ enc, const int *__restrict__ oth,
+                                                        const int *__restrict__ slot, int KL, int *__restrict__ lenc, int *__restrict__ loth,
+                                                        int *__restrict__ lslot, int *overflow) {
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x, N = (size_t)n;
+  if (i >= N) return;
+  int j = 0;
+  for (int k = 0; k < K; ++k) {
+    const int e = enc[k * N + i];
+    if (e < 0 || (e >> 1) < n) continue;   // absent, or a chain link (connection index below n: the column march's)
+    if (j < KL) { lenc[j * N + i] = e; loth[j * N + i] = oth[k * N + i]; lslot[j * N + i] = slot[k * N + i]; }
+    ++j;
+  }
+  if (j > KL) *overflow = 1;
+  for (; j < KL; ++j) { lenc[j * N + i] = -1; loth[j * N + i] = 0; lslot[j * N + i] = -1; }
+}
+void launch_ell_lateral(int n, int K, const int *enc, const int *oth, const int *slot, int KL, int *lenc, int *loth, int *lslot, int *overflow,
+                        hipStream_t stream) {
+  if (n > 0) LAUNCH(k_ell_lateral, dim3(nblk(n)), n, K, enc, oth, slot, KL, lenc, loth, lslot, overflow);
+}
+
 void launch_assemble_cols_lateral(int mode, const GenArgs &a, hipStream_t stream) {
   if (a.n <= 0) return;
   if (!a.ell_enc || a.ell_k > 8) throw std::runtime_error("internal: the lateral pass needs the ELL incidence lists");
   dim3 grid(nblk(a.n));
-  if (a.ell_k <= 6) {
+  if (a.ell_k <= 4) {   // (the compacted lateral lists: four gathers per row instead of six, fewer registers)
+    if (mode == 0) LAUNCH((k_flux_rows_ell<0, 4, true>), grid, a); else if (mode == 1) LAUNCH((k_flux_rows_ell<1, 4, true>), grid, a);
+    else LAUNCH((k_flux_rows_ell<2, 4, true>), grid, a);
+  } else if (a.ell_k <= 6) {
     if (mode == 0) LAUNCH((k_flux_rows_ell<0, 6, true>), grid, a); else if (mode == 1) LAUNCH((k_flux_rows_ell<1, 6, true>), grid, a);
     else LAUNCH((k_flux_rows_ell<2, 6, true>), grid, a);
   } else {

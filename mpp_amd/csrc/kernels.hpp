@@ -130,6 +130,9 @@ void launch_assemble_general(int mode, const GenArgs &a, hipStream_t stream);
 // every row adds the fluxes of its lateral connections (the ELL incidence lists, entries of chain links skipped: their connection
 // index is below n) to F and to its diagonal, writes its off-column entries, and subtracts the source term
 void launch_assemble_cols_lateral(int mode, const GenArgs &a, hipStream_t stream);
+// set-up: the lateral entries of the K-wide ELL lists compacted into KL-wide ones ([j*n + row], -1 padded); *overflow = 1 if a row has more
+void launch_ell_lateral(int n, int K, const int *enc, const int *oth, const int *slot, int KL, int *lenc, int *loth, int *lslot, int *overflow,
+                        hipStream_t stream);
 
 // ---- boundary conditions: one thread per cell that carries at least one BC connection ----
 struct BcArgs {

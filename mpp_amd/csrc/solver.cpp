@@ -137,6 +137,8 @@ struct Solver {
   DevBuf<int> d_cup, d_cdn;
   DevBuf<int> d_rowptr, d_col, d_diag, d_rc_ptr, d_rc_conn, d_rc_slot, d_tri_lo, d_tri_up, d_ell_enc, d_ell_o, d_ell_slot;
   int ell_k = 0;   // incident connections per row in the ELL copy (0: none)
+  DevBuf<int> d_lat_enc, d_lat_o, d_lat_slot;   // the lateral entries of those lists, four wide (3-D meshes of complete columns)
+  int lat_k = 0;
   DevBuf<double> d_val;
   // compact SpMV index (see k_spmv_pipe_c): built when the pattern allows it
   DevBuf<int> d_tileptr;
@@ -1067,6 +1069,18 @@ struct Solver {
     ptc.reset();
     { PhaseTimer pt("setup: SpMV indices"); build_compact_index(); build_multibase_index(); }
     plan_complete_rows();
+    lat_k = 0;
+    if (columns && !vertical_only && !th && !thermal && nghost == 0 && ell_k > 4 && ell_k <= 8) {   // lateral pass of use_cols3d(): <= 4 laterals per row
+      const size_t cnt = 4 * (size_t)n;
+      d_lat_enc.alloc(cnt); d_lat_o.alloc(cnt); d_lat_slot.alloc(cnt);
+      DevBuf<int> ovf;
+      ovf.alloc(1); ovf.zero(stream);
+      launch_ell_lateral(n, ell_k, d_ell_enc.p, d_ell_o.p, d_ell_slot.p, 4, d_lat_enc.p, d_lat_o.p, d_lat_slot.p, ovf.p, stream);
+      int h = 0;
+      HIP_CHECK(hipMemcpyAsync(&h, ovf.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+      HIP_CHECK(hipStreamSynchronize(stream));
+      if (!h) lat_k = 4; else { d_lat_enc.release(); d_lat_o.release(); d_lat_slot.release(); }
+    }
     if (nghost > 0) {
       halo.d_send_idx.upload(halo.send_cells, stream);
       halo.sendbuf.alloc(std::max<size_t>(halo.send_cells.size(), 1));
@@ -1472,6 +1486,11 @@ struct Solver {
     a.F = Fout; a.val = d_val.p; a.n = n; a.dtInv = 1.0 / dtime;
     return a;
   }
+  GenArgs lat_args(const double *P, double *Fout) const {   // the lateral pass of use_cols3d(): the compacted lists where they exist
+    GenArgs a = gen_args(P, Fout);
+    if (lat_k > 0) { a.ell_enc = d_lat_enc.p; a.ell_o = d_lat_o.p; a.ell_slot = d_lat_slot.p; a.ell_k = lat_k; }
+    return a;
+  }
   BcArgs bc_args(const double *P, double *Fout) const {
     BcArgs a;
     a.cell = cells(P);
@@ -1514,7 +1533,7 @@ struct Solver {
     if (Fout == fwd_rhs) fwd_rhs = nullptr;
     if (rows_complete()) { assemble_complete_rows(0, P, Fout); ++nfuncs; ++cum_funcs; return; }
     if (use_cols()) launch_assemble_cols(0, cols_args(P, Fout), stream);
-    else if (use_cols3d()) { launch_assemble_cols(0, cols_args(P, Fout), stream); launch_assemble_cols_lateral(0, gen_args(P, Fout), stream); }
+    else if (use_cols3d()) { launch_assemble_cols(0, cols_args(P, Fout), stream); launch_assemble_cols_lateral(0, lat_args(P, Fout), stream); }
     else {
       if (!d_rc_ptr.p) throw Error("option assembly=general must be set before mppgpu_setup");
       launch_assemble_general(0, gen_args(P, Fout), stream);
@@ -1581,7 +1600,7 @@ struct Solver {
     fwd_rhs = nullptr;
     if (rows_complete()) { assemble_complete_rows(2, P, Fout); ++nfuncs; ++cum_funcs; return; }
     if (use_cols()) launch_assemble_cols(2, cols_args(P, Fout), stream);
-    else if (use_cols3d()) { launch_assemble_cols(2, cols_args(P, Fout), stream); launch_assemble_cols_lateral(2, gen_args(P, Fout), stream); }
+    else if (use_cols3d()) { launch_assemble_cols(2, cols_args(P, Fout), stream); launch_assemble_cols_lateral(2, lat_args(P, Fout), stream); }
     else {
       if (!d_rc_ptr.p) throw Error("option assembly=general must be set before mppgpu_setup");
       launch_assemble_general(2, gen_args(P, Fout), stream);
@@ -1600,7 +1619,7 @@ struct Solver {
     if (th) { launch_th_assemble(2, th_args(P, th_scratch.p), stream); ghost_zero(P); pc_ready = false; return; }
     if (rows_complete()) { assemble_complete_rows(1, P, Fres ? Fres : F.p, Fres != nullptr); return; }
     if (use_cols()) launch_assemble_cols(1, cols_args(P, F.p), stream);
-    else if (use_cols3d()) { launch_assemble_cols(1, cols_args(P, F.p), stream); launch_assemble_cols_lateral(1, gen_args(P, F.p), stream); }
+    else if (use_cols3d()) { launch_assemble_cols(1, cols_args(P, F.p), stream); launch_assemble_cols_lateral(1, lat_args(P, F.p), stream); }
     else launch_assemble_general(1, gen_args(P, F.p), stream);
     launch_bc(1, bc_args(P, F.p), stream);
     launch_sinks(1, sink_args(P, F.p), stream);

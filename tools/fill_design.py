@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Fill the measured numbers of DESIGN.md from the evidence files of a round (the @@NAME@@ placeholders of DESIGN.md.in).
 
-    python3 tools/fill_design.py profiles/r04_evidence > DESIGN.md
+    python3 tools/fill_design.py profiles/r05_evidence > DESIGN.md
 
 Reads bench.json, bench2.json, bench_256x256x50*.json, bench_1024x128x100.json, kernel_traffic.json,
 rocprofv3_kernel_stats_bench.csv, th_512x512x80.json, thermal_512.json, pmc_th_512x512x80.json, pmc_thermal_512.json and the
@@ -58,12 +58,15 @@ def main():
         row("k_spmv_cols_dots", "PETSc `MatMult` + the line search's `VecDot` / `VecNorm`s (A x not written), from the CSR values at their computed places — the product launches of a Newton iteration on soil columns; **the `roofline` kernel**", bspmv),
         row("k_spmv_c<3, false, true>", "… on the compact 16-bit index (grids that are not soil columns)", bspmv),
         row("k_spmv_c<3, false, false>", "PETSc `MatMult_SeqAIJ` (y = A x): multi-iteration Krylov solves, 3-D problems; timed stand-alone behind the bench", bspmv),
-        row("k_tri_solve_lds<2, 4, 3, 4, 2>", "start of `KSPSolve_BCGS`: `PCApply` (back substitution of L⁻¹F), `MatMult`, `PCApply`, 3 dots", 32 + bspmv + 48),
-        row("k_tri_solve_lds<2, 5, 2, 4, 3>", "`VecWAXPY` (s = r − αv), `MatMult`, `PCApply`, 2 dots", 24 + bspmv + 48),
-        row("k_tri_solve_lds<2, 4, 3, 4, 1>", "`MatMult` + `PCApply` + 2 dots (later iterations, GMRES)", bspmv + 48),
+        row("k_tri_solve_lds<2, 4, 3, 4, 2, true>", "start of `KSPSolve_BCGS`: `PCApply` (back substitution of L⁻¹F), `MatMult`, `PCApply`, 3 dots + the line search's F·(J p) (`ls_fold`) — **the `roofline` kernels** (this one and the next, averaged)", 32 + bspmv + 48),
+        row("k_tri_solve_lds<2, 5, 2, 4, 3, true>", "`VecWAXPY` (s = r − αv), `MatMult`, `PCApply`, 2 dots + F·(J s)", 24 + bspmv + 48),
+        row("k_tri_solve_lds<2, 4, 3, 4, 2, false>", "… without the line search's sum (a solve whose sums are not folded)", 32 + bspmv + 48),
+        row("k_tri_solve_lds<2, 5, 2, 4, 3, false>", "… likewise", 24 + bspmv + 48),
+        row("k_tri_solve_lds<2, 4, 3, 4, 1, false>", "`MatMult` + `PCApply` + 2 dots (later iterations, GMRES)", bspmv + 48),
         row("k_assemble_cols<2, 3, 0, true>", "GE:388-453, 1603-2200 (residual + Jacobian), `PCSetUp`, forward elimination, `VecWAXPY`, 2 `VecNorm`", 148.0),
         row("k_assemble_cols<0, 3, 0, true>", "GE:388-421, 1603-1938 (residual), `VecWAXPY`, 2 `VecNorm`", 104.0),
-        row("k_bcgs_xr<true>", "`VecAXPBYPCZ`, `VecWAXPY`, `VecNorm` (r not written when the solve is expected to end)", 40.0),
+        row("k_bcgs_xr<true, true>", "`VecAXPBYPCZ`, `VecWAXPY`, `VecNorm` (r not written when the solve is expected to end) + the line search's Y·Y", 40.0),
+        row("k_bcgs_xr<true, false>", "… without Y·Y", 40.0),
         row("k_bc<2>", "boundary fluxes + derivatives (GE:1815-1877, 2076-2139) into side arrays", 0.0),
     ):
         if r:
@@ -112,14 +115,19 @@ def main():
     roof = bench["roofline"]
     cb = bench.get("cpu_baseline", {})
     results.append("")
-    results.append("Driver runs: 105.7 (`BENCH_r02.json`), 125.5 (`BENCH_r03.json`) Newton it/s; box-to-box spread of this pool ≈ ±4 %% (the column march "
-                   "follows the box's clocks: %.2f ms here, 1.83–2.30 ms over the round's boxes)." % bench["kernels"]["jacobian"]["avg_ms"])
-    results.append("`roofline` of that line: %s → **%.0f GB/s of algorithmic CSR bytes = %.3f of peak** (%.5f ms per launch, HIP events); "
-                   "%.0f GB/s = %.3f of peak on the bytes it moves (PMC %.3f GB per launch); the plain `y = A x` kernel timed behind the "
-                   "region: %.5f ms = %.3f of peak." % (
-                       ("the line search's product launches of the timed region (`k_spmv_cols_dots`: the CSR values at their computed places, no index — it moves less than SURVEY's CSR count, hence above 1.0 on it)" if roof.get("structure_exploited") else "the CSR SpMV launches of the timed region"), roof["achieved"], roof["frac"], roof["avg_launch_ms"],
+    results.append("Driver runs: 105.7 (`BENCH_r02.json`), 125.5 (`BENCH_r03.json`), 143.6 (`BENCH_r04.json`) Newton it/s; box-to-box spread of this pool ≈ ±4 %% (the column march "
+                   "follows the box's clocks: %.2f ms here, 1.83–2.30 ms over the boxes of rounds 4–5)." % bench["kernels"]["jacobian"]["avg_ms"])
+    results.append("`roofline` of that line: %s → **%.0f GB/s on the kernels' own byte model = %.3f of peak** (%.5f ms per launch, HIP events; "
+                   "`frac` is a fraction of peak of bytes the timed kernels can be said to move — round 5; SURVEY's CSR count over the same time "
+                   "is `achieved_algorithmic` %.0f GB/s); %.0f GB/s = %.3f of peak on the bytes they move (PMC %.3f GB per launch); the plain "
+                   "`y = A x` kernel timed behind the region: %.5f ms = %.3f of peak; the CSR kernel inside a timed region of its own (7-point "
+                   "grid, `extra_configs`): %s." % (
+                       ("the fused product + column-solve launches of the timed region (`k_tri_solve_lds<…, SPMV, FDOT>`: t = M⁻¹(A v) from the CSR values at their computed places with the Krylov dots and the line search's F·(J p), F·(J s) — with `ls_fold` no product launch of the search's own is left in the region)" if roof.get("roofline_kernel_class") == "spmv_pc" else "the line search's product launches of the timed region (`k_spmv_cols_dots`)"),
+                       roof["achieved"], roof["frac"], roof["avg_launch_ms"], roof.get("achieved_algorithmic", 0),
                        roof.get("achieved_physical", 0), roof.get("frac_physical", 0), (roof.get("traffic") or 0) / 1e9,
-                       roof.get("plain_spmv_kernel", {}).get("avg_launch_ms", 0), roof.get("plain_spmv_kernel", {}).get("frac", 0)))
+                       roof.get("plain_spmv_kernel", {}).get("avg_launch_ms", 0), roof.get("plain_spmv_kernel", {}).get("frac", 0),
+                       "; ".join("%.0f GB/s = %.3f of peak over %d launches of %.3f ms" % (e["roofline"]["achieved"], e["roofline"]["frac"], e["roofline"].get("launches", 0), e["roofline"]["avg_launch_ms"])
+                                 for e in (bench.get("extra_configs") or []) if "roofline" in e) or "not in this line"))
     if cb.get("value"):
         results.append("`cpu_baseline` (the oracle, \"port\"): %.3f Newton it/s on %d threads of an %s (GMRES(30)+ILU(0), the reference's "
                        "defaults; %.3f with the GPU's own BiCGStab + block-Jacobi; %.4f on one core — the reference itself is serial) → "
@@ -203,7 +211,7 @@ def main():
             tot += moved[k] * calls
     newton_prof = None
     for k, (calls, ms) in stats.items():
-        if k.startswith("k_tri_solve_lds<2, 5, 2, 4, 3>"):
+        if k.startswith("k_tri_solve_lds<2, 5, 2, 4, 3"):
             newton_prof = calls
     bytes_txt = "%.0f" % (tot / N / newton_prof) if newton_prof else "?"
     subs = {"KERNEL_TABLE": kernel_table, "LAWS_TABLE": laws_table, "RESULTS": results_txt,
