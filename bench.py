@@ -735,6 +735,7 @@ def run_vsfm3d(args, group, rank, world, local_rank, launched, dog):
                "config": {"workload": "VSFM v-channel 7-point grid %dx%dx%d, %s+%s" % (args.nx, args.ny, args.nz, args.ksp, args.pc),
                           "cells": N, "cells_per_gpu": part.nowned, "ghost_cells_rank0": part.nghost,
                           "halo_bytes_per_neighbour_per_exchange": int(max(part.recv_count)) * 8 if len(part.recv_count) else 0,
+                          "halo_stats_rank0": soe.halo_stats(),
                           "column_segments": layout["column_segments"], "spmv_variant": layout["spmv_variant"],
                           "parallelism": "x-y blocks of whole soil columns over %d GPU(s), RCCL halo exchange + all-reduce" % world},
                "setup_s": round(t_setup, 2)}

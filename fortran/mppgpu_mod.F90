@@ -32,7 +32,7 @@ module mppgpu_mod
         mppgpu_set_source_sink_auxvar, mppgpu_thermal_set_soils, mppgpu_thermal_set_soln_prev_clm, &
         mppgpu_thermal_pre_step_dt, mppgpu_thermal_step_dt, mppgpu_thermal_get_soln, mppgpu_thermal_compute_rhs, &
         mppgpu_thermal_compute_operators, mppgpu_th_add_condition, mppgpu_th_set_soils, mppgpu_kernel_stats, mppgpu_kernel_calls, &
-        mppgpu_reset_stats, mppgpu_get_comm_stats, mppgpu_get_pc_info, mppgpu_get_assembly_info, mppgpu_bench_kernel, &
+        mppgpu_reset_stats, mppgpu_get_comm_stats, mppgpu_get_halo_stats, mppgpu_get_pc_info, mppgpu_get_assembly_info, mppgpu_bench_kernel, &
         mppgpu_comm_get_unique_id, mppgpu_comm_runtime_version, mppgpu_comm_init, &
         mppgpu_comm_init_local, mppgpu_set_ghost_cells, mppgpu_set_halo, &
         mppgpu_pre_step_dt, mppgpu_post_step_dt, &
@@ -328,6 +328,12 @@ module mppgpu_mod
        import :: c_int, c_ptr, c_long_long
        type(c_ptr), value :: h
        integer(c_long_long) :: allreduces, halo_exchanges, chain_fallbacks, host_readbacks
+     end function
+     integer(c_int) function mppgpu_get_halo_stats(h, neighbours, cells_sent, cells_received, bytes_received_per_exchange, &
+          max_cells_from_one_neighbour) bind(C, name='mppgpu_get_halo_stats')
+       import :: c_int, c_ptr, c_long_long
+       type(c_ptr), value :: h
+       integer(c_long_long) :: neighbours, cells_sent, cells_received, bytes_received_per_exchange, max_cells_from_one_neighbour
      end function
      integer(c_int) function mppgpu_get_assembly_info(h, n, info) bind(C, name='mppgpu_get_assembly_info')
        import :: c_int, c_ptr

@@ -320,6 +320,15 @@ int mppgpu_reset_stats(mppgpu_handle h);
  * (PETSC_COMM_SELF, host-resident Vec). */
 int mppgpu_get_comm_stats(mppgpu_handle h, long long *allreduces, long long *halo_exchanges, long long *chain_fallbacks,
                           long long *host_readbacks);
+/* the halo plan of a rank's piece of a split mesh (mppgpu_set_ghost_cells / mppgpu_set_halo; the reference's counterpart is the
+ * VecScatter of ugrid_type, src/mpp/dtypes/UnstructuredGridType.F90, sized by ncells_ghost = ncols_ghost*nlevgrnd,
+ * src/mpp/dtypes/MeshType.F90:362): neighbours = ranks this one exchanges with, cells_sent / cells_received = owned cells copied out /
+ * ghost cells filled per exchange and field, bytes_received_per_exchange = 8 * cells_received * fields (fields = 2 for the coupled
+ * thermal-hydrology system: P and T of a ghost cell travel), max_cells_from_one_neighbour = the largest receive count -- for a 7-point
+ * nx x ny x nz grid split into x-y blocks of whole soil columns this is nz * nx (nz * nx * 8 B per neighbour and SpMV).
+ * Zeros without ghost cells.  Any output pointer may be NULL. */
+int mppgpu_get_halo_stats(mppgpu_handle h, long long *neighbours, long long *cells_sent, long long *cells_received,
+                          long long *bytes_received_per_exchange, long long *max_cells_from_one_neighbour);
 /* how the ILU(0) preconditioner (PETSc PCILU, MatSolve_SeqAIJ) applies its triangular solves on this handle, known once the
  * preconditioner has been set up: path = 0 no ILU(0) in use (or not set up yet), 1 one launch per dependency level,
  * 2 one launch per triangle with the tiles of a level chained by flags, 3 one launch per box level of a structured grid;

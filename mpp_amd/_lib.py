@@ -69,6 +69,7 @@ SIGNATURES = {
     "mppgpu_kernel_calls": (ct.c_int, [_h, ct.c_char_p, _llp, _ip]),
     "mppgpu_reset_stats": (ct.c_int, [_h]),
     "mppgpu_get_comm_stats": (ct.c_int, [_h, _llp, _llp, _llp, _llp]),
+    "mppgpu_get_halo_stats": (ct.c_int, [_h, _llp, _llp, _llp, _llp, _llp]),
     "mppgpu_get_pc_info": (ct.c_int, [_h, _ip, _ip, _ip]),
     "mppgpu_get_assembly_info": (ct.c_int, [_h, ct.c_int, _ip]),
     "mppgpu_comm_runtime_version": (ct.c_int, [_ip]),

@@ -4165,6 +4165,25 @@ int mppgpu_get_comm_stats(mppgpu_handle h, long long *allreduces, long long *hal
   API_END()
 }
 
+int mppgpu_get_halo_stats(mppgpu_handle h, long long *neighbours, long long *cells_sent, long long *cells_received,
+                          long long *bytes_received_per_exchange, long long *max_cells_from_one_neighbour) {
+  API_BEGIN(h)
+  const auto &hp = S.halo;
+  long long nb = 0, sent = 0, recv = 0, mx = 0;
+  if (S.nghost > 0 && hp.set) {
+    nb = (long long)hp.peer.size();
+    sent = (long long)hp.send_cells.size();
+    recv = hp.recv_ptr.empty() ? 0 : hp.recv_ptr.back();
+    for (size_t k = 0; k + 1 < hp.recv_ptr.size(); ++k) mx = std::max<long long>(mx, hp.recv_ptr[k + 1] - hp.recv_ptr[k]);
+  }
+  if (neighbours) *neighbours = nb;
+  if (cells_sent) *cells_sent = sent;
+  if (cells_received) *cells_received = recv;
+  if (bytes_received_per_exchange) *bytes_received_per_exchange = 8 * recv * (S.th ? 2 : 1);
+  if (max_cells_from_one_neighbour) *max_cells_from_one_neighbour = mx;
+  API_END()
+}
+
 int mppgpu_get_assembly_info(mppgpu_handle h, int n, int *info) {
   API_BEGIN(h)
   S.ensure_ready();

@@ -237,6 +237,13 @@ class SystemOfEquationsVSFM:
         self._chk(self.L.mppgpu_get_comm_stats(self.h, ct.byref(a), ct.byref(b), ct.byref(c), ct.byref(d)))
         return dict(allreduces=a.value, halo_exchanges=b.value, chain_fallbacks=c.value, host_readbacks=d.value)
 
+    def halo_stats(self):
+        """the halo plan of this rank's piece of a split mesh (mppgpu_get_halo_stats)"""
+        v = [ct.c_longlong() for _ in range(5)]
+        self._chk(self.L.mppgpu_get_halo_stats(self.h, *[ct.byref(x) for x in v]))
+        return dict(zip(("neighbours", "cells_sent", "cells_received", "bytes_received_per_exchange", "max_cells_from_one_neighbour"),
+                        (x.value for x in v)))
+
     def assembly_info(self):
         """layout and kernel selection of this handle (mppgpu_get_assembly_info)"""
         v = (ct.c_int * 14)()

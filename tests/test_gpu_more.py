@@ -236,6 +236,13 @@ def test_3d_mesh_split_across_ranks_vsfm():
     assert [part.recv_count.tolist() for part, _ in parts] == [[6 * 9], [6 * 9, 6 * 9], [6 * 9]]   # nz x edge cells per neighbour
     gs = [P.to_gpu(lp, opts) for _, lp in parts]
     V.comm_init_local([g.soe for g in gs])
+    # the halo of a 7-point nx x ny x nz grid cut in y is nz x nx cells = nz * nx * 8 bytes per neighbour and exchange
+    nzx = 9 * 6
+    assert gs[0].soe.halo_stats() == dict(neighbours=1, cells_sent=nzx, cells_received=nzx, bytes_received_per_exchange=8 * nzx,
+                                          max_cells_from_one_neighbour=nzx)
+    assert gs[1].soe.halo_stats() == dict(neighbours=2, cells_sent=2 * nzx, cells_received=2 * nzx, bytes_received_per_exchange=16 * nzx,
+                                          max_cells_from_one_neighbour=nzx)
+    assert ref.soe.halo_stats()["bytes_received_per_exchange"] == 0
 
     def resid(part, g):
         g.soe.SetDtime(prob.dt); g.soe.PreSolve()

@@ -403,8 +403,11 @@ def test_th_mesh_split_across_ranks_with_ghost_cells(case, nranks):
     if case == "vchannel":
         assert all(part.mode == "columns" for part, _ in parts)
         # halo bytes per SpMV and neighbour = nz x (cells of the edge) x 8 B per field
-        for part, _ in parts:
+        for (part, _), g in zip(parts, gs):
             assert all(int(cnt) % 7 == 0 for cnt in part.recv_count)
+            hs = g.soe.halo_stats()     # both fields of a ghost cell travel: 16 bytes per ghost cell and exchange
+            assert hs["cells_received"] == part.nghost and hs["bytes_received_per_exchange"] == 16 * part.nghost
+            assert hs["neighbours"] == len(part.peer) and hs["max_cells_from_one_neighbour"] == int(max(part.recv_count))
     for (part, lp), g in zip(parts, gs):
         own = part.l2g[:part.nowned]
         p = g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE)
