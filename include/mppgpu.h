@@ -168,11 +168,12 @@ int mppgpu_get_condition_values(mppgpu_handle h, int kind, int cond_id, int n, d
 int mppgpu_set_source_sink_auxvar(mppgpu_handle h, int var_type, int n, const double *values);
 
 /* solver selection: the PETSc options database the reference reads through SNESSetFromOptions
- * (src/mpp/mpp/MultiPhysicsProbBaseType.F90:1205).  Keys: "ksp_type" (bcgs|gmres|preonly),
- * "pc_type" (bjacobi|ilu|jacobi|none; ilu = PETSc's default ILU(0) in the caller's natural ordering -- on
- * vertical-only grids it coincides with the exact per-column LU and is served by the same kernels),
+ * (src/mpp/mpp/MultiPhysicsProbBaseType.F90:1205).  Defaults as PETSc's: GMRES(30) + ILU(0).  Keys: "ksp_type" (bcgs|gmres|preonly),
+ * "pc_type" (bjacobi|ilu|jacobi|none; ilu = PETSc's default ILU(0) in the caller's natural ordering, the default here too since
+ * round 5 -- on vertical-only grids it coincides with the exact per-column LU and is served by the same kernels),
  * "ksp_rtol", "ksp_atol", "ksp_dtol", "ksp_max_it", "snes_rtol", "snes_atol", "snes_stol", "snes_max_it",
- * "profile" (0 | 1: HIP-event timing of every kernel class | 2: of the CSR SpMV only), "problem_type" (vsfm|thermal|th),
+ * "profile" (0 | 1: HIP-event timing of every kernel class | 2: of the CSR SpMV launches and the SpMV fused with the column solve only),
+ * "problem_type" (vsfm|thermal|th),
  * "cnfac" (thermal).
  * Tuning keys (results unchanged): "spmv_variant", "assembly" (auto|general|columns), "nseg", "fused_assembly"
  * (0|1), "fused_trials" (line-search trial points whose Jacobian is assembled together with the residual),

@@ -565,7 +565,9 @@ __global__ __launch_bounds__(kBlock) void k_flux_rows_ell(GenArgs a) {
     ot[k].P = ca.P[o]; ot[k].kr = a.aux.kr[o]; ot[k].den = a.aux.den[o];
     ot[k].dkr = JAC ? a.aux.dkr[o] : 0.0; ot[k].dden = JAC ? a.aux.dden[o] : 0.0;
     ot[k].sat = ot[k].dsat = 0.0;
-    g[k].Dq = a.conn.Dq[ic]; g[k].upweight = a.conn.upw[ic]; g[k].dist_gravity = a.conn.dgrav[ic]; g[k].area = a.conn.area[ic];
+    // (LAT: conn.Dq holds conductance x face area -- the flux is linear in it, as in the march -- and conn.area is null: three gathers)
+    g[k].Dq = a.conn.Dq[ic]; g[k].upweight = a.conn.upw[ic]; g[k].dist_gravity = a.conn.dgrav[ic];
+    g[k].area = (LAT && !a.conn.area) ? 1.0 : a.conn.area[ic];
   }
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

@@ -1489,6 +1489,7 @@ struct Solver {
   GenArgs lat_args(const double *P, double *Fout) const {   // the lateral pass of use_cols3d(): the compacted lists where they exist
     GenArgs a = gen_args(P, Fout);
     if (lat_k > 0) { a.ell_enc = d_lat_enc.p; a.ell_o = d_lat_o.p; a.ell_slot = d_lat_slot.p; a.ell_k = lat_k; }
+    if (d_DqA.p) a.conn = ConnArrays{d_DqA.p, d_upw.p, d_dgrav.p, nullptr};   // conductance x face area as one operand (col_operands)
     return a;
   }
   BcArgs bc_args(const double *P, double *Fout) const {
@@ -3729,11 +3730,11 @@ struct Solver {
       if (t != 1 && t != 2) throw Error("int_energy_enthalpy_type must be 1 (constant) or 2 (IFC67)");
       ie_type = t;
     } else if (key == "cnfac") cnfac = num();
-    else if (key == "profile") {   // 0 off, 1 every kernel class, 2 the CSR SpMV only (the graded roofline kernel)
-      prof.flush();
+    else if (key == "profile") {   // 0 off, 1 every kernel class, 2 the roofline kernels only: the CSR SpMV launches and the SpMV fused with
+      prof.flush();                // the column solve (with ls_fold the only product launches a Newton iteration on soil columns has left)
       const int m = (int)num();
       prof.enabled = m != 0;
-      prof.mask = m == 2 ? (1u << KC_SPMV) : ~0u;
+      prof.mask = m == 2 ? ((1u << KC_SPMV) | (1u << KC_SPMV_PC)) : ~0u;
     }
     else if (key == "profile_stride") { prof.flush(); prof.stride = std::max(1, (int)num()); }
     else throw Error("unknown option '" + key + "'");

@@ -101,8 +101,9 @@ def test_config3_1024x1024x100_every_column_reproduces_the_reference_baseline(go
         assert colv.max() - colv.min() <= 1e-12 * abs(colv.max())   # all columns agree with each other
 
 
-@pytest.mark.parametrize("extra", [{}, {"assembly": "columns", "nseg": 1, "spmv_variant": 20}],
-                         ids=["default", "fused_rows"])
+@pytest.mark.parametrize("extra", [{}, {"assembly": "columns", "nseg": 1, "spmv_variant": 20},
+                                   {"assembly": "columns", "nseg": 1, "tri_lds": 1}, {"assembly": "columns", "nseg": 1, "tri_lds": 1, "ls_fold": 0}],
+                         ids=["default", "fused_rows", "fused_lds_solves_folded_line_search", "fused_lds_solves"])
 def test_sharded_global_solve_on_one_gpu_equals_the_unsharded_solve(extra):
     """SURVEY 8(e) on real kernels: the column set split over 3 handles (ranks) of this process, one host thread each,
     forming ONE global Newton-Krylov solve through the in-process communicator (same call sites as the RCCL
@@ -113,7 +114,9 @@ def test_sharded_global_solve_on_one_gpu_equals_the_unsharded_solve(extra):
     from mpp_amd import vsfm as V
     ncols, nz, nranks = 203, 30, 3
     mult = np.exp(0.5 * np.random.default_rng(11).standard_normal(ncols))
-    opts = dict({"ksp_type": "bcgs", "pc_type": "bjacobi"}, **extra)   # fused_rows: every fused pass under a communicator
+    # fused_rows: every fused pass under a communicator; fused_lds_*: the kernels a rank of the 8-GPU benchmark runs (M^-1 A v as one
+    # kernel with the column solve in LDS, and -- round 5 -- the line search's sums all-reduced out of those kernels: ls_fold)
+    opts = dict({"ksp_type": "bcgs", "pc_type": "bjacobi"}, **extra)
     ref_prob = P.celia1990(ncols=ncols, nz=nz, perm_mult=mult)
     ref = P.to_gpu(ref_prob, opts)
     shards = []
@@ -152,6 +155,11 @@ def test_sharded_global_solve_on_one_gpu_equals_the_unsharded_solve(extra):
     for c0, nloc, prob, g in shards:
         p = g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE).reshape(nloc, nz)
         assert np.abs(p - p_ref[c0:c0 + nloc]).max() <= 1e-9 * np.abs(p_ref).max()
+    folded = [s[3].soe.assembly_info()["line_search_sums_folded"] for s in shards]
+    if extra.get("tri_lds") and extra.get("ls_fold", 1):
+        assert min(folded) > 0 and len(set(folded)) == 1      # every rank folded the same line searches
+    else:
+        assert max(folded) == 0
 
 
 def _run_ranks(fns):
