@@ -52,6 +52,7 @@ step "vsfm3d pmc"; timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE -d $O/f_v3d -o f
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE -d $O/w_v3d -o w --output-format csv -- python3 $V3 --profile spmv > $O/v3d_w.log 2>&1; echo "write rc=$?"
 python3 tools/pmc_summary.py $O/f_v3d $O/w_v3d k_spmv k_tri k_flux k_assemble k_auxvars k_bcgs k_waxpy k_copy > $O/pmc_vsfm3d_512x512x100.json 2> $O/pmc_v3d.err; echo "rc=$?"
 rm -rf $O/f_v3d $O/w_v3d
+step "the driver's bench command"; timeout -k 10 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_form_steps20_warmup5.json 2> $O/bench_driver_form.err; echo "rc=$?"; cut -c1-200 $O/bench_driver_form_steps20_warmup5.json
 step "config 4 on four in-process ranks"; timeout -k 10 900 python3 tools/thermal_ranks_bench.py --n 512 --out $O/thermal_ranks_512.json > $O/thermal_ranks_512.log 2>&1; echo "rc=$?"; tail -1 $O/thermal_ranks_512.log | cut -c1-600
 timeout -k 10 600 python3 tools/thermal_ranks_bench.py --n 256 --out $O/thermal_ranks_256.json > $O/thermal_ranks_256.log 2>&1; echo "rc=$?"
 fi
