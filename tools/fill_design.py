@@ -149,7 +149,7 @@ def main():
     extra_txt = "; ".join(extra_rows) if extra_rows else "(none in this line)"
     per_newton = 0.0
     out = open(os.path.join(ROOT, "DESIGN.md.in")).read()
-    th_line = "%.1f Newton it/s (BiCGStab + per-column 2×2 block-Jacobi; round 2: 95.8, round 3: 103.6), column march %.2f ms" % (
+    th_line = "%.1f Newton it/s (BiCGStab + per-column 2×2 block-Jacobi; round 2: 95.8, round 3: 103.6, round 4: 122.9), column march %.2f ms" % (
         th["newton_its_per_s"], th["kernels"]["jacobian"]["avg_ms"])
 
     def kstats(fname):
@@ -197,8 +197,8 @@ def main():
         its = t["linear_iterations"]
         thermal = ("library set-up %.1f s in all (r02: 88, r03: 34.3; `mppgpu_setup` itself 25.6 → 3.0 s with the index analysis on "
                    "the device, `profiles/r04/setup_phase_timing_device.log`), %d GMRES(30) iterations in %.1f s at PETSc's default "
-                   "`ksp_rtol` 1e-5 = %.1f ms per iteration (r03: 16.3; error vs the manufactured solution %.2f K), %d iterations / "
-                   "%.1f s at 1e-8 (%.4f K); ILU(0) application %.2f ms in %d launches (r03: 6.59 ms in 270)" % (
+                   "`ksp_rtol` 1e-5 = %.1f ms per iteration (r03: 16.3, r04: 14.0; error vs the manufactured solution %.2f K), %d iterations / "
+                   "%.1f s at 1e-8 (%.4f K); ILU(0) application %.2f ms in %d launches (r03: 6.59 ms in 270, r04: 4.60 in 4)" % (
                        t["setup_s"], its, t["step_s"], 1e3 * t["step_s"] / max(its, 1),
                        t["max_error_vs_manufactured_solution"], sw.get("1e-08", {}).get("linear_iterations", 0),
                        sw.get("1e-08", {}).get("step_s", 0), sw.get("1e-08", {}).get("max_error_vs_manufactured_solution", 0),
