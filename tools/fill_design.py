@@ -55,7 +55,7 @@ def main():
     rows = ["| kernel | what it restates | algorithmic bytes / launch | moved (PMC) | rocprofv3 average in the bench | frac of 8 TB/s (algorithmic / moved) |",
             "|---|---|---|---|---|---|"]
     for r in (
-        row("k_spmv_cols_dots", "PETSc `MatMult` + the line search's `VecDot` / `VecNorm`s (A x not written), from the CSR values at their computed places — the product launches of a Newton iteration on soil columns; **the `roofline` kernel**", bspmv),
+        row("k_spmv_cols_dots", "PETSc `MatMult` + the line search's `VecDot` / `VecNorm`s (A x not written), from the CSR values at their computed places — the line search's own product pass: since `ls_fold` (round 5) only where the Krylov solve took more than one iteration or ‖X‖ was not at hand (the roofline kernel of round 4)", bspmv),
         row("k_spmv_c<3, false, true>", "… on the compact 16-bit index (grids that are not soil columns)", bspmv),
         row("k_spmv_c<3, false, false>", "PETSc `MatMult_SeqAIJ` (y = A x): multi-iteration Krylov solves, 3-D problems; timed stand-alone behind the bench", bspmv),
         row("k_tri_solve_lds<2, 4, 3, 4, 2, true>", "start of `KSPSolve_BCGS`: `PCApply` (back substitution of L⁻¹F), `MatMult`, `PCApply`, 3 dots + the line search's F·(J p) (`ls_fold`) — **the `roofline` kernels** (this one and the next, averaged)", 32 + bspmv + 48),
@@ -112,6 +112,11 @@ def main():
                         ("256×256×50, SpMV class timed only", c2s, "bench_256x256x50_spmv.json"),
                         ("1024×128×100 (one rank's share of an 8-GPU run), SpMV class timed only", s8, "bench_1024x128x100.json")):
         results.append("| %s | **%.1f** | %.3f | %s | `%s/%s` |" % (label, j["value"], 1e3 / j["value"], rb(j), ev, f))
+    dfile = os.path.join(ev, "bench_driver_form_steps20_warmup5.json")
+    if os.path.exists(dfile):
+        dj = json.load(open(dfile))
+        results.append("| 1024×1024×100, **the driver's command** (`bench.py --gpus 1 --steps 20 --warmup 5`: later steps backtrack less than the first four) | **%.1f** | %.3f | %s | `%s/bench_driver_form_steps20_warmup5.json` |"
+                       % (dj["value"], 1e3 / dj["value"], rb(dj), ev))
     roof = bench["roofline"]
     cb = bench.get("cpu_baseline", {})
     results.append("")
