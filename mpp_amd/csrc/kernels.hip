@@ -1105,6 +1105,43 @@ __global__ __launch_bounds__(kBlock) void k_tri_factor(TriArgs a) {
   }
 }
 
+// the column LU and its application along linked chains of cells (ColChainArgs: a rank's piece of a split 3-D mesh); k_tri_factor's and
+// k_tri_solve's arithmetic, level by level
+__global__ __launch_bounds__(kBlock) void k_chain_tri_factor(ColChainArgs a) {
+  const int c = blockIdx.x * kBlock + threadIdx.x;
+  if (c >= a.nchains) return;
+  double inv_prev = 0.0, c_prev = 0.0;
+  for (int i = a.start[c]; i >= 0; i = a.nxt[i]) {
+    const int sl = a.t.tri_lo[i], su = a.t.tri_up[i];
+    const double lo = sl >= 0 ? a.t.val[sl] : 0.0;
+    const double di = a.t.val[a.t.tri_di[i]];
+    const double up = su >= 0 ? a.t.val[su] : 0.0;
+    const double l = lo * inv_prev;
+    const double piv = fma(-l, c_prev, di);
+    const double inv = 1.0 / piv;
+    a.t.l[i] = l; a.t.invb[i] = inv; a.t.c[i] = up;
+    inv_prev = inv; c_prev = up;
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_chain_tri_solve(ColChainArgs a, const double *__restrict__ r, double *__restrict__ z) {
+  const int c = blockIdx.x * kBlock + threadIdx.x;
+  if (c >= a.nchains) return;
+  double prev = 0.0;
+  int last = -1;
+  for (int i = a.start[c]; i >= 0; i = a.nxt[i]) {
+    const double d = r[i] - a.t.l[i] * prev;
+    z[i] = d;
+    prev = d;
+    last = i;
+  }
+  double next = 0.0;
+  for (int i = last; i >= 0; i = a.prv[i]) {
+    const double xk = (z[i] - a.t.c[i] * next) * a.t.invb[i];
+    z[i] = xk;
+    next = xk;
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void k_tri_solve(TriArgs a, const double *__restrict__ r, double *__restrict__ z) {
   const int c = blockIdx.x * kBlock + threadIdx.x;
   if (c >= a.ncols) return;
@@ -3087,6 +3124,12 @@ void launch_tri_l(const TriArgs &a, hipStream_t stream) {
 }
 void launch_tri_factor(const TriArgs &a, hipStream_t stream) {
   if (a.ncols > 0) LAUNCH(k_tri_factor, dim3(nblk(a.ncols)), a);
+}
+void launch_chain_tri_factor(const ColChainArgs &a, hipStream_t stream) {
+  if (a.nchains > 0) LAUNCH(k_chain_tri_factor, dim3(nblk(a.nchains)), a);
+}
+void launch_chain_tri_solve(const ColChainArgs &a, const double *r, double *z, hipStream_t stream) {
+  if (a.nchains > 0) LAUNCH(k_chain_tri_solve, dim3(nblk(a.nchains)), a, r, z);
 }
 void launch_tri_solve(const TriArgs &a, const double *r, double *z, hipStream_t stream) {
   if (a.ncols > 0) LAUNCH(k_tri_solve, dim3(nblk(a.ncols)), a, r, z);

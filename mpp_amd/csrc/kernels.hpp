@@ -206,6 +206,18 @@ struct TriArgs {
   double *l, *invb, *c;                 // factors, level-major
 };
 void launch_tri_factor(const TriArgs &a, hipStream_t stream);
+// The same per-column LU on a mesh that is NOT in the tiled column layout -- a rank's piece of a split 3-D mesh: its ghost cells stay
+// last, so its cells keep the caller's order -- with the columns given as linked chains of owned cells: start[c] = first (lowest) cell
+// of chain c, nxt[i] / prv[i] = the cell above / below cell i in its chain (-1 at the ends).  One thread per chain; the factors go where
+// TriArgs puts them (per cell).  A cell without a vertical neighbour is a chain of one (its block is its diagonal entry): ghost cells
+// (identity rows) are such chains.  Round 5: this is what keeps `pc_type bjacobi` the SAME operator on every rank count.
+struct ColChainArgs {
+  int nchains;
+  const int *start, *nxt, *prv;
+  TriArgs t;
+};
+void launch_chain_tri_factor(const ColChainArgs &a, hipStream_t stream);
+void launch_chain_tri_solve(const ColChainArgs &a, const double *r, double *z, hipStream_t stream);
 // l_k = lower_k inv_{k-1} from the CSR values and the stored reciprocal pivots (k_tri_factor's arithmetic): the elimination factors of
 // a factorisation whose march did not store them (ColsArgs::store_l = false)
 void launch_tri_l(const TriArgs &a, hipStream_t stream);

@@ -137,6 +137,11 @@ struct Solver {
   DevBuf<int> d_cup, d_cdn;
   DevBuf<int> d_rowptr, d_col, d_diag, d_rc_ptr, d_rc_conn, d_rc_slot, d_tri_lo, d_tri_up, d_ell_enc, d_ell_o, d_ell_slot;
   int ell_k = 0;   // incident connections per row in the ELL copy (0: none)
+  // a rank's piece of a split 3-D mesh (ghost cells: identity layout): the soil columns of its owned cells as linked chains, for the
+  // per-column block-Jacobi preconditioner (ColChainArgs); gc_n = 0: none
+  DevBuf<int> d_gc_start, d_gc_nxt, d_gc_prv;
+  int gc_n = 0;
+  std::vector<int> h_gc_nxt, h_gc_prv;
   DevBuf<int> d_lat_enc, d_lat_o, d_lat_slot;   // the lateral entries of those lists, four wide (3-D meshes of complete columns)
   int lat_k = 0;
   DevBuf<double> d_val;
@@ -917,6 +922,32 @@ struct Solver {
     // tridiagonal slots of the per-column blocks
     {
       Scratch<int> lo((size_t)n, -1), up((size_t)n, -1);
+      gc_n = 0;
+      if (!columns && nghost > 0 && !th && !thermal) {
+        // ghost cells keep the caller's order (identity layout), but the owned cells of a rank that was given whole soil columns
+        // (mpp_amd.parallel.partition_mesh) still form vertical chains: found here from the vertical connections between owned cells
+        const int nown = n - nghost;
+        h_gc_nxt.assign(n, -1); h_gc_prv.assign(n, -1);
+        bool ok = true;
+        for (int c = 0; c < nc && ok; ++c) {
+          if (!cvert[c]) continue;
+          const int u = ext2int[cup_e[c]], d = ext2int[cdn_e[c]];
+          if (u >= nown || d >= nown) continue;   // a link to a ghost cell: not part of this rank's blocks
+          if (h_gc_nxt[u] != -1 || h_gc_prv[d] != -1) ok = false;   // two links on one side of a cell: not chains
+          h_gc_nxt[u] = d; h_gc_prv[d] = u;
+        }
+        if (ok) {
+          std::vector<int> start;
+          for (int i = 0; i < n; ++i) if (h_gc_prv[i] == -1) start.push_back(i);   // (ghost cells and cells without a vertical neighbour: chains of one)
+          for (int i = 0; i < n; ++i) {
+            if (h_gc_prv[i] >= 0) lo[i] = find_slot(i, h_gc_prv[i]);
+            if (h_gc_nxt[i] >= 0) up[i] = find_slot(i, h_gc_nxt[i]);
+          }
+          gc_n = (int)start.size();
+          d_gc_start.upload(start, stream); d_gc_nxt.upload(h_gc_nxt, stream); d_gc_prv.upload(h_gc_prv, stream);
+          HIP_CHECK(hipStreamSynchronize(stream));
+        }
+      }
       if (columns) {
         PhaseTimer pt("setup: column block slots");
         host_parallel_for(ncols, [&](long long col) {
@@ -1800,6 +1831,7 @@ struct Solver {
   TriArgs tri_args() const {
     return TriArgs{ncols, nz, d_tri_lo.p, d_diag.p, d_tri_up.p, d_val.p, tri_l.p, tri_invb.p, tri_c.p};
   }
+  ColChainArgs chain_args() const { return ColChainArgs{gc_n, d_gc_start.p, d_gc_nxt.p, d_gc_prv.p, tri_args()}; }
   ThTriArgs th_tri_args() const {
     return ThTriArgs{ncols, nz, n, nnzc, d_crowptr.p, d_tri_lo.p, d_cdiag.p, d_tri_up.p, d_val.p, thtri_L.p, thtri_inv.p, thtri_C.p, opt.th_stage ? 1 : 0};
   }
@@ -1810,7 +1842,10 @@ struct Solver {
       if (!vertical_only || !columns) throw Error("pc_type bjacobi of the coupled system needs a grid whose connections are all vertical (use ilu)");
       if (!thtri_L.p) { thtri_L.alloc(4 * (size_t)n); thtri_inv.alloc(4 * (size_t)n); thtri_C.alloc(4 * (size_t)n); }
       launch_th_tri_factor(th_tri_args(), stream);
-    } else if (opt.pc_type == 2) { launch_tri_factor(tri_args(), stream); tri_l_valid = true; }
+    } else if (opt.pc_type == 2) {
+      if (gc_n > 0) launch_chain_tri_factor(chain_args(), stream); else launch_tri_factor(tri_args(), stream);
+      tri_l_valid = true;
+    }
     else if (opt.pc_type == 3) launch_jacobi_setup(nrow, d_diag.p, d_val.p, jac_invd.p, stream);
     else if (opt.pc_type == 1) {
       ilu_box_analyse();
@@ -1951,6 +1986,7 @@ struct Solver {
     ProfScope ps(prof, KC_PC_APPLY);
     if (nghost > 0 && !th) launch_set(nghost, 0.0, const_cast<double *>(r) + nred, stream);   // block-Jacobi across ranks (TH: zero already)
     if (opt.pc_type == 2 && th) launch_th_tri_solve(th_tri_args(), r, z, stream);
+    else if (opt.pc_type == 2 && gc_n > 0) launch_chain_tri_solve(chain_args(), r, z, stream);   // (a rank of a split mesh: columns as chains)
     else if (opt.pc_type == 2) { ensure_tri_l(); launch_tri_solve(tri_args(), r, z, stream); }
     else if (opt.pc_type == 3) launch_pointwise_mult(nred, jac_invd.p, r, z, stream);
     else if (opt.pc_type == 1 && box_active()) {

@@ -429,3 +429,49 @@ def test_3d_mesh_of_complete_columns_is_assembled_by_the_column_march_plus_a_lat
     assert np.abs(p[0] - p[1]).max() <= 1e-10 * np.abs(p[1]).max() and np.abs(p[0] - p[2]).max() <= 1e-10 * np.abs(p[1]).max()
     cg, ch = g.soe.counters(), h.soe.counters()
     assert (cg["newton"], cg["time_cuts"]) == (ch["newton"], ch["time_cuts"]) and abs(cg["linear"] - ch["linear"]) <= 2 * ch["newton"]
+
+
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_column_block_jacobi_is_the_same_operator_on_a_split_3d_mesh(nranks):
+    """BASELINE's VSFM solver, BiCGStab + per-column block-Jacobi, on the 7-point v-channel split over ranks that own whole soil columns:
+    a rank's cells keep the caller's order (ghost cells last), so the column blocks are found as linked chains of owned cells
+    (ColChainArgs, k_chain_tri_factor / k_chain_tri_solve) -- the SAME preconditioner as on one handle, whatever the rank count:
+    M^-1 r of the owned cells equals the single handle's to rounding, and two time steps take the single handle's Newton iterations and
+    its linear iterations (+- 1 per solve: the all-reduced dot products are summed in another order)"""
+    from mpp_amd import vsfm as V
+    prob = P.vchannel(6, 6, 8)
+    n = prob.mesh.ncells_local
+    rng = np.random.default_rng(17)
+    prob.perm = prob.perm * np.exp(0.3 * rng.standard_normal(n))[:, None]
+    opts = {"ksp_type": "bcgs", "pc_type": "bjacobi", "ksp_rtol": 1e-9}
+    ref = P.to_gpu(prob, opts)
+    x = prob.press_ic - rng.uniform(0, 2.0e5, n)
+    r = rng.standard_normal(n)
+    ref.soe.SetDtime(prob.dt); ref.soe.PreSolve()
+    ref.soe.ComputeJacobian(x)
+    z_ref = ref.soe.PCApply(r)
+    parts = P.split_problem(prob, nranks)
+    gs = [P.to_gpu(lp, opts) for _, lp in parts]
+    V.comm_init_local([g.soe for g in gs])
+
+    def apply(part, g):
+        g.soe.SetDtime(prob.dt); g.soe.PreSolve()
+        g.soe.ComputeJacobian(x[part.l2g])
+        return g.soe.PCApply(r[part.l2g])
+
+    zs = _run_ranks([lambda part=part, g=g: apply(part, g) for (part, _), g in zip(parts, gs)])
+    for (part, lp), z in zip(parts, zs):
+        own = part.l2g[:part.nowned]
+        assert np.abs(z[:part.nowned] - z_ref[own]).max() <= 1e-12 * np.abs(z_ref).max()
+    res_ref = [ref.soe.StepDT(prob.dt, s + 1) for s in range(2)]
+    res = _run_ranks([lambda g=g: [g.soe.StepDT(prob.dt, s + 1) for s in range(2)] for g in gs])
+    assert all(rr == res_ref for rr in res) and all(c for c, _ in res_ref)
+    c_ref = ref.soe.counters()
+    assert c_ref["linear"] > 3 * c_ref["newton"]            # (the lateral couplings make BiCGStab iterate: not a one-iteration solve)
+    for g in gs:
+        c = g.soe.counters()
+        assert c["newton"] == c_ref["newton"] and abs(c["linear"] - c_ref["linear"]) <= c_ref["newton"], (c, c_ref)
+    p_ref = ref.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE)
+    for (part, lp), g in zip(parts, gs):
+        p = g.soe.GetDataForCLM(C.AUXVAR_INTERNAL, C.VAR_PRESSURE)
+        assert np.abs(p[:part.nowned] - p_ref[part.l2g[:part.nowned]]).max() <= 1e-7 * np.abs(p_ref).max()
