@@ -168,7 +168,9 @@ __global__ __launch_bounds__(kBlock) void k_accum(CellArrays ca, int n, double d
 #define MPP_MARCH_DEPTH_RESIDUAL 2
 #endif
 constexpr int kMarchDepthResidual = MPP_MARCH_DEPTH_RESIDUAL;
-template <int MODE, int SAT_T, int DEN_T, bool FUSE>  // MODE 0 residual, 1 Jacobian, 2 both; SAT_T / DEN_T: see physics.hpp
+// C3D (never with FUSE): the march of a 3-D mesh of complete columns -- tridiagonal at the CSR slots of the 7-point rows, auxvars left for
+// the lateral pass (ColsArgs::slot_di, aux); a template parameter so that the marches of vertical-only grids keep their registers
+template <int MODE, int SAT_T, int DEN_T, bool FUSE, bool C3D = false>  // MODE 0 residual, 1 Jacobian, 2 both; SAT_T / DEN_T: see physics.hpp
 __global__ __launch_bounds__(kBlock) void k_assemble_cols(ColsArgs a) {
   __shared__ double red[kBlock / 64];
   extern __shared__ __attribute__((aligned(16))) double cls_lds[];   // [7][ncls] when soil classes are in use
@@ -272,7 +274,8 @@ __global__ __launch_bounds__(kBlock) void k_assemble_cols(ColsArgs a) {
       if (JAC) {
         double di = dconn_prev + dacc_prev;
         if (FUSE && js >= 0) di += bc_inline ? (kp == 0 ? sD0 : sD1) : a.side_d[js];
-        if (a.slot_di) {   // 7-point rows: the column's tridiagonal at its CSR slots (the lateral pass adds to the diagonal afterwards)
+        if (C3D) {   // 7-point rows: the column's tridiagonal at its CSR slots (the lateral pass adds to the diagonal afterwards;
+                                    // never with the complete-row march: compiled out of it -- its registers are spoken for)
           if (kp > 0) a.val[a.slot_lo[ip]] = lo_prev;
           a.val[a.slot_di[ip]] = di;
           if (!last) a.val[a.slot_up[ip]] = up_prev;
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(kBlock) void k_assemble_cols(ColsArgs a) {
           if (SAT_T == kSatSBC) { s.pu = t[3 * nc]; s.ps = t[4 * nc]; s.b2 = t[5 * nc]; s.b3 = t[6 * nc]; }
         }
         cur = auxvar_compute<JAC, SAT_T, DEN_T>(L.sf, ca.eos, s, Pi, L.frac, pt);
-        if (!FUSE && a.aux.kr && owned) {   // for the lateral pass of a 3-D mesh (k_flux_rows_ell<.., LAT>)
+        if (C3D && owned) {   // for the lateral pass of a 3-D mesh (k_flux_rows_ell<.., LAT>)
           a.aux.kr[i] = cur.kr; a.aux.den[i] = cur.den;
           if (JAC) { a.aux.dkr[i] = cur.dkr; a.aux.dden[i] = cur.dden; }
         }
@@ -388,7 +391,7 @@ __global__ __launch_bounds__(kBlock) void k_assemble_cols(ColsArgs a) {
           }
         }
       }
-      if (!FUSE && a.aux.kr && owned && !act) {   // (k_auxvars leaves zeros for an inactive cell)
+      if (C3D && owned && !act) {   // (k_auxvars leaves zeros for an inactive cell)
         a.aux.kr[i] = 0.0; a.aux.den[i] = 0.0;
         if (JAC) { a.aux.dkr[i] = 0.0; a.aux.dden[i] = 0.0; }
       }
@@ -2947,6 +2950,10 @@ static void launch_cols_mode(int mode, const ColsArgs &a, dim3 grid, hipStream_t
 #define COLS(M, F) hipLaunchKernelGGL((k_assemble_cols<M, SAT_T, DEN_T, F>), grid, dim3(kBlock), lds, stream, a)
   if (a.col_bc) {   // complete-row variant (grid.y == 1)
     if (mode == 0) COLS(0, true); else if (mode == 1) COLS(1, true); else COLS(2, true);
+  } else if (a.slot_di) {   // 3-D mesh of complete columns: a lateral pass follows
+#define COLS3(M) hipLaunchKernelGGL((k_assemble_cols<M, SAT_T, DEN_T, false, true>), grid, dim3(kBlock), lds, stream, a)
+    if (mode == 0) COLS3(0); else if (mode == 1) COLS3(1); else COLS3(2);
+#undef COLS3
   } else {
     if (mode == 0) COLS(0, false); else if (mode == 1) COLS(1, false); else COLS(2, false);
   }

@@ -63,8 +63,8 @@ def main():
         row("k_tri_solve_lds<2, 4, 3, 4, 2, false>", "… without the line search's sum (a solve whose sums are not folded)", 32 + bspmv + 48),
         row("k_tri_solve_lds<2, 5, 2, 4, 3, false>", "… likewise", 24 + bspmv + 48),
         row("k_tri_solve_lds<2, 4, 3, 4, 1, false>", "`MatMult` + `PCApply` + 2 dots (later iterations, GMRES)", bspmv + 48),
-        row("k_assemble_cols<2, 3, 0, true>", "GE:388-453, 1603-2200 (residual + Jacobian), `PCSetUp`, forward elimination, `VecWAXPY`, 2 `VecNorm`", 148.0),
-        row("k_assemble_cols<0, 3, 0, true>", "GE:388-421, 1603-1938 (residual), `VecWAXPY`, 2 `VecNorm`", 104.0),
+        row("k_assemble_cols<2, 3, 0, true, false>", "GE:388-453, 1603-2200 (residual + Jacobian), `PCSetUp`, forward elimination, `VecWAXPY`, 2 `VecNorm`", 148.0),
+        row("k_assemble_cols<0, 3, 0, true, false>", "GE:388-421, 1603-1938 (residual), `VecWAXPY`, 2 `VecNorm`", 104.0),
         row("k_bcgs_xr<true, true>", "`VecAXPBYPCZ`, `VecWAXPY`, `VecNorm` (r not written when the solve is expected to end) + the line search's Y·Y", 40.0),
         row("k_bcgs_xr<true, false>", "… without Y·Y", 40.0),
         row("k_bc<2>", "boundary fluxes + derivatives (GE:1815-1877, 2076-2139) into side arrays", 0.0),
