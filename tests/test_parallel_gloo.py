@@ -84,6 +84,85 @@ def test_two_rank_gloo_host_logic():
             np.testing.assert_allclose(pr[j * 20:(j + 1) * 20], oo.get(C.AUXVAR_INTERNAL, C.VAR_PRESSURE), rtol=1e-8)
 
 
+def _halo_worker(rank, world, port, q):
+    """one rank of a column-partitioned 7-point mesh: its block built directly (workloads.vchannel_rank), the halo plan executed with
+    gloo point-to-point messages exactly as mppgpu_set_halo describes it (send lists of owned cells per neighbour, ghosts received in
+    the order of the receive counts), then the owned rows of y = J x from the refreshed local vector"""
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        nx, ny, nz = 5, 2 * world, 4
+        part, lp = P.vchannel_rank(nx, ny, nz, world, rank)
+        n_glob = nx * ny * nz
+        xg = np.random.default_rng(99).standard_normal(n_glob)           # the same global vector on every rank
+        x = np.zeros(part.l2g.size)
+        x[:part.nowned] = xg[part.l2g[:part.nowned]]                      # owned values; ghosts not yet known
+        reqs, bufs, off = [], [], part.nowned
+        for k, peer in enumerate(part.peer):
+            send = torch.from_numpy(x[part.send_cells[part.send_ptr[k]:part.send_ptr[k + 1]] - 1].copy())
+            recv = torch.empty(int(part.recv_count[k]), dtype=torch.float64)
+            reqs += [dist.isend(send, int(peer)), dist.irecv(recv, int(peer))]
+            bufs.append((off, recv))
+            off += int(part.recv_count[k])
+        for r in reqs:
+            r.wait()
+        for o, recv in bufs:
+            x[o:o + recv.numel()] = recv.numpy()
+        # the rank's Jacobian rows from the oracle on its LOCAL problem state would need ghost support in the oracle; the global
+        # oracle's rows restricted to the owned cells serve: columns mapped through l2g
+        glob = P.vchannel(nx, ny, nz)
+        o = P.to_oracle(glob)
+        o.set_dtime(glob.dt); o.pre_solve()
+        rp, cj, val = o.jacobian(glob.press_ic - np.random.default_rng(5).uniform(0, 2e5, n_glob))
+        g2l = np.full(n_glob, -1)
+        g2l[part.l2g] = np.arange(part.l2g.size)
+        y = np.zeros(part.nowned)
+        for li in range(part.nowned):
+            gi = part.l2g[li]
+            cols = cj[rp[gi]:rp[gi + 1]]
+            assert (g2l[cols] >= 0).all()                                  # every coupling of an owned row is owned or a ghost
+            y[li] = val[rp[gi]:rp[gi + 1]] @ x[g2l[cols]]
+        q.put((rank, part.l2g[:part.nowned].copy(), y, x.copy(), part.l2g.copy(), int(part.nghost)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gloo_halo_exchange_of_the_whole_column_partition(world):
+    """SURVEY 8(e) on CPU processes: the halo plan of the whole-column partition run with real messages (gloo, world 2 and 3) -- after
+    the exchange every ghost holds its owner's value, and the owned rows of J x formed rank by rank equal the global product"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_halo_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    nx, ny, nz = 5, 2 * world, 4
+    n = nx * ny * nz
+    xg = np.random.default_rng(99).standard_normal(n)
+    glob = P.vchannel(nx, ny, nz)
+    o = P.to_oracle(glob)
+    o.set_dtime(glob.dt); o.pre_solve()
+    rp, cj, val = o.jacobian(glob.press_ic - np.random.default_rng(5).uniform(0, 2e5, n))
+    from oracle import vsfm_oracle as VO
+    y_ref = VO.spmv(rp, cj, val, xg)
+    seen = np.zeros(n, dtype=bool)
+    for rank, own, y, x, l2g, nghost in res:
+        assert np.array_equal(x, xg[l2g])                                  # ghosts hold their owners' values
+        assert nghost == (1 if rank in (0, world - 1) else 2) * nz * nx    # nz x nx cells per neighbour
+        assert np.abs(y - y_ref[own]).max() <= 1e-13 * np.abs(y_ref).max()
+        seen[own] = True
+    assert seen.all()
+
+
 def _hg_worker(rank, world, port, q):
     g = PAR.HostGroup(rank=rank, world=world, addr="127.0.0.1", port=port, timeout=60.0)
     uid = g.broadcast_bytes(bytes(range(128)) if rank == 0 else b"")
