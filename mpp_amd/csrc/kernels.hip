@@ -276,9 +276,14 @@ __global__ __launch_bounds__(kBlock) void k_assemble_cols(ColsArgs a) {
         if (FUSE && js >= 0) di += bc_inline ? (kp == 0 ? sD0 : sD1) : a.side_d[js];
         if (C3D) {   // 7-point rows: the column's tridiagonal at its CSR slots (the lateral pass adds to the diagonal afterwards;
                                     // never with the complete-row march: compiled out of it -- its registers are spoken for)
-          if (kp > 0) a.val[a.slot_lo[ip]] = lo_prev;
-          a.val[a.slot_di[ip]] = di;
-          if (!last) a.val[a.slot_up[ip]] = up_prev;
+          if (a.tri3) {   // coalesced, for the lateral pass to place (it writes the whole row)
+            const size_t nn = (size_t)a.ncols * nz;
+            stnt(kp > 0 ? lo_prev : 0.0, a.tri3 + ip); stnt(di, a.tri3 + nn + ip); stnt(last ? 0.0 : up_prev, a.tri3 + 2 * nn + ip);
+          } else {
+            if (kp > 0) a.val[a.slot_lo[ip]] = lo_prev;
+            a.val[a.slot_di[ip]] = di;
+            if (!last) a.val[a.slot_up[ip]] = up_prev;
+          }
         } else {
           int slot = row_slot(kp);
           if (kp > 0) a.val[slot++] = lo_prev;
@@ -584,7 +589,13 @@ __global__ __launch_bounds__(kBlock) void k_flux_rows_ell(GenArgs a) {
       if (slot[k] >= 0) a.val[slot[k]] = live[k] ? (side == 0 ? Jdn : -Jup) : 0.0;
     }
   }
-  if (JAC && mine) a.val[a.diag_slot[i]] = dconn + a.val[a.diag_slot[i]];
+  if (LAT && JAC && a.tri3) {   // the march left the column's tridiagonal in three arrays: this pass writes the whole row
+    const double lo = ldnt(a.tri3 + i), di = ldnt(a.tri3 + n + i), up = ldnt(a.tri3 + 2 * n + i);
+    const int sl = a.slot_lo[i], su = a.slot_up[i];
+    if (sl >= 0) a.val[sl] = lo;
+    a.val[a.diag_slot[i]] = mine ? dconn + di : di;
+    if (su >= 0) a.val[su] = up;
+  } else if (JAC && mine) a.val[a.diag_slot[i]] = dconn + a.val[a.diag_slot[i]];
   if (RES) {
     if (a.src) f -= a.src[i];
     a.F[i] = f;

@@ -102,6 +102,10 @@ struct ColsArgs {
   // (launch_assemble_cols_lateral).  Never together with col_bc.
   const int *slot_lo = nullptr, *slot_di = nullptr, *slot_up = nullptr;
   AuxOut aux = {nullptr, nullptr, nullptr, nullptr};
+  // ... or (tri3 != nullptr) the tridiagonal goes, coalesced, into three arrays of n entries -- lower at [i], diagonal at [n + i], upper
+  // at [2 n + i] -- and the lateral pass, which holds the row's other four entries, writes the WHOLE CSR row: one kernel fills every
+  // line of the values instead of two kernels each filling part of it
+  double *tri3 = nullptr;
 };
 // mode 0 residual, 1 Jacobian, 2 both
 void launch_assemble_cols(int mode, const ColsArgs &a, hipStream_t stream);
@@ -124,6 +128,10 @@ struct GenArgs {
   double *F, *val;
   int n;
   double dtInv;
+  // lateral pass of a 3-D mesh of complete columns (launch_assemble_cols_lateral) with the march's tridiagonal in three arrays
+  // (ColsArgs::tri3): the row's lower / upper chain slots (-1: none); the pass writes the whole row
+  const double *tri3 = nullptr;
+  const int *slot_lo = nullptr, *slot_up = nullptr;
 };
 void launch_assemble_general(int mode, const GenArgs &a, hipStream_t stream);
 // the lateral half of the assembly of a 3-D mesh of complete soil columns: after launch_assemble_cols with ColsArgs::slot_di / aux set,

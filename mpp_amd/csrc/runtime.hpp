@@ -260,6 +260,7 @@ struct Options {
   bool ls_spec = true;         // ... and the search's first trial point (the full step) is evaluated there too (LsAhead::spec)
   bool cols3d = true;          // 3-D meshes of complete soil columns: column march (accumulation + chain links) + lateral pass instead of the
                                // general auxvar pass + row gather over every connection (Solver::use_cols3d)
+  bool cols3d_rows = true;     // ... with the march's tridiagonal handed over in three coalesced arrays and the lateral pass writing whole CSR rows
   bool ls_fold = true;         // the search's F . (J Y) and ||Y|| out of the kernels of a one-iteration BiCGStab solve (F . (J p), F . (J s) reduced by the
                                // two fused product kernels, Y . Y by the update): no product pass of the search's own (Solver::ksp_bcgs, fold_ls)
   bool wide_xr = true;         // BiCGStab update kernel on a one-pair-per-lane grid (large vectors)

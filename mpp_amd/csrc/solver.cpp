@@ -142,6 +142,7 @@ struct Solver {
   DevBuf<int> d_gc_start, d_gc_nxt, d_gc_prv;
   int gc_n = 0;
   std::vector<int> h_gc_nxt, h_gc_prv;
+  DevBuf<double> d_tri3;   // the march's tridiagonal of a 3-D mesh of complete columns, three arrays of n (ColsArgs::tri3)
   DevBuf<int> d_lat_enc, d_lat_o, d_lat_slot;   // the lateral entries of those lists, four wide (3-D meshes of complete columns)
   int lat_k = 0;
   DevBuf<double> d_val;
@@ -1209,6 +1210,7 @@ struct Solver {
     BigVec<double> a(n), b(n), c(n), d(n);   // (first touched by the threads that fill them)
     host_parallel_for(n, [&](long long i) { const int e = int2ext[i]; a[i] = por[e]; b[i] = sat_res[e]; c[i] = alpha[e]; d[i] = lam[e]; });
     d_por.upload(a, stream); d_sat_res.upload(b, stream); d_alpha.upload(c, stream); d_m.upload(d, stream);
+    if (use_cols3d() && opt.cols3d_rows && d_tri3.n < 3 * (size_t)n) d_tri3.alloc(3 * (size_t)n);
     if (col_operands()) {   // the column march streams porosity x volume as one operand
       HIP_CHECK(hipStreamSynchronize(stream));   // (a is about to be reused)
       host_parallel_for(n, [&](long long i) { a[i] = a[i] * vol[int2ext[i]]; });
@@ -1502,6 +1504,7 @@ struct Solver {
       a.slot_lo = d_tri_lo.p; a.slot_di = d_diag.p; a.slot_up = d_tri_up.p;
       a.aux = AuxOut{aux_kr.p, aux_dkr.p, aux_den.p, aux_dden.p};
       a.src = nullptr;
+      if (opt.cols3d_rows) a.tri3 = d_tri3.p;   // (allocated by ensure_ready)
     }
     return a;
   }
@@ -1521,6 +1524,7 @@ struct Solver {
     GenArgs a = gen_args(P, Fout);
     if (lat_k > 0) { a.ell_enc = d_lat_enc.p; a.ell_o = d_lat_o.p; a.ell_slot = d_lat_slot.p; a.ell_k = lat_k; }
     if (d_DqA.p) a.conn = ConnArrays{d_DqA.p, d_upw.p, d_dgrav.p, nullptr};   // conductance x face area as one operand (col_operands)
+    if (opt.cols3d_rows && d_tri3.p) { a.tri3 = d_tri3.p; a.slot_lo = d_tri_lo.p; a.slot_up = d_tri_up.p; }
     return a;
   }
   BcArgs bc_args(const double *P, double *Fout) const {
@@ -3738,6 +3742,7 @@ struct Solver {
     else if (key == "ls_spec") opt.ls_spec = num() != 0;
     else if (key == "ls_fold") opt.ls_fold = num() != 0;
     else if (key == "cols3d") opt.cols3d = num() != 0;
+    else if (key == "cols3d_rows") opt.cols3d_rows = num() != 0;
     else if (key == "ls_trace") opt.ls_trace = num() != 0;   // one line per bt line search on stderr (development aid)
     else if (key == "fused_spmv_pc") opt.fused_spmv_pc = num() != 0;
     else if (key == "fused_first") opt.fused_first = num() != 0;
