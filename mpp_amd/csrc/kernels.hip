@@ -168,10 +168,15 @@ __global__ __launch_bounds__(kBlock) void k_accum(CellArrays ca, int n, double d
 #define MPP_MARCH_DEPTH_RESIDUAL 2
 #endif
 constexpr int kMarchDepthResidual = MPP_MARCH_DEPTH_RESIDUAL;
+// the residual-only march of the benchmark's soil (no real power at all) needs 102 registers, six more than five waves per SIMD allow
+#ifndef MPP_RESIDUAL_MARCH_WAVES
+#define MPP_RESIDUAL_MARCH_WAVES 5
+#endif
 // C3D (never with FUSE): the march of a 3-D mesh of complete columns -- tridiagonal at the CSR slots of the 7-point rows, auxvars left for
 // the lateral pass (ColsArgs::slot_di, aux); a template parameter so that the marches of vertical-only grids keep their registers
 template <int MODE, int SAT_T, int DEN_T, bool FUSE, bool C3D = false>  // MODE 0 residual, 1 Jacobian, 2 both; SAT_T / DEN_T: see physics.hpp
-__global__ __launch_bounds__(kBlock) void k_assemble_cols(ColsArgs a) {
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((MODE == 0 && SAT_T == kSatVGHalf && DEN_T == 0) ? MPP_RESIDUAL_MARCH_WAVES : 1)))
+void k_assemble_cols(ColsArgs a) {
   __shared__ double red[kBlock / 64];
   extern __shared__ __attribute__((aligned(16))) double cls_lds[];   // [7][ncls] when soil classes are in use
   constexpr bool RES = (MODE == 0 || MODE == 2), JAC = (MODE == 1 || MODE == 2);
@@ -1014,8 +1019,11 @@ __global__ __launch_bounds__(kBlock) void k_spmv_cols_dots(int n, int ncols, int
 // tiles next to it, the two y-neighbour tiles -- so each tile carries up to 8 window bases (int32) and an entry is
 // (window << 13) | offset, 13-bit offset from its window's base.  Same 8 index bytes per 3-point row (+0.5 byte per row
 // for the bases), same values, x, y and summation order as every other variant.
+#ifndef MPP_SPMV_MB_WAVES
+#define MPP_SPMV_MB_WAVES 5
+#endif
 template <int J>
-__global__ __launch_bounds__(kBlock) void k_spmv_pipe_mb(int n, int tpw, const int *__restrict__ tileptr,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MPP_SPMV_MB_WAVES))) void k_spmv_pipe_mb(int n, int tpw, const int *__restrict__ tileptr,
                                                          const unsigned short *__restrict__ roff,
                                                          const unsigned short *__restrict__ mcol, const int *__restrict__ tbase,
                                                          const double *__restrict__ val, const double *__restrict__ x,

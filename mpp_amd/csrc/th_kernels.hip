@@ -21,6 +21,11 @@ namespace mpp {
 namespace {
 
 constexpr int kBlock = 256;
+// the block-Thomas solves (one lane per column, latency-bound at 0.65-0.68 of peak) need 130 registers, two more than four waves per
+// SIMD allow: asked for four (128 registers, no scratch)
+#ifndef MPP_TH_SOLVE_WAVES
+#define MPP_TH_SOLVE_WAVES 4
+#endif
 
 // active[i]: 0 inactive cell, 1 active cell of this rank, 2 ghost cell (a copy of a cell another rank owns: a cell like any other
 // for its neighbours' fluxes, an identity row with a zero right-hand side itself)
@@ -556,7 +561,7 @@ __global__ __launch_bounds__(kBlock) void k_th_tri_solve(ThTriArgs a, const doub
 // writes it): ND = 1 leaves the partial sums of z.z, ND = 2 those of z.w and z.z (in that order) over both fields, one per
 // block, layout partials[j * gridDim.x + block]
 template <int ND>
-__global__ __launch_bounds__(kBlock) void k_th_tri_solve_dots(ThTriArgs a, const double *__restrict__ r, double *__restrict__ z,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MPP_TH_SOLVE_WAVES))) void k_th_tri_solve_dots(ThTriArgs a, const double *__restrict__ r, double *__restrict__ z,
                                                               const double *__restrict__ w, double *__restrict__ partials) {
   __shared__ double lds[kBlock / 64];
   const int c = blockIdx.x * kBlock + threadIdx.x;
@@ -588,7 +593,7 @@ __global__ __launch_bounds__(kBlock) void k_th_tri_solve_dots(ThTriArgs a, const
 // FDOT (round 5): the partial sums of fdot . (A x) over both fields as well, in row ND of `partials` -- the line search's F . (J p) /
 // F . (J s) of a one-iteration BiCGStab solve out of the kernels that hold those rows anyway (Solver::ksp_bcgs, ls_fold)
 template <int ND, bool FDOT = false>
-__global__ __launch_bounds__(kBlock) void k_th_spmv_tri(ThTriArgs a, const double *__restrict__ x, double *__restrict__ z,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MPP_TH_SOLVE_WAVES))) void k_th_spmv_tri(ThTriArgs a, const double *__restrict__ x, double *__restrict__ z,
                                                         const double *__restrict__ w, double *__restrict__ partials,
                                                         const double *__restrict__ fdot) {
 #pragma clang fp contract(off)

@@ -219,7 +219,12 @@ def main():
         if k.startswith("k_tri_solve_lds<2, 5, 2, 4, 3"):
             newton_prof = calls
     bytes_txt = "%.0f" % (tot / N / newton_prof) if newton_prof else "?"
-    subs = {"KERNEL_TABLE": kernel_table, "LAWS_TABLE": laws_table, "RESULTS": results_txt,
+    v3d_pmc = frac_rows("rocprofv3_kernel_stats_vsfm3d_512x512x100.csv", "pmc_vsfm3d_512x512x100.json", 512 * 512 * 100, (
+        ("k_assemble_cols<2, 3, 0, false, true>", "march (residual + Jacobian)"), ("k_flux_rows_ell<2, 4, true>", "lateral pass (residual + Jacobian)"),
+        ("k_assemble_cols<0, 3, 0, false, true>", "march (residual)"), ("k_flux_rows_ell<0, 4, true>", "lateral pass (residual)"),
+        ("k_spmv_pipe_mb<7>", "7-point CSR SpMV `k_spmv_pipe_mb<7>`"), ("k_tri_solve_lds<2, 4, 6, 4, 0, false>", "LDS column solve + 2 dots"),
+        ("k_tri_factor", "column factorisation")))
+    subs = {"V3D_PMC": v3d_pmc or "(PMC passes not in the evidence directory)", "KERNEL_TABLE": kernel_table, "LAWS_TABLE": laws_table, "RESULTS": results_txt,
             "READBACKS": "%.2f–%.2f" % (min(rb(s8), rb(c2s)), max(rb(bench), rb(bench2))),
             "ANSWER": "%.1e" % bench["answer_check"]["max_rel_err"], "SHARE": share, "THERMAL": thermal, "TH": th_line, "BYTES": bytes_txt,
             "TH_PMC": th_pmc or "(PMC passes not in the evidence directory)", "THERMAL_PMC": thermal_pmc or "(PMC passes not in the evidence directory)",
