@@ -168,9 +168,11 @@ __global__ __launch_bounds__(kBlock) void k_accum(CellArrays ca, int n, double d
 #define MPP_MARCH_DEPTH_RESIDUAL 2
 #endif
 constexpr int kMarchDepthResidual = MPP_MARCH_DEPTH_RESIDUAL;
-// the residual-only march of the benchmark's soil (no real power at all) needs 102 registers, six more than five waves per SIMD allow
+// the residual-only march of the benchmark's soil (no real power at all) needs 102 registers, six more than five waves per SIMD allow.
+// Asked for five (amdgpu_waves_per_eu: 96 registers + 32 bytes of scratch per lane) it ran 3-4 % SLOWER (1.044 / 1.070 -> 1.084 / 1.098 ms,
+// profiles/r05/occupancy_hints_ab.json): occupancy is not what holds it; the hint stays off (1 = none)
 #ifndef MPP_RESIDUAL_MARCH_WAVES
-#define MPP_RESIDUAL_MARCH_WAVES 5
+#define MPP_RESIDUAL_MARCH_WAVES 1
 #endif
 // C3D (never with FUSE): the march of a 3-D mesh of complete columns -- tridiagonal at the CSR slots of the 7-point rows, auxvars left for
 // the lateral pass (ColsArgs::slot_di, aux); a template parameter so that the marches of vertical-only grids keep their registers
@@ -1019,8 +1021,10 @@ __global__ __launch_bounds__(kBlock) void k_spmv_cols_dots(int n, int ncols, int
 // tiles next to it, the two y-neighbour tiles -- so each tile carries up to 8 window bases (int32) and an entry is
 // (window << 13) | offset, 13-bit offset from its window's base.  Same 8 index bytes per 3-point row (+0.5 byte per row
 // for the bases), same values, x, y and summation order as every other variant.
+// (103 registers at J = 7; asked for five waves per SIMD -- 96 registers, 36 bytes of scratch -- the 7-point product went from 0.445 to
+// 0.538 ms: the spills sit in its inner loop; off, profiles/r05/occupancy_hints_ab.json)
 #ifndef MPP_SPMV_MB_WAVES
-#define MPP_SPMV_MB_WAVES 5
+#define MPP_SPMV_MB_WAVES 1
 #endif
 template <int J>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MPP_SPMV_MB_WAVES))) void k_spmv_pipe_mb(int n, int tpw, const int *__restrict__ tileptr,

@@ -22,9 +22,10 @@ namespace {
 
 constexpr int kBlock = 256;
 // the block-Thomas solves (one lane per column, latency-bound at 0.65-0.68 of peak) need 130 registers, two more than four waves per
-// SIMD allow: asked for four (128 registers, no scratch)
+// SIMD allow; asked for four (128 registers, no scratch) the coupled benchmark did not move (125.5 / 123.8 -> 123.1 / 126.8 Newton it/s,
+// profiles/r05/occupancy_hints_ab.json): the hint stays off (1 = none)
 #ifndef MPP_TH_SOLVE_WAVES
-#define MPP_TH_SOLVE_WAVES 4
+#define MPP_TH_SOLVE_WAVES 1
 #endif
 
 // active[i]: 0 inactive cell, 1 active cell of this rank, 2 ghost cell (a copy of a cell another rank owns: a cell like any other
