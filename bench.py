@@ -19,8 +19,11 @@ group (mpp_amd.parallel.HostGroup).
 
 --workload thermal / th: the other two BASELINE configurations through the same launcher, rank set-up and output line (see
 run_thermal / run_th below): thermal n^3 heat diffusion (config 4; GMRES(30) + ILU(0), the mesh split into z-slabs with ghost
-planes and an RCCL halo exchange) and the coupled thermal-hydrology columns (config 5; column-sharded like the VSFM grid).  The
-default workload, and its line, are the VSFM headline.
+planes and an RCCL halo exchange) and the coupled thermal-hydrology columns (config 5; column-sharded like the VSFM grid).
+--workload vsfm3d / --workload th --mesh 3d: the 7-point grids (SURVEY 8d's 3-D variant: v-channel soil and geometry); N > 1: ranks own
+x-y blocks of WHOLE soil columns, the neighbours' edge columns as ghosts (mpp_amd.workloads.vchannel_rank builds a rank's block
+without the global mesh).  The default workload, and its line, are the VSFM headline; at N = 1 its extra_configs carry a short run of the
+7-point grid whose `roofline` is the CSR SpMV proper inside that run's own timed region.
 
 Prints ONE JSON line (rank 0).
 """
