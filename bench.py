@@ -1040,9 +1040,10 @@ def main():
         csr_bytes = float(stats["spmv"]["bytes_per_launch"])           # 12 nnz + 20 N + 4
         nnz_local = (csr_bytes - 20.0 * n_local - 4.0) / 12.0
         if folded:
-            # the two kernels of an iteration, averaged: values 8 nnz; first kernel d, c, 1/pivot in, x out, then F in, c, 1/pivot, x again,
-            # z out = 72 N; second kernel r, v, F in, s out, c, 1/pivot, s again, z out = 64 N
-            own_bytes = 8.0 * nnz_local + 68.0 * n_local
+            # the two kernels of an iteration: values 8 nnz each; first kernel d inv, g in, x out, then F in, g, x again, z out = 56 N;
+            # second kernel r, v, F in, s out, g, s again, z out = 56 N  (g = up / pivot: the back substitution in product form,
+            # DESIGN.md section 6; until round 5's first half c and 1 / pivot were read in their place: 72 N and 64 N)
+            own_bytes = 8.0 * nnz_local + 56.0 * n_local
             csr_bytes = float(sp["bytes_per_launch"])                   # SURVEY's count of the SpMV + PCApply pair it replaces
         else:
             own_bytes = 8.0 * nnz_local + 16.0 * n_local if index_free else csr_bytes
@@ -1052,8 +1053,8 @@ def main():
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(min(achieved / HBM_PEAK_GBS, 1.0), 4), "traffic": traffic,
                 "achieved_is": ("the timed kernels' own byte model, averaged over the two fused kernels of a BiCGStab iteration: values 8 nnz + "
-                                "68 N (first: d, c, 1/pivot in, x out, F in, c, 1/pivot, x again, z out; second: r, v, F in, s out, c, 1/pivot, s "
-                                "again, z out) / HIP-event average launch time of those launches inside the timed region.  achieved_algorithmic = "
+                                "56 N (first: d/pivot, g in, x out, F in, g, x again, z out; second: r, v, F in, s out, g, s "
+                                "again, z out; g = upper entry / pivot) / HIP-event average launch time of those launches inside the timed region.  achieved_algorithmic = "
                                 "SURVEY 8(d)'s count of the CSR SpMV + PCApply pair each launch replaces (12 nnz + 60 N + 4) over the same time")
                                if folded else
                                (("the timed kernel's own byte model (index-free launches: values 8 nnz + x 8 N + f 8 N; no column index, no row "

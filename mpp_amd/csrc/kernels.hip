@@ -147,6 +147,18 @@ __global__ __launch_bounds__(kBlock) void k_accum(CellArrays ca, int n, double d
   out[i] = acc;
 }
 
+// Column LU (Thomas) as every kernel stores and applies it (round 5: the back substitution in product form):
+//   l_k = lo_k inv_{k-1},  inv_k = 1 / fma(-l_k, up_{k-1}, di_k),  g_k = up_k inv_k   (plane c holds g, not the upper entries)
+//   forward  d_k = r_k - l_k d_{k-1};   backward  x_k = fma(-g_k, x_{k+1}, d_k inv_k)
+// A kernel that has inv_k in a register when it parks d_k (the fused products: they redo the pivots) parks d_k inv_k, and its back
+// sweep reads g alone -- 8 instead of 16 bytes a cell; the assembly march leaves its forward-eliminated residual scaled the same way.
+// The two products are rounded by themselves wherever they are formed (tri_scale), so that every kernel gives the same bits.
+__device__ __forceinline__ double tri_scale(double a, double b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ __forceinline__ double tri_back(double t, double g, double next) { return fma(-g, next, t); }   // t = d inv
+
 // ------------------------------------------------------------------------------------------------
 // fused column march: auxvars + accumulation + vertical fluxes (+ derivatives) in one pass.
 // Restates RichardsODEComputeResidual / ComputeJacobian (GoveqnRichardsODEPressureType.F90:388-453) for meshes
@@ -302,11 +314,11 @@ void k_assemble_cols(ColsArgs a) {
           const double piv = fma(-l, c_pp, di);   // (written as the fma it is: k_tri_solve_lds recomputes l and must round alike)
           const double inv = 1.0 / piv;
           if (a.store_l) stnt(l, a.tl + ip);
-          stnt(inv, a.tinvb + ip); stnt(up_prev, a.tc + ip);
+          stnt(inv, a.tinvb + ip); stnt(tri_scale(up_prev, inv), a.tc + ip);
           inv_pp = inv; c_pp = up_prev;
-          if (a.fwd) {   // forward elimination of the residual as well: the Krylov solver's first M^{-1} F starts from here
+          if (a.fwd) {   // forward elimination of the residual as well (left scaled: d inv): the Krylov solver's first M^{-1} F starts from here
             const double d = (RES ? f_row : Fin_prev) - l * d_pp;
-            stnt(d, a.fwd + ip);
+            stnt(tri_scale(d, inv), a.fwd + ip);
             d_pp = d;
           }
         }
@@ -1126,7 +1138,7 @@ __global__ __launch_bounds__(kBlock) void k_tri_factor(TriArgs a) {
     const double l = lo * inv_prev;
     const double piv = fma(-l, c_prev, di);
     const double inv = 1.0 / piv;
-    a.l[i] = l; a.invb[i] = inv; a.c[i] = up;
+    a.l[i] = l; a.invb[i] = inv; a.c[i] = tri_scale(up, inv);
     inv_prev = inv; c_prev = up;
   }
 }
@@ -1145,7 +1157,7 @@ __global__ __launch_bounds__(kBlock) void k_chain_tri_factor(ColChainArgs a) {
     const double l = lo * inv_prev;
     const double piv = fma(-l, c_prev, di);
     const double inv = 1.0 / piv;
-    a.t.l[i] = l; a.t.invb[i] = inv; a.t.c[i] = up;
+    a.t.l[i] = l; a.t.invb[i] = inv; a.t.c[i] = tri_scale(up, inv);
     inv_prev = inv; c_prev = up;
   }
 }
@@ -1162,7 +1174,7 @@ __global__ __launch_bounds__(kBlock) void k_chain_tri_solve(ColChainArgs a, cons
   }
   double next = 0.0;
   for (int i = last; i >= 0; i = a.prv[i]) {
-    const double xk = (z[i] - a.t.c[i] * next) * a.t.invb[i];
+    const double xk = tri_back(tri_scale(z[i], a.t.invb[i]), a.t.c[i], next);
     z[i] = xk;
     next = xk;
   }
@@ -1185,7 +1197,7 @@ __global__ __launch_bounds__(kBlock) void k_tri_solve(TriArgs a, const double *_
 #pragma unroll 4
   for (int k = a.nz - 1; k >= 0; --k) {
     const size_t i = cbase + (size_t)k * tw;
-    const double xk = (z[i] - ldnt(a.c + i) * next) * ldnt(a.invb + i);
+    const double xk = tri_back(tri_scale(z[i], ldnt(a.invb + i)), ldnt(a.c + i), next);
     stnt(xk, z + i);
     next = xk;
   }
@@ -2402,7 +2414,7 @@ __global__ __launch_bounds__(kBlock) void k_tri_solve_dots(TriArgs a, const doub
 #pragma unroll 4
     for (int k = a.nz - 1; k >= 0; --k) {
       const size_t i = cbase + (size_t)k * tw;
-      const double xk = (z[i] - ldnt(a.c + i) * next) * ldnt(a.invb + i);
+      const double xk = tri_back(tri_scale(z[i], ldnt(a.invb + i)), ldnt(a.c + i), next);
       z[i] = xk;
       next = xk;
       if (ND == 2) { acc0 += xk * w[i]; acc1 += xk * xk; } else acc0 += xk * xk;
@@ -2460,13 +2472,13 @@ __global__ __launch_bounds__(64) void k_tri_solve_lds(TriArgs a, const double *_
   double accx = 0.0, accf = 0.0;
   if (SPMV == 2) {   // x = U^{-1} d, top down
     double *xs = valid ? xout + cbase : scratch64 + lane;
-    double cb[RB][G], ib[RB][G], db[RB][G];
+    double cb[RB][G], db[RB][G];
     auto fetch = [&](int q, int ktop) {
 #pragma unroll
       for (int j = 0; j < G; ++j) {
         const size_t i = cbase + (size_t)max(ktop - j, 0) * tw;
-        // (c and 1 / pivot are read again by this kernel's last sweep, a tile's worth later: plain loads, so that the caches may keep them)
-        cb[q][j] = a.c[i]; ib[q][j] = a.invb[i]; db[q][j] = ldnt(r + i);
+        // (g is read again by this kernel's last sweep, a tile's worth later: a plain load, so that the caches may keep it)
+        cb[q][j] = a.c[i]; db[q][j] = ldnt(r + i);
       }
     };
 #pragma unroll
@@ -2479,7 +2491,7 @@ __global__ __launch_bounds__(64) void k_tri_solve_lds(TriArgs a, const double *_
 #pragma unroll
         for (int j = 0; j < G; ++j) {
           const int k = k0 - q * G - j;
-          const double xk = (db[q][j] - cb[q][j] * next) * ib[q][j];
+          const double xk = tri_back(db[q][j], cb[q][j], next);
           next = xk;
           xs[(size_t)k * tws] = xk;   // (plain store: the last sweep reads it back as the dot products' w)
           dsl[k * 64 + lane] = xk;
@@ -2496,7 +2508,7 @@ __global__ __launch_bounds__(64) void k_tri_solve_lds(TriArgs a, const double *_
       for (int j = 0; j < G; ++j) {
         const int k = k0 - q * G - j;
         if (k >= 0) {
-          const double xk = (db[q][j] - cb[q][j] * next) * ib[q][j];
+          const double xk = tri_back(db[q][j], cb[q][j], next);
           next = xk;
           xs[(size_t)k * tws] = xk;   // (plain store: the last sweep reads it back as the dot products' w)
           dsl[k * 64 + lane] = xk;
@@ -2548,7 +2560,7 @@ __global__ __launch_bounds__(64) void k_tri_solve_lds(TriArgs a, const double *_
       if (FDOT) accf += pf * rk;                // (row kr of A x meets fdot_kr: the line search's F . (J Y), see FDOT above)
       const double d = fma(-pl, prev, rk);
       prev = d;
-      dsl[kr * 64 + lane] = d;
+      dsl[kr * 64 + lane] = tri_scale(d, finv);   // (finv: still row kr's -- parked as the back sweep wants it)
     };
     auto step = [&](int k, double xk, double lo, double di, double up, double vk, double fk) {
       if (SPMV == 2) xk = dsl[k * 64 + lane];   // (rows below k have been replaced by their eliminated sums already: not needed any more)
@@ -2628,12 +2640,13 @@ __global__ __launch_bounds__(64) void k_tri_solve_lds(TriArgs a, const double *_
   }
   double acc0 = 0.0, acc1 = 0.0;
   {
-    double cb[RB][G], ib[RB][G], wb[RB][G];
+    double cb[RB][G], ib[SPMV ? 1 : RB][SPMV ? 1 : G], wb[RB][G];
     auto fetch = [&](int q, int ktop) {   // levels ktop, ktop-1, ..., ktop-G+1 (clamped at 0) into group q
 #pragma unroll
       for (int j = 0; j < G; ++j) {
         const size_t i = cbase + (size_t)max(ktop - j, 0) * tw;
-        cb[q][j] = ldnt(a.c + i); ib[q][j] = ldnt(a.invb + i);
+        cb[q][j] = ldnt(a.c + i);
+        if (!SPMV) ib[q][j] = ldnt(a.invb + i);   // (SPMV: the slab holds d inv already)
         if (ND == 2) wb[q][j] = (SPMV >= 2) ? xout[i] : ldnt(w + i);   // (SPMV >= 2: w is the x this kernel wrote a tile's worth
                                                                          // ago -- same pointer, plain store and load: the caches may still hold it)
       }
@@ -2648,7 +2661,7 @@ __global__ __launch_bounds__(64) void k_tri_solve_lds(TriArgs a, const double *_
 #pragma unroll
         for (int j = 0; j < G; ++j) {
           const int k = k0 - q * G - j;
-          const double xk = (dsl[k * 64 + lane] - cb[q][j] * next) * ib[q][j];
+          const double xk = tri_back(SPMV ? dsl[k * 64 + lane] : tri_scale(dsl[k * 64 + lane], ib[q][j]), cb[q][j], next);
           next = xk;
           stnt(xk, zs + (size_t)k * tws);
           if (ND == 2) { acc0 += xk * wb[q][j]; acc1 += xk * xk; } else acc0 += xk * xk;
@@ -2664,7 +2677,7 @@ __global__ __launch_bounds__(64) void k_tri_solve_lds(TriArgs a, const double *_
       for (int j = 0; j < G; ++j) {
         const int k = k0 - q * G - j;
         if (k >= 0) {
-          const double xk = (dsl[k * 64 + lane] - cb[q][j] * next) * ib[q][j];
+          const double xk = tri_back(SPMV ? dsl[k * 64 + lane] : tri_scale(dsl[k * 64 + lane], ib[q][j]), cb[q][j], next);
           next = xk;
           stnt(xk, zs + (size_t)k * tws);
           if (ND == 2) { acc0 += xk * wb[q][j]; acc1 += xk * xk; } else acc0 += xk * xk;
@@ -2703,7 +2716,7 @@ __global__ __launch_bounds__(kBlock) void k_tri_back_dots(TriArgs a, const doubl
 #pragma unroll 4
     for (int k = a.nz - 1; k >= 0; --k) {
       const size_t i = cbase + (size_t)k * tw;
-      const double xk = (ldnt(d + i) - ldnt(a.c + i) * next) * ldnt(a.invb + i);
+      const double xk = tri_back(ldnt(d + i), ldnt(a.c + i), next);   // (d: the march's forward-eliminated residual, scaled by inv already)
       stnt(xk, z + i);
       next = xk;
       acc += xk * xk;

@@ -446,10 +446,14 @@ struct ThTriArgs {
   int ncols, nz, n, nnzc;
   const int *crowptr, *tri_lo, *cdiag, *tri_up;   // cell-pattern slots of the (k-1), k, (k+1) entries of cell row (k,c); -1 absent
   const double *val;                               // the 2N x 2N CSR values
-  double *L, *inv, *C;                             // 2 x 2 blocks as four planes of n doubles each: [q*n + i], q = pp, pt, tp, tt
+  double *L, *inv, *C;                             // 2 x 2 blocks as four planes of n doubles each: [q*n + i], q = pp, pt, tp, tt:
+                                                   // L = the lower blocks (a copy), inv = the pivots' inverses, C = inv * upper block
   int stage = 1;                                   // rows of `val` through LDS (option th_stage; 0 for the A/B)
+  int inv_fly = 0;                                 // plane inv neither written by the combined factorisation + solve nor read by the fused products
 };
 void launch_th_tri_factor(const ThTriArgs &a, hipStream_t stream);
+// the factorisation and z = M^{-1} r with its dot products (as launch_th_tri_solve_dots) in one sweep; plane L is NOT written
+int launch_th_tri_factor_solve_dots(const ThTriArgs &a, const double *r, double *z, const double *w, double *partials, hipStream_t stream);
 // y = A x of the coupled system on a vertical-only grid from the values at their computed places (no index; a.L / a.inv / a.C unused)
 void launch_th_spmv_cols(const ThTriArgs &a, const double *x, double *y, hipStream_t stream);
 // the same product with the line search's sums: partials[j * blocks + b] = x.x, f.(A x), q.q (q may be null: two sums), A x not written;

@@ -229,6 +229,8 @@ struct Options {
   bool spmv_cols_dots = true;  // scalar system on soil columns: the line search's product + sums from the column tridiagonals at their computed places
   bool lazy_tri_l = true;      // column LU of the scalar system: the march does not store l where the fused SpMV + solve kernels will run
   bool th_spmv_tri = true;     // coupled TH on soil columns, block-Jacobi: SpMV + block-Thomas solve + dots as one kernel (k_th_spmv_tri)
+  bool th_lazy_factor = true;  // coupled TH, BiCGStab + block-Jacobi: the block factorisation rides on the first solve's sweep (k_th_tri_factor<true, .>)
+  bool th_inv_fly = true;      // ... and the fused products (k_th_spmv_tri<.., true>) redo the pivots' inverses from the rows they hold: plane inv neither written nor read
   bool th_stage = true;        // TH factorisation / index-free SpMV: matrix rows staged through LDS (off: the lane-by-lane reads, for the A/B)
   bool th_spmv_cols = true;    // coupled TH on soil columns: y = A x from the block-tridiagonal values at their computed places (no index)
   bool th_fused_dots = true;   // coupled TH, bjacobi: the Krylov dot products of M^{-1} r come out of the block column solve

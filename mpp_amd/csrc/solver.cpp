@@ -1837,15 +1837,23 @@ struct Solver {
   }
   ColChainArgs chain_args() const { return ColChainArgs{gc_n, d_gc_start.p, d_gc_nxt.p, d_gc_prv.p, tri_args()}; }
   ThTriArgs th_tri_args() const {
-    return ThTriArgs{ncols, nz, n, nnzc, d_crowptr.p, d_tri_lo.p, d_cdiag.p, d_tri_up.p, d_val.p, thtri_L.p, thtri_inv.p, thtri_C.p, opt.th_stage ? 1 : 0};
+    return ThTriArgs{ncols, nz, n, nnzc, d_crowptr.p, d_tri_lo.p, d_cdiag.p, d_tri_up.p, d_val.p, thtri_L.p, thtri_inv.p, thtri_C.p, opt.th_stage ? 1 : 0,
+                     opt.th_inv_fly ? 1 : 0};
   }
   void op_pc_setup() {
     if (pc_ready) return;
-    ProfScope ps(prof, KC_PC_SETUP);
     if (opt.pc_type == 2 && th) {
       if (!vertical_only || !columns) throw Error("pc_type bjacobi of the coupled system needs a grid whose connections are all vertical (use ilu)");
       if (!thtri_L.p) { thtri_L.alloc(4 * (size_t)n); thtri_inv.alloc(4 * (size_t)n); thtri_C.alloc(4 * (size_t)n); }
+      // BiCGStab's first act is z = M^{-1} b with its norm: the factorisation rides on that solve's sweep (k_th_tri_factor<true, .>,
+      // op_pc_apply_dots); any other consumer of the factors runs the factorisation by itself first (ensure_th_factor)
+      th_factor_pending = opt.th_lazy_factor && opt.ksp_type == 2 && fused_pc_dots() && th_index_free() && opt.th_spmv_tri;
+      if (th_factor_pending) { pc_ready = true; return; }   // (no launch of the set-up class)
+    }
+    ProfScope ps(prof, KC_PC_SETUP);
+    if (opt.pc_type == 2 && th) {
       launch_th_tri_factor(th_tri_args(), stream);
+      th_l_valid = true;
     } else if (opt.pc_type == 2) {
       if (gc_n > 0) launch_chain_tri_factor(chain_args(), stream); else launch_tri_factor(tri_args(), stream);
       tri_l_valid = true;
@@ -1989,7 +1997,7 @@ struct Solver {
   void op_pc_apply(const double *r, double *z) {
     ProfScope ps(prof, KC_PC_APPLY);
     if (nghost > 0 && !th) launch_set(nghost, 0.0, const_cast<double *>(r) + nred, stream);   // block-Jacobi across ranks (TH: zero already)
-    if (opt.pc_type == 2 && th) launch_th_tri_solve(th_tri_args(), r, z, stream);
+    if (opt.pc_type == 2 && th) { ensure_th_factor(true); launch_th_tri_solve(th_tri_args(), r, z, stream); }
     else if (opt.pc_type == 2 && gc_n > 0) launch_chain_tri_solve(chain_args(), r, z, stream);   // (a rank of a split mesh: columns as chains)
     else if (opt.pc_type == 2) { ensure_tri_l(); launch_tri_solve(tri_args(), r, z, stream); }
     else if (opt.pc_type == 3) launch_pointwise_mult(nred, jac_invd.p, r, z, stream);
@@ -2035,6 +2043,16 @@ struct Solver {
            fused_pc_dots();
   }
   bool tri_l_valid = true;
+  // coupled system, block Thomas: the factors not computed yet (the first solve will, on its way) / planes L and inv (what the
+  // stand-alone solves read besides G: the combined kernel writes no L, and no inv either under th_inv_fly) hold the present factors
+  bool th_factor_pending = false, th_l_valid = false;
+  void ensure_th_factor(bool need_l) {
+    if (!th || opt.pc_type != 2 || !pc_ready) return;
+    if (!th_factor_pending && (th_l_valid || !need_l)) return;
+    launch_th_tri_factor(th_tri_args(), stream);
+    th_factor_pending = false;
+    th_l_valid = true;
+  }
   void ensure_tri_l() {
     if (tri_l_valid || th || thermal) return;
     ProfScope ps(prof, KC_PC_SETUP);
@@ -2056,6 +2074,7 @@ struct Solver {
       const int nv = (w ? 2 : 1) + ((fdot && w) ? 1 : 0);
       {
         ProfScope ps(prof, KC_SPMV_PC);
+        ensure_th_factor(false);
         const int nbk = launch_th_spmv_tri(th_tri_args(), v, t, w, col_partials.p, stream, w ? fdot : nullptr);
         finalize(nbk, nv, col_partials.p, slot, step);
       }
@@ -2109,7 +2128,11 @@ struct Solver {
     {
       ProfScope ps(prof, KC_PC_APPLY);
       int nbk;
-      if (th) nbk = launch_th_tri_solve_dots(th_tri_args(), r, z, w, col_partials.p, stream);
+      if (th && th_factor_pending) {
+        nbk = launch_th_tri_factor_solve_dots(th_tri_args(), r, z, w, col_partials.p, stream);
+        th_factor_pending = false;
+        th_l_valid = false;
+      } else if (th) { ensure_th_factor(true); nbk = launch_th_tri_solve_dots(th_tri_args(), r, z, w, col_partials.p, stream); }
       else if (!w && r == fwd_rhs && pc_ready)
         nbk = launch_tri_back_dots(tri_args(), fwd_elim.p, z, col_partials.p, stream);
       else if (tri_lds()) { ensure_tri_l(); nbk = launch_tri_solve_lds(tri_args(), r, z, w, col_partials.p, tri_scratch.p, opt.tri_group, stream); }
@@ -3713,6 +3736,8 @@ struct Solver {
     else if (key == "lazy_tri_l") opt.lazy_tri_l = num() != 0;   // column LU: elimination factors not stored by the march where the fused solves redo them
     else if (key == "th_spmv_tri") opt.th_spmv_tri = num() != 0;   // coupled system on columns: M^{-1} A v + dots in one kernel
     else if (key == "th_stage") opt.th_stage = num() != 0;
+    else if (key == "th_lazy_factor") opt.th_lazy_factor = num() != 0;   // coupled system: block factorisation inside the first solve's sweep
+    else if (key == "th_inv_fly") opt.th_inv_fly = num() != 0;           // ... and the fused products redo the pivots' inverses instead of reading them
     else if (key == "setup_device") { need_setup(false); opt.setup_device = num() != 0; }   // incidence lists built on the device (0: on the host)
     else if (key == "setup_verify") { need_setup(false); opt.setup_verify = num() != 0; }   // ... both, compared (an error if they differ)
     else if (key == "ilu_box") { opt.ilu_box = (int)num(); pc_ready = false; }   // the factors are repacked for the other solve path
@@ -4298,7 +4323,7 @@ int mppgpu_bench_kernel(mppgpu_handle h, const char *name, int variant, int reps
       S.op_pc_apply_dots(S.F.p, S.G.p, S.W.p, 0, 0);
       S.opt.tri_lds = keep;
     }
-    else if (k == "pc_setup") { cls = mpp::KC_PC_SETUP; S.pc_ready = false; S.op_pc_setup(); }
+    else if (k == "pc_setup") { cls = mpp::KC_PC_SETUP; S.pc_ready = false; S.op_pc_setup(); S.ensure_th_factor(true); }
     else if (k == "residual") { cls = mpp::KC_RESIDUAL; S.op_residual(S.soln.p, S.G.p); }
     else if (k == "jacobian") { cls = mpp::KC_JACOBIAN; S.op_jacobian(S.soln.p); }
     else if (k == "assemble_both") { cls = mpp::KC_JACOBIAN; S.op_residual_jacobian(S.soln.p, S.G.p); }

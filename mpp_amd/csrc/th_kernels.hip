@@ -203,13 +203,6 @@ __device__ __forceinline__ B2 b2_load(const double *p, size_t n, size_t i) { ret
 __device__ __forceinline__ void b2_store(double *p, size_t n, size_t i, const B2 &b) {
   p[i] = b.pp; p[n + i] = b.pt; p[2 * n + i] = b.tp; p[3 * n + i] = b.tt;
 }
-__device__ __forceinline__ B2 b2_mul(const B2 &x, const B2 &y) {
-  return B2{x.pp * y.pp + x.pt * y.tp, x.pp * y.pt + x.pt * y.tt, x.tp * y.pp + x.tt * y.tp, x.tp * y.pt + x.tt * y.tt};
-}
-__device__ __forceinline__ B2 b2_inv(const B2 &x) {
-  const double id = 1.0 / (x.pp * x.tt - x.pt * x.tp);
-  return B2{x.tt * id, -x.pt * id, -x.tp * id, x.pp * id};
-}
 
 struct ThRowAcc {      // what a row accumulates before it is written
   double fm, fe;
@@ -414,95 +407,154 @@ __device__ __forceinline__ B2 b2_load_val(const ThTriArgs &a, size_t i, int s) {
   const size_t g = (size_t)r0 + s, h = (size_t)2 * a.nnzc + g;
   return B2{a.val[g], a.val[g + len], a.val[h], a.val[h + len]};
 }
+__device__ __forceinline__ double th_block_sum(double v, double *lds) {   // lanes -> wave leaders -> thread 0 (fixed order)
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = 0.0;
+  if (threadIdx.x == 0) for (int q = 0; q < kBlock / 64; ++q) t += lds[q];
+  return t;
+}
+// Block Thomas as the kernels below store and apply it (round 5; before: L = lo inv_prev, the pivots' inverses and a copy of the upper
+// blocks, 96 bytes a cell read by every solve):
+//   G_k = inv_k up_k,  inv_k = (di_k - lo_k G_{k-1})^{-1};   forward  e_k = inv_k (r_k - lo_k e_{k-1});   backward  z_k = e_k - G_k z_{k+1}
+// A solve reads inv on the way up and G on the way down (64 bytes a cell), and lo is the matrix's own lower block: the fused
+// k_th_spmv_tri holds it anyway (the row it multiplies), the stand-alone solves read the copy in plane L.  Every product and sum of
+// the elimination is rounded by itself (no contraction) in every kernel that performs it: they must agree bit for bit.
+__device__ __forceinline__ B2 b2_mul_nc(const B2 &x, const B2 &y) {
+#pragma clang fp contract(off)
+  return B2{x.pp * y.pp + x.pt * y.tp, x.pp * y.pt + x.pt * y.tt, x.tp * y.pp + x.tt * y.tp, x.tp * y.pt + x.tt * y.tt};
+}
+__device__ __forceinline__ void th_factor_level(const B2 &lo, const B2 &di, const B2 &up, const B2 &g_prev, B2 &inv, B2 &g) {
+#pragma clang fp contract(off)
+  const B2 lg = b2_mul_nc(lo, g_prev);
+  const B2 piv{di.pp - lg.pp, di.pt - lg.pt, di.tp - lg.tp, di.tt - lg.tt};
+  const double id = 1.0 / (piv.pp * piv.tt - piv.pt * piv.tp);
+  inv = B2{piv.tt * id, -piv.pt * id, -piv.tp * id, piv.pp * id};
+  g = b2_mul_nc(inv, up);
+}
+// e = inv (r - lo e_prev), the forward step of every solve
+__device__ __forceinline__ void th_forward_level(const B2 &lo, const B2 &inv, double rp, double rt, double &ep, double &et) {
+#pragma clang fp contract(off)
+  const double tp = rp - (lo.pp * ep + lo.pt * et);
+  const double tt = rt - (lo.tp * ep + lo.tt * et);
+  ep = inv.pp * tp + inv.pt * tt;
+  et = inv.tp * tp + inv.tt * tt;
+}
+
+template <int ND> __device__ __forceinline__ void th_tri_backward_column(const ThTriArgs &a, double *__restrict__ z, const double *__restrict__ w,
+                                                                         size_t cbase, int tw, double &acc0, double &acc1);
+
 // The rows of a level of a full column tile are one contiguous piece of `val` per block row; lane by lane a row is a 48-byte stride
 // (see k_th_spmv_cols), so a wave stages the two pieces of the level in LDS with 16-byte loads in address order and every lane
 // takes its three blocks from there.  The slots (tri_lo, cdiag, tri_up, crowptr) are still read and checked against the column
 // layout, level by level: a wave that finds anything else reads through them as before.
-__global__ __launch_bounds__(kBlock) void k_th_tri_factor(ThTriArgs a) {
+// SOLVE (round 5): the factorisation and the first solve of a Krylov solve, z = M^{-1} r with the sums of z.z (ND = 1) or z.w and z.z
+// (ND = 2), as one kernel -- the elimination of r rides on the factorisation's sweep (the operands it needs are in registers), plane L
+// is not written (the fused products that follow take lo from the matrix), and the factorisation's pass of its own (0.76 ms and 208
+// bytes a cell at 512 x 512 x 80) is gone from a Newton iteration.
+template <bool SOLVE, int ND>
+__global__ __launch_bounds__(kBlock) void k_th_tri_factor(ThTriArgs a, const double *__restrict__ r, double *__restrict__ z,
+                                                          const double *__restrict__ w, double *__restrict__ partials) {
   typedef double dpair __attribute__((ext_vector_type(2)));   // two doubles, one 16-byte access
   __shared__ dpair stage[kBlock / 64][2][64 * 3];
+  __shared__ double lds[kBlock / 64];
   const int c = blockIdx.x * kBlock + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (c - lane >= a.ncols) return;   // (the whole wave)
-  const bool live = c < a.ncols;
-  const int tile = c >> 6, tw = min(64, a.ncols - (tile << 6));
-  const size_t cbase = (size_t)tile * 64 * a.nz + lane, n = (size_t)a.n;
-  B2 inv_prev{0, 0, 0, 0}, c_prev{0, 0, 0, 0};
-  for (int k = 0; k < a.nz; ++k) {
-    const size_t i = cbase + (size_t)k * tw;
-    const B2 zero{0, 0, 0, 0};
-    B2 lo = zero, di = zero, up = zero;
-    bool staged = false;
-    if (tw == 64 && a.stage) {   // (every lane is a column)
-      const int len = 3 - (k == 0) - (k == a.nz - 1);
-      const int base = a.crowptr[i - lane], r0 = a.crowptr[i], sl = a.tri_lo[i], sd = a.cdiag[i], su = a.tri_up[i];
-      const bool mine = a.crowptr[i - lane + 64] - base == 64 * len && r0 - base == lane * len && sl == (k > 0 ? r0 : -1) &&
-                        sd == r0 + (k > 0) && su == (k < a.nz - 1 ? sd + 1 : -1);
-      if (__builtin_amdgcn_ballot_w64(mine) == ~0ull) {
-        const dpair *gP = reinterpret_cast<const dpair *>(a.val + (size_t)2 * base),
-                    *gT = reinterpret_cast<const dpair *>(a.val + (size_t)2 * a.nnzc + (size_t)2 * base);
-        dpair *sP = stage[wave][0], *sT = stage[wave][1];
-        for (int j = 0; j < len; ++j) {
-          sP[j * 64 + lane] = __builtin_nontemporal_load(gP + j * 64 + lane);
-          sT[j * 64 + lane] = __builtin_nontemporal_load(gT + j * 64 + lane);
+  double acc0 = 0.0, acc1 = 0.0;
+  if (c - lane < a.ncols) {   // (the whole wave)
+    const bool live = c < a.ncols;
+    const int tile = c >> 6, tw = min(64, a.ncols - (tile << 6));
+    const size_t cbase = (size_t)tile * 64 * a.nz + lane, n = (size_t)a.n;
+    B2 g_prev{0, 0, 0, 0};
+    double ep = 0.0, et = 0.0;
+    for (int k = 0; k < a.nz; ++k) {
+      const size_t i = cbase + (size_t)k * tw;
+      const B2 zero{0, 0, 0, 0};
+      B2 lo = zero, di = zero, up = zero;
+      bool staged = false;
+      if (tw == 64 && a.stage) {   // (every lane is a column)
+        const int len = 3 - (k == 0) - (k == a.nz - 1);
+        const int base = a.crowptr[i - lane], r0 = a.crowptr[i], sl = a.tri_lo[i], sd = a.cdiag[i], su = a.tri_up[i];
+        const bool mine = a.crowptr[i - lane + 64] - base == 64 * len && r0 - base == lane * len && sl == (k > 0 ? r0 : -1) &&
+                          sd == r0 + (k > 0) && su == (k < a.nz - 1 ? sd + 1 : -1);
+        if (__builtin_amdgcn_ballot_w64(mine) == ~0ull) {
+          const dpair *gP = reinterpret_cast<const dpair *>(a.val + (size_t)2 * base),
+                      *gT = reinterpret_cast<const dpair *>(a.val + (size_t)2 * a.nnzc + (size_t)2 * base);
+          dpair *sP = stage[wave][0], *sT = stage[wave][1];
+          for (int j = 0; j < len; ++j) {
+            sP[j * 64 + lane] = __builtin_nontemporal_load(gP + j * 64 + lane);
+            sT[j * 64 + lane] = __builtin_nontemporal_load(gT + j * 64 + lane);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          const double *vP = reinterpret_cast<const double *>(sP) + lane * 2 * len, *vT = reinterpret_cast<const double *>(sT) + lane * 2 * len;
+          const int d = k > 0;   // the diagonal block's place in the row
+          if (k > 0) lo = B2{vP[0], vP[len], vT[0], vT[len]};
+          di = B2{vP[d], vP[d + len], vT[d], vT[d + len]};
+          if (k < a.nz - 1) up = B2{vP[d + 1], vP[d + 1 + len], vT[d + 1], vT[d + 1 + len]};
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (the reads above precede the next level's writes)
+          __builtin_amdgcn_wave_barrier();
+          staged = true;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const double *vP = reinterpret_cast<const double *>(sP) + lane * 2 * len, *vT = reinterpret_cast<const double *>(sT) + lane * 2 * len;
-        const int d = k > 0;   // the diagonal block's place in the row
-        if (k > 0) lo = B2{vP[0], vP[len], vT[0], vT[len]};
-        di = B2{vP[d], vP[d + len], vT[d], vT[d + len]};
-        if (k < a.nz - 1) up = B2{vP[d + 1], vP[d + 1 + len], vT[d + 1], vT[d + 1 + len]};
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (the reads above precede the next level's writes)
-        __builtin_amdgcn_wave_barrier();
-        staged = true;
+      }
+      if (!staged) {
+        if (!live) continue;
+        const int sl = a.tri_lo[i], su = a.tri_up[i];
+        if (sl >= 0) lo = b2_load_val(a, i, sl);
+        di = b2_load_val(a, i, a.cdiag[i]);
+        if (su >= 0) up = b2_load_val(a, i, su);
+      }
+      if (!live) continue;
+      B2 inv, g;
+      th_factor_level(lo, di, up, g_prev, inv, g);
+      if (!SOLVE) b2_store(a.L, n, i, lo);
+      if (!(SOLVE && a.inv_fly)) b2_store(a.inv, n, i, inv);   // (inv_fly: the products that follow redo the pivots from the rows they read)
+      b2_store(a.C, n, i, g);
+      g_prev = g;
+      if (SOLVE) {
+        th_forward_level(lo, inv, r[i], r[n + i], ep, et);
+        z[i] = ep; z[n + i] = et;
       }
     }
-    if (!staged) {
-      if (!live) continue;
-      const int sl = a.tri_lo[i], su = a.tri_up[i];
-      if (sl >= 0) lo = b2_load_val(a, i, sl);
-      di = b2_load_val(a, i, a.cdiag[i]);
-      if (su >= 0) up = b2_load_val(a, i, su);
+    if (SOLVE && live) th_tri_backward_column<ND>(a, z, w, cbase, tw, acc0, acc1);
+  }
+  if (SOLVE) {
+    const double t0 = th_block_sum(acc0, lds);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t0;
+    if (ND == 2) {
+      const double t1 = th_block_sum(acc1, lds);
+      if (threadIdx.x == 0) partials[(size_t)gridDim.x + blockIdx.x] = t1;
     }
-    const B2 l = b2_mul(lo, inv_prev);
-    const B2 lc = b2_mul(l, c_prev);
-    const B2 piv{di.pp - lc.pp, di.pt - lc.pt, di.tp - lc.tp, di.tt - lc.tt};
-    const B2 inv = b2_inv(piv);
-    b2_store(a.L, n, i, l); b2_store(a.inv, n, i, inv); b2_store(a.C, n, i, up);
-    inv_prev = inv; c_prev = up;
   }
 }
 
 // Both sweeps of a column's block-Thomas solve.  The operands of a level do not depend on the recurrence, only the arithmetic does:
 // they are fetched kThDepth levels ahead into a ring of registers (the compiler's own loop waits for every level's loads before it
-// starts the next ones).  Measured: 0.68-0.71 ms at 512 x 512 x 80 either way -- the solve already runs at 5.5 TB/s of its 176 bytes
-// per cell -- so the ring buys robustness at low occupancy, not time.  ND = 0: no dot products; 1: z.z; 2: z.w and z.z.
+// starts the next ones).  Measured (round 4's storage): 0.68-0.71 ms at 512 x 512 x 80 either way -- the solve already ran at 5.5 TB/s
+// of its 176 bytes per cell -- so the ring buys robustness at low occupancy, not time.  ND = 0: no dot products; 1: z.z; 2: z.w and z.z.
 constexpr int kThDepth = 4;
 __device__ __forceinline__ void th_tri_forward_column(const ThTriArgs &a, const double *__restrict__ r, double *__restrict__ z,
                                                       size_t cbase, int tw) {
-#pragma clang fp contract(off)   // (every product and sum rounded by itself: the fused k_th_spmv_tri must reproduce these bits, and
-                                 // which multiply-adds the compiler would fuse depends on the code around them)
   const size_t n = (size_t)a.n;
-  B2 l[kThDepth];
+  B2 l[kThDepth], inv[kThDepth];
   double rp[kThDepth], rt[kThDepth];
   auto fetch = [&](int slot, int k) {
     const size_t i = cbase + (size_t)min(k, a.nz - 1) * tw;   // (past the last level: a harmless repeat)
-    l[slot] = b2_load(a.L, n, i); rp[slot] = r[i]; rt[slot] = r[n + i];
+    l[slot] = b2_load(a.L, n, i); inv[slot] = b2_load(a.inv, n, i); rp[slot] = r[i]; rt[slot] = r[n + i];
   };
 #pragma unroll
   for (int j = 0; j < kThDepth; ++j) fetch(j, j);
-  double dp = 0.0, dt = 0.0;
+  double ep = 0.0, et = 0.0;
   for (int k0 = 0; k0 < a.nz; k0 += kThDepth) {
 #pragma unroll
     for (int j = 0; j < kThDepth; ++j) {
       const int k = k0 + j;
       if (k < a.nz) {
         const size_t i = cbase + (size_t)k * tw;
-        const double np = rp[j] - (l[j].pp * dp + l[j].pt * dt);
-        const double nt = rt[j] - (l[j].tp * dp + l[j].tt * dt);
-        z[i] = np; z[n + i] = nt;
-        dp = np; dt = nt;
+        th_forward_level(l[j], inv[j], rp[j], rt[j], ep, et);
+        z[i] = ep; z[n + i] = et;
         fetch(j, k + kThDepth);
       }
     }
@@ -513,11 +565,11 @@ __device__ __forceinline__ void th_tri_backward_column(const ThTriArgs &a, doubl
                                                        size_t cbase, int tw, double &acc0, double &acc1) {
 #pragma clang fp contract(off)
   const size_t n = (size_t)a.n;
-  B2 cc[kThDepth], inv[kThDepth];
+  B2 g[kThDepth];
   double zp[kThDepth], zt[kThDepth], wp[kThDepth], wt[kThDepth];
   auto fetch = [&](int slot, int k) {
     const size_t i = cbase + (size_t)max(k, 0) * tw;
-    cc[slot] = b2_load(a.C, n, i); inv[slot] = b2_load(a.inv, n, i); zp[slot] = z[i]; zt[slot] = z[n + i];
+    g[slot] = b2_load(a.C, n, i); zp[slot] = z[i]; zt[slot] = z[n + i];
     if (ND == 2) { wp[slot] = w[i]; wt[slot] = w[n + i]; }
   };
 #pragma unroll
@@ -529,9 +581,8 @@ __device__ __forceinline__ void th_tri_backward_column(const ThTriArgs &a, doubl
       const int k = k0 - j;
       if (k >= 0) {
         const size_t i = cbase + (size_t)k * tw;
-        const double bp = zp[j] - (cc[j].pp * xp + cc[j].pt * xt);
-        const double bt = zt[j] - (cc[j].tp * xp + cc[j].tt * xt);
-        const double yp = inv[j].pp * bp + inv[j].pt * bt, yt = inv[j].tp * bp + inv[j].tt * bt;
+        const double yp = zp[j] - (g[j].pp * xp + g[j].pt * xt);
+        const double yt = zt[j] - (g[j].tp * xp + g[j].tt * xt);
         const double wpj = wp[j], wtj = wt[j];
         fetch(j, k - kThDepth);
         z[i] = yp; z[n + i] = yt;
@@ -593,7 +644,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MPP_TH_S
 // elimination in the order of th_tri_forward_column: the same bits as the two kernels.
 // FDOT (round 5): the partial sums of fdot . (A x) over both fields as well, in row ND of `partials` -- the line search's F . (J p) /
 // F . (J s) of a one-iteration BiCGStab solve out of the kernels that hold those rows anyway (Solver::ksp_bcgs, ls_fold)
-template <int ND, bool FDOT = false>
+// INVF (round 5, option th_inv_fly): the pivots' inverses are not read either -- the forward sweep holds the level's three blocks (the
+// row it multiplies) and redoes the factorisation's step (th_factor_level: a division and 30 multiply-adds a level, the same bits
+// as the stored inv and G) where it would read 32 bytes a cell.
+template <int ND, bool FDOT = false, bool INVF = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MPP_TH_SOLVE_WAVES))) void k_th_spmv_tri(ThTriArgs a, const double *__restrict__ x, double *__restrict__ z,
                                                         const double *__restrict__ w, double *__restrict__ partials,
                                                         const double *__restrict__ fdot) {
@@ -626,14 +680,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MPP_TH_S
       nstaged = true;
     };
     prefetch(0);
-    // x of the levels k - 1, k, k + 1 (zero outside the column), L of level k one level ahead
+    // x of the levels k - 1, k, k + 1 (zero outside the column), the pivot's inverse of level k one level ahead
     double xPm = 0.0, xTm = 0.0, xP0 = 0.0, xT0 = 0.0, xPp = 0.0, xTp = 0.0;
-    B2 lnext{0, 0, 0, 0};
+    B2 inext{0, 0, 0, 0};
     if (live) {
       xP0 = x[cbase]; xT0 = x[n + cbase];
       if (a.nz > 1) { xPp = x[cbase + tw]; xTp = x[n + cbase + tw]; }
-      lnext = b2_load(a.L, n, cbase);
+      if (!INVF) inext = b2_load(a.inv, n, cbase);
     }
+    B2 g_prev{0, 0, 0, 0};
     double dp = 0.0, dt = 0.0;
     for (int k = 0; k < a.nz; ++k) {
       const size_t i = cbase + (size_t)k * tw;
@@ -648,13 +703,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MPP_TH_S
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
       if (k + 1 < a.nz) prefetch(k + 1);
-      const B2 l = lnext;
+      B2 inv = inext;
       double xPn = 0.0, xTn = 0.0;
       if (live) {
         if (k + 2 < a.nz) { xPn = x[i + 2 * (size_t)tw]; xTn = x[n + i + 2 * (size_t)tw]; }
-        if (k + 1 < a.nz) lnext = b2_load(a.L, n, i + tw);
+        if (!INVF && k + 1 < a.nz) inext = b2_load(a.inv, n, i + tw);
       }
       double sp = 0.0, st = 0.0;
+      B2 lb{0, 0, 0, 0}, db{0, 0, 0, 0}, ub{0, 0, 0, 0};   // the row's blocks: lb is the elimination's multiplier; db, ub for INVF
       const bool lo = k > 0, up = k < a.nz - 1;
 #define TH_ROW_PRODUCT(vP, vT, LEN)                                                         \
       {                                                                                     \
@@ -670,20 +726,31 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MPP_TH_S
       if (staged) {
         const double *vP = reinterpret_cast<const double *>(sP) + lane * 2 * len, *vT = reinterpret_cast<const double *>(sT) + lane * 2 * len;
         TH_ROW_PRODUCT(vP, vT, len)
+        if (lo) lb = B2{vP[0], vP[len], vT[0], vT[len]};
+        if (INVF) {
+          const int d = lo;
+          db = B2{vP[d], vP[d + len], vT[d], vT[d + len]};
+          if (up) ub = B2{vP[d + 1], vP[d + 1 + len], vT[d + 1], vT[d + 1 + len]};
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (the reads above precede the next level's writes)
         __builtin_amdgcn_wave_barrier();
       } else if (live) {
         const int r0 = a.crowptr[i], rl = a.crowptr[i + 1] - r0;
         const double *vP = a.val + (size_t)2 * r0, *vT = a.val + (size_t)2 * a.nnzc + (size_t)2 * r0;
         TH_ROW_PRODUCT(vP, vT, rl)
+        if (lo) lb = B2{vP[0], vP[rl], vT[0], vT[rl]};
+        if (INVF) {
+          const int d = lo;
+          db = B2{vP[d], vP[d + rl], vT[d], vT[d + rl]};
+          if (up) ub = B2{vP[d + 1], vP[d + 1 + rl], vT[d + 1], vT[d + 1 + rl]};
+        }
       }
 #undef TH_ROW_PRODUCT
       if (live) {
         if (FDOT) { accf += fdot[i] * sp; accf += fdot[n + i] * st; }   // (the two rows of A x of this cell meet fdot)
-        const double np = sp - (l.pp * dp + l.pt * dt);
-        const double nt = st - (l.tp * dp + l.tt * dt);
-        z[i] = np; z[n + i] = nt;
-        dp = np; dt = nt;
+        if (INVF) { B2 g; th_factor_level(lb, db, ub, g_prev, inv, g); g_prev = g; }
+        th_forward_level(lb, inv, sp, st, dp, dt);
+        z[i] = dp; z[n + i] = dt;
       }
       xPm = xP0; xTm = xT0; xP0 = xPp; xT0 = xTp; xPp = xPn; xTp = xTn;
     }
@@ -719,15 +786,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MPP_TH_S
 // variant plays on the compact index); a block then walks kThDotsChunks pieces of 256 rows so that the second stage sums a few
 // thousand partial sums, not 10^5.  Partial sums: partials[j * gridDim.x + block], j = 0 (x.x), 1 (f.(A x)), 2 (q.q).
 constexpr int kThDotsChunks = 8;
-__device__ __forceinline__ double th_block_sum(double v, double *lds) {   // lanes -> wave leaders -> thread 0 (fixed order)
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
-  __syncthreads();
-  double t = 0.0;
-  if (threadIdx.x == 0) for (int q = 0; q < kBlock / 64; ++q) t += lds[q];
-  return t;
-}
 template <bool DOTS>
 __global__ __launch_bounds__(kBlock) void k_th_spmv_cols(ThTriArgs a, const double *__restrict__ x, double *__restrict__ y,
                                                          const double *__restrict__ f, const double *__restrict__ q,
@@ -833,7 +891,7 @@ inline dim3 nblk(long long n) { return dim3((unsigned)((n + kBlock - 1) / kBlock
 #define TH_LAUNCH(kernel, grid, ...) hipLaunchKernelGGL(kernel, grid, dim3(kBlock), 0, stream, __VA_ARGS__)
 
 void launch_th_tri_factor(const ThTriArgs &a, hipStream_t stream) {
-  if (a.ncols > 0) TH_LAUNCH(k_th_tri_factor, nblk(a.ncols), a);
+  if (a.ncols > 0) TH_LAUNCH((k_th_tri_factor<false, 0>), nblk(a.ncols), a, (const double *)nullptr, (double *)nullptr, (const double *)nullptr, (double *)nullptr);
 }
 void launch_th_spmv_cols(const ThTriArgs &a, const double *x, double *y, hipStream_t stream) {
   if (a.n > 0) TH_LAUNCH(k_th_spmv_cols<false>, nblk(a.n), a, x, y, nullptr, nullptr, nullptr);
@@ -851,9 +909,21 @@ void launch_th_tri_solve(const ThTriArgs &a, const double *r, double *z, hipStre
 int launch_th_spmv_tri(const ThTriArgs &a, const double *x, double *z, const double *w, double *partials, hipStream_t stream, const double *fdot) {
   if (a.ncols <= 0) return 0;
   const dim3 grid = nblk(a.ncols);
-  if (w && fdot) TH_LAUNCH((k_th_spmv_tri<2, true>), grid, a, x, z, w, partials, fdot);
+  if (a.inv_fly) {
+    if (w && fdot) TH_LAUNCH((k_th_spmv_tri<2, true, true>), grid, a, x, z, w, partials, fdot);
+    else if (w) TH_LAUNCH((k_th_spmv_tri<2, false, true>), grid, a, x, z, w, partials, (const double *)nullptr);
+    else TH_LAUNCH((k_th_spmv_tri<1, false, true>), grid, a, x, z, w, partials, (const double *)nullptr);
+  }
+  else if (w && fdot) TH_LAUNCH((k_th_spmv_tri<2, true>), grid, a, x, z, w, partials, fdot);
   else if (w) TH_LAUNCH(k_th_spmv_tri<2>, grid, a, x, z, w, partials, (const double *)nullptr);
   else TH_LAUNCH(k_th_spmv_tri<1>, grid, a, x, z, w, partials, (const double *)nullptr);
+  return (int)grid.x;
+}
+int launch_th_tri_factor_solve_dots(const ThTriArgs &a, const double *r, double *z, const double *w, double *partials, hipStream_t stream) {
+  if (a.ncols <= 0) return 0;
+  const dim3 grid = nblk(a.ncols);
+  if (w) TH_LAUNCH((k_th_tri_factor<true, 2>), grid, a, r, z, w, partials);
+  else TH_LAUNCH((k_th_tri_factor<true, 1>), grid, a, r, z, w, partials);
   return (int)grid.x;
 }
 int launch_th_tri_solve_dots(const ThTriArgs &a, const double *r, double *z, const double *w, double *partials, hipStream_t stream) {

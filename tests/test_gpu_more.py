@@ -33,6 +33,42 @@ def test_fortran_host_reproduces_celia1990_baseline(golden_dir, tmp_path):
                 assert got[sec][k] == pytest.approx(v, rel=1e-9), (sec, k)
 
 
+@pytest.mark.parametrize("sat", [0, 1])
+def test_fortran_hosted_vsfm_mms_matches_the_oracle(sat):
+    """fortran/vsfm_mms_gpu.F90: the manufactured-solution check driven from Fortran -- per-cell-array setters, a mass-rate
+    source on every cell computed with mppgpu_host_density / mppgpu_host_sat_relperm, PreStepDT, one StepDT(1.0)
+    (src/driver/standalone/vsfm/vsfm_mms_problem.F90:97-102); the printed pressures against the oracle's solve of the same
+    problem, the printed max-norm error against the analytic P(x), at two resolutions"""
+    from oracle import adapters as A
+    exe = os.path.join(ROOT, "fortran", "_build", "vsfm_mms_gpu")
+    if not os.path.exists(exe):
+        pytest.skip("no Fortran compiler was available at build time")
+    errs = []
+    for nx in (20, 40):
+        run = subprocess.run([exe, str(nx), str(sat)], capture_output=True, text=True, timeout=300)
+        if run.returncode != 0 and "error while loading shared libraries" in run.stderr:
+            pytest.skip("Fortran runtime libraries are not installed on this box: " + run.stderr.strip())
+        assert run.returncode == 0, run.stdout + run.stderr
+        o = A.to_oracle(A.vsfm_mms(nx, bool(sat)), with_blocks=False)
+        o.pre_step_dt()
+        assert o.step_dt(1.0, 1)[0]
+        po = o.get(C.AUXVAR_INTERNAL, C.VAR_PRESSURE)
+        got = {}
+        for line in run.stdout.splitlines():
+            if "=" in line and not line.startswith("category"):
+                k, v = line.split("=")
+                got[k.strip()] = float(v)
+        assert got["min"] == pytest.approx(po.min(), rel=1e-8) and got["max"] == pytest.approx(po.max(), rel=1e-8)
+        assert got["mean"] == pytest.approx(po.sum() / po.size, rel=1e-8)
+        for c in range(1, nx + 1, nx // 5):
+            assert got["cell %6d" % c] == pytest.approx(po[c - 1], rel=1e-8), c
+        exact = P.vsfm_mms(nx, bool(sat)).exact
+        assert got["max_error"] == pytest.approx(np.abs(po - exact).max(), rel=1e-4)
+        errs.append(got["max_error"])
+    assert errs[0] < (40.0 if sat else 1000.0)
+    assert (3.9 if sat else 1.9) < errs[0] / errs[1] < (4.1 if sat else 2.1), errs
+
+
 def test_rccl_single_rank_communicator_gives_identical_answers():
     """the all-reduce path with a one-rank RCCL communicator must not change a single bit"""
     from mpp_amd import vsfm as V

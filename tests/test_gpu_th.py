@@ -438,3 +438,32 @@ def test_th_fused_spmv_and_block_solve_reproduces_the_two_kernels_bit_for_bit(nc
         assert np.array_equal(f.soe.GetDataForCLM(C.AUXVAR_INTERNAL, var), vu)
         assert np.array_equal(s0.soe.GetDataForCLM(C.AUXVAR_INTERNAL, var), vu)
     assert f.soe.kernel_stats("spmv_pc")["calls"] > 0 and u.soe.kernel_stats("spmv_pc")["calls"] == 0   # the fused kernel really ran
+
+
+@pytest.mark.parametrize("ncols,nz", [(70, 9), (128, 5), (5, 2)])
+def test_th_block_factorisation_inside_the_first_solve_is_the_factorisation(ncols, nz):
+    """k_th_tri_factor<true, .> (round 5, option th_lazy_factor): the block-Thomas factorisation rides on the sweep of BiCGStab's first
+    solve z = M^-1 b -- no factorisation pass of its own in a Newton iteration -- against the factorisation kernel followed by the
+    stand-alone solve: one th_factor_level / th_forward_level for both, so the same bits, Newton and linear counts; the lazy run
+    launches no kernel of the pc_setup class at all.  Then the consumers that need the stand-alone factors (PCApply through the ABI
+    reads plane L, which the combined kernel does not write) get them: the same M^-1 r from both handles"""
+    tp = P.th_columns(ncols=ncols, nz=nz, perm_mult=np.exp(0.3 * np.random.default_rng(5).standard_normal(ncols)))
+    base = {"ksp_type": "bcgs", "pc_type": "bjacobi", "profile": 1}
+    lazy = P.to_th_gpu(tp, dict(base, th_lazy_factor=1, th_inv_fly=1))    # (the default: pivots redone by the fused products as well)
+    lazy_inv = P.to_th_gpu(tp, dict(base, th_lazy_factor=1, th_inv_fly=0))
+    eager = P.to_th_gpu(tp, dict(base, th_lazy_factor=0, th_inv_fly=0))
+    for s in range(2):
+        for g in (lazy, lazy_inv, eager):
+            P.th_gpu_set_conditions(tp, g)
+        re = eager.soe.StepDT(tp.dt, s + 1)
+        assert lazy.soe.StepDT(tp.dt, s + 1) == re and lazy_inv.soe.StepDT(tp.dt, s + 1) == re and re[0]
+    assert lazy.soe.counters() == eager.soe.counters() == lazy_inv.soe.counters()
+    for var in (C.VAR_PRESSURE, 605):
+        ve = eager.soe.GetDataForCLM(C.AUXVAR_INTERNAL, var)
+        assert np.array_equal(lazy.soe.GetDataForCLM(C.AUXVAR_INTERNAL, var), ve)
+        assert np.array_equal(lazy_inv.soe.GetDataForCLM(C.AUXVAR_INTERNAL, var), ve)
+    assert lazy.soe.kernel_stats("pc_setup")["calls"] == 0 and lazy_inv.soe.kernel_stats("pc_setup")["calls"] == 0
+    assert eager.soe.kernel_stats("pc_setup")["calls"] > 0
+    r = np.random.default_rng(11).standard_normal(2 * tp.mesh.ncells_local)
+    ze = eager.soe.PCApply(r)
+    assert np.array_equal(lazy.soe.PCApply(r), ze) and np.array_equal(lazy_inv.soe.PCApply(r), ze)
