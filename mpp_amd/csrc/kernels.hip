@@ -313,8 +313,8 @@ void k_assemble_cols(ColsArgs a) {
           const double l = lo_prev * inv_pp;
           const double piv = fma(-l, c_pp, di);   // (written as the fma it is: k_tri_solve_lds recomputes l and must round alike)
           const double inv = 1.0 / piv;
-          if (a.store_l) stnt(l, a.tl + ip);
-          stnt(inv, a.tinvb + ip); stnt(tri_scale(up_prev, inv), a.tc + ip);
+          if (a.store_l) { stnt(l, a.tl + ip); stnt(inv, a.tinvb + ip); }   // (read by the plain solves only)
+          stnt(tri_scale(up_prev, inv), a.tc + ip);
           inv_pp = inv; c_pp = up_prev;
           if (a.fwd) {   // forward elimination of the residual as well (left scaled: d inv): the Krylov solver's first M^{-1} F starts from here
             const double d = (RES ? f_row : Fin_prev) - l * d_pp;
@@ -1111,17 +1111,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MPP_SPMV
 // block-Jacobi preconditioner, one block per soil column = exact LU of the column's tridiagonal (Thomas).
 // factor: l_k = a_k / b'_{k-1}, b'_k = b_k - l_k c_{k-1};  stored: l, 1/b', c   (level-major, coalesced)
 // ------------------------------------------------------------------------------------------------
-// the elimination factors alone, from a factorisation that kept only the reciprocal pivots and the upper entries
-__global__ __launch_bounds__(kBlock) void k_tri_l(TriArgs a) {
-  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= (size_t)a.ncols * a.nz) return;
-  const size_t per_tile = (size_t)64 * a.nz;
-  const int tile = (int)(i / per_tile), tw = min(64, a.ncols - (tile << 6));
-  const int k = (int)((i - (size_t)tile * per_tile) / tw);
-  const int sl = a.tri_lo[i];
-  const double lo = sl >= 0 ? a.val[sl] : 0.0;
-  a.l[i] = lo * (k > 0 ? a.invb[i - tw] : 0.0);
-}
 __global__ __launch_bounds__(kBlock) void k_tri_factor(TriArgs a) {
   const int c = blockIdx.x * kBlock + threadIdx.x;
   if (c >= a.ncols) return;
@@ -3161,10 +3150,6 @@ void launch_spmv(int variant, int n, int max_row_nnz, const int *rowptr, const i
   else LAUNCH(k_spmv_row, dim3(nblk(n)), n, rowptr, col, val, x, y);   // variant 0, and rows of more than 8 entries
 }
 
-void launch_tri_l(const TriArgs &a, hipStream_t stream) {
-  const long long n = (long long)a.ncols * a.nz;
-  if (n > 0) LAUNCH(k_tri_l, dim3(nblk(n)), a);
-}
 void launch_tri_factor(const TriArgs &a, hipStream_t stream) {
   if (a.ncols > 0) LAUNCH(k_tri_factor, dim3(nblk(a.ncols)), a);
 }
@@ -3208,6 +3193,8 @@ int launch_back_spmv_tri_lds(const TriArgs &a, const double *d, double *x, doubl
                              const Fold &fold, const double *fdot) {
   const dim3 grid(tri_solve_lds_blocks(a.ncols));
   const size_t shmem = (size_t)a.nz * 64 * sizeof(double);
+  // (round 5: back sweeps of 6 and 7 groups -- they carry one stream less since plane c holds up / pivot -- measured equal to 4:
+  // profiles/r05/lu_product_form_ab.json)
   if (fdot) hipLaunchKernelGGL((k_tri_solve_lds<2, 4, 3, 4, 2, true>), grid, dim3(64), shmem, stream, a, d, z, (const double *)x, partials, scratch64, x, (const double *)nullptr, (const double *)nullptr, fold, fdot);
   else hipLaunchKernelGGL((k_tri_solve_lds<2, 4, 3, 4, 2>), grid, dim3(64), shmem, stream, a, d, z, (const double *)x, partials, scratch64, x, (const double *)nullptr, (const double *)nullptr, fold, (const double *)nullptr);
   return (int)grid.x;

@@ -88,7 +88,8 @@ struct ColsArgs {
   const int *bc_ptr = nullptr, *bc_type = nullptr;
   const double *bc_Dq = nullptr, *bc_dgrav = nullptr, *bc_area = nullptr, *bc_value = nullptr;
   double *tl = nullptr, *tinvb = nullptr, *tc = nullptr;
-  bool store_l = true;   // false: the elimination factors l are not written (the fused solves redo them; launch_tri_l rebuilds them on demand)
+  bool store_l = true;   // false: the elimination factors l and the reciprocal pivots are not written (the fused solves redo them from the
+                         // rows they read and take g = up / pivot alone; launch_tri_factor rebuilds all three planes on demand)
   double *fwd = nullptr;    // with tl: L^{-1} F as well (F = the residual of this pass, or the one in `F` in mode 1)
   double *partials = nullptr;
   // optional trial point (complete-row variant): the state is trial_x + trial_a * trial_y, written to trial_w
@@ -211,7 +212,7 @@ struct TriArgs {
   int ncols, nz;
   const int *tri_lo, *tri_di, *tri_up;  // CSR slots of the (k-1), k, (k+1) entries of row (k,c); -1 when absent
   const double *val;
-  double *l, *invb, *c;                 // factors, level-major
+  double *l, *invb, *c;                 // factors, level-major: l_k = lo_k / pivot_{k-1}, 1 / pivot_k, g_k = up_k / pivot_k
 };
 void launch_tri_factor(const TriArgs &a, hipStream_t stream);
 // The same per-column LU on a mesh that is NOT in the tiled column layout -- a rank's piece of a split 3-D mesh: its ghost cells stay
@@ -226,9 +227,6 @@ struct ColChainArgs {
 };
 void launch_chain_tri_factor(const ColChainArgs &a, hipStream_t stream);
 void launch_chain_tri_solve(const ColChainArgs &a, const double *r, double *z, hipStream_t stream);
-// l_k = lower_k inv_{k-1} from the CSR values and the stored reciprocal pivots (k_tri_factor's arithmetic): the elimination factors of
-// a factorisation whose march did not store them (ColsArgs::store_l = false)
-void launch_tri_l(const TriArgs &a, hipStream_t stream);
 void launch_tri_solve(const TriArgs &a, const double *r, double *z, hipStream_t stream);
 // the same solve with fused dot products of the result: z.z (w == nullptr) or z.w and z.z; returns the number of partial
 // blocks (<= kMaxPartialBlocks is the caller's responsibility); finish with launch_finalize

@@ -1598,9 +1598,10 @@ struct Solver {
     if (factor) {
       a.tl = tri_l.p; a.tinvb = tri_invb.p; a.tc = tri_c.p;
       // the solves that form A x on the way redo the elimination factors from the rows they read: where those are the ones a solve
-      // will use, l is not written (8 of the march's 107 bytes per cell) and rebuilt only if a plain solve asks (ensure_tri_l)
+      // will use, neither l nor 1 / pivot is written (16 of the march's 107 bytes per cell: their back sweeps read g = up / pivot alone)
+      // and both are rebuilt only if a plain solve asks (ensure_tri_l: the factorisation kernel, same arithmetic, same bits)
       // (BiCGStab only: every product of its iterations goes through op_BA_dots; GMRES uses the fused kernel for its first product alone
-      // and would pay a k_tri_l pass -- 28 bytes per cell -- per Newton iteration for the 8 the march saves: ADVICE r04)
+      // and would pay a factorisation pass per Newton iteration for the 16 bytes the march saves: ADVICE r04)
       a.store_l = !(opt.lazy_tri_l && opt.ksp_type == 2 && fused_spmv_pc_possible());
       tri_l_valid = a.store_l;
     }
@@ -2056,7 +2057,7 @@ struct Solver {
   void ensure_tri_l() {
     if (tri_l_valid || th || thermal) return;
     ProfScope ps(prof, KC_PC_SETUP);
-    launch_tri_l(tri_args(), stream);
+    launch_tri_factor(tri_args(), stream);
     tri_l_valid = true;
   }
   bool fused_spmv_pc() const {
