@@ -154,7 +154,7 @@ def main():
     extra_txt = "; ".join(extra_rows) if extra_rows else "(none in this line)"
     per_newton = 0.0
     out = open(os.path.join(ROOT, "DESIGN.md.in")).read()
-    th_line = "%.1f Newton it/s (BiCGStab + per-column 2×2 block-Jacobi; round 2: 95.8, round 3: 103.6, round 4: 122.9), column march %.2f ms" % (
+    th_line = "%.1f Newton it/s (BiCGStab + per-column 2×2 block-Jacobi; round 2: 95.8, round 3: 103.6, round 4: 122.9, round 5 before the factorisation left the iteration: 128.5), column march %.2f ms" % (
         th["newton_its_per_s"], th["kernels"]["jacobian"]["avg_ms"])
 
     def kstats(fname):
@@ -181,9 +181,11 @@ def main():
         return "; ".join(out)
 
     th_pmc = frac_rows("rocprofv3_kernel_stats_th_512x512x80.csv", "pmc_th_512x512x80.json", 512 * 512 * 80, (
-        ("k_th_spmv_tri<2>", "`k_th_spmv_tri` (SpMV + block-Thomas solve + dots)"), ("k_th_spmv_cols<true>", "index-free SpMV with the line search's sums"),
+        ("k_th_spmv_tri<2, true, true>", "`k_th_spmv_tri<2, true, true>` (SpMV + block-Thomas solve with the pivots redone + dots + the line search's sum)"),
+        ("k_th_spmv_tri<2, true, false>", "`k_th_spmv_tri<2, true>` (SpMV + block-Thomas solve + dots + the line search's sum)"),
+        ("k_th_tri_factor<true, 1>", "block factorisation + first solve + norm in one sweep"), ("k_th_spmv_cols<true>", "index-free SpMV with the line search's sums"),
         ("k_th_spmv_cols<false>", "index-free SpMV"), ("k_th_tri_solve_dots<2>", "block-Thomas solve + dots"),
-        ("k_th_tri_solve_dots<1>", "… with one dot"), ("k_th_tri_factor", "block factorisation"), ("k_bcgs_xr<true>", "`k_bcgs_xr`"),
+        ("k_th_tri_solve_dots<1>", "… with one dot"), ("k_th_tri_factor<false, 0>", "block factorisation alone"), ("k_bcgs_xr<true>", "`k_bcgs_xr`"),
         ("k_th_cols<2, 1>", "column march `k_th_cols<2>` (residual + Jacobian)"), ("k_th_cols<0, 1>", "`k_th_cols<0>` (residual)")))
     thermal_pmc = frac_rows("rocprofv3_kernel_stats_thermal_512.csv", "pmc_thermal_512.json", 512 ** 3, (
         ("k_box_lower_stream<8, false>", "lower stream"), ("k_box_upper_stream<8, false>", "upper stream"),
@@ -224,11 +226,13 @@ def main():
         ("k_assemble_cols<0, 3, 0, false, true>", "march (residual)"), ("k_flux_rows_ell<0, 4, true>", "lateral pass (residual)"),
         ("k_spmv_pipe_mb<7>", "7-point CSR SpMV `k_spmv_pipe_mb<7>`"), ("k_tri_solve_lds<2, 4, 6, 4, 0, false>", "LDS column solve + 2 dots"),
         ("k_tri_factor", "column factorisation")))
+    df = os.path.join(ev, "bench_driver_form_steps20_warmup5.json")   # `python bench.py --gpus 1 --steps 20 --warmup 5`, as the driver runs it
+    driver_form = ("%.1f" % json.load(open(df))["value"]) if os.path.exists(df) else "(not in the evidence directory)"
     subs = {"V3D_PMC": v3d_pmc or "(PMC passes not in the evidence directory)", "KERNEL_TABLE": kernel_table, "LAWS_TABLE": laws_table, "RESULTS": results_txt,
             "READBACKS": "%.2f–%.2f" % (min(rb(s8), rb(c2s)), max(rb(bench), rb(bench2))),
             "ANSWER": "%.1e" % bench["answer_check"]["max_rel_err"], "SHARE": share, "THERMAL": thermal, "TH": th_line, "BYTES": bytes_txt,
             "TH_PMC": th_pmc or "(PMC passes not in the evidence directory)", "THERMAL_PMC": thermal_pmc or "(PMC passes not in the evidence directory)",
-            "EXTRA": extra_txt}
+            "EXTRA": extra_txt, "DRIVER_FORM": driver_form}
     for k, v in subs.items():
         out = out.replace("@@%s@@" % k, v)
     sys.stdout.write(out)
