@@ -21,11 +21,16 @@ namespace mpp {
 namespace {
 
 constexpr int kBlock = 256;
-// the block-Thomas solves (one lane per column, latency-bound at 0.65-0.68 of peak) need 130 registers, two more than four waves per
-// SIMD allow; asked for four (128 registers, no scratch) the coupled benchmark did not move (125.5 / 123.8 -> 123.1 / 126.8 Newton it/s,
-// profiles/r05/occupancy_hints_ab.json): the hint stays off (1 = none)
+// The fused product + block-Thomas kernel (one lane per column) needs 130-140 registers, a few more than four waves per SIMD allow.
+// Asked for four (128 registers, 8 bytes of scratch in the variant that also reduces the line search's sum) it gains where the grid is
+// a whole number of rounds at four waves and not at three: 512 x 512 columns are 4096 waves = 16 per CU, one round instead of 1.33 --
+// 147.2 / 147.0 -> 149.2 / 150.0 Newton it/s at 512 x 512 x 80 (profiles/r05/th_waves_ab.json; round 5's first try on the kernel of
+// that time, which read two factor planes more, had shown nothing: profiles/r05/occupancy_hints_ab.json).  The stand-alone solves
+// (24 bytes of scratch at 128 registers) stay as the compiler makes them.  Not kept (same file): BiCGStab's s = r - alpha v formed
+// where this kernel loads its operand, as the scalar system's SPMV == 3 -- at 128 registers the two extra streams spill (40 bytes of
+// scratch) and the launch and 16 bytes a cell they save do not show: 149.8 / 150.0 / 149.8 against 150.0 / 149.7 / 151.0 Newton it/s.
 #ifndef MPP_TH_SOLVE_WAVES
-#define MPP_TH_SOLVE_WAVES 1
+#define MPP_TH_SOLVE_WAVES 4
 #endif
 
 // active[i]: 0 inactive cell, 1 active cell of this rank, 2 ghost cell (a copy of a cell another rank owns: a cell like any other
@@ -613,7 +618,7 @@ __global__ __launch_bounds__(kBlock) void k_th_tri_solve(ThTriArgs a, const doub
 // writes it): ND = 1 leaves the partial sums of z.z, ND = 2 those of z.w and z.z (in that order) over both fields, one per
 // block, layout partials[j * gridDim.x + block]
 template <int ND>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MPP_TH_SOLVE_WAVES))) void k_th_tri_solve_dots(ThTriArgs a, const double *__restrict__ r, double *__restrict__ z,
+__global__ __launch_bounds__(kBlock) void k_th_tri_solve_dots(ThTriArgs a, const double *__restrict__ r, double *__restrict__ z,
                                                               const double *__restrict__ w, double *__restrict__ partials) {
   __shared__ double lds[kBlock / 64];
   const int c = blockIdx.x * kBlock + threadIdx.x;
