@@ -460,7 +460,7 @@ template <int ND> __device__ __forceinline__ void th_tri_backward_column(const T
 // is not written (the fused products that follow take lo from the matrix), and the factorisation's pass of its own (0.76 ms and 208
 // bytes a cell at 512 x 512 x 80) is gone from a Newton iteration.
 template <bool SOLVE, int ND>
-__global__ __launch_bounds__(kBlock) void k_th_tri_factor(ThTriArgs a, const double *__restrict__ r, double *__restrict__ z,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MPP_TH_SOLVE_WAVES))) void k_th_tri_factor(ThTriArgs a, const double *__restrict__ r, double *__restrict__ z,
                                                           const double *__restrict__ w, double *__restrict__ partials) {
   typedef double dpair __attribute__((ext_vector_type(2)));   // two doubles, one 16-byte access
   __shared__ dpair stage[kBlock / 64][2][64 * 3];
@@ -473,38 +473,58 @@ __global__ __launch_bounds__(kBlock) void k_th_tri_factor(ThTriArgs a, const dou
     const size_t cbase = (size_t)tile * 64 * a.nz + lane, n = (size_t)a.n;
     B2 g_prev{0, 0, 0, 0};
     double ep = 0.0, et = 0.0;
+    dpair *sP = stage[wave][0], *sT = stage[wave][1];
+    // the pieces of a level (and the right-hand side with them) are requested one level ahead, into registers, as in k_th_spmv_tri
+    dpair nP[3], nT[3];
+    double nrp = 0.0, nrt = 0.0;
+    bool nstaged = false;
+    auto prefetch = [&](int k) {
+      nstaged = false;
+      const size_t i = cbase + (size_t)k * tw;
+      if (SOLVE && live) { nrp = r[i]; nrt = r[n + i]; }
+      if (tw != 64 || !a.stage) return;   // (staged: every lane is a column)
+      const int len = 3 - (k == 0) - (k == a.nz - 1);
+      const int base = a.crowptr[i - lane], r0 = a.crowptr[i];
+      bool mine = a.crowptr[i - lane + 64] - base == 64 * len && r0 - base == lane * len;
+      if (!SOLVE) {   // the stand-alone factorisation also checks the slot tables against the layout; the combined kernel relies, like
+                      // k_th_spmv_tri, on the rows' sorted columns (cell below, cell, cell above)
+        const int sl = a.tri_lo[i], sd = a.cdiag[i], su = a.tri_up[i];
+        mine = mine && sl == (k > 0 ? r0 : -1) && sd == r0 + (k > 0) && su == (k < a.nz - 1 ? sd + 1 : -1);
+      }
+      if (__builtin_amdgcn_ballot_w64(mine) != ~0ull) return;
+      const dpair *gP = reinterpret_cast<const dpair *>(a.val + (size_t)2 * base),
+                  *gT = reinterpret_cast<const dpair *>(a.val + (size_t)2 * a.nnzc + (size_t)2 * base);
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        if (j < len) { nP[j] = __builtin_nontemporal_load(gP + j * 64 + lane); nT[j] = __builtin_nontemporal_load(gT + j * 64 + lane); }
+      nstaged = true;
+    };
+    prefetch(0);
     for (int k = 0; k < a.nz; ++k) {
       const size_t i = cbase + (size_t)k * tw;
+      const int len = 3 - (k == 0) - (k == a.nz - 1);
       const B2 zero{0, 0, 0, 0};
       B2 lo = zero, di = zero, up = zero;
-      bool staged = false;
-      if (tw == 64 && a.stage) {   // (every lane is a column)
-        const int len = 3 - (k == 0) - (k == a.nz - 1);
-        const int base = a.crowptr[i - lane], r0 = a.crowptr[i], sl = a.tri_lo[i], sd = a.cdiag[i], su = a.tri_up[i];
-        const bool mine = a.crowptr[i - lane + 64] - base == 64 * len && r0 - base == lane * len && sl == (k > 0 ? r0 : -1) &&
-                          sd == r0 + (k > 0) && su == (k < a.nz - 1 ? sd + 1 : -1);
-        if (__builtin_amdgcn_ballot_w64(mine) == ~0ull) {
-          const dpair *gP = reinterpret_cast<const dpair *>(a.val + (size_t)2 * base),
-                      *gT = reinterpret_cast<const dpair *>(a.val + (size_t)2 * a.nnzc + (size_t)2 * base);
-          dpair *sP = stage[wave][0], *sT = stage[wave][1];
-          for (int j = 0; j < len; ++j) {
-            sP[j * 64 + lane] = __builtin_nontemporal_load(gP + j * 64 + lane);
-            sT[j * 64 + lane] = __builtin_nontemporal_load(gT + j * 64 + lane);
-          }
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-          const double *vP = reinterpret_cast<const double *>(sP) + lane * 2 * len, *vT = reinterpret_cast<const double *>(sT) + lane * 2 * len;
-          const int d = k > 0;   // the diagonal block's place in the row
-          if (k > 0) lo = B2{vP[0], vP[len], vT[0], vT[len]};
-          di = B2{vP[d], vP[d + len], vT[d], vT[d + len]};
-          if (k < a.nz - 1) up = B2{vP[d + 1], vP[d + 1 + len], vT[d + 1], vT[d + 1 + len]};
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (the reads above precede the next level's writes)
-          __builtin_amdgcn_wave_barrier();
-          staged = true;
-        }
+      const bool staged = nstaged;
+      const double rp = nrp, rt = nrt;
+      if (staged) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          if (j < len) { sP[j * 64 + lane] = nP[j]; sT[j * 64 + lane] = nT[j]; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
-      if (!staged) {
+      if (k + 1 < a.nz) prefetch(k + 1);
+      if (staged) {
+        const double *vP = reinterpret_cast<const double *>(sP) + lane * 2 * len, *vT = reinterpret_cast<const double *>(sT) + lane * 2 * len;
+        const int d = k > 0;   // the diagonal block's place in the row
+        if (k > 0) lo = B2{vP[0], vP[len], vT[0], vT[len]};
+        di = B2{vP[d], vP[d + len], vT[d], vT[d + len]};
+        if (k < a.nz - 1) up = B2{vP[d + 1], vP[d + 1 + len], vT[d + 1], vT[d + 1 + len]};
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (the reads above precede the next level's writes)
+        __builtin_amdgcn_wave_barrier();
+      } else {
         if (!live) continue;
         const int sl = a.tri_lo[i], su = a.tri_up[i];
         if (sl >= 0) lo = b2_load_val(a, i, sl);
@@ -519,7 +539,7 @@ __global__ __launch_bounds__(kBlock) void k_th_tri_factor(ThTriArgs a, const dou
       b2_store(a.C, n, i, g);
       g_prev = g;
       if (SOLVE) {
-        th_forward_level(lo, inv, r[i], r[n + i], ep, et);
+        th_forward_level(lo, inv, rp, rt, ep, et);
         z[i] = ep; z[n + i] = et;
       }
     }
