@@ -154,7 +154,7 @@ def main():
     extra_txt = "; ".join(extra_rows) if extra_rows else "(none in this line)"
     per_newton = 0.0
     out = open(os.path.join(ROOT, "DESIGN.md.in")).read()
-    th_line = "%.1f Newton it/s (BiCGStab + per-column 2×2 block-Jacobi; round 2: 95.8, round 3: 103.6, round 4: 122.9, round 5 before the factorisation left the iteration: 128.5; this evidence run's box — boxes differ by ± 3 %, 144–151 were seen on the final sources, the A/Bs below are each on one box), column march %.2f ms" % (
+    th_line = "%.1f Newton it/s (BiCGStab + per-column 2×2 block-Jacobi; round 2: 95.8, round 3: 103.6, round 4: 122.9, round 5 before the factorisation left the iteration: 128.5; this evidence run's box — boxes differ by ± 3 %%, 144–151 were seen on the final sources, the A/Bs below are each on one box), column march %.2f ms" % (
         th["newton_its_per_s"], th["kernels"]["jacobian"]["avg_ms"])
 
     def kstats(fname):
