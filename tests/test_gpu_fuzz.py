@@ -3,6 +3,8 @@ conditions, inactive cells and a solver route, then compares the GPU library wit
 state first, then two time steps (convergence reason, Newton count, pressures).  The single-feature tests live in
 test_gpu_parity.py / test_gpu_r02.py; this one is after the interactions between them (complete-row march with inline
 boundary fluxes x seepage x sinks x soil classes x fused Krylov kernels ...)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -12,6 +14,8 @@ from mpp_amd import mesh as M
 from test_gpu_parity import _operator_parity
 
 pytestmark = pytest.mark.gpu
+# MPP_FUZZ_SEED_OFFSET=k draws another family of problems for the same test ids (a soak run: tools/gpu/r05_run17.sh); 0 is the suite's
+_OFF = 100000 * int(os.environ.get("MPP_FUZZ_SEED_OFFSET", "0"))
 
 SATF = [C.SAT_FUNC_VAN_GENUCHTEN, C.SAT_FUNC_BROOKS_COREY, C.SAT_FUNC_SMOOTHED_BROOKS_COREY_BZ2, C.SAT_FUNC_SMOOTHED_BROOKS_COREY_BZ3]
 ROUTES = [{}, {"assembly": "general"}, {"assembly": "columns", "nseg": 1}, {"assembly": "columns", "nseg": 3},
@@ -24,7 +28,7 @@ SOLVERS = [("bcgs", "bjacobi", C.KSP_BCGS, C.PC_BJACOBI), ("gmres", "bjacobi", C
 
 
 def draw(seed):
-    rng = np.random.default_rng(1000 + seed)
+    rng = np.random.default_rng(1000 + seed + _OFF)
     ncols = int(rng.choice([1, 7, 70, 130, 257]))
     nz = int(rng.choice([2, 3, 11, 24, 40]))
     prob = P.celia1990(ncols=ncols, nz=nz, perm_mult=np.exp(0.5 * rng.standard_normal(ncols)))
@@ -150,7 +154,7 @@ SOLVERS_3D = [("gmres", "ilu", C.KSP_GMRES, C.PC_ILU0), ("bcgs", "ilu", C.KSP_BC
 
 
 def draw3d(seed):
-    rng = np.random.default_rng(5000 + seed)
+    rng = np.random.default_rng(5000 + seed + _OFF)
     nx, ny, nz = (int(v) for v in rng.integers(2, 9, 3))
     prob = P.vchannel(nx, ny, nz)
     n = prob.mesh.ncells_local
@@ -230,7 +234,7 @@ def test_random_th_columns_problem_matches_the_oracle(seed):
     formulations and the assembly route drawn at random: operators, ILU(0) application and two coupled steps (test_gpu_th.py's
     comparison)"""
     from test_gpu_th import _th_columns_vs_oracle
-    rng = np.random.default_rng(9000 + seed)
+    rng = np.random.default_rng(9000 + seed + _OFF)
     ncols, nz = int(rng.choice([1, 3, 70, 131])), int(rng.choice([2, 5, 9, 20]))
     _th_columns_vs_oracle(ncols, nz, str(rng.choice(["general", "columns"])), mixed=bool(rng.random() < 0.5),
                           linear_porosity=bool(rng.random() < 0.4), seed=100 + seed,
@@ -245,7 +249,7 @@ def test_random_thermal_problem_matches_the_oracle(seed):
     """grid, land units (soil / wetland / land ice, bedrock layers), water / ice / snow contents, tuning factors, inactive cells,
     Crank-Nicolson factor, Dirichlet + heat-flux faces in either order with and without a gap to the boundary value, the
     reference-defects switch: right-hand side, operator and one step against the oracle"""
-    rng = np.random.default_rng(7000 + seed)
+    rng = np.random.default_rng(7000 + seed + _OFF)
     nx, ny, nz = (int(v) for v in rng.integers(2, 9, 3))
     case = P.thermal_flux_case(nx, ny, nz, bc_dist_up=float(rng.choice([0.0, 0.4])))
     tp = case[0]
@@ -280,7 +284,7 @@ def test_random_3d_th_problem_matches_the_oracle(seed):
     anisotropic permeabilities, retention curves, porosity model, density / internal-energy formulations; general assembly,
     GMRES + ILU(0); operators, ILU(0) application and two coupled steps against the oracle"""
     from test_gpu_th import _th_columns_vs_oracle
-    rng = np.random.default_rng(11000 + seed)
+    rng = np.random.default_rng(11000 + seed + _OFF)
     nx, ny, nz = (int(v) for v in rng.integers(2, 7, 3))
     tp = P.th_vchannel(nx, ny, nz)
     n = tp.mesh.ncells_local
@@ -311,7 +315,7 @@ def test_random_split_3d_vsfm_problem_equals_the_single_handle_solve(seed):
         # solves then differ by 10^3 Pa with residuals of 1e-13, and BiCGStab breaks down) -- not what this test is after
         prob.density_type = C.DENSITY_TGDPB01
     n = prob.mesh.ncells_local
-    rng = np.random.default_rng(13000 + seed)
+    rng = np.random.default_rng(13000 + seed + _OFF)
     nranks = int(rng.integers(2, 5))
     if n < 4 * nranks:
         nranks = 2
